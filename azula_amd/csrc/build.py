@@ -1,0 +1,69 @@
+r"""Builds ``libazula_amd.so`` (gfx950 HIP kernels + C ABI) in-tree with hipcc.
+
+    python -m azula_amd.csrc.build [--force] [--verbose]
+
+No torch, no cmake: one ``hipcc -shared -fPIC`` per source file (cached on mtime) and a final link.
+The resulting ``.so`` sits next to the sources so that it travels with the tree.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SOURCES = ["transition.hip", "layout.hip", "linear.hip", "norm.hip", "conv.hip", "attention.hip", "graph.hip"]
+LIB = os.path.join(HERE, "libazula_amd.so")
+OBJ_DIR = os.path.join(HERE, "_obj")
+FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-ffp-contract=on",  # contraction only where written as a*b+c in one expression; az_mul/az_add never fuse
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: azula_amd needs the ROCm toolchain to build its gfx950 kernels")
+    return exe
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = [os.path.join(HERE, "common.h"), os.path.join(ROOT, "include", "azula_amd.h")]
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    objs = []
+    for s in srcs:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src, *headers]):
+            cmd = [hipcc(), *FLAGS, "-x", "hip", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True))

@@ -1,0 +1,52 @@
+// Shared device/host helpers for the gfx950 kernels of azula_amd.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/azula_amd.h"
+
+#define AZ_WAVE 64
+
+#define AZ_REQUIRE(cond, code) \
+  do {                         \
+    if (!(cond)) return (code); \
+  } while (0)
+
+#define AZ_ALIGNED16(p) ((((uintptr_t)(p)) & 15u) == 0)
+
+static inline int az_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? AZ_OK : (int)e;
+}
+
+static inline hipStream_t az_s(az_stream_t s) { return (hipStream_t)s; }
+
+// Separately rounded fp32 ops: the compiler may not contract these into FMAs, so a chain
+// written with them reproduces torch's eager op-by-op rounding bit for bit.
+__device__ __forceinline__ float az_mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float az_add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float az_sub(float a, float b) { return __fsub_rn(a, b); }
+
+// Accurate expf (ocml, ~1 ulp): SiLU sits in memory-bound kernels / conv epilogues, the VALU cost is hidden.
+__device__ __forceinline__ float az_silu(float v) { return v / (1.0f + expf(-v)); }
+
+// 64-lane butterfly reductions (wave64).
+__device__ __forceinline__ float az_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float az_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Memory-bound launches: cap the grid at 256 CUs x 8 blocks and grid-stride the rest.
+static inline int az_stream_grid(int64_t work_items, int block) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}

@@ -1,0 +1,347 @@
+// K3 / K5: implicit-GEMM convolution and token-linear on gfx950 fp32 MFMA.
+//
+//   out[pixel, co] = sum_{tap, ci} W[tap][co][ci] * in[pixel + tap, ci]
+//
+// GEMM view: "A" = packed weights (rows = output channels), "B" = gathered input pixels
+// (columns = output pixels), K = taps x input channels, accumulated with
+// v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain; 157.3 TFLOP/s chip peak, same as the VALU
+// peak, but one operand VGPR per 2048 MACs instead of two per MAC).  Weights are the A operand
+// so that each lane ends up holding 4 CONSECUTIVE output channels of one pixel: the NHWC
+// epilogue (bias, SiLU, gate, residual) and the store are all 16-byte vectors.
+//
+// Block tile 128 (co) x 128 (pixels) x 32 (k); 4 waves in 2 x 2, each 64 x 64 = 2 x 2 MFMA
+// tiles (64 accumulator VGPRs).  LDS: both operand tiles are stored [row][k] with a 36-float
+// row stride: ds_write_b128 from the loader and ds_read_b128 fragment reads are both
+// bank-conflict-free (36*r mod 64 visits 16 distinct 4-bank slots).  Double-buffered LDS with
+// register staging: the global loads of tile t+1 are issued before the MFMAs of tile t and
+// written to the other buffer after them (one barrier per K-tile); 2 blocks/CU co-reside so
+// one block's MFMAs cover the other's barrier/load latency.
+//
+// The gather handles zero padding, stride, two concatenated sources and read-side nearest x2
+// upsampling, so concat / upsample / pad never touch HBM as separate passes.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;   // output-channel tile
+constexpr int BN = 128;   // pixel tile
+constexpr int BK = 32;    // k tile (input channels of one tap)
+constexpr int LDSS = 36;  // padded LDS row stride in floats (144 B, 16-B aligned)
+constexpr int TILE_F = (BM + BN) * LDSS;
+
+struct ConvP {
+  AzConvArgs a;
+  int npix;     // batch * hout * wout
+  int cin_s;    // c0s + c1s
+  int nkc;      // ceil(cin_s / BK)
+  int nk;       // taps * nkc
+  int kps;      // K-tiles per split
+  int tiles_m;  // ceil(cout_s / BM)
+  int tiles_n;  // ceil(npix / BN)
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Epilogue for 4 consecutive output channels [co, co+4) of output pixel n.
+__device__ __forceinline__ void epilogue_store(const AzConvArgs& a, int n, int co, float4 v) {
+  const int hw = a.hout * a.wout;
+  const int b = n / hw;
+  const int rem = n - b * hw;
+  if (a.bias) {
+    const float4 bv = ld4(a.bias + co);
+    v.x += bv.x;
+    v.y += bv.y;
+    v.z += bv.z;
+    v.w += bv.w;
+  }
+  if (a.act == 1) {
+    v.x = az_silu(v.x);
+    v.y = az_silu(v.y);
+    v.z = az_silu(v.z);
+    v.w = az_silu(v.w);
+  }
+  if (a.gate) {
+    const float4 g = ld4(a.gate + (int64_t)b * a.gate_bstride + co);
+    v.x *= g.x;
+    v.y *= g.y;
+    v.z *= g.z;
+    v.w *= g.w;
+  }
+  if (a.res) {
+    int64_t rp;
+    if (a.res_up) {
+      const int oh = rem / a.wout, ow = rem - oh * a.wout;
+      rp = ((int64_t)b * a.hres + (oh >> 1)) * a.wres + (ow >> 1);
+    } else {
+      rp = n;
+    }
+    const float4 r = ld4(a.res + rp * a.cout_s + co);
+    v.x += r.x;
+    v.y += r.y;
+    v.z += r.z;
+    v.w += r.w;
+  }
+  if (a.dst_nchw) {
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (co + j < a.dst_c) a.dst[((int64_t)b * a.dst_c + co + j) * hw + rem] = vv[j];
+  } else {
+    *reinterpret_cast<float4*>(a.dst + (int64_t)n * a.cout_s + co) = v;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * TILE_F];
+  const AzConvArgs& a = p.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wc = wid >> 1;  // wave's 64-channel half
+  const int wp = wid & 1;   // wave's 64-pixel half
+
+  // XCD-aware bijective remap: each XCD (private L2) walks a contiguous range of tiles, and
+  // consecutive tiles share the same pixel tile (activation rows), differing in channels.
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  const int tile_n = wg / p.tiles_m;
+  const int tile_m = wg - tile_n * p.tiles_m;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const int kt_begin = blockIdx.y * p.kps;
+  const int kt_end = min(p.nk, kt_begin + p.kps);
+
+  // ---- loader coordinates: thread -> (16-B chunk cc along k, rows r0 + 32*i)
+  const int cc = tid & 7;
+  const int r0 = tid >> 3;
+  int pb[4], ihb[4], iwb[4];
+  bool pv[4];
+  const int hw_out = a.hout * a.wout;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + r0 + 32 * i;
+    pv[i] = n < p.npix;
+    const int nn = pv[i] ? n : 0;
+    const int b = nn / hw_out;
+    const int rem = nn - b * hw_out;
+    const int oh = rem / a.wout;
+    const int ow = rem - oh * a.wout;
+    pb[i] = b;
+    ihb[i] = oh * a.stride - a.pad;
+    iwb[i] = ow * a.stride - a.pad;
+  }
+
+  float4 ra[4], rb[4];
+
+  auto load_tile = [&](int kt) {
+    const int tap = kt / p.nkc;
+    const int kc = kt - tap * p.nkc;
+    const int ky = tap / a.ksize;
+    const int kx = tap - ky * a.ksize;
+    const int c = kc * BK + cc * 4;
+    const bool cv = c < p.cin_s;
+    // weights: [tap][cout_s][cin_s]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = m0 + r0 + 32 * i;
+      if (cv && co < a.cout_s)
+        ra[i] = ld4(a.weight + ((int64_t)tap * a.cout_s + co) * p.cin_s + c);
+      else
+        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // pixels: gather from src0 | src1 with padding / upsampling
+    const bool first = c < a.c0s;
+    const float* src = first ? a.src0 : a.src1;
+    const int cs = first ? a.c0s : a.c1s;
+    const int cl = first ? c : c - a.c0s;
+    const int up = first ? a.up0 : a.up1;
+    const int hs = first ? a.h0 : a.h1;
+    const int ws = first ? a.w0 : a.w1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ih = ihb[i] + ky;
+      const int iw = iwb[i] + kx;
+      const bool ok = cv && pv[i] && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
+      if (ok) {
+        const int64_t pix = ((int64_t)pb[i] * hs + (ih >> up)) * ws + (iw >> up);
+        rb[i] = ld4(src + pix * cs + cl);
+      } else {
+        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    float* As = smem + buf * TILE_F;
+    float* Bs = As + BM * LDSS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(As + (r0 + 32 * i) * LDSS + cc * 4) = ra[i];
+      *reinterpret_cast<float4*>(Bs + (r0 + 32 * i) * LDSS + cc * 4) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_off = (lane & 31) * LDSS + (lane >> 5) * 4;
+
+  if (kt_begin < kt_end) {
+    load_tile(kt_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    if (more) load_tile(kt + 1);  // global loads in flight under the MFMAs below
+
+    const float* As = smem + buf * TILE_F + (wc * 64) * LDSS + frag_off;
+    const float* Bs = smem + buf * TILE_F + BM * LDSS + (wp * 64) * LDSS + frag_off;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      const float4 a0 = ld4(As + kk * 8);
+      const float4 a1 = ld4(As + 32 * LDSS + kk * 8);
+      const float4 b0 = ld4(Bs + kk * 8);
+      const float4 b1 = ld4(Bs + 32 * LDSS + kk * 8);
+      const float av0[4] = {a0.x, a0.y, a0.z, a0.w};
+      const float av1[4] = {a1.x, a1.y, a1.z, a1.w};
+      const float bv0[4] = {b0.x, b0.y, b0.z, b0.w};
+      const float bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
+      }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds, for pixel (lane & 31) of each pixel tile, channels
+  //      ct*32 + 8*q + 4*(lane >> 5) + [0, 4) in registers 4q .. 4q+3.
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const int n = n0 + wp * 64 + pt * 32 + (lane & 31);
+    if (n >= p.npix) continue;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = m0 + wc * 64 + ct * 32 + 8 * q + 4 * (lane >> 5);
+        if (co >= a.cout_s) continue;
+        const float4 v =
+            make_float4(acc[ct][pt][4 * q + 0], acc[ct][pt][4 * q + 1], acc[ct][pt][4 * q + 2], acc[ct][pt][4 * q + 3]);
+        if (a.splitk > 1)
+          *reinterpret_cast<float4*>(a.workspace + ((int64_t)blockIdx.y * p.npix + n) * a.cout_s + co) = v;
+        else
+          epilogue_store(a, n, co, v);
+      }
+    }
+  }
+}
+
+// Split-K combine + epilogue: one thread per (pixel, 4 channels).
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvP p) {
+  const AzConvArgs& a = p.a;
+  const int q = a.cout_s / 4;
+  const int64_t total = (int64_t)p.npix * q;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(e / q);
+    const int co = (int)(e - (int64_t)n * q) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < a.splitk; ++z) {
+      const float4 w = ld4(a.workspace + ((int64_t)z * p.npix + n) * a.cout_s + co);
+      v.x += w.x;
+      v.y += w.y;
+      v.z += w.z;
+      v.w += w.w;
+    }
+    epilogue_store(a, n, co, v);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_t ksize) {
+  const int64_t tiles = ((npix + BN - 1) / BN) * ((cout_s + BM - 1) / BM);
+  const int64_t nk = (int64_t)ksize * ksize * ((cin_s + BK - 1) / BK);
+  // Fill 256 CUs x 2 resident blocks; keep >= 8 K-tiles per split so the slab traffic
+  // (2 x 4 B x outputs per split) stays small next to the operand traffic.
+  int64_t want = (512 + tiles - 1) / tiles;
+  int64_t maxs = nk / 8;
+  if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want > 32) want = 32;
+  if (want < 1) want = 1;
+  if (tiles >= 384) want = 1;
+  return (int)want;
+}
+
+int az_conv2d_f32(const AzConvArgs* a, az_stream_t stream) {
+  AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
+  AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout > 0 && a->wout > 0, AZ_E_SHAPE);
+  AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
+  AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
+  AZ_REQUIRE(a->ksize >= 1 && a->ksize <= 7 && a->stride >= 1 && a->pad >= 0, AZ_E_SHAPE);
+  AZ_REQUIRE((a->hin + 2 * a->pad - a->ksize) / a->stride + 1 == a->hout &&
+                 (a->win + 2 * a->pad - a->ksize) / a->stride + 1 == a->wout,
+             AZ_E_SHAPE);
+  AZ_REQUIRE(((a->hin + a->up0) >> a->up0) <= a->h0 && ((a->win + a->up0) >> a->up0) <= a->w0, AZ_E_SHAPE);
+  if (a->src1)
+    AZ_REQUIRE(((a->hin + a->up1) >> a->up1) <= a->h1 && ((a->win + a->up1) >> a->up1) <= a->w1, AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(a->src0) && AZ_ALIGNED16(a->src1) && AZ_ALIGNED16(a->weight) && AZ_ALIGNED16(a->bias) &&
+                 AZ_ALIGNED16(a->gate) && AZ_ALIGNED16(a->res) && AZ_ALIGNED16(a->workspace),
+             AZ_E_ALIGN);
+  if (!a->dst_nchw) AZ_REQUIRE(AZ_ALIGNED16(a->dst), AZ_E_ALIGN);
+  if (a->dst_nchw) AZ_REQUIRE(a->dst_c > 0 && a->dst_c <= a->cout_s, AZ_E_SHAPE);
+  if (a->gate) AZ_REQUIRE(a->gate_bstride % 4 == 0, AZ_E_ALIGN);
+  if (a->res && a->res_up) AZ_REQUIRE(((a->hout + 1) >> 1) <= a->hres && ((a->wout + 1) >> 1) <= a->wres, AZ_E_SHAPE);
+  AZ_REQUIRE(a->splitk >= 1 && (a->splitk == 1 || a->workspace), AZ_E_SHAPE);
+  const int64_t npix64 = (int64_t)a->batch * a->hout * a->wout;
+  AZ_REQUIRE(npix64 < (1ll << 31), AZ_E_SHAPE);
+
+  ConvP p;
+  p.a = *a;
+  p.npix = (int)npix64;
+  p.cin_s = a->c0s + a->c1s;
+  p.nkc = (p.cin_s + BK - 1) / BK;
+  p.nk = a->ksize * a->ksize * p.nkc;
+  int splitk = a->splitk;
+  if (splitk > p.nk) splitk = p.nk;
+  p.kps = (p.nk + splitk - 1) / splitk;
+  splitk = (p.nk + p.kps - 1) / p.kps;  // no empty splits
+  p.a.splitk = splitk;
+  p.tiles_m = (a->cout_s + BM - 1) / BM;
+  p.tiles_n = (p.npix + BN - 1) / BN;
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  AZ_REQUIRE(nwg < (1ll << 31), AZ_E_SHAPE);
+  hipStream_t st = az_s(stream);
+  hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
+  int rc = az_launch_status();
+  if (rc != AZ_OK) return rc;
+  if (splitk > 1) {
+    const int grid = az_stream_grid((int64_t)p.npix * (a->cout_s / 4), 256);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, p);
+    rc = az_launch_status();
+  }
+  return rc;
+}
+
+}  // extern "C"

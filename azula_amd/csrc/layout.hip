@@ -1,0 +1,103 @@
+// Layout kernels: planar NCHW <-> channel-padded NHWC (the backbone-internal layout), and
+// the one-off weight repack for the implicit-GEMM convolution.  HBM-bound, LDS-free: reads are
+// coalesced along the pixel axis, writes are 16-byte channel vectors.
+#include "common.h"
+
+namespace {
+
+// One thread per (b, pixel): reads C planes (coalesced across the wave), writes cs channels.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                           const float* __restrict__ scale, int64_t B, int64_t C,
+                                                           int64_t HW, int64_t cs) {
+  const float s = scale ? *scale : 1.0f;
+  const int64_t total = B * HW;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = p / HW, i = p - b * HW;
+    for (int64_t c0 = 0; c0 < cs; c0 += 4) {
+      float v[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int64_t c = c0 + cc;
+        v[cc] = c < C ? az_mul(s, src[(b * C + c) * HW + i]) : 0.f;
+      }
+      *reinterpret_cast<float4*>(dst + p * cs + c0) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                           int64_t B, int64_t C, int64_t HW, int64_t cs) {
+  const int64_t total = B * HW;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = p / HW, i = p - b * HW;
+    for (int64_t c0 = 0; c0 < C; c0 += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src + p * cs + c0);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+        if (c0 + cc < C) dst[(b * C + c0 + cc) * HW + i] = vv[cc];
+    }
+  }
+}
+
+// dst[tap][co][ci_packed] <- src[co][ci][tap]; zero padding everywhere else.
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                               int cout, int cin, int taps, int cout_s, int cin0,
+                                                               int c0s, int cin_s) {
+  const int64_t total = (int64_t)taps * cout_s * cin_s;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int cip = (int)(e % cin_s);
+    const int co = (int)((e / cin_s) % cout_s);
+    const int tap = (int)(e / ((int64_t)cin_s * cout_s));
+    int ci = -1;
+    if (cip < c0s) {
+      if (cip < cin0) ci = cip;
+    } else {
+      const int r = cip - c0s;
+      if (r < cin - cin0) ci = cin0 + r;
+    }
+    float v = 0.f;
+    if (ci >= 0 && co < cout) v = src[((int64_t)co * cin + ci) * taps + tap];
+    dst[e] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int az_nchw_to_nhwc_f32(float* dst, const float* src, const float* scale_dev, int64_t B, int64_t C, int64_t HW,
+                        int64_t cs, az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(B > 0 && C > 0 && HW > 0 && cs >= C && cs % 4 == 0, AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(dst), AZ_E_ALIGN);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(az_stream_grid(B * HW, 256)), dim3(256), 0, az_s(stream), dst, src,
+                     scale_dev, B, C, HW, cs);
+  return az_launch_status();
+}
+
+int az_nhwc_to_nchw_f32(float* dst, const float* src, int64_t B, int64_t C, int64_t HW, int64_t cs,
+                        az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(B > 0 && C > 0 && HW > 0 && cs >= C && cs % 4 == 0, AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(src), AZ_E_ALIGN);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(az_stream_grid(B * HW, 256)), dim3(256), 0, az_s(stream), dst, src,
+                     B, C, HW, cs);
+  return az_launch_status();
+}
+
+int az_pack_conv_weight_f32(float* dst, const float* src, int32_t cout, int32_t cin, int32_t ks, int32_t cout_s,
+                            int32_t cin0, int32_t c0s, int32_t cin_s, az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(cout > 0 && cin > 0 && ks > 0 && cout_s >= cout && cout_s % 4 == 0 && cin_s % 4 == 0, AZ_E_SHAPE);
+  AZ_REQUIRE(cin0 >= 0 && cin0 <= cin && c0s >= cin0 && cin_s >= c0s + (cin - cin0), AZ_E_SHAPE);
+  const int64_t total = (int64_t)ks * ks * cout_s * cin_s;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream), dst, src,
+                     cout, cin, ks * ks, cout_s, cin0, c0s, cin_s);
+  return az_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,381 @@
+// K2 / K6: normalisation kernels on the channel-padded NHWC layout.  All HBM-bound.
+//
+// GroupNorm is split so that the full-tensor passes are pure streams:
+//   stats    : read x once, per-(b, pixel-chunk, group) Chan-combinable partials (n, mean, M2)
+//   finalize : fold (mean, rstd, GN affine, AdaZero/FiLM modulation) into per-(b, c) S, T
+//   apply    : y = act(x * S + T)           (optionally 2x2 average pooled)
+// Reductions: per-thread shifted sums -> (n, mean, M2) -> LDS combine (Chan et al.), so the
+// variance never suffers E[x^2] - E[x]^2 cancellation.
+//
+// Row norms (LayerNorm / RMSNorm over the channel axis, one row = one pixel / token): one
+// wave64 per row, wave-shuffle reductions, two-pass variance for parity with torch.var_mean.
+#include "common.h"
+
+namespace {
+
+struct Moments {
+  float n, mean, m2;
+};
+
+__device__ __forceinline__ Moments combine(Moments a, Moments b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  Moments r;
+  r.n = a.n + b.n;
+  const float d = b.mean - a.mean;
+  const float f = b.n / r.n;
+  r.mean = a.mean + d * f;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+  return r;
+}
+
+// Fast path: group size Cg % 4 == 0 and the slice of `qs` float4 channel-chunks divides 256.
+// grid = (nchunks, B, slices); slice z covers float4 chunks [z*256, z*256 + qs).
+__global__ __launch_bounds__(256) void gn_stats_vec_kernel(float* __restrict__ partials,
+                                                           const float* __restrict__ x, int64_t HW, int C,
+                                                           int cs, int groups, int nchunks, int qs) {
+  __shared__ float sh_n[256], sh_mean[256], sh_m2[256];
+  __shared__ int sh_g[256];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, b = blockIdx.y, z = blockIdx.z;
+  const int Cg = C / groups;
+  const int cq = z * 256 + (tid % qs);  // float4 chunk index along channels
+  const int pl = tid / qs;              // pixel lane
+  const int ppi = 256 / qs;             // pixels per iteration
+  const int64_t ppc = (HW + nchunks - 1) / nchunks;
+  const int64_t p0 = (int64_t)chunk * ppc;
+  const int64_t p1 = p0 + ppc < HW ? p0 + ppc : HW;
+  const int c = cq * 4;
+  const bool live = c < C;
+  float s1 = 0.f, s2 = 0.f, cnt = 0.f, shift = 0.f;
+  if (live) {
+    const float* base = x + ((int64_t)b * HW) * cs + c;
+    bool first = true;
+    for (int64_t p = p0 + pl; p < p1; p += ppi) {
+      const float4 v = *reinterpret_cast<const float4*>(base + p * cs);
+      if (first) {
+        shift = v.x;
+        first = false;
+      }
+      const float a0 = v.x - shift, a1 = v.y - shift, a2 = v.z - shift, a3 = v.w - shift;
+      s1 += (a0 + a1) + (a2 + a3);
+      s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      cnt += 4.f;
+    }
+  }
+  Moments m;
+  m.n = cnt;
+  m.mean = cnt > 0.f ? shift + s1 / cnt : 0.f;
+  m.m2 = cnt > 0.f ? fmaxf(s2 - s1 * s1 / cnt, 0.f) : 0.f;
+  sh_n[tid] = m.n;
+  sh_mean[tid] = m.mean;
+  sh_m2[tid] = m.m2;
+  sh_g[tid] = live ? c / Cg : -1;
+  __syncthreads();
+  // one leader thread per group present in this slice
+  const int g_lo = (z * 1024) / Cg;
+  const int g = g_lo + tid;
+  const int c_hi = z * 1024 + qs * 4 < C ? z * 1024 + qs * 4 : C;
+  if (g < groups && g * Cg < c_hi && (g + 1) * Cg > z * 1024) {
+    Moments acc = {0.f, 0.f, 0.f};
+    for (int t = 0; t < 256; ++t)
+      if (sh_g[t] == g) acc = combine(acc, Moments{sh_n[t], sh_mean[t], sh_m2[t]});
+    // a group never straddles slices when Cg divides 1024 (checked on the host)
+    float* out = partials + (((int64_t)b * nchunks + chunk) * groups + g) * 4;
+    out[0] = acc.n;
+    out[1] = acc.mean;
+    out[2] = acc.m2;
+    out[3] = 0.f;
+  }
+}
+
+// Generic path (any C / groups): grid = (nchunks, B, groups), scalar loads.
+__global__ __launch_bounds__(256) void gn_stats_generic_kernel(float* __restrict__ partials,
+                                                               const float* __restrict__ x, int64_t HW, int C,
+                                                               int cs, int groups, int nchunks) {
+  __shared__ float sh_n[256], sh_mean[256], sh_m2[256];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, b = blockIdx.y, g = blockIdx.z;
+  const int Cg = C / groups;
+  const int64_t ppc = (HW + nchunks - 1) / nchunks;
+  const int64_t p0 = (int64_t)chunk * ppc;
+  const int64_t p1 = p0 + ppc < HW ? p0 + ppc : HW;
+  const int64_t total = (p1 > p0 ? p1 - p0 : 0) * Cg;
+  float s1 = 0.f, s2 = 0.f, cnt = 0.f, shift = 0.f;
+  bool first = true;
+  for (int64_t e = tid; e < total; e += 256) {
+    const int64_t p = p0 + e / Cg;
+    const int c = g * Cg + (int)(e % Cg);
+    const float v = x[((int64_t)b * HW + p) * cs + c];
+    if (first) {
+      shift = v;
+      first = false;
+    }
+    const float a = v - shift;
+    s1 += a;
+    s2 += a * a;
+    cnt += 1.f;
+  }
+  sh_n[tid] = cnt;
+  sh_mean[tid] = cnt > 0.f ? shift + s1 / cnt : 0.f;
+  sh_m2[tid] = cnt > 0.f ? fmaxf(s2 - s1 * s1 / cnt, 0.f) : 0.f;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      const Moments r = combine(Moments{sh_n[tid], sh_mean[tid], sh_m2[tid]},
+                                Moments{sh_n[tid + o], sh_mean[tid + o], sh_m2[tid + o]});
+      sh_n[tid] = r.n;
+      sh_mean[tid] = r.mean;
+      sh_m2[tid] = r.m2;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float* out = partials + (((int64_t)b * nchunks + chunk) * groups + g) * 4;
+    out[0] = sh_n[0];
+    out[1] = sh_mean[0];
+    out[2] = sh_m2[0];
+    out[3] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(AzNormFinalizeArgs a) {
+  const int b = blockIdx.x;
+  const int Cg = (int)(a.C / a.groups);
+  for (int c = threadIdx.x; c < a.cs; c += blockDim.x) {
+    float S = 0.f, T = 0.f;
+    if (c < a.C) {
+      const int g = c / Cg;
+      Moments acc = {0.f, 0.f, 0.f};
+      for (int k = 0; k < a.nchunks; ++k) {
+        const float* p = a.partials + (((int64_t)b * a.nchunks + k) * a.groups + g) * 4;
+        acc = combine(acc, Moments{p[0], p[1], p[2]});
+      }
+      const float var = acc.m2 / acc.n;  // biased, as torch.nn.GroupNorm
+      const float rstd = rsqrtf(var + a.eps);
+      const float w = a.weight ? a.weight[c] : 1.f;
+      const float bi = a.bias ? a.bias[c] : 0.f;
+      const float sc = 1.f + (a.scale ? a.scale[(int64_t)b * a.scale_bstride + c] : 0.f);
+      const float sh = a.shift ? a.shift[(int64_t)b * a.scale_bstride + c] : 0.f;
+      S = rstd * w * sc;
+      T = (bi - acc.mean * rstd * w) * sc + sh;
+    }
+    a.S[(int64_t)b * a.cs + c] = S;
+    a.T[(int64_t)b * a.cs + c] = T;
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void affine_act_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                         const float* __restrict__ S, const float* __restrict__ T,
+                                                         int64_t B, int64_t HW, int cs) {
+  const int q = cs / 4;
+  const int64_t per_b = HW * q;
+  const int64_t total = B * per_b;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = e / per_b;
+    const int c4 = (int)(e % q);
+    const float4 v = reinterpret_cast<const float4*>(x)[e];
+    const float4 s = *reinterpret_cast<const float4*>(S + b * cs + c4 * 4);
+    const float4 t = *reinterpret_cast<const float4*>(T + b * cs + c4 * 4);
+    float4 o;
+    o.x = fmaf(v.x, s.x, t.x);
+    o.y = fmaf(v.y, s.y, t.y);
+    o.z = fmaf(v.z, s.z, t.z);
+    o.w = fmaf(v.w, s.w, t.w);
+    if (ACT == 1) {
+      o.x = az_silu(o.x);
+      o.y = az_silu(o.y);
+      o.z = az_silu(o.z);
+      o.w = az_silu(o.w);
+    }
+    reinterpret_cast<float4*>(y)[e] = o;
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void affine_act_pool_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                              const float* __restrict__ S,
+                                                              const float* __restrict__ T, int64_t B, int H, int W,
+                                                              int cs) {
+  const int q = cs / 4;
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t per_b = (int64_t)Ho * Wo * q;
+  const int64_t total = B * per_b;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = e / per_b;
+    const int64_t r = e - b * per_b;
+    const int c4 = (int)(r % q);
+    const int ow = (int)((r / q) % Wo);
+    const int oh = (int)(r / ((int64_t)q * Wo));
+    const float4 s = *reinterpret_cast<const float4*>(S + b * cs + c4 * 4);
+    const float4 t = *reinterpret_cast<const float4*>(T + b * cs + c4 * 4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int64_t pix = (b * H + (2 * oh + dy)) * W + (2 * ow + dx);
+        const float4 v = *reinterpret_cast<const float4*>(x + pix * cs + c4 * 4);
+        float4 o;
+        o.x = fmaf(v.x, s.x, t.x);
+        o.y = fmaf(v.y, s.y, t.y);
+        o.z = fmaf(v.z, s.z, t.z);
+        o.w = fmaf(v.w, s.w, t.w);
+        if (ACT == 1) {
+          o.x = az_silu(o.x);
+          o.y = az_silu(o.y);
+          o.z = az_silu(o.z);
+          o.w = az_silu(o.w);
+        }
+        acc.x += o.x;
+        acc.y += o.y;
+        acc.z += o.z;
+        acc.w += o.w;
+      }
+    acc.x *= 0.25f;
+    acc.y *= 0.25f;
+    acc.z *= 0.25f;
+    acc.w *= 0.25f;
+    reinterpret_cast<float4*>(y)[e] = acc;
+  }
+}
+
+// One wave per row.  kind 0: layer norm (unbiased variance), kind 1: RMS norm.
+__global__ __launch_bounds__(256) void rownorm_mod_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int64_t scale_bstride,
+                                                          int64_t rows, int64_t rows_per_batch, int C, int cs,
+                                                          int kind, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const bool vec = (C % 4) == 0;
+  for (int64_t row = wave; row < rows; row += nwaves) {
+    const float* xr = x + row * cs;
+    float* yr = y + row * cs;
+    const int64_t b = row / rows_per_batch;
+    float s = 0.f;
+    if (vec) {
+      for (int c = lane * 4; c < C; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        if (kind == 0) s += (v.x + v.y) + (v.z + v.w);
+        else s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) {
+        const float v = xr[c];
+        s += kind == 0 ? v : v * v;
+      }
+    }
+    s = az_wave_sum(s);
+    float mean = 0.f, rstd;
+    if (kind == 0) {
+      mean = s / (float)C;
+      float q = 0.f;
+      if (vec) {
+        for (int c = lane * 4; c < C; c += 256) {
+          const float4 v = *reinterpret_cast<const float4*>(xr + c);
+          const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+          q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+      } else {
+        for (int c = lane; c < C; c += 64) {
+          const float a0 = xr[c] - mean;
+          q += a0 * a0;
+        }
+      }
+      q = az_wave_sum(q);
+      rstd = rsqrtf(q / (float)(C - 1) + eps);
+    } else {
+      rstd = rsqrtf(s / (float)C + eps);
+    }
+    const float* sc = scale ? scale + b * scale_bstride : nullptr;
+    const float* sh = shift ? shift + b * scale_bstride : nullptr;
+    for (int c = lane; c < cs; c += 64) {
+      float o = 0.f;
+      if (c < C) {
+        o = (xr[c] - mean) * rstd;
+        o = o * (1.f + (sc ? sc[c] : 0.f)) + (sh ? sh[c] : 0.f);
+      }
+      yr[c] = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int az_groupnorm_stats_f32(float* partials, const float* x, int64_t B, int64_t HW, int64_t C, int64_t cs,
+                           int32_t groups, int32_t nchunks, az_stream_t stream) {
+  AZ_REQUIRE(partials && x, AZ_E_NULL);
+  AZ_REQUIRE(B > 0 && HW > 0 && C > 0 && cs >= C && cs % 4 == 0 && groups > 0 && C % groups == 0 && nchunks > 0,
+             AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(x), AZ_E_ALIGN);
+  const int Cg = (int)(C / groups);
+  const int q = (int)(cs / 4);
+  const int qs = q < 256 ? q : 256;
+  const bool fast = (Cg % 4 == 0) && (256 % qs == 0) && (q <= 256 || (q % 256 == 0 && 1024 % Cg == 0));
+  if (fast) {
+    dim3 grid((unsigned)nchunks, (unsigned)B, (unsigned)((q + 255) / 256));
+    hipLaunchKernelGGL(gn_stats_vec_kernel, grid, dim3(256), 0, az_s(stream), partials, x, HW, (int)C, (int)cs,
+                       (int)groups, (int)nchunks, qs);
+  } else {
+    dim3 grid((unsigned)nchunks, (unsigned)B, (unsigned)groups);
+    hipLaunchKernelGGL(gn_stats_generic_kernel, grid, dim3(256), 0, az_s(stream), partials, x, HW, (int)C, (int)cs,
+                       (int)groups, (int)nchunks);
+  }
+  return az_launch_status();
+}
+
+int az_groupnorm_finalize_f32(const AzNormFinalizeArgs* a, az_stream_t stream) {
+  AZ_REQUIRE(a && a->S && a->T && a->partials, AZ_E_NULL);
+  AZ_REQUIRE(a->B > 0 && a->C > 0 && a->cs >= a->C && a->groups > 0 && a->C % a->groups == 0 && a->nchunks > 0,
+             AZ_E_SHAPE);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)a->B), dim3(256), 0, az_s(stream), *a);
+  return az_launch_status();
+}
+
+int az_affine_act_f32(float* y, const float* x, const float* S, const float* T, int64_t B, int64_t H, int64_t W,
+                      int64_t cs, int32_t act, int32_t pool, az_stream_t stream) {
+  AZ_REQUIRE(y && x && S && T, AZ_E_NULL);
+  AZ_REQUIRE(B > 0 && H > 0 && W > 0 && cs > 0 && cs % 4 == 0, AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(y) && AZ_ALIGNED16(x) && AZ_ALIGNED16(S) && AZ_ALIGNED16(T), AZ_E_ALIGN);
+  hipStream_t st = az_s(stream);
+  if (pool) {
+    AZ_REQUIRE(H % 2 == 0 && W % 2 == 0, AZ_E_SHAPE);
+    const int grid = az_stream_grid(B * (H / 2) * (W / 2) * (cs / 4), 256);
+    if (act == 1)
+      hipLaunchKernelGGL(affine_act_pool_kernel<1>, dim3(grid), dim3(256), 0, st, y, x, S, T, B, (int)H, (int)W,
+                         (int)cs);
+    else
+      hipLaunchKernelGGL(affine_act_pool_kernel<0>, dim3(grid), dim3(256), 0, st, y, x, S, T, B, (int)H, (int)W,
+                         (int)cs);
+  } else {
+    const int grid = az_stream_grid(B * H * W * (cs / 4), 256);
+    if (act == 1)
+      hipLaunchKernelGGL(affine_act_kernel<1>, dim3(grid), dim3(256), 0, st, y, x, S, T, B, H * W, (int)cs);
+    else
+      hipLaunchKernelGGL(affine_act_kernel<0>, dim3(grid), dim3(256), 0, st, y, x, S, T, B, H * W, (int)cs);
+  }
+  return az_launch_status();
+}
+
+int az_rownorm_mod_f32(float* y, const float* x, const float* scale, const float* shift, int64_t scale_bstride,
+                       int64_t rows, int64_t rows_per_batch, int64_t C, int64_t cs, int32_t kind, float eps,
+                       az_stream_t stream) {
+  AZ_REQUIRE(y && x, AZ_E_NULL);
+  AZ_REQUIRE(rows > 0 && rows_per_batch > 0 && C > 0 && cs >= C && cs % 4 == 0 && (kind == 0 || kind == 1),
+             AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(y) && AZ_ALIGNED16(x), AZ_E_ALIGN);
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rownorm_mod_kernel, dim3((unsigned)blocks), dim3(256), 0, az_s(stream), y, x, scale, shift,
+                     scale_bstride, rows, rows_per_batch, (int)C, (int)cs, (int)kind, eps);
+  return az_launch_status();
+}
+
+}  // extern "C"

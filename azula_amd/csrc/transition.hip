@@ -1,0 +1,378 @@
+// K1: fused Karras/ADM post-conditioning + (CFG combine) + DDPM/DDIM transition + next-step
+// pre-scale, plus the tiny per-step scalar plumbing kernels.  HBM-bound: one pass over the
+// latent, 16-byte accesses, grid capped at 2048 blocks with a grid-stride loop.
+//
+// Reference arithmetic replaced (see include/azula_amd.h): azula/denoise.py:317,322,
+// azula/plugins/adm/__init__.py:126-134, azula/guidance/cfg.py:63-65, azula/sample.py:257-259.
+#include "common.h"
+
+namespace {
+
+struct Coef {
+  float c_skip, c_out, alpha_t, alpha_s, k_x, k_eps, c_in_next, lo, hi, g;
+};
+
+__device__ __forceinline__ Coef load_coef(const AzStepCoef* c) {
+  Coef k;
+  k.c_skip = c->c_skip;
+  k.c_out = c->c_out;
+  k.alpha_t = c->alpha_t;
+  k.alpha_s = c->alpha_s;
+  k.k_x = c->k_x;
+  k.k_eps = c->k_eps;
+  k.c_in_next = c->c_in_next;
+  k.lo = c->clip_lo;
+  k.hi = c->clip_hi;
+  k.g = c->guidance;
+  return k;
+}
+
+// Posterior mean for one element, reference association order, every op rounded on its own.
+template <bool CFG>
+__device__ __forceinline__ float post_mean(const Coef& k, float x, float f, float fn) {
+  float m = az_add(az_mul(k.c_skip, x), az_mul(k.c_out, f));
+  m = fminf(fmaxf(m, k.lo), k.hi);
+  if (CFG) {
+    float mn = az_add(az_mul(k.c_skip, x), az_mul(k.c_out, fn));
+    mn = fminf(fmaxf(mn, k.lo), k.hi);
+    m = az_add(m, az_mul(k.g, az_sub(m, mn)));
+  }
+  return m;
+}
+
+template <bool EPS>
+__device__ __forceinline__ float step_x(const Coef& k, float x, float m, float e) {
+  float xs = az_mul(k.alpha_s, m);
+  xs = az_add(xs, az_mul(k.k_x, az_sub(x, az_mul(k.alpha_t, m))));
+  if (EPS) xs = az_add(xs, az_mul(k.k_eps, e));
+  return xs;
+}
+
+// ---- flat elementwise form: every tensor has the same (n,) layout --------------------------
+template <bool CFG, bool EPS, bool XIN, bool MEAN>
+__global__ __launch_bounds__(256) void transition_flat_kernel(const float* __restrict__ x_t,
+                                                              const float* __restrict__ F,
+                                                              const float* __restrict__ Fn,
+                                                              const float* __restrict__ eps, float* x_s,
+                                                              float* __restrict__ xin, float* __restrict__ mean_out,
+                                                              int64_t n4, int64_t n, const AzStepCoef* coef) {
+  const Coef k = load_coef(coef);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 xv = reinterpret_cast<const float4*>(x_t)[i];
+    const float4 fv = reinterpret_cast<const float4*>(F)[i];
+    float4 nv = make_float4(0.f, 0.f, 0.f, 0.f), ev = nv;
+    if (CFG) nv = reinterpret_cast<const float4*>(Fn)[i];
+    if (EPS) ev = reinterpret_cast<const float4*>(eps)[i];
+    float4 m, o;
+    m.x = post_mean<CFG>(k, xv.x, fv.x, nv.x);
+    m.y = post_mean<CFG>(k, xv.y, fv.y, nv.y);
+    m.z = post_mean<CFG>(k, xv.z, fv.z, nv.z);
+    m.w = post_mean<CFG>(k, xv.w, fv.w, nv.w);
+    o.x = step_x<EPS>(k, xv.x, m.x, ev.x);
+    o.y = step_x<EPS>(k, xv.y, m.y, ev.y);
+    o.z = step_x<EPS>(k, xv.z, m.z, ev.z);
+    o.w = step_x<EPS>(k, xv.w, m.w, ev.w);
+    reinterpret_cast<float4*>(x_s)[i] = o;
+    if (MEAN) reinterpret_cast<float4*>(mean_out)[i] = m;
+    if (XIN) {
+      float4 q;
+      q.x = az_mul(k.c_in_next, o.x);
+      q.y = az_mul(k.c_in_next, o.y);
+      q.z = az_mul(k.c_in_next, o.z);
+      q.w = az_mul(k.c_in_next, o.w);
+      reinterpret_cast<float4*>(xin)[i] = q;
+    }
+  }
+  // scalar tail (n not a multiple of 4)
+  if (blockIdx.x == 0) {
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+      const float x = x_t[i];
+      const float m = post_mean<CFG>(k, x, F[i], CFG ? Fn[i] : 0.f);
+      const float o = step_x<EPS>(k, x, m, EPS ? eps[i] : 0.f);
+      x_s[i] = o;
+      if (MEAN) mean_out[i] = m;
+      if (XIN) xin[i] = az_mul(k.c_in_next, o);
+    }
+  }
+}
+
+// ---- image form: x is (B, C, inner) planar; F may be planar with more channels (ADM: 6 of
+// which 3 are read) or NHWC with channel stride fC; xin may be written NHWC with stride xs_c.
+// One thread owns 4 consecutive pixels of one sample: all accesses are 16 B.
+template <bool CFG, bool EPS, bool MEAN>
+__global__ __launch_bounds__(256) void transition_image_kernel(AzTransitionArgs a, int64_t quads_per_sample) {
+  const Coef k = load_coef(a.coef);
+  const int64_t total = a.batch * quads_per_sample;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int C = (int)a.channels;
+  const int64_t inner = a.inner;
+  const int64_t fC = a.f_channels;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+    const int64_t b = q / quads_per_sample;
+    const int64_t i0 = (q - b * quads_per_sample) * 4;
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      float xs[4][4];  // [channel in chunk][pixel]
+      float4 fpix[4], npix[4];
+      if (a.f_nhwc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t off = (b * inner + i0 + j) * fC + c0;
+          fpix[j] = *reinterpret_cast<const float4*>(a.F + off);
+          if (CFG) npix[j] = *reinterpret_cast<const float4*>(a.F_neg + off);
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = c0 + cc;
+        if (c >= C) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xs[cc][j] = 0.f;
+          continue;
+        }
+        const int64_t xo = (b * C + c) * inner + i0;
+        const float4 xv = *reinterpret_cast<const float4*>(a.x_t + xo);
+        float4 fv, nv = make_float4(0.f, 0.f, 0.f, 0.f), ev = nv;
+        if (a.f_nhwc) {
+          const float* fp = reinterpret_cast<const float*>(fpix);
+          fv = make_float4(fp[0 * 4 + cc], fp[1 * 4 + cc], fp[2 * 4 + cc], fp[3 * 4 + cc]);
+          if (CFG) {
+            const float* np = reinterpret_cast<const float*>(npix);
+            nv = make_float4(np[0 * 4 + cc], np[1 * 4 + cc], np[2 * 4 + cc], np[3 * 4 + cc]);
+          }
+        } else {
+          const int64_t fo = (b * fC + c) * inner + i0;
+          fv = *reinterpret_cast<const float4*>(a.F + fo);
+          if (CFG) nv = *reinterpret_cast<const float4*>(a.F_neg + fo);
+        }
+        if (EPS) ev = *reinterpret_cast<const float4*>(a.eps + xo);
+        float4 m, o;
+        m.x = post_mean<CFG>(k, xv.x, fv.x, nv.x);
+        m.y = post_mean<CFG>(k, xv.y, fv.y, nv.y);
+        m.z = post_mean<CFG>(k, xv.z, fv.z, nv.z);
+        m.w = post_mean<CFG>(k, xv.w, fv.w, nv.w);
+        o.x = step_x<EPS>(k, xv.x, m.x, ev.x);
+        o.y = step_x<EPS>(k, xv.y, m.y, ev.y);
+        o.z = step_x<EPS>(k, xv.z, m.z, ev.z);
+        o.w = step_x<EPS>(k, xv.w, m.w, ev.w);
+        *reinterpret_cast<float4*>(a.x_s + xo) = o;
+        if (MEAN) *reinterpret_cast<float4*>(a.mean_out + xo) = m;
+        xs[cc][0] = o.x;
+        xs[cc][1] = o.y;
+        xs[cc][2] = o.z;
+        xs[cc][3] = o.w;
+      }
+      if (a.xin_next != nullptr) {
+        if (a.nhwc_pad > 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float4 v;
+            v.x = az_mul(k.c_in_next, xs[0][j]);
+            v.y = az_mul(k.c_in_next, xs[1][j]);
+            v.z = az_mul(k.c_in_next, xs[2][j]);
+            v.w = az_mul(k.c_in_next, xs[3][j]);
+            *reinterpret_cast<float4*>(a.xin_next + (b * inner + i0 + j) * a.nhwc_pad + c0) = v;
+          }
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int c = c0 + cc;
+            if (c >= C) continue;
+            float4 v;
+            v.x = az_mul(k.c_in_next, xs[cc][0]);
+            v.y = az_mul(k.c_in_next, xs[cc][1]);
+            v.z = az_mul(k.c_in_next, xs[cc][2]);
+            v.w = az_mul(k.c_in_next, xs[cc][3]);
+            *reinterpret_cast<float4*>(a.xin_next + (b * C + c) * inner + i0) = v;
+          }
+        }
+      }
+    }
+    // zero the remaining pad channels of the NHWC pre-scaled output
+    if (a.xin_next != nullptr && a.nhwc_pad > 0) {
+      for (int c0 = (C + 3) & ~3; c0 < a.nhwc_pad; c0 += 4)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<float4*>(a.xin_next + (b * inner + i0 + j) * a.nhwc_pad + c0) =
+              make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+__global__ void step_begin_kernel(AzStepCoef* cur, const AzStepCoef* table, int32_t* counter, int32_t n_steps) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int32_t s = *counter;
+    if (s < 0) s = 0;
+    if (s >= n_steps) s = n_steps - 1;
+    *cur = table[s];
+    *counter = *counter + 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                    const float* __restrict__ s, int64_t n4, int64_t n) {
+  const float k = *s;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x = az_mul(k, v.x);
+    v.y = az_mul(k, v.y);
+    v.z = az_mul(k, v.z);
+    v.w = az_mul(k, v.w);
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) y[i] = az_mul(k, x[i]);
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ y, const float* __restrict__ a,
+                                                    const float* __restrict__ x, const float* __restrict__ b,
+                                                    const float* __restrict__ z, int64_t rows, int64_t inner,
+                                                    int a_stride) {
+  const int64_t n = rows * inner;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = a_stride ? i / inner : 0;
+    y[i] = az_add(az_mul(a[r * a_stride], x[i]), az_mul(b[r * a_stride], z[i]));
+  }
+}
+
+__global__ void gather_rows_kernel(float* __restrict__ dst, const float* __restrict__ table,
+                                   const int64_t* __restrict__ idx, int64_t nrows, int64_t ncols,
+                                   int64_t table_rows) {
+  const int64_t r = blockIdx.x;
+  int64_t src = idx[r];
+  if (src < 0) src = 0;
+  if (src >= table_rows) src = table_rows - 1;
+  for (int64_t c = threadIdx.x; c < ncols; c += blockDim.x) dst[r * ncols + c] = table[src * ncols + c];
+}
+
+__global__ void gather_step_row_kernel(float* __restrict__ dst, const float* __restrict__ table,
+                                       const AzStepCoef* coef, int which, int64_t ncols, int64_t table_rows) {
+  int64_t src = which == 0 ? coef->time_index : coef->step;
+  if (src < 0) src = 0;
+  if (src >= table_rows) src = table_rows - 1;
+  for (int64_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * blockDim.x)
+    dst[c] = table[src * ncols + c];
+}
+
+__global__ void coef_c_time_kernel(float* dst, const AzStepCoef* coef) {
+  if (threadIdx.x == 0) dst[0] = coef->c_time;
+}
+
+template <bool CFG, bool EPS>
+int launch_flat(const AzTransitionArgs* a, int64_t n, hipStream_t st) {
+  const int64_t n4 = n / 4;
+  const int grid = az_stream_grid(n4 > 0 ? n4 : 1, 256);
+  const bool xin = a->xin_next != nullptr, mean = a->mean_out != nullptr;
+#define AZ_FLAT(X, M)                                                                                          \
+  hipLaunchKernelGGL((transition_flat_kernel<CFG, EPS, X, M>), dim3(grid), dim3(256), 0, st, a->x_t, a->F, a->F_neg, \
+                     a->eps, a->x_s, a->xin_next, a->mean_out, n4, n, a->coef)
+  if (xin && mean) AZ_FLAT(true, true);
+  else if (xin) AZ_FLAT(true, false);
+  else if (mean) AZ_FLAT(false, true);
+  else AZ_FLAT(false, false);
+#undef AZ_FLAT
+  return az_launch_status();
+}
+
+template <bool CFG, bool EPS>
+int launch_image(const AzTransitionArgs* a, hipStream_t st) {
+  const int64_t qps = a->inner / 4;
+  const int grid = az_stream_grid(a->batch * qps, 256);
+  if (a->mean_out != nullptr)
+    hipLaunchKernelGGL((transition_image_kernel<CFG, EPS, true>), dim3(grid), dim3(256), 0, st, *a, qps);
+  else
+    hipLaunchKernelGGL((transition_image_kernel<CFG, EPS, false>), dim3(grid), dim3(256), 0, st, *a, qps);
+  return az_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int az_version(void) { return AZ_VERSION; }
+
+const char* az_error_string(int code) {
+  switch (code) {
+    case AZ_OK: return "ok";
+    case AZ_E_NULL: return "azula_amd: required pointer is NULL";
+    case AZ_E_SHAPE: return "azula_amd: inconsistent or unsupported shape";
+    case AZ_E_ALIGN: return "azula_amd: pointer/stride not 16-byte aligned";
+    case AZ_E_UNSUPPORTED: return "azula_amd: unsupported configuration";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "azula_amd: unknown error";
+  }
+}
+
+int az_step_begin(AzStepCoef* cur, const AzStepCoef* table, int32_t* step_counter, int32_t n_steps,
+                  az_stream_t stream) {
+  AZ_REQUIRE(cur && table && step_counter, AZ_E_NULL);
+  AZ_REQUIRE(n_steps > 0, AZ_E_SHAPE);
+  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, az_s(stream), cur, table, step_counter, n_steps);
+  return az_launch_status();
+}
+
+int az_transition_f32(const AzTransitionArgs* a, az_stream_t stream) {
+  AZ_REQUIRE(a && a->x_t && a->F && a->x_s && a->coef, AZ_E_NULL);
+  AZ_REQUIRE(a->batch > 0 && a->channels > 0 && a->inner > 0 && a->f_channels >= a->channels, AZ_E_SHAPE);
+  const int64_t n = a->batch * a->channels * a->inner;
+  const bool cfg = a->F_neg != nullptr, eps = a->eps != nullptr;
+  const bool flat = !a->f_nhwc && a->nhwc_pad == 0 && a->f_channels == a->channels;
+  AZ_REQUIRE(AZ_ALIGNED16(a->x_t) && AZ_ALIGNED16(a->F) && AZ_ALIGNED16(a->x_s), AZ_E_ALIGN);
+  AZ_REQUIRE(AZ_ALIGNED16(a->F_neg) && AZ_ALIGNED16(a->eps) && AZ_ALIGNED16(a->xin_next) && AZ_ALIGNED16(a->mean_out),
+             AZ_E_ALIGN);
+  hipStream_t st = az_s(stream);
+  if (flat) {
+    if (cfg) return eps ? launch_flat<true, true>(a, n, st) : launch_flat<true, false>(a, n, st);
+    return eps ? launch_flat<false, true>(a, n, st) : launch_flat<false, false>(a, n, st);
+  }
+  AZ_REQUIRE(a->inner % 4 == 0, AZ_E_SHAPE);
+  if (a->f_nhwc) AZ_REQUIRE(a->f_channels % 4 == 0, AZ_E_SHAPE);
+  if (a->nhwc_pad > 0) AZ_REQUIRE(a->nhwc_pad % 4 == 0 && a->nhwc_pad >= a->channels, AZ_E_SHAPE);
+  if (cfg) return eps ? launch_image<true, true>(a, st) : launch_image<true, false>(a, st);
+  return eps ? launch_image<false, true>(a, st) : launch_image<false, false>(a, st);
+}
+
+int az_scale_f32(float* y, const float* x, const float* s_dev, int64_t n, az_stream_t stream) {
+  AZ_REQUIRE(y && x && s_dev, AZ_E_NULL);
+  AZ_REQUIRE(n > 0, AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(y) && AZ_ALIGNED16(x), AZ_E_ALIGN);
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(scale_kernel, dim3(az_stream_grid(n4 > 0 ? n4 : 1, 256)), dim3(256), 0, az_s(stream), y, x,
+                     s_dev, n4, n);
+  return az_launch_status();
+}
+
+int az_axpby_f32(float* y, const float* a_dev, const float* x, const float* b_dev, const float* z, int64_t rows,
+                 int64_t inner, int32_t a_stride, az_stream_t stream) {
+  AZ_REQUIRE(y && a_dev && x && b_dev && z, AZ_E_NULL);
+  AZ_REQUIRE(rows > 0 && inner > 0 && (a_stride == 0 || a_stride == 1), AZ_E_SHAPE);
+  hipLaunchKernelGGL(axpby_kernel, dim3(az_stream_grid(rows * inner, 256)), dim3(256), 0, az_s(stream), y, a_dev, x,
+                     b_dev, z, rows, inner, a_stride);
+  return az_launch_status();
+}
+
+int az_gather_rows_f32(float* dst, const float* table, const int64_t* idx, int64_t nrows, int64_t ncols,
+                       int64_t table_rows, az_stream_t stream) {
+  AZ_REQUIRE(dst && table && idx, AZ_E_NULL);
+  AZ_REQUIRE(nrows > 0 && ncols > 0 && table_rows > 0, AZ_E_SHAPE);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nrows), dim3(256), 0, az_s(stream), dst, table, idx, nrows,
+                     ncols, table_rows);
+  return az_launch_status();
+}
+
+int az_gather_step_row_f32(float* dst, const float* table, const AzStepCoef* coef, int32_t which, int64_t ncols,
+                           int64_t table_rows, az_stream_t stream) {
+  AZ_REQUIRE(dst && table && coef, AZ_E_NULL);
+  AZ_REQUIRE(ncols > 0 && table_rows > 0, AZ_E_SHAPE);
+  hipLaunchKernelGGL(gather_step_row_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, az_s(stream), dst,
+                     table, coef, which, ncols, table_rows);
+  return az_launch_status();
+}
+
+int az_coef_c_time_f32(float* dst, const AzStepCoef* coef, az_stream_t stream) {
+  AZ_REQUIRE(dst && coef, AZ_E_NULL);
+  hipLaunchKernelGGL(coef_c_time_kernel, dim3(1), dim3(64), 0, az_s(stream), dst, coef);
+  return az_launch_status();
+}
+
+}  // extern "C"

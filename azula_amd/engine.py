@@ -1,0 +1,305 @@
+r"""Host-side execution engine: kernel tapes, static activation pools and hipGraph replay.
+
+A backbone forward is compiled ONCE per input shape into a :class:`Tape` -- a flat list of
+C-ABI calls whose every argument (device pointers, sizes, POD structs) is static.  Per-step
+scalars live in device memory (``AzStepCoef``), so the same tape -- and the hipGraph captured
+from it -- serves every sampling step.  Python is only the builder; replay is one
+``hipGraphLaunch`` per step.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import AzConvArgs, AzNormFinalizeArgs, AzTransitionArgs
+
+
+def pad4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+class Tape:
+    r"""A recorded sequence of C-ABI kernel launches with static arguments."""
+
+    def __init__(self) -> None:
+        self.ops: list[tuple] = []
+        self.keep: list = []  # tensors / structs that must outlive the tape
+
+    def add(self, name: str, *args, keep=()) -> None:
+        fn = getattr(_lib.lib(), name)
+        self.ops.append((fn, args, name))
+        self.keep.extend(keep)
+
+    def extend(self, other: "Tape") -> None:
+        self.ops.extend(other.ops)
+        self.keep.extend(other.keep)
+
+    def run(self, stream: int | None = None) -> None:
+        if stream is None:
+            stream = _lib.stream_ptr()
+        for fn, args, name in self.ops:
+            rc = fn(*args, stream)
+            if rc != 0:
+                _lib.check(rc, name)
+
+    def __len__(self) -> int:
+        return len(self.ops)
+
+
+class StepGraph:
+    r"""hipGraph captured from a tape (on a private capture stream), launched on torch's stream."""
+
+    def __init__(self, tape: Tape, device: torch.device) -> None:
+        self.tape = tape
+        self.handle = C.c_void_p()
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            _lib.call("az_graph_begin", side.cuda_stream)
+            try:
+                tape.run(side.cuda_stream)
+            finally:
+                _lib.call("az_graph_end", side.cuda_stream, C.byref(self.handle))
+        torch.cuda.current_stream(device).wait_stream(side)
+        self._side = side
+
+    def launch(self) -> None:
+        _lib.call("az_graph_launch", self.handle, _lib.stream_ptr())
+
+    @property
+    def num_nodes(self) -> int:
+        n = C.c_int64()
+        _lib.call("az_graph_num_nodes", self.handle, C.byref(n))
+        return n.value
+
+    def __del__(self) -> None:
+        try:
+            if self.handle:
+                _lib.lib().az_graph_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Pool:
+    r"""Static activation buffers with explicit reuse (a graph needs fixed addresses)."""
+
+    def __init__(self, device: torch.device) -> None:
+        self.device = device
+        self.free: dict[int, list[torch.Tensor]] = {}
+        self.all: list[torch.Tensor] = []
+
+    def alloc(self, numel: int) -> torch.Tensor:
+        lst = self.free.get(numel)
+        if lst:
+            return lst.pop()
+        t = torch.empty(numel, dtype=torch.float32, device=self.device)
+        self.all.append(t)
+        return t
+
+    def release(self, t: torch.Tensor) -> None:
+        self.free.setdefault(t.numel(), []).append(t)
+
+    @property
+    def bytes(self) -> int:
+        return sum(t.numel() * 4 for t in self.all)
+
+
+class Act:
+    r"""An NHWC activation: ``buf`` holds (B, H, W, cs) floats, ``C`` real channels."""
+
+    __slots__ = ("buf", "B", "H", "W", "C", "cs", "pinned")
+
+    def __init__(self, buf: torch.Tensor, B: int, H: int, W: int, C_: int, cs: int, pinned: bool = False) -> None:
+        self.buf, self.B, self.H, self.W, self.C, self.cs, self.pinned = buf, B, H, W, C_, cs, pinned
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr()
+
+
+class Builder:
+    r"""Emits kernels onto a tape; owns the pool, packed weights and the split-K workspace."""
+
+    def __init__(self, device: torch.device) -> None:
+        self.device = device
+        self.tape = Tape()
+        self.pool = Pool(device)
+        self._ws_need = 0
+        self._ws_users: list[AzConvArgs] = []
+        self.workspace: torch.Tensor | None = None
+
+    # -- buffers ---------------------------------------------------------------------------
+    def new_act(self, B: int, H: int, W: int, C_: int, pinned: bool = False) -> Act:
+        cs = pad4(C_)
+        return Act(self.pool.alloc(B * H * W * cs), B, H, W, C_, cs, pinned)
+
+    def free(self, a: Act) -> None:
+        if not a.pinned:
+            self.pool.release(a.buf)
+
+    def const(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self.tape.keep.append(t)
+        return t
+
+    def empty(self, *shape) -> torch.Tensor:
+        t = torch.empty(*shape, dtype=torch.float32, device=self.device)
+        self.tape.keep.append(t)
+        return t
+
+    # -- weights ---------------------------------------------------------------------------
+    def pack_conv(self, weight: torch.Tensor, bias: torch.Tensor | None, cin0: int | None = None):
+        r"""torch (cout, cin, k, k) [or (cout, cin) for linears] -> packed [taps][cout_s][cin_s]."""
+        w = weight.detach().to(device=self.device, dtype=torch.float32)
+        if w.ndim == 2:
+            w = w[:, :, None, None]
+        elif w.ndim == 3:  # Conv1d k=1
+            w = w[:, :, :, None]
+        w = w.contiguous()
+        cout, cin, kh, kw = w.shape
+        assert kh == kw, "square kernels only"
+        if cin0 is None:
+            cin0 = cin
+        c0s = pad4(cin0)
+        cin_s = c0s + pad4(cin - cin0)
+        cout_s = pad4(cout)
+        packed = torch.empty(kh * kw * cout_s * cin_s, dtype=torch.float32, device=self.device)
+        _lib.call(
+            "az_pack_conv_weight_f32", packed.data_ptr(), w.data_ptr(), cout, cin, kh, cout_s, cin0, c0s, cin_s,
+            _lib.stream_ptr(),
+        )
+        bp = None
+        if bias is not None:
+            bp = torch.zeros(cout_s, dtype=torch.float32, device=self.device)
+            bp[:cout] = bias.detach().to(device=self.device, dtype=torch.float32)
+        self.tape.keep.extend([packed, bp, w])
+        return packed, bp, kh
+
+    # -- kernels ---------------------------------------------------------------------------
+    def conv(
+        self,
+        src0: Act,
+        packed,
+        cout: int,
+        *,
+        src1: Act | None = None,
+        up0: int = 0,
+        up1: int = 0,
+        hin: int | None = None,
+        win: int | None = None,
+        stride: int = 1,
+        act: int = 0,
+        gate: torch.Tensor | None = None,
+        gate_off: int = 0,
+        gate_bstride: int = 0,
+        res: Act | None = None,
+        res_up: int = 0,
+        dst_nchw: torch.Tensor | None = None,
+    ) -> Act | None:
+        weight, bias, ks = packed
+        pad = ks // 2
+        B = src0.B
+        if hin is None:
+            hin = src0.H << up0
+        if win is None:
+            win = src0.W << up0
+        hout = (hin + 2 * pad - ks) // stride + 1
+        wout = (win + 2 * pad - ks) // stride + 1
+        a = AzConvArgs()
+        a.src0, a.c0s, a.up0, a.h0, a.w0 = src0.ptr, src0.cs, up0, src0.H, src0.W
+        if src1 is not None:
+            a.src1, a.c1s, a.up1, a.h1, a.w1 = src1.ptr, src1.cs, up1, src1.H, src1.W
+        a.batch, a.hin, a.win = B, hin, win
+        a.weight = weight.data_ptr()
+        a.bias = bias.data_ptr() if bias is not None else None
+        a.cout_s = pad4(cout)
+        a.ksize, a.stride, a.pad = ks, stride, pad
+        a.hout, a.wout = hout, wout
+        a.act = act
+        if gate is not None:
+            a.gate = gate.data_ptr() + 4 * gate_off
+            a.gate_bstride = gate_bstride
+        if res is not None:
+            a.res, a.res_up, a.hres, a.wres = res.ptr, res_up, res.H, res.W
+            assert res.cs == a.cout_s
+        out = None
+        if dst_nchw is not None:
+            a.dst, a.dst_nchw, a.dst_c = dst_nchw.data_ptr(), 1, cout
+        else:
+            out = self.new_act(B, hout, wout, cout)
+            a.dst = out.ptr
+        npix = B * hout * wout
+        cin_s = a.c0s + a.c1s
+        a.splitk = _lib.lib().az_conv2d_suggest_splitk(npix, a.cout_s, cin_s, ks)
+        if a.splitk > 1:
+            self._ws_need = max(self._ws_need, a.splitk * npix * a.cout_s)
+            self._ws_users.append(a)
+        a._flops = 2 * npix * cout * (src0.C + (src1.C if src1 is not None else 0)) * ks * ks  # algorithmic
+        self.tape.add("az_conv2d_f32", C.byref(a), keep=[a])
+        return out
+
+    def finish(self) -> None:
+        r"""Allocates the shared split-K workspace and patches it into the recorded convs."""
+        if self._ws_need and (self.workspace is None or self.workspace.numel() < self._ws_need):
+            self.workspace = torch.empty(self._ws_need, dtype=torch.float32, device=self.device)
+        for a in self._ws_users:
+            a.workspace = self.workspace.data_ptr()
+        self._ws_users = []
+
+    def linear_small(self, y, ldy, x, ldx, W, bias, M, N, K, in_act=0, out_act=0, y_off=0) -> None:
+        self.tape.add(
+            "az_linear_small_f32", y.data_ptr() + 4 * y_off, ldy, x.data_ptr(), ldx, W.data_ptr(),
+            bias.data_ptr() if bias is not None else None, M, N, K, in_act, out_act,
+        )
+
+    def group_norm(
+        self, x: Act, groups: int, *, weight=None, bias=None, scale=None, shift=None, scale_off=0, shift_off=0,
+        bstride=0, act=0, pool=0, eps=1e-5,
+    ) -> Act:
+        r"""y = act((GN(x)*w + b) * (1 + scale) + shift), optionally 2x2 average pooled."""
+        B, HW = x.B, x.H * x.W
+        nchunks = int(min(256, max(1, (HW * x.cs * 4) // 131072)))
+        partials = self.empty(B * nchunks * groups * 4)
+        S, T = self.empty(B * x.cs), self.empty(B * x.cs)
+        self.tape.add("az_groupnorm_stats_f32", partials.data_ptr(), x.ptr, B, HW, x.C, x.cs, groups, nchunks)
+        f = AzNormFinalizeArgs()
+        f.S, f.T, f.partials = S.data_ptr(), T.data_ptr(), partials.data_ptr()
+        f.weight = weight.data_ptr() if weight is not None else None
+        f.bias = bias.data_ptr() if bias is not None else None
+        f.scale = scale.data_ptr() + 4 * scale_off if scale is not None else None
+        f.shift = shift.data_ptr() + 4 * shift_off if shift is not None else None
+        f.scale_bstride = bstride
+        f.B, f.C, f.cs, f.groups, f.nchunks, f.eps = B, x.C, x.cs, groups, nchunks, eps
+        self.tape.add("az_groupnorm_finalize_f32", C.byref(f), keep=[f])
+        if pool:
+            y = self.new_act(B, x.H // 2, x.W // 2, x.C)
+        else:
+            y = self.new_act(B, x.H, x.W, x.C)
+        self.tape.add("az_affine_act_f32", y.ptr, x.ptr, S.data_ptr(), T.data_ptr(), B, x.H, x.W, x.cs, act, pool)
+        return y
+
+    def row_norm(self, x: Act, kind: int, *, scale=None, shift=None, scale_off=0, shift_off=0, bstride=0, eps=1e-5):
+        y = self.new_act(x.B, x.H, x.W, x.C)
+        rows = x.B * x.H * x.W
+        self.tape.add(
+            "az_rownorm_mod_f32", y.ptr, x.ptr,
+            scale.data_ptr() + 4 * scale_off if scale is not None else None,
+            shift.data_ptr() + 4 * shift_off if shift is not None else None,
+            bstride, rows, x.H * x.W, x.C, x.cs, kind, eps,
+        )
+        return y
+
+
+def transition_args(**kw) -> AzTransitionArgs:
+    a = AzTransitionArgs()
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def inf() -> float:
+    return math.inf

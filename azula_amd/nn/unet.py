@@ -1,0 +1,325 @@
+r"""U-Net backbone executed by hand-written gfx950 kernels.
+
+Drop-in for ``azula.nn.unet`` (reference ``azula/nn/unet.py:18-259``): same constructor
+arguments, same ``state_dict`` keys (``descent.{l}.{j}...``, ``ascent.{k}.{j}...``),
+same ``forward(x, mod, cond)`` semantics for 2-D inputs.  The modules below only HOLD the
+parameters; the forward is a compiled tape of C-ABI kernels on a channel-padded NHWC layout:
+
+* every conv is the MFMA implicit GEMM (``az_conv2d_f32``); SiLU, bias, the gated residual
+  ``x + c*y`` (``unet.py:93``), the skip concat ``cat((y, x))`` (``unet.py:257``), nearest x2
+  upsampling (``unet.py:187``), ``narrow`` (``unet.py:253-255``) and zero padding are folded into
+  its gather / epilogue and never touch HBM as separate passes;
+* normalisation + AdaZero modulation ``(a + 1) * norm(x) + b`` (``unet.py:91``) is one stats pass
+  + one fused scale/shift pass;
+* the first conv reads the NHWC input written by the sampler's transition kernel and the last
+  conv writes planar NCHW directly.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Sequence
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from ..engine import Act, Builder, pad4
+from .. import _lib
+
+__all__ = ["UNet", "UNetBlock"]
+
+
+def _conv_holder(cin: int, cout: int, kernel_size, stride=1, identity_init: bool = False) -> nn.Conv2d:
+    conv = nn.Conv2d(cin, cout, kernel_size=kernel_size, stride=stride, padding=tuple(k // 2 for k in kernel_size))
+    if identity_init:  # azula/nn/layers.py:53-66: near-identity down/up-sampling convolutions
+        center = [k // 2 for k in conv.weight.shape[2:]]
+        eye = torch.zeros_like(conv.weight.data[:cin])
+        for i in range(min(cin, cout)):
+            eye[(i, i, *center)] = 1.0
+        conv.weight.data[:cin].mul_(1e-2)
+        conv.weight.data[:cin].add_(eye)
+    return conv
+
+
+class UNetBlock(nn.Module):
+    r"""Parameter holder of a modulated U-Net block (reference ``azula/nn/unet.py:18-116``).
+
+    ``ada_zero`` = Linear(D, D) -> SiLU -> Linear(D, 3C) (last weight x 1e-2), or a raw
+    ``(3, C, 1, 1)`` parameter when ``mod_features == 0``;  ``ffn`` = conv -> SiLU -> conv.
+    """
+
+    def __init__(
+        self,
+        channels: int,
+        mod_features: int = 0,
+        norm: str = "layer",
+        groups: int = 16,
+        ffn_factor: int = 1,
+        spatial: int = 2,
+        dropout: float | None = None,
+        checkpointing: bool = False,
+        kernel_size: Sequence[int] = (3, 3),
+        **kwargs,
+    ) -> None:
+        super().__init__()
+        if spatial != 2:
+            raise NotImplementedError("azula_amd.nn.UNet implements spatial=2 only")
+        if norm not in ("layer", "rms", "group"):
+            raise NotImplementedError(norm)
+        if kwargs.get("padding_mode", "zeros") != "zeros":
+            raise NotImplementedError("periodic (circular) padding is not implemented on the HIP path")
+        self.channels, self.mod_features = channels, mod_features
+        self.norm_kind, self.groups = norm, min(groups, channels)
+        self.ffn_factor = ffn_factor
+        if mod_features > 0:
+            self.ada_zero = nn.Sequential(
+                nn.Linear(mod_features, mod_features), nn.SiLU(), nn.Linear(mod_features, 3 * channels), nn.Identity()
+            )
+            self.ada_zero[-2].weight.data.mul_(1e-2)
+        else:
+            self.ada_zero = nn.Parameter(torch.randn(3, channels, 1, 1))
+            self.ada_zero.data.mul_(1e-2)
+        self.ffn = nn.Sequential(
+            _conv_holder(channels, ffn_factor * channels, kernel_size),
+            nn.SiLU(),
+            nn.Identity() if dropout is None else nn.Dropout(dropout),
+            _conv_holder(ffn_factor * channels, channels, kernel_size),
+        )
+
+    def forward(self, x: Tensor, mod: Tensor | None = None) -> Tensor:
+        raise RuntimeError("UNetBlock is executed as part of a compiled UNet plan; call UNet.forward")
+
+
+def _copy_tape(t):
+    from ..engine import Tape
+
+    c = Tape()
+    c.extend(t)
+    return c
+
+
+class UNetPlan:
+    r"""Compiled forward for one (batch, H, W, modulation-rows) signature."""
+
+    def __init__(self, net: "UNet", B: int, H: int, W: int, mod_rows: int, device: torch.device) -> None:
+        self.B, self.H, self.W = B, H, W
+        bld = self.bld = Builder(device)
+        cin = net.in_channels + net.cond_channels
+        D = net.mod_features
+        self.x_in = Act(torch.empty(B * H * W * pad4(cin), dtype=torch.float32, device=device), B, H, W, cin, pad4(cin), True)
+        self.mod = torch.empty(max(mod_rows, 1), max(D, 1), dtype=torch.float32, device=device)
+        self.mod_rows = mod_rows
+        self.out = torch.empty(B, net.out_channels, H, W, dtype=torch.float32, device=device)
+        self.versions = net._param_versions()
+        L = len(net.hid_blocks)
+        stride = net.stride
+
+        def block(blk: UNetBlock, x: Act, keep_input: bool) -> Act:
+            Cc, cs = blk.channels, pad4(blk.channels)
+            # -- modulation triple (a, b, c), each padded to cs
+            if blk.mod_features > 0:
+                rows = mod_rows
+                h = bld.empty(rows, D)
+                abc = bld.empty(rows, 3 * cs)
+                l0, l2 = blk.ada_zero[0], blk.ada_zero[2]
+                w2 = torch.zeros(3 * cs, D, dtype=torch.float32, device=device)
+                b2 = torch.zeros(3 * cs, dtype=torch.float32, device=device)
+                for n in range(3):
+                    w2[n * cs : n * cs + Cc] = l2.weight.detach()[n * Cc : (n + 1) * Cc]
+                    b2[n * cs : n * cs + Cc] = l2.bias.detach()[n * Cc : (n + 1) * Cc]
+                bld.linear_small(h, D, self.mod, D, bld.const(l0.weight), bld.const(l0.bias), rows, D, D, 0, 1)
+                bld.linear_small(abc, 3 * cs, h, D, bld.const(w2), bld.const(b2), rows, 3 * cs, D, 0, 0)
+                bstride = 3 * cs if rows > 1 else 0
+            else:
+                abc = torch.zeros(3 * cs, dtype=torch.float32, device=device)
+                for n in range(3):
+                    abc[n * cs : n * cs + Cc] = blk.ada_zero.detach()[n].flatten()
+                abc = bld.const(abc)
+                bstride = 0
+            # -- y = (a + 1) * norm(x) + b
+            if blk.norm_kind == "group":
+                n_ = bld.group_norm(x, blk.groups, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
+            else:
+                kind = 0 if blk.norm_kind == "layer" else 1
+                n_ = bld.row_norm(x, kind, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
+            c0, c3 = blk.ffn[0], blk.ffn[3]
+            h1 = bld.conv(n_, bld.pack_conv(c0.weight, c0.bias), c0.out_channels, act=1)
+            bld.free(n_)
+            y = bld.conv(
+                h1, bld.pack_conv(c3.weight, c3.bias), c3.out_channels, gate=abc, gate_off=2 * cs,
+                gate_bstride=bstride, res=x,
+            )
+            bld.free(h1)
+            if not keep_input:
+                bld.free(x)
+            return y
+
+        cur = self.x_in
+        skips: list[Act] = []
+        for i in range(L):
+            first = net.descent[i][0]
+            if i > 0:
+                skips.append(cur)  # output of level i-1 = memory entry (unet.py:226-230)
+            nxt = bld.conv(cur, bld.pack_conv(first.weight, first.bias), first.out_channels, stride=stride if i > 0 else 1)
+            cur = nxt
+            for j in range(net.hid_blocks[i]):
+                cur = block(net.descent[i][1 + j], cur, keep_input=False)
+        for k in range(L):
+            i = L - 1 - k
+            mods = net.ascent[k]
+            idx = 0
+            if i + 1 < L:
+                y = skips[i]
+                conv = mods[0]
+                merged = bld.conv(
+                    y, bld.pack_conv(conv.weight, conv.bias, cin0=y.C), conv.out_channels, src1=cur, up1=1,
+                    hin=y.H, win=y.W,
+                )
+                bld.free(cur)
+                bld.free(y)
+                cur = merged
+                idx = 1
+            for j in range(net.hid_blocks[i]):
+                cur = block(mods[idx + j], cur, keep_input=False)
+            idx += net.hid_blocks[i]
+            if i == 0:
+                conv = mods[idx]
+                bld.conv(cur, bld.pack_conv(conv.weight, conv.bias), conv.out_channels, dst_nchw=self.out)
+                bld.free(cur)
+            # i > 0: nearest upsampling is folded into the next level's merge conv (up1 = 1)
+        bld.finish()
+        self.tape = bld.tape
+
+
+class UNet(nn.Module):
+    r"""Modulated U-Net (reference ``azula/nn/unet.py:119-259``), gfx950-native forward.
+
+    Arguments are those of ``azula.nn.unet.UNet``; ``spatial`` must be 2 and ``periodic`` False.
+    """
+
+    def __init__(
+        self,
+        in_channels: int,
+        out_channels: int,
+        cond_channels: int = 0,
+        hid_channels: Sequence[int] = (64, 128, 256),
+        hid_blocks: Sequence[int] = (3, 3, 3),
+        kernel_size: int | Sequence[int] = 3,
+        stride: int | Sequence[int] = 2,
+        spatial: int = 2,
+        periodic: bool = False,
+        identity_init: bool = False,
+        **kwargs,
+    ) -> None:
+        super().__init__()
+        assert len(hid_blocks) == len(hid_channels)
+        if spatial != 2:
+            raise NotImplementedError("azula_amd.nn.UNet implements spatial=2 only")
+        if periodic:
+            raise NotImplementedError("periodic padding is not implemented on the HIP path")
+        if isinstance(kernel_size, int):
+            kernel_size = [kernel_size] * spatial
+        if isinstance(stride, int):
+            stride = [stride] * spatial
+        if len(set(kernel_size)) != 1 or len(set(stride)) != 1 or kernel_size[0] % 2 == 0:
+            raise NotImplementedError("square odd kernels and isotropic strides only")
+        if stride[0] != 2:
+            raise NotImplementedError("stride 2 only (nearest x2 upsampling is folded into the merge conv)")
+        self.in_channels, self.out_channels, self.cond_channels = in_channels, out_channels, cond_channels
+        self.hid_channels, self.hid_blocks = tuple(hid_channels), tuple(hid_blocks)
+        self.stride = stride[0]
+        self.mod_features = kwargs.get("mod_features", 0)
+        ks = tuple(kernel_size)
+
+        self.descent, self.ascent = nn.ModuleList(), nn.ModuleList()
+        for i, num_blocks in enumerate(hid_blocks):
+            do, up = nn.ModuleList(), nn.ModuleList()
+            for _ in range(num_blocks):
+                do.append(UNetBlock(hid_channels[i], kernel_size=ks, spatial=spatial, **kwargs))
+                up.append(UNetBlock(hid_channels[i], kernel_size=ks, spatial=spatial, **kwargs))
+            if i > 0:
+                do.insert(0, _conv_holder(hid_channels[i - 1], hid_channels[i], ks, stride=self.stride, identity_init=identity_init))
+                up.append(nn.Upsample(scale_factor=tuple(float(s) for s in stride), mode="nearest"))
+            else:
+                do.insert(0, _conv_holder(in_channels + cond_channels, hid_channels[i], ks))
+                up.append(_conv_holder(hid_channels[i], out_channels, ks))
+            if i + 1 < len(hid_blocks):
+                up.insert(0, _conv_holder(hid_channels[i] + hid_channels[i + 1], hid_channels[i], ks, identity_init=identity_init))
+            self.descent.append(do)
+            self.ascent.insert(0, up)
+        self._plans: dict = {}
+
+    # -- plan management -----------------------------------------------------------------------
+    def _param_versions(self) -> tuple:
+        return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+
+    def plan(self, B: int, H: int, W: int, mod_rows: int, device: torch.device) -> UNetPlan:
+        key = (B, H, W, mod_rows, str(device))
+        p = self._plans.get(key)
+        if p is None or p.versions != self._param_versions():
+            p = UNetPlan(self, B, H, W, mod_rows, device)
+            self._plans[key] = p
+        return p
+
+    def _check_device(self, x: Tensor) -> None:
+        if not x.is_cuda:
+            raise RuntimeError(
+                "azula_amd.nn.UNet executes only on an AMD GPU (gfx950 HIP kernels); there is no CPU fallback. "
+                "Move the module and its inputs to 'cuda'."
+            )
+        p = next(self.parameters())
+        if p.device != x.device or p.dtype != torch.float32 or x.dtype != torch.float32:
+            raise RuntimeError("azula_amd.nn.UNet needs fp32 parameters and inputs on the same GPU")
+
+    # -- fused sampling (see azula_amd.sample.BackboneProgram) --------------------------------------
+    def _program(self, x: Tensor, mod_rows: int):
+        from ..sample import BackboneProgram
+
+        self._check_device(x)
+        if x.ndim != 4 or self.cond_channels:
+            return None, None
+        B, _, H, W = x.shape
+        p = self.plan(B, H, W, mod_rows, x.device)
+        prog = BackboneProgram(
+            tape=_copy_tape(p.tape), x_in=p.x_in.buf, x_in_cs=p.x_in.cs, out=p.out, f_channels=self.out_channels,
+            f_nhwc=False,
+        )
+        prog.tape.keep.append(p)
+        return prog, p.mod
+
+    def _az_compile_modulated(self, x: Tensor, mod_rows: int = 1):
+        r"""(program, mod buffer): the caller's tape must fill the (mod_rows, D) buffer first."""
+        if self.mod_features == 0:
+            return None
+        return self._program(x, mod_rows)
+
+    def _az_compile(self, x: Tensor, kwargs: dict, cur_coef: Tensor):
+        r"""Bare UNet as a KarrasDenoiser backbone: only meaningful without modulation (the
+        second positional argument, c_time, is then ignored exactly as in the reference)."""
+        if self.mod_features > 0 or kwargs:
+            return None
+        return self._program(x, 0)[0]
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, mod: Tensor | None = None, cond: Tensor | None = None) -> Tensor:
+        r"""x: (B, C_i, H, W); mod: (D) or (B, D); cond: (B, C_c, H, W) -> (B, C_o, H, W)."""
+        self._check_device(x)
+        if cond is not None:
+            x = torch.cat((x, cond), dim=1)
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        assert Cin == self.in_channels + self.cond_channels
+        if self.mod_features > 0:
+            assert mod is not None, "this UNet is modulated: pass mod"
+            mod = mod.to(torch.float32)
+            rows = 1 if mod.ndim == 1 else mod.shape[0]
+            assert rows in (1, B)
+        else:
+            rows = 0
+        p = self.plan(B, H, W, rows, x.device)
+        s = _lib.stream_ptr()
+        _lib.call("az_nchw_to_nhwc_f32", p.x_in.ptr, x.data_ptr(), None, B, Cin, H * W, p.x_in.cs, s)
+        if rows:
+            p.mod.copy_(mod.reshape(rows, -1))
+        p.tape.run(s)
+        return p.out.clone()

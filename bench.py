@@ -1,0 +1,251 @@
+r"""Headline benchmark: images/s of DDIMSampler(steps=64) on the ADM-shaped 256x256 UNet
+(BASELINE.json configs[1]), one process per GPU, batch sharded (weak scaling, 4 images/GPU).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" of this contract is one pass of the hot path over one batch: a full 64-step DDIM
+sampling of the per-GPU batch (64 hipGraph replays), followed for N > 1 by the RCCL all-gather
+of x0.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 MFMA == fp32 VALU peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0  # HBM3E spec (6.3 TB/s measured achievable)
+
+CONFIGS = {
+    # BASELINE.json configs[1]: azula.nn.unet ADM-shaped UNet, 3x256x256, DDIM-64, batch 4 per GPU
+    "c2": dict(
+        kind="unet", batch=4, shape=(3, 256, 256), steps=64,
+        net=dict(in_channels=3, out_channels=3, hid_channels=(256, 256, 512, 512, 1024, 1024),
+                 hid_blocks=(2, 2, 2, 2, 2, 2), norm="group", groups=32, mod_features=1024),
+        name="azula.nn.unet ADM-shaped UNet 3x256x256 (320.5M params), KarrasDenoiser+VPSchedule, DDIMSampler(steps=64, eta=0)",
+    ),
+    # small variant for quick functional checks of the harness
+    "tiny": dict(
+        kind="unet", batch=2, shape=(3, 64, 64), steps=8,
+        net=dict(in_channels=3, out_channels=3, hid_channels=(32, 64), hid_blocks=(1, 1), norm="group", groups=8,
+                 mod_features=64),
+        name="tiny UNet 3x64x64 (harness check only)",
+    ),
+}
+
+
+def build_denoiser(cfg, device):
+    from azula_amd.denoise import KarrasDenoiser
+    from azula_amd.nn import TimeModulated, UNet
+    from azula_amd.noise import VPSchedule
+
+    torch.manual_seed(0)  # weights = module default init under seed 0
+    net = UNet(**cfg["net"])
+    wrapped = TimeModulated(net, cfg["net"]["mod_features"], name="unet")
+    return KarrasDenoiser(wrapped, VPSchedule()).to(device).eval()
+
+
+def conv_roofline(sampler, device):
+    r"""Per-launch HIP-event timing of the dominant kernel (conv_igemm, fp32 MFMA) over one
+    backbone forward run eagerly on the launch stream; achieved = sum(flops) / sum(time)."""
+    loop = next(iter(sampler._fused_cache.values()))
+    tape = loop.tape
+    stream = torch.cuda.current_stream(device)
+    sptr = stream.cuda_stream
+    recs = []
+    loop.counter.zero_()
+    for rep in range(2):  # first repetition warms caches / clocks
+        recs = []
+        loop.counter.zero_()
+        for fn, args, name in tape.ops:
+            if name == "az_conv2d_f32":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                rc = fn(*args, sptr)
+                e1.record(stream)
+                desc = args[0]._obj
+                recs.append((e0, e1, desc._flops, desc.splitk))
+            else:
+                rc = fn(*args, sptr)
+            assert rc == 0, (name, rc)
+        torch.cuda.synchronize(device)
+    flops = sum(r[2] for r in recs)
+    ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+    return dict(flops=flops, ms=ms, launches=len(recs), splitk_launches=sum(1 for r in recs if r[3] > 1))
+
+
+def transition_roofline(device, n=1 << 26):
+    r"""K1 at a size that defeats the 256 MiB Infinity Cache (64 Mi elements = 256 MiB per tensor):
+    DDIM eta=0 form, 12 B/element algorithmic (read x_t, read F, write x_s)."""
+    import ctypes as C
+    from azula_amd import _lib
+
+    x = torch.randn(n, device=device)
+    F = torch.randn(n, device=device)
+    out = torch.empty(n, device=device)
+    row = torch.zeros(16, device=device)
+    row[1], row[2], row[4], row[5], row[6] = 0.4, 0.6, 0.5, 0.7, 0.9
+    row[9], row[10] = -float("inf"), float("inf")
+    a = _lib.AzTransitionArgs(x_t=x.data_ptr(), F=F.data_ptr(), x_s=out.data_ptr(), batch=1, channels=1, inner=n,
+                              f_channels=1, coef=row.data_ptr())
+    stream = torch.cuda.current_stream(device)
+    for _ in range(3):
+        _lib.call("az_transition_f32", C.byref(a), stream.cuda_stream)
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        _lib.call("az_transition_f32", C.byref(a), stream.cuda_stream)
+    e1.record(stream)
+    torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / reps
+    gbs = 12.0 * n / (ms * 1e-3) / 1e9
+    return dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
+                traffic=None, elements=n, bytes_per_element=12, avg_us=round(ms * 1e3, 2),
+                kernel="transition_flat_kernel (DDIM eta=0)")
+
+
+def cpu_baseline(denoiser, cfg, budget_s=25.0):
+    r"""The oracle (CPU restatement of azula's op sequence, bit-checked against the reference in the
+    build container) timed on this host: DDIM steps of the same network at batch 1."""
+    from oracle import nets, sampling
+
+    sd = {k: v.detach().cpu() for k, v in denoiser.backbone.state_dict().items()}
+    ncfg = dict(cfg["net"])
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    mean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, ncfg, a, c), x, t)  # noqa: E731
+    torch.manual_seed(1)
+    x = torch.randn(1, *cfg["shape"])
+    pairs = sampling.time_pairs(steps=cfg["steps"])
+    a_t, s_t = sampling.vp_schedule(pairs[0, 0])
+    a_s, s_s = sampling.vp_schedule(pairs[0, 1])
+
+    def one_step(x):
+        m = mean(x, pairs[0, 0])
+        return sampling.transition(x, m, torch.zeros_like(x), a_t, s_t, a_s, s_s, 0.0)
+
+    t0 = time.perf_counter()
+    one_step(x)  # warm-up
+    warm = time.perf_counter() - t0
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one_step(x)
+        n += 1
+        el = time.perf_counter() - t0
+        if n >= 2 and el + warm > budget_s or n >= 8:
+            break
+    s_per_step = el / n
+    return dict(
+        value=round(1.0 / (cfg["steps"] * s_per_step), 6), unit="images/s", cores=threads, kind="port",
+        sample=f"{n} DDIM steps of the same UNet at batch 1 ({s_per_step:.2f} s/step, 1 warm-up), extrapolated x{cfg['steps']} steps",
+    )
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+    torch.set_grad_enabled(False)
+
+    from azula_amd.sample import DDIMSampler
+
+    cfg = CONFIGS[args.config]
+    den = build_denoiser(cfg, device)
+    sampler = DDIMSampler(den, steps=cfg["steps"], silent=True)
+    B = cfg["batch"]
+    torch.manual_seed(1 + rank)
+    x1 = sampler.init((B, *cfg["shape"]), device=device)  # resident in HBM before timing
+    gathered = torch.empty(world * B, *cfg["shape"], device=device) if world > 1 else None
+
+    def one_pass():
+        x0 = sampler(x1)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, x0)  # the only collective: final x0
+        return x0
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        one_pass()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x0 = one_pass()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    assert torch.isfinite(x0).all()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        images_per_s = world * B * args.steps / elapsed
+        out = {
+            "metric": "images/sec (whole node), DDIM-64 256x256 UNet",
+            "value": round(images_per_s, 4),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "ms_per_denoise_step": round(ms_per_step / cfg["steps"], 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (random-init weights under seed 0, x1 ~ sampler.init under seed 1)",
+            "config": {"workload": cfg["name"], "per_gpu_batch": B, "global_batch": world * B,
+                       "denoise_steps": cfg["steps"], "parallelism": f"batch-sharded x{world}, all-gather of x0"},
+        }
+        conv = conv_roofline(sampler, device)
+        tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": None,
+            "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32), all launches of one backbone forward",
+            "launches": conv["launches"], "avg_us": round(conv["ms"] * 1e3 / conv["launches"], 2),
+            "flops_per_forward": conv["flops"], "forward_conv_ms": round(conv["ms"], 3),
+        }
+        out["roofline_transition"] = transition_roofline(device)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(den, cfg)
+            out["speedup_vs_cpu"] = round(images_per_s / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,228 @@
+/*
+ * azula_amd -- C ABI of the MI355X (gfx950) sampling hot path.
+ *
+ * The reference (probabilists/azula, /root/reference) is pure Python and has NO FFI: its
+ * "operator boundary" is the duck-typed protocol Schedule / Denoiser / Sampler
+ * (azula/noise.py:49-63, azula/denoise.py:97-114, azula/sample.py:54-161).  This header is
+ * the boundary a maintainer would bind (ctypes stub in INTEGRATION.md) to replace the ATen
+ * op sequences that protocol dispatches per sampling step.  Each entry point cites the
+ * reference lines whose arithmetic it replaces.
+ *
+ * Contract of every function below:
+ *   - plain C, raw DEVICE pointers + sizes + POD structs + a hipStream_t (passed as void*);
+ *   - returns 0 on success, a negative AZ_E_* argument error, or a positive hipError_t;
+ *   - never allocates, never synchronises, never throws, keeps no mutable global state,
+ *     is re-entrant and hipGraph-capturable (workspace is supplied by the caller);
+ *   - all tensors are fp32.  "NHWC" tensors have a channel stride that is a multiple of 4
+ *     floats (zero-filled pad channels), so every access is a 16-byte vector.
+ */
+#ifndef AZULA_AMD_H
+#define AZULA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZ_VERSION 1
+
+enum {
+  AZ_OK = 0,
+  AZ_E_NULL = -1,      /* required pointer is NULL            */
+  AZ_E_SHAPE = -2,     /* inconsistent / unsupported shape    */
+  AZ_E_ALIGN = -3,     /* pointer or stride not 16-B aligned  */
+  AZ_E_UNSUPPORTED = -4
+};
+
+typedef void* az_stream_t; /* hipStream_t */
+
+int az_version(void);
+const char* az_error_string(int code);
+
+/* ------------------------------------------------------------------ per-step scalars
+ * One row per sampling step, computed on the HOST with torch-CPU 0-d ops in the
+ * reference's op order (azula/noise.py:125-129, azula/denoise.py:309-312,
+ * azula/plugins/adm/__init__.py:109-114, azula/sample.py:249-253) and uploaded once --
+ * the analogue of the reference's single `time_pairs` H2D copy (azula/sample.py:151).   */
+typedef struct AzStepCoef {
+  float c_in;      /* backbone input scale for THIS step                                  */
+  float c_skip;    /* mean = c_skip * x_t + c_out * F                                      */
+  float c_out;
+  float c_time;    /* Karras: log(sigma_t / alpha_t)                                       */
+  float alpha_t;
+  float alpha_s;
+  float k_x;       /* sigma_s * sqrt(1 - tau) / sigma_t                                    */
+  float k_eps;     /* sigma_s * sqrt(tau)                                                  */
+  float c_in_next; /* c_in of the NEXT step (pre-scaled second output), 0 on the last step */
+  float clip_lo;   /* mean clip (ADM eval, plugins/adm/__init__.py:133-134); -inf/+inf = off */
+  float clip_hi;
+  float guidance;  /* CFG strength (azula/guidance/cfg.py:63-65)                           */
+  int32_t time_index; /* ADM: searchsorted(sigmas, sigma_t * c_in)                          */
+  int32_t step;       /* step number (informational)                                        */
+  float pad[2];
+} AzStepCoef; /* 64 bytes */
+
+/* cur[0] = table[*step_counter]; *step_counter += 1.  One thread; first node of a step
+ * graph, so that the same captured graph can be replayed for every step.               */
+int az_step_begin(AzStepCoef* cur, const AzStepCoef* table, int32_t* step_counter, int32_t n_steps,
+                  az_stream_t stream);
+
+/* ------------------------------------------------------------------ K1: fused transition
+ * Replaces, in ONE pass over the latent (12 B/element for DDIM eta=0, 16 B with eps):
+ *   azula/denoise.py:322            mean = c_skip*x_t + c_out*F   [ADM: clip, plugins/adm/__init__.py:126-134]
+ *   azula/guidance/cfg.py:63-65     mean = mean_p + g*(mean_p - mean_n)        (if F_neg != NULL)
+ *   azula/sample.py:257-259         x_s = alpha_s*mean + k_x*(x_t - alpha_t*mean) + k_eps*eps
+ *   azula/denoise.py:317 (next step) xin = c_in_next * x_s                      (if xin_next != NULL)
+ * Arithmetic is done with separately rounded mul/add in the reference's association order,
+ * so the result is bit-identical to the torch-CPU op sequence for the same inputs.
+ *
+ * Flat form: x_t, F, F_neg, eps, x_s, xin_next all have n elements.
+ * F may have `f_channels` >= channels per sample (ADM learn_var: 6 of which 3 are used):
+ *   F element (b, c, i) is at F[(b*f_channels + c)*inner + i], x at (b*channels + c)*inner + i. */
+typedef struct AzTransitionArgs {
+  const float* x_t;
+  const float* F;      /* backbone output (positive branch)            */
+  const float* F_neg;  /* backbone output (negative CFG branch) or NULL */
+  const float* eps;    /* noise or NULL (treated as 0: DDIM eta = 0)    */
+  float* x_s;          /* may alias x_t                                 */
+  float* xin_next;     /* optional: c_in_next * x_s, same layout as x_s unless nhwc_pad > 0 */
+  float* mean_out;     /* optional: posterior mean (for Denoiser.forward), same layout as x_s */
+  int64_t batch, channels, inner; /* x is (batch, channels, inner)      */
+  int64_t f_channels;  /* channels of F per sample (>= channels)        */
+  int32_t f_nhwc;      /* 1: F is NHWC with channel stride f_channels (backbone-native layout) */
+  int32_t nhwc_pad;    /* >0: xin_next is written NHWC with this channel stride (zero pad)    */
+  const AzStepCoef* coef; /* DEVICE pointer                              */
+} AzTransitionArgs;
+int az_transition_f32(const AzTransitionArgs* args, az_stream_t stream);
+
+/* y = s * x with s read from device memory (azula/denoise.py:317 c_in * x_t, generic backbones). */
+int az_scale_f32(float* y, const float* x, const float* s_dev, int64_t n, az_stream_t stream);
+
+/* y[r, i] = a[r*a_stride] * x[r, i] + b[r*a_stride] * z[r, i]  with a, b in device memory
+ * (a_stride = 0: one scalar pair for all rows; 1: one pair per row = per-sample times t of
+ * shape (B,), azula/denoise.py:306-307).  Separately rounded mul/mul/add as
+ * azula/denoise.py:322  mean = c_skip * x_t + c_out * output.                               */
+int az_axpby_f32(float* y, const float* a_dev, const float* x, const float* b_dev, const float* z, int64_t rows,
+                 int64_t inner, int32_t a_stride, az_stream_t stream);
+
+/* ------------------------------------------------------------------ layout
+ * NCHW (B,C,H,W) -> NHWC with channel stride cs (>= C, multiple of 4), scaled by *scale_dev
+ * (NULL = 1).  Pad channels are written as 0.  And back.                                  */
+int az_nchw_to_nhwc_f32(float* dst, const float* src, const float* scale_dev, int64_t B, int64_t C, int64_t HW,
+                        int64_t cs, az_stream_t stream);
+int az_nhwc_to_nchw_f32(float* dst, const float* src, int64_t B, int64_t C, int64_t HW, int64_t cs,
+                        az_stream_t stream);
+
+/* ------------------------------------------------------------------ K5 (small M): linear + activation
+ * y[m, n] = out_act( sum_k in_act(x[m, k]) * W[n, k] + bias[n] ),  M small (modulation / time MLPs:
+ * azula/nn/unet.py:65-70, azula/nn/dit.py:58-63, plugins/adm/_src/unet.py:196-202,460-464).
+ * act: 0 none, 1 SiLU.  K must be a multiple of 4 or K == 1.  ldy = row stride of y.        */
+int az_linear_small_f32(float* y, int64_t ldy, const float* x, int64_t ldx, const float* W, const float* bias,
+                        int64_t M, int64_t N, int64_t K, int32_t in_act, int32_t out_act, az_stream_t stream);
+
+/* dst[r, :] = table[idx[r], :]  (label_emb / per-step embedding rows).  idx is int64 on device. */
+int az_gather_rows_f32(float* dst, const float* table, const int64_t* idx, int64_t nrows, int64_t ncols,
+                       int64_t table_rows, az_stream_t stream);
+/* dst[0, :] = table[coef->time_index or coef->step, :] (which: 0 = time_index, 1 = step)       */
+int az_gather_step_row_f32(float* dst, const float* table, const AzStepCoef* coef, int32_t which, int64_t ncols,
+                           int64_t table_rows, az_stream_t stream);
+/* dst[0] = coef->c_time (feeds the time-embedding MLP of a Karras-wrapped backbone)            */
+int az_coef_c_time_f32(float* dst, const AzStepCoef* coef, az_stream_t stream);
+
+/* ------------------------------------------------------------------ K2: GroupNorm (+ modulation, + SiLU)
+ * Three launches over an NHWC tensor x (B, HW, cs):
+ *  (1) az_groupnorm_stats_f32: per (b, pixel-chunk, group) partial (count, mean, M2), Chan-combinable;
+ *  (2) az_groupnorm_finalize_f32: per (b, c): S = rstd*w*(1+a), T = (bias - mean*rstd*w)*(1+a) + sh
+ *      so that  y = x*S + T  ==  (GN(x)*w + bias) * (1 + a) + sh
+ *      (azula/nn/unet.py:91 with w=1,bias=0;  plugins/adm/_src/nn.py:87 + _src/unet.py:179-183,239-243);
+ *  (3) az_affine_act_f32: y = act(x*S + T), optionally 2x2 average pooled (ADM Downsample,
+ *      _src/unet.py:133).
+ * partials: float[B * nchunks * groups * 4].                                                   */
+int az_groupnorm_stats_f32(float* partials, const float* x, int64_t B, int64_t HW, int64_t C, int64_t cs,
+                           int32_t groups, int32_t nchunks, az_stream_t stream);
+typedef struct AzNormFinalizeArgs {
+  float* S;               /* (B, cs) */
+  float* T;               /* (B, cs) */
+  const float* partials;  /* from az_groupnorm_stats_f32 */
+  const float* weight;    /* (C) or NULL (= 1) */
+  const float* bias;      /* (C) or NULL (= 0) */
+  const float* scale;     /* a: (C) if scale_bstride == 0 else (B, scale_bstride...) ; NULL = 0 */
+  const float* shift;     /* same addressing as scale */
+  int64_t scale_bstride;  /* elements between consecutive batch rows of scale/shift (0 = shared) */
+  int64_t B, C, cs;
+  int32_t groups, nchunks;
+  float eps;
+} AzNormFinalizeArgs;
+int az_groupnorm_finalize_f32(const AzNormFinalizeArgs* args, az_stream_t stream);
+/* pool: 0 none, 1 = 2x2 average pool of act(.) (needs H, W even; dst is (B, H/2*W/2, cs)).      */
+int az_affine_act_f32(float* y, const float* x, const float* S, const float* T, int64_t B, int64_t H, int64_t W,
+                      int64_t cs, int32_t act, int32_t pool, az_stream_t stream);
+
+/* Row norms over the channel axis of an NHWC / token tensor (rows, cs), C real channels:
+ *   kind 0: azula layer_norm, UNBIASED variance, no affine (azula/nn/layers.py:152-155);
+ *   kind 1: RMS norm (azula/nn/layers.py:193-195, torch.nn.RMSNorm in azula/nn/dit.py:52-55);
+ * followed by y = n * (1 + a[b, c]) + sh[b, c]  (azula/nn/unet.py:91, azula/nn/dit.py:107).
+ * rows_per_batch maps a row to its batch index for the modulation lookup.                      */
+int az_rownorm_mod_f32(float* y, const float* x, const float* scale, const float* shift, int64_t scale_bstride,
+                       int64_t rows, int64_t rows_per_batch, int64_t C, int64_t cs, int32_t kind, float eps,
+                       az_stream_t stream);
+
+/* ------------------------------------------------------------------ K3/K5: implicit-GEMM convolution
+ * out[b, oh, ow, co] = epilogue( bias[co] + sum_{ky,kx,ci} in[b, oh*s+ky-p, ow*s+kx-p, ci] * W[co, ci, ky, kx] )
+ * on gfx950 fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain).  Replaces
+ * F.conv2d 3x3 / 1x1 (azula/nn/unet.py:79-83,175-200; plugins/adm/_src/unet.py:182,207,213,215,471,602),
+ * nn.Linear on token tensors (ksize = 1: azula/nn/dit.py:88-93,169-170; azula/nn/attention.py:45-46)
+ * and Conv1d k=1 (plugins/adm/_src/unet.py:277,285).
+ * The input is the channel concatenation [src0 (c0) | src1 (c1)] (skip concat: azula/nn/unet.py:257,
+ * plugins/adm/_src/unet.py:631); either source may be read through nearest x2 upsampling
+ * (azula/nn/unet.py:187, plugins/adm/_src/unet.py:104-106) without materialising it.
+ * Weights are pre-packed once as [ky*ks+kx][cout_s][cin_s] (az_pack_conv_weight_f32).
+ * Epilogue: v = acc + bias; v = act(v); if (gate) v = gate[b*gate_bstride + co] * v; if (res) v += res;
+ *           (azula/nn/unet.py:93 x + c*y; plugins/adm/_src/unet.py:247,296 skip + h).           */
+typedef struct AzConvArgs {
+  const float* src0; /* NHWC (B, h0, w0, c0s) */
+  const float* src1; /* NHWC (B, h1, w1, c1s) or NULL */
+  int32_t c0s, c1s;  /* channel strides (multiples of 4); input channels = c0s + c1s */
+  int32_t up0, up1;  /* 1: read source through nearest x2 upsampling */
+  int32_t h0, w0, h1, w1; /* stored spatial dims of each source */
+  int32_t batch, hin, win; /* logical input dims (after upsampling / narrowing) */
+  const float* weight;     /* packed [ks*ks][cout_s][cin_s], cin_s = c0s + c1s */
+  const float* bias;       /* (cout_s) or NULL */
+  int32_t cout_s;          /* output channel stride (multiple of 4) */
+  int32_t ksize, stride, pad;
+  int32_t hout, wout;
+  int32_t act;             /* 0 none, 1 SiLU */
+  const float* gate;       /* optional (…, cout_s) */
+  int64_t gate_bstride;    /* 0 = shared across the batch */
+  const float* res;        /* optional residual, NHWC (B, hres, wres, cout_s) */
+  int32_t res_up;          /* 1: residual is read through nearest x2 upsampling (ADM up block) */
+  int32_t hres, wres;
+  float* dst;              /* NHWC (B, hout, wout, cout_s), or NCHW (B, dst_c, hout, wout) */
+  int32_t dst_nchw;        /* 1: write NCHW with dst_c real channels */
+  int32_t dst_c;
+  int32_t splitk;          /* >= 1; > 1 needs workspace of splitk * B*hout*wout * cout_s floats */
+  float* workspace;
+} AzConvArgs;
+int az_conv2d_f32(const AzConvArgs* args, az_stream_t stream);
+/* Suggested split-K factor for a conv shape on this device (pure function of the shape).     */
+int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_t ksize);
+/* torch layout (cout, cin, ks, ks) -> packed [ks*ks][cout_s][cin_s] with zero padding; the
+ * input channels [0, cin0) map to packed [0, cin0) and [cin0, cin) to [c0s, c0s + cin - cin0)
+ * (two-source concat with padded strides).  Runs on the device.                               */
+int az_pack_conv_weight_f32(float* dst, const float* src, int32_t cout, int32_t cin, int32_t ks, int32_t cout_s,
+                            int32_t cin0, int32_t c0s, int32_t cin_s, az_stream_t stream);
+
+/* ------------------------------------------------------------------ hipGraph helpers (host side)
+ * Capture everything enqueued on `stream` between begin/end into an executable graph.         */
+typedef struct AzGraph AzGraph;
+int az_graph_begin(az_stream_t stream);
+int az_graph_end(az_stream_t stream, AzGraph** out);
+int az_graph_launch(AzGraph* g, az_stream_t stream);
+int az_graph_destroy(AzGraph* g);
+int az_graph_num_nodes(AzGraph* g, int64_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZULA_AMD_H */

@@ -1,0 +1,357 @@
+r"""Oracle: backbone forwards as pure functions over azula ``state_dict`` s (torch CPU, fp32).
+
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.
+
+Each network is restated as a function ``f(sd, cfg, x, ...)`` that walks the reference's
+``state_dict`` keys and calls the same ATen ops the reference
+modules dispatch, in the same order.  ``tap`` (optional dict) collects per-block outputs for
+the per-layer fixtures (G5).
+"""
+
+from __future__ import annotations
+
+import math
+import torch
+import torch.nn.functional as F
+
+from torch import Tensor
+
+
+# --------------------------------------------------------------------------- shared layers
+def _linear(sd, key: str, x: Tensor) -> Tensor:
+    return F.linear(x, sd[key + ".weight"], sd.get(key + ".bias"))
+
+
+def _conv(sd, key: str, x: Tensor, stride: int = 1, padding: int = 1) -> Tensor:
+    return F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=stride, padding=padding)
+
+
+def layer_norm_unbiased(x: Tensor, dim: int, eps: float = 1e-5) -> Tensor:
+    r"""azula/nn/layers.py:152-155 (``var_mean`` default = unbiased, no affine)."""
+    v, m = torch.var_mean(x, dim=dim, keepdim=True)
+    return (x - m) * torch.rsqrt(v + eps)
+
+
+def rms_norm(x: Tensor, dim: int = -1, eps: float = 1e-5) -> Tensor:
+    r"""azula/nn/layers.py:193-195."""
+    return x * torch.rsqrt(torch.mean(torch.square(x), dim=dim, keepdim=True) + eps)
+
+
+def sine_encoding(x: Tensor, features: int, omega: float = 1e4) -> Tensor:
+    r"""azula/nn/layers.py:286-299 (sin block then cos block)."""
+    x = x.unsqueeze(dim=-1)
+    freqs = torch.linspace(0, 1, features // 2, dtype=x.dtype)
+    freqs = torch.exp(math.log(1 / omega) * freqs)
+    return torch.cat((torch.sin(x * freqs), torch.cos(x * freqs)), dim=-1)
+
+
+def _ada_zero(sd, key: str, mod: Tensor | None, channels: int, trailing: tuple[int, ...]):
+    r"""(a, b, c) modulation triple -- azula/nn/unet.py:63-75,86-89, azula/nn/dit.py:57-68,102-105."""
+    if key in sd:  # mod_features == 0: raw (3, C, 1, 1) / (3, C) parameter
+        return sd[key].unbind(0)
+    h = _linear(sd, key + ".0", mod)
+    h = F.silu(h)
+    h = _linear(sd, key + ".2", h)  # (..., 3C) laid out (n C)
+    h = h.unflatten(-1, (3, channels)).movedim(-2, 0)  # n ... C
+    return tuple(t.reshape(*t.shape[:-1], *trailing) for t in h.unbind(0))
+
+
+# --------------------------------------------------------------------------- azula.nn.unet
+def unet_block(sd, key: str, x: Tensor, mod, norm: str, groups: int) -> Tensor:
+    r"""UNetBlock._forward -- azula/nn/unet.py:85-95."""
+    C = x.shape[1]
+    a, b, c = _ada_zero(sd, key + ".ada_zero", mod, C, (C, 1, 1))
+    if norm == "group":
+        n = F.group_norm(x, min(groups, C), eps=1e-5)  # affine=False, unet.py:54-60
+    elif norm == "layer":
+        n = layer_norm_unbiased(x, dim=-3)
+    elif norm == "rms":
+        n = rms_norm(x, dim=-3)
+    else:
+        raise NotImplementedError(norm)
+    y = (a + 1) * n + b
+    y = _conv(sd, key + ".ffn.0", y)
+    y = F.silu(y)
+    y = _conv(sd, key + ".ffn.3", y)
+    return x + c * y
+
+
+def unet_forward(sd, cfg: dict, x: Tensor, mod: Tensor | None = None, tap: dict | None = None):
+    r"""UNet.forward -- azula/nn/unet.py:205-259 (wiring: :165-203).
+
+    cfg keys: hid_channels, hid_blocks, norm ("group" | "layer" | "rms"), groups.
+    """
+    hid_blocks = list(cfg["hid_blocks"])
+    norm, groups = cfg.get("norm", "layer"), cfg.get("groups", 16)
+    L = len(hid_blocks)
+    memory = []
+    for i in range(L):
+        memory.append(x if memory else None)
+        x = _conv(sd, f"descent.{i}.0", x, stride=2 if i > 0 else 1)
+        for j in range(hid_blocks[i]):
+            x = unet_block(sd, f"descent.{i}.{1 + j}", x, mod, norm, groups)
+        if tap is not None:
+            tap[f"descent.{i}"] = x
+    for k in range(L):
+        i = L - 1 - k  # ascent[0] is the deepest level
+        idx = 0
+        if i + 1 < L:
+            x = _conv(sd, f"ascent.{k}.0", x)
+            idx = 1
+        for j in range(hid_blocks[i]):
+            x = unet_block(sd, f"ascent.{k}.{idx + j}", x, mod, norm, groups)
+        idx += hid_blocks[i]
+        if i > 0:
+            x = F.interpolate(x, scale_factor=(2.0, 2.0), mode="nearest")
+        else:
+            x = _conv(sd, f"ascent.{k}.{idx}", x)
+        if tap is not None:
+            tap[f"ascent.{k}"] = x
+        y = memory.pop()
+        if y is None:
+            continue
+        for d in range(2, x.ndim):
+            if x.shape[d] > y.shape[d]:
+                x = torch.narrow(x, d, 0, y.shape[d])
+        x = torch.cat((y, x), dim=1)
+    return x
+
+
+def time_wrapped_unet(sd, cfg: dict, x: Tensor, c_time: Tensor, **_) -> Tensor:
+    r"""The tutorial's time-embedding wrapper (docs/tutorials/mnist.ipynb cell 8, no label):
+    ``mod = Linear(1, D) -> SiLU -> Linear(D, D)`` on ``c_time[..., None]`` then ``unet(x, mod)``.
+    Keys: ``time_embedding.{0,2}``, ``unet.*``."""
+    mod = _linear(sd, "time_embedding.0", c_time[..., None])
+    mod = _linear(sd, "time_embedding.2", F.silu(mod))
+    sub = {k[len("unet."):]: v for k, v in sd.items() if k.startswith("unet.")}
+    return unet_forward(sub, cfg, x, mod)
+
+
+# --------------------------------------------------------------------------- azula.nn.dit / vit
+def msa_forward(sd, key: str, x: Tensor, heads: int, qk_norm: bool = True) -> Tensor:
+    r"""MultiheadSelfAttention.forward without RoPE -- azula/nn/attention.py:89-108."""
+    qkv = _linear(sd, key + ".qkv_proj", x)  # (..., L, (n H C))
+    *lead, L, _ = qkv.shape
+    qkv = qkv.reshape(*lead, L, 3, heads, -1)
+    q, k, v = (qkv[..., n, :, :].transpose(-2, -3) for n in range(3))  # ... H L C
+    if qk_norm:
+        C = q.shape[-1]
+        q = F.rms_norm(q, (C,), eps=1e-5)  # torch.nn.RMSNorm path, attention.py:48-56
+        k = F.rms_norm(k, (C,), eps=1e-5)
+    y = F.scaled_dot_product_attention(query=q, key=k, value=v)
+    y = y.transpose(-2, -3).flatten(-2)  # ... L (H C)
+    return F.linear(y, sd[key + ".y_proj.weight"])
+
+
+def dit_block(sd, key: str, x: Tensor, mod, heads: int) -> Tensor:
+    r"""DiTBlock._forward (silu FFN) -- azula/nn/dit.py:95-112."""
+    C = x.shape[-1]
+    a, b, c = _ada_zero(sd, key + ".ada_zero", mod, C, (1, C))
+    y = (a + 1) * F.rms_norm(x, (C,), eps=1e-5) + b
+    y = y + msa_forward(sd, key + ".msa", y, heads)
+    y = _linear(sd, key + ".ffn.0", y)
+    y = F.silu(y)
+    y = _linear(sd, key + ".ffn.3", y)
+    return x + c * y
+
+
+def dit_forward(sd, cfg: dict, x: Tensor, mod=None, pos: Tensor | None = None, tap=None):
+    r"""DiT.forward -- azula/nn/dit.py:184-218.  cfg: hid_channels, hid_blocks, attention_heads."""
+    x = _linear(sd, "in_proj", x)
+    if pos is None:
+        pos = torch.arange(x.shape[-2], dtype=x.dtype)[..., None]
+    e = sine_encoding(pos, cfg["hid_channels"], omega=1e2).flatten(-2)  # ... (P C)
+    x = x + F.linear(e, sd["pos_embedding.2.weight"])
+    for i in range(cfg["hid_blocks"]):
+        x = dit_block(sd, f"blocks.{i}", x, mod, cfg["attention_heads"])
+        if tap is not None:
+            tap[f"blocks.{i}"] = x
+    return _linear(sd, "out_proj", x)
+
+
+def vit_forward(sd, cfg: dict, x: Tensor, mod=None, tap=None) -> Tensor:
+    r"""ViT.forward -- azula/nn/vit.py:76-108 (Patchify/Unpatchify channel_last,
+    azula/nn/layers.py:198-247).  cfg adds patch_size (int)."""
+    p = cfg["patch_size"]
+    B, Z, H, W = x.shape
+    # '... Z (A a) (B b) -> ... A B (Z a b)'
+    t = x.reshape(B, Z, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, H // p, W // p, Z * p * p)
+    shape = t.shape[1:-1]
+    pos = torch.cartesian_prod(*(torch.arange(s, dtype=x.dtype) for s in shape)).reshape(-1, len(shape))
+    y = dit_forward(sd, cfg, t.flatten(1, -2), mod, pos=pos, tap=tap)
+    y = y.unflatten(-2, shape)
+    Zo = y.shape[-1] // (p * p)
+    return y.reshape(B, H // p, W // p, Zo, p, p).permute(0, 3, 1, 4, 2, 5).reshape(B, Zo, H, W)
+
+
+def time_wrapped_vit(sd, cfg: dict, x: Tensor, c_time: Tensor, **_) -> Tensor:
+    r"""Same wrapper pattern as :func:`time_wrapped_unet` around a ViT (keys ``vit.*``)."""
+    mod = _linear(sd, "time_embedding.0", c_time[..., None])
+    mod = _linear(sd, "time_embedding.2", F.silu(mod))
+    sub = {k[len("vit."):]: v for k, v in sd.items() if k.startswith("vit.")}
+    return vit_forward(sub, cfg, x, mod)
+
+
+# --------------------------------------------------------------------------- ADM UNetModel
+def adm_timestep_embedding(timesteps: Tensor, dim: int, max_period: int = 10000) -> Tensor:
+    r"""cos || sin, fp32 -- azula/plugins/adm/_src/nn.py:90-108."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = timesteps[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def _gn32(sd, key: str, x: Tensor) -> Tensor:
+    return F.group_norm(x, 32, sd[key + ".weight"], sd[key + ".bias"], eps=1e-5)  # _src/nn.py:80-87
+
+
+def adm_resblock(sd, key: str, x: Tensor, emb: Tensor, up: bool, down: bool, scale_shift: bool) -> Tensor:
+    r"""ResBlock._forward -- azula/plugins/adm/_src/unet.py:227-247."""
+    h = F.silu(_gn32(sd, key + ".in_layers.0", x))
+    if up:  # :104-106 nearest x2 on both branches
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    elif down:  # :133 AvgPool2d(2, 2)
+        h = F.avg_pool2d(h, 2, 2)
+        x = F.avg_pool2d(x, 2, 2)
+    h = _conv(sd, key + ".in_layers.2", h)
+    emb_out = _linear(sd, key + ".emb_layers.1", F.silu(emb))[..., None, None]
+    if scale_shift:
+        scale, shift = torch.chunk(emb_out, 2, dim=1)
+        h = _gn32(sd, key + ".out_layers.0", h) * (1 + scale) + shift
+        h = _conv(sd, key + ".out_layers.3", F.silu(h))
+    else:
+        h = h + emb_out
+        h = _conv(sd, key + ".out_layers.3", F.silu(_gn32(sd, key + ".out_layers.0", h)))
+    if key + ".skip_connection.weight" in sd:
+        w = sd[key + ".skip_connection.weight"]
+        x = F.conv2d(x, w, sd[key + ".skip_connection.bias"], padding=w.shape[-1] // 2)
+    return x + h
+
+
+def adm_attention(sd, key: str, x: Tensor, heads: int, new_order: bool) -> Tensor:
+    r"""AttentionBlock._forward + QKVAttention(Legacy) -- _src/unet.py:289-296,330-384."""
+    b, c, *spatial = x.shape
+    x = x.reshape(b, c, -1)
+    qkv = F.conv1d(_gn32(sd, key + ".norm", x), sd[key + ".qkv.weight"], sd[key + ".qkv.bias"])
+    bs, width, length = qkv.shape
+    ch = width // (3 * heads)
+    scale = 1 / math.sqrt(math.sqrt(ch))
+    if new_order:
+        q, k, v = qkv.chunk(3, dim=1)
+        q = (q * scale).view(bs * heads, ch, length)
+        k = (k * scale).view(bs * heads, ch, length)
+        v = v.reshape(bs * heads, ch, length)
+        w = torch.einsum("bct,bcs->bts", q, k)
+    else:
+        q, k, v = qkv.reshape(bs * heads, ch * 3, length).split(ch, dim=1)
+        w = torch.einsum("bct,bcs->bts", q * scale, k * scale)
+    w = torch.softmax(w.float(), dim=-1).type(w.dtype)
+    a = torch.einsum("bts,bcs->bct", w, v).reshape(bs, -1, length)
+    h = F.conv1d(a, sd[key + ".proj_out.weight"], sd[key + ".proj_out.bias"])
+    return (x + h).reshape(b, c, *spatial)
+
+
+def adm_layout(cfg: dict):
+    r"""Block list of UNetModel.__init__ -- _src/unet.py:468-600.  Returns
+    (input_blocks, middle, output_blocks); each block is a list of
+    ("res", up, down) | ("attn", heads) | ("conv",) layer descriptors."""
+    mc, mult = cfg["num_channels"], cfg["channel_mult"]
+    nres = cfg["num_res_blocks"]
+    attn_ds = {cfg["image_size"] // r for r in cfg["attention_resolutions"]}  # plugins/adm/__init__.py:182
+    updown = cfg.get("resblock_updown", False)
+    assert updown, "conv_resample Down/Upsample variant not restated (no card uses it)"
+    hc = cfg.get("num_head_channels", -1)
+
+    def heads(ch):
+        return cfg.get("num_heads", 1) if hc == -1 else ch // hc
+
+    ch = int(mult[0] * mc)
+    inputs, chans, ds = [[("conv",)]], [ch], 1
+    for level, m in enumerate(mult):
+        for _ in range(nres):
+            ch = int(m * mc)
+            blk = [("res", False, False)]
+            if ds in attn_ds:
+                blk.append(("attn", heads(ch)))
+            inputs.append(blk)
+            chans.append(ch)
+        if level != len(mult) - 1:
+            inputs.append([("res", False, True)])
+            chans.append(ch)
+            ds *= 2
+    middle = [("res", False, False), ("attn", heads(ch)), ("res", False, False)]
+    outputs = []
+    for level, m in list(enumerate(mult))[::-1]:
+        for i in range(nres + 1):
+            chans.pop()
+            ch = int(mc * m)
+            blk = [("res", False, False)]
+            if ds in attn_ds:
+                blk.append(("attn", heads(ch)))
+            if level and i == nres:
+                blk.append(("res", True, False))
+                ds //= 2
+            outputs.append(blk)
+    return inputs, middle, outputs
+
+
+def adm_unet_forward(sd, cfg: dict, x: Tensor, timesteps: Tensor, y: Tensor | None = None, tap=None):
+    r"""UNetModel.forward -- azula/plugins/adm/_src/unet.py:605-634."""
+    inputs, middle, outputs = adm_layout(cfg)
+    ss = cfg.get("use_scale_shift_norm", False)
+    new_order = cfg.get("use_new_attention_order", False)
+    emb = adm_timestep_embedding(timesteps, cfg["num_channels"])
+    emb = _linear(sd, "time_embed.2", F.silu(_linear(sd, "time_embed.0", emb)))
+    if cfg.get("num_classes") is not None:
+        assert y is not None and y.shape == (x.shape[0],)
+        emb = emb + F.embedding(y, sd["label_emb.weight"])
+    else:
+        assert y is None
+
+    def run(prefix, blk, h):
+        for j, layer in enumerate(blk):
+            key = f"{prefix}.{j}"
+            if layer[0] == "conv":
+                h = _conv(sd, key, h)
+            elif layer[0] == "res":
+                h = adm_resblock(sd, key, h, emb, layer[1], layer[2], ss)
+            else:
+                h = adm_attention(sd, key, h, layer[1], new_order)
+        return h
+
+    hs, h = [], x
+    for i, blk in enumerate(inputs):
+        h = run(f"input_blocks.{i}", blk, h)
+        hs.append(h)
+        if tap is not None:
+            tap[f"input_blocks.{i}"] = h
+    h = run("middle_block", middle, h)
+    if tap is not None:
+        tap["middle_block"] = h
+    for i, blk in enumerate(outputs):
+        h = torch.cat([h, hs.pop()], dim=1)
+        h = run(f"output_blocks.{i}", blk, h)
+        if tap is not None:
+            tap[f"output_blocks.{i}"] = h
+    h = F.silu(_gn32(sd, "out.0", h))
+    return _conv(sd, "out.2", h)
+
+
+# --------------------------------------------------------------------------- synthetic weights
+def rerandomise_zero_tensors(sd: dict, seed: int = 123) -> int:
+    r"""Refill every all-zero weight tensor with ndim > 1 by N(0, 1/fan_in) from
+    ``torch.Generator().manual_seed(seed)``: random-init ADM has 84 such
+    tensors (``zero_module``, _src/unet.py:207,285,602) which would make parity vacuous."""
+    g = torch.Generator().manual_seed(seed)
+    n = 0
+    for k in sorted(sd):
+        v = sd[k]
+        if torch.is_floating_point(v) and v.ndim > 1 and not torch.any(v != 0):
+            fan_in = v[0].numel()
+            v.copy_(torch.randn(v.shape, generator=g) / math.sqrt(fan_in))
+            n += 1
+    return n

@@ -1,0 +1,192 @@
+r"""Oracle: noise schedule, preconditioning and DDPM/DDIM transitions (torch CPU, fp32).
+
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  Functional restatement: the
+reference's classes become plain functions over tensors so that each formula can be pinned
+on its own.
+"""
+
+from __future__ import annotations
+
+import math
+import torch
+
+from torch import Tensor
+from typing import Callable
+
+
+# --------------------------------------------------------------------------- schedule
+def vp_alpha(t: Tensor, alpha_min: float = 1e-3) -> Tensor:
+    r"""alpha_t = exp(log(alpha_min) * t^2)  -- azula/noise.py:125-126."""
+    return torch.exp(math.log(alpha_min) * t**2)
+
+
+def vp_sigma(t: Tensor, alpha_min: float = 1e-3, sigma_min: float = 1e-3) -> Tensor:
+    r"""sigma_t = sqrt(1 - alpha_t^2 + sigma_min^2)  -- azula/noise.py:128-129."""
+    return torch.sqrt(1 - vp_alpha(t, alpha_min) ** 2 + sigma_min**2)
+
+
+def vp_schedule(t: Tensor, alpha_min: float = 1e-3, sigma_min: float = 1e-3):
+    r"""(alpha_t, sigma_t)  -- azula/noise.py:122-123."""
+    return vp_alpha(t, alpha_min), vp_sigma(t, alpha_min, sigma_min)
+
+
+def timesteps(start: float = 1.0, stop: float = 0.0, steps: int = 64, dtype=None) -> Tensor:
+    r"""linspace(start, stop, steps + 1)  -- azula/sample.py:86-94."""
+    return torch.linspace(start, stop, steps + 1, dtype=dtype)
+
+
+def time_pairs(start: float = 1.0, stop: float = 0.0, steps: int = 64, dtype=None) -> Tensor:
+    r"""(steps, 2) sliding pairs (t, s)  -- azula/sample.py:151."""
+    return timesteps(start, stop, steps, dtype).unfold(0, 2, 1)
+
+
+# --------------------------------------------------------------------------- denoisers
+def _expand(a: Tensor, ndim: int) -> Tensor:
+    while a.ndim < ndim:  # azula/denoise.py:306-307
+        a = a[..., None]
+    return a
+
+
+def karras_coefficients(alpha_t: Tensor, sigma_t: Tensor):
+    r"""c_in, c_out, c_skip, c_time  -- azula/denoise.py:309-312."""
+    c_in = torch.rsqrt(alpha_t**2 + sigma_t**2)
+    c_out = sigma_t * torch.rsqrt(alpha_t**2 + sigma_t**2)
+    c_skip = alpha_t / (alpha_t**2 + sigma_t**2)
+    c_time = torch.log(sigma_t / alpha_t)
+    return c_in, c_out, c_skip, c_time
+
+
+def karras_mean(
+    backbone: Callable[..., Tensor],
+    x_t: Tensor,
+    t: Tensor,
+    schedule: Callable[[Tensor], tuple[Tensor, Tensor]] = vp_schedule,
+    backbone_dtype: torch.dtype = torch.float32,
+    **kwargs,
+) -> Tensor:
+    r"""mu = c_skip x_t + c_out F(c_in x_t, c_time)  -- azula/denoise.py:293-324."""
+    alpha_t, sigma_t = schedule(t)
+    alpha_t, sigma_t = _expand(alpha_t, x_t.ndim), _expand(sigma_t, x_t.ndim)
+    c_in, c_out, c_skip, c_time = karras_coefficients(alpha_t, sigma_t)
+    c_time = c_time.reshape_as(t)
+    out = backbone((c_in * x_t).to(backbone_dtype), c_time.to(backbone_dtype), **kwargs).to(x_t)
+    return c_skip * x_t + c_out * out
+
+
+def adm_sigmas(discrete_schedule: str = "linear", discrete_steps: int = 1000) -> Tensor:
+    r"""Discrete sigma table of the ADM plugin  -- azula/plugins/adm/__init__.py:66-84."""
+    if discrete_schedule == "linear":
+        beta = torch.linspace(
+            0.1 / discrete_steps, 20.0 / discrete_steps, discrete_steps, dtype=torch.float64
+        )
+    elif discrete_schedule == "cosine":
+        t = torch.linspace(0, 1, discrete_steps + 1, dtype=torch.float64)
+        alpha_bar = torch.cos((t + 0.008) / 1.008 * torch.pi / 2) ** 2
+        beta = torch.clip(1 - alpha_bar[1:] / alpha_bar[:-1], max=0.999)
+    else:
+        raise ValueError(discrete_schedule)
+    return torch.sqrt(1 - torch.cumprod(1 - beta, dim=0)).to(torch.float32)
+
+
+def adm_coefficients(alpha_t: Tensor, sigma_t: Tensor, sigmas: Tensor):
+    r"""c_in, c_out, c_skip, time index, c_var  -- azula/plugins/adm/__init__.py:109-114."""
+    c_in = torch.rsqrt(alpha_t**2 + sigma_t**2)
+    c_out = -sigma_t / alpha_t
+    c_skip = 1 / alpha_t
+    c_time = sigma_t * torch.rsqrt(alpha_t**2 + sigma_t**2)
+    idx = torch.searchsorted(sigmas, c_time.flatten())
+    c_var = sigma_t**2 / (alpha_t**2 + sigma_t**2)
+    return c_in, c_out, c_skip, idx, c_var
+
+
+def adm_posterior(
+    backbone: Callable[..., Tensor],
+    x_t: Tensor,
+    t: Tensor,
+    sigmas: Tensor,
+    label: Tensor | None = None,
+    learn_var: bool = True,
+    clip_mean: bool = True,
+    alpha_min: float = 1e-2,
+    sigma_min: float = 1e-2,
+):
+    r"""(mean, var) of AblatedDenoiser in eval mode  -- azula/plugins/adm/__init__.py:86-136."""
+    alpha_t, sigma_t = vp_schedule(t, alpha_min, sigma_min)
+    alpha_t, sigma_t = _expand(alpha_t, x_t.ndim), _expand(sigma_t, x_t.ndim)
+    c_in, c_out, c_skip, idx, c_var = adm_coefficients(alpha_t, sigma_t, sigmas)
+    out = backbone(c_in * x_t, idx, y=label).to(x_t)
+    if learn_var:
+        out, log_var = torch.chunk(out, 2, dim=1)
+        mean = c_skip * x_t + c_out * out
+        var = c_var * torch.exp(log_var)
+    else:
+        mean = c_skip * x_t + c_out * out
+        var = c_var
+    if clip_mean:
+        mean = torch.clip(mean, min=-1.0, max=1.0)
+    return mean, var
+
+
+def cfg_mean(mean_fn, x_t, t, positive: dict, negative: dict, guidance=1.0, **kwargs) -> Tensor:
+    r"""mu+ + g (mu+ - mu-), two sequential calls  -- azula/guidance/cfg.py:60-65."""
+    pos = mean_fn(x_t, t, **positive, **kwargs)
+    neg = mean_fn(x_t, t, **negative, **kwargs)
+    return pos + guidance * (pos - neg)
+
+
+# --------------------------------------------------------------------------- samplers
+def sampler_init(shape, alpha_T: Tensor, sigma_T: Tensor, mean=0.0, var=1.0) -> Tensor:
+    r"""x_T = alpha_T mean + sqrt(alpha_T^2 var + sigma_T^2) eps  -- azula/sample.py:121-128."""
+    mean_T, std_T = alpha_T * mean, torch.sqrt(alpha_T**2 * var + sigma_T**2)
+    mean_T, std_T = mean_T.expand(shape), std_T.expand(shape)
+    return mean_T + std_T * torch.randn_like(mean_T)
+
+
+def transition(
+    x_t: Tensor,
+    mean: Tensor,
+    eps: Tensor,
+    alpha_t: Tensor,
+    sigma_t: Tensor,
+    alpha_s: Tensor,
+    sigma_s: Tensor,
+    eta: float | None,
+) -> Tensor:
+    r"""DDIM (``eta`` float, azula/sample.py:248-261) or DDPM (``eta=None``, :204-216) update."""
+    tau = 1 - (alpha_t / alpha_s * sigma_s / sigma_t) ** 2
+    if eta is not None:
+        tau = torch.clip(eta * tau, min=0, max=1)
+    x_s = alpha_s * mean
+    x_s = x_s + sigma_s * torch.sqrt(1 - tau) / sigma_t * (x_t - alpha_t * mean)
+    x_s = x_s + sigma_s * torch.sqrt(tau) * eps
+    return x_s
+
+
+def sample(
+    mean_fn: Callable[..., Tensor],
+    x: Tensor,
+    schedule: Callable[[Tensor], tuple[Tensor, Tensor]] = vp_schedule,
+    steps: int = 64,
+    eta: float | None = 0.0,
+    start: float = 1.0,
+    stop: float = 0.0,
+    eps_list: list[Tensor] | None = None,
+    record_eps: list | None = None,
+    **kwargs,
+) -> Tensor:
+    r"""Full reverse loop  -- azula/sample.py:139-161 with step :204-216 / :248-261.
+
+    ``mean_fn(x_t, t, **kwargs)`` returns the posterior mean.  One ``randn_like`` per step is
+    drawn AFTER the denoiser call (even when tau = 0), exactly as the reference does, unless
+    ``eps_list`` supplies the noise.
+    """
+    x_t = x
+    for i, (t, s) in enumerate(time_pairs(start, stop, steps).unbind()):
+        alpha_s, sigma_s = schedule(s)
+        alpha_t, sigma_t = schedule(t)
+        mean = mean_fn(x_t, t, **kwargs)
+        eps = torch.randn_like(x_t) if eps_list is None else eps_list[i]
+        if record_eps is not None:
+            record_eps.append(eps)
+        x_t = transition(x_t, mean, eps, alpha_t, sigma_t, alpha_s, sigma_s, eta)
+    return x_t

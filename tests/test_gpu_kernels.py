@@ -1,0 +1,375 @@
+r"""Per-kernel parity: each C-ABI entry point against the oracle / a plain torch fp32 CPU
+reference of the same op, called exactly as the product calls it (ctypes -> HIP)."""
+
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import max_err
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def az():
+    from azula_amd import _lib
+
+    _lib.lib()
+    return _lib
+
+
+def dev(t):
+    return t.to("cuda").contiguous()
+
+
+def to_nhwc(x, cs=None):
+    B, Cc, H, W = x.shape
+    cs = cs or (Cc + 3) // 4 * 4
+    y = torch.zeros(B, H, W, cs, dtype=x.dtype, device=x.device)
+    y[..., :Cc] = x.permute(0, 2, 3, 1)
+    return y.contiguous()
+
+
+def from_nhwc(y, Cc):
+    return y[..., :Cc].permute(0, 3, 1, 2).contiguous()
+
+
+def coef_row(**kw):
+    from azula_amd._lib import COEF_FIELDS, COEF_WORDS
+
+    row = torch.zeros(COEF_WORDS, dtype=torch.float32)
+    row[COEF_FIELDS.index("clip_lo")] = -math.inf
+    row[COEF_FIELDS.index("clip_hi")] = math.inf
+    for k, v in kw.items():
+        if k in ("time_index", "step"):
+            row.view(torch.int32)[COEF_FIELDS.index(k)] = int(v)
+        else:
+            row[COEF_FIELDS.index(k)] = float(v)
+    return row
+
+
+def ref_transition(x, Fp, Fn, eps, k):
+    """torch-CPU op sequence of denoise.py:322 (+clip, +cfg) and sample.py:257-259."""
+    f32 = lambda v: torch.tensor(v, dtype=torch.float32)  # noqa: E731
+    mean = f32(k["c_skip"]) * x + f32(k["c_out"]) * Fp
+    mean = torch.clip(mean, min=k.get("clip_lo", -math.inf), max=k.get("clip_hi", math.inf))
+    if Fn is not None:
+        mn = f32(k["c_skip"]) * x + f32(k["c_out"]) * Fn
+        mn = torch.clip(mn, min=k.get("clip_lo", -math.inf), max=k.get("clip_hi", math.inf))
+        mean = mean + f32(k["guidance"]) * (mean - mn)
+    xs = f32(k["alpha_s"]) * mean
+    xs = xs + f32(k["k_x"]) * (x - f32(k["alpha_t"]) * mean)
+    if eps is not None:
+        xs = xs + f32(k["k_eps"]) * eps
+    return mean, xs, f32(k.get("c_in_next", 0.0)) * xs
+
+
+COEFS = dict(c_skip=0.37, c_out=-1.9, alpha_t=0.61, alpha_s=0.83, k_x=0.71, k_eps=0.29, c_in_next=1.3, guidance=2.0)
+
+
+@pytest.mark.parametrize("n", [4096, 1027, 3])
+@pytest.mark.parametrize("cfg", [False, True])
+@pytest.mark.parametrize("use_eps", [False, True])
+def test_transition_flat_bit_exact(az, n, cfg, use_eps):
+    g = torch.Generator().manual_seed(n)
+    x, Fp, Fn, eps = (torch.randn(n, generator=g) for _ in range(4))
+    k = dict(COEFS, clip_lo=-1.0, clip_hi=1.0) if cfg else dict(COEFS)
+    mean, xs, xin = ref_transition(x, Fp, Fn if cfg else None, eps if use_eps else None, k)
+    row = dev(coef_row(**k))
+    dx, dF, dFn, de = dev(x), dev(Fp), dev(Fn), dev(eps)
+    o_xs, o_xin, o_mean = (torch.empty(n, device="cuda") for _ in range(3))
+    a = az.AzTransitionArgs(
+        x_t=dx.data_ptr(), F=dF.data_ptr(), F_neg=dFn.data_ptr() if cfg else None,
+        eps=de.data_ptr() if use_eps else None, x_s=o_xs.data_ptr(), xin_next=o_xin.data_ptr(),
+        mean_out=o_mean.data_ptr(), batch=1, channels=1, inner=n, f_channels=1, coef=row.data_ptr(),
+    )
+    az.call("az_transition_f32", C.byref(a), az.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(o_mean.cpu(), mean)
+    assert torch.equal(o_xs.cpu(), xs)
+    assert torch.equal(o_xin.cpu(), xin)
+
+
+def test_transition_flat_in_place_and_golden(az, golden):
+    """Against the reference-generated G3 vectors, x_s aliasing x_t."""
+    from oracle import sampling
+
+    g = golden("g3_transition")
+    for case in g.meta["cases"]:
+        t, s = torch.tensor(case["t"]), torch.tensor(case["s"])
+        a_t, s_t = sampling.vp_schedule(t)
+        a_s, s_s = sampling.vp_schedule(s)
+        c_in, c_out, c_skip, _ = sampling.karras_coefficients(a_t, s_t)
+        tau = 1 - (a_t / a_s * s_s / s_t) ** 2
+        if case["eta"] is not None:
+            tau = torch.clip(case["eta"] * tau, min=0, max=1)
+        row = dev(coef_row(c_skip=c_skip, c_out=c_out, alpha_t=a_t, alpha_s=a_s, k_x=s_s * torch.sqrt(1 - tau) / s_t,
+                           k_eps=s_s * torch.sqrt(tau)))
+        x, Fb, eps = dev(g["x_t"]), dev(g["F"]), dev(g["eps"])
+        n = x.numel()
+        arg = az.AzTransitionArgs(x_t=x.data_ptr(), F=Fb.data_ptr(), eps=eps.data_ptr(), x_s=x.data_ptr(), batch=1,
+                                  channels=1, inner=n, f_channels=1, coef=row.data_ptr())
+        az.call("az_transition_f32", C.byref(arg), az.stream_ptr())
+        assert torch.equal(x.cpu(), g[case["tag"]]), case["tag"]
+
+
+@pytest.mark.parametrize("f_nhwc,fC", [(0, 3), (0, 6), (1, 4), (1, 8)])
+@pytest.mark.parametrize("cfg", [False, True])
+def test_transition_image_layouts(az, f_nhwc, fC, cfg):
+    B, Cc, H, W = 2, 3, 8, 12
+    g = torch.Generator().manual_seed(5)
+    x, eps = torch.randn(B, Cc, H, W, generator=g), torch.randn(B, Cc, H, W, generator=g)
+    Fp, Fn = torch.randn(B, fC, H, W, generator=g), torch.randn(B, fC, H, W, generator=g)
+    k = dict(COEFS, clip_lo=-1.0, clip_hi=1.0)
+    mean, xs, xin = ref_transition(x, Fp[:, :Cc], Fn[:, :Cc] if cfg else None, eps, k)
+    row = dev(coef_row(**k))
+    dx, de = dev(x), dev(eps)
+    dF = dev(Fp.permute(0, 2, 3, 1)) if f_nhwc else dev(Fp)
+    dFn = dev(Fn.permute(0, 2, 3, 1)) if f_nhwc else dev(Fn)
+    o_xs, o_mean = torch.empty_like(dx), torch.empty_like(dx)
+    o_xin = torch.full((B, H, W, 8), 7.0, device="cuda")
+    a = az.AzTransitionArgs(
+        x_t=dx.data_ptr(), F=dF.data_ptr(), F_neg=dFn.data_ptr() if cfg else None, eps=de.data_ptr(),
+        x_s=o_xs.data_ptr(), xin_next=o_xin.data_ptr(), mean_out=o_mean.data_ptr(), batch=B, channels=Cc,
+        inner=H * W, f_channels=fC, f_nhwc=f_nhwc, nhwc_pad=8, coef=row.data_ptr(),
+    )
+    az.call("az_transition_f32", C.byref(a), az.stream_ptr())
+    assert torch.equal(o_xs.cpu(), xs) and torch.equal(o_mean.cpu(), mean)
+    assert torch.equal(from_nhwc(o_xin, Cc).cpu(), xin)
+    assert (o_xin[..., Cc:] == 0).all()
+
+
+def test_step_begin_and_scalar_plumbing(az):
+    table = torch.stack([coef_row(c_time=0.1 * i, c_in=i, time_index=900 - i, step=i) for i in range(5)])
+    dt = dev(table)
+    cur = torch.zeros(16, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ct = torch.zeros(1, device="cuda")
+    emb = dev(torch.arange(1000 * 8, dtype=torch.float32).reshape(1000, 8))
+    row = torch.zeros(8, device="cuda")
+    for i in range(5):
+        az.call("az_step_begin", cur.data_ptr(), dt.data_ptr(), cnt.data_ptr(), 5, az.stream_ptr())
+        az.call("az_coef_c_time_f32", ct.data_ptr(), cur.data_ptr(), az.stream_ptr())
+        az.call("az_gather_step_row_f32", row.data_ptr(), emb.data_ptr(), cur.data_ptr(), 0, 8, 1000, az.stream_ptr())
+        assert torch.equal(cur.cpu(), table[i]) and cnt.item() == i + 1
+        assert ct.item() == table[i, 3].item()
+        assert torch.equal(row.cpu(), emb[900 - i].cpu())
+    idx = dev(torch.tensor([3, 999, 0]))
+    out = torch.zeros(3, 8, device="cuda")
+    az.call("az_gather_rows_f32", out.data_ptr(), emb.data_ptr(), idx.data_ptr(), 3, 8, 1000, az.stream_ptr())
+    assert torch.equal(out, emb[idx])
+
+
+def test_scale_axpby_layout(az):
+    g = torch.Generator().manual_seed(1)
+    x, z = torch.randn(3, 5, 7, generator=g), torch.randn(3, 5, 7, generator=g)
+    a, b = torch.randn(3, generator=g), torch.randn(3, generator=g)
+    dx, dz, da, db = dev(x), dev(z), dev(a), dev(b)
+    y = torch.empty_like(dx)
+    az.call("az_scale_f32", y.data_ptr(), dx.data_ptr(), da.data_ptr(), x.numel(), az.stream_ptr())
+    assert torch.equal(y.cpu(), a[0] * x)
+    az.call("az_axpby_f32", y.data_ptr(), da.data_ptr(), dx.data_ptr(), db.data_ptr(), dz.data_ptr(), 3, 35, 1, az.stream_ptr())
+    assert torch.equal(y.cpu(), a[:, None, None] * x + b[:, None, None] * z)
+    az.call("az_axpby_f32", y.data_ptr(), da.data_ptr(), dx.data_ptr(), db.data_ptr(), dz.data_ptr(), 1, 105, 0, az.stream_ptr())
+    assert torch.equal(y.cpu(), a[0] * x + b[0] * z)
+    # NCHW <-> NHWC with channel padding and scale
+    img = torch.randn(2, 5, 6, 7, generator=g)
+    di = dev(img)
+    nh = torch.full((2, 6, 7, 8), 9.0, device="cuda")
+    az.call("az_nchw_to_nhwc_f32", nh.data_ptr(), di.data_ptr(), da.data_ptr(), 2, 5, 42, 8, az.stream_ptr())
+    assert torch.equal(from_nhwc(nh, 5).cpu(), a[0] * img) and (nh[..., 5:] == 0).all()
+    back = torch.empty_like(di)
+    az.call("az_nhwc_to_nchw_f32", back.data_ptr(), nh.data_ptr(), 2, 5, 42, 8, az.stream_ptr())
+    assert torch.equal(back.cpu(), a[0] * img)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 48, 1), (1, 1024, 1024), (3, 100, 16), (5, 7, 40), (64, 96, 64)])
+@pytest.mark.parametrize("in_act,out_act", [(0, 0), (0, 1), (1, 0)])
+def test_linear_small(az, M, N, K, in_act, out_act):
+    g = torch.Generator().manual_seed(M * N + K)
+    x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    ref = F.linear(F.silu(x) if in_act else x, W, b)
+    ref = F.silu(ref) if out_act else ref
+    dx, dW, db = dev(x), dev(W), dev(b)
+    y = torch.empty(M, N, device="cuda")
+    az.call("az_linear_small_f32", y.data_ptr(), N, dx.data_ptr(), K, dW.data_ptr(), db.data_ptr(), M, N, K, in_act,
+            out_act, az.stream_ptr())
+    assert max_err(y, ref) < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize(
+    "B,Cc,H,W,groups",
+    [(2, 32, 16, 16, 8), (2, 8, 16, 16, 8), (1, 12, 9, 7, 3), (2, 256, 32, 32, 32), (1, 2048, 8, 8, 32), (3, 64, 64, 64, 32)],
+)
+@pytest.mark.parametrize("affine,mod", [(False, True), (True, True), (True, False)])
+def test_groupnorm_mod_silu(az, B, Cc, H, W, groups, affine, mod):
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(B * Cc + H)
+    x = torch.randn(B, Cc, H, W, generator=g) * 1.7 + 0.9
+    w, b = (torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)) if affine else (None, None)
+    a, sh = torch.randn(B, Cc, generator=g), torch.randn(B, Cc, generator=g)
+    ref = F.group_norm(x, groups, w, b, eps=1e-5)
+    if mod:
+        ref = ref * (1 + a[:, :, None, None]) + sh[:, :, None, None]
+    ref = F.silu(ref)
+    bld = Builder(torch.device("cuda"))
+    cs = (Cc + 3) // 4 * 4
+    xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cc, cs, True)
+    ab = torch.zeros(B, 2 * cs, device="cuda")
+    ab[:, :Cc], ab[:, cs : cs + Cc] = dev(a), dev(sh)
+    y = bld.group_norm(
+        xa, groups, weight=dev(w) if affine else None, bias=dev(b) if affine else None, scale=ab if mod else None,
+        shift=ab if mod else None, shift_off=cs, bstride=2 * cs, act=1,
+    )
+    bld.tape.run()
+    out = from_nhwc(y.buf.reshape(B, H, W, cs), Cc)
+    assert max_err(out, ref) < 2e-5
+    assert (y.buf.reshape(B, H, W, cs)[..., Cc:] == 0).all()
+
+
+def test_groupnorm_avgpool(az):
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(3)
+    B, Cc, H, W = 2, 64, 16, 16
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w, b = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    ref = F.avg_pool2d(F.silu(F.group_norm(x, 32, w, b, eps=1e-5)), 2, 2)
+    bld = Builder(torch.device("cuda"))
+    y = bld.group_norm(Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cc, Cc, True), 32, weight=dev(w), bias=dev(b), act=1, pool=1)
+    bld.tape.run()
+    assert max_err(from_nhwc(y.buf.reshape(B, H // 2, W // 2, Cc), Cc), ref) < 2e-5
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("Cc", [5, 64, 768, 1000])
+def test_rownorm_mod(az, kind, Cc):
+    from azula_amd.engine import Act, Builder
+    from oracle import nets
+
+    g = torch.Generator().manual_seed(Cc)
+    B, H, W = 2, 3, 5
+    x = torch.randn(B, Cc, H, W, generator=g) * 2 + 0.5
+    a, sh = torch.randn(B, Cc, generator=g), torch.randn(B, Cc, generator=g)
+    n = nets.layer_norm_unbiased(x, dim=1) if kind == 0 else nets.rms_norm(x, dim=1)
+    ref = n * (1 + a[:, :, None, None]) + sh[:, :, None, None]
+    cs = (Cc + 3) // 4 * 4
+    ab = torch.zeros(B, 2 * cs, device="cuda")
+    ab[:, :Cc], ab[:, cs : cs + Cc] = dev(a), dev(sh)
+    bld = Builder(torch.device("cuda"))
+    y = bld.row_norm(Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cc, cs, True), kind, scale=ab, shift=ab, shift_off=cs, bstride=2 * cs)
+    bld.tape.run()
+    assert max_err(from_nhwc(y.buf.reshape(B, H, W, cs), Cc), ref) < 2e-5
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, ks, stride
+    (2, 3, 16, 16, 16, 3, 1),
+    (1, 32, 32, 8, 8, 3, 1),
+    (2, 40, 24, 9, 7, 3, 1),
+    (2, 16, 32, 16, 16, 3, 2),
+    (1, 5, 7, 15, 15, 3, 2),
+    (2, 64, 48, 8, 8, 1, 1),
+    (1, 256, 256, 16, 16, 3, 1),
+    (1, 130, 260, 12, 12, 3, 1),
+    (4, 8, 3, 32, 32, 3, 1),
+]
+
+
+def conv_tol(cin, ks):
+    return 3e-6 * math.sqrt(cin * ks * ks) + 1e-5
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks,stride", CONV_CASES)
+@pytest.mark.parametrize("splitk", [0, 3])
+def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk):
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(Cin * Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, stride=stride, padding=ks // 2)
+    bld = Builder(torch.device("cuda"))
+    xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, (Cin + 3) // 4 * 4, True)
+    y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, stride=stride)
+    if splitk:
+        a = bld.tape.keep[-1]
+        a.splitk = splitk
+        bld._ws_need = max(bld._ws_need, splitk * B * y.H * y.W * y.cs)
+        bld._ws_users.append(a)
+    bld.finish()
+    bld.tape.run()
+    out = from_nhwc(y.buf.reshape(B, y.H, y.W, y.cs), Cout)
+    assert out.shape == ref.shape
+    assert max_err(out, ref) < conv_tol(Cin, ks), max_err(out, ref)
+    assert (y.buf.reshape(B, y.H, y.W, y.cs)[..., Cout:] == 0).all()
+
+
+def test_conv2d_concat_upsample_narrow_gate_res(az):
+    """cat((y, upsample(x)[narrowed])) -> conv -> x0 + c * silu-free epilogue, as azula/nn/unet.py:253-257,93."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(11)
+    B, Cy, Cx, Cout, H, W = 2, 12, 20, 12, 15, 13
+    y = torch.randn(B, Cy, H, W, generator=g)
+    x = torch.randn(B, Cx, 8, 7, generator=g)
+    w = torch.randn(Cout, Cy + Cx, 3, 3, generator=g) / math.sqrt(9 * (Cy + Cx))
+    b = torch.randn(Cout, generator=g)
+    gate = torch.randn(B, Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    up = F.interpolate(x, scale_factor=(2.0, 2.0), mode="nearest")[:, :, :H, :W]
+    ref = res + gate[:, :, None, None] * F.silu(F.conv2d(torch.cat((y, up), 1), w, b, padding=1))
+    bld = Builder(torch.device("cuda"))
+    ya = Act(to_nhwc(dev(y)).reshape(-1), B, H, W, Cy, 12, True)
+    xa = Act(to_nhwc(dev(x)).reshape(-1), B, 8, 7, Cx, 20, True)
+    ra = Act(to_nhwc(dev(res)).reshape(-1), B, H, W, Cout, 12, True)
+    out = bld.conv(ya, bld.pack_conv(dev(w), dev(b), cin0=Cy), Cout, src1=xa, up1=1, hin=H, win=W, act=1,
+                   gate=dev(gate), gate_bstride=Cout, res=ra)
+    bld.finish()
+    bld.tape.run()
+    assert max_err(from_nhwc(out.buf.reshape(B, H, W, 12), Cout), ref) < conv_tol(Cy + Cx, 3)
+
+
+def test_conv2d_nchw_output_and_res_up(az):
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(12)
+    B, Cin, Cout, H, W = 2, 16, 3, 12, 12
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 12
+    b = torch.randn(Cout, generator=g)
+    bld = Builder(torch.device("cuda"))
+    dst = torch.empty(B, Cout, H, W, device="cuda")
+    bld.conv(Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, 16, True), bld.pack_conv(dev(w), dev(b)), Cout, dst_nchw=dst)
+    # ADM up-block shape: conv over upsampled input + upsampled identity residual
+    w2 = torch.randn(Cin, Cin, 3, 3, generator=g) / 12
+    xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, 16, True)
+    up = bld.conv(xa, bld.pack_conv(dev(w2), None), Cin, up0=1, res=xa, res_up=1)
+    bld.finish()
+    bld.tape.run()
+    assert max_err(dst, F.conv2d(x, w, b, padding=1)) < conv_tol(Cin, 3)
+    xu = F.interpolate(x, scale_factor=2, mode="nearest")
+    assert max_err(from_nhwc(up.buf.reshape(B, 2 * H, 2 * W, 16), Cin), xu + F.conv2d(xu, w2, None, padding=1)) < conv_tol(Cin, 3)
+
+
+def test_graph_capture_replay(az):
+    from azula_amd.engine import StepGraph, Tape
+
+    x = torch.ones(1024, device="cuda")
+    s = torch.full((1,), 2.0, device="cuda")
+    tape = Tape()
+    tape.add("az_scale_f32", x.data_ptr(), x.data_ptr(), s.data_ptr(), 1024)
+    tape.add("az_scale_f32", x.data_ptr(), x.data_ptr(), s.data_ptr(), 1024)
+    tape.run()
+    graph = StepGraph(tape, x.device)
+    assert graph.num_nodes == 2
+    for _ in range(3):
+        graph.launch()
+    torch.cuda.synchronize()
+    assert (x == 4.0**4).all()

@@ -1,0 +1,151 @@
+r"""Host-side logic of the drop-in API (runs without a GPU).
+
+Covers the reference's CPU-runnable configuration (BASELINE.json configs[0]: KarrasDenoiser +
+2-layer MLP + VPSchedule + DDPMSampler(1000) on CPU) against the golden vectors, the
+reference's own invariant test (tests/test_denoise.py:135-143) and the host coefficient tables.
+"""
+
+import pytest
+import torch
+
+from conftest import max_err
+from azula_amd.denoise import DiracPosterior, GaussianPosterior, KarrasDenoiser
+from azula_amd.noise import Schedule, VESchedule, VPSchedule
+from azula_amd.sample import DDIMSampler, DDPMSampler
+from oracle import synth
+
+
+class ToyMLP(torch.nn.Module):
+    """Same architecture as the reference tests' Dummy (tests/test_sample.py:28-53)."""
+
+    def __init__(self, features=5):
+        super().__init__()
+        self.l1 = torch.nn.Linear(features, 64)
+        self.l2 = torch.nn.Linear(64, features)
+
+    def forward(self, x_t, t, label=None):
+        f = torch.exp(torch.log(torch.tensor(1e-4)) * torch.linspace(0, 1, 32, dtype=x_t.dtype))
+        e = torch.cat((torch.sin(t.unsqueeze(-1) * f), torch.cos(t.unsqueeze(-1) * f)), dim=-1)
+        return self.l2(torch.relu(self.l1(x_t) + e))
+
+
+def toy_denoiser(g):
+    net = ToyMLP()
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"]))
+    return KarrasDenoiser(net, VPSchedule()).eval()
+
+
+def test_schedule_tables_match_reference(golden):
+    g = golden("g1_schedule")
+    for case in g.meta["cases"]:
+        sched = VPSchedule(case["alpha_min"], case["sigma_min"])
+        ts = DDIMSampler(None, steps=case["steps"]).timesteps
+        assert torch.equal(ts, g[case["tag"] + "_t"])
+        al, si = zip(*(sched(t) for t in ts.unbind()))
+        torch.testing.assert_close(torch.stack(al), g[case["tag"] + "_alpha"], rtol=2e-7, atol=1e-9)
+        torch.testing.assert_close(torch.stack(si), g[case["tag"] + "_sigma"], rtol=2e-7, atol=1e-9)
+    assert isinstance(VPSchedule(), Schedule)
+    a, s = VESchedule()(torch.tensor(0.0))
+    assert a == 1 and abs(s.item() - 1e-3) < 1e-9
+
+
+def test_config1_readme_cpu(golden):
+    g = golden("g4_toy_loop")
+    den = toy_denoiser(g)
+    torch.manual_seed(g.meta["init_seed"])
+    smp = DDPMSampler(den, steps=1000, silent=True)
+    x1 = smp.init((64, 5))
+    assert torch.equal(x1, g["x1"])
+    torch.manual_seed(g.meta["loop_seed"])
+    x0 = smp(x1)
+    assert x0.shape == (64, 5) and torch.isfinite(x0).all()
+    assert max_err(x0, g["ddpm1000"]) < 1e-4
+    x0 = DDIMSampler(den, steps=64, silent=True)(x1)
+    assert max_err(x0, g["ddim64"]) < 1e-5
+
+
+@pytest.mark.parametrize("batch", [(), (64,)])
+def test_ve_reschedule_invariance(batch):
+    """Reference tests/test_denoise.py:135-143: the mean is unchanged by re-scheduling to VE."""
+
+    class ReSchedule(Schedule):
+        def __init__(self, s):
+            self.s = s
+
+        def __call__(self, t):
+            a, s = self.s(t)
+            return torch.ones_like(a), s / a
+
+    den = KarrasDenoiser(ToyMLP(), VPSchedule())
+    x = torch.randn(*batch, 5)
+    t = torch.rand(batch)
+    a, s = den.schedule(t)
+    x_t = torch.normal(a[..., None] * x, s[..., None])
+    q = den(x_t, t)
+    assert isinstance(q, DiracPosterior) and q.mean.shape == x.shape
+    den.schedule = ReSchedule(den.schedule)
+    q_ve = den(x_t / a[..., None], t)
+    assert torch.allclose(q.mean, q_ve.mean, atol=1e-6)
+
+
+def test_ddim_eta1_equals_ddpm(golden):
+    g = golden("g4_toy_loop")
+    den = toy_denoiser(g)
+    torch.manual_seed(7)
+    a = DDPMSampler(den, steps=32, silent=True)(g["x1"])
+    torch.manual_seed(7)
+    b = DDIMSampler(den, eta=1.0, steps=32, silent=True)(g["x1"])
+    assert max_err(a, b) < 1e-6
+
+
+def test_host_coefficient_table_matches_golden(golden):
+    """The (steps, 16) AzStepCoef table the fused path uploads, against G2/G1."""
+    from azula_amd._lib import COEF_FIELDS
+    from azula_amd.sample import FusedDenoiser
+
+    g = golden("g2_precond")
+    den = KarrasDenoiser(torch.nn.Identity(), VPSchedule())
+    smp = DDIMSampler(den, steps=64)
+    tab = smp._host_table(FusedDenoiser(coefficients=den.host_coefficients, programs=[]))
+    col = {n: i for i, n in enumerate(COEF_FIELDS)}
+    assert tab.shape == (64, 16)
+    for j, name in enumerate(["c_in", "c_out", "c_skip", "c_time"]):
+        torch.testing.assert_close(tab[:, col[name]], g["karras"][:64, j], rtol=2e-7, atol=1e-9)
+    torch.testing.assert_close(tab[:-1, col["c_in_next"]], tab[1:, col["c_in"]], rtol=0, atol=0)
+    assert tab[-1, col["c_in_next"]] == 0
+    assert (tab[:, col["k_eps"]] == 0).all()  # eta = 0
+    assert tab.view(torch.int32)[:, col["step"]].tolist() == list(range(64))
+    tab = DDPMSampler(den, steps=64)._host_table(FusedDenoiser(coefficients=den.host_coefficients, programs=[]))
+    assert (tab[:, col["k_eps"]] > 0).all()
+
+
+def test_gaussian_posterior_log_prob():
+    """Reference tests/test_denoise.py:48-65."""
+    mean, var, x = torch.randn(7), torch.rand(7) + 0.1, torch.randn(7)
+    ref = torch.distributions.Normal(mean, var.sqrt()).log_prob(x)
+    assert torch.allclose(GaussianPosterior(mean, var).log_prob(x), ref, atol=1e-6)
+
+
+def test_unet_state_dict_matches_reference_shapes(golden):
+    from azula_amd.nn import UNet
+
+    for name in ("unet_group", "unet_layer_odd", "unet_rms_nomod"):
+        g = golden("g5_" + name)
+        cfg = g.meta["cfg"]
+        net = UNet(
+            cfg["in_channels"], cfg["out_channels"], hid_channels=cfg["hid_channels"], hid_blocks=cfg["hid_blocks"],
+            norm=cfg["norm"], groups=cfg["groups"], mod_features=cfg["mod_features"],
+        )
+        mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        ref = {k: tuple(v) for k, v in g.meta["shapes"].items()}
+        assert mine == ref, name
+
+
+def test_backbones_fail_loudly_on_cpu():
+    from azula_amd.nn import TimeModulated, UNet
+
+    net = UNet(3, 3, hid_channels=(8, 16), hid_blocks=(1, 1), mod_features=8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.randn(1, 3, 8, 8), torch.randn(8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        TimeModulated(net, 8)(torch.randn(1, 3, 8, 8), torch.tensor(0.3))

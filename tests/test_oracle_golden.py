@@ -1,0 +1,130 @@
+r"""The oracle (CPU restatement) against the committed golden vectors.
+
+The vectors were produced by the REFERENCE itself (``oracle/make_golden.py``, which also
+asserted bit-equality oracle == reference in the build container).  Here the oracle is re-run
+on whatever host executes the tests; elementwise results must agree to the last bit or two
+(vector-ISA dependent libm), network results to fp32 round-off.
+"""
+
+import torch
+
+from conftest import max_err
+from oracle import nets, sampling, synth
+
+torch.set_grad_enabled(False)
+TIGHT = dict(rtol=2e-7, atol=1e-9)
+
+
+def test_g1_schedule_tables(golden):
+    g = golden("g1_schedule")
+    for case in g.meta["cases"]:
+        tag = case["tag"]
+        ts = sampling.timesteps(steps=case["steps"])
+        assert torch.equal(ts, g[tag + "_t"])
+        al, si = zip(*(sampling.vp_schedule(t, case["alpha_min"], case["sigma_min"]) for t in ts.unbind()))
+        torch.testing.assert_close(torch.stack(al), g[tag + "_alpha"], **TIGHT)
+        torch.testing.assert_close(torch.stack(si), g[tag + "_sigma"], **TIGHT)
+        assert ts[0] == 1 and ts[-1] == 0  # G7: endpoints
+        assert g[tag + "_alpha"][-1] == 1.0  # alpha_0 == 1 (reference tests/test_noise.py)
+
+
+def test_g2_preconditioning(golden):
+    g = golden("g2_precond")
+    ts = g["t"]
+    rows = []
+    for t in ts.unbind():
+        a, s = sampling.vp_schedule(t)
+        rows.append(torch.stack(sampling.karras_coefficients(a, s)))
+    torch.testing.assert_close(torch.stack(rows), g["karras"], **TIGHT)
+    sig = sampling.adm_sigmas("linear", 1000)
+    torch.testing.assert_close(sig, g["adm_sigmas"], **TIGHT)
+    torch.testing.assert_close(sampling.adm_sigmas("cosine", 1000), g["adm_sigmas_cosine"], **TIGHT)
+    idx = []
+    for t in ts[:-1].unbind():
+        a, s = sampling.vp_schedule(t, 1e-2, 1e-2)
+        idx.append(sampling.adm_coefficients(a, s, g["adm_sigmas"])[3][0])
+    assert torch.equal(torch.stack(idx), g["adm_idx"])
+    assert g["adm_idx"][0] == 954 and g["adm_idx"][-1] == 11  # DDIM-64 indices 954, 939, ..., 11
+
+
+def test_g3_single_transition(golden):
+    g = golden("g3_transition")
+    for case in g.meta["cases"]:
+        t, s = torch.tensor(case["t"]), torch.tensor(case["s"])
+        mean = sampling.karras_mean(lambda x, c: g["F"], g["x_t"], t)
+        torch.testing.assert_close(mean, g[case["tag"] + "_mean"], rtol=1e-6, atol=1e-6)
+        a_t, s_t = sampling.vp_schedule(t)
+        a_s, s_s = sampling.vp_schedule(s)
+        x_s = sampling.transition(g["x_t"], g[case["tag"] + "_mean"], g["eps"], a_t, s_t, a_s, s_s, case["eta"])
+        torch.testing.assert_close(x_s, g[case["tag"]], rtol=1e-6, atol=1e-6)
+
+
+def _toy(sd):
+    def f(x, c_time, **_):
+        h = torch.nn.functional.linear(x, sd["l1.weight"], sd["l1.bias"]) + nets.sine_encoding(c_time, 64)
+        return torch.nn.functional.linear(torch.relu(h), sd["l2.weight"], sd["l2.bias"])
+
+    return f
+
+
+def test_g4_toy_loop(golden):
+    g = golden("g4_toy_loop")
+    sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"])
+    mean = lambda x, t: sampling.karras_mean(_toy(sd), x, t)  # noqa: E731
+    x0 = sampling.sample(mean, g["x1"], steps=64, eta=0.0)
+    assert max_err(x0, g["ddim64"]) < 1e-5
+    x0 = sampling.sample(mean, g["x1"], steps=64, eta=None, eps_list=list(g["ddpm64_eps"]))
+    assert max_err(x0, g["ddpm64"]) < 1e-5
+    # G7: DDIM(eta=1) == DDPM given identical noise
+    x0b = sampling.sample(mean, g["x1"], steps=64, eta=1.0, eps_list=list(g["ddpm64_eps"]))
+    assert max_err(x0b, x0) < 1e-6
+    # same generator stream as the reference run
+    torch.manual_seed(g.meta["loop_seed"])
+    x0 = sampling.sample(mean, g["x1"], steps=1000, eta=None)
+    assert max_err(x0, g["ddpm1000"]) < 1e-4
+
+
+def test_g5_unets(golden):
+    for name in ("unet_group", "unet_layer_odd", "unet_rms_nomod"):
+        g = golden("g5_" + name)
+        cfg = g.meta["cfg"]
+        sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"])
+        tap = {}
+        y = nets.unet_forward(sd, cfg, g["x"], g["modB"] if "modB" in g else None, tap=tap)
+        assert max_err(y, g["y_modB"]) < 1e-5, name
+        for k, v in tap.items():
+            assert max_err(v, g["tap_" + k]) < 1e-5, (name, k)
+        if "mod1" in g:
+            assert max_err(nets.unet_forward(sd, cfg, g["x"], g["mod1"]), g["y_mod1"]) < 1e-5
+
+
+def test_g5_vit(golden):
+    g = golden("g5_vit")
+    sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"])
+    y = nets.vit_forward(sd, g.meta["cfg"], g["x"], g["modB"])
+    assert max_err(y, g["y_modB"]) < 1e-5
+    assert max_err(nets.vit_forward(sd, g.meta["cfg"], g["x"], g["mod1"]), g["y_mod1"]) < 1e-5
+
+
+def test_g5_adm(golden):
+    for name in ("adm_uncond", "adm_cond_neworder"):
+        g = golden("g5_" + name)
+        cfg = g.meta["cfg"]
+        sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"])
+        y = g["y"] if "y" in g else None
+        out = nets.adm_unet_forward(sd, cfg, g["x"], g["idx"], y)
+        assert max_err(out, g["out"]) < 2e-5, name
+        sig = sampling.adm_sigmas(cfg["discrete_schedule"], cfg["discrete_steps"])
+        bb = lambda a, i, y=None: nets.adm_unet_forward(sd, cfg, a, i, y)  # noqa: E731
+        mean, var = sampling.adm_posterior(bb, g["x"], torch.tensor(0.7), sig, label=y)
+        assert max_err(mean, g["mean_t07"]) < 2e-5 and max_err(var, g["var_t07"]) < 2e-5
+
+
+def test_g6_unet_loop(golden):
+    g = golden("g6_unet_loop")
+    cfg = g.meta["cfg"]
+    sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"])
+    mean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, cfg, a, c), x, t)  # noqa: E731
+    assert max_err(mean(g["x1"], torch.tensor(0.5)), g["mean_t05"]) < 1e-5
+    x0 = sampling.sample(mean, g["x1"], steps=8, eta=None, eps_list=list(g["ddpm8_eps"]))
+    assert max_err(x0, g["ddpm8"]) < 1e-4
