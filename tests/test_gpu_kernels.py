@@ -114,7 +114,9 @@ def test_transition_flat_in_place_and_golden(az, golden):
         arg = az.AzTransitionArgs(x_t=x.data_ptr(), F=Fb.data_ptr(), eps=eps.data_ptr(), x_s=x.data_ptr(), batch=1,
                                   channels=1, inner=n, f_channels=1, coef=row.data_ptr())
         az.call("az_transition_f32", C.byref(arg), az.stream_ptr())
-        assert torch.equal(x.cpu(), g[case["tag"]]), case["tag"]
+        # the kernel arithmetic is bit-exact (test above); the host-computed scalars may differ in
+        # the last ulp between the CPU that wrote the fixture and this one (vector libm variants)
+        torch.testing.assert_close(x.cpu(), g[case["tag"]], rtol=2e-6, atol=2e-6, msg=case["tag"])
 
 
 @pytest.mark.parametrize("f_nhwc,fC", [(0, 3), (0, 6), (1, 4), (1, 8)])
@@ -346,7 +348,8 @@ def test_conv2d_nchw_output_and_res_up(az):
     b = torch.randn(Cout, generator=g)
     bld = Builder(torch.device("cuda"))
     dst = torch.empty(B, Cout, H, W, device="cuda")
-    bld.conv(Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, 16, True), bld.pack_conv(dev(w), dev(b)), Cout, dst_nchw=dst)
+    x0a = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, 16, True)  # keep alive until the tape has run
+    bld.conv(x0a, bld.pack_conv(dev(w), dev(b)), Cout, dst_nchw=dst)
     # ADM up-block shape: conv over upsampled input + upsampled identity residual
     w2 = torch.randn(Cin, Cin, 3, 3, generator=g) / 12
     xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, 16, True)
