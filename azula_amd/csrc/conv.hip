@@ -35,14 +35,27 @@ struct ConvP {
   AzConvArgs a;
   int npix;     // batch * hout * wout
   int cin_s;    // c0s + c1s
-  int nkc;      // ceil(cin_s / BK)
-  int nk;       // taps * nkc
+  int nkc0;     // K-tiles of source 0 per tap: ceil(c0s / BK)
+  int nkc1;     // K-tiles of source 1 per tap
+  int nk;       // taps * (nkc0 + nkc1)
   int kps;      // K-tiles per split
   int tiles_m;  // ceil(cout_s / BM)
   int tiles_n;  // ceil(npix / BN)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte buffer load: per-lane byte offset `voff` (bounds-checked: >= num_records returns 0,
+// which is how padding, ragged tiles and channel tails are zero-filled without branches) plus a
+// wave-uniform byte offset `soff` (not bounds-checked) that walks the K dimension.
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
+  return __builtin_bit_cast(float4, v);
+}
+
+constexpr unsigned OOB = 0x80000000u;  // any offset >= num_records reads as zero
 
 // Epilogue for 4 consecutive output channels [co, co+4) of output pixel n.
 __device__ __forceinline__ void epilogue_store(const AzConvArgs& a, int n, int co, float4 v) {
@@ -119,60 +132,96 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   // ---- loader coordinates: thread -> (16-B chunk cc along k, rows r0 + 32*i)
   const int cc = tid & 7;
   const int r0 = tid >> 3;
-  int pb[4], ihb[4], iwb[4];
-  bool pv[4];
   const int hw_out = a.hout * a.wout;
+  const int b_first = n0 / hw_out;  // wave-uniform: offsets are relative to this sample
+
+  // Buffer descriptors (wave-uniform: kernel arguments + blockIdx only).
+  const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
+  const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : e * 4); };
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.weight, 0, clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src0 + b_first * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src1 ? a.src1 + b_first * s1_elems : a.src0), 0,
+      a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u, 0x00020000);
+
+  // Per-thread constants: weight-row byte offsets, pixel coordinates.
+  unsigned voffW[4];
+  int prel[4], ihb[4], iwb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    const int co = m0 + r0 + 32 * i;
+    voffW[i] = co < a.cout_s ? (unsigned)((co * p.cin_s + cc * 4) * 4) : OOB;
     const int n = n0 + r0 + 32 * i;
-    pv[i] = n < p.npix;
-    const int nn = pv[i] ? n : 0;
+    const bool pv = n < p.npix;
+    const int nn = pv ? n : 0;
     const int b = nn / hw_out;
     const int rem = nn - b * hw_out;
     const int oh = rem / a.wout;
     const int ow = rem - oh * a.wout;
-    pb[i] = b;
+    prel[i] = pv ? b - b_first : -1;
     ihb[i] = oh * a.stride - a.pad;
     iwb[i] = ow * a.stride - a.pad;
   }
 
-  float4 ra[4], rb[4];
+  // K iterator (wave-uniform): tap -> source -> 32-channel chunk.  The per-lane activation
+  // offsets voffA change only when (tap, source) changes; inside, the K walk is a scalar offset.
+  const int nk_tap = p.nkc0 + p.nkc1;
+  int it_tap = kt_begin / nk_tap;
+  int it_r = kt_begin - it_tap * nk_tap;
+  int it_src = it_r >= p.nkc0 ? 1 : 0;
+  int it_kc = it_src ? it_r - p.nkc0 : it_r;
+  unsigned voffA[4];
 
-  auto load_tile = [&](int kt) {
-    const int tap = kt / p.nkc;
-    const int kc = kt - tap * p.nkc;
-    const int ky = tap / a.ksize;
-    const int kx = tap - ky * a.ksize;
-    const int c = kc * BK + cc * 4;
-    const bool cv = c < p.cin_s;
-    // weights: [tap][cout_s][cin_s]
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int co = m0 + r0 + 32 * i;
-      if (cv && co < a.cout_s)
-        ra[i] = ld4(a.weight + ((int64_t)tap * a.cout_s + co) * p.cin_s + c);
-      else
-        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // pixels: gather from src0 | src1 with padding / upsampling
-    const bool first = c < a.c0s;
-    const float* src = first ? a.src0 : a.src1;
-    const int cs = first ? a.c0s : a.c1s;
-    const int cl = first ? c : c - a.c0s;
-    const int up = first ? a.up0 : a.up1;
-    const int hs = first ? a.h0 : a.h1;
-    const int ws = first ? a.w0 : a.w1;
+  auto set_tap_src = [&]() {
+    const int ky = it_tap / a.ksize;
+    const int kx = it_tap - ky * a.ksize;
+    const int cs = it_src ? a.c1s : a.c0s;
+    const int up = it_src ? a.up1 : a.up0;
+    const int hs = it_src ? a.h1 : a.h0;
+    const int ws = it_src ? a.w1 : a.w0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ih = ihb[i] + ky;
       const int iw = iwb[i] + kx;
-      const bool ok = cv && pv[i] && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
-      if (ok) {
-        const int64_t pix = ((int64_t)pb[i] * hs + (ih >> up)) * ws + (iw >> up);
-        rb[i] = ld4(src + pix * cs + cl);
-      } else {
-        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
+      const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> up);
+      voffA[i] = ok ? (unsigned)((pix * cs + cc * 4) * 4) : OOB;
+    }
+  };
+
+  float4 ra[4], rb[4];
+
+  auto load_tile = [&]() {
+    const int cs = it_src ? a.c1s : a.c0s;
+    const int kbase = it_kc * BK;                        // channel offset inside the source
+    const int kglob = (it_src ? a.c0s : 0) + kbase;      // channel offset in the packed weights
+    const unsigned soffW = (unsigned)(((int64_t)it_tap * a.cout_s * p.cin_s + kglob) * 4);
+    const unsigned soffA = (unsigned)(kbase * 4);
+    const bool kv = kbase + cc * 4 < cs;  // channel tail of this source (lane-dependent only there)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = buf_ld4(rw, voffW[i], soffW);
+    if (it_src) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] = buf_ld4(rs1, kv ? voffA[i] : OOB, soffA);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] = buf_ld4(rs0, kv ? voffA[i] : OOB, soffA);
+    }
+  };
+
+  auto advance = [&]() {
+    ++it_kc;
+    if (it_kc == (it_src ? p.nkc1 : p.nkc0)) {
+      it_kc = 0;
+      ++it_src;
+      if (it_src == 2 || p.nkc1 == 0) {
+        it_src = 0;
+        ++it_tap;
       }
+      set_tap_src();
     }
   };
 
@@ -197,7 +246,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   const int frag_off = (lane & 31) * LDSS + (lane >> 5) * 4;
 
   if (kt_begin < kt_end) {
-    load_tile(kt_begin);
+    set_tap_src();
+    load_tile();
     store_tile(0);
   }
   __syncthreads();
@@ -205,7 +255,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int buf = (kt - kt_begin) & 1;
     const bool more = kt + 1 < kt_end;
-    if (more) load_tile(kt + 1);  // global loads in flight under the MFMAs below
+    if (more) {
+      advance();
+      load_tile();  // global loads in flight under the MFMAs below
+    }
 
     const float* As = smem + buf * TILE_F + (wc * 64) * LDSS + frag_off;
     const float* Bs = smem + buf * TILE_F + BM * LDSS + (wp * 64) * LDSS + frag_off;
@@ -281,7 +334,7 @@ extern "C" {
 
 int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_t ksize) {
   const int64_t tiles = ((npix + BN - 1) / BN) * ((cout_s + BM - 1) / BM);
-  const int64_t nk = (int64_t)ksize * ksize * ((cin_s + BK - 1) / BK);
+  const int64_t nk = (int64_t)ksize * ksize * ((cin_s + BK - 1) / BK);  // (two-source convs: within +1 per tap)
   // Fill 256 CUs x 2 resident blocks; keep >= 8 K-tiles per split so the slab traffic
   // (2 x 4 B x outputs per split) stays small next to the operand traffic.
   int64_t want = (512 + tiles - 1) / tiles;
@@ -321,8 +374,18 @@ int az_conv2d_f32(const AzConvArgs* a, az_stream_t stream) {
   p.a = *a;
   p.npix = (int)npix64;
   p.cin_s = a->c0s + a->c1s;
-  p.nkc = (p.cin_s + BK - 1) / BK;
-  p.nk = a->ksize * a->ksize * p.nkc;
+  p.nkc0 = (a->c0s + BK - 1) / BK;
+  p.nkc1 = (a->c1s + BK - 1) / BK;
+  p.nk = a->ksize * a->ksize * (p.nkc0 + p.nkc1);
+  // 32-bit relative byte offsets inside the kernel: a pixel tile spans at most
+  // ceil(BN / (hout*wout)) + 1 samples of either source.
+  {
+    const int64_t span = (BN + (int64_t)a->hout * a->wout - 1) / ((int64_t)a->hout * a->wout) + 1;
+    AZ_REQUIRE(span * a->h0 * a->w0 * a->c0s * 4 < (1ll << 31), AZ_E_SHAPE);
+    AZ_REQUIRE(span * a->h1 * a->w1 * a->c1s * 4 < (1ll << 31), AZ_E_SHAPE);
+    AZ_REQUIRE((int64_t)a->cout_s * p.cin_s * 4 < (1ll << 31), AZ_E_SHAPE);
+    AZ_REQUIRE((int64_t)a->ksize * a->ksize * a->cout_s * p.cin_s * 4 < (1ll << 32), AZ_E_SHAPE);
+  }
   int splitk = a->splitk;
   if (splitk > p.nk) splitk = p.nk;
   p.kps = (p.nk + splitk - 1) / splitk;

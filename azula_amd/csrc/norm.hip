@@ -139,29 +139,44 @@ __global__ __launch_bounds__(256) void gn_stats_generic_kernel(float* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(AzNormFinalizeArgs a) {
-  const int b = blockIdx.x;
+// One wave per (b, group): lanes combine the pixel-chunk partials (Chan), butterfly-merge, then
+// write S/T for the group's channels.  Blocks past the last group zero the pad channels.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(AzNormFinalizeArgs a) {
+  const int b = blockIdx.y;
+  const int g = blockIdx.x;
+  const int lane = threadIdx.x;
   const int Cg = (int)(a.C / a.groups);
-  for (int c = threadIdx.x; c < a.cs; c += blockDim.x) {
-    float S = 0.f, T = 0.f;
-    if (c < a.C) {
-      const int g = c / Cg;
-      Moments acc = {0.f, 0.f, 0.f};
-      for (int k = 0; k < a.nchunks; ++k) {
-        const float* p = a.partials + (((int64_t)b * a.nchunks + k) * a.groups + g) * 4;
-        acc = combine(acc, Moments{p[0], p[1], p[2]});
-      }
-      const float var = acc.m2 / acc.n;  // biased, as torch.nn.GroupNorm
-      const float rstd = rsqrtf(var + a.eps);
-      const float w = a.weight ? a.weight[c] : 1.f;
-      const float bi = a.bias ? a.bias[c] : 0.f;
-      const float sc = 1.f + (a.scale ? a.scale[(int64_t)b * a.scale_bstride + c] : 0.f);
-      const float sh = a.shift ? a.shift[(int64_t)b * a.scale_bstride + c] : 0.f;
-      S = rstd * w * sc;
-      T = (bi - acc.mean * rstd * w) * sc + sh;
+  if (g == a.groups) {  // pad channels [C, cs)
+    for (int c = (int)a.C + lane; c < a.cs; c += 64) {
+      a.S[(int64_t)b * a.cs + c] = 0.f;
+      a.T[(int64_t)b * a.cs + c] = 0.f;
     }
-    a.S[(int64_t)b * a.cs + c] = S;
-    a.T[(int64_t)b * a.cs + c] = T;
+    return;
+  }
+  Moments acc = {0.f, 0.f, 0.f};
+  for (int k = lane; k < a.nchunks; k += 64) {
+    const float* p = a.partials + (((int64_t)b * a.nchunks + k) * a.groups + g) * 4;
+    acc = combine(acc, Moments{p[0], p[1], p[2]});
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Moments other;
+    other.n = __shfl_xor(acc.n, o, 64);
+    other.mean = __shfl_xor(acc.mean, o, 64);
+    other.m2 = __shfl_xor(acc.m2, o, 64);
+    // combine in a lane-symmetric order so that every lane ends with identical bits
+    acc = (lane & o) ? combine(other, acc) : combine(acc, other);
+  }
+  const float var = acc.m2 / acc.n;  // biased, as torch.nn.GroupNorm
+  const float rstd = rsqrtf(var + a.eps);
+  for (int j = lane; j < Cg; j += 64) {
+    const int c = g * Cg + j;
+    const float w = a.weight ? a.weight[c] : 1.f;
+    const float bi = a.bias ? a.bias[c] : 0.f;
+    const float sc = 1.f + (a.scale ? a.scale[(int64_t)b * a.scale_bstride + c] : 0.f);
+    const float sh = a.shift ? a.shift[(int64_t)b * a.scale_bstride + c] : 0.f;
+    a.S[(int64_t)b * a.cs + c] = rstd * w * sc;
+    a.T[(int64_t)b * a.cs + c] = (bi - acc.mean * rstd * w) * sc + sh;
   }
 }
 
@@ -335,7 +350,7 @@ int az_groupnorm_finalize_f32(const AzNormFinalizeArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->S && a->T && a->partials, AZ_E_NULL);
   AZ_REQUIRE(a->B > 0 && a->C > 0 && a->cs >= a->C && a->groups > 0 && a->C % a->groups == 0 && a->nchunks > 0,
              AZ_E_SHAPE);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)a->B), dim3(256), 0, az_s(stream), *a);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)a->groups + 1, (unsigned)a->B), dim3(64), 0, az_s(stream), *a);
   return az_launch_status();
 }
 
