@@ -114,6 +114,7 @@ class AzConvArgs(C.Structure):
         ("res_up", C.c_int32),
         ("hres", C.c_int32),
         ("wres", C.c_int32),
+        ("res_bcast", C.c_int32),
         ("dst", c_f32p),
         ("dst_nchw", C.c_int32),
         ("dst_c", C.c_int32),
@@ -173,6 +174,9 @@ PROTOTYPES: dict[str, list] = {
     "az_conv2d_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_suggest_splitk": [i64, i32, i32, i32],
     "az_pack_conv_weight_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, c_stream],
+    "az_attention_f32": [C.POINTER(AzAttnArgs), c_stream],
+    "az_patchify_f32": [vp, vp, vp, i64, i64, i64, i64, i64, i64, c_stream],
+    "az_unpatchify_f32": [vp, vp, i64, i64, i64, i64, i64, i64, c_stream],
     "az_graph_begin": [c_stream],
     "az_graph_end": [c_stream, C.POINTER(vp)],
     "az_graph_launch": [vp, c_stream],

@@ -1,0 +1,273 @@
+// K4: multi-head self-attention softmax(q k^T * scale) v in fp32 on gfx950 MFMA, plus the
+// token-layout helpers of the ViT path (patchify / unpatchify).
+//
+// Replaces F.scaled_dot_product_attention after per-head q/k RMSNorm (azula/nn/attention.py:89-104)
+// and the einsum-softmax-einsum of the ADM attention blocks (plugins/adm/_src/unet.py:338-345,
+// 371-379; softmax in fp32 there too).  Flash-style: the T x T score matrix never exists.
+//
+// Work split: one workgroup = one (batch, head) x 128 query rows; each of its 4 waves owns 32
+// queries.  K/V tiles of 64 keys are staged through LDS (row stride D+4 floats: fragment
+// ds_read_b128 are bank-conflict-free) and shared by the 4 waves.
+//
+// Both contractions use v_mfma_f32_32x32x2_f32 in the TRANSPOSED orientation
+//     S^T = K  Q^T   (A = keys,  B = queries)      O^T = V^T P^T   (A = V^T, B = P^T)
+// so that a lane owns one QUERY column: the online-softmax max/sum are in-lane reductions over
+// its 16 score registers plus one cross-half shuffle, and the P^T registers feed the second
+// MFMA directly as its B operand -- no LDS round trip, no cross-lane movement of P.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int QT = 128;  // queries per workgroup
+constexpr int KT = 64;   // keys per LDS tile
+
+struct AttnP {
+  AzAttnArgs a;
+};
+
+// key index inside a 32-key tile held by accumulator register r of a lane in half h
+__device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int D>
+__global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
+  constexpr int DP = D < 32 ? 32 : D;  // padded head dim (whole 32-wide O^T tiles)
+  constexpr int DT = DP / 32;          // number of 32-wide output tiles
+  constexpr int LS = DP + 4;           // LDS row stride (floats)
+  constexpr int KJ = D / 8;            // groups of 8 head-dim values in the QK^T contraction
+  __shared__ __attribute__((aligned(16))) float smem[2 * KT * LS];
+  float* Ks = smem;
+  float* Vs = smem + KT * LS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int h2 = lane >> 5;  // half-wave
+  const int ql = lane & 31;
+  const int bh = blockIdx.y;
+  const int b = bh / a.heads;
+  const int hd = bh - b * a.heads;
+  const int T = a.tokens;
+  const int q0 = blockIdx.x * QT + wave * 32;
+  const int qi = q0 + ql;  // this lane's query
+
+  const float* qp = a.q + (int64_t)b * a.q_bstride + (int64_t)hd * a.q_hstride;
+  const float* kp = a.k + (int64_t)b * a.k_bstride + (int64_t)hd * a.k_hstride;
+  const float* vp = a.v + (int64_t)b * a.v_bstride + (int64_t)hd * a.v_hstride;
+
+  // ---- Q fragment: lane holds q[qi][8*jj + 4*h2 + s], pre-multiplied by scale (* rms factor)
+  float qf[KJ][4];
+  {
+    float ss = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < KJ; ++jj) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (qi < T) v = *reinterpret_cast<const float4*>(qp + (int64_t)qi * a.q_tstride + 8 * jj + 4 * h2);
+      qf[jj][0] = v.x;
+      qf[jj][1] = v.y;
+      qf[jj][2] = v.z;
+      qf[jj][3] = v.w;
+      ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    float f = a.scale;
+    if (a.qk_rmsnorm) {
+      ss += __shfl_xor(ss, 32, 64);
+      f *= rsqrtf(ss / (float)D + a.eps);
+    }
+#pragma unroll
+    for (int jj = 0; jj < KJ; ++jj)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) qf[jj][s] *= f;
+  }
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // cooperative K/V tile loader: thread -> (row = tid / CH + pass * rows_per_pass, 16-B chunk)
+  constexpr int CH = D / 4;               // chunks per row
+  constexpr int RPP = 256 / CH;           // rows per pass
+  const int lc = tid % CH, lr = tid / CH;
+
+  for (int k0 = 0; k0 < T; k0 += KT) {
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int rr = 0; rr < KT; rr += RPP) {
+      const int row = rr + lr;
+      if (row < KT) {
+        const int key = k0 + row;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (key < T) {
+          kv = *reinterpret_cast<const float4*>(kp + (int64_t)key * a.k_tstride + lc * 4);
+          vv = *reinterpret_cast<const float4*>(vp + (int64_t)key * a.v_tstride + lc * 4);
+        }
+        if (a.qk_rmsnorm) {  // per-key RMS norm: CH consecutive lanes hold one row
+          float ss = (kv.x * kv.x + kv.y * kv.y) + (kv.z * kv.z + kv.w * kv.w);
+#pragma unroll
+          for (int o = 1; o < CH; o <<= 1) ss += __shfl_xor(ss, o, 64);
+          const float f = rsqrtf(ss / (float)D + a.eps);
+          kv.x *= f;
+          kv.y *= f;
+          kv.z *= f;
+          kv.w *= f;
+        }
+        *reinterpret_cast<float4*>(Ks + row * LS + lc * 4) = kv;
+        *reinterpret_cast<float4*>(Vs + row * LS + lc * 4) = vv;
+        if (D < DP && lc == 0) {  // zero the padded V columns once per row
+#pragma unroll
+          for (int c = D; c < DP; c += 4) *reinterpret_cast<float4*>(Vs + row * LS + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int sub = 0; sub < KT / 32; ++sub) {
+      if (k0 + sub * 32 >= T) break;  // wave-uniform
+      // ---- S^T tile (32 keys x 32 queries): A = K rows, B = Q columns
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      const float* kr = Ks + (sub * 32 + ql) * LS + 4 * h2;
+#pragma unroll
+      for (int jj = 0; jj < KJ; ++jj) {
+        const float4 kf = *reinterpret_cast<const float4*>(kr + 8 * jj);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[jj][0], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[jj][1], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[jj][2], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[jj][3], sacc, 0, 0, 0);
+      }
+      // ---- online softmax over this lane's query column
+      float mt = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + sub * 32 + key_of(r, h2);
+        if (key >= T) sacc[r] = -INFINITY;
+        mt = fmaxf(mt, sacc[r]);
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
+      float ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = sacc[r] == -INFINITY ? 0.f : expf(sacc[r] - m_new);
+        sacc[r] = pv;
+        ls += pv;
+      }
+      ls += __shfl_xor(ls, 32, 64);
+      l_run = l_run * alpha + ls;
+      m_run = m_new;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+      // ---- O^T += V^T P^T: A = V^T (lane: d = ql + 32 t, key = key_of(r, h2)), B = P^T regs
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* vr = Vs + (sub * 32 + key_of(r, h2)) * LS + ql;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32 * t], sacc[r], oacc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds O[qi][32 t + 8 g + 4 h2 + (0..3)] in oacc[t][4g .. 4g+3]
+  if (qi < T) {
+    const float inv = 1.f / l_run;
+    float* op = a.out + (int64_t)b * a.o_bstride + (int64_t)hd * a.o_hstride + (int64_t)qi * a.o_tstride;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * t + 8 * g + 4 * h2;
+        if (d < D)
+          *reinterpret_cast<float4*>(op + d) = make_float4(oacc[t][4 * g] * inv, oacc[t][4 * g + 1] * inv,
+                                                            oacc[t][4 * g + 2] * inv, oacc[t][4 * g + 3] * inv);
+      }
+  }
+}
+
+// NCHW (B, Z, H, W) -> tokens (B, L = H/p * W/p, cs) with feature index z*p*p + a*p + b
+// ('... Z (A a) (B b) -> ... A B (Z a b)', azula/nn/layers.py:198-222); optional scale.
+__global__ __launch_bounds__(256) void patchify_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                       const float* __restrict__ scale, int64_t B, int Z, int H,
+                                                       int W, int p, int cs) {
+  const float s = scale ? *scale : 1.f;
+  const int Hp = H / p, Wp = W / p, F = Z * p * p;
+  const int64_t total = B * Hp * Wp * cs;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(e % cs);
+    const int64_t tok = e / cs;
+    float v = 0.f;
+    if (f < F) {
+      const int z = f / (p * p), ab = f - z * p * p, ai = ab / p, bi = ab - ai * p;
+      const int wp = (int)(tok % Wp), hp = (int)((tok / Wp) % Hp);
+      const int64_t b = tok / ((int64_t)Wp * Hp);
+      v = az_mul(s, src[((b * Z + z) * H + hp * p + ai) * W + wp * p + bi]);
+    }
+    dst[e] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void unpatchify_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                         int64_t B, int Z, int H, int W, int p, int cs) {
+  const int Hp = H / p, Wp = W / p;
+  const int64_t total = B * Z * H * W;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(e % W), hh = (int)((e / W) % H), z = (int)((e / ((int64_t)W * H)) % Z);
+    const int64_t b = e / ((int64_t)W * H * Z);
+    const int wp = w / p, bi = w - wp * p, hp = hh / p, ai = hh - hp * p;
+    const int64_t tok = (b * Hp + hp) * Wp + wp;
+    dst[e] = src[tok * cs + z * p * p + ai * p + bi];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int az_attention_f32(const AzAttnArgs* a, az_stream_t stream) {
+  AZ_REQUIRE(a && a->q && a->k && a->v && a->out, AZ_E_NULL);
+  AZ_REQUIRE(a->batch > 0 && a->heads > 0 && a->tokens > 0, AZ_E_SHAPE);
+  AZ_REQUIRE(a->head_dim == 16 || a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 128, AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(AZ_ALIGNED16(a->q) && AZ_ALIGNED16(a->k) && AZ_ALIGNED16(a->v) && AZ_ALIGNED16(a->out), AZ_E_ALIGN);
+  const int64_t strides[] = {a->q_bstride, a->q_tstride, a->q_hstride, a->k_bstride, a->k_tstride, a->k_hstride,
+                             a->v_bstride, a->v_tstride, a->v_hstride, a->o_bstride, a->o_tstride, a->o_hstride};
+  for (int64_t s : strides) AZ_REQUIRE(s % 4 == 0, AZ_E_ALIGN);
+  dim3 grid((unsigned)((a->tokens + QT - 1) / QT), (unsigned)(a->batch * a->heads));
+  hipStream_t st = az_s(stream);
+  switch (a->head_dim) {
+    case 16: hipLaunchKernelGGL(attention_kernel<16>, grid, dim3(256), 0, st, *a); break;
+    case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, st, *a); break;
+    case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, st, *a); break;
+    default: hipLaunchKernelGGL(attention_kernel<128>, grid, dim3(256), 0, st, *a); break;
+  }
+  return az_launch_status();
+}
+
+int az_patchify_f32(float* dst, const float* src, const float* scale_dev, int64_t B, int64_t Z, int64_t H, int64_t W,
+                    int64_t p, int64_t cs, az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(B > 0 && Z > 0 && p > 0 && H % p == 0 && W % p == 0 && cs >= Z * p * p, AZ_E_SHAPE);
+  const int64_t total = B * (H / p) * (W / p) * cs;
+  hipLaunchKernelGGL(patchify_kernel, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream), dst, src, scale_dev,
+                     B, (int)Z, (int)H, (int)W, (int)p, (int)cs);
+  return az_launch_status();
+}
+
+int az_unpatchify_f32(float* dst, const float* src, int64_t B, int64_t Z, int64_t H, int64_t W, int64_t p, int64_t cs,
+                      az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(B > 0 && Z > 0 && p > 0 && H % p == 0 && W % p == 0 && cs >= Z * p * p, AZ_E_SHAPE);
+  hipLaunchKernelGGL(unpatchify_kernel, dim3(az_stream_grid(B * Z * H * W, 256)), dim3(256), 0, az_s(stream), dst, src,
+                     B, (int)Z, (int)H, (int)W, (int)p, (int)cs);
+  return az_launch_status();
+}
+
+}  // extern "C"

@@ -88,7 +88,7 @@ __device__ __forceinline__ void epilogue_store(const AzConvArgs& a, int n, int c
       const int oh = rem / a.wout, ow = rem - oh * a.wout;
       rp = ((int64_t)b * a.hres + (oh >> 1)) * a.wres + (ow >> 1);
     } else {
-      rp = n;
+      rp = a.res_bcast ? rem : n;
     }
     const float4 r = ld4(a.res + rp * a.cout_s + co);
     v.x += r.x;

@@ -224,6 +224,9 @@ class Builder:
             a.gate = gate.data_ptr() + 4 * gate_off
             a.gate_bstride = gate_bstride
         if res is not None:
+            if hasattr(res, "act"):  # batch-shared residual (positional embedding table)
+                res = res.act
+                a.res_bcast = 1
             a.res, a.res_up, a.hres, a.wres = res.ptr, res_up, res.H, res.W
             assert res.cs == a.cout_s
         out = None
@@ -303,3 +306,40 @@ def transition_args(**kw) -> AzTransitionArgs:
 
 def inf() -> float:
     return math.inf
+
+
+# ------------------------------------------------------------------------------- token-path helpers
+def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool, scale: float, eps: float = 1e-5) -> Act:
+    r"""softmax(q k^T * scale) v over a fused-QKV token tensor (B, L, 1, 3*heads*dim).
+
+    order: "nHC" = azula '(n H C)' (attention.py:90), "H3C" = ADM legacy (unet.py:338),
+    "3HC" = ADM new order (unet.py:371).  Output (B, L, 1, heads*dim) laid out '(H C)'."""
+    from ._lib import AzAttnArgs
+
+    Cq = qkv.C // 3
+    dim = Cq // heads
+    assert qkv.cs == qkv.C and dim * heads == Cq
+    L = qkv.H * qkv.W
+    out = self.new_act(qkv.B, qkv.H, qkv.W, Cq)
+    a = AzAttnArgs()
+    base = qkv.ptr
+    if order in ("nHC", "3HC"):
+        offs, hs = (0, Cq, 2 * Cq), dim
+    elif order == "H3C":
+        offs, hs = (0, dim, 2 * dim), 3 * dim
+    else:
+        raise ValueError(order)
+    a.q, a.k, a.v, a.out = base + 4 * offs[0], base + 4 * offs[1], base + 4 * offs[2], out.ptr
+    a.batch, a.heads, a.tokens, a.head_dim = qkv.B, heads, L, dim
+    for n in ("q", "k", "v"):
+        setattr(a, n + "_bstride", L * qkv.cs)
+        setattr(a, n + "_tstride", qkv.cs)
+        setattr(a, n + "_hstride", hs)
+    a.o_bstride, a.o_tstride, a.o_hstride = L * out.cs, out.cs, dim
+    a.scale, a.qk_rmsnorm, a.eps = scale, int(qk_rmsnorm), eps
+    a._flops = 4 * qkv.B * heads * L * L * dim
+    self.tape.add("az_attention_f32", C.byref(a), keep=[a])
+    return out
+
+
+Builder.attention = _builder_attention

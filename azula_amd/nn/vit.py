@@ -1,0 +1,361 @@
+r"""DiT / ViT backbones executed by gfx950 kernels -- drop-ins for ``azula.nn.dit`` / ``azula.nn.vit``.
+
+Same constructors and ``state_dict`` keys as the reference (``azula/nn/dit.py:24-218``,
+``azula/nn/vit.py:22-108``, ``azula/nn/attention.py:17-108``).  Note the reference's
+block is NOT the standard two-branch DiT: ONE (a, b, c) AdaLN-zero triple per block,
+
+    y = (a + 1) * RMSNorm(x) + b;   y = y + MSA(y);   y = FFN(y);   out = x + c * y   (dit.py:102-110)
+
+Compiled forward (token tensors are "NHWC" images of width 1, so every linear is the MFMA
+implicit GEMM with ksize = 1):
+
+* patchify is an index remap fused with the ``c_in`` pre-scale; ``in_proj`` adds the
+  (batch-shared, precomputed) positional embedding in its epilogue;
+* RMSNorm + modulation is one row-norm pass; q/k RMSNorm and the 1/sqrt(C) scale are folded
+  into the attention kernel's operand loads; ``y + y_proj(att)``, SiLU and ``x + c * ffn`` are
+  GEMM epilogues.
+"""
+
+from __future__ import annotations
+
+import math
+from collections.abc import Sequence
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import _lib
+from ..engine import Act, Builder, pad4
+
+__all__ = ["DiT", "DiTBlock", "MultiheadSelfAttention", "ViT"]
+
+
+class MultiheadSelfAttention(nn.Module):
+    r"""Parameter holder (reference ``azula/nn/attention.py:17-70``): fused ``qkv_proj`` and
+    bias-free ``y_proj``; per-head q/k RMSNorm has no parameters."""
+
+    def __init__(
+        self,
+        channels: int,
+        pos_channels: int = 1,
+        attention_heads: int = 1,
+        qkv_bias: bool = True,
+        qk_norm: bool = True,
+        rope: bool = False,
+        dropout: float | None = None,
+    ) -> None:
+        super().__init__()
+        assert channels % attention_heads == 0
+        if rope:
+            raise NotImplementedError("RoPE is not implemented on the HIP path")
+        self.qkv_proj = nn.Linear(channels, 3 * channels, bias=qkv_bias)
+        self.y_proj = nn.Linear(channels, channels, bias=False)
+        self.heads = attention_heads
+        self.qk_norm = qk_norm
+        self.theta_proj = None
+
+
+class DiTBlock(nn.Module):
+    r"""Parameter holder of a modulated DiT block (reference ``azula/nn/dit.py:24-93``)."""
+
+    def __init__(
+        self,
+        channels: int,
+        mod_features: int = 0,
+        ffn_factor: int = 4,
+        ffn_activation: str = "silu",
+        dropout: float | None = None,
+        checkpointing: bool = False,
+        **kwargs,
+    ) -> None:
+        super().__init__()
+        if ffn_activation != "silu":
+            raise NotImplementedError(f"ffn_activation='{ffn_activation}' is not implemented on the HIP path")
+        self.channels, self.mod_features = channels, mod_features
+        if mod_features > 0:
+            self.ada_zero = nn.Sequential(
+                nn.Linear(mod_features, mod_features), nn.SiLU(), nn.Linear(mod_features, 3 * channels), nn.Identity()
+            )
+            self.ada_zero[-2].weight.data.mul_(1e-2)
+        else:
+            self.ada_zero = nn.Parameter(torch.randn(3, channels))
+            self.ada_zero.data.mul_(1e-2)
+        self.msa = MultiheadSelfAttention(channels, **kwargs)
+        self.ffn = nn.Sequential(
+            nn.Linear(channels, ffn_factor * channels),
+            nn.SiLU(),
+            nn.Identity() if dropout is None else nn.Dropout(dropout),
+            nn.Linear(ffn_factor * channels, channels),
+        )
+
+
+def host_sine_encoding(x: Tensor, features: int, omega: float) -> Tensor:
+    r"""sin block || cos block, computed on the host in the reference's op order
+    (``azula/nn/layers.py:286-299``)."""
+    x = x.unsqueeze(dim=-1)
+    freqs = torch.linspace(0, 1, features // 2, dtype=x.dtype)
+    freqs = torch.exp(math.log(1 / omega) * freqs)
+    return torch.cat((torch.sin(x * freqs), torch.cos(x * freqs)), dim=-1)
+
+
+class DiTPlan:
+    r"""Compiled forward for (batch, tokens[, patch geometry], modulation rows)."""
+
+    def __init__(self, net: "DiT", B: int, L: int, pos: Tensor, mod_rows: int, device, patch=None) -> None:
+        bld = self.bld = Builder(device)
+        D, C_ = net.mod_features, net.hid_channels
+        self.mod = torch.empty(max(mod_rows, 1), max(D, 1), dtype=torch.float32, device=device)
+        self.mod_rows = mod_rows
+        self.versions = net._param_versions()
+        cin = net.in_proj.in_features
+        cout = net.out_proj.out_features
+        if patch is not None:
+            Z, H, W, p = patch
+            self.x_nchw = torch.empty(B, Z, H, W, dtype=torch.float32, device=device)
+            tokens = bld.new_act(B, L, 1, cin, pinned=True)
+            bld.tape.add("az_patchify_f32", tokens.ptr, self.x_nchw.data_ptr(), None, B, Z, H, W, p, tokens.cs)
+            self.x_in_buf, self.x_in_cs = self.x_nchw, 0
+        else:
+            tokens = bld.new_act(B, L, 1, cin, pinned=True)
+            self.x_in_buf, self.x_in_cs = tokens.buf, tokens.cs
+        self.tokens = tokens
+
+        # positional embedding table (L, C): host sine encoding -> one GEMM at build time
+        enc = host_sine_encoding(pos.to(torch.float32).cpu(), C_, omega=1e2).flatten(-2)  # (L, P*C)
+        pb = Builder(device)
+        enc_act = Act(enc.to(device).contiguous().reshape(-1), 1, L, 1, enc.shape[1], enc.shape[1], True)
+        ptab = pb.conv(enc_act, pb.pack_conv(net.pos_embedding[2].weight, None), C_)
+        pb.finish()
+        pb.tape.run()
+        self.pos_table = ptab
+        bld.tape.keep.extend([pb, enc_act])
+        ptab.pinned = True
+
+        x = bld.conv(tokens, bld.pack_conv(net.in_proj.weight, net.in_proj.bias), C_, res=_bcast(ptab))
+        for blk in net.blocks:
+            cs = pad4(C_)
+            if blk.mod_features > 0:
+                rows = mod_rows
+                h = bld.empty(rows, D)
+                abc = bld.empty(rows, 3 * cs)
+                l0, l2 = blk.ada_zero[0], blk.ada_zero[2]
+                w2 = torch.zeros(3 * cs, D, dtype=torch.float32, device=device)
+                b2 = torch.zeros(3 * cs, dtype=torch.float32, device=device)
+                for n in range(3):
+                    w2[n * cs : n * cs + C_] = l2.weight.detach()[n * C_ : (n + 1) * C_]
+                    b2[n * cs : n * cs + C_] = l2.bias.detach()[n * C_ : (n + 1) * C_]
+                bld.linear_small(h, D, self.mod, D, bld.const(l0.weight), bld.const(l0.bias), rows, D, D, 0, 1)
+                bld.linear_small(abc, 3 * cs, h, D, bld.const(w2), bld.const(b2), rows, 3 * cs, D, 0, 0)
+                bstride = 3 * cs if rows > 1 else 0
+            else:
+                abc = torch.zeros(3 * cs, dtype=torch.float32, device=device)
+                for n in range(3):
+                    abc[n * cs : n * cs + C_] = blk.ada_zero.detach()[n]
+                abc = bld.const(abc)
+                bstride = 0
+            y = bld.row_norm(x, 1, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
+            msa = blk.msa
+            qkv = bld.conv(y, bld.pack_conv(msa.qkv_proj.weight, msa.qkv_proj.bias), 3 * C_)
+            dim = C_ // msa.heads
+            att = bld.attention(qkv, msa.heads, "nHC", msa.qk_norm, 1.0 / math.sqrt(dim))
+            bld.free(qkv)
+            y2 = bld.conv(att, bld.pack_conv(msa.y_proj.weight, None), C_, res=y)
+            bld.free(att)
+            bld.free(y)
+            f0, f3 = blk.ffn[0], blk.ffn[3]
+            f1 = bld.conv(y2, bld.pack_conv(f0.weight, f0.bias), f0.out_features, act=1)
+            bld.free(y2)
+            out = bld.conv(f1, bld.pack_conv(f3.weight, f3.bias), C_, gate=abc, gate_off=2 * cs, gate_bstride=bstride, res=x)
+            bld.free(f1)
+            bld.free(x)
+            x = out
+        o = bld.conv(x, bld.pack_conv(net.out_proj.weight, net.out_proj.bias), cout)
+        bld.free(x)
+        if patch is not None:
+            Z, H, W, p = patch
+            Zo = cout // (p * p)
+            self.out = torch.empty(B, Zo, H, W, dtype=torch.float32, device=device)
+            bld.tape.add("az_unpatchify_f32", self.out.data_ptr(), o.ptr, B, Zo, H, W, p, o.cs)
+            self.out_tokens = None
+        else:
+            self.out, self.out_tokens = None, o
+        bld.finish()
+        self.tape = bld.tape
+
+
+class _Bcast:
+    r"""Marks a residual Act as batch-shared (conv epilogue ``res_bcast``)."""
+
+    def __init__(self, act: Act) -> None:
+        self.act = act
+
+
+def _bcast(a: Act) -> "_Bcast":
+    return _Bcast(a)
+
+
+class DiT(nn.Module):
+    r"""Modulated DiT-like module on token tensors (reference ``azula/nn/dit.py:135-218``)."""
+
+    def __init__(
+        self,
+        in_channels: int,
+        out_channels: int,
+        cond_channels: int = 0,
+        mod_features: int = 0,
+        pos_channels: int = 1,
+        hid_channels: int = 1024,
+        hid_blocks: int = 3,
+        **kwargs,
+    ) -> None:
+        super().__init__()
+        self.mod_features, self.hid_channels, self.pos_channels = mod_features, hid_channels, pos_channels
+        self.cond_channels = cond_channels
+        self.in_proj = nn.Linear(in_channels + cond_channels, hid_channels)
+        self.out_proj = nn.Linear(hid_channels, out_channels)
+        self.pos_embedding = nn.Sequential(
+            nn.Identity(), nn.Identity(), nn.Linear(pos_channels * hid_channels, hid_channels, bias=False)
+        )
+        self.pos_embedding[-1].weight.data.mul_(1e-2)
+        self.blocks = nn.ModuleList([
+            DiTBlock(channels=hid_channels, pos_channels=pos_channels, mod_features=mod_features, **kwargs)
+            for _ in range(hid_blocks)
+        ])
+        self._plans: dict = {}
+
+    def _param_versions(self) -> tuple:
+        return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+
+    def _check_device(self, x: Tensor) -> None:
+        if not x.is_cuda:
+            raise RuntimeError(
+                f"azula_amd.nn.{type(self).__name__} executes only on an AMD GPU (gfx950 HIP kernels); "
+                "there is no CPU fallback."
+            )
+        p = next(self.parameters())
+        if p.device != x.device or p.dtype != torch.float32 or x.dtype != torch.float32:
+            raise RuntimeError("azula_amd backbones need fp32 parameters and inputs on the same GPU")
+
+    def _mod_rows(self, mod, B: int) -> int:
+        if self.mod_features == 0:
+            return 0
+        assert mod is not None, "this network is modulated: pass mod"
+        rows = 1 if mod.ndim == 1 else mod.shape[0]
+        assert rows in (1, B)
+        return rows
+
+    def _get_plan(self, key, make):
+        p = self._plans.get(key)
+        if p is None or p.versions != self._param_versions():
+            p = make()
+            self._plans[key] = p
+        return p
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, mod: Tensor | None = None, pos: Tensor | None = None, cond: Tensor | None = None):
+        r"""x: (B, L, C_i) tokens -> (B, L, C_o).  ``pos``: (L, P) or None (sequence indices)."""
+        self._check_device(x)
+        if cond is not None:
+            x = torch.cat((x, cond), dim=-1)
+        assert x.ndim == 3, "DiT.forward expects (B, L, C) tokens"
+        x = x.contiguous()
+        B, L, Cin = x.shape
+        rows = self._mod_rows(mod, B)
+        if pos is None:
+            pos_h = torch.arange(L, dtype=torch.float32)[:, None]
+            pkey = None
+        else:
+            pos_h = pos.detach().to("cpu", torch.float32).reshape(L, -1)
+            pkey = hash(pos_h.numpy().tobytes())
+        plan = self._get_plan((B, L, rows, pkey, str(x.device)), lambda: DiTPlan(self, B, L, pos_h, rows, x.device))
+        t = plan.tokens
+        if t.cs == Cin:
+            t.buf.copy_(x.reshape(-1))
+        else:
+            t.buf.zero_()
+            t.buf.view(B * L, t.cs)[:, :Cin].copy_(x.reshape(B * L, Cin))
+        if rows:
+            plan.mod.copy_(mod.to(torch.float32).reshape(rows, -1))
+        plan.tape.run()
+        o = plan.out_tokens
+        return o.buf.view(B, L, o.cs)[..., : o.C].clone()
+
+
+class ViT(DiT):
+    r"""Modulated ViT-like module on images (reference ``azula/nn/vit.py:22-108``)."""
+
+    def __init__(
+        self,
+        in_channels: int,
+        out_channels: int,
+        cond_channels: int = 0,
+        mod_features: int = 0,
+        hid_channels: int = 1024,
+        hid_blocks: int = 3,
+        spatial: int = 2,
+        patch_size: int | Sequence[int] = 1,
+        unpatch_size: int | Sequence[int] | None = None,
+        **kwargs,
+    ) -> None:
+        if spatial != 2:
+            raise NotImplementedError("azula_amd.nn.ViT implements spatial=2 only")
+        if isinstance(patch_size, int):
+            patch_size = [patch_size] * spatial
+        if unpatch_size is None:
+            unpatch_size = patch_size
+        elif isinstance(unpatch_size, int):
+            unpatch_size = [unpatch_size] * spatial
+        if len(set(patch_size)) != 1 or list(unpatch_size) != list(patch_size):
+            raise NotImplementedError("square patches with unpatch_size == patch_size only")
+        if cond_channels:
+            raise NotImplementedError("cond_channels is not implemented on the HIP path")
+        p = patch_size[0]
+        super().__init__(
+            in_channels=p * p * in_channels, out_channels=p * p * out_channels, cond_channels=0,
+            mod_features=mod_features, pos_channels=spatial, hid_channels=hid_channels, hid_blocks=hid_blocks, **kwargs,
+        )
+        self.patch_size = p
+        self.image_in, self.image_out = in_channels, out_channels
+        self.spatial = spatial
+
+    def _vit_plan(self, B: int, H: int, W: int, rows: int, device) -> DiTPlan:
+        p = self.patch_size
+        Hp, Wp = H // p, W // p
+        pos = torch.cartesian_prod(torch.arange(Hp, dtype=torch.float32), torch.arange(Wp, dtype=torch.float32))
+        pos = pos.reshape(-1, 2)
+        return self._get_plan(
+            ("vit", B, H, W, rows, str(device)),
+            lambda: DiTPlan(self, B, Hp * Wp, pos, rows, device, patch=(self.image_in, H, W, p)),
+        )
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, mod: Tensor | None = None, cond: Tensor | None = None) -> Tensor:
+        r"""x: (B, C_i, H, W); mod: (D) or (B, D) -> (B, C_o, H, W)."""
+        self._check_device(x)
+        assert cond is None, "cond is not implemented on the HIP path"
+        B, Z, H, W = x.shape
+        assert Z == self.image_in and H % self.patch_size == 0 and W % self.patch_size == 0
+        rows = self._mod_rows(mod, B)
+        plan = self._vit_plan(B, H, W, rows, x.device)
+        plan.x_nchw.copy_(x)
+        if rows:
+            plan.mod.copy_(mod.to(torch.float32).reshape(rows, -1))
+        plan.tape.run()
+        return plan.out.clone()
+
+    # -- fused sampling ---------------------------------------------------------------------------
+    def _az_compile_modulated(self, x: Tensor, mod_rows: int = 1):
+        from ..sample import BackboneProgram
+        from .unet import _copy_tape
+
+        if self.mod_features == 0 or x.ndim != 4:
+            return None
+        self._check_device(x)
+        B, _, H, W = x.shape
+        plan = self._vit_plan(B, H, W, mod_rows, x.device)
+        prog = BackboneProgram(
+            tape=_copy_tape(plan.tape), x_in=plan.x_nchw, x_in_cs=0, out=plan.out, f_channels=self.image_out, f_nhwc=False
+        )
+        prog.tape.keep.append(plan)
+        return prog, plan.mod

@@ -198,6 +198,7 @@ typedef struct AzConvArgs {
   const float* res;        /* optional residual, NHWC (B, hres, wres, cout_s) */
   int32_t res_up;          /* 1: residual is read through nearest x2 upsampling (ADM up block) */
   int32_t hres, wres;
+  int32_t res_bcast;       /* 1: residual is (hout, wout, cout_s), shared by the batch (positional embedding) */
   float* dst;              /* NHWC (B, hout, wout, cout_s), or NCHW (B, dst_c, hout, wout) */
   int32_t dst_nchw;        /* 1: write NCHW with dst_c real channels */
   int32_t dst_c;
@@ -212,6 +213,37 @@ int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_
  * (two-source concat with padded strides).  Runs on the device.                               */
 int az_pack_conv_weight_f32(float* dst, const float* src, int32_t cout, int32_t cin, int32_t ks, int32_t cout_s,
                             int32_t cin0, int32_t c0s, int32_t cin_s, az_stream_t stream);
+
+/* ------------------------------------------------------------------ K4: multi-head self-attention
+ * out[b, t, h, :] = softmax_s( scale * <q[b,t,h,:], k[b,s,h,:]> ) v[b,s,h,:], fp32 softmax, flash-style.
+ * Element (b, t, h, c) of q is at q + b*q_bstride + t*q_tstride + h*q_hstride + c (c contiguous);
+ * likewise k, v, out -- so one kernel serves the fused-QKV layouts of
+ *   azula/nn/attention.py:89-104   '(n H C)' + per-head q/k RMSNorm (qk_rmsnorm = 1) + SDPA (scale = C^-1/2),
+ *   plugins/adm/_src/unet.py:338-345  legacy '(H 3 C)' order, scale = C^-1/4 on q and k (pass C^-1/2),
+ *   plugins/adm/_src/unet.py:371-379  new '(3 H C)' order.
+ * head_dim in {16, 32, 64, 128}; all strides multiples of 4 floats.                               */
+typedef struct AzAttnArgs {
+  const float* q;
+  const float* k;
+  const float* v;
+  float* out;
+  int32_t batch, heads, tokens, head_dim;
+  int64_t q_bstride, q_tstride, q_hstride;
+  int64_t k_bstride, k_tstride, k_hstride;
+  int64_t v_bstride, v_tstride, v_hstride;
+  int64_t o_bstride, o_tstride, o_hstride;
+  float scale;
+  int32_t qk_rmsnorm; /* 1: q and k rows are RMS-normalised (eps) before the dot product */
+  float eps;
+} AzAttnArgs;
+int az_attention_f32(const AzAttnArgs* args, az_stream_t stream);
+
+/* Patchify NCHW (B, Z, H, W) -> tokens (B, H/p * W/p, cs), feature = z*p*p + a*p + b, scaled by
+ * *scale_dev (NULL = 1), pad features zero; and back (azula/nn/layers.py:198-247, azula/nn/vit.py:92-106). */
+int az_patchify_f32(float* dst, const float* src, const float* scale_dev, int64_t B, int64_t Z, int64_t H, int64_t W,
+                    int64_t p, int64_t cs, az_stream_t stream);
+int az_unpatchify_f32(float* dst, const float* src, int64_t B, int64_t Z, int64_t H, int64_t W, int64_t p, int64_t cs,
+                      az_stream_t stream);
 
 /* ------------------------------------------------------------------ hipGraph helpers (host side)
  * Capture everything enqueued on `stream` between begin/end into an executable graph.         */

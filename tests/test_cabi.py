@@ -48,7 +48,7 @@ def test_python_prototypes_match_header(built_lib):
 def test_struct_layouts_match_c():
     from azula_amd import _lib
 
-    names = ["AzStepCoef", "AzTransitionArgs", "AzNormFinalizeArgs", "AzConvArgs"]
+    names = ["AzStepCoef", "AzTransitionArgs", "AzNormFinalizeArgs", "AzConvArgs", "AzAttnArgs"]
     prog = '#include <stdio.h>\n#include "azula_amd.h"\nint main(void){' + "".join(
         f'printf("%zu\\n", sizeof({n}));' for n in names
     ) + "return 0;}"

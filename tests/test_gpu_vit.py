@@ -1,0 +1,126 @@
+r"""Attention kernel + ViT/DiT backbone parity on the GPU (oracle / reference golden vectors)."""
+
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import max_err
+from oracle import nets, sampling, synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.mark.parametrize("B,H,T,D", [(2, 4, 16, 16), (1, 2, 64, 32), (2, 3, 256, 64), (1, 2, 100, 64), (1, 1, 1024, 64), (1, 2, 40, 128)])
+@pytest.mark.parametrize("order,rms", [("nHC", True), ("nHC", False), ("H3C", False), ("3HC", False)])
+def test_attention_kernel(B, H, T, D, order, rms):
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(B * T + D)
+    q, k, v = (torch.randn(B, H, T, D, generator=g) for _ in range(3))
+    if order in ("nHC", "3HC"):
+        qkv = torch.stack((q, k, v), dim=0).permute(1, 3, 0, 2, 4).reshape(B, T, 3 * H * D)  # (n H C)
+    else:
+        qkv = torch.stack((q, k, v), dim=2).permute(0, 3, 1, 2, 4).reshape(B, T, 3 * H * D)  # (H 3 C)
+    qn, kn = (F.rms_norm(q, (D,), eps=1e-5), F.rms_norm(k, (D,), eps=1e-5)) if rms else (q, k)
+    ref = F.scaled_dot_product_attention(qn, kn, v)  # default scale 1/sqrt(D)
+    ref = ref.transpose(1, 2).reshape(B, T, H * D)
+    bld = Builder(torch.device("cuda"))
+    act = Act(qkv.cuda().contiguous().reshape(-1), B, T, 1, 3 * H * D, 3 * H * D, True)
+    out = bld.attention(act, H, order, rms, 1.0 / math.sqrt(D))
+    bld.tape.run()
+    got = out.buf.reshape(B, T, H * D)
+    assert max_err(got, ref) < 2e-5, max_err(got, ref)
+
+
+def test_attention_spiked_scores():
+    """Online-softmax rescale path: one key dominates from a late tile (guide rule 26)."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(0)
+    B, H, T, D = 1, 1, 256, 64
+    q, k, v = (torch.randn(B, H, T, D, generator=g) for _ in range(3))
+    k[0, 0, 200] = 6.0 * q[0, 0, 3]  # spike in the 4th key tile for query 3
+    qkv = torch.stack((q, k, v), dim=0).permute(1, 3, 0, 2, 4).reshape(B, T, 3 * D)
+    ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).float().transpose(1, 2).reshape(B, T, D)
+    bld = Builder(torch.device("cuda"))
+    out = bld.attention(Act(qkv.cuda().contiguous().reshape(-1), B, T, 1, 3 * D, 3 * D, True), 1, "nHC", False, 1 / 8.0)
+    bld.tape.run()
+    assert max_err(out.buf.reshape(B, T, D), ref) < 2e-5
+
+
+def test_patchify_roundtrip():
+    from azula_amd import _lib
+
+    x = torch.randn(2, 3, 8, 12, device="cuda")
+    p, cs = 2, 12
+    tok = torch.empty(2, 4 * 6, cs, device="cuda")
+    _lib.call("az_patchify_f32", tok.data_ptr(), x.data_ptr(), None, 2, 3, 8, 12, p, cs, _lib.stream_ptr())
+    ref = x.reshape(2, 3, 4, p, 6, p).permute(0, 2, 4, 1, 3, 5).reshape(2, 24, 12)
+    assert torch.equal(tok, ref)
+    back = torch.empty_like(x)
+    _lib.call("az_unpatchify_f32", back.data_ptr(), tok.data_ptr(), 2, 3, 8, 12, p, cs, _lib.stream_ptr())
+    assert torch.equal(back, x)
+
+
+def build_vit(cfg):
+    from azula_amd.nn import ViT
+
+    return ViT(
+        cfg["in_channels"], cfg["out_channels"], hid_channels=cfg["hid_channels"], hid_blocks=cfg["hid_blocks"],
+        attention_heads=cfg["attention_heads"], patch_size=cfg["patch_size"], mod_features=cfg["mod_features"],
+    )
+
+
+def test_vit_forward_matches_reference(golden):
+    g = golden("g5_vit")
+    cfg = g.meta["cfg"]
+    net = build_vit(cfg)
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v) for k, v in g.meta["shapes"].items()}
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"]))
+    net = net.cuda().eval()
+    x = g["x"].cuda()
+    for tag in ("modB", "mod1"):
+        y = net(x, g[tag].cuda())
+        err, sc = max_err(y, g["y_" + tag]), g["y_" + tag].abs().max().item()
+        print("vit", tag, "max|d|", err, "scale", sc)
+        assert err < 1e-4 * max(1.0, sc)
+
+
+def test_dit_token_forward_matches_oracle(golden):
+    from azula_amd.nn import DiT
+
+    g = golden("g5_vit")
+    shapes = {k: tuple(v) for k, v in g.meta["shapes"].items()}
+    shapes["pos_embedding.2.weight"] = (64, 64)  # pos_channels = 1 for the plain DiT
+    sd = synth.synth_state_dict(shapes, 17)
+    net = DiT(16, 16, mod_features=32, hid_channels=64, hid_blocks=2, attention_heads=4)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    gen = torch.Generator().manual_seed(5)
+    x, mod = torch.randn(2, 24, 16, generator=gen), torch.randn(2, 32, generator=gen)
+    ref = nets.dit_forward(sd, dict(hid_channels=64, hid_blocks=2, attention_heads=4), x, mod)
+    y = net(x.cuda(), mod.cuda())
+    assert max_err(y, ref) < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_vit_ddim50_fused_matches_reference(golden):
+    from azula_amd.denoise import KarrasDenoiser
+    from azula_amd.nn import TimeModulated
+    from azula_amd.noise import VPSchedule
+    from azula_amd.sample import DDIMSampler
+
+    g = golden("g6_vit_loop")
+    cfg = g.meta["cfg"]
+    w = TimeModulated(build_vit(cfg), cfg["mod_features"], name="vit")
+    w.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"]))
+    den = KarrasDenoiser(w, VPSchedule()).cuda().eval()
+    smp = DDIMSampler(den, steps=50, silent=True)
+    x0 = smp(g["x1"].cuda())
+    assert next(iter(smp._fused_cache.values())).graph is not None
+    err, sc = max_err(x0, g["ddim50"]), g["ddim50"].abs().max().item()
+    print("ViT DDIM-50 fused max|d| vs reference:", err, "scale", sc)
+    assert err < 5e-4 * max(1.0, sc)
