@@ -161,15 +161,16 @@ PROTOTYPES: dict[str, list] = {
     "az_transition_f32": [C.POINTER(AzTransitionArgs), c_stream],
     "az_scale_f32": [vp, vp, vp, i64, c_stream],
     "az_axpby_f32": [vp, vp, vp, vp, vp, i64, i64, i32, c_stream],
+    "az_cfg_combine_f32": [vp, vp, vp, vp, i64, c_stream],
     "az_nchw_to_nhwc_f32": [vp, vp, vp, i64, i64, i64, i64, c_stream],
     "az_nhwc_to_nchw_f32": [vp, vp, i64, i64, i64, i64, c_stream],
     "az_linear_small_f32": [vp, i64, vp, i64, vp, vp, i64, i64, i64, i32, i32, c_stream],
     "az_gather_rows_f32": [vp, vp, vp, i64, i64, i64, c_stream],
     "az_gather_step_row_f32": [vp, vp, vp, i32, i64, i64, c_stream],
     "az_coef_c_time_f32": [vp, vp, c_stream],
-    "az_groupnorm_stats_f32": [vp, vp, i64, i64, i64, i64, i32, i32, c_stream],
+    "az_groupnorm_stats_f32": [vp, vp, vp, i64, i64, i64, i64, i64, i32, i32, c_stream],
     "az_groupnorm_finalize_f32": [C.POINTER(AzNormFinalizeArgs), c_stream],
-    "az_affine_act_f32": [vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, c_stream],
+    "az_affine_act_f32": [vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, i32, i32, c_stream],
     "az_rownorm_mod_f32": [vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, c_stream],
     "az_conv2d_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_suggest_splitk": [i64, i32, i32, i32],

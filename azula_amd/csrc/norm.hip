@@ -31,8 +31,11 @@ __device__ __forceinline__ Moments combine(Moments a, Moments b) {
 
 // Fast path: group size Cg % 4 == 0 and the slice of `qs` float4 channel-chunks divides 256.
 // grid = (nchunks, B, slices); slice z covers float4 chunks [z*256, z*256 + qs).
+// Two-source form: logical channels [0, c0s) live in x (stride c0s), [c0s, cs) in x1 (stride cs - c0s):
+// the skip concatenation of the ADM decoder (plugins/adm/_src/unet.py:631) is never materialised.
 __global__ __launch_bounds__(256) void gn_stats_vec_kernel(float* __restrict__ partials,
-                                                           const float* __restrict__ x, int64_t HW, int C,
+                                                           const float* __restrict__ x,
+                                                           const float* __restrict__ x1, int c0s, int64_t HW, int C,
                                                            int cs, int groups, int nchunks, int qs) {
   __shared__ float sh_n[256], sh_mean[256], sh_m2[256];
   __shared__ int sh_g[256];
@@ -49,10 +52,12 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(float* __restrict__ p
   const bool live = c < C;
   float s1 = 0.f, s2 = 0.f, cnt = 0.f, shift = 0.f;
   if (live) {
-    const float* base = x + ((int64_t)b * HW) * cs + c;
+    const bool second = x1 != nullptr && c >= c0s;
+    const int scs = x1 == nullptr ? cs : (second ? cs - c0s : c0s);
+    const float* base = (second ? x1 : x) + ((int64_t)b * HW) * scs + (second ? c - c0s : c);
     bool first = true;
     for (int64_t p = p0 + pl; p < p1; p += ppi) {
-      const float4 v = *reinterpret_cast<const float4*>(base + p * cs);
+      const float4 v = *reinterpret_cast<const float4*>(base + p * scs);
       if (first) {
         shift = v.x;
         first = false;
@@ -91,8 +96,9 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(float* __restrict__ p
 
 // Generic path (any C / groups): grid = (nchunks, B, groups), scalar loads.
 __global__ __launch_bounds__(256) void gn_stats_generic_kernel(float* __restrict__ partials,
-                                                               const float* __restrict__ x, int64_t HW, int C,
-                                                               int cs, int groups, int nchunks) {
+                                                               const float* __restrict__ x,
+                                                               const float* __restrict__ x1, int c0s, int64_t HW,
+                                                               int C, int cs, int groups, int nchunks) {
   __shared__ float sh_n[256], sh_mean[256], sh_m2[256];
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, b = blockIdx.y, g = blockIdx.z;
@@ -106,7 +112,9 @@ __global__ __launch_bounds__(256) void gn_stats_generic_kernel(float* __restrict
   for (int64_t e = tid; e < total; e += 256) {
     const int64_t p = p0 + e / Cg;
     const int c = g * Cg + (int)(e % Cg);
-    const float v = x[((int64_t)b * HW + p) * cs + c];
+    float v;
+    if (x1 != nullptr && c >= c0s) v = x1[((int64_t)b * HW + p) * (cs - c0s) + (c - c0s)];
+    else v = x[((int64_t)b * HW + p) * (x1 != nullptr ? c0s : cs) + c];
     if (first) {
       shift = v;
       first = false;
@@ -180,8 +188,16 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(AzNormFinalizeArgs a) {
   }
 }
 
+__device__ __forceinline__ float4 ld_cat(const float* __restrict__ x, const float* __restrict__ x1, int c0s, int cs,
+                                         int64_t pix, int c) {
+  if (x1 == nullptr) return *reinterpret_cast<const float4*>(x + pix * cs + c);
+  if (c < c0s) return *reinterpret_cast<const float4*>(x + pix * c0s + c);
+  return *reinterpret_cast<const float4*>(x1 + pix * (cs - c0s) + (c - c0s));
+}
+
 template <int ACT>
 __global__ __launch_bounds__(256) void affine_act_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                         const float* __restrict__ x1, int c0s,
                                                          const float* __restrict__ S, const float* __restrict__ T,
                                                          int64_t B, int64_t HW, int cs) {
   const int q = cs / 4;
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(float* __restrict__ y, 
        e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = e / per_b;
     const int c4 = (int)(e % q);
-    const float4 v = reinterpret_cast<const float4*>(x)[e];
+    const float4 v = ld_cat(x, x1, c0s, cs, e / q, c4 * 4);
     const float4 s = *reinterpret_cast<const float4*>(S + b * cs + c4 * 4);
     const float4 t = *reinterpret_cast<const float4*>(T + b * cs + c4 * 4);
     float4 o;
@@ -211,6 +227,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(float* __restrict__ y, 
 
 template <int ACT>
 __global__ __launch_bounds__(256) void affine_act_pool_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                              const float* __restrict__ x1, int c0s,
                                                               const float* __restrict__ S,
                                                               const float* __restrict__ T, int64_t B, int H, int W,
                                                               int cs) {
@@ -233,7 +250,7 @@ __global__ __launch_bounds__(256) void affine_act_pool_kernel(float* __restrict_
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
         const int64_t pix = (b * H + (2 * oh + dy)) * W + (2 * ow + dx);
-        const float4 v = *reinterpret_cast<const float4*>(x + pix * cs + c4 * 4);
+        const float4 v = ld_cat(x, x1, c0s, cs, pix, c4 * 4);
         float4 o;
         o.x = fmaf(v.x, s.x, t.x);
         o.y = fmaf(v.y, s.y, t.y);
@@ -324,9 +341,10 @@ __global__ __launch_bounds__(256) void rownorm_mod_kernel(float* __restrict__ y,
 
 extern "C" {
 
-int az_groupnorm_stats_f32(float* partials, const float* x, int64_t B, int64_t HW, int64_t C, int64_t cs,
-                           int32_t groups, int32_t nchunks, az_stream_t stream) {
+int az_groupnorm_stats_f32(float* partials, const float* x, const float* x1, int64_t c0s, int64_t B, int64_t HW,
+                           int64_t C, int64_t cs, int32_t groups, int32_t nchunks, az_stream_t stream) {
   AZ_REQUIRE(partials && x, AZ_E_NULL);
+  if (x1) AZ_REQUIRE(c0s > 0 && c0s < cs && c0s % 4 == 0 && C == cs && AZ_ALIGNED16(x1), AZ_E_SHAPE);
   AZ_REQUIRE(B > 0 && HW > 0 && C > 0 && cs >= C && cs % 4 == 0 && groups > 0 && C % groups == 0 && nchunks > 0,
              AZ_E_SHAPE);
   AZ_REQUIRE(AZ_ALIGNED16(x), AZ_E_ALIGN);
@@ -336,12 +354,12 @@ int az_groupnorm_stats_f32(float* partials, const float* x, int64_t B, int64_t H
   const bool fast = (Cg % 4 == 0) && (256 % qs == 0) && (q <= 256 || (q % 256 == 0 && 1024 % Cg == 0));
   if (fast) {
     dim3 grid((unsigned)nchunks, (unsigned)B, (unsigned)((q + 255) / 256));
-    hipLaunchKernelGGL(gn_stats_vec_kernel, grid, dim3(256), 0, az_s(stream), partials, x, HW, (int)C, (int)cs,
-                       (int)groups, (int)nchunks, qs);
+    hipLaunchKernelGGL(gn_stats_vec_kernel, grid, dim3(256), 0, az_s(stream), partials, x, x1, (int)c0s, HW, (int)C,
+                       (int)cs, (int)groups, (int)nchunks, qs);
   } else {
     dim3 grid((unsigned)nchunks, (unsigned)B, (unsigned)groups);
-    hipLaunchKernelGGL(gn_stats_generic_kernel, grid, dim3(256), 0, az_s(stream), partials, x, HW, (int)C, (int)cs,
-                       (int)groups, (int)nchunks);
+    hipLaunchKernelGGL(gn_stats_generic_kernel, grid, dim3(256), 0, az_s(stream), partials, x, x1, (int)c0s, HW, (int)C,
+                       (int)cs, (int)groups, (int)nchunks);
   }
   return az_launch_status();
 }
@@ -354,9 +372,10 @@ int az_groupnorm_finalize_f32(const AzNormFinalizeArgs* a, az_stream_t stream) {
   return az_launch_status();
 }
 
-int az_affine_act_f32(float* y, const float* x, const float* S, const float* T, int64_t B, int64_t H, int64_t W,
-                      int64_t cs, int32_t act, int32_t pool, az_stream_t stream) {
+int az_affine_act_f32(float* y, const float* x, const float* x1, int64_t c0s, const float* S, const float* T,
+                      int64_t B, int64_t H, int64_t W, int64_t cs, int32_t act, int32_t pool, az_stream_t stream) {
   AZ_REQUIRE(y && x && S && T, AZ_E_NULL);
+  if (x1) AZ_REQUIRE(c0s > 0 && c0s < cs && c0s % 4 == 0 && AZ_ALIGNED16(x1), AZ_E_SHAPE);
   AZ_REQUIRE(B > 0 && H > 0 && W > 0 && cs > 0 && cs % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE(AZ_ALIGNED16(y) && AZ_ALIGNED16(x) && AZ_ALIGNED16(S) && AZ_ALIGNED16(T), AZ_E_ALIGN);
   hipStream_t st = az_s(stream);
@@ -364,17 +383,17 @@ int az_affine_act_f32(float* y, const float* x, const float* S, const float* T, 
     AZ_REQUIRE(H % 2 == 0 && W % 2 == 0, AZ_E_SHAPE);
     const int grid = az_stream_grid(B * (H / 2) * (W / 2) * (cs / 4), 256);
     if (act == 1)
-      hipLaunchKernelGGL(affine_act_pool_kernel<1>, dim3(grid), dim3(256), 0, st, y, x, S, T, B, (int)H, (int)W,
-                         (int)cs);
+      hipLaunchKernelGGL(affine_act_pool_kernel<1>, dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, (int)H,
+                         (int)W, (int)cs);
     else
-      hipLaunchKernelGGL(affine_act_pool_kernel<0>, dim3(grid), dim3(256), 0, st, y, x, S, T, B, (int)H, (int)W,
-                         (int)cs);
+      hipLaunchKernelGGL(affine_act_pool_kernel<0>, dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, (int)H,
+                         (int)W, (int)cs);
   } else {
     const int grid = az_stream_grid(B * H * W * (cs / 4), 256);
     if (act == 1)
-      hipLaunchKernelGGL(affine_act_kernel<1>, dim3(grid), dim3(256), 0, st, y, x, S, T, B, H * W, (int)cs);
+      hipLaunchKernelGGL(affine_act_kernel<1>, dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, H * W, (int)cs);
     else
-      hipLaunchKernelGGL(affine_act_kernel<0>, dim3(grid), dim3(256), 0, st, y, x, S, T, B, H * W, (int)cs);
+      hipLaunchKernelGGL(affine_act_kernel<0>, dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, H * W, (int)cs);
   }
   return az_launch_status();
 }

@@ -236,6 +236,14 @@ __global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ y, const
   }
 }
 
+__global__ __launch_bounds__(256) void cfg_combine_kernel(float* __restrict__ y, const float* __restrict__ pos,
+                                                          const float* __restrict__ neg, const float* __restrict__ g,
+                                                          int64_t n) {
+  const float k = *g;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = az_add(pos[i], az_mul(k, az_sub(pos[i], neg[i])));
+}
+
 __global__ void gather_rows_kernel(float* __restrict__ dst, const float* __restrict__ table,
                                    const int64_t* __restrict__ idx, int64_t nrows, int64_t ncols,
                                    int64_t table_rows) {
@@ -348,6 +356,15 @@ int az_axpby_f32(float* y, const float* a_dev, const float* x, const float* b_de
   AZ_REQUIRE(rows > 0 && inner > 0 && (a_stride == 0 || a_stride == 1), AZ_E_SHAPE);
   hipLaunchKernelGGL(axpby_kernel, dim3(az_stream_grid(rows * inner, 256)), dim3(256), 0, az_s(stream), y, a_dev, x,
                      b_dev, z, rows, inner, a_stride);
+  return az_launch_status();
+}
+
+int az_cfg_combine_f32(float* y, const float* pos, const float* neg, const float* g_dev, int64_t n,
+                       az_stream_t stream) {
+  AZ_REQUIRE(y && pos && neg && g_dev, AZ_E_NULL);
+  AZ_REQUIRE(n > 0, AZ_E_SHAPE);
+  hipLaunchKernelGGL(cfg_combine_kernel, dim3(az_stream_grid(n, 256)), dim3(256), 0, az_s(stream), y, pos, neg, g_dev,
+                     n);
   return az_launch_status();
 }
 

@@ -261,14 +261,20 @@ class Builder:
 
     def group_norm(
         self, x: Act, groups: int, *, weight=None, bias=None, scale=None, shift=None, scale_off=0, shift_off=0,
-        bstride=0, act=0, pool=0, eps=1e-5,
+        bstride=0, act=0, pool=0, eps=1e-5, x1: Act | None = None,
     ) -> Act:
-        r"""y = act((GN(x)*w + b) * (1 + scale) + shift), optionally 2x2 average pooled."""
+        r"""y = act((GN(x)*w + b) * (1 + scale) + shift), optionally 2x2 average pooled.  With ``x1`` the
+        input is the channel concatenation [x | x1], read in place (never materialised)."""
         B, HW = x.B, x.H * x.W
+        x1p, c0s = None, 0
+        if x1 is not None:
+            assert x.C == x.cs and x1.C == x1.cs and (x1.H, x1.W) == (x.H, x.W)
+            x1p, c0s = x1.ptr, x.cs
+            x = Act(x.buf, x.B, x.H, x.W, x.C + x1.C, x.cs + x1.cs, True)
         nchunks = int(min(256, max(1, (HW * x.cs * 4) // 131072)))
         partials = self.empty(B * nchunks * groups * 4)
         S, T = self.empty(B * x.cs), self.empty(B * x.cs)
-        self.tape.add("az_groupnorm_stats_f32", partials.data_ptr(), x.ptr, B, HW, x.C, x.cs, groups, nchunks)
+        self.tape.add("az_groupnorm_stats_f32", partials.data_ptr(), x.ptr, x1p, c0s, B, HW, x.C, x.cs, groups, nchunks)
         f = AzNormFinalizeArgs()
         f.S, f.T, f.partials = S.data_ptr(), T.data_ptr(), partials.data_ptr()
         f.weight = weight.data_ptr() if weight is not None else None
@@ -282,7 +288,9 @@ class Builder:
             y = self.new_act(B, x.H // 2, x.W // 2, x.C)
         else:
             y = self.new_act(B, x.H, x.W, x.C)
-        self.tape.add("az_affine_act_f32", y.ptr, x.ptr, S.data_ptr(), T.data_ptr(), B, x.H, x.W, x.cs, act, pool)
+        self.tape.add(
+            "az_affine_act_f32", y.ptr, x.ptr, x1p, c0s, S.data_ptr(), T.data_ptr(), B, x.H, x.W, x.cs, act, pool
+        )
         return y
 
     def row_norm(self, x: Act, kind: int, *, scale=None, shift=None, scale_off=0, shift_off=0, bstride=0, eps=1e-5):

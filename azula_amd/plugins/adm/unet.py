@@ -1,0 +1,342 @@
+r"""ADM (guided-diffusion) UNet executed by gfx950 kernels.
+
+Parameter layout and ``state_dict`` keys follow guided-diffusion's ``UNetModel`` exactly
+(reference ``azula/plugins/adm/_src/unet.py:387-634``), so OpenAI checkpoints load
+into ``denoiser.backbone`` unchanged.  The modules only hold parameters; the forward is a
+compiled tape on the channel-padded NHWC layout:
+
+* ResBlock (``_src/unet.py:227-247``): GN(32)+SiLU is a stats pass + one fused pass (with the
+  2x2 average pool of ``down`` blocks folded in, ``:133``); nearest x2 of ``up`` blocks is a
+  read-side shift of the conv gather and of the identity residual (``:104-106``); FiLM
+  ``GN(h) * (1 + scale) + shift`` (``:239-243``) is folded into the second GN's scale/shift
+  table; the skip (identity or 1x1 conv, ``:215``) is the conv epilogue's residual;
+* decoder concat ``cat([h, hs.pop()])`` (``:631``) is never materialised: GroupNorm statistics,
+  the normalise pass and the 1x1 skip conv all read the two sources in place;
+* AttentionBlock (``:289-296``): GN -> 1x1 QKV GEMM -> flash attention (legacy ``(H 3 C)`` or new
+  ``(3 H C)`` order, scale folded) -> zero-init 1x1 ``proj_out`` + residual epilogue;
+* the sinusoidal timestep embedding (``_src/nn.py:90-108``) is a host table indexed on the
+  device by the step's ``time_index``.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from ... import _lib
+from ...engine import Act, Builder, pad4
+
+__all__ = ["UNetModel"]
+
+
+def _zero(m: nn.Module) -> nn.Module:
+    for p in m.parameters():
+        p.detach().zero_()
+    return m
+
+
+class ResBlock(nn.Module):
+    r"""Parameter holder: in_layers (GN, SiLU, conv), emb_layers (SiLU, Linear), out_layers
+    (GN, SiLU, Dropout, zero-init conv), skip_connection (reference ``_src/unet.py:140-225``)."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_scale_shift_norm=False, up=False, down=False):
+        super().__init__()
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.up, self.down, self.use_scale_shift_norm = up, down, use_scale_shift_norm
+        oc = self.out_channels
+        self.in_layers = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(), nn.Conv2d(channels, oc, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, 2 * oc if use_scale_shift_norm else oc))
+        self.out_layers = nn.Sequential(
+            nn.GroupNorm(32, oc), nn.SiLU(), nn.Dropout(p=dropout), _zero(nn.Conv2d(oc, oc, 3, padding=1))
+        )
+        self.skip_connection = nn.Identity() if oc == channels else nn.Conv2d(channels, oc, 1)
+
+
+class AttentionBlock(nn.Module):
+    r"""Parameter holder: norm, qkv (Conv1d k=1), zero-init proj_out (reference ``_src/unet.py:250-296``)."""
+
+    def __init__(self, channels, num_heads=1, num_head_channels=-1, use_new_attention_order=False):
+        super().__init__()
+        self.channels = channels
+        self.num_heads = num_heads if num_head_channels == -1 else channels // num_head_channels
+        assert channels % self.num_heads == 0
+        self.new_order = use_new_attention_order
+        self.norm = nn.GroupNorm(32, channels)
+        self.qkv = nn.Conv1d(channels, channels * 3, 1)
+        self.proj_out = _zero(nn.Conv1d(channels, channels, 1))
+
+
+class TimestepEmbedSequential(nn.Sequential):
+    pass
+
+
+def timestep_embedding_table(steps: int, dim: int, max_period: int = 10000) -> Tensor:
+    r"""Rows = embeddings of the integer timesteps 0..steps-1, host fp32, reference op order
+    (``_src/nn.py:90-108``): cos block || sin block."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = torch.arange(steps)[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+class ADMPlan:
+    r"""Compiled forward for (batch, H, W, embedding rows).  ``emb_rows`` = 1 when all samples
+    share the timestep and there are no labels, else the batch size."""
+
+    def __init__(self, net: "UNetModel", B: int, H: int, W: int, emb_rows: int, device, x_in: Act | None = None,
+                 coef_ptr: int | None = None) -> None:
+        bld = self.bld = Builder(device)
+        mc, E = net.model_channels, 4 * net.model_channels
+        self.versions = net._param_versions()
+        self.emb_rows = emb_rows
+        cin = net.in_channels
+        self.x_in = x_in if x_in is not None else Act(
+            torch.empty(B * H * W * pad4(cin), dtype=torch.float32, device=device), B, H, W, cin, pad4(cin), True
+        )
+        self.out = torch.empty(B, net.out_channels, H, W, dtype=torch.float32, device=device)
+        self.table = bld.const(timestep_embedding_table(net.table_steps, mc))
+        self.t_idx = torch.zeros(emb_rows, dtype=torch.int64, device=device)
+        self.labels = torch.zeros(B, dtype=torch.int64, device=device) if net.num_classes is not None else None
+        temb = bld.empty(emb_rows, mc)
+        if coef_ptr is not None:  # fused sampling: row index = the step's time_index, read on the device
+            assert emb_rows == 1 or net.num_classes is not None
+            bld.tape.add("az_gather_step_row_f32", temb.data_ptr(), self.table.data_ptr(), coef_ptr, 0, mc, net.table_steps)
+            trow = 1
+        else:
+            bld.tape.add("az_gather_rows_f32", temb.data_ptr(), self.table.data_ptr(), self.t_idx.data_ptr(), emb_rows, mc, net.table_steps)
+            trow = emb_rows
+        te0, te2 = net.time_embed[0], net.time_embed[2]
+        hid = bld.empty(trow, E)
+        emb = bld.empty(emb_rows, E)
+        bld.linear_small(hid, E, temb, mc, bld.const(te0.weight), bld.const(te0.bias), trow, E, mc, 0, 1)
+        if net.num_classes is None:
+            bld.linear_small(emb, E, hid, E, bld.const(te2.weight), bld.const(te2.bias), trow, E, E, 0, 0)
+        else:  # emb = time_embed(t) + label_emb(y), per sample (_src/unet.py:621-623)
+            tbase = bld.empty(trow, E)
+            bld.linear_small(tbase, E, hid, E, bld.const(te2.weight), bld.const(te2.bias), trow, E, E, 0, 0)
+            lab = bld.empty(B, E)
+            lw = bld.const(net.label_emb.weight)
+            bld.tape.add("az_gather_rows_f32", lab.data_ptr(), lw.data_ptr(), self.labels.data_ptr(), B, E, net.num_classes)
+            ones = bld.const(torch.ones(1))
+            if trow == 1:
+                tb = bld.empty(B, E)
+                bld.tape.add("az_gather_rows_f32", tb.data_ptr(), tbase.data_ptr(), bld.const(torch.zeros(B, dtype=torch.int64)).data_ptr(), B, E, 1)
+                tbase = tb
+            bld.tape.add("az_axpby_f32", emb.data_ptr(), ones.data_ptr(), tbase.data_ptr(), ones.data_ptr(), lab.data_ptr(), 1, B * E, 0)
+        ebs = E if emb_rows > 1 else 0  # batch stride of emb rows
+
+        def resblock(rb: ResBlock, x: Act, x1: Act | None = None) -> Act:
+            r"""x (| x1 concatenated) -> block output.  Does not free its inputs."""
+            oc, ocs = rb.out_channels, pad4(rb.out_channels)
+            gi, ci = rb.in_layers[0], rb.in_layers[2]
+            go, co = rb.out_layers[0], rb.out_layers[3]
+            # FiLM table: emb_layers = SiLU -> Linear(E, 2*oc); (scale | shift) padded to ocs each
+            lin = rb.emb_layers[1]
+            w = torch.zeros(2 * ocs, E, dtype=torch.float32, device=device)
+            b_ = torch.zeros(2 * ocs, dtype=torch.float32, device=device)
+            for n in range(2):
+                w[n * ocs : n * ocs + oc] = lin.weight.detach()[n * oc : (n + 1) * oc]
+                b_[n * ocs : n * ocs + oc] = lin.bias.detach()[n * oc : (n + 1) * oc]
+            film = bld.empty(emb_rows, 2 * ocs)
+            bld.linear_small(film, 2 * ocs, emb, E, bld.const(w), bld.const(b_), emb_rows, 2 * ocs, E, 1, 0)
+            fbs = 2 * ocs if emb_rows > 1 else 0
+            # h = conv(updown(SiLU(GN(x))))
+            n1 = bld.group_norm(x, 32, weight=bld.const(gi.weight), bias=bld.const(gi.bias), act=1, pool=int(rb.down), x1=x1)
+            h = bld.conv(n1, bld.pack_conv(ci.weight, ci.bias), oc, up0=int(rb.up))
+            bld.free(n1)
+            # h = SiLU(GN(h) * (1 + scale) + shift)
+            n2 = bld.group_norm(h, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), scale=film, shift=film,
+                                scale_off=0, shift_off=ocs, bstride=fbs, act=1)
+            bld.free(h)
+            # skip path
+            if rb.down:
+                assert x1 is None
+                ones, zeros = bld.const(torch.ones(B * x.cs)), bld.const(torch.zeros(B * x.cs))
+                xs = bld.new_act(B, x.H // 2, x.W // 2, x.C)
+                bld.tape.add("az_affine_act_f32", xs.ptr, x.ptr, None, 0, ones.data_ptr(), zeros.data_ptr(), B, x.H, x.W, x.cs, 0, 1)
+                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=xs)
+                bld.free(xs)
+            elif rb.up:
+                assert x1 is None
+                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=x, res_up=1)
+            elif isinstance(rb.skip_connection, nn.Identity):
+                assert x1 is None
+                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=x)
+            else:
+                sc = rb.skip_connection
+                skip = bld.conv(x, bld.pack_conv(sc.weight, sc.bias, cin0=x.C if x1 is not None else None), oc, src1=x1)
+                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=skip)
+                bld.free(skip)
+            bld.free(n2)
+            return out
+
+        def attention(ab: AttentionBlock, x: Act) -> Act:
+            Cc = ab.channels
+            n_ = bld.group_norm(x, 32, weight=bld.const(ab.norm.weight), bias=bld.const(ab.norm.bias))
+            tok = Act(n_.buf, B, n_.H * n_.W, 1, Cc, n_.cs, True)
+            qkv = bld.conv(tok, bld.pack_conv(ab.qkv.weight, ab.qkv.bias), 3 * Cc)
+            ch = Cc // ab.num_heads
+            att = bld.attention(qkv, ab.num_heads, "3HC" if ab.new_order else "H3C", False, 1.0 / math.sqrt(ch))
+            bld.free(qkv)
+            xt = Act(x.buf, B, x.H * x.W, 1, Cc, x.cs, True)
+            o = bld.conv(att, bld.pack_conv(ab.proj_out.weight, ab.proj_out.bias), Cc, res=xt)
+            bld.free(att)
+            bld.free(n_)
+            return Act(o.buf, B, x.H, x.W, Cc, o.cs)
+
+        def run(block: nn.Sequential, h: Act, h1: Act | None = None) -> Act:
+            for layer in block:
+                if isinstance(layer, nn.Conv2d):
+                    nh = bld.conv(h, bld.pack_conv(layer.weight, layer.bias), layer.out_channels)
+                elif isinstance(layer, ResBlock):
+                    nh = resblock(layer, h, h1)
+                else:
+                    nh = attention(layer, h)
+                if h1 is None and h not in hs and h is not self.x_in:
+                    bld.free(h)
+                h, h1 = nh, None
+            return h
+
+        hs: list[Act] = []
+        h = self.x_in
+        for block in net.input_blocks:
+            h = run(block, h)
+            hs.append(h)
+        hs_keep = list(hs)
+        h = run(net.middle_block, h)
+        for block in net.output_blocks:
+            skip = hs.pop()
+            nh = run(block, h, skip)
+            if h not in hs_keep:
+                bld.free(h)
+            bld.free(skip)
+            h = nh
+        go, co = net.out[0], net.out[2]
+        n_ = bld.group_norm(h, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), act=1)
+        bld.conv(n_, bld.pack_conv(co.weight, co.bias), net.out_channels, dst_nchw=self.out)
+        bld.finish()
+        self.tape = bld.tape
+
+
+class UNetModel(nn.Module):
+    r"""guided-diffusion ``UNetModel`` (reference ``_src/unet.py:387-634``), gfx950-native forward.
+
+    Supported configuration space = the plugin's cards (``cards.yaml``): ``resblock_updown=True``,
+    ``use_scale_shift_norm=True``, ``dims=2``; anything else raises ``NotImplementedError``.
+    """
+
+    def __init__(
+        self,
+        image_size,
+        in_channels,
+        model_channels,
+        out_channels,
+        num_res_blocks,
+        attention_resolutions,
+        dropout=0,
+        channel_mult=(1, 2, 4, 8),
+        conv_resample=True,
+        dims=2,
+        num_classes=None,
+        use_checkpoint=False,
+        num_heads=1,
+        num_head_channels=-1,
+        num_heads_upsample=-1,
+        use_scale_shift_norm=False,
+        resblock_updown=False,
+        use_new_attention_order=False,
+    ) -> None:
+        super().__init__()
+        if dims != 2 or not resblock_updown or not use_scale_shift_norm:
+            raise NotImplementedError(
+                "the HIP path implements dims=2, resblock_updown=True, use_scale_shift_norm=True (all ADM cards)"
+            )
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        self.image_size, self.in_channels, self.model_channels = image_size, in_channels, model_channels
+        self.out_channels, self.num_classes = out_channels, num_classes
+        self.table_steps = 1000
+        E = model_channels * 4
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, E), nn.SiLU(), nn.Linear(E, E))
+        if num_classes is not None:
+            self.label_emb = nn.Embedding(num_classes, E)
+
+        def res(ch, oc=None, **kw):
+            return ResBlock(ch, E, dropout, out_channels=oc, use_scale_shift_norm=True, **kw)
+
+        def attn(ch, heads):
+            return AttentionBlock(ch, num_heads=heads, num_head_channels=num_head_channels,
+                                  use_new_attention_order=use_new_attention_order)
+
+        ch = int(channel_mult[0] * model_channels)
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(nn.Conv2d(in_channels, ch, 3, padding=1))])
+        chans, ds = [ch], 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [res(ch, int(mult * model_channels))]
+                ch = int(mult * model_channels)
+                if ds in attention_resolutions:
+                    layers.append(attn(ch, num_heads))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(res(ch, ch, down=True)))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = TimestepEmbedSequential(res(ch), attn(ch, num_heads), res(ch))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = chans.pop()
+                layers = [res(ch + ich, int(model_channels * mult))]
+                ch = int(model_channels * mult)
+                if ds in attention_resolutions:
+                    layers.append(attn(ch, num_heads_upsample))
+                if level and i == num_res_blocks:
+                    layers.append(res(ch, ch, up=True))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), _zero(nn.Conv2d(ch, out_channels, 3, padding=1)))
+        self._plans: dict = {}
+
+    def _param_versions(self) -> tuple:
+        return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+
+    def plan(self, B, H, W, emb_rows, device, x_in: Act | None = None, coef_ptr: int | None = None, tag=None) -> ADMPlan:
+        key = (B, H, W, emb_rows, str(device), x_in.ptr if x_in is not None else None, coef_ptr, tag)
+        p = self._plans.get(key)
+        if p is None or p.versions != self._param_versions():
+            p = ADMPlan(self, B, H, W, emb_rows, device, x_in=x_in, coef_ptr=coef_ptr)
+            self._plans[key] = p
+        return p
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, timesteps: Tensor, y: Tensor | None = None) -> Tensor:
+        r"""x: (N, C, H, W); timesteps: (N,) or (1,) integer indices; y: (N,) labels iff class-conditional."""
+        assert (y is not None) == (self.num_classes is not None), (
+            "must specify y if and only if the model is class-conditional"
+        )
+        if not x.is_cuda:
+            raise RuntimeError("azula_amd ADM UNetModel executes only on an AMD GPU (no CPU fallback)")
+        assert x.dtype == torch.float32
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        timesteps = timesteps.reshape(-1)
+        if torch.is_floating_point(timesteps):
+            raise NotImplementedError("fractional timesteps are not implemented (azula passes integer indices)")
+        rows = B if (timesteps.numel() > 1 or self.num_classes is not None) else 1
+        p = self.plan(B, H, W, rows, x.device)
+        s = _lib.stream_ptr()
+        _lib.call("az_nchw_to_nhwc_f32", p.x_in.ptr, x.data_ptr(), None, B, Cin, H * W, p.x_in.cs, s)
+        p.t_idx.copy_(timesteps.to(torch.int64).expand(rows) if timesteps.numel() == 1 else timesteps.to(torch.int64))
+        if y is not None:
+            assert y.shape == (B,)
+            p.labels.copy_(y.to(torch.int64))
+        p.tape.run(s)
+        return p.out.clone()

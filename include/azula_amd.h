@@ -106,6 +106,11 @@ int az_scale_f32(float* y, const float* x, const float* s_dev, int64_t n, az_str
 int az_axpby_f32(float* y, const float* a_dev, const float* x, const float* b_dev, const float* z, int64_t rows,
                  int64_t inner, int32_t a_stride, az_stream_t stream);
 
+/* y = pos + g * (pos - neg), g in device memory: classifier-free guidance outside a fused
+ * sampler (azula/guidance/cfg.py:63-65), same association and rounding as the reference.   */
+int az_cfg_combine_f32(float* y, const float* pos, const float* neg, const float* g_dev, int64_t n,
+                       az_stream_t stream);
+
 /* ------------------------------------------------------------------ layout
  * NCHW (B,C,H,W) -> NHWC with channel stride cs (>= C, multiple of 4), scaled by *scale_dev
  * (NULL = 1).  Pad channels are written as 0.  And back.                                  */
@@ -139,8 +144,10 @@ int az_coef_c_time_f32(float* dst, const AzStepCoef* coef, az_stream_t stream);
  *  (3) az_affine_act_f32: y = act(x*S + T), optionally 2x2 average pooled (ADM Downsample,
  *      _src/unet.py:133).
  * partials: float[B * nchunks * groups * 4].                                                   */
-int az_groupnorm_stats_f32(float* partials, const float* x, int64_t B, int64_t HW, int64_t C, int64_t cs,
-                           int32_t groups, int32_t nchunks, az_stream_t stream);
+/* x1 / c0s: optional second source -- the input is the channel concatenation [x (c0s) | x1 (cs - c0s)]
+ * (ADM decoder: GroupNorm over cat([h, skip]), plugins/adm/_src/unet.py:631,179); NULL / 0 otherwise.  */
+int az_groupnorm_stats_f32(float* partials, const float* x, const float* x1, int64_t c0s, int64_t B, int64_t HW,
+                           int64_t C, int64_t cs, int32_t groups, int32_t nchunks, az_stream_t stream);
 typedef struct AzNormFinalizeArgs {
   float* S;               /* (B, cs) */
   float* T;               /* (B, cs) */
@@ -156,8 +163,8 @@ typedef struct AzNormFinalizeArgs {
 } AzNormFinalizeArgs;
 int az_groupnorm_finalize_f32(const AzNormFinalizeArgs* args, az_stream_t stream);
 /* pool: 0 none, 1 = 2x2 average pool of act(.) (needs H, W even; dst is (B, H/2*W/2, cs)).      */
-int az_affine_act_f32(float* y, const float* x, const float* S, const float* T, int64_t B, int64_t H, int64_t W,
-                      int64_t cs, int32_t act, int32_t pool, az_stream_t stream);
+int az_affine_act_f32(float* y, const float* x, const float* x1, int64_t c0s, const float* S, const float* T,
+                      int64_t B, int64_t H, int64_t W, int64_t cs, int32_t act, int32_t pool, az_stream_t stream);
 
 /* Row norms over the channel axis of an NHWC / token tensor (rows, cs), C real channels:
  *   kind 0: azula layer_norm, UNBIASED variance, no affine (azula/nn/layers.py:152-155);

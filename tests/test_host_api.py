@@ -149,3 +149,45 @@ def test_backbones_fail_loudly_on_cpu():
         net(torch.randn(1, 3, 8, 8), torch.randn(8))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         TimeModulated(net, 8)(torch.randn(1, 3, 8, 8), torch.tensor(0.3))
+
+
+def test_vit_and_adm_state_dicts_match_reference_shapes(golden):
+    from azula_amd.nn import ViT
+    from azula_amd.plugins import adm
+
+    g = golden("g5_vit")
+    cfg = g.meta["cfg"]
+    net = ViT(cfg["in_channels"], cfg["out_channels"], hid_channels=cfg["hid_channels"], hid_blocks=cfg["hid_blocks"],
+              attention_heads=cfg["attention_heads"], patch_size=cfg["patch_size"], mod_features=cfg["mod_features"])
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v) for k, v in g.meta["shapes"].items()}
+    for name in ("adm_uncond", "adm_cond_neworder"):
+        g = golden("g5_" + name)
+        den = adm.make_model(**g.meta["cfg"])
+        assert {k: tuple(v.shape) for k, v in den.backbone.state_dict().items()} == {
+            k: tuple(v) for k, v in g.meta["shapes"].items()
+        }
+        torch.testing.assert_close(den.sigmas, golden("g2_precond")[
+            "adm_sigmas" if g.meta["cfg"]["discrete_schedule"] == "linear" else "adm_sigmas_cosine"], rtol=2e-7, atol=1e-9)
+    # zero-init quirk of the reference is reproduced: random-init eps-hat == 0
+    den = adm.make_model(**golden("g5_adm_uncond").meta["cfg"])
+    assert not den.backbone.out[2].weight.any() and not den.backbone.middle_block[1].proj_out.weight.any()
+
+
+def test_adm_cards_and_hub_layout(tmp_path):
+    from azula_amd import hub
+    from azula_amd.plugins import adm, load_cards
+
+    cards = load_cards(adm)
+    assert list(cards) == ["imagenet_64x64_cond", "imagenet_128x128_cond", "imagenet_256x256", "imagenet_256x256_cond",
+                           "imagenet_512x512_cond", "ffhq_256x256"]
+    c = cards["imagenet_256x256"]
+    assert c.config["num_channels"] == 256 and c.config["channel_mult"] == [1, 1, 2, 2, 4, 4] and c.config["num_classes"] is None
+    hub.set_hub_dir(str(tmp_path))
+    assert hub.cached_path(c.url).endswith("https.openaipublic.blob.core.windows.net.diffusion.jul.2021.256x256_diffusion_uncond.pt")
+    with pytest.raises(FileNotFoundError, match="does not download"):
+        adm.load_model("imagenet_256x256")
+    # adm_coefficients on the host: DDIM-64 indices of the discrete table
+    den = adm.AblatedDenoiser(torch.nn.Identity())
+    a, s = den.schedule(torch.tensor(1.0))
+    co = den.host_coefficients(a, s)
+    assert int(co["time_index"]) == 954 and abs(float(co["c_out"]) + 100) < 1.0
