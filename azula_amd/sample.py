@@ -88,6 +88,7 @@ class Sampler(abc.ABC):
         self.dtype = dtype
         self.device = device
         self.rng_parity = True  # draw one randn per step like the reference even when it is unused
+        self.shard: tuple[int, int] | None = None  # (rank, world): see azula_amd.parallel
         self._fused_cache: dict = {}
 
     @property
@@ -131,6 +132,18 @@ class Sampler(abc.ABC):
     def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
         raise NotImplementedError()
 
+    def _draw_noise(self, like: Tensor, out: Tensor | None = None) -> Tensor:
+        r"""One ``randn_like`` per step, as the reference (``azula/sample.py:214,259``).  When the batch
+        is sharded (``self.shard = (rank, world)``) every rank draws the FULL batch from its
+        identically seeded generator and keeps its slice, so an N-GPU run reproduces the
+        single-device random stream sample for sample."""
+        if self.shard is None:
+            return torch.randn_like(like) if out is None else out.normal_()
+        rank, world = self.shard
+        full = torch.randn((world * like.shape[0], *like.shape[1:]), dtype=like.dtype, device=like.device)
+        mine = full[rank * like.shape[0] : (rank + 1) * like.shape[0]]
+        return mine.contiguous() if out is None else out.copy_(mine)
+
     # ---------------------------------------------------------------------------- shared DDPM/DDIM
     def _tau(self, alpha_t, sigma_t, alpha_s, sigma_s) -> Tensor:
         raise NotImplementedError()
@@ -150,7 +163,7 @@ class Sampler(abc.ABC):
         if not x_t.is_cuda:  # host tensors: reference op sequence
             x_s = alpha_s * q_t.mean
             x_s = x_s + k_x * (x_t - alpha_t * q_t.mean)
-            x_s = x_s + k_eps * torch.randn_like(x_t)
+            x_s = x_s + k_eps * self._draw_noise(x_t)
             return x_s
         require_f32_cuda(x_t, type(self).__name__)
         dev = x_t.device
@@ -164,7 +177,7 @@ class Sampler(abc.ABC):
             row[COEF_FIELDS.index(name)] = v.to(device=dev, dtype=torch.float32)
         x_c = x_t.contiguous()
         mean = q_t.mean.to(x_c).contiguous()
-        eps = torch.randn_like(x_c)
+        eps = self._draw_noise(x_c)
         x_s = torch.empty_like(x_c)
         a = transition_args(
             x_t=x_c.data_ptr(), F=mean.data_ptr(), eps=eps.data_ptr(), x_s=x_s.data_ptr(), batch=1, channels=1,
@@ -283,7 +296,7 @@ class _FusedLoop:
             _lib.call("az_scale_f32", p0.x_in.data_ptr(), self.x.data_ptr(), c_in0.data_ptr(), self.x.numel(), stream)
         for i in s.progress_bar(range(s.steps)):
             if self.eps is not None:
-                self.eps.normal_()  # same generator calls as the reference's randn_like(x_t)
+                s._draw_noise(self.eps, out=self.eps)  # same generator calls as the reference's randn_like(x_t)
             if i == 0 and self.graph is None:
                 self.tape.run(stream)  # first step eagerly (loads code objects), then capture
                 self.graph = StepGraph(self.tape, x.device)

@@ -200,15 +200,14 @@ def main() -> None:
     den = build_denoiser(cfg, device)
     sampler = DDIMSampler(den, steps=cfg["steps"], silent=True)
     B = cfg["batch"]
-    torch.manual_seed(1 + rank)
-    x1 = sampler.init((B, *cfg["shape"]), device=device)  # resident in HBM before timing
-    gathered = torch.empty(world * B, *cfg["shape"], device=device) if world > 1 else None
+    from azula_amd.parallel import init_sharded, sample_sharded
+
+    torch.manual_seed(1)  # same seed on every rank: the full batch is drawn and sliced (parity with 1 GPU)
+    x1 = init_sharded(sampler, (world * B, *cfg["shape"]), device=device)  # resident in HBM before timing
 
     def one_pass():
-        x0 = sampler(x1)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, x0)  # the only collective: final x0
-        return x0
+        # 64 graph replays on this rank's shard, then the only collective: all-gather of x0
+        return sample_sharded(sampler, x1)
 
     def fence():
         if world > 1:
