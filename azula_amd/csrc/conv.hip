@@ -328,6 +328,261 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvP p) {
   }
 }
 
+// =================================================================================================
+// Winograd F(2x2, 3x3) form of the stride-1 3x3 convolution, fully fused:
+//   out tile (2x2) = A^T [ sum_ci U[xi,nu][co][ci] * V[xi,nu][ci] ] A ,  U = G g G^T (offline),  V = B^T d B
+// 16 "frequency" GEMMs of depth Cin replace the 9-tap GEMM: 4 multiplies per output instead of 9
+// (2.25x fewer MFMA passes) in exact fp32 arithmetic (the transforms only add / subtract; the 1/2
+// factors live in the offline filter transform).  One kernel does everything:
+//   * the input transform B^T d B runs in the loader threads on the raw 4x4 patches (gathered
+//     with the same bounds-checked buffer loads as the direct kernel: padding, two sources and
+//     nearest-x2 upsampling are address arithmetic);
+//   * each wave owns ALL 16 frequencies of a (32 couts x 32 tiles) sub-block as 16 accumulators of
+//     v_mfma_f32_32x32x2_f32 (256 AGPRs: the whole 512-register file goes to ONE wave per SIMD), so
+//     the output transform A^T M A is a per-lane register computation feeding the same fused
+//     epilogue (bias, SiLU, gate, residual, NHWC/NCHW store).
+// Block = 64 couts x 64 tiles (= 256 output pixels), K stage = 8 input channels, XOR-swizzled
+// 8-float LDS rows (conflict-free ds_read_b128 fragments), 2 stages = 128 KB -> one workgroup per CU.
+constexpr int WT = 64;                 // tiles per workgroup (= 256 output pixels)
+constexpr int WC = 64;                 // output channels per workgroup
+constexpr int WK = 8;                  // input channels per stage
+constexpr int WU_STAGE = 16 * WC * WK; // floats
+constexpr int WV_STAGE = 16 * WT * WK;
+constexpr int W_STAGE = WU_STAGE + WV_STAGE;  // 16384 floats = 64 KB; two stages = 128 KB
+
+struct WinoP {
+  AzConvArgs a;
+  int npix;
+  int tiles_h, tiles_w, ntiles;
+  int nkc0, nkc1, nk;  // 8-channel chunks per source, total
+  int kps;             // chunks per split
+  int cblocks;         // ceil(cout_s / WC)
+  int tblocks;         // ceil(ntiles / WT)
+};
+
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// LDS rows hold 8 floats (one 8-channel chunk) = two 16-byte halves; the half index is XORed with
+// bit 3 of the row so that the ds_read_b128 fragment reads (32 rows x 1 half per half-wave) and the
+// ds_write_b128 of the loaders are bank-conflict-free without padding.
+__device__ __forceinline__ int wswz(int row, int half) { return row * WK + 4 * (half ^ ((row >> 3) & 1)); }
+
+__global__ __launch_bounds__(256, 1) void conv_winograd_kernel(WinoP p) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // 2 * W_STAGE floats
+  const AzConvArgs& a = p.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wco = wave >> 1;  // which 32 of the 64 couts
+  const int wti = wave & 1;   // which 32 of the 64 tiles
+  const int l31 = lane & 31;
+  const int h = lane >> 5;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  const int tb = wg / p.cblocks;
+  const int cb = wg - tb * p.cblocks;
+  const int t0 = tb * WT;
+  const int tiles_img = p.tiles_h * p.tiles_w;
+  const int b_first = t0 / tiles_img;
+
+  const int kt_begin = blockIdx.y * p.kps;
+  const int kt_end = min(p.nk, kt_begin + p.kps);
+
+  const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
+  const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : e * 4); };
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.weight, 0, clamp_bytes((int64_t)p.nk * p.cblocks * WU_STAGE), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src0 + b_first * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src1 ? a.src1 + b_first * s1_elems : a.src0), 0,
+      a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u, 0x00020000);
+
+  // ---- loader roles: threads 0..127 gather + transform one (tile, 4-channel half) each;
+  //      threads 128..255 stream the pre-transformed filter chunk (16 x 16 B each).
+  const bool vrole = tid < 128;
+  const int vj = tid >> 1;  // tile within the block
+  const int vh = tid & 1;   // which 4 of the 8 channels
+  int v_b = -1, v_ih0 = 0, v_iw0 = 0;
+  if (vrole) {
+    const int t = t0 + vj;
+    if (t < p.ntiles) {
+      const int b = t / tiles_img;
+      const int r = t - b * tiles_img;
+      const int th = r / p.tiles_w;
+      v_b = b - b_first;
+      v_ih0 = 2 * th - 1;
+      v_iw0 = 2 * (r - th * p.tiles_w) - 1;
+    }
+  }
+  unsigned voffV[16];
+  int cur_src = -1;
+  auto set_src = [&](int src) {
+    cur_src = src;
+    const int cs = src ? a.c1s : a.c0s;
+    const int up = src ? a.up1 : a.up0;
+    const int hs = src ? a.h1 : a.h0;
+    const int ws = src ? a.w1 : a.w0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ih = v_ih0 + r, iw = v_iw0 + c;
+        const bool ok = v_b >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
+        const int pix = (v_b * hs + (ih >> up)) * ws + (iw >> up);
+        voffV[r * 4 + c] = ok ? (unsigned)((pix * cs + vh * 4) * 4) : OOB;
+      }
+  };
+
+  float4 rv[16];  // raw 4x4 patch (V role) or 16 filter vectors (U role)
+
+  auto load_stage = [&](int kt) {
+    if (vrole) {
+      const int src = kt >= p.nkc0 ? 1 : 0;
+      if (src != cur_src) set_src(src);
+      const int kc = src ? kt - p.nkc0 : kt;
+      const int cs = src ? a.c1s : a.c0s;
+      const unsigned soff = (unsigned)(kc * WK * 4);
+      const bool kv = kc * WK + vh * 4 < cs;
+      if (src) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rv[i] = buf_ld4(rs1, kv ? voffV[i] : OOB, soff);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rv[i] = buf_ld4(rs0, kv ? voffV[i] : OOB, soff);
+      }
+    } else {
+      const unsigned soff = (unsigned)(((int64_t)kt * p.cblocks + cb) * (WU_STAGE * 4));
+      const int u = tid - 128;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rv[i] = buf_ld4(rw, (unsigned)((u + 128 * i) * 16), soff);
+    }
+  };
+
+  auto store_stage = [&](int buf) {
+    float* Us = wsm + buf * W_STAGE;
+    float* Vs = Us + WU_STAGE;
+    if (vrole) {
+      // t = B^T d (rows), V = t B (columns); B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+      float4 t[4][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        t[0][c] = f4sub(rv[0 * 4 + c], rv[2 * 4 + c]);
+        t[1][c] = f4add(rv[1 * 4 + c], rv[2 * 4 + c]);
+        t[2][c] = f4sub(rv[2 * 4 + c], rv[1 * 4 + c]);
+        t[3][c] = f4sub(rv[1 * 4 + c], rv[3 * 4 + c]);
+      }
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        *reinterpret_cast<float4*>(Vs + wswz((xi * 4 + 0) * WT + vj, vh)) = f4sub(t[xi][0], t[xi][2]);
+        *reinterpret_cast<float4*>(Vs + wswz((xi * 4 + 1) * WT + vj, vh)) = f4add(t[xi][1], t[xi][2]);
+        *reinterpret_cast<float4*>(Vs + wswz((xi * 4 + 2) * WT + vj, vh)) = f4sub(t[xi][2], t[xi][1]);
+        *reinterpret_cast<float4*>(Vs + wswz((xi * 4 + 3) * WT + vj, vh)) = f4sub(t[xi][1], t[xi][3]);
+      }
+    } else {
+      const int u = tid - 128;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int e = u + 128 * i;  // float4 index in the [16][64][8] chunk: row = e >> 1, half = e & 1
+        *reinterpret_cast<float4*>(Us + wswz(e >> 1, e & 1)) = rv[i];
+      }
+    }
+  };
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int f = 0; f < 16; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+  if (kt_begin < kt_end) {
+    load_stage(kt_begin);
+    store_stage(0);
+  }
+  __syncthreads();
+
+  // fragment addresses: row (within a frequency) = wave's 32-row block + l31; half = h (swizzled)
+  const int fragA = wswz(wco * 32 + l31, h);  // + f * WC * WK
+  const int fragB = wswz(wti * 32 + l31, h);  // + f * WT * WK
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    if (more) load_stage(kt + 1);  // 16 buffer loads in flight under 64 MFMAs (4096 cycles)
+    const float* Us = wsm + buf * W_STAGE;
+    const float* Vs = Us + WU_STAGE;
+    // Register double-buffered fragments: the reads of frequency f+1 are issued before the 4 MFMAs
+    // (256 cycles) of frequency f -- with ONE wave per SIMD nothing else hides the LDS latency.
+    float4 fa[2], fb[2];
+    fa[0] = *reinterpret_cast<const float4*>(Us + fragA);
+    fb[0] = *reinterpret_cast<const float4*>(Vs + fragB);
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      const int cur = f & 1, nxt = cur ^ 1;
+      if (f < 15) {
+        fa[nxt] = *reinterpret_cast<const float4*>(Us + (f + 1) * WC * WK + fragA);
+        fb[nxt] = *reinterpret_cast<const float4*>(Vs + (f + 1) * WT * WK + fragB);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].x, acc[f], 0, 0, 0);
+      acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].y, acc[f], 0, 0, 0);
+      acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].z, fb[cur].z, acc[f], 0, 0, 0);
+      acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].w, fb[cur].w, acc[f], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- output transform (per lane) + fused epilogue.
+  // Lane: tile = wti*32 + l31; couts wco*32 + 8*g + 4*h + (0..3) in registers 4g .. 4g+3.
+  const int t = t0 + wti * 32 + l31;
+  if (t >= p.ntiles) return;
+  const int b = t / tiles_img;
+  const int rr = t - b * tiles_img;
+  const int th = rr / p.tiles_w;
+  const int tw = rr - th * p.tiles_w;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int co = cb * WC + wco * 32 + 8 * g + 4 * h;
+    if (co >= a.cout_s) continue;
+    float y[2][2][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s[2][4];
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        const float m0 = acc[0 * 4 + nu][4 * g + r], m1 = acc[1 * 4 + nu][4 * g + r];
+        const float m2 = acc[2 * 4 + nu][4 * g + r], m3 = acc[3 * 4 + nu][4 * g + r];
+        s[0][nu] = (m0 + m1) + m2;
+        s[1][nu] = (m1 - m2) - m3;
+      }
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        y[py][0][r] = (s[py][0] + s[py][1]) + s[py][2];
+        y[py][1][r] = (s[py][1] - s[py][2]) - s[py][3];
+      }
+    }
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const int oh = 2 * th + py, ow = 2 * tw + px;
+        if (oh >= a.hout || ow >= a.wout) continue;
+        const int n = (b * a.hout + oh) * a.wout + ow;
+        const float4 v = make_float4(y[py][px][0], y[py][px][1], y[py][px][2], y[py][px][3]);
+        if (a.splitk > 1)
+          *reinterpret_cast<float4*>(a.workspace + ((int64_t)blockIdx.y * p.npix + n) * a.cout_s + co) = v;
+        else
+          epilogue_store(a, n, co, v);
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -405,6 +660,89 @@ int az_conv2d_f32(const AzConvArgs* a, az_stream_t stream) {
     rc = az_launch_status();
   }
   return rc;
+}
+
+/* Winograd F(2x2,3x3) path: same AzConvArgs, but `weight` must be the filter transform packed by
+ * the host (U = G g G^T laid out [chunk][cout block][16][32][8], see azula_amd/engine.py).  Only
+ * ksize = 3, stride = 1, pad = 1. */
+int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
+  AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
+  AZ_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1, AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
+  AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
+  AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
+  AZ_REQUIRE(((a->hin + a->up0) >> a->up0) <= a->h0 && ((a->win + a->up0) >> a->up0) <= a->w0, AZ_E_SHAPE);
+  if (a->src1)
+    AZ_REQUIRE(((a->hin + a->up1) >> a->up1) <= a->h1 && ((a->win + a->up1) >> a->up1) <= a->w1, AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(a->src0) && AZ_ALIGNED16(a->src1) && AZ_ALIGNED16(a->weight) && AZ_ALIGNED16(a->bias) &&
+                 AZ_ALIGNED16(a->gate) && AZ_ALIGNED16(a->res) && AZ_ALIGNED16(a->workspace),
+             AZ_E_ALIGN);
+  if (!a->dst_nchw) AZ_REQUIRE(AZ_ALIGNED16(a->dst), AZ_E_ALIGN);
+  if (a->dst_nchw) AZ_REQUIRE(a->dst_c > 0 && a->dst_c <= a->cout_s, AZ_E_SHAPE);
+  if (a->gate) AZ_REQUIRE(a->gate_bstride % 4 == 0, AZ_E_ALIGN);
+  if (a->res && a->res_up) AZ_REQUIRE(((a->hout + 1) >> 1) <= a->hres && ((a->wout + 1) >> 1) <= a->wres, AZ_E_SHAPE);
+  AZ_REQUIRE(a->splitk >= 1 && (a->splitk == 1 || a->workspace), AZ_E_SHAPE);
+  const int64_t npix64 = (int64_t)a->batch * a->hout * a->wout;
+  AZ_REQUIRE(npix64 < (1ll << 31), AZ_E_SHAPE);
+
+  WinoP p;
+  p.a = *a;
+  p.npix = (int)npix64;
+  p.tiles_h = (a->hout + 1) / 2;
+  p.tiles_w = (a->wout + 1) / 2;
+  p.ntiles = a->batch * p.tiles_h * p.tiles_w;
+  p.nkc0 = (a->c0s + WK - 1) / WK;
+  p.nkc1 = (a->c1s + WK - 1) / WK;
+  p.nk = p.nkc0 + p.nkc1;
+  {
+    const int64_t tiles_img = (int64_t)p.tiles_h * p.tiles_w;
+    const int64_t span = (WT + tiles_img - 1) / tiles_img + 1;
+    AZ_REQUIRE(span * a->h0 * a->w0 * a->c0s * 4 < (1ll << 31), AZ_E_SHAPE);
+    AZ_REQUIRE(span * a->h1 * a->w1 * a->c1s * 4 < (1ll << 31), AZ_E_SHAPE);
+  }
+  int splitk = a->splitk;
+  if (splitk > p.nk) splitk = p.nk;
+  p.kps = (p.nk + splitk - 1) / splitk;
+  splitk = (p.nk + p.kps - 1) / p.kps;
+  p.a.splitk = splitk;
+  p.cblocks = (a->cout_s + WC - 1) / WC;
+  p.tblocks = (p.ntiles + WT - 1) / WT;
+  AZ_REQUIRE((int64_t)p.nk * p.cblocks * WU_STAGE * 4 < (1ll << 32), AZ_E_SHAPE);
+  const int64_t nwg = (int64_t)p.cblocks * p.tblocks;
+  hipStream_t st = az_s(stream);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_winograd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * W_STAGE * 4);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_winograd_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 2 * W_STAGE * 4, st, p);
+  int rc = az_launch_status();
+  if (rc != AZ_OK) return rc;
+  if (splitk > 1) {
+    ConvP cp;
+    cp.a = p.a;
+    cp.npix = p.npix;
+    const int grid = az_stream_grid((int64_t)p.npix * (a->cout_s / 4), 256);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, cp);
+    rc = az_launch_status();
+  }
+  return rc;
+}
+
+/* Split-K suggestion for the Winograd path (pure function of the shape). */
+int az_conv2d_winograd_suggest_splitk(int64_t batch, int32_t hout, int32_t wout, int32_t cout_s, int32_t cin_s) {
+  const int64_t tiles = batch * ((hout + 1) / 2) * ((wout + 1) / 2);
+  const int64_t blocks = ((tiles + WT - 1) / WT) * ((cout_s + WC - 1) / WC);
+  const int64_t nk = (cin_s + WK - 1) / WK;
+  int64_t want = (256 + blocks - 1) / blocks;
+  int64_t maxs = nk / 16;
+  if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want > 16) want = 16;
+  if (blocks >= 192) want = 1;
+  return (int)(want < 1 ? 1 : want);
 }
 
 }  // extern "C"

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -121,6 +122,59 @@ class Act:
         return self.buf.data_ptr()
 
 
+WINOGRAD = os.environ.get("AZ_WINOGRAD", "1") != "0"  # F(2x2,3x3) for stride-1 3x3 convs (see conv.hip)
+
+
+class ConvWeights:
+    r"""Convolution / linear weights in the layouts the kernels consume."""
+
+    def __init__(self, bld: "Builder", weight: torch.Tensor, bias: torch.Tensor | None, cin0: int | None) -> None:
+        w = weight.detach().to(device=bld.device, dtype=torch.float32)
+        if w.ndim == 2:
+            w = w[:, :, None, None]
+        elif w.ndim == 3:  # Conv1d k=1
+            w = w[:, :, :, None]
+        self.w = w.contiguous()
+        self.cout, self.cin, self.ks, kw = self.w.shape
+        assert self.ks == kw, "square kernels only"
+        self.cin0 = self.cin if cin0 is None else cin0
+        self.c0s, self.c1s = pad4(self.cin0), pad4(self.cin - self.cin0)
+        self.cout_s = pad4(self.cout)
+        self.device = bld.device
+        self.bias = None
+        if bias is not None:
+            self.bias = torch.zeros(self.cout_s, dtype=torch.float32, device=bld.device)
+            self.bias[: self.cout] = bias.detach().to(device=bld.device, dtype=torch.float32)
+        self._direct = self._wino = None
+
+    def direct(self) -> torch.Tensor:
+        r"""[tap][cout_s][cin_s] (K contiguous), zero padded (az_pack_conv_weight_f32)."""
+        if self._direct is None:
+            cin_s = self.c0s + self.c1s
+            packed = torch.empty(self.ks * self.ks * self.cout_s * cin_s, dtype=torch.float32, device=self.device)
+            _lib.call(
+                "az_pack_conv_weight_f32", packed.data_ptr(), self.w.data_ptr(), self.cout, self.cin, self.ks,
+                self.cout_s, self.cin0, self.c0s, cin_s, _lib.stream_ptr(),
+            )
+            self._direct = packed
+        return self._direct
+
+    def winograd(self) -> torch.Tensor:
+        r"""Filter transform U = G g G^T (fp64 -> fp32, one-off) laid out
+        [8-channel chunk][64-cout block][16 frequencies][64][8]; source 1 starts on a chunk boundary."""
+        if self._wino is None:
+            G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=self.device)
+            U = torch.einsum("xk,ockl,yl->xyoc", G, self.w.double(), G).reshape(16, self.cout, self.cin).float()
+            nk0, nk1 = (self.c0s + 7) // 8, (self.c1s + 7) // 8
+            cb = (self.cout_s + 63) // 64
+            Up = torch.zeros(16, cb * 64, (nk0 + nk1) * 8, dtype=torch.float32, device=self.device)
+            Up[:, : self.cout, : self.cin0] = U[:, :, : self.cin0]
+            if self.cin > self.cin0:
+                Up[:, : self.cout, nk0 * 8 : nk0 * 8 + self.cin - self.cin0] = U[:, :, self.cin0 :]
+            self._wino = Up.reshape(16, cb, 64, nk0 + nk1, 8).permute(3, 1, 0, 2, 4).contiguous().reshape(-1)
+        return self._wino
+
+
 class Builder:
     r"""Emits kernels onto a tape; owns the pool, packed weights and the split-K workspace."""
 
@@ -152,32 +206,12 @@ class Builder:
         return t
 
     # -- weights ---------------------------------------------------------------------------
-    def pack_conv(self, weight: torch.Tensor, bias: torch.Tensor | None, cin0: int | None = None):
-        r"""torch (cout, cin, k, k) [or (cout, cin) for linears] -> packed [taps][cout_s][cin_s]."""
-        w = weight.detach().to(device=self.device, dtype=torch.float32)
-        if w.ndim == 2:
-            w = w[:, :, None, None]
-        elif w.ndim == 3:  # Conv1d k=1
-            w = w[:, :, :, None]
-        w = w.contiguous()
-        cout, cin, kh, kw = w.shape
-        assert kh == kw, "square kernels only"
-        if cin0 is None:
-            cin0 = cin
-        c0s = pad4(cin0)
-        cin_s = c0s + pad4(cin - cin0)
-        cout_s = pad4(cout)
-        packed = torch.empty(kh * kw * cout_s * cin_s, dtype=torch.float32, device=self.device)
-        _lib.call(
-            "az_pack_conv_weight_f32", packed.data_ptr(), w.data_ptr(), cout, cin, kh, cout_s, cin0, c0s, cin_s,
-            _lib.stream_ptr(),
-        )
-        bp = None
-        if bias is not None:
-            bp = torch.zeros(cout_s, dtype=torch.float32, device=self.device)
-            bp[:cout] = bias.detach().to(device=self.device, dtype=torch.float32)
-        self.tape.keep.extend([packed, bp, w])
-        return packed, bp, kh
+    def pack_conv(self, weight: torch.Tensor, bias: torch.Tensor | None, cin0: int | None = None) -> "ConvWeights":
+        r"""Wraps torch (cout, cin, k, k) [or (cout, cin) / (cout, cin, 1)] weights; the kernel-specific
+        packed forms (direct implicit GEMM, Winograd) are materialised on first use."""
+        cw = ConvWeights(self, weight, bias, cin0)
+        self.tape.keep.append(cw)
+        return cw
 
     # -- kernels ---------------------------------------------------------------------------
     def conv(
@@ -199,8 +233,9 @@ class Builder:
         res: Act | None = None,
         res_up: int = 0,
         dst_nchw: torch.Tensor | None = None,
+        winograd: bool | None = None,
     ) -> Act | None:
-        weight, bias, ks = packed
+        ks, bias = packed.ks, packed.bias
         pad = ks // 2
         B = src0.B
         if hin is None:
@@ -213,8 +248,8 @@ class Builder:
         a.src0, a.c0s, a.up0, a.h0, a.w0 = src0.ptr, src0.cs, up0, src0.H, src0.W
         if src1 is not None:
             a.src1, a.c1s, a.up1, a.h1, a.w1 = src1.ptr, src1.cs, up1, src1.H, src1.W
+        assert (a.c0s, a.c1s) == (packed.c0s, packed.c1s), "weights were packed for different source strides"
         a.batch, a.hin, a.win = B, hin, win
-        a.weight = weight.data_ptr()
         a.bias = bias.data_ptr() if bias is not None else None
         a.cout_s = pad4(cout)
         a.ksize, a.stride, a.pad = ks, stride, pad
@@ -237,12 +272,28 @@ class Builder:
             a.dst = out.ptr
         npix = B * hout * wout
         cin_s = a.c0s + a.c1s
-        a.splitk = _lib.lib().az_conv2d_suggest_splitk(npix, a.cout_s, cin_s, ks)
+        lib = _lib.lib()
+        use_wino = WINOGRAD if winograd is None else winograd
+        use_wino = use_wino and ks == 3 and stride == 1
+        if use_wino:
+            tiles = B * ((hout + 1) // 2) * ((wout + 1) // 2)
+            blocks = ((tiles + 63) // 64) * ((a.cout_s + 63) // 64)
+            a.splitk = lib.az_conv2d_winograd_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
+            if winograd is None and blocks * a.splitk < 128:
+                use_wino = False  # too few workgroups: the direct kernel's split-K fills the chip better
+        if use_wino:
+            a.weight = packed.winograd().data_ptr()
+            name = "az_conv2d_winograd_f32"
+        else:
+            a.weight = packed.direct().data_ptr()
+            a.splitk = lib.az_conv2d_suggest_splitk(npix, a.cout_s, cin_s, ks)
+            name = "az_conv2d_f32"
         if a.splitk > 1:
             self._ws_need = max(self._ws_need, a.splitk * npix * a.cout_s)
             self._ws_users.append(a)
         a._flops = 2 * npix * cout * (src0.C + (src1.C if src1 is not None else 0)) * ks * ks  # algorithmic
-        self.tape.add("az_conv2d_f32", C.byref(a), keep=[a])
+        a._algo = name
+        self.tape.add(name, C.byref(a), keep=[a])
         return out
 
     def finish(self) -> None:

@@ -68,7 +68,7 @@ def conv_roofline(sampler, device):
         recs = []
         loop.counter.zero_()
         for fn, args, name in tape.ops:
-            if name == "az_conv2d_f32":
+            if name in ("az_conv2d_f32", "az_conv2d_winograd_f32"):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
                 rc = fn(*args, sptr)
@@ -82,11 +82,12 @@ def conv_roofline(sampler, device):
     flops = sum(r[2] for r in recs)
     ms = sum(r[0].elapsed_time(r[1]) for r in recs)
     if os.environ.get("AZ_BENCH_DETAIL"):
-        for (e0, e1, fl, sk), d in zip(recs, [a[0]._obj for _, a, n in tape.ops if n == "az_conv2d_f32"]):
+        convs = [a[0]._obj for _, a, n in tape.ops if n in ("az_conv2d_f32", "az_conv2d_winograd_f32")]
+        for (e0, e1, fl, sk), d in zip(recs, convs):
             t = e0.elapsed_time(e1)
             print(
                 f"conv {d.batch}x{d.hin}x{d.win} cin={d.c0s}+{d.c1s} cout={d.cout_s} k={d.ksize} s={d.stride} "
-                f"splitk={sk}: {t * 1e3:8.1f} us {fl / t / 1e9:7.1f} TF/s",
+                f"splitk={sk} {d._algo[10:-4]}: {t * 1e3:8.1f} us {fl / t / 1e9:7.1f} TF/s",
                 file=sys.stderr,
             )
     return dict(flops=flops, ms=ms, launches=len(recs), splitk_launches=sum(1 for r in recs if r[3] > 1))

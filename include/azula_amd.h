@@ -213,6 +213,13 @@ typedef struct AzConvArgs {
   float* workspace;
 } AzConvArgs;
 int az_conv2d_f32(const AzConvArgs* args, az_stream_t stream);
+/* Winograd F(2x2,3x3) form of the same operation for ksize = 3, stride = 1, pad = 1: 2.25x fewer
+ * multiplies in exact fp32 (transforms only add/subtract; the input transform, the 16 frequency
+ * GEMMs and the output transform + epilogue are ONE kernel).  `weight` must be the host-side
+ * filter transform U = G g G^T packed [chunk of 8 cin][cout block of 64][16][64][8]
+ * (azula_amd/engine.py: Builder.pack_winograd); all other fields as az_conv2d_f32.             */
+int az_conv2d_winograd_f32(const AzConvArgs* args, az_stream_t stream);
+int az_conv2d_winograd_suggest_splitk(int64_t batch, int32_t hout, int32_t wout, int32_t cout_s, int32_t cin_s);
 /* Suggested split-K factor for a conv shape on this device (pure function of the shape).     */
 int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_t ksize);
 /* torch layout (cout, cin, ks, ks) -> packed [ks*ks][cout_s][cin_s] with zero padding; the

@@ -289,7 +289,10 @@ def conv_tol(cin, ks):
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ks,stride", CONV_CASES)
 @pytest.mark.parametrize("splitk", [0, 3])
-def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk):
+@pytest.mark.parametrize("wino", [False, True])
+def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk, wino):
+    if wino and (ks != 3 or stride != 1):
+        pytest.skip("Winograd F(2x2,3x3) is the stride-1 3x3 path")
     from azula_amd.engine import Act, Builder
 
     g = torch.Generator().manual_seed(Cin * Cout + H)
@@ -299,7 +302,8 @@ def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk):
     ref = F.conv2d(x, w, b, stride=stride, padding=ks // 2)
     bld = Builder(torch.device("cuda"))
     xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, (Cin + 3) // 4 * 4, True)
-    y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, stride=stride)
+    y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, stride=stride, winograd=wino)
+    assert bld.tape.ops[-1][2] == ("az_conv2d_winograd_f32" if wino else "az_conv2d_f32")
     if splitk:
         a = bld.tape.keep[-1]
         a.splitk = splitk
@@ -309,11 +313,12 @@ def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk):
     bld.tape.run()
     out = from_nhwc(y.buf.reshape(B, y.H, y.W, y.cs), Cout)
     assert out.shape == ref.shape
-    assert max_err(out, ref) < conv_tol(Cin, ks), max_err(out, ref)
+    assert max_err(out, ref) < conv_tol(Cin, ks) * (3 if wino else 1), max_err(out, ref)
     assert (y.buf.reshape(B, y.H, y.W, y.cs)[..., Cout:] == 0).all()
 
 
-def test_conv2d_concat_upsample_narrow_gate_res(az):
+@pytest.mark.parametrize("wino", [False, True])
+def test_conv2d_concat_upsample_narrow_gate_res(az, wino):
     """cat((y, upsample(x)[narrowed])) -> conv -> x0 + c * silu-free epilogue, as azula/nn/unet.py:253-257,93."""
     from azula_amd.engine import Act, Builder
 
@@ -332,13 +337,14 @@ def test_conv2d_concat_upsample_narrow_gate_res(az):
     xa = Act(to_nhwc(dev(x)).reshape(-1), B, 8, 7, Cx, 20, True)
     ra = Act(to_nhwc(dev(res)).reshape(-1), B, H, W, Cout, 12, True)
     out = bld.conv(ya, bld.pack_conv(dev(w), dev(b), cin0=Cy), Cout, src1=xa, up1=1, hin=H, win=W, act=1,
-                   gate=dev(gate), gate_bstride=Cout, res=ra)
+                   gate=dev(gate), gate_bstride=Cout, res=ra, winograd=wino)
     bld.finish()
     bld.tape.run()
-    assert max_err(from_nhwc(out.buf.reshape(B, H, W, 12), Cout), ref) < conv_tol(Cy + Cx, 3)
+    assert max_err(from_nhwc(out.buf.reshape(B, H, W, 12), Cout), ref) < conv_tol(Cy + Cx, 3) * (3 if wino else 1)
 
 
-def test_conv2d_nchw_output_and_res_up(az):
+@pytest.mark.parametrize("wino", [False, True])
+def test_conv2d_nchw_output_and_res_up(az, wino):
     from azula_amd.engine import Act, Builder
 
     g = torch.Generator().manual_seed(12)
@@ -349,16 +355,17 @@ def test_conv2d_nchw_output_and_res_up(az):
     bld = Builder(torch.device("cuda"))
     dst = torch.empty(B, Cout, H, W, device="cuda")
     x0a = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, 16, True)  # keep alive until the tape has run
-    bld.conv(x0a, bld.pack_conv(dev(w), dev(b)), Cout, dst_nchw=dst)
+    bld.conv(x0a, bld.pack_conv(dev(w), dev(b)), Cout, dst_nchw=dst, winograd=wino)
     # ADM up-block shape: conv over upsampled input + upsampled identity residual
     w2 = torch.randn(Cin, Cin, 3, 3, generator=g) / 12
     xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, 16, True)
-    up = bld.conv(xa, bld.pack_conv(dev(w2), None), Cin, up0=1, res=xa, res_up=1)
+    up = bld.conv(xa, bld.pack_conv(dev(w2), None), Cin, up0=1, res=xa, res_up=1, winograd=wino)
     bld.finish()
     bld.tape.run()
-    assert max_err(dst, F.conv2d(x, w, b, padding=1)) < conv_tol(Cin, 3)
+    tol = conv_tol(Cin, 3) * (3 if wino else 1)
+    assert max_err(dst, F.conv2d(x, w, b, padding=1)) < tol
     xu = F.interpolate(x, scale_factor=2, mode="nearest")
-    assert max_err(from_nhwc(up.buf.reshape(B, 2 * H, 2 * W, 16), Cin), xu + F.conv2d(xu, w2, None, padding=1)) < conv_tol(Cin, 3)
+    assert max_err(from_nhwc(up.buf.reshape(B, 2 * H, 2 * W, 16), Cin), xu + F.conv2d(xu, w2, None, padding=1)) < tol
 
 
 def test_graph_capture_replay(az):

@@ -21,7 +21,8 @@ scale = 0.0 if os.environ.get("AZ_ZERO") else 1.0
 x = Act(torch.randn(B * H * W * Cin, device=dev) * scale, B, H, W, Cin, Cin, True)
 w = torch.randn(Cout, Cin, ks, ks, device=dev) / (Cin * ks * ks) ** 0.5 * scale
 b = torch.randn(Cout, device=dev)
-y = bld.conv(x, bld.pack_conv(w, b), Cout, stride=stride, act=1)
+wino = {"1": True, "0": False}.get(os.environ.get("AZ_WINO", ""), None)
+y = bld.conv(x, bld.pack_conv(w, b), Cout, stride=stride, act=1, winograd=wino)
 bld.finish()
 desc = bld.tape.keep[-1] if hasattr(bld.tape.keep[-1], "_flops") else [k for k in bld.tape.keep if hasattr(k, "_flops")][-1]
 for _ in range(3):
@@ -33,4 +34,4 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(f"conv {B}x{H}x{W} {Cin}->{Cout} k{ks} s{stride} splitk={desc.splitk}: {ms * 1e3:.1f} us  {desc._flops / ms / 1e9:.1f} TF/s")
+print(f"conv[{desc._algo[10:-4]}] {B}x{H}x{W} {Cin}->{Cout} k{ks} s{stride} splitk={desc.splitk}: {ms * 1e3:.1f} us  {desc._flops / ms / 1e9:.1f} TF/s")
