@@ -441,54 +441,75 @@ __global__ __launch_bounds__(256, 1) void conv_winograd_kernel(WinoP p) {
 
   float4 rv[16];  // raw 4x4 patch (V role) or 16 filter vectors (U role)
 
-  auto load_stage = [&](int kt) {
+  // Stage pipeline (2 LDS buffers, registers hold the stage after next):
+  //   stage kt computes from buf[kt&1]; meanwhile the registers holding stage kt+1 are
+  //   transformed (f = 10, 11) and written to buf[(kt+1)&1] (f = 12..15: its last readers passed
+  //   the previous barrier), and the loads of stage kt+2 are issued into the freed registers.
+  //   All of it is interleaved between the MFMAs, so only lgkmcnt(0) + one barrier per stage is
+  //   exposed, and every global load has ~3500 cycles to land.
+  // (kt is wave-uniform: the source / descriptor choice must stay provably uniform, otherwise hipcc
+  //  wraps every buffer load in a waterfall loop)
+  bool ld_kv = true;
+  auto prep_loads = [&](int kt) {
     if (vrole) {
       const int src = kt >= p.nkc0 ? 1 : 0;
       if (src != cur_src) set_src(src);
       const int kc = src ? kt - p.nkc0 : kt;
-      const int cs = src ? a.c1s : a.c0s;
-      const unsigned soff = (unsigned)(kc * WK * 4);
-      const bool kv = kc * WK + vh * 4 < cs;
-      if (src) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) rv[i] = buf_ld4(rs1, kv ? voffV[i] : OOB, soff);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) rv[i] = buf_ld4(rs0, kv ? voffV[i] : OOB, soff);
-      }
-    } else {
-      const unsigned soff = (unsigned)(((int64_t)kt * p.cblocks + cb) * (WU_STAGE * 4));
-      const int u = tid - 128;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) rv[i] = buf_ld4(rw, (unsigned)((u + 128 * i) * 16), soff);
+      ld_kv = kc * WK + vh * 4 < (src ? a.c1s : a.c0s);
     }
   };
-
-  auto store_stage = [&](int buf) {
+  auto issue_loads = [&](int part, int kt) {  // 4 of the 16 loads of stage kt
+    const bool src1 = kt >= p.nkc0;
+    const unsigned soffV = (unsigned)((src1 ? kt - p.nkc0 : kt) * WK * 4);
+    const unsigned soffU = (unsigned)(((int64_t)kt * p.cblocks + cb) * (WU_STAGE * 4));
+    if (vrole) {
+      if (src1) {
+#pragma unroll
+        for (int i = 4 * part; i < 4 * part + 4; ++i) rv[i] = buf_ld4(rs1, ld_kv ? voffV[i] : OOB, soffV);
+      } else {
+#pragma unroll
+        for (int i = 4 * part; i < 4 * part + 4; ++i) rv[i] = buf_ld4(rs0, ld_kv ? voffV[i] : OOB, soffV);
+      }
+    } else {
+#pragma unroll
+      for (int i = 4 * part; i < 4 * part + 4; ++i) rv[i] = buf_ld4(rw, (unsigned)((tid - 128 + 128 * i) * 16), soffU);
+    }
+  };
+  // in-place input transform V = B^T d B; B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+  auto transform_cols = [&]() {
+    if (vrole) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 d0 = rv[c], d1 = rv[4 + c], d2 = rv[8 + c], d3 = rv[12 + c];
+        rv[c] = f4sub(d0, d2);
+        rv[4 + c] = f4add(d1, d2);
+        rv[8 + c] = f4sub(d2, d1);
+        rv[12 + c] = f4sub(d1, d3);
+      }
+    }
+  };
+  auto transform_rows = [&]() {
+    if (vrole) {
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        const float4 t0 = rv[4 * xi], t1 = rv[4 * xi + 1], t2 = rv[4 * xi + 2], t3 = rv[4 * xi + 3];
+        rv[4 * xi] = f4sub(t0, t2);
+        rv[4 * xi + 1] = f4add(t1, t2);
+        rv[4 * xi + 2] = f4sub(t2, t1);
+        rv[4 * xi + 3] = f4sub(t1, t3);
+      }
+    }
+  };
+  auto write_part = [&](int buf, int part) {  // 4 of the 16 vectors -> LDS
     float* Us = wsm + buf * W_STAGE;
     float* Vs = Us + WU_STAGE;
     if (vrole) {
-      // t = B^T d (rows), V = t B (columns); B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-      float4 t[4][4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        t[0][c] = f4sub(rv[0 * 4 + c], rv[2 * 4 + c]);
-        t[1][c] = f4add(rv[1 * 4 + c], rv[2 * 4 + c]);
-        t[2][c] = f4sub(rv[2 * 4 + c], rv[1 * 4 + c]);
-        t[3][c] = f4sub(rv[1 * 4 + c], rv[3 * 4 + c]);
-      }
-#pragma unroll
-      for (int xi = 0; xi < 4; ++xi) {
-        *reinterpret_cast<float4*>(Vs + wswz((xi * 4 + 0) * WT + vj, vh)) = f4sub(t[xi][0], t[xi][2]);
-        *reinterpret_cast<float4*>(Vs + wswz((xi * 4 + 1) * WT + vj, vh)) = f4add(t[xi][1], t[xi][2]);
-        *reinterpret_cast<float4*>(Vs + wswz((xi * 4 + 2) * WT + vj, vh)) = f4sub(t[xi][2], t[xi][1]);
-        *reinterpret_cast<float4*>(Vs + wswz((xi * 4 + 3) * WT + vj, vh)) = f4sub(t[xi][1], t[xi][3]);
-      }
+      for (int i = 4 * part; i < 4 * part + 4; ++i) *reinterpret_cast<float4*>(Vs + wswz(i * WT + vj, vh)) = rv[i];
     } else {
-      const int u = tid - 128;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int e = u + 128 * i;  // float4 index in the [16][64][8] chunk: row = e >> 1, half = e & 1
+      for (int i = 4 * part; i < 4 * part + 4; ++i) {
+        const int e = tid - 128 + 128 * i;  // float4 index in the [16][64][8] chunk: row = e >> 1, half = e & 1
         *reinterpret_cast<float4*>(Us + wswz(e >> 1, e & 1)) = rv[i];
       }
     }
@@ -501,8 +522,18 @@ __global__ __launch_bounds__(256, 1) void conv_winograd_kernel(WinoP p) {
     for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
   if (kt_begin < kt_end) {
-    load_stage(kt_begin);
-    store_stage(0);
+    prep_loads(kt_begin);
+#pragma unroll
+    for (int part = 0; part < 4; ++part) issue_loads(part, kt_begin);
+    transform_cols();
+    transform_rows();
+#pragma unroll
+    for (int part = 0; part < 4; ++part) write_part(0, part);
+    if (kt_begin + 1 < kt_end) {
+      prep_loads(kt_begin + 1);
+#pragma unroll
+      for (int part = 0; part < 4; ++part) issue_loads(part, kt_begin + 1);
+    }
   }
   __syncthreads();
 
@@ -511,8 +542,9 @@ __global__ __launch_bounds__(256, 1) void conv_winograd_kernel(WinoP p) {
   const int fragB = wswz(wti * 32 + l31, h);  // + f * WT * WK
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int buf = (kt - kt_begin) & 1;
-    const bool more = kt + 1 < kt_end;
-    if (more) load_stage(kt + 1);  // 16 buffer loads in flight under 64 MFMAs (4096 cycles)
+    const bool more = kt + 1 < kt_end;    // registers hold stage kt+1
+    const bool more2 = kt + 2 < kt_end;   // stage kt+2 will be loaded
+    if (more2) prep_loads(kt + 2);
     const float* Us = wsm + buf * W_STAGE;
     const float* Vs = Us + WU_STAGE;
     // Register double-buffered fragments: the reads of frequency f+1 are issued before the 4 MFMAs
@@ -532,9 +564,17 @@ __global__ __launch_bounds__(256, 1) void conv_winograd_kernel(WinoP p) {
       acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].y, acc[f], 0, 0, 0);
       acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].z, fb[cur].z, acc[f], 0, 0, 0);
       acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].w, fb[cur].w, acc[f], 0, 0, 0);
+      // the 4 MFMAs above form one dependent accumulate chain and must stay back to back (any
+      // instruction between them costs ~43 cycles); everything else goes between chains
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        if (f == 10) transform_cols();
+        if (f == 11) transform_rows();
+        if (f >= 12) write_part(buf ^ 1, f - 12);
+      }
+      if (more2 && f >= 12) issue_loads(f - 12, kt + 2);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) store_stage(buf ^ 1);
     __syncthreads();
   }
 

@@ -122,7 +122,9 @@ class Act:
         return self.buf.data_ptr()
 
 
-WINOGRAD = os.environ.get("AZ_WINOGRAD", "1") != "0"  # F(2x2,3x3) for stride-1 3x3 convs (see conv.hip)
+# F(2x2,3x3) for stride-1 3x3 convs (see conv.hip): "1" = where it pays (default), "0" = never,
+# "2" = wherever it is legal (used by the parity tests to push whole networks through it)
+WINOGRAD = os.environ.get("AZ_WINOGRAD", "1")
 
 
 class ConvWeights:
@@ -273,14 +275,13 @@ class Builder:
         npix = B * hout * wout
         cin_s = a.c0s + a.c1s
         lib = _lib.lib()
-        use_wino = WINOGRAD if winograd is None else winograd
+        use_wino = (WINOGRAD != "0") if winograd is None else winograd
         use_wino = use_wino and ks == 3 and stride == 1
         if use_wino:
             tiles = B * ((hout + 1) // 2) * ((wout + 1) // 2)
-            blocks = ((tiles + 63) // 64) * ((a.cout_s + 63) // 64)
             a.splitk = lib.az_conv2d_winograd_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
-            if winograd is None and blocks * a.splitk < 128:
-                use_wino = False  # too few workgroups: the direct kernel's split-K fills the chip better
+            if winograd is None and WINOGRAD == "1" and tiles < 256:
+                use_wino = False  # < 4 tile blocks (8x8 at batch 4): the direct kernel's split-K is faster
         if use_wino:
             a.weight = packed.winograd().data_ptr()
             name = "az_conv2d_winograd_f32"

@@ -123,3 +123,23 @@ def test_ddpm8_with_device_rng(golden):
     assert max_err(x0, ref) < 5e-4 * max(1.0, ref.abs().max().item())
     # and against the golden DDPM-8 through the generic step() with CPU-recorded noise
     assert g["ddpm8"].shape == x0.shape
+
+
+def test_unet_forward_through_winograd(golden, monkeypatch):
+    """The same reference vectors with every stride-1 3x3 conv forced through the Winograd kernel
+    (at these tiny shapes the default policy would pick the direct kernel)."""
+    from azula_amd import engine
+
+    monkeypatch.setattr(engine, "WINOGRAD", "2")
+    for name in ("unet_group", "unet_layer_odd"):
+        g = golden("g5_" + name)
+        cfg = g.meta["cfg"]
+        net = build_unet(cfg)
+        net.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"]))
+        net = net.cuda().eval()
+        y = net(g["x"].cuda(), g["modB"].cuda())
+        plan = next(iter(net._plans.values()))
+        assert any(name_ == "az_conv2d_winograd_f32" for _, _, name_ in plan.tape.ops)
+        err, sc = max_err(y, g["y_modB"]), g["y_modB"].abs().max().item()
+        print(name, "winograd max|d| vs reference:", err, "scale", sc)
+        assert err < 2e-4 * max(1.0, sc)
