@@ -55,6 +55,14 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t rsrc, unsigned 
   return __builtin_bit_cast(float4, v);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 buf_ld2(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)soff, 0);
+  return __builtin_bit_cast(f32x2, v);
+}
+
 constexpr unsigned OOB = 0x80000000u;  // any offset >= num_records reads as zero
 
 // Epilogue for 4 consecutive output channels [co, co+4) of output pixel n.
@@ -337,10 +345,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvP p) {
 //   * the input transform B^T d B runs in the loader threads on the raw 4x4 patches (gathered
 //     with the same bounds-checked buffer loads as the direct kernel: padding, two sources and
 //     nearest-x2 upsampling are address arithmetic);
-//   * each wave owns ALL 16 frequencies of a (32 couts x 32 tiles) sub-block as 16 accumulators of
-//     v_mfma_f32_32x32x2_f32 (256 AGPRs: the whole 512-register file goes to ONE wave per SIMD), so
-//     the output transform A^T M A is a per-lane register computation feeding the same fused
-//     epilogue (bias, SiLU, gate, residual, NHWC/NCHW store).
+//   * 8 waves (2 per SIMD, so one wave's MFMAs cover its SIMD partner's loads / transform / barrier
+//     waits): each owns 8 of the 16 frequencies of a (32 couts x 32 tiles) sub-block as 8
+//     accumulators of v_mfma_f32_32x32x2_f32; the output transform A^T M A is linear, so every wave
+//     reduces its 8 frequencies to a partial 2x2 output in registers and the halves meet through
+//     LDS once per workgroup before the same fused epilogue (bias, SiLU, gate, residual, store).
 // Block = 64 couts x 64 tiles (= 256 output pixels), K stage = 8 input channels, XOR-swizzled
 // 8-float LDS rows (conflict-free ds_read_b128 fragments), 2 stages = 128 KB -> one workgroup per CU.
 constexpr int WT = 64;                 // tiles per workgroup (= 256 output pixels)
@@ -368,14 +377,15 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 // ds_write_b128 of the loaders are bank-conflict-free without padding.
 __device__ __forceinline__ int wswz(int row, int half) { return row * WK + 4 * (half ^ ((row >> 3) & 1)); }
 
-__global__ __launch_bounds__(256, 1) void conv_winograd_kernel(WinoP p) {
+__global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];  // 2 * W_STAGE floats
   const AzConvArgs& a = p.a;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wco = wave >> 1;  // which 32 of the 64 couts
-  const int wti = wave & 1;   // which 32 of the 64 tiles
+  const int wave = tid >> 6;        // 8 waves = 2 per SIMD: wave w and w+4 share a SIMD
+  const int fh = wave >> 2;         // which 8 of the 16 frequencies (xi in {0,1} or {2,3})
+  const int wco = (wave >> 1) & 1;  // which 32 of the 64 couts
+  const int wti = wave & 1;         // which 32 of the 64 tiles
   const int l31 = lane & 31;
   const int h = lane >> 5;
 
@@ -403,11 +413,12 @@ __global__ __launch_bounds__(256, 1) void conv_winograd_kernel(WinoP p) {
       (void*)(a.src1 ? a.src1 + b_first * s1_elems : a.src0), 0,
       a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u, 0x00020000);
 
-  // ---- loader roles: threads 0..127 gather + transform one (tile, 4-channel half) each;
-  //      threads 128..255 stream the pre-transformed filter chunk (16 x 16 B each).
-  const bool vrole = tid < 128;
-  const int vj = tid >> 1;  // tile within the block
-  const int vh = tid & 1;   // which 4 of the 8 channels
+  // ---- loader roles: waves 0..3 (threads 0..255) gather + transform one (tile, channel pair) each
+  //      (16 x 8-byte loads); waves 4..7 stream the pre-transformed filter chunk (8 x 16 B each).
+  //      Wave w (V role) and wave w+4 (U role) share a SIMD, so every SIMD carries the same load.
+  const bool vrole = tid < 256;
+  const int vj = (tid & 255) >> 2;  // tile within the block
+  const int vq = tid & 3;           // which channel pair of the 8
   int v_b = -1, v_ih0 = 0, v_iw0 = 0;
   if (vrole) {
     const int t = t0 + vj;
@@ -435,127 +446,96 @@ __global__ __launch_bounds__(256, 1) void conv_winograd_kernel(WinoP p) {
         const int ih = v_ih0 + r, iw = v_iw0 + c;
         const bool ok = v_b >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
         const int pix = (v_b * hs + (ih >> up)) * ws + (iw >> up);
-        voffV[r * 4 + c] = ok ? (unsigned)((pix * cs + vh * 4) * 4) : OOB;
+        voffV[r * 4 + c] = ok ? (unsigned)((pix * cs + vq * 2) * 4) : OOB;
       }
   };
 
-  float4 rv[16];  // raw 4x4 patch (V role) or 16 filter vectors (U role)
+  f32x2 rv[16];  // V role: raw 4x4 patch of a channel pair; U role: 8 filter float4 (rv[2i], rv[2i+1])
 
-  // Stage pipeline (2 LDS buffers, registers hold the stage after next):
-  //   stage kt computes from buf[kt&1]; meanwhile the registers holding stage kt+1 are
-  //   transformed (f = 10, 11) and written to buf[(kt+1)&1] (f = 12..15: its last readers passed
-  //   the previous barrier), and the loads of stage kt+2 are issued into the freed registers.
-  //   All of it is interleaved between the MFMAs, so only lgkmcnt(0) + one barrier per stage is
-  //   exposed, and every global load has ~3500 cycles to land.
-  // (kt is wave-uniform: the source / descriptor choice must stay provably uniform, otherwise hipcc
-  //  wraps every buffer load in a waterfall loop)
-  bool ld_kv = true;
-  auto prep_loads = [&](int kt) {
-    if (vrole) {
-      const int src = kt >= p.nkc0 ? 1 : 0;
-      if (src != cur_src) set_src(src);
-      const int kc = src ? kt - p.nkc0 : kt;
-      ld_kv = kc * WK + vh * 4 < (src ? a.c1s : a.c0s);
-    }
-  };
-  auto issue_loads = [&](int part, int kt) {  // 4 of the 16 loads of stage kt
+  auto load_stage = [&](int kt) {  // kt is wave-uniform: descriptor choice stays provably uniform
     const bool src1 = kt >= p.nkc0;
-    const unsigned soffV = (unsigned)((src1 ? kt - p.nkc0 : kt) * WK * 4);
-    const unsigned soffU = (unsigned)(((int64_t)kt * p.cblocks + cb) * (WU_STAGE * 4));
     if (vrole) {
+      if ((src1 ? 1 : 0) != cur_src) set_src(src1 ? 1 : 0);
+      const int kc = src1 ? kt - p.nkc0 : kt;
+      const unsigned soff = (unsigned)(kc * WK * 4);
+      const bool kv = kc * WK + vq * 2 < (src1 ? a.c1s : a.c0s);
       if (src1) {
 #pragma unroll
-        for (int i = 4 * part; i < 4 * part + 4; ++i) rv[i] = buf_ld4(rs1, ld_kv ? voffV[i] : OOB, soffV);
+        for (int i = 0; i < 16; ++i) rv[i] = buf_ld2(rs1, kv ? voffV[i] : OOB, soff);
       } else {
 #pragma unroll
-        for (int i = 4 * part; i < 4 * part + 4; ++i) rv[i] = buf_ld4(rs0, ld_kv ? voffV[i] : OOB, soffV);
+        for (int i = 0; i < 16; ++i) rv[i] = buf_ld2(rs0, kv ? voffV[i] : OOB, soff);
       }
     } else {
+      const unsigned soff = (unsigned)(((int64_t)kt * p.cblocks + cb) * (WU_STAGE * 4));
 #pragma unroll
-      for (int i = 4 * part; i < 4 * part + 4; ++i) rv[i] = buf_ld4(rw, (unsigned)((tid - 128 + 128 * i) * 16), soffU);
-    }
-  };
-  // in-place input transform V = B^T d B; B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-  auto transform_cols = [&]() {
-    if (vrole) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 d0 = rv[c], d1 = rv[4 + c], d2 = rv[8 + c], d3 = rv[12 + c];
-        rv[c] = f4sub(d0, d2);
-        rv[4 + c] = f4add(d1, d2);
-        rv[8 + c] = f4sub(d2, d1);
-        rv[12 + c] = f4sub(d1, d3);
+      for (int i = 0; i < 8; ++i) {
+        const float4 v = buf_ld4(rw, (unsigned)((tid - 256 + 256 * i) * 16), soff);
+        rv[2 * i] = f32x2{v.x, v.y};
+        rv[2 * i + 1] = f32x2{v.z, v.w};
       }
     }
   };
-  auto transform_rows = [&]() {
-    if (vrole) {
-#pragma unroll
-      for (int xi = 0; xi < 4; ++xi) {
-        const float4 t0 = rv[4 * xi], t1 = rv[4 * xi + 1], t2 = rv[4 * xi + 2], t3 = rv[4 * xi + 3];
-        rv[4 * xi] = f4sub(t0, t2);
-        rv[4 * xi + 1] = f4add(t1, t2);
-        rv[4 * xi + 2] = f4sub(t2, t1);
-        rv[4 * xi + 3] = f4sub(t1, t3);
-      }
-    }
-  };
-  auto write_part = [&](int buf, int part) {  // 4 of the 16 vectors -> LDS
+
+  const int voffL = wswz(vj, vq >> 1) + 2 * (vq & 1);  // + f * WT * WK   (V, frequency f)
+  auto store_stage = [&](int buf) {
     float* Us = wsm + buf * W_STAGE;
     float* Vs = Us + WU_STAGE;
     if (vrole) {
+      // in-place V = B^T d B (packed fp32 adds); B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
 #pragma unroll
-      for (int i = 4 * part; i < 4 * part + 4; ++i) *reinterpret_cast<float4*>(Vs + wswz(i * WT + vj, vh)) = rv[i];
+      for (int c = 0; c < 4; ++c) {
+        const f32x2 d0 = rv[c], d1 = rv[4 + c], d2 = rv[8 + c], d3 = rv[12 + c];
+        rv[c] = d0 - d2;
+        rv[4 + c] = d1 + d2;
+        rv[8 + c] = d2 - d1;
+        rv[12 + c] = d1 - d3;
+      }
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        const f32x2 u0 = rv[4 * xi], u1 = rv[4 * xi + 1], u2 = rv[4 * xi + 2], u3 = rv[4 * xi + 3];
+        *reinterpret_cast<f32x2*>(Vs + (4 * xi + 0) * WT * WK + voffL) = u0 - u2;
+        *reinterpret_cast<f32x2*>(Vs + (4 * xi + 1) * WT * WK + voffL) = u1 + u2;
+        *reinterpret_cast<f32x2*>(Vs + (4 * xi + 2) * WT * WK + voffL) = u2 - u1;
+        *reinterpret_cast<f32x2*>(Vs + (4 * xi + 3) * WT * WK + voffL) = u1 - u3;
+      }
     } else {
 #pragma unroll
-      for (int i = 4 * part; i < 4 * part + 4; ++i) {
-        const int e = tid - 128 + 128 * i;  // float4 index in the [16][64][8] chunk: row = e >> 1, half = e & 1
-        *reinterpret_cast<float4*>(Us + wswz(e >> 1, e & 1)) = rv[i];
+      for (int i = 0; i < 8; ++i) {
+        const int e = tid - 256 + 256 * i;  // float4 index in the [16][64][8] chunk: row = e >> 1, half = e & 1
+        *reinterpret_cast<float4*>(Us + wswz(e >> 1, e & 1)) = make_float4(rv[2 * i].x, rv[2 * i].y, rv[2 * i + 1].x, rv[2 * i + 1].y);
       }
     }
   };
 
-  f32x16 acc[16];
+  f32x16 acc[8];
 #pragma unroll
-  for (int f = 0; f < 16; ++f)
+  for (int f = 0; f < 8; ++f)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
   if (kt_begin < kt_end) {
-    prep_loads(kt_begin);
-#pragma unroll
-    for (int part = 0; part < 4; ++part) issue_loads(part, kt_begin);
-    transform_cols();
-    transform_rows();
-#pragma unroll
-    for (int part = 0; part < 4; ++part) write_part(0, part);
-    if (kt_begin + 1 < kt_end) {
-      prep_loads(kt_begin + 1);
-#pragma unroll
-      for (int part = 0; part < 4; ++part) issue_loads(part, kt_begin + 1);
-    }
+    load_stage(kt_begin);
+    store_stage(0);
   }
   __syncthreads();
 
   // fragment addresses: row (within a frequency) = wave's 32-row block + l31; half = h (swizzled)
-  const int fragA = wswz(wco * 32 + l31, h);  // + f * WC * WK
-  const int fragB = wswz(wti * 32 + l31, h);  // + f * WT * WK
+  const int fragA = (fh * 8) * WC * WK + wswz(wco * 32 + l31, h);  // + f * WC * WK
+  const int fragB = (fh * 8) * WT * WK + wswz(wti * 32 + l31, h);  // + f * WT * WK
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int buf = (kt - kt_begin) & 1;
-    const bool more = kt + 1 < kt_end;    // registers hold stage kt+1
-    const bool more2 = kt + 2 < kt_end;   // stage kt+2 will be loaded
-    if (more2) prep_loads(kt + 2);
+    const bool more = kt + 1 < kt_end;
+    if (more) load_stage(kt + 1);  // in flight under this stage's MFMAs (and the partner wave's)
     const float* Us = wsm + buf * W_STAGE;
     const float* Vs = Us + WU_STAGE;
-    // Register double-buffered fragments: the reads of frequency f+1 are issued before the 4 MFMAs
-    // (256 cycles) of frequency f -- with ONE wave per SIMD nothing else hides the LDS latency.
     float4 fa[2], fb[2];
     fa[0] = *reinterpret_cast<const float4*>(Us + fragA);
     fb[0] = *reinterpret_cast<const float4*>(Vs + fragB);
 #pragma unroll
-    for (int f = 0; f < 16; ++f) {
+    for (int f = 0; f < 8; ++f) {
       const int cur = f & 1, nxt = cur ^ 1;
-      if (f < 15) {
+      if (f < 7) {
         fa[nxt] = *reinterpret_cast<const float4*>(Us + (f + 1) * WC * WK + fragA);
         fb[nxt] = *reinterpret_cast<const float4*>(Vs + (f + 1) * WT * WK + fragB);
       }
@@ -564,22 +544,50 @@ __global__ __launch_bounds__(256, 1) void conv_winograd_kernel(WinoP p) {
       acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].y, acc[f], 0, 0, 0);
       acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].z, fb[cur].z, acc[f], 0, 0, 0);
       acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].w, fb[cur].w, acc[f], 0, 0, 0);
-      // the 4 MFMAs above form one dependent accumulate chain and must stay back to back (any
-      // instruction between them costs ~43 cycles); everything else goes between chains
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) {
-        if (f == 10) transform_cols();
-        if (f == 11) transform_rows();
-        if (f >= 12) write_part(buf ^ 1, f - 12);
-      }
-      if (more2 && f >= 12) issue_loads(f - 12, kt + 2);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (more) store_stage(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- output transform (per lane) + fused epilogue.
+  // ---- output transform.  Y = A^T M A is linear in M, so each wave transforms the 8 frequencies
+  // (two xi rows) it owns into a partial 2x2 output; the xi in {2,3} waves hand theirs to their
+  // xi in {0,1} partners through LDS (once per workgroup), which add and run the fused epilogue.
   // Lane: tile = wti*32 + l31; couts wco*32 + 8*g + 4*h + (0..3) in registers 4g .. 4g+3.
+  float y[4][4][4];  // [g][pixel py*2+px][r]
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s[2][4];
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        const float ma = acc[nu][4 * g + r], mb = acc[4 + nu][4 * g + r];  // xi = 2*fh, 2*fh + 1
+        if (fh == 0) {
+          s[0][nu] = ma + mb;  // A^T rows: [1 1 1 0], [0 1 -1 -1]
+          s[1][nu] = mb;
+        } else {
+          s[0][nu] = ma;
+          s[1][nu] = -ma - mb;
+        }
+      }
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        y[g][py * 2 + 0][r] = (s[py][0] + s[py][1]) + s[py][2];
+        y[g][py * 2 + 1][r] = (s[py][1] - s[py][2]) - s[py][3];
+      }
+    }
+  float* xch = wsm + ((wave & 3) * 64) * 64;  // [64 values][64 lanes] per wave pair
+  if (fh == 1) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int px = 0; px < 4; ++px)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xch[((g * 4 + px) * 4 + r) * 64 + lane] = y[g][px][r];
+  }
+  __syncthreads();
+  if (fh == 1) return;
   const int t = t0 + wti * 32 + l31;
   if (t >= p.ntiles) return;
   const int b = t / tiles_img;
@@ -590,36 +598,21 @@ __global__ __launch_bounds__(256, 1) void conv_winograd_kernel(WinoP p) {
   for (int g = 0; g < 4; ++g) {
     const int co = cb * WC + wco * 32 + 8 * g + 4 * h;
     if (co >= a.cout_s) continue;
-    float y[2][2][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float s[2][4];
-#pragma unroll
-      for (int nu = 0; nu < 4; ++nu) {
-        const float m0 = acc[0 * 4 + nu][4 * g + r], m1 = acc[1 * 4 + nu][4 * g + r];
-        const float m2 = acc[2 * 4 + nu][4 * g + r], m3 = acc[3 * 4 + nu][4 * g + r];
-        s[0][nu] = (m0 + m1) + m2;
-        s[1][nu] = (m1 - m2) - m3;
-      }
-#pragma unroll
-      for (int py = 0; py < 2; ++py) {
-        y[py][0][r] = (s[py][0] + s[py][1]) + s[py][2];
-        y[py][1][r] = (s[py][1] - s[py][2]) - s[py][3];
-      }
+    for (int px = 0; px < 4; ++px) {
+      const int oh = 2 * th + (px >> 1), ow = 2 * tw + (px & 1);
+      if (oh >= a.hout || ow >= a.wout) continue;
+      const int n = (b * a.hout + oh) * a.wout + ow;
+      float4 v;
+      v.x = y[g][px][0] + xch[((g * 4 + px) * 4 + 0) * 64 + lane];
+      v.y = y[g][px][1] + xch[((g * 4 + px) * 4 + 1) * 64 + lane];
+      v.z = y[g][px][2] + xch[((g * 4 + px) * 4 + 2) * 64 + lane];
+      v.w = y[g][px][3] + xch[((g * 4 + px) * 4 + 3) * 64 + lane];
+      if (a.splitk > 1)
+        *reinterpret_cast<float4*>(a.workspace + ((int64_t)blockIdx.y * p.npix + n) * a.cout_s + co) = v;
+      else
+        epilogue_store(a, n, co, v);
     }
-#pragma unroll
-    for (int py = 0; py < 2; ++py)
-#pragma unroll
-      for (int px = 0; px < 2; ++px) {
-        const int oh = 2 * th + py, ow = 2 * tw + px;
-        if (oh >= a.hout || ow >= a.wout) continue;
-        const int n = (b * a.hout + oh) * a.wout + ow;
-        const float4 v = make_float4(y[py][px][0], y[py][px][1], y[py][px][2], y[py][px][3]);
-        if (a.splitk > 1)
-          *reinterpret_cast<float4*>(a.workspace + ((int64_t)blockIdx.y * p.npix + n) * a.cout_s + co) = v;
-        else
-          epilogue_store(a, n, co, v);
-      }
   }
 }
 
@@ -757,7 +750,7 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_winograd_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 2 * W_STAGE * 4, st, p);
+  hipLaunchKernelGGL(conv_winograd_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 2 * W_STAGE * 4, st, p);
   int rc = az_launch_status();
   if (rc != AZ_OK) return rc;
   if (splitk > 1) {
