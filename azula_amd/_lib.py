@@ -176,6 +176,7 @@ PROTOTYPES: dict[str, list] = {
     "az_conv2d_suggest_splitk": [i64, i32, i32, i32],
     "az_conv2d_winograd_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_winograd_suggest_splitk": [i64, i32, i32, i32, i32],
+    "az_winograd_pack_filter_f32": [vp, vp, i32, i32, i32, i32, i32, i32, c_stream],
     "az_pack_conv_weight_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, c_stream],
     "az_attention_f32": [C.POINTER(AzAttnArgs), c_stream],
     "az_patchify_f32": [vp, vp, vp, i64, i64, i64, i64, i64, i64, c_stream],

@@ -65,6 +65,45 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(float* __restrict
   }
 }
 
+// Winograd F(2x2,3x3) filter transform U = G g G^T (accumulated in fp64, rounded once) written
+// directly in the layout conv_winograd_kernel streams: [8-cin chunk][64-cout block][16][64][8].
+__global__ __launch_bounds__(256) void winograd_filter_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                              int cout, int cin, int cin0, int nk0, int nk,
+                                                              int cblocks) {
+  const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+  const int64_t total = (int64_t)nk * cblocks * 16 * 64 * 8;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e & 7);
+    const int col = (int)((e >> 3) & 63);
+    const int f = (int)((e >> 9) & 15);
+    const int64_t r = e >> 13;
+    const int cbk = (int)(r % cblocks);
+    const int kt = (int)(r / cblocks);
+    const int co = cbk * 64 + col;
+    int ci = -1;
+    if (kt < nk0) {
+      const int pc = kt * 8 + k;
+      if (pc < cin0) ci = pc;
+    } else {
+      const int pc = (kt - nk0) * 8 + k;
+      if (pc < cin - cin0) ci = cin0 + pc;
+    }
+    float v = 0.f;
+    if (co < cout && ci >= 0) {
+      const float* g = src + ((int64_t)co * cin + ci) * 9;
+      const int xi = f >> 2, nu = f & 3;
+      double acc = 0.0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc += G[xi][a] * (double)g[a * 3 + b] * G[nu][b];
+      v = (float)acc;
+    }
+    dst[e] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -97,6 +136,18 @@ int az_pack_conv_weight_f32(float* dst, const float* src, int32_t cout, int32_t 
   const int64_t total = (int64_t)ks * ks * cout_s * cin_s;
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream), dst, src,
                      cout, cin, ks * ks, cout_s, cin0, c0s, cin_s);
+  return az_launch_status();
+}
+
+int az_winograd_pack_filter_f32(float* dst, const float* src, int32_t cout, int32_t cin, int32_t cin0, int32_t nk0,
+                                int32_t nk, int32_t cblocks, az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(cout > 0 && cin > 0 && cin0 >= 0 && cin0 <= cin && nk0 * 8 >= cin0 && (nk - nk0) * 8 >= cin - cin0 &&
+                 cblocks * 64 >= cout,
+             AZ_E_SHAPE);
+  const int64_t total = (int64_t)nk * cblocks * 16 * 64 * 8;
+  hipLaunchKernelGGL(winograd_filter_kernel, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream), dst, src,
+                     cout, cin, cin0, nk0, nk, cblocks);
   return az_launch_status();
 }
 

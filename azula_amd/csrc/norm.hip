@@ -55,13 +55,23 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(float* __restrict__ p
     const bool second = x1 != nullptr && c >= c0s;
     const int scs = x1 == nullptr ? cs : (second ? cs - c0s : c0s);
     const float* base = (second ? x1 : x) + ((int64_t)b * HW) * scs + (second ? c - c0s : c);
-    bool first = true;
-    for (int64_t p = p0 + pl; p < p1; p += ppi) {
-      const float4 v = *reinterpret_cast<const float4*>(base + p * scs);
-      if (first) {
-        shift = v.x;
-        first = false;
+    int64_t p = p0 + pl;
+    if (p < p1) shift = base[p * scs];  // shift = first element: sums of (x - shift) cannot cancel badly
+    // 4 independent 16-byte loads in flight per lane (a streaming reduction is latency-bound otherwise)
+    for (; p + 3 * ppi < p1; p += 4 * ppi) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(base + (p + u * ppi) * scs);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float a0 = v[u].x - shift, a1 = v[u].y - shift, a2 = v[u].z - shift, a3 = v[u].w - shift;
+        s1 += (a0 + a1) + (a2 + a3);
+        s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
       }
+      cnt += 16.f;
+    }
+    for (; p < p1; p += ppi) {
+      const float4 v = *reinterpret_cast<const float4*>(base + p * scs);
       const float a0 = v.x - shift, a1 = v.y - shift, a2 = v.z - shift, a3 = v.w - shift;
       s1 += (a0 + a1) + (a2 + a3);
       s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);

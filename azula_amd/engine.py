@@ -162,18 +162,17 @@ class ConvWeights:
         return self._direct
 
     def winograd(self) -> torch.Tensor:
-        r"""Filter transform U = G g G^T (fp64 -> fp32, one-off) laid out
+        r"""Filter transform U = G g G^T (az_winograd_pack_filter_f32: fp64 accumulate, one-off) laid out
         [8-channel chunk][64-cout block][16 frequencies][64][8]; source 1 starts on a chunk boundary."""
         if self._wino is None:
-            G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=self.device)
-            U = torch.einsum("xk,ockl,yl->xyoc", G, self.w.double(), G).reshape(16, self.cout, self.cin).float()
             nk0, nk1 = (self.c0s + 7) // 8, (self.c1s + 7) // 8
             cb = (self.cout_s + 63) // 64
-            Up = torch.zeros(16, cb * 64, (nk0 + nk1) * 8, dtype=torch.float32, device=self.device)
-            Up[:, : self.cout, : self.cin0] = U[:, :, : self.cin0]
-            if self.cin > self.cin0:
-                Up[:, : self.cout, nk0 * 8 : nk0 * 8 + self.cin - self.cin0] = U[:, :, self.cin0 :]
-            self._wino = Up.reshape(16, cb, 64, nk0 + nk1, 8).permute(3, 1, 0, 2, 4).contiguous().reshape(-1)
+            packed = torch.empty((nk0 + nk1) * cb * 16 * 64 * 8, dtype=torch.float32, device=self.device)
+            _lib.call(
+                "az_winograd_pack_filter_f32", packed.data_ptr(), self.w.data_ptr(), self.cout, self.cin, self.cin0,
+                nk0, nk0 + nk1, cb, _lib.stream_ptr(),
+            )
+            self._wino = packed
         return self._wino
 
 

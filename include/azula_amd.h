@@ -259,6 +259,12 @@ int az_patchify_f32(float* dst, const float* src, const float* scale_dev, int64_
 int az_unpatchify_f32(float* dst, const float* src, int64_t B, int64_t Z, int64_t H, int64_t W, int64_t p, int64_t cs,
                       az_stream_t stream);
 
+/* torch (cout, cin, 3, 3) -> Winograd filter transform U = G g G^T (fp64 accumulate, one rounding) in
+ * the layout az_conv2d_winograd_f32 streams: [nk chunks of 8 cin][cblocks of 64 cout][16][64][8]; input
+ * channels [0, cin0) fill chunks [0, nk0), the rest start at chunk nk0 (two-source concat).      */
+int az_winograd_pack_filter_f32(float* dst, const float* src, int32_t cout, int32_t cin, int32_t cin0, int32_t nk0,
+                                int32_t nk, int32_t cblocks, az_stream_t stream);
+
 /* ------------------------------------------------------------------ hipGraph helpers (host side)
  * Capture everything enqueued on `stream` between begin/end into an executable graph.         */
 typedef struct AzGraph AzGraph;
