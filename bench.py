@@ -34,6 +34,23 @@ CONFIGS = {
                  hid_blocks=(2, 2, 2, 2, 2, 2), norm="group", groups=32, mod_features=1024),
         name="azula.nn.unet ADM-shaped UNet 3x256x256 (320.5M params), KarrasDenoiser+VPSchedule, DDIMSampler(steps=64, eta=0)",
     ),
+    # BASELINE.json configs[2]: azula.nn.vit ViT as DiT-B/2 (4x32x32 latent), DDIM-50, batch 64 per GPU
+    "c3": dict(
+        kind="vit", batch=64, shape=(4, 32, 32), steps=50,
+        net=dict(in_channels=4, out_channels=4, hid_channels=768, hid_blocks=12, attention_heads=12, patch_size=2,
+                 mod_features=768),
+        name="azula.nn.vit ViT DiT-B/2 4x32x32 (115M params), KarrasDenoiser+VPSchedule, DDIMSampler(steps=50, eta=0)",
+    ),
+    # BASELINE.json configs[4]: ADM imagenet_256x256 architecture (random init, zero-init layers re-randomised),
+    # DDIM-64; "guidance" adds the second (negative) backbone evaluation of CFG on the class-conditional card
+    "c5": dict(
+        kind="adm", card="imagenet_256x256", batch=4, shape=(3, 256, 256), steps=64,
+        name="azula.plugins.adm imagenet_256x256 UNetModel (552.8M params, random init), AblatedDenoiser, DDIMSampler(steps=64)",
+    ),
+    "c5cfg": dict(
+        kind="adm", card="imagenet_256x256_cond", batch=4, shape=(3, 256, 256), steps=64, cfg=2.0,
+        name="azula.plugins.adm imagenet_256x256_cond (random init) + CFGDenoiser(g=2), DDIMSampler(steps=64)",
+    ),
     # small variant for quick functional checks of the harness
     "tiny": dict(
         kind="unet", batch=2, shape=(3, 64, 64), steps=8,
@@ -44,14 +61,33 @@ CONFIGS = {
 }
 
 
+def rerandomise_zero_tensors(module, seed=123):
+    r"""every all-zero weight tensor with ndim > 1 (ADM zero_module layers) is refilled
+    N(0, 1/fan_in) from a fixed generator, otherwise random-init ADM outputs exactly 0."""
+    import math
+
+    g = torch.Generator().manual_seed(seed)
+    for _, v in sorted(module.state_dict().items()):
+        if torch.is_floating_point(v) and v.ndim > 1 and not torch.any(v != 0):
+            v.copy_(torch.randn(v.shape, generator=g) / math.sqrt(v[0].numel()))
+
+
 def build_denoiser(cfg, device):
     from azula_amd.denoise import KarrasDenoiser
-    from azula_amd.nn import TimeModulated, UNet
+    from azula_amd.nn import TimeModulated, UNet, ViT
     from azula_amd.noise import VPSchedule
 
     torch.manual_seed(0)  # weights = module default init under seed 0 (SURVEY.md section 8d)
-    net = UNet(**cfg["net"])
-    wrapped = TimeModulated(net, cfg["net"]["mod_features"], name="unet")
+    if cfg["kind"] == "adm":
+        from azula_amd.guidance import CFGDenoiser
+        from azula_amd.plugins import adm
+
+        den = adm.make_model(**adm.load_cards(adm)[cfg["card"]].config)
+        rerandomise_zero_tensors(den.backbone)
+        den = den.to(device).eval()
+        return CFGDenoiser(den) if cfg.get("cfg") else den
+    net = UNet(**cfg["net"]) if cfg["kind"] == "unet" else ViT(**cfg["net"])
+    wrapped = TimeModulated(net, cfg["net"]["mod_features"], name=cfg["kind"])
     return KarrasDenoiser(wrapped, VPSchedule()).to(device).eval()
 
 
@@ -211,9 +247,14 @@ def main() -> None:
     torch.manual_seed(1)  # same seed on every rank: the full batch is drawn and sliced (parity with 1 GPU)
     x1 = init_sharded(sampler, (world * B, *cfg["shape"]), device=device)  # resident in HBM before timing
 
+    kwargs = {}
+    if cfg.get("cfg"):
+        lab = torch.arange(B, device=device) % 1000
+        kwargs = dict(positive={"label": lab}, negative={"label": torch.zeros_like(lab)}, guidance=cfg["cfg"])
+
     def one_pass():
         # 64 graph replays on this rank's shard, then the only collective: all-gather of x0
-        return sample_sharded(sampler, x1)
+        return sample_sharded(sampler, x1, **kwargs)
 
     def fence():
         if world > 1:
@@ -238,7 +279,8 @@ def main() -> None:
         ms_per_step = elapsed / args.steps * 1e3
         images_per_s = world * B * args.steps / elapsed
         out = {
-            "metric": "images/sec (whole node), DDIM-64 256x256 UNet",
+            "metric": "images/sec (whole node), DDIM-64 256x256 UNet" if args.config == "c2"
+            else f"images/sec (whole node), {args.config}",
             "value": round(images_per_s, 4),
             "unit": "images/s",
             "n_gpus": world,
@@ -272,7 +314,7 @@ def main() -> None:
                           "flops_per_forward": allc["flops"]},
         }
         out["roofline_transition"] = transition_roofline(device)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and cfg["kind"] == "unet":
             out["cpu_baseline"] = cpu_baseline(den, cfg)
             out["speedup_vs_cpu"] = round(images_per_s / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
