@@ -38,7 +38,6 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(float* __restrict__ p
                                                            const float* __restrict__ x1, int c0s, int64_t HW, int C,
                                                            int cs, int groups, int nchunks, int qs) {
   __shared__ float sh_n[256], sh_mean[256], sh_m2[256];
-  __shared__ int sh_g[256];
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, b = blockIdx.y, z = blockIdx.z;
   const int Cg = C / groups;
@@ -85,17 +84,25 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(float* __restrict__ p
   sh_n[tid] = m.n;
   sh_mean[tid] = m.mean;
   sh_m2[tid] = m.m2;
-  sh_g[tid] = live ? c / Cg : -1;
   __syncthreads();
-  // one leader thread per group present in this slice
+  // two short serial phases instead of one 256-long scan: (1) the first qs threads fold the ppi
+  // pixel lanes of their channel chunk, (2) one leader per group folds its Cg/4 chunks.
+  if (tid < qs) {
+    Moments acc = {sh_n[tid], sh_mean[tid], sh_m2[tid]};
+    for (int k = 1; k < ppi; ++k) acc = combine(acc, Moments{sh_n[tid + k * qs], sh_mean[tid + k * qs], sh_m2[tid + k * qs]});
+    sh_n[tid] = acc.n;
+    sh_mean[tid] = acc.mean;
+    sh_m2[tid] = acc.m2;
+  }
+  __syncthreads();
   const int g_lo = (z * 1024) / Cg;
   const int g = g_lo + tid;
   const int c_hi = z * 1024 + qs * 4 < C ? z * 1024 + qs * 4 : C;
   if (g < groups && g * Cg < c_hi && (g + 1) * Cg > z * 1024) {
-    Moments acc = {0.f, 0.f, 0.f};
-    for (int t = 0; t < 256; ++t)
-      if (sh_g[t] == g) acc = combine(acc, Moments{sh_n[t], sh_mean[t], sh_m2[t]});
     // a group never straddles slices when Cg divides 1024 (checked on the host)
+    const int q_lo = (g * Cg) / 4 - z * 256, q_hi = ((g + 1) * Cg) / 4 - z * 256;
+    Moments acc = {0.f, 0.f, 0.f};
+    for (int t = q_lo; t < q_hi; ++t) acc = combine(acc, Moments{sh_n[t], sh_mean[t], sh_m2[t]});
     float* out = partials + (((int64_t)b * nchunks + chunk) * groups + g) * 4;
     out[0] = acc.n;
     out[1] = acc.mean;

@@ -322,7 +322,7 @@ class Builder:
             assert x.C == x.cs and x1.C == x1.cs and (x1.H, x1.W) == (x.H, x.W)
             x1p, c0s = x1.ptr, x.cs
             x = Act(x.buf, x.B, x.H, x.W, x.C + x1.C, x.cs + x1.cs, True)
-        nchunks = int(min(256, max(1, (HW * x.cs * 4) // 131072)))
+        nchunks = int(min(512, max(1, (HW * x.cs * 4) // 65536)))  # ~64 KB of x per workgroup
         partials = self.empty(B * nchunks * groups * 4)
         S, T = self.empty(B * x.cs), self.empty(B * x.cs)
         self.tape.add("az_groupnorm_stats_f32", partials.data_ptr(), x.ptr, x1p, c0s, B, HW, x.C, x.cs, groups, nchunks)
