@@ -18,7 +18,13 @@
 // one block's MFMAs cover the other's barrier/load latency.
 //
 // The gather handles zero padding, stride, two concatenated sources and read-side nearest x2
-// upsampling, so concat / upsample / pad never touch HBM as separate passes.
+// upsampling, so concat / upsample / pad never touch HBM as separate passes.  It is built on
+// bounds-checked buffer loads: a per-lane byte offset that only changes when the (tap, source)
+// changes (out-of-range = reads as zero, so padding / ragged tiles / channel tails need no
+// branches) plus a wave-uniform scalar offset that walks K.
+//
+// This file holds two kernels behind the same AzConvArgs: the direct implicit GEMM below (any
+// ksize / stride, linears) and the fused Winograd F(2x2,3x3) kernel further down (3x3 stride 1).
 #include "common.h"
 
 namespace {
