@@ -220,7 +220,11 @@ class Sampler(abc.ABC):
 
     def _call_fused(self, x: Tensor, kwargs: dict) -> Tensor | None:
         dev = x.device
-        key = (tuple(x.shape), str(dev), tuple(sorted(kwargs)))
+        g = kwargs.get("guidance")
+        key = (
+            tuple(x.shape), str(dev), tuple(sorted(kwargs)), self.start, self.stop, self.steps, getattr(self, "eta", None),
+            None if torch.is_tensor(g) else g, id(self.denoiser),
+        )
         ent = self._fused_cache.get(key)
         if ent is None:
             cur = torch.zeros(COEF_WORDS, dtype=torch.float32, device=dev)
