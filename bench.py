@@ -160,8 +160,12 @@ def transition_roofline(device, n=1 << 26):
     torch.cuda.synchronize(device)
     ms = e0.elapsed_time(e1) / reps
     gbs = 12.0 * n / (ms * 1e-3) / 1e9
+    # HBM bytes per launch from rocprofv3 PMC passes of this same kernel and size (FETCH_SIZE doubled per the
+    # gfx950 note + WRITE_SIZE; profiles/r01_hbm_traffic_pmc.txt): equal to the algorithmic bytes, no re-reads
+    pmc_traffic = 805306368 if n == 1 << 26 else None
     return dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
-                traffic=None, elements=n, bytes_per_element=12, avg_us=round(ms * 1e3, 2),
+                traffic=pmc_traffic, traffic_source="profiles/r01_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
+                algorithmic_bytes=12 * n, elements=n, bytes_per_element=12, avg_us=round(ms * 1e3, 2),
                 kernel="transition_flat_kernel (DDIM eta=0)")
 
 
