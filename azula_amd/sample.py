@@ -32,7 +32,9 @@ from ._lib import COEF_FIELDS, COEF_WORDS
 from .denoise import Denoiser, require_f32_cuda
 from .engine import StepGraph, Tape, transition_args
 
-__all__ = ["Sampler", "DDPMSampler", "DDIMSampler", "FusedDenoiser", "BackboneProgram"]
+__all__ = [
+    "Sampler", "DDPMSampler", "DDIMSampler", "EulerSampler", "HeunSampler", "ItoSampler", "FusedDenoiser", "BackboneProgram",
+]
 
 
 # ------------------------------------------------------------------------------- fused protocol
@@ -148,23 +150,34 @@ class Sampler(abc.ABC):
     def _tau(self, alpha_t, sigma_t, alpha_s, sigma_s) -> Tensor:
         raise NotImplementedError()
 
+    def _kernel_scalars(self, alpha_t, sigma_t, alpha_s, sigma_s):
+        r"""(a_t, a_s, k_x, k_eps) of the kernel form x_s = a_s m + k_x (x_t - a_t m) + k_eps eps.
+        DDPM / DDIM use it verbatim (reference op order, ``azula/sample.py:249-259``)."""
+        tau = self._tau(alpha_t, sigma_t, alpha_s, sigma_s)
+        return alpha_t, alpha_s, sigma_s * torch.sqrt(1 - tau) / sigma_t, sigma_s * torch.sqrt(tau)
+
     def _transition_scalars(self, t: Tensor, s: Tensor):
-        r"""0-d scalars of one transition in the reference's op order (``azula/sample.py:249-259``)."""
+        r"""0-d scalars of one transition: the schedule at (t, s) and the kernel coefficients."""
         alpha_s, sigma_s = self.denoiser.schedule(s)
         alpha_t, sigma_t = self.denoiser.schedule(t)
-        tau = self._tau(alpha_t, sigma_t, alpha_s, sigma_s)
-        k_x = sigma_s * torch.sqrt(1 - tau) / sigma_t
-        k_eps = sigma_s * torch.sqrt(tau)
-        return alpha_t, sigma_t, alpha_s, sigma_s, k_x, k_eps
+        return (alpha_t, sigma_t, alpha_s, sigma_s, *self._kernel_scalars(alpha_t, sigma_t, alpha_s, sigma_s))
+
+    def _host_step(self, x_t: Tensor, mean: Tensor, t: Tensor, s: Tensor) -> Tensor:
+        r"""Host tensors: the reference's op sequence (``azula/sample.py:210-214, 257-259``)."""
+        _, _, _, _, a_t, a_s, k_x, k_eps = self._transition_scalars(t, s)
+        x_s = a_s * mean
+        x_s = x_s + k_x * (x_t - a_t * mean)
+        x_s = x_s + k_eps * self._draw_noise(x_t)
+        return x_s
 
     def _step_impl(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
-        alpha_t, sigma_t, alpha_s, sigma_s, k_x, k_eps = self._transition_scalars(t, s)
         q_t = self.denoiser(x_t, t, **kwargs)
-        if not x_t.is_cuda:  # host tensors: reference op sequence
-            x_s = alpha_s * q_t.mean
-            x_s = x_s + k_x * (x_t - alpha_t * q_t.mean)
-            x_s = x_s + k_eps * self._draw_noise(x_t)
-            return x_s
+        if not x_t.is_cuda:
+            return self._host_step(x_t, q_t.mean, t, s)
+        return self._device_transition(x_t, q_t.mean, t, s)
+
+    def _device_transition(self, x_t: Tensor, mean: Tensor, t: Tensor, s: Tensor) -> Tensor:
+        _, _, _, _, alpha_t, alpha_s, k_x, k_eps = self._transition_scalars(t, s)
         require_f32_cuda(x_t, type(self).__name__)
         dev = x_t.device
         zero = torch.zeros((), device=dev)
@@ -176,7 +189,7 @@ class Sampler(abc.ABC):
         for name, v in vals.items():
             row[COEF_FIELDS.index(name)] = v.to(device=dev, dtype=torch.float32)
         x_c = x_t.contiguous()
-        mean = q_t.mean.to(x_c).contiguous()
+        mean = mean.to(x_c).contiguous()
         eps = self._draw_noise(x_c)
         x_s = torch.empty_like(x_c)
         a = transition_args(
@@ -189,8 +202,8 @@ class Sampler(abc.ABC):
     # ---------------------------------------------------------------------------- fused path
     def _fusable(self, x: Tensor) -> bool:
         cls_step = type(self).step
-        if cls_step not in (DDPMSampler.step, DDIMSampler.step):
-            return False  # user subclass overrides step (guidance samplers): generic loop
+        if cls_step not in (DDPMSampler.step, DDIMSampler.step, EulerSampler.step, ItoSampler.step):
+            return False  # user subclass overrides step (guidance samplers), Heun: generic loop
         return x.dtype == torch.float32 and self.dtype in (None, torch.float32) and x.ndim >= 2
 
     def _host_table(self, fused: FusedDenoiser) -> Tensor:
@@ -200,14 +213,14 @@ class Sampler(abc.ABC):
         irows = rows.view(torch.int32)  # integer slots (time_index, step) are bit-cast in place
         col = {n: i for i, n in enumerate(COEF_FIELDS)}
         for i, (t, s) in enumerate(ts.unfold(0, 2, 1).unbind()):
-            alpha_t, sigma_t, alpha_s, sigma_s, k_x, k_eps = self._transition_scalars(t, s)
+            alpha_t, sigma_t, alpha_s, sigma_s, ka_t, ka_s, k_x, k_eps = self._transition_scalars(t, s)
             co = fused.coefficients(alpha_t, sigma_t)
             for name, v in co.items():
                 if name == "time_index":
                     irows[i, col[name]] = int(v)
                 else:
                     rows[i, col[name]] = v.to(torch.float32)
-            rows[i, col["alpha_t"]], rows[i, col["alpha_s"]] = alpha_t, alpha_s
+            rows[i, col["alpha_t"]], rows[i, col["alpha_s"]] = ka_t, ka_s
             rows[i, col["k_x"]], rows[i, col["k_eps"]] = k_x, k_eps
             rows[i, col["clip_lo"]], rows[i, col["clip_hi"]] = fused.clip
             rows[i, col["guidance"]] = fused.guidance
@@ -345,6 +358,116 @@ class DDIMSampler(Sampler):
         # eta = 0 => tau = 0 => k_eps = 0: the noise term vanishes.  The reference still draws
         # randn_like (advancing the RNG); `rng_parity` keeps that draw without reading it.
         return self.eta != 0
+
+    def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
+        return self._step_impl(x_t, t, s, **kwargs)
+
+
+# ------------------------------------------------------------------------------- next samplers
+def _lin2(a: Tensor, x: Tensor, b: Tensor, y: Tensor) -> Tensor:
+    r"""a * x + b * y with 0-d coefficient tensors: ``az_axpby_f32`` on device tensors."""
+    if not x.is_cuda:
+        return a * x + b * y
+    require_f32_cuda(x, "sampler")
+    x, y = x.contiguous(), y.to(x).contiguous()
+    out = torch.empty_like(x)
+    a = a.to(device=x.device, dtype=torch.float32).reshape(1)
+    b = b.to(device=x.device, dtype=torch.float32).reshape(1)
+    _lib.call("az_axpby_f32", out.data_ptr(), a.data_ptr(), x.data_ptr(), b.data_ptr(), y.data_ptr(), 1, x.numel(), 0, _lib.stream_ptr())
+    return out
+
+
+class EulerSampler(Sampler):
+    r"""Explicit Euler (1st order) sampler (reference ``azula/sample.py:264-305``):
+    z_t = (x_t - alpha_t mu) / sigma_t;  x_s = alpha_s/alpha_t x_t + alpha_s (sigma_s/alpha_s - sigma_t/alpha_t) z_t.
+    The update is linear in (x_t, mu), so on the device it is the same fused transition kernel
+    with folded coefficients (tolerance-level, not bit-level, parity with the reference)."""
+
+    def __init__(self, denoiser: Denoiser, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.denoiser = denoiser
+
+    @staticmethod
+    def _euler_coefficients(alpha_t, sigma_t, alpha_s, sigma_s):
+        r"""x_s = A x_t + B mu."""
+        c = alpha_s * (sigma_s / alpha_s - sigma_t / alpha_t)
+        return alpha_s / alpha_t + c / sigma_t, -c * alpha_t / sigma_t
+
+    def _kernel_scalars(self, alpha_t, sigma_t, alpha_s, sigma_s):
+        A, B = self._euler_coefficients(alpha_t, sigma_t, alpha_s, sigma_s)
+        zero = torch.zeros_like(A)
+        return zero, B, A, zero  # x_s = B m + A (x_t - 0 m)
+
+    def _needs_noise(self) -> bool:
+        return False
+
+    def _host_step(self, x_t, mean, t, s):
+        alpha_s, sigma_s = self.denoiser.schedule(s)
+        alpha_t, sigma_t = self.denoiser.schedule(t)
+        z_t = (x_t - alpha_t * mean) / sigma_t
+        return alpha_s / alpha_t * x_t + alpha_s * (sigma_s / alpha_s - sigma_t / alpha_t) * z_t
+
+    def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
+        return self._step_impl(x_t, t, s, **kwargs)
+
+
+class HeunSampler(EulerSampler):
+    r"""Explicit Heun (2nd order) sampler (reference ``azula/sample.py:308-352``): an Euler predictor,
+    a second denoiser call at ``s`` and the trapezoidal corrector.  Two backbone evaluations per step;
+    runs the generic step loop (each evaluation is the compiled kernel tape, the elementwise
+    updates are ``az_axpby_f32``)."""
+
+    def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
+        alpha_s, sigma_s = self.denoiser.schedule(s)
+        alpha_t, sigma_t = self.denoiser.schedule(t)
+        q_t = self.denoiser(x_t, t, **kwargs)
+        if not x_t.is_cuda:  # host tensors: reference op sequence
+            z_t = (x_t - alpha_t * q_t.mean) / sigma_t
+            x_s = alpha_s / alpha_t * x_t + alpha_s * (sigma_s / alpha_s - sigma_t / alpha_t) * z_t
+            q_s = self.denoiser(x_s, s, **kwargs)
+            z_s = (x_s - alpha_s * q_s.mean) / sigma_s
+            z_t = (z_t + z_s) / 2
+            return alpha_s / alpha_t * x_t + alpha_s * (sigma_s / alpha_s - sigma_t / alpha_t) * z_t
+        c = alpha_s * (sigma_s / alpha_s - sigma_t / alpha_t)
+        z_t = _lin2(1 / sigma_t, x_t, -alpha_t / sigma_t, q_t.mean)
+        x_p = _lin2(alpha_s / alpha_t, x_t, c, z_t)
+        q_s = self.denoiser(x_p, s, **kwargs)
+        z_s = _lin2(1 / sigma_s, x_p, -alpha_s / sigma_s, q_s.mean)
+        z_m = _lin2(torch.full_like(c, 0.5), z_t, torch.full_like(c, 0.5), z_s)
+        return _lin2(alpha_s / alpha_t, x_t, c, z_m)
+
+
+class ItoSampler(Sampler):
+    r"""Ito SDE sampler (reference ``azula/sample.py:355-431``):
+    x_s = alpha_s/alpha_t x_t + (1 + eta^2)/tau (sigma_s/sigma_t - alpha_s/alpha_t)(x_t - alpha_t mu)
+          + eta alpha_s sqrt|sigma_t^2/alpha_t^2 - sigma_s^2/alpha_s^2| eps  -- the fused kernel's form."""
+
+    def __init__(self, denoiser: Denoiser, eta: float = 1.0, temperature: float = 1.0, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.denoiser = denoiser
+        self.eta = eta
+        self.temperature = temperature
+
+    def _ito(self, alpha_t, sigma_t, alpha_s, sigma_s):
+        k = (1 + self.eta**2) / self.temperature * (sigma_s / sigma_t - alpha_s / alpha_t)
+        k_eps = self.eta * alpha_s * torch.sqrt(torch.abs((sigma_t / alpha_t) ** 2 - (sigma_s / alpha_s) ** 2))
+        return alpha_s / alpha_t, k, k_eps
+
+    def _kernel_scalars(self, alpha_t, sigma_t, alpha_s, sigma_s):
+        r_, k, k_eps = self._ito(alpha_t, sigma_t, alpha_s, sigma_s)
+        # x_s = r x + k (x - a_t m) = (-k a_t) m + (r + k) (x - 0 m)
+        return torch.zeros_like(k), -k * alpha_t, r_ + k, k_eps
+
+    def _needs_noise(self) -> bool:
+        return self.eta != 0
+
+    def _host_step(self, x_t, mean, t, s):
+        alpha_s, sigma_s = self.denoiser.schedule(s)
+        alpha_t, sigma_t = self.denoiser.schedule(t)
+        r_, k, k_eps = self._ito(alpha_t, sigma_t, alpha_s, sigma_s)
+        x_s = r_ * x_t
+        x_s = x_s + k * (x_t - alpha_t * mean)
+        return x_s + k_eps * self._draw_noise(x_s)
 
     def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
         return self._step_impl(x_t, t, s, **kwargs)

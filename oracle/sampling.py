@@ -190,3 +190,44 @@ def sample(
             record_eps.append(eps)
         x_t = transition(x_t, mean, eps, alpha_t, sigma_t, alpha_s, sigma_s, eta)
     return x_t
+
+
+# --------------------------------------------------------------------------- SURVEY 8f samplers
+def euler_update(x_t, mean, alpha_t, sigma_t, alpha_s, sigma_s) -> Tensor:
+    r"""EulerSampler.step arithmetic -- azula/sample.py:296-305."""
+    z_t = (x_t - alpha_t * mean) / sigma_t
+    return alpha_s / alpha_t * x_t + alpha_s * (sigma_s / alpha_s - sigma_t / alpha_t) * z_t
+
+
+def sample_euler(mean_fn, x, schedule=vp_schedule, steps: int = 64, heun: bool = False, **kwargs) -> Tensor:
+    r"""Euler (azula/sample.py:296-305) / Heun (:340-352) loops."""
+    x_t = x
+    for t, s in time_pairs(steps=steps).unbind():
+        alpha_s, sigma_s = schedule(s)
+        alpha_t, sigma_t = schedule(t)
+        mean = mean_fn(x_t, t, **kwargs)
+        z_t = (x_t - alpha_t * mean) / sigma_t
+        x_s = alpha_s / alpha_t * x_t + alpha_s * (sigma_s / alpha_s - sigma_t / alpha_t) * z_t
+        if heun:
+            z_s = (x_s - alpha_s * mean_fn(x_s, s, **kwargs)) / sigma_s
+            z_t = (z_t + z_s) / 2
+            x_s = alpha_s / alpha_t * x_t + alpha_s * (sigma_s / alpha_s - sigma_t / alpha_t) * z_t
+        x_t = x_s
+    return x_t
+
+
+def sample_ito(mean_fn, x, schedule=vp_schedule, steps: int = 64, eta: float = 1.0, temperature: float = 1.0,
+               eps_list=None, record_eps=None, **kwargs) -> Tensor:
+    r"""ItoSampler loop -- azula/sample.py:417-431."""
+    x_t = x
+    for i, (t, s) in enumerate(time_pairs(steps=steps).unbind()):
+        alpha_s, sigma_s = schedule(s)
+        alpha_t, sigma_t = schedule(t)
+        mean = mean_fn(x_t, t, **kwargs)
+        x_s = alpha_s / alpha_t * x_t
+        x_s = x_s + (1 + eta**2) / temperature * (sigma_s / sigma_t - alpha_s / alpha_t) * (x_t - alpha_t * mean)
+        eps = torch.randn_like(x_s) if eps_list is None else eps_list[i]
+        if record_eps is not None:
+            record_eps.append(eps)
+        x_t = x_s + eta * alpha_s * torch.sqrt(torch.abs((sigma_t / alpha_t) ** 2 - (sigma_s / alpha_s) ** 2)) * eps
+    return x_t

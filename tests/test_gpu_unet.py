@@ -143,3 +143,31 @@ def test_unet_forward_through_winograd(golden, monkeypatch):
         err, sc = max_err(y, g["y_modB"]), g["y_modB"].abs().max().item()
         print(name, "winograd max|d| vs reference:", err, "scale", sc)
         assert err < 2e-4 * max(1.0, sc)
+
+
+def test_next_samplers_on_gpu(golden):
+    """Euler and Ito ride the fused transition kernel (folded coefficients), Heun the generic
+    two-evaluation step; all against reference-generated vectors (G8)."""
+    from azula_amd.sample import EulerSampler, HeunSampler, ItoSampler
+
+    g = golden("g8_unet_next_samplers")
+    den, sd, cfg = wrapped_denoiser(g)
+    x1 = g["x1"].cuda()
+    sc = max(1.0, g["euler16"].abs().max().item())
+    smp = EulerSampler(den, steps=16, silent=True)
+    x0 = smp(x1)
+    assert next(iter(smp._fused_cache.values())).graph is not None
+    print("euler16", max_err(x0, g["euler16"]))
+    assert max_err(x0, g["euler16"]) < 5e-4 * sc
+    x0 = HeunSampler(den, steps=8, silent=True)(x1)
+    print("heun8", max_err(x0, g["heun8"]))
+    assert max_err(x0, g["heun8"]) < 5e-4 * sc
+    # Ito with the device RNG: compare with the oracle fed the same noise
+    torch.manual_seed(5)
+    eps = [torch.randn_like(x1).cpu() for _ in range(16)]
+    torch.manual_seed(5)
+    x0 = ItoSampler(den, steps=16, silent=True)(x1)
+    omean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, cfg, a, c), x, t)  # noqa: E731
+    ref = sampling.sample_ito(omean, g["x1"], steps=16, eps_list=eps)
+    print("ito16", max_err(x0, ref))
+    assert max_err(x0, ref) < 5e-4 * max(1.0, ref.abs().max().item())

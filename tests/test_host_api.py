@@ -191,3 +191,20 @@ def test_adm_cards_and_hub_layout(tmp_path):
     a, s = den.schedule(torch.tensor(1.0))
     co = den.host_coefficients(a, s)
     assert int(co["time_index"]) == 954 and abs(float(co["c_out"]) + 100) < 1.0
+
+
+def test_next_samplers_cpu_match_reference(golden):
+    """Euler / Heun / Ito on the host follow the reference bit for bit (G8)."""
+    from azula_amd.sample import EulerSampler, HeunSampler, ItoSampler
+
+    g = golden("g8_toy_next_samplers")
+    net = ToyMLP()
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"]))
+    den = KarrasDenoiser(net, VPSchedule()).eval()
+    assert max_err(EulerSampler(den, steps=64, silent=True)(g["x1"]), g["euler64"]) < 1e-5
+    assert max_err(HeunSampler(den, steps=64, silent=True)(g["x1"]), g["heun64"]) < 1e-5
+    torch.manual_seed(2)
+    x0 = ItoSampler(den, steps=64, silent=True, **g.meta["ito"])(g["x1"])
+    assert max_err(x0, g["ito64"]) < 1e-5
+    # DDIM(eta=0) and Euler are the same ODE step (reference docstring sample.py:236-237)
+    assert max_err(DDIMSampler(den, steps=64, silent=True)(g["x1"]), g["euler64"]) < 1e-4
