@@ -375,8 +375,6 @@ struct WinoP {
   int tblocks;         // ceil(ntiles / WT)
 };
 
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // LDS rows hold 8 floats (one 8-channel chunk) = two 16-byte halves; the half index is XORed with
 // bit 3 of the row so that the ds_read_b128 fragment reads (32 rows x 1 half per half-wave) and the

@@ -10,7 +10,6 @@ from it -- serves every sampling step.  Python is only the builder; replay is on
 from __future__ import annotations
 
 import ctypes as C
-import math
 import os
 
 import torch
@@ -362,9 +361,6 @@ def transition_args(**kw) -> AzTransitionArgs:
         setattr(a, k, v)
     return a
 
-
-def inf() -> float:
-    return math.inf
 
 
 # ------------------------------------------------------------------------------- token-path helpers
