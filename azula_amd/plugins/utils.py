@@ -1,9 +1,9 @@
-r"""Plugin helpers (reference ``azula/plugins/utils.py:29-60``)."""
+r"""Plugin helpers: model cards (counterpart of ``azula/plugins/utils.py:29-60``)."""
 
 from __future__ import annotations
 
-import os
 import sys
+from pathlib import Path
 from types import ModuleType, SimpleNamespace
 
 import yaml
@@ -12,11 +12,19 @@ __all__ = ["load_cards"]
 
 
 def load_cards(plugin: ModuleType | str) -> dict[str, SimpleNamespace]:
-    r"""Name -> card (``url``, ``hash``, ``config``) mapping read from the plugin's ``cards.yaml``."""
-    if isinstance(plugin, str):
-        plugin = sys.modules[plugin]
-    file = os.path.join(os.path.dirname(plugin.__file__), "cards.yaml")
-    assert os.path.exists(file), f"{plugin} is not a plugin"
-    with open(file) as f:
-        cards = yaml.safe_load(f)
-    return {name: SimpleNamespace(**card) for name, card in cards.items()}
+    r"""Returns ``{name: card}`` for the pre-trained models of a plugin; every card has ``url``,
+    ``hash`` and ``config`` (keyword arguments of the plugin's ``make_model``).
+
+    The plugin's ``cards.yaml`` may factor hyper-parameters shared by all cards into a top-level
+    ``common`` mapping; they are merged under each card's own ``config``.
+    """
+    module = sys.modules[plugin] if isinstance(plugin, str) else plugin
+    path = Path(module.__file__).with_name("cards.yaml")
+    if not path.is_file():
+        raise AssertionError(f"{module} is not a plugin (no cards.yaml next to it)")
+    doc = yaml.safe_load(path.read_text())
+    shared = doc.get("common", {})
+    out: dict[str, SimpleNamespace] = {}
+    for name, entry in doc["cards"].items():
+        out[name] = SimpleNamespace(url=entry["url"], hash=entry.get("hash"), config={**shared, **entry.get("config", {})})
+    return out
