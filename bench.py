@@ -47,6 +47,11 @@ CONFIGS = {
         kind="adm", card="imagenet_256x256", batch=4, shape=(3, 256, 256), steps=64,
         name="azula.plugins.adm imagenet_256x256 UNetModel (552.8M params, random init), AblatedDenoiser, DDIMSampler(steps=64)",
     ),
+    # BASELINE.json configs[3]: ADM 256x256, DDPMSampler(steps=1000), batch 256 sharded 8-way = 32 per GPU
+    "c4": dict(
+        kind="adm", card="imagenet_256x256", batch=32, shape=(3, 256, 256), steps=1000, sampler="ddpm",
+        name="azula.plugins.adm imagenet_256x256 UNetModel (random init), DDPMSampler(steps=1000), 32 images per GPU",
+    ),
     "c5cfg": dict(
         kind="adm", card="imagenet_256x256_cond", batch=4, shape=(3, 256, 256), steps=64, cfg=2.0,
         name="azula.plugins.adm imagenet_256x256_cond (random init) + CFGDenoiser(g=2), DDIMSampler(steps=64)",
@@ -226,6 +231,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--denoise-steps", type=int, default=0, help="override the config's sampler steps (checks only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -240,11 +246,15 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
     torch.set_grad_enabled(False)
 
-    from azula_amd.sample import DDIMSampler
+    from azula_amd.sample import DDIMSampler, DDPMSampler
 
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.denoise_steps:
+        cfg["steps"] = args.denoise_steps
+        cfg["name"] += f" [steps overridden to {args.denoise_steps}: not a headline number]"
     den = build_denoiser(cfg, device)
-    sampler = DDIMSampler(den, steps=cfg["steps"], silent=True)
+    Smp = DDPMSampler if cfg.get("sampler") == "ddpm" else DDIMSampler
+    sampler = Smp(den, steps=cfg["steps"], silent=True)
     B = cfg["batch"]
     from azula_amd.parallel import init_sharded, sample_sharded
 
