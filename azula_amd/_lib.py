@@ -148,6 +148,8 @@ class AzAttnArgs(C.Structure):
         ("scale", C.c_float),
         ("qk_rmsnorm", C.c_int32),
         ("eps", C.c_float),
+        ("rope_cos", c_f32p),
+        ("rope_sin", c_f32p),
     ]
 
 
@@ -179,6 +181,7 @@ PROTOTYPES: dict[str, list] = {
     "az_winograd_pack_filter_f32": [vp, vp, i32, i32, i32, i32, i32, i32, c_stream],
     "az_pack_conv_weight_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, c_stream],
     "az_attention_f32": [C.POINTER(AzAttnArgs), c_stream],
+    "az_swiglu_f32": [vp, vp, i64, i64, i64, i64, c_stream],
     "az_patchify_f32": [vp, vp, vp, i64, i64, i64, i64, i64, i64, c_stream],
     "az_unpatchify_f32": [vp, vp, i64, i64, i64, i64, i64, i64, c_stream],
     "az_graph_begin": [c_stream],

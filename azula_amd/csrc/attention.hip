@@ -79,6 +79,19 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
     for (int jj = 0; jj < KJ; ++jj)
 #pragma unroll
       for (int s = 0; s < 4; ++s) qf[jj][s] *= f;
+    if (a.rope_cos != nullptr && qi < T) {  // rotate adjacent (re, im) channel pairs by theta[token][head][pair]
+      const int64_t rbase = (int64_t)qi * a.heads * (D / 2) + (int64_t)hd * (D / 2);
+#pragma unroll
+      for (int jj = 0; jj < KJ; ++jj) {
+        const float2 c = *reinterpret_cast<const float2*>(a.rope_cos + rbase + 4 * jj + 2 * h2);
+        const float2 sn = *reinterpret_cast<const float2*>(a.rope_sin + rbase + 4 * jj + 2 * h2);
+        const float r0 = qf[jj][0], i0 = qf[jj][1], r1 = qf[jj][2], i1 = qf[jj][3];
+        qf[jj][0] = r0 * c.x - i0 * sn.x;
+        qf[jj][1] = r0 * sn.x + i0 * c.x;
+        qf[jj][2] = r1 * c.y - i1 * sn.y;
+        qf[jj][3] = r1 * sn.y + i1 * c.y;
+      }
+    }
   }
 
   f32x16 oacc[DT];
@@ -114,6 +127,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
           kv.y *= f;
           kv.z *= f;
           kv.w *= f;
+        }
+        if (a.rope_cos != nullptr && key < T) {
+          const int64_t ro = (int64_t)key * a.heads * (D / 2) + (int64_t)hd * (D / 2) + 2 * lc;
+          const float2 c = *reinterpret_cast<const float2*>(a.rope_cos + ro);
+          const float2 sn = *reinterpret_cast<const float2*>(a.rope_sin + ro);
+          const float r0 = kv.x, i0 = kv.y, r1 = kv.z, i1 = kv.w;
+          kv.x = r0 * c.x - i0 * sn.x;
+          kv.y = r0 * sn.x + i0 * c.x;
+          kv.z = r1 * c.y - i1 * sn.y;
+          kv.w = r1 * sn.y + i1 * c.y;
         }
         *reinterpret_cast<float4*>(Ks + row * LS + lc * 4) = kv;
         *reinterpret_cast<float4*>(Vs + row * LS + lc * 4) = vv;
@@ -228,6 +251,22 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(float* __restrict__ dst
   }
 }
 
+// y[r, c] = x[r, 2c] * silu(x[r, 2c + 1])  (azula/nn/layers.py:107-110: unflatten(-1, (-1, 2)))
+__global__ __launch_bounds__(256) void swiglu_kernel(float* __restrict__ y, const float* __restrict__ x, int64_t rows,
+                                                     int cout, int xs, int ys) {
+  const int64_t total = rows * ys;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % ys);
+    const int64_t r = e / ys;
+    float v = 0.f;
+    if (c < cout) {
+      const float2 p = *reinterpret_cast<const float2*>(x + r * xs + 2 * c);
+      v = p.x * az_silu(p.y);
+    }
+    y[e] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -248,6 +287,14 @@ int az_attention_f32(const AzAttnArgs* a, az_stream_t stream) {
     case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, st, *a); break;
     default: hipLaunchKernelGGL(attention_kernel<128>, grid, dim3(256), 0, st, *a); break;
   }
+  return az_launch_status();
+}
+
+int az_swiglu_f32(float* y, const float* x, int64_t rows, int64_t cout, int64_t xs, int64_t ys, az_stream_t stream) {
+  AZ_REQUIRE(y && x, AZ_E_NULL);
+  AZ_REQUIRE(rows > 0 && cout > 0 && xs >= 2 * cout && ys >= cout && xs % 2 == 0, AZ_E_SHAPE);
+  hipLaunchKernelGGL(swiglu_kernel, dim3(az_stream_grid(rows * ys, 256)), dim3(256), 0, az_s(stream), y, x, rows,
+                     (int)cout, (int)xs, (int)ys);
   return az_launch_status();
 }
 

@@ -88,6 +88,17 @@ __device__ __forceinline__ void epilogue_store(const AzConvArgs& a, int n, int c
     v.y = az_silu(v.y);
     v.z = az_silu(v.z);
     v.w = az_silu(v.w);
+  } else if (a.act >= 2) {  // 2: ReLU, 3: ReLU^2 (azula/nn/layers.py:85-86)
+    v.x = fmaxf(v.x, 0.f);
+    v.y = fmaxf(v.y, 0.f);
+    v.z = fmaxf(v.z, 0.f);
+    v.w = fmaxf(v.w, 0.f);
+    if (a.act == 3) {
+      v.x *= v.x;
+      v.y *= v.y;
+      v.z *= v.z;
+      v.w *= v.w;
+    }
   }
   if (a.gate) {
     const float4 g = ld4(a.gate + (int64_t)b * a.gate_bstride + co);

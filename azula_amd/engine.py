@@ -364,7 +364,8 @@ def transition_args(**kw) -> AzTransitionArgs:
 
 
 # ------------------------------------------------------------------------------- token-path helpers
-def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool, scale: float, eps: float = 1e-5) -> Act:
+def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool, scale: float, eps: float = 1e-5,
+                       rope: tuple | None = None) -> Act:
     r"""softmax(q k^T * scale) v over a fused-QKV token tensor (B, L, 1, 3*heads*dim).
 
     order: "nHC" = azula '(n H C)' (attention.py:90), "H3C" = ADM legacy (unet.py:338),
@@ -392,6 +393,9 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
         setattr(a, n + "_hstride", hs)
     a.o_bstride, a.o_tstride, a.o_hstride = L * out.cs, out.cs, dim
     a.scale, a.qk_rmsnorm, a.eps = scale, int(qk_rmsnorm), eps
+    if rope is not None:  # (cos, sin) tables of shape (L, heads * dim / 2)
+        a.rope_cos, a.rope_sin = rope[0].data_ptr(), rope[1].data_ptr()
+        self.tape.keep.extend(rope)
     a._flops = 4 * qkv.B * heads * L * L * dim
     self.tape.add("az_attention_f32", C.byref(a), keep=[a])
     return out

@@ -47,13 +47,18 @@ class MultiheadSelfAttention(nn.Module):
     ) -> None:
         super().__init__()
         assert channels % attention_heads == 0
-        if rope:
-            raise NotImplementedError("RoPE is not implemented on the HIP path")
         self.qkv_proj = nn.Linear(channels, 3 * channels, bias=qkv_bias)
         self.y_proj = nn.Linear(channels, channels, bias=False)
+        if rope:  # learned rotary axes (reference attention.py:60-68): random directions, log-uniform magnitudes
+            magnitude = torch.exp(math.log(1e-1) * torch.rand(channels // 2, 1))
+            direction = torch.randn(channels // 2, pos_channels)
+            direction = direction / torch.linalg.norm(direction, dim=-1, keepdim=True)
+            self.theta_proj = nn.Linear(pos_channels, channels // 2, bias=False)
+            self.theta_proj.weight.data.copy_(magnitude * direction)
+        else:
+            self.theta_proj = None
         self.heads = attention_heads
         self.qk_norm = qk_norm
-        self.theta_proj = None
 
 
 class DiTBlock(nn.Module):
@@ -70,9 +75,9 @@ class DiTBlock(nn.Module):
         **kwargs,
     ) -> None:
         super().__init__()
-        if ffn_activation != "silu":
-            raise NotImplementedError(f"ffn_activation='{ffn_activation}' is not implemented on the HIP path")
-        self.channels, self.mod_features = channels, mod_features
+        if ffn_activation not in ("relu", "relu2", "silu", "swiglu"):
+            raise NotImplementedError(f"Unknown activation '{ffn_activation}'.")
+        self.channels, self.mod_features, self.ffn_activation = channels, mod_features, ffn_activation
         if mod_features > 0:
             self.ada_zero = nn.Sequential(
                 nn.Linear(mod_features, mod_features), nn.SiLU(), nn.Linear(mod_features, 3 * channels), nn.Identity()
@@ -84,9 +89,9 @@ class DiTBlock(nn.Module):
         self.msa = MultiheadSelfAttention(channels, **kwargs)
         self.ffn = nn.Sequential(
             nn.Linear(channels, ffn_factor * channels),
-            nn.SiLU(),
+            nn.Identity(),  # activation (parameter-free; applied in the GEMM epilogue / az_swiglu_f32)
             nn.Identity() if dropout is None else nn.Dropout(dropout),
-            nn.Linear(ffn_factor * channels, channels),
+            nn.Linear(ffn_factor * channels // (2 if ffn_activation == "swiglu" else 1), channels),
         )
 
 
@@ -158,14 +163,24 @@ class DiTPlan:
             msa = blk.msa
             qkv = bld.conv(y, bld.pack_conv(msa.qkv_proj.weight, msa.qkv_proj.bias), 3 * C_)
             dim = C_ // msa.heads
-            att = bld.attention(qkv, msa.heads, "nHC", msa.qk_norm, 1.0 / math.sqrt(dim))
+            rope = None
+            if msa.theta_proj is not None:  # theta = theta_proj(pos) on the host (reference op order), tables on device
+                theta = torch.nn.functional.linear(pos.to(torch.float32).cpu(), msa.theta_proj.weight.detach().float().cpu())
+                rope = (bld.const(torch.cos(theta)), bld.const(torch.sin(theta)))
+            att = bld.attention(qkv, msa.heads, "nHC", msa.qk_norm, 1.0 / math.sqrt(dim), rope=rope)
             bld.free(qkv)
             y2 = bld.conv(att, bld.pack_conv(msa.y_proj.weight, None), C_, res=y)
             bld.free(att)
             bld.free(y)
             f0, f3 = blk.ffn[0], blk.ffn[3]
-            f1 = bld.conv(y2, bld.pack_conv(f0.weight, f0.bias), f0.out_features, act=1)
+            code = {"silu": 1, "relu": 2, "relu2": 3, "swiglu": 0}[blk.ffn_activation]
+            f1 = bld.conv(y2, bld.pack_conv(f0.weight, f0.bias), f0.out_features, act=code)
             bld.free(y2)
+            if blk.ffn_activation == "swiglu":  # x1 * silu(x2) over interleaved pairs (layers.py:107-110)
+                glu = bld.new_act(f1.B, f1.H, f1.W, f1.C // 2)
+                bld.tape.add("az_swiglu_f32", glu.ptr, f1.ptr, f1.B * f1.H * f1.W, f1.C // 2, f1.cs, glu.cs)
+                bld.free(f1)
+                f1 = glu
             out = bld.conv(f1, bld.pack_conv(f3.weight, f3.bias), C_, gate=abc, gate_off=2 * cs, gate_bstride=bstride, res=x)
             bld.free(f1)
             bld.free(x)

@@ -199,7 +199,7 @@ typedef struct AzConvArgs {
   int32_t cout_s;          /* output channel stride (multiple of 4) */
   int32_t ksize, stride, pad;
   int32_t hout, wout;
-  int32_t act;             /* 0 none, 1 SiLU */
+  int32_t act;             /* 0 none, 1 SiLU, 2 ReLU, 3 ReLU^2 */
   const float* gate;       /* optional (…, cout_s) */
   int64_t gate_bstride;    /* 0 = shared across the batch */
   const float* res;        /* optional residual, NHWC (B, hres, wres, cout_s) */
@@ -249,8 +249,16 @@ typedef struct AzAttnArgs {
   float scale;
   int32_t qk_rmsnorm; /* 1: q and k rows are RMS-normalised (eps) before the dot product */
   float eps;
+  /* optional rotary embedding (azula/nn/attention.py:93-96,112-156): cos/sin of theta, laid out
+   * (tokens, heads, head_dim / 2), shared by the batch; adjacent channel pairs (2i, 2i+1) of q and k are
+   * rotated after the RMS norm.  NULL = no RoPE.                                                */
+  const float* rope_cos;
+  const float* rope_sin;
 } AzAttnArgs;
 int az_attention_f32(const AzAttnArgs* args, az_stream_t stream);
+
+/* y[r, c] = x[r, 2c] * silu(x[r, 2c+1]), c < cout (SwiGLU, azula/nn/layers.py:89-110); xs / ys = row strides. */
+int az_swiglu_f32(float* y, const float* x, int64_t rows, int64_t cout, int64_t xs, int64_t ys, az_stream_t stream);
 
 /* Patchify NCHW (B, Z, H, W) -> tokens (B, H/p * W/p, cs), feature = z*p*p + a*p + b, scaled by
  * *scale_dev (NULL = 1), pad features zero; and back (azula/nn/layers.py:198-247, azula/nn/vit.py:92-106). */

@@ -128,8 +128,20 @@ def time_wrapped_unet(sd, cfg: dict, x: Tensor, c_time: Tensor, **_) -> Tensor:
 
 
 # --------------------------------------------------------------------------- azula.nn.dit / vit
-def msa_forward(sd, key: str, x: Tensor, heads: int, qk_norm: bool = True) -> Tensor:
-    r"""MultiheadSelfAttention.forward without RoPE -- azula/nn/attention.py:89-108."""
+def apply_rope(q: Tensor, k: Tensor, theta: Tensor):
+    r"""azula/nn/attention.py:112-156: rotate adjacent (real, imag) channel pairs by theta."""
+
+    def rot(v):
+        v = v.unflatten(-1, (-1, 2))
+        re, im = v[..., 0], v[..., 1]
+        c, s_ = torch.cos(theta), torch.sin(theta)
+        return torch.stack((re * c - im * s_, re * s_ + im * c), dim=-1).flatten(-2)
+
+    return rot(q), rot(k)
+
+
+def msa_forward(sd, key: str, x: Tensor, heads: int, qk_norm: bool = True, pos: Tensor | None = None) -> Tensor:
+    r"""MultiheadSelfAttention.forward -- azula/nn/attention.py:89-108 (RoPE iff ``theta_proj`` exists)."""
     qkv = _linear(sd, key + ".qkv_proj", x)  # (..., L, (n H C))
     *lead, L, _ = qkv.shape
     qkv = qkv.reshape(*lead, L, 3, heads, -1)
@@ -138,19 +150,31 @@ def msa_forward(sd, key: str, x: Tensor, heads: int, qk_norm: bool = True) -> Te
         C = q.shape[-1]
         q = F.rms_norm(q, (C,), eps=1e-5)  # torch.nn.RMSNorm path, attention.py:48-56
         k = F.rms_norm(k, (C,), eps=1e-5)
+    if key + ".theta_proj.weight" in sd:
+        theta = F.linear(pos, sd[key + ".theta_proj.weight"])  # ... L (H C)
+        theta = theta.unflatten(-1, (heads, -1)).transpose(-2, -3)  # ... H L C
+        q, k = apply_rope(q, k, theta)
     y = F.scaled_dot_product_attention(query=q, key=k, value=v)
     y = y.transpose(-2, -3).flatten(-2)  # ... L (H C)
     return F.linear(y, sd[key + ".y_proj.weight"])
 
 
-def dit_block(sd, key: str, x: Tensor, mod, heads: int) -> Tensor:
-    r"""DiTBlock._forward (silu FFN) -- azula/nn/dit.py:95-112."""
+def dit_block(sd, key: str, x: Tensor, mod, heads: int, pos=None, act: str = "silu", qk_norm: bool = True) -> Tensor:
+    r"""DiTBlock._forward -- azula/nn/dit.py:95-112 (FFN activations: dit.py:74-85, layers.py:71-110)."""
     C = x.shape[-1]
     a, b, c = _ada_zero(sd, key + ".ada_zero", mod, C, (1, C))
     y = (a + 1) * F.rms_norm(x, (C,), eps=1e-5) + b
-    y = y + msa_forward(sd, key + ".msa", y, heads)
+    y = y + msa_forward(sd, key + ".msa", y, heads, qk_norm=qk_norm, pos=pos)
     y = _linear(sd, key + ".ffn.0", y)
-    y = F.silu(y)
+    if act == "silu":
+        y = F.silu(y)
+    elif act == "relu":
+        y = F.relu(y)
+    elif act == "relu2":
+        y = F.relu(y).square()
+    elif act == "swiglu":
+        y = y.unflatten(-1, (-1, 2))
+        y = y[..., 0] * F.silu(y[..., 1])
     y = _linear(sd, key + ".ffn.3", y)
     return x + c * y
 
@@ -163,7 +187,8 @@ def dit_forward(sd, cfg: dict, x: Tensor, mod=None, pos: Tensor | None = None, t
     e = sine_encoding(pos, cfg["hid_channels"], omega=1e2).flatten(-2)  # ... (P C)
     x = x + F.linear(e, sd["pos_embedding.2.weight"])
     for i in range(cfg["hid_blocks"]):
-        x = dit_block(sd, f"blocks.{i}", x, mod, cfg["attention_heads"])
+        x = dit_block(sd, f"blocks.{i}", x, mod, cfg["attention_heads"], pos=pos, act=cfg.get("ffn_activation", "silu"),
+                      qk_norm=cfg.get("qk_norm", True))
         if tap is not None:
             tap[f"blocks.{i}"] = x
     return _linear(sd, "out_proj", x)

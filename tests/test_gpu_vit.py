@@ -124,3 +124,22 @@ def test_vit_ddim50_fused_matches_reference(golden):
     err, sc = max_err(x0, g["ddim50"]), g["ddim50"].abs().max().item()
     print("ViT DDIM-50 fused max|d| vs reference:", err, "scale", sc)
     assert err < 5e-4 * max(1.0, sc)
+
+
+@pytest.mark.parametrize("name", ["vit_rope_swiglu", "vit_relu2_noqknorm", "vit_relu"])
+def test_vit_variants_match_reference(golden, name):
+    """RoPE (attention.py:112-156), SwiGLU / ReLU^2 / ReLU FFNs (layers.py:71-110), qk_norm=False."""
+    from azula_amd.nn import ViT
+
+    g = golden("g5_" + name)
+    cfg = g.meta["cfg"]
+    extra = {k: cfg[k] for k in ("rope", "ffn_activation", "qk_norm") if k in cfg}
+    net = ViT(cfg["in_channels"], cfg["out_channels"], hid_channels=cfg["hid_channels"], hid_blocks=cfg["hid_blocks"],
+              attention_heads=cfg["attention_heads"], patch_size=cfg["patch_size"], mod_features=cfg["mod_features"], **extra)
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v) for k, v in g.meta["shapes"].items()}
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"]))
+    net = net.cuda().eval()
+    y = net(g["x"].cuda(), g["modB"].cuda())
+    err, sc = max_err(y, g["y_modB"]), g["y_modB"].abs().max().item()
+    print(name, "max|d|", err, "scale", sc)
+    assert err < 1e-4 * max(1.0, sc)
