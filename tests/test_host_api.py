@@ -208,3 +208,29 @@ def test_next_samplers_cpu_match_reference(golden):
     assert max_err(x0, g["ito64"]) < 1e-5
     # DDIM(eta=0) and Euler are the same ODE step (reference docstring sample.py:236-237)
     assert max_err(DDIMSampler(den, steps=64, silent=True)(g["x1"]), g["euler64"]) < 1e-4
+
+
+def test_layers_for_custom_backbones():
+    """azula_amd.nn.layers (counterpart of azula.nn.layers) against the oracle formulas."""
+    from azula_amd.nn import layers
+    from oracle import nets
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 6, 8, 12, generator=g)
+    assert torch.equal(layers.LayerNorm(dim=-3)(x), nets.layer_norm_unbiased(x, dim=-3))
+    assert torch.equal(layers.RMSNorm(dim=1)(x), nets.rms_norm(x, dim=1))
+    t = torch.rand(7, generator=g)
+    assert torch.equal(layers.SineEncoding(64)(t), nets.sine_encoding(t, 64))
+    assert layers.SineEncoding(32)(x.half()).dtype == torch.float16  # promote_dtype casts back
+    for cl in (False, True):
+        p = layers.Patchify((2, 3), channel_last=cl)(x)
+        assert p.shape == ((2, 4, 4, 36) if cl else (2, 36, 4, 4))
+        assert torch.equal(layers.Unpatchify((2, 3), channel_last=cl)(p), x)
+    # '... Z (A a) (B b) -> ... A B (Z a b)': feature index z*p*p + a*p + b
+    p = layers.Patchify((2, 2), channel_last=True)(x)
+    assert p[1, 2, 3, 1 * 4 + 1 * 2 + 0] == x[1, 1, 2 * 2 + 1, 3 * 2 + 0]
+    y = torch.randn(4, 10, generator=g)
+    assert torch.equal(layers.SwiGLU()(y), y[:, 0::2] * torch.nn.functional.silu(y[:, 1::2]))
+    assert torch.equal(layers.ReLU2()(y), torch.relu(y) ** 2)
+    conv = layers.ConvNd(3, 5, spatial=2, identity_init=True, kernel_size=3, padding=1)
+    assert abs(conv.weight[1, 1, 1, 1].item() - 1) < 0.1 and conv.weight[1, 0].abs().max() < 0.1
