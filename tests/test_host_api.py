@@ -234,3 +234,33 @@ def test_layers_for_custom_backbones():
     assert torch.equal(layers.ReLU2()(y), torch.relu(y) ** 2)
     conv = layers.ConvNd(3, 5, spatial=2, identity_init=True, kernel_size=3, padding=1)
     assert abs(conv.weight[1, 1, 1, 1].item() - 1) < 0.1 and conv.weight[1, 0].abs().max() < 0.1
+
+
+@pytest.mark.parametrize("with_label", [False, True])
+@pytest.mark.parametrize("batch", [(), (64,)])
+def test_samplers_shapes_and_kwargs(with_label, batch):
+    """Mirror of the reference's tests/test_sample.py:57-92 for the samplers this build provides:
+    init / output shapes, finiteness, and keyword arguments flowing untouched to the backbone."""
+    from functools import partial
+
+    from azula_amd.nn.layers import SineEncoding
+    from azula_amd.sample import EulerSampler, HeunSampler, ItoSampler
+
+    class Dummy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1, self.l2 = torch.nn.Linear(5, 64), torch.nn.Linear(64, 5)
+            self.time_encoding = SineEncoding(64)
+
+        def forward(self, x_t, t, label=None):
+            assert isinstance(label, str) if with_label else label is None
+            return self.l2(torch.relu(self.l1(x_t) + self.time_encoding(t)))
+
+    den = KarrasDenoiser(Dummy(), VPSchedule())
+    for S in (partial(DDPMSampler), partial(DDIMSampler, eta=0.0), partial(DDIMSampler, eta=1.0), partial(EulerSampler),
+              partial(HeunSampler), partial(ItoSampler, eta=1.0)):
+        sampler = S(den, steps=64, silent=True)
+        x1 = sampler.init((*batch, 5))
+        assert x1.shape == (*batch, 5) and torch.isfinite(x1).all()
+        x0 = sampler(x1, label="cat") if with_label else sampler(x1)
+        assert x0.shape == (*batch, 5) and torch.isfinite(x0).all()
