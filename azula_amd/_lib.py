@@ -65,6 +65,23 @@ class AzTransitionArgs(C.Structure):
     ]
 
 
+MULTISTEP_MAX_HIST = 7
+
+
+class AzMultistepArgs(C.Structure):
+    _fields_ = [
+        ("x_s", c_f32p),
+        ("pred", c_f32p),
+        ("x_t", c_f32p),
+        ("mean", c_f32p),
+        ("hist", c_f32p * MULTISTEP_MAX_HIST),
+        ("coef", c_f32p),
+        ("count", C.c_int64),
+        ("n_hist", C.c_int32),
+        ("pad_", C.c_int32),
+    ]
+
+
 class AzNormFinalizeArgs(C.Structure):
     _fields_ = [
         ("S", c_f32p),
@@ -161,6 +178,7 @@ PROTOTYPES: dict[str, list] = {
     "az_version": [],
     "az_step_begin": [vp, vp, vp, i32, c_stream],
     "az_transition_f32": [C.POINTER(AzTransitionArgs), c_stream],
+    "az_multistep_f32": [C.POINTER(AzMultistepArgs), c_stream],
     "az_scale_f32": [vp, vp, vp, i64, c_stream],
     "az_axpby_f32": [vp, vp, vp, vp, vp, i64, i64, i32, c_stream],
     "az_cfg_combine_f32": [vp, vp, vp, vp, i64, c_stream],

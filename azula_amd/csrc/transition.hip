@@ -236,6 +236,63 @@ __global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ y, const
   }
 }
 
+// Linear multistep update (Adams-Bashforth family, reference azula/sample.py:519-546 and the
+// v/zE/xE/RE variants): one pass computes the newest prediction pred = a x_t + b mean, stores it
+// in its history slot and forms x_s = p x_t + sum_j w_j hist_j + w_new pred.  Reads 2 + n_hist
+// streams and writes 2: the HBM minimum for the step.  `Vec` = float4 body / float tail.
+struct MultistepPtrs {
+  const float* h[AZ_MULTISTEP_MAX_HIST];
+};
+
+template <int NH>
+__global__ __launch_bounds__(256) void multistep_kernel(float* __restrict__ x_s, float* __restrict__ pred,
+                                                        const float* __restrict__ x_t, const float* __restrict__ mean,
+                                                        MultistepPtrs hist, const float* __restrict__ coef,
+                                                        int64_t n) {
+  const float a = coef[0], b = coef[1], p = coef[2], wn = coef[3];
+  float w[NH > 0 ? NH : 1];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) w[j] = coef[4 + j];
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 xv = reinterpret_cast<const float4*>(x_t)[i];
+    const float4 mv = reinterpret_cast<const float4*>(mean)[i];
+    float4 hv[NH > 0 ? NH : 1];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) hv[j] = reinterpret_cast<const float4*>(hist.h[j])[i];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ms[4] = {mv.x, mv.y, mv.z, mv.w};
+    float pr[4], out[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      pr[c] = az_add(az_mul(a, xs[c]), az_mul(b, ms[c]));
+      float acc = az_mul(p, xs[c]);
+#pragma unroll
+      for (int j = 0; j < NH; ++j) acc = az_add(acc, az_mul(w[j], reinterpret_cast<const float*>(&hv[j])[c]));
+      out[c] = az_add(acc, az_mul(wn, pr[c]));
+    }
+    reinterpret_cast<float4*>(pred)[i] = make_float4(pr[0], pr[1], pr[2], pr[3]);
+    reinterpret_cast<float4*>(x_s)[i] = make_float4(out[0], out[1], out[2], out[3]);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+      const float x = x_t[i];
+      const float pr = az_add(az_mul(a, x), az_mul(b, mean[i]));
+      float acc = az_mul(p, x);
+#pragma unroll
+      for (int j = 0; j < NH; ++j) acc = az_add(acc, az_mul(w[j], hist.h[j][i]));
+      pred[i] = pr;
+      x_s[i] = az_add(acc, az_mul(wn, pr));
+    }
+}
+
+template <int NH>
+void launch_multistep(const AzMultistepArgs* a, hipStream_t s) {
+  MultistepPtrs hp;
+  for (int j = 0; j < AZ_MULTISTEP_MAX_HIST; ++j) hp.h[j] = j < NH ? a->hist[j] : nullptr;
+  hipLaunchKernelGGL(multistep_kernel<NH>, dim3(az_stream_grid((a->count + 3) / 4, 256)), dim3(256), 0, s, a->x_s,
+                     a->pred, a->x_t, a->mean, hp, a->coef, a->count);
+}
+
 __global__ __launch_bounds__(256) void cfg_combine_kernel(float* __restrict__ y, const float* __restrict__ pos,
                                                           const float* __restrict__ neg, const float* __restrict__ g,
                                                           int64_t n) {
@@ -356,6 +413,30 @@ int az_axpby_f32(float* y, const float* a_dev, const float* x, const float* b_de
   AZ_REQUIRE(rows > 0 && inner > 0 && (a_stride == 0 || a_stride == 1), AZ_E_SHAPE);
   hipLaunchKernelGGL(axpby_kernel, dim3(az_stream_grid(rows * inner, 256)), dim3(256), 0, az_s(stream), y, a_dev, x,
                      b_dev, z, rows, inner, a_stride);
+  return az_launch_status();
+}
+
+int az_multistep_f32(const AzMultistepArgs* a, az_stream_t stream) {
+  AZ_REQUIRE(a && a->x_s && a->pred && a->x_t && a->mean && a->coef, AZ_E_NULL);
+  AZ_REQUIRE(a->count > 0 && a->n_hist >= 0 && a->n_hist <= AZ_MULTISTEP_MAX_HIST, AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(a->x_s) && AZ_ALIGNED16(a->pred) && AZ_ALIGNED16(a->x_t) && AZ_ALIGNED16(a->mean),
+             AZ_E_ALIGN);
+  for (int j = 0; j < a->n_hist; ++j) {
+    AZ_REQUIRE(a->hist[j], AZ_E_NULL);
+    AZ_REQUIRE(AZ_ALIGNED16(a->hist[j]), AZ_E_ALIGN);
+    AZ_REQUIRE(a->hist[j] != a->pred, AZ_E_SHAPE);  // the newest slot must not alias live history
+  }
+  hipStream_t s = az_s(stream);
+  switch (a->n_hist) {
+    case 0: launch_multistep<0>(a, s); break;
+    case 1: launch_multistep<1>(a, s); break;
+    case 2: launch_multistep<2>(a, s); break;
+    case 3: launch_multistep<3>(a, s); break;
+    case 4: launch_multistep<4>(a, s); break;
+    case 5: launch_multistep<5>(a, s); break;
+    case 6: launch_multistep<6>(a, s); break;
+    default: launch_multistep<7>(a, s); break;
+  }
   return az_launch_status();
 }
 

@@ -33,7 +33,8 @@ from .denoise import Denoiser, require_f32_cuda
 from .engine import StepGraph, Tape, transition_args
 
 __all__ = [
-    "Sampler", "DDPMSampler", "DDIMSampler", "EulerSampler", "HeunSampler", "ItoSampler", "FusedDenoiser", "BackboneProgram",
+    "Sampler", "DDPMSampler", "DDIMSampler", "EulerSampler", "HeunSampler", "ItoSampler", "zABSampler", "vABSampler",
+    "zEABSampler", "xEABSampler", "REABSampler", "PCSampler", "FusedDenoiser", "BackboneProgram",
 ]
 
 
@@ -178,6 +179,11 @@ class Sampler(abc.ABC):
 
     def _device_transition(self, x_t: Tensor, mean: Tensor, t: Tensor, s: Tensor) -> Tensor:
         _, _, _, _, alpha_t, alpha_s, k_x, k_eps = self._transition_scalars(t, s)
+        return self._device_kernel(x_t, mean, alpha_t, alpha_s, k_x, k_eps, True)
+
+    def _device_kernel(self, x_t: Tensor, mean: Tensor, alpha_t, alpha_s, k_x, k_eps, draw: bool) -> Tensor:
+        r"""x_s = alpha_s m + k_x (x_t - alpha_t m) + k_eps eps through ``az_transition_f32``; ``draw=False``
+        skips the noise draw and the eps stream (the kernel's EPS=false instantiation)."""
         require_f32_cuda(x_t, type(self).__name__)
         dev = x_t.device
         zero = torch.zeros((), device=dev)
@@ -190,10 +196,10 @@ class Sampler(abc.ABC):
             row[COEF_FIELDS.index(name)] = v.to(device=dev, dtype=torch.float32)
         x_c = x_t.contiguous()
         mean = mean.to(x_c).contiguous()
-        eps = self._draw_noise(x_c)
+        eps = self._draw_noise(x_c) if draw else None
         x_s = torch.empty_like(x_c)
         a = transition_args(
-            x_t=x_c.data_ptr(), F=mean.data_ptr(), eps=eps.data_ptr(), x_s=x_s.data_ptr(), batch=1, channels=1,
+            x_t=x_c.data_ptr(), F=mean.data_ptr(), eps=eps.data_ptr() if draw else 0, x_s=x_s.data_ptr(), batch=1, channels=1,
             inner=x_c.numel(), f_channels=1, coef=row.data_ptr(),
         )
         _lib.call("az_transition_f32", C.byref(a), _lib.stream_ptr())
@@ -471,3 +477,267 @@ class ItoSampler(Sampler):
 
     def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
         return self._step_impl(x_t, t, s, **kwargs)
+
+
+# ------------------------------------------------------------------------------- multistep family
+def _lagrange_weights(u: Tensor, i: int, n: int, moments: Callable[[Tensor, int, Tensor], Tensor]) -> Tensor:
+    r"""Weights of the order-``n`` linear multistep rule on the nodes ``u[i+1-n : i+1]``: solve the
+    Vandermonde system ``sum_j c_j u_j^k = moments_k`` in fp64 and round back to ``u``'s dtype, as the
+    reference's ``promote_dtype(min_dtype=float64)`` static methods do (``azula/sample.py:486-508``)."""
+    wide = u.to(torch.promote_types(u.dtype, torch.float64))
+    n = min(n, i + 1)
+    k = torch.arange(n, device=u.device)
+    V = wide[i + 1 - n : i + 1] ** k[:, None]
+    return torch.linalg.solve(V, moments(wide, i, k)).to(u.dtype)
+
+
+def _moments_poly(t: Tensor, i: int, k: Tensor) -> Tensor:
+    r"""int_{t_i}^{t_{i+1}} u^k du (``azula/sample.py:505-506``)."""
+    return t[i + 1] ** (k + 1) / (k + 1) - t[i] ** (k + 1) / (k + 1)
+
+
+def _moments_exp(t: Tensor, i: int, k: Tensor) -> Tensor:
+    r"""int e^u u^k du by repeated integration by parts (``azula/sample.py:670-683``)."""
+    k_fact = torch.cumprod(torch.clip(k, min=1), dim=0)
+    hi = torch.exp(t[i + 1]) * torch.cumsum((-t[i + 1]) ** k / k_fact, dim=0)
+    lo = torch.exp(t[i]) * torch.cumsum((-t[i]) ** k / k_fact, dim=0)
+    return (-1) ** k * k_fact * (hi - lo)
+
+
+def _moments_negexp(t: Tensor, i: int, k: Tensor) -> Tensor:
+    r"""int e^{-u} u^k du (``azula/sample.py:783-792``)."""
+    k_fact = torch.cumprod(torch.clip(k, min=1), dim=0)
+    hi = torch.exp(-t[i + 1]) * torch.cumsum(t[i + 1] ** k / k_fact, dim=0)
+    lo = torch.exp(-t[i]) * torch.cumsum(t[i] ** k / k_fact, dim=0)
+    return -k_fact * (hi - lo)
+
+
+def _moments_sech(t: Tensor, i: int, k: Tensor) -> Tensor:
+    r"""int e^u / (1 + e^{2u}) u^k du, 256-panel trapezoid (``azula/sample.py:907-910``)."""
+    u = torch.linspace(t[i], t[i + 1], steps=256 + 1, dtype=t.dtype, device=t.device)
+    y = torch.exp(u) / (1 + torch.exp(2 * u)) * (u ** k[:, None])
+    return torch.trapezoid(y, u, dim=-1)
+
+
+class _MultistepSampler(Sampler):
+    r"""Shared loop of the Adams-Bashforth family.  A subclass states, in the reference's op order,
+
+    * ``_variable(alpha, sigma)``: the integration variable u_t,
+    * ``_predict(x_t, mean, alpha_t, sigma_t)``: the buffered prediction (z, v, x or f),
+    * ``_advance(x_t, integral, alpha_t, sigma_t, alpha_s, sigma_s)``: x_s,
+    * ``_moments``: the basis integrals of its rule.
+
+    Host tensors run exactly that sequence.  Device tensors use that both maps are LINEAR: probing
+    them with 0-d fp64 unit inputs yields (a, b) and (p, q) of ``az_multistep_f32``
+    (pred = a x_t + b mean, x_s = p x_t + q sum_j c_j pred_j), so each step is ONE pass over
+    2 + (order - 1) streams instead of ~3 order + 6 ATen passes.  The whole (steps, 4 + order)
+    coefficient table is built on the host (fp64 solves) and uploaded once."""
+
+    _moments: Callable[[Tensor, int, Tensor], Tensor]
+
+    def __init__(self, denoiser: Denoiser, order: int = 2, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.denoiser = denoiser
+        self.order = order
+
+    def _variable(self, alpha: Tensor, sigma: Tensor) -> Tensor:
+        raise NotImplementedError()
+
+    def _predict(self, x_t, mean, alpha_t, sigma_t):
+        raise NotImplementedError()
+
+    def _advance(self, x_t, integral, alpha_t, sigma_t, alpha_s, sigma_s):
+        raise NotImplementedError()
+
+    @classmethod
+    def _weights(cls, u: Tensor, i: int, n: int) -> Tensor:
+        return _lagrange_weights(u, i, n, cls._moments)
+
+    def _device_table(self, alpha: Tensor, sigma: Tensor) -> Tensor:
+        r"""(steps, 4 + MAX_HIST) fp32 rows [a, b, p, w_new, w_hist oldest-first] from host scalars."""
+        u = self._variable(alpha, sigma)
+        rows = torch.zeros(self.steps, 4 + _lib.MULTISTEP_MAX_HIST, dtype=torch.float32)
+        one, zero = torch.ones((), dtype=torch.float64), torch.zeros((), dtype=torch.float64)
+        al, sg = alpha.double(), sigma.double()
+        for i in range(self.steps):
+            c = self._weights(u, i, self.order).double()
+            rows[i, 0] = self._predict(one, zero, al[i], sg[i])
+            rows[i, 1] = self._predict(zero, one, al[i], sg[i])
+            rows[i, 2] = self._advance(one, zero, al[i], sg[i], al[i + 1], sg[i + 1])
+            q = self._advance(zero, one, al[i], sg[i], al[i + 1], sg[i + 1])
+            rows[i, 3] = q * c[-1]
+            rows[i, 4 : 4 + len(c) - 1] = q * c[:-1]
+        return rows
+
+    @torch.no_grad()
+    def __call__(self, x: Tensor, **kwargs) -> Tensor:
+        if self.order < 1 or self.order > _lib.MULTISTEP_MAX_HIST + 1:
+            raise ValueError(f"order must be in [1, {_lib.MULTISTEP_MAX_HIST + 1}], got {self.order}")
+        time = self.timesteps.to(device=x.device)
+        if not x.is_cuda:
+            return self._call_host(x, time, kwargs)
+        require_f32_cuda(x, type(self).__name__)
+        alpha, sigma = self.denoiser.schedule(self.timesteps.cpu())
+        table = self._device_table(alpha, sigma).to(x.device)
+        ring = [torch.empty_like(x, memory_format=torch.contiguous_format) for _ in range(self.order)]
+        x_t = x.contiguous()
+        x_next = [torch.empty_like(x_t), torch.empty_like(x_t)]
+        stream = _lib.stream_ptr()
+        for i, t in enumerate(self.progress_bar(time[:-1])):
+            mean = self.denoiser(x_t, t, **kwargs).mean.to(x_t).contiguous()
+            n_hist = min(self.order, i + 1) - 1
+            args = _lib.AzMultistepArgs()
+            args.x_s = x_next[i % 2].data_ptr()
+            args.pred = ring[i % self.order].data_ptr()
+            args.x_t, args.mean = x_t.data_ptr(), mean.data_ptr()
+            for j in range(n_hist):  # oldest first: steps i - n_hist .. i - 1
+                args.hist[j] = ring[(i - n_hist + j) % self.order].data_ptr()
+            args.coef = table[i].data_ptr()
+            args.count, args.n_hist = x_t.numel(), n_hist
+            _lib.call("az_multistep_f32", C.byref(args), stream)
+            x_t = x_next[i % 2]
+        return x_t
+
+    def _call_host(self, x: Tensor, time: Tensor, kwargs: dict) -> Tensor:
+        alpha, sigma = self.denoiser.schedule(time)
+        u = self._variable(alpha, sigma)
+        x_t, buffer = x, []
+        for i, t in enumerate(self.progress_bar(time[:-1])):
+            q_t = self.denoiser(x_t, t, **kwargs)
+            buffer.append(self._predict(x_t, q_t.mean, alpha[i], sigma[i]))
+            if len(buffer) > self.order:
+                buffer.pop(0)
+            coeffs = self._weights(u, i, self.order)
+            integral = sum(b * c for b, c in zip(buffer, coeffs, strict=True))
+            x_t = self._advance(x_t, integral, alpha[i], sigma[i], alpha[i + 1], sigma[i + 1])
+        return x_t
+
+
+class zABSampler(_MultistepSampler):
+    r"""Adams-Bashforth multistep sampler with noise (z) prediction, u = sigma / alpha
+    (reference ``azula/sample.py:434-546``; rho-AB of Zhang et al. 2023, k-diffusion's LMS)."""
+
+    _moments = staticmethod(_moments_poly)
+
+    @staticmethod
+    def _adams_bashforth(t: Tensor, /, i: int, n: int) -> Tensor:
+        return _lagrange_weights(t, i, n, _moments_poly)
+
+    def _variable(self, alpha, sigma):
+        return sigma / alpha
+
+    def _predict(self, x_t, mean, alpha_t, sigma_t):
+        return (x_t - alpha_t * mean) / sigma_t
+
+    def _advance(self, x_t, integral, alpha_t, sigma_t, alpha_s, sigma_s):
+        return alpha_s / alpha_t * x_t + alpha_s * integral
+
+
+class vABSampler(zABSampler):
+    r"""Adams-Bashforth sampler with velocity (v) prediction, u = sigma / (alpha + sigma)
+    (reference ``azula/sample.py:549-620``)."""
+
+    def _variable(self, alpha, sigma):
+        return sigma / (alpha + sigma)
+
+    def _predict(self, x_t, mean, alpha_t, sigma_t):
+        return 1 / sigma_t * x_t - (1 + alpha_t / sigma_t) * mean
+
+    def _advance(self, x_t, integral, alpha_t, sigma_t, alpha_s, sigma_s):
+        return (alpha_s + sigma_s) / (alpha_t + sigma_t) * x_t + (alpha_s + sigma_s) * integral
+
+
+class zEABSampler(_MultistepSampler):
+    r"""Exponential Adams-Bashforth sampler with noise prediction, u = log sigma - log alpha
+    (reference ``azula/sample.py:623-715``; DPM-Solver family)."""
+
+    _moments = staticmethod(_moments_exp)
+
+    @staticmethod
+    def _exponential_adams_bashforth(t: Tensor, /, i: int, n: int) -> Tensor:
+        return _lagrange_weights(t, i, n, _moments_exp)
+
+    def _variable(self, alpha, sigma):
+        return sigma.log() - alpha.log()
+
+    def _predict(self, x_t, mean, alpha_t, sigma_t):
+        return (x_t - alpha_t * mean) / sigma_t
+
+    def _advance(self, x_t, integral, alpha_t, sigma_t, alpha_s, sigma_s):
+        return alpha_s / alpha_t * x_t + alpha_s * integral
+
+
+class xEABSampler(_MultistepSampler):
+    r"""Exponential Adams-Bashforth sampler with data (x) prediction
+    (reference ``azula/sample.py:718-821``; DPM-Solver++ family)."""
+
+    _moments = staticmethod(_moments_negexp)
+
+    @staticmethod
+    def _exponential_adams_bashforth(t: Tensor, /, i: int, n: int) -> Tensor:
+        return _lagrange_weights(t, i, n, _moments_negexp)
+
+    def _variable(self, alpha, sigma):
+        return sigma.log() - alpha.log()
+
+    def _predict(self, x_t, mean, alpha_t, sigma_t):
+        return mean
+
+    def _advance(self, x_t, integral, alpha_t, sigma_t, alpha_s, sigma_s):
+        return sigma_s / sigma_t * x_t - sigma_s * integral
+
+
+class REABSampler(_MultistepSampler):
+    r"""Rescaled exponential Adams-Bashforth sampler (reference ``azula/sample.py:824-950``): the
+    prediction f_t = (1 - a_t) / (b_t alpha_t) x_t - mean / b_t with a_t = sigma_t^2 / (alpha_t^2 +
+    sigma_t^2), b_t = sqrt(a_t); basis integrals by 256-panel trapezoid."""
+
+    _moments = staticmethod(_moments_sech)
+
+    @staticmethod
+    def _exponential_adams_bashforth(t: Tensor, /, i: int, n: int) -> Tensor:
+        return _lagrange_weights(t, i, n, _moments_sech)
+
+    def _variable(self, alpha, sigma):
+        return sigma.log() - alpha.log()
+
+    def _predict(self, x_t, mean, alpha_t, sigma_t):
+        a_t = sigma_t**2 / (alpha_t**2 + sigma_t**2)
+        b_t = sigma_t * torch.rsqrt(alpha_t**2 + sigma_t**2)
+        return (1 - a_t) / b_t / alpha_t * x_t - 1 / b_t * mean
+
+    def _advance(self, x_t, integral, alpha_t, sigma_t, alpha_s, sigma_s):
+        return (
+            torch.sqrt((alpha_s**2 + sigma_s**2) / (alpha_t**2 + sigma_t**2)) * x_t
+            + torch.sqrt(alpha_s**2 + sigma_t**2) * integral
+        )
+
+
+class PCSampler(Sampler):
+    r"""Predictor-corrector sampler (reference ``azula/sample.py:953-993``): ``corrections`` Langevin-like
+    corrector moves at time t, then a deterministic (DDIM eta=0) predictor to s.  Both are instances
+    of the fused transition kernel's form x' = a_s m + k_x (x - a_t m) + k_eps eps."""
+
+    def __init__(self, denoiser: Denoiser, corrections: int = 1, delta: float = 0.01, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.denoiser = denoiser
+        self.corrections = corrections
+        self.delta = delta
+
+    def _fusable(self, x: Tensor) -> bool:
+        return False  # several denoiser evaluations per step: generic loop
+
+    def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
+        alpha_s, sigma_s = self.denoiser.schedule(s)
+        alpha_t, sigma_t = self.denoiser.schedule(t)
+        keep, kick = math.sqrt(1 - self.delta), math.sqrt(self.delta)
+        for _ in range(self.corrections):
+            q_t = self.denoiser(x_t, t, **kwargs)
+            if x_t.is_cuda:
+                x_t = self._device_kernel(x_t, q_t.mean, alpha_t, alpha_t, keep + 0 * alpha_t, kick * sigma_t, True)
+            else:
+                x_t = alpha_t * q_t.mean + keep * (x_t - alpha_t * q_t.mean) + kick * sigma_t * self._draw_noise(x_t)
+        q_t = self.denoiser(x_t, t, **kwargs)
+        if x_t.is_cuda:
+            return self._device_kernel(x_t, q_t.mean, alpha_t, alpha_s, sigma_s / sigma_t, 0 * alpha_t, False)
+        return alpha_s * q_t.mean + sigma_s / sigma_t * (x_t - alpha_t * q_t.mean)

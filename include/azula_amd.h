@@ -96,6 +96,32 @@ typedef struct AzTransitionArgs {
 } AzTransitionArgs;
 int az_transition_f32(const AzTransitionArgs* args, az_stream_t stream);
 
+/* ---- linear multistep update ------------------------------------------------
+ * Replaces the per-step tensor arithmetic of the Adams-Bashforth sampler family:
+ *   zABSampler.__call__   azula/sample.py:519-546     vABSampler.__call__   azula/sample.py:593-620
+ *   zEABSampler.__call__  azula/sample.py:688-715     xEABSampler.__call__  azula/sample.py:797-821
+ *   REABSampler.__call__  azula/sample.py:915-950
+ * which all have the form (prediction linear in x_t and the posterior mean, history of <= order
+ * predictions, x_s linear in x_t and the history):
+ *   pred = a x_t + b mean                      -> written to `pred` (its history slot)
+ *   x_s  = p x_t + sum_j w_j hist[j] + w_new pred
+ * `coef` is a DEVICE pointer to 4 + n_hist floats [a, b, p, w_new, w_0 .. w_{n_hist-1}] (the
+ * fp64 Vandermonde solves of `_adams_bashforth` stay on the host, azula/sample.py:486-508).
+ * x_s may alias x_t; pred must not alias any hist[j].  All pointers 16-byte aligned.          */
+#define AZ_MULTISTEP_MAX_HIST 7
+typedef struct AzMultistepArgs {
+  float* x_s;
+  float* pred;
+  const float* x_t;
+  const float* mean;
+  const float* hist[AZ_MULTISTEP_MAX_HIST]; /* older predictions, oldest first */
+  const float* coef;                        /* DEVICE pointer                  */
+  int64_t count;                            /* elements                        */
+  int32_t n_hist;                           /* 0 .. AZ_MULTISTEP_MAX_HIST      */
+  int32_t pad_;
+} AzMultistepArgs;
+int az_multistep_f32(const AzMultistepArgs* args, az_stream_t stream);
+
 /* y = s * x with s read from device memory (azula/denoise.py:317 c_in * x_t, generic backbones). */
 int az_scale_f32(float* y, const float* x, const float* s_dev, int64_t n, az_stream_t stream);
 

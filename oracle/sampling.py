@@ -231,3 +231,98 @@ def sample_ito(mean_fn, x, schedule=vp_schedule, steps: int = 64, eta: float = 1
             record_eps.append(eps)
         x_t = x_s + eta * alpha_s * torch.sqrt(torch.abs((sigma_t / alpha_t) ** 2 - (sigma_s / alpha_s) ** 2)) * eps
     return x_t
+
+
+# --------------------------------------------------------------------------- SURVEY 8f multistep family
+def _basis_integrals(kind: str, t: Tensor, i: int, k: Tensor) -> Tensor:
+    r"""Right-hand side of the Lagrange system for each rule (fp64):
+    AB  azula/sample.py:505-506;  zEAB :670-683;  xEAB :783-792;  REAB :907-910."""
+    lo, hi = t[i], t[i + 1]
+    if kind in ("zAB", "vAB"):
+        return hi ** (k + 1) / (k + 1) - lo ** (k + 1) / (k + 1)
+    if kind == "REAB":
+        u = torch.linspace(lo, hi, steps=256 + 1, dtype=t.dtype)
+        return torch.trapezoid(torch.exp(u) / (1 + torch.exp(2 * u)) * (u ** k[:, None]), u, dim=-1)
+    k_fact = torch.cumprod(torch.clip(k, min=1), dim=0)
+    if kind == "zEAB":
+        return (-1) ** k * k_fact * (
+            torch.exp(hi) * torch.cumsum((-hi) ** k / k_fact, dim=0)
+            - torch.exp(lo) * torch.cumsum((-lo) ** k / k_fact, dim=0)
+        )
+    if kind == "xEAB":
+        return -k_fact * (
+            torch.exp(-hi) * torch.cumsum(hi**k / k_fact, dim=0) - torch.exp(-lo) * torch.cumsum(lo**k / k_fact, dim=0)
+        )
+    raise ValueError(kind)
+
+
+def multistep_weights(kind: str, u: Tensor, i: int, n: int) -> Tensor:
+    r"""``_adams_bashforth`` / ``_exponential_adams_bashforth``: fp64 Vandermonde solve, rounded back
+    to the dtype of ``u`` -- azula/sample.py:486-508 (and :652-685, :765-794, :884-912)."""
+    t = u.to(torch.float64)
+    n = min(n, i + 1)
+    k = torch.arange(n)
+    V = t[i + 1 - n : i + 1] ** k[:, None]
+    return torch.linalg.solve(V, _basis_integrals(kind, t, i, k)).to(u.dtype)
+
+
+def sample_multistep(mean_fn, x, kind: str, order: int = 2, schedule=vp_schedule, steps: int = 64, **kwargs) -> Tensor:
+    r"""zAB (azula/sample.py:519-546), vAB (:593-620), zEAB (:688-715), xEAB (:797-821), REAB (:915-950)."""
+    time = timesteps(steps=steps)
+    alpha, sigma = schedule(time)
+    if kind == "zAB":
+        u = sigma / alpha
+    elif kind == "vAB":
+        u = sigma / (alpha + sigma)
+    else:
+        u = sigma.log() - alpha.log()
+    x_t, buffer = x, []
+    for i, t in enumerate(time[:-1].unbind()):
+        alpha_t, sigma_t, alpha_s, sigma_s = alpha[i], sigma[i], alpha[i + 1], sigma[i + 1]
+        mean = mean_fn(x_t, t, **kwargs)
+        if kind in ("zAB", "zEAB"):
+            pred = (x_t - alpha_t * mean) / sigma_t
+        elif kind == "vAB":
+            pred = 1 / sigma_t * x_t - (1 + alpha_t / sigma_t) * mean
+        elif kind == "xEAB":
+            pred = mean
+        else:
+            a_t = sigma_t**2 / (alpha_t**2 + sigma_t**2)
+            b_t = sigma_t * torch.rsqrt(alpha_t**2 + sigma_t**2)
+            pred = (1 - a_t) / b_t / alpha_t * x_t - 1 / b_t * mean
+        buffer.append(pred)
+        if len(buffer) > order:
+            buffer.pop(0)
+        coeffs = multistep_weights(kind, u, i, order)
+        integral = sum(b * c for b, c in zip(buffer, coeffs, strict=True))
+        if kind in ("zAB", "zEAB"):
+            x_t = alpha_s / alpha_t * x_t + alpha_s * integral
+        elif kind == "vAB":
+            x_t = (alpha_s + sigma_s) / (alpha_t + sigma_t) * x_t + (alpha_s + sigma_s) * integral
+        elif kind == "xEAB":
+            x_t = sigma_s / sigma_t * x_t - sigma_s * integral
+        else:
+            x_t = (
+                torch.sqrt((alpha_s**2 + sigma_s**2) / (alpha_t**2 + sigma_t**2)) * x_t
+                + torch.sqrt(alpha_s**2 + sigma_t**2) * integral
+            )
+    return x_t
+
+
+def sample_pc(mean_fn, x, schedule=vp_schedule, steps: int = 64, corrections: int = 1, delta: float = 0.01,
+              eps_list=None, record_eps=None, **kwargs) -> Tensor:
+    r"""PCSampler loop -- azula/sample.py:975-993 (corrector noise drawn after each denoiser call)."""
+    x_t, j = x, 0
+    for t, s in time_pairs(steps=steps).unbind():
+        alpha_s, sigma_s = schedule(s)
+        alpha_t, sigma_t = schedule(t)
+        for _ in range(corrections):
+            mean = mean_fn(x_t, t, **kwargs)
+            eps = torch.randn_like(x_t) if eps_list is None else eps_list[j]
+            j += 1
+            if record_eps is not None:
+                record_eps.append(eps)
+            x_t = alpha_t * mean + math.sqrt(1 - delta) * (x_t - alpha_t * mean) + math.sqrt(delta) * sigma_t * eps
+        mean = mean_fn(x_t, t, **kwargs)
+        x_t = alpha_s * mean + sigma_s / sigma_t * (x_t - alpha_t * mean)
+    return x_t

@@ -119,6 +119,46 @@ def test_transition_flat_in_place_and_golden(az, golden):
         torch.testing.assert_close(x.cpu(), g[case["tag"]], rtol=2e-6, atol=2e-6, msg=case["tag"])
 
 
+@pytest.mark.parametrize("n_hist", [0, 1, 2, 7])
+@pytest.mark.parametrize("n", [4, 1001, 65536 + 3])
+def test_multistep_bit_exact(az, n, n_hist):
+    """az_multistep_f32 (AB-family update, azula/sample.py:519-546): separately rounded fp32 mul/add in
+    the documented order, float4 body + scalar tail, x_s aliasing x_t."""
+    g = torch.Generator().manual_seed(n + n_hist)
+    x, mean = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    hist = [torch.randn(n, generator=g) for _ in range(n_hist)]
+    coef = torch.randn(4 + n_hist, generator=g)
+    pred = coef[0] * x + coef[1] * mean
+    acc = coef[2] * x
+    for j, h in enumerate(hist):
+        acc = acc + coef[4 + j] * h
+    want = acc + coef[3] * pred
+    dx, dm, dc = dev(x), dev(mean), dev(coef)
+    dh = [dev(h) for h in hist]
+    dpred = torch.empty(n, device="cuda")
+    a = az.AzMultistepArgs(x_s=dx.data_ptr(), pred=dpred.data_ptr(), x_t=dx.data_ptr(), mean=dm.data_ptr(),
+                           coef=dc.data_ptr(), count=n, n_hist=n_hist)
+    for j, h in enumerate(dh):
+        a.hist[j] = h.data_ptr()
+    az.call("az_multistep_f32", C.byref(a), az.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(dpred.cpu(), pred)
+    assert torch.equal(dx.cpu(), want)
+
+
+def test_multistep_rejects_bad_arguments(az):
+    x = torch.zeros(16, device="cuda")
+    c = torch.zeros(12, device="cuda")
+    a = az.AzMultistepArgs(x_s=x.data_ptr(), pred=x.data_ptr(), x_t=x.data_ptr(), mean=x.data_ptr(), coef=c.data_ptr(),
+                           count=16, n_hist=8)
+    with pytest.raises(az.AzulaAmdError):
+        az.call("az_multistep_f32", C.byref(a), az.stream_ptr())
+    a.n_hist = 1
+    a.hist[0] = x.data_ptr()  # history slot aliasing the slot being written
+    with pytest.raises(az.AzulaAmdError):
+        az.call("az_multistep_f32", C.byref(a), az.stream_ptr())
+
+
 @pytest.mark.parametrize("f_nhwc,fC", [(0, 3), (0, 6), (1, 4), (1, 8)])
 @pytest.mark.parametrize("cfg", [False, True])
 def test_transition_image_layouts(az, f_nhwc, fC, cfg):

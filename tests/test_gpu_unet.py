@@ -171,3 +171,27 @@ def test_next_samplers_on_gpu(golden):
     ref = sampling.sample_ito(omean, g["x1"], steps=16, eps_list=eps)
     print("ito16", max_err(x0, ref))
     assert max_err(x0, ref) < 5e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_multistep_and_pc_samplers_on_gpu(golden):
+    """the AB family steps through az_multistep_f32 (one pass per step, host fp64 solves),
+    PC through the transition kernel; against reference-generated vectors (G9)."""
+    import azula_amd.sample as S
+
+    g = golden("g9_unet_multistep")
+    den, sd, cfg = wrapped_denoiser(g)
+    x1 = g["x1"].cuda()
+    for kind in ("zAB", "vAB", "zEAB", "xEAB", "REAB"):
+        want = g[f"{kind}_o3"]
+        x0 = getattr(S, kind + "Sampler")(den, order=3, steps=g.meta["steps"], silent=True)(x1)
+        err, sc = max_err(x0, want), max(1.0, want.abs().max().item())
+        print(kind, "order 3 max|d| vs reference:", err, "scale", sc)
+        assert x0.is_cuda and err < 1e-3 * sc, kind
+    torch.manual_seed(5)
+    eps = [torch.randn_like(x1).cpu() for _ in range(g.meta["pc_steps"])]
+    torch.manual_seed(5)
+    x0 = S.PCSampler(den, corrections=1, steps=g.meta["pc_steps"], silent=True)(x1)
+    omean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, cfg, a, c), x, t)  # noqa: E731
+    ref = sampling.sample_pc(omean, g["x1"], steps=g.meta["pc_steps"], corrections=1, eps_list=eps)
+    print("pc", max_err(x0, ref))
+    assert max_err(x0, ref) < 5e-4 * max(1.0, ref.abs().max().item())

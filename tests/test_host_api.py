@@ -210,6 +210,68 @@ def test_next_samplers_cpu_match_reference(golden):
     assert max_err(DDIMSampler(den, steps=64, silent=True)(g["x1"]), g["euler64"]) < 1e-4
 
 
+MULTISTEP = ("zAB", "vAB", "zEAB", "xEAB", "REAB")
+
+
+def _emulate_multistep_kernel(smp, den, x):
+    """az_multistep_f32's arithmetic (separately rounded fp32 mul/add, history oldest first) in torch,
+    driven by the sampler's own device coefficient table."""
+    alpha, sigma = den.schedule(smp.timesteps)
+    table = smp._device_table(alpha, sigma)
+    x_t, hist = x, []
+    for i, t in enumerate(smp.timesteps[:-1].unbind()):
+        a, b, p, w_new = table[i, :4]
+        mean = den(x_t, t).mean
+        pred = a * x_t + b * mean
+        acc = p * x_t
+        for j, h in enumerate(hist):
+            acc = acc + table[i, 4 + j] * h
+        x_t = acc + w_new * pred
+        hist = (hist + [pred])[-(smp.order - 1) :] if smp.order > 1 else []
+    return x_t
+
+
+def test_multistep_samplers_cpu_match_reference(golden):
+    """the Adams-Bashforth family and the PC sampler.  (1) The host path reproduces the
+    reference's vectors (G9); (2) the folded (a, b, p, w) table that drives az_multistep_f32 gives the
+    same samples when the kernel's arithmetic is emulated in fp32 -- the part of the device path that
+    can be checked without a GPU."""
+    import azula_amd.sample as S
+
+    g = golden("g9_toy_multistep")
+    net = ToyMLP()
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"]))
+    den = KarrasDenoiser(net, VPSchedule()).eval()
+    steps = g.meta["steps"]
+    for kind in MULTISTEP:
+        for order in (1, 2, 3):
+            smp = getattr(S, kind + "Sampler")(den, order=order, steps=steps, silent=True)
+            want = g[f"{kind}_o{order}"]
+            assert max_err(smp(g["x1"]), want) < 2e-5, (kind, order)
+            assert max_err(_emulate_multistep_kernel(smp, den, g["x1"]), want) < 2e-4, (kind, order)
+    torch.manual_seed(3)
+    x0 = S.PCSampler(den, steps=steps, silent=True, **g.meta["pc"])(g["x1"])
+    assert max_err(x0, g["pc"]) < 1e-5
+    with pytest.raises(ValueError, match="order"):
+        S.zABSampler(den, order=9, steps=4, silent=True)(g["x1"])
+
+
+def test_multistep_weight_functions_keep_reference_names(golden):
+    """The reference exposes the solves as static methods; callers (and its tests) use them."""
+    import azula_amd.sample as S
+
+    g = golden("g9_multistep_weights")
+    alpha, sigma = g["alpha"], g["sigma"]
+    u = sigma.log() - alpha.log()
+    for kind, fn in (("zEAB", S.zEABSampler._exponential_adams_bashforth), ("xEAB", S.xEABSampler._exponential_adams_bashforth),
+                     ("REAB", S.REABSampler._exponential_adams_bashforth)):
+        c = fn(u, i=7, n=3)
+        assert c.dtype == torch.float32
+        torch.testing.assert_close(c, g[f"{kind}_w3"][7, :3], rtol=2e-5, atol=1e-7)
+    c = S.vABSampler._adams_bashforth(sigma / (alpha + sigma), i=1, n=4)  # n is clipped to i + 1
+    torch.testing.assert_close(c, g["vAB_w4"][1, :2], rtol=2e-5, atol=1e-7)
+
+
 def test_layers_for_custom_backbones():
     """azula_amd.nn.layers (counterpart of azula.nn.layers) against the oracle formulas."""
     from azula_amd.nn import layers

@@ -128,3 +128,39 @@ def test_g6_unet_loop(golden):
     assert max_err(mean(g["x1"], torch.tensor(0.5)), g["mean_t05"]) < 1e-5
     x0 = sampling.sample(mean, g["x1"], steps=8, eta=None, eps_list=list(g["ddpm8_eps"]))
     assert max_err(x0, g["ddpm8"]) < 1e-4
+
+
+MULTISTEP = ("zAB", "vAB", "zEAB", "xEAB", "REAB")
+
+
+def test_g9_multistep_weights(golden):
+    """The fp64 Vandermonde solves of the AB family, rounded to fp32, against the reference's."""
+    g = golden("g9_multistep_weights")
+    alpha, sigma = g["alpha"], g["sigma"]
+    for kind in MULTISTEP:
+        u = sigma / alpha if kind == "zAB" else sigma / (alpha + sigma) if kind == "vAB" else sigma.log() - alpha.log()
+        for order in (1, 2, 3, 4):
+            want = g[f"{kind}_w{order}"]
+            for i in range(g.meta["steps"]):
+                c = sampling.multistep_weights(kind, u, i, order)
+                torch.testing.assert_close(c, want[i, : len(c)], rtol=2e-5, atol=1e-7, msg=f"{kind} {order} {i}")
+    # first-order rules collapse to closed forms: AB -> u_s - u_t, zEAB -> e^{u_s} - e^{u_t}
+    u = (sigma / alpha).double()
+    assert abs(float(sampling.multistep_weights("zAB", u, 5, 1)) - float(u[6] - u[5])) < 1e-12 * float(u[5])
+    u = (sigma.log() - alpha.log()).double()
+    assert abs(float(sampling.multistep_weights("zEAB", u, 5, 1)) - float(u[6].exp() - u[5].exp())) < 1e-9
+
+
+def test_g9_toy_multistep_loops(golden):
+    g = golden("g9_toy_multistep")
+    sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"])
+    mean = lambda x, t: sampling.karras_mean(_toy(sd), x, t)  # noqa: E731
+    for kind in MULTISTEP:
+        for order in (1, 2, 3):
+            x0 = sampling.sample_multistep(mean, g["x1"], kind, order=order, steps=g.meta["steps"])
+            assert max_err(x0, g[f"{kind}_o{order}"]) < 2e-5, (kind, order)
+    x0 = sampling.sample_pc(mean, g["x1"], steps=g.meta["steps"], eps_list=list(g["pc_eps"]), **g.meta["pc"])
+    assert max_err(x0, g["pc"]) < 1e-5
+    # order-1 zAB is the Euler step and order-1 zEAB/xEAB the DDIM step: same ODE, same answer at fp32 level
+    assert max_err(g["zAB_o1"], sampling.sample_euler(mean, g["x1"], steps=g.meta["steps"])) < 1e-4
+    assert max_err(g["xEAB_o1"], sampling.sample(mean, g["x1"], steps=g.meta["steps"], eta=0.0)) < 1e-4
