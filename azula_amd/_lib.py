@@ -167,6 +167,8 @@ class AzAttnArgs(C.Structure):
         ("eps", C.c_float),
         ("rope_cos", c_f32p),
         ("rope_sin", c_f32p),
+        ("q_weight", c_f32p),
+        ("k_weight", c_f32p),
     ]
 
 
@@ -191,7 +193,10 @@ PROTOTYPES: dict[str, list] = {
     "az_groupnorm_stats_f32": [vp, vp, vp, i64, i64, i64, i64, i64, i32, i32, c_stream],
     "az_groupnorm_finalize_f32": [C.POINTER(AzNormFinalizeArgs), c_stream],
     "az_affine_act_f32": [vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, i32, i32, c_stream],
-    "az_rownorm_mod_f32": [vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, c_stream],
+    "az_rownorm_mod_f32": [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, c_stream],
+    "az_token_copy_f32": [vp, i64, i64, vp, i64, i64, i64, i64, i64, c_stream],
+    "az_token_fill_f32": [vp, i64, i64, i64, vp, i64, vp, i64, i64, c_stream],
+    "az_timestep_embedding_f32": [vp, i64, vp, i64, i64, i32, f32, c_stream],
     "az_conv2d_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_suggest_splitk": [i64, i32, i32, i32],
     "az_conv2d_winograd_f32": [C.POINTER(AzConvArgs), c_stream],

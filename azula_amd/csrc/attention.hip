@@ -79,6 +79,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
     for (int jj = 0; jj < KJ; ++jj)
 #pragma unroll
       for (int s = 0; s < 4; ++s) qf[jj][s] *= f;
+    if (a.q_weight != nullptr) {  // learned per-channel gain of the q RMS norm
+#pragma unroll
+      for (int jj = 0; jj < KJ; ++jj) {
+        const float4 w = *reinterpret_cast<const float4*>(a.q_weight + 8 * jj + 4 * h2);
+        qf[jj][0] *= w.x;
+        qf[jj][1] *= w.y;
+        qf[jj][2] *= w.z;
+        qf[jj][3] *= w.w;
+      }
+    }
     if (a.rope_cos != nullptr && qi < T) {  // rotate adjacent (re, im) channel pairs by theta[token][head][pair]
       const int64_t rbase = (int64_t)qi * a.heads * (D / 2) + (int64_t)hd * (D / 2);
 #pragma unroll
@@ -127,6 +137,13 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
           kv.y *= f;
           kv.z *= f;
           kv.w *= f;
+        }
+        if (a.k_weight != nullptr) {
+          const float4 w = *reinterpret_cast<const float4*>(a.k_weight + lc * 4);
+          kv.x *= w.x;
+          kv.y *= w.y;
+          kv.z *= w.z;
+          kv.w *= w.w;
         }
         if (a.rope_cos != nullptr && key < T) {
           const int64_t ro = (int64_t)key * a.heads * (D / 2) + (int64_t)hd * (D / 2) + 2 * lc;
@@ -251,6 +268,48 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(float* __restrict__ dst
   }
 }
 
+// Token-window copy: dst[b, dst_off + i, :] = src[b, src_off + i, :], i < n (16-byte vectors).
+__global__ __launch_bounds__(256) void token_copy_kernel(float4* __restrict__ dst, const float4* __restrict__ src,
+                                                         int64_t dst_tokens, int64_t dst_off, int64_t src_tokens,
+                                                         int64_t src_off, int64_t n, int64_t B, int64_t cs4) {
+  const int64_t total = B * n * cs4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = e % cs4, i = (e / cs4) % n, b = e / (cs4 * n);
+    dst[((b * dst_tokens + dst_off + i) * cs4) + c] = src[((b * src_tokens + src_off + i) * cs4) + c];
+  }
+}
+
+// dst[b, dst_off + j, :] = row[b, :] + pos[j, :], j < n  (in-context class tokens of JiT,
+// plugins/jit/_src/model.py:364-367: y_emb repeated over the context plus its positional embedding)
+__global__ __launch_bounds__(256) void token_fill_kernel(float4* __restrict__ dst, const float4* __restrict__ row,
+                                                         const float4* __restrict__ pos, int64_t dst_tokens,
+                                                         int64_t dst_off, int64_t n, int64_t B, int64_t cs4,
+                                                         int64_t row_bstride4) {
+  const int64_t total = B * n * cs4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = e % cs4, j = (e / cs4) % n, b = e / (cs4 * n);
+    const float4 r = row[b * row_bstride4 + c], q = pos[j * cs4 + c];
+    dst[((b * dst_tokens + dst_off + j) * cs4) + c] =
+        make_float4(az_add(r.x, q.x), az_add(r.y, q.y), az_add(r.z, q.z), az_add(r.w, q.w));
+  }
+}
+
+// Sinusoidal timestep embedding, cos block then sin block (plugins/jit/_src/model.py:59-81):
+// dst[r, j] = cos(t_r f_j), dst[r, half + j] = sin(t_r f_j), f_j = exp(-ln(max_period) j / half).
+__global__ __launch_bounds__(256) void timestep_embedding_kernel(float* __restrict__ dst, int64_t ldd,
+                                                                 const float* __restrict__ t, int64_t t_stride,
+                                                                 int64_t rows, int half, float log_period) {
+  const int64_t total = rows * half;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(e % half);
+    const int64_t r = e / half;
+    const float f = expf(az_mul(-log_period, (float)j) / (float)half);
+    const float arg = az_mul(t[r * t_stride], f);
+    dst[r * ldd + j] = cosf(arg);
+    dst[r * ldd + half + j] = sinf(arg);
+  }
+}
+
 // y[r, c] = x[r, 2c] * silu(x[r, 2c + 1])  (azula/nn/layers.py:107-110: unflatten(-1, (-1, 2)))
 __global__ __launch_bounds__(256) void swiglu_kernel(float* __restrict__ y, const float* __restrict__ x, int64_t rows,
                                                      int cout, int xs, int ys) {
@@ -314,6 +373,42 @@ int az_unpatchify_f32(float* dst, const float* src, int64_t B, int64_t Z, int64_
   AZ_REQUIRE(B > 0 && Z > 0 && p > 0 && H % p == 0 && W % p == 0 && cs >= Z * p * p, AZ_E_SHAPE);
   hipLaunchKernelGGL(unpatchify_kernel, dim3(az_stream_grid(B * Z * H * W, 256)), dim3(256), 0, az_s(stream), dst, src,
                      B, (int)Z, (int)H, (int)W, (int)p, (int)cs);
+  return az_launch_status();
+}
+
+int az_token_copy_f32(float* dst, int64_t dst_tokens, int64_t dst_off, const float* src, int64_t src_tokens,
+                      int64_t src_off, int64_t n, int64_t B, int64_t cs, az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(B > 0 && n > 0 && cs > 0 && cs % 4 == 0 && dst_off >= 0 && src_off >= 0 && dst_off + n <= dst_tokens &&
+                 src_off + n <= src_tokens,
+             AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(dst) && AZ_ALIGNED16(src), AZ_E_ALIGN);
+  hipLaunchKernelGGL(token_copy_kernel, dim3(az_stream_grid(B * n * (cs / 4), 256)), dim3(256), 0, az_s(stream),
+                     reinterpret_cast<float4*>(dst), reinterpret_cast<const float4*>(src), dst_tokens, dst_off,
+                     src_tokens, src_off, n, B, cs / 4);
+  return az_launch_status();
+}
+
+int az_token_fill_f32(float* dst, int64_t dst_tokens, int64_t dst_off, int64_t n, const float* row,
+                      int64_t row_bstride, const float* pos, int64_t B, int64_t cs, az_stream_t stream) {
+  AZ_REQUIRE(dst && row && pos, AZ_E_NULL);
+  AZ_REQUIRE(B > 0 && n > 0 && cs > 0 && cs % 4 == 0 && row_bstride % 4 == 0 && dst_off >= 0 &&
+                 dst_off + n <= dst_tokens,
+             AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(dst) && AZ_ALIGNED16(row) && AZ_ALIGNED16(pos), AZ_E_ALIGN);
+  hipLaunchKernelGGL(token_fill_kernel, dim3(az_stream_grid(B * n * (cs / 4), 256)), dim3(256), 0, az_s(stream),
+                     reinterpret_cast<float4*>(dst), reinterpret_cast<const float4*>(row),
+                     reinterpret_cast<const float4*>(pos), dst_tokens, dst_off, n, B, cs / 4, row_bstride / 4);
+  return az_launch_status();
+}
+
+int az_timestep_embedding_f32(float* dst, int64_t ldd, const float* t_dev, int64_t t_stride, int64_t rows,
+                              int32_t half, float max_period, az_stream_t stream) {
+  AZ_REQUIRE(dst && t_dev, AZ_E_NULL);
+  AZ_REQUIRE(rows > 0 && half > 0 && ldd >= 2 * half && max_period > 0.f && (t_stride == 0 || t_stride == 1),
+             AZ_E_SHAPE);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(az_stream_grid(rows * half, 256)), dim3(256), 0, az_s(stream),
+                     dst, ldd, t_dev, t_stride, rows, (int)half, logf(max_period));
   return az_launch_status();
 }
 

@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void affine_act_pool_kernel(float* __restrict_
 
 // One wave per row.  kind 0: layer norm (unbiased variance), kind 1: RMS norm.
 __global__ __launch_bounds__(256) void rownorm_mod_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                          const float* __restrict__ weight,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int64_t scale_bstride,
                                                           int64_t rows, int64_t rows_per_batch, int C, int cs,
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(256) void rownorm_mod_kernel(float* __restrict__ y,
       float o = 0.f;
       if (c < C) {
         o = (xr[c] - mean) * rstd;
+        if (weight) o *= weight[c];
         o = o * (1.f + (sc ? sc[c] : 0.f)) + (sh ? sh[c] : 0.f);
       }
       yr[c] = o;
@@ -415,7 +417,8 @@ int az_affine_act_f32(float* y, const float* x, const float* x1, int64_t c0s, co
   return az_launch_status();
 }
 
-int az_rownorm_mod_f32(float* y, const float* x, const float* scale, const float* shift, int64_t scale_bstride,
+int az_rownorm_mod_f32(float* y, const float* x, const float* weight, const float* scale, const float* shift,
+                       int64_t scale_bstride,
                        int64_t rows, int64_t rows_per_batch, int64_t C, int64_t cs, int32_t kind, float eps,
                        az_stream_t stream) {
   AZ_REQUIRE(y && x, AZ_E_NULL);
@@ -424,8 +427,8 @@ int az_rownorm_mod_f32(float* y, const float* x, const float* scale, const float
   AZ_REQUIRE(AZ_ALIGNED16(y) && AZ_ALIGNED16(x), AZ_E_ALIGN);
   int64_t blocks = (rows + 3) / 4;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(rownorm_mod_kernel, dim3((unsigned)blocks), dim3(256), 0, az_s(stream), y, x, scale, shift,
-                     scale_bstride, rows, rows_per_batch, (int)C, (int)cs, (int)kind, eps);
+  hipLaunchKernelGGL(rownorm_mod_kernel, dim3((unsigned)blocks), dim3(256), 0, az_s(stream), y, x, weight, scale,
+                     shift, scale_bstride, rows, rows_per_batch, (int)C, (int)cs, (int)kind, eps);
   return az_launch_status();
 }
 

@@ -161,3 +161,35 @@ class KarrasDenoiser(Denoiser):
         from .sample import FusedDenoiser
 
         return FusedDenoiser(coefficients=self.host_coefficients, programs=[program])
+
+
+class SimpleDenoiser(Denoiser):
+    r"""Denoiser whose backbone predicts the mean directly (reference ``azula/denoise.py:177-230``):
+    mu(x_t) = F(c_in x_t, c_time) with c_in = rsqrt(a^2 + s^2), c_time = log(s / a).  In the fused step it
+    is the Karras form with c_skip = 0, c_out = 1 (0 * x + 1 * F is exact in fp32)."""
+
+    def __init__(self, backbone: nn.Module, schedule: Schedule) -> None:
+        super().__init__()
+        self.backbone = backbone
+        self.schedule = schedule
+
+    @torch.no_grad()
+    def forward(self, x_t: Tensor, t: Tensor, **kwargs) -> DiracPosterior:
+        alpha_t, sigma_t = self.schedule(t)
+        alpha_t, sigma_t = _expand_like(alpha_t, x_t.ndim), _expand_like(sigma_t, x_t.ndim)
+        c_in = torch.rsqrt(alpha_t**2 + sigma_t**2)
+        c_time = torch.log(sigma_t / alpha_t).reshape_as(t)
+        dtype = get_module_dtype(self.backbone) or x_t.dtype
+        if not x_t.is_cuda:
+            return DiracPosterior(mean=self.backbone((c_in * x_t).to(dtype), c_time.to(dtype), **kwargs).to(x_t))
+        require_f32_cuda(x_t, "SimpleDenoiser")
+        x_in = precondition(x_t.contiguous(), c_in.to(x_t.device))
+        output = self.backbone(x_in.to(dtype), c_time.to(device=x_t.device, dtype=dtype), **kwargs)
+        return DiracPosterior(mean=output.to(x_t))
+
+    def host_coefficients(self, alpha_t: Tensor, sigma_t: Tensor) -> dict:
+        c_in = torch.rsqrt(alpha_t**2 + sigma_t**2)
+        return {"c_in": c_in, "c_out": torch.ones_like(c_in), "c_skip": torch.zeros_like(c_in),
+                "c_time": torch.log(sigma_t / alpha_t)}
+
+    _az_fused = KarrasDenoiser._az_fused

@@ -343,11 +343,12 @@ class Builder:
         )
         return y
 
-    def row_norm(self, x: Act, kind: int, *, scale=None, shift=None, scale_off=0, shift_off=0, bstride=0, eps=1e-5):
+    def row_norm(self, x: Act, kind: int, *, weight=None, scale=None, shift=None, scale_off=0, shift_off=0, bstride=0,
+                 eps=1e-5):
         y = self.new_act(x.B, x.H, x.W, x.C)
         rows = x.B * x.H * x.W
         self.tape.add(
-            "az_rownorm_mod_f32", y.ptr, x.ptr,
+            "az_rownorm_mod_f32", y.ptr, x.ptr, weight.data_ptr() if weight is not None else None,
             scale.data_ptr() + 4 * scale_off if scale is not None else None,
             shift.data_ptr() + 4 * shift_off if shift is not None else None,
             bstride, rows, x.H * x.W, x.C, x.cs, kind, eps,
@@ -365,7 +366,7 @@ def transition_args(**kw) -> AzTransitionArgs:
 
 # ------------------------------------------------------------------------------- token-path helpers
 def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool, scale: float, eps: float = 1e-5,
-                       rope: tuple | None = None) -> Act:
+                       rope: tuple | None = None, qk_weight: tuple | None = None) -> Act:
     r"""softmax(q k^T * scale) v over a fused-QKV token tensor (B, L, 1, 3*heads*dim).
 
     order: "nHC" = azula '(n H C)' (attention.py:90), "H3C" = ADM legacy (unet.py:338),
@@ -396,6 +397,9 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
     if rope is not None:  # (cos, sin) tables of shape (L, heads * dim / 2)
         a.rope_cos, a.rope_sin = rope[0].data_ptr(), rope[1].data_ptr()
         self.tape.keep.extend(rope)
+    if qk_weight is not None:  # learned (dim,) gains of the q / k RMS norms
+        a.q_weight, a.k_weight = qk_weight[0].data_ptr(), qk_weight[1].data_ptr()
+        self.tape.keep.extend(qk_weight)
     a._flops = 4 * qkv.B * heads * L * L * dim
     self.tape.add("az_attention_f32", C.byref(a), keep=[a])
     return out

@@ -12,12 +12,12 @@ the reference.
 from __future__ import annotations
 
 import abc
-from math import log
+from math import acos, log
 
 import torch
 from torch import Tensor
 
-__all__ = ["Schedule", "VPSchedule", "VESchedule"]
+__all__ = ["Schedule", "VPSchedule", "VESchedule", "CosineSchedule", "RectifiedSchedule", "DecaySchedule"]
 
 
 class Schedule(abc.ABC):
@@ -61,3 +61,46 @@ class VESchedule(Schedule):
 
     def __call__(self, t: Tensor) -> tuple[Tensor, Tensor]:
         return self.alpha(t), self.sigma(t)
+
+
+class CosineSchedule(VPSchedule):
+    r"""alpha_t = cos(t arccos alpha_min), sigma_t as the VP schedule (reference ``azula/noise.py:132-157``)."""
+
+    def alpha(self, t: Tensor) -> Tensor:
+        return torch.cos(acos(self.alpha_min) * t)
+
+
+class RectifiedSchedule(Schedule):
+    r"""Straight-line (rectified flow / flow matching) schedule: alpha_t = t alpha_min + (1 - t),
+    sigma_t = t + (1 - t) sigma_min (reference ``azula/noise.py:160-190``)."""
+
+    def __init__(self, alpha_min: float = 1e-3, sigma_min: float = 1e-3) -> None:
+        self.alpha_min, self.sigma_min = alpha_min, sigma_min
+
+    def warp(self, t: Tensor) -> Tensor:
+        return t
+
+    def alpha(self, t: Tensor) -> Tensor:
+        t = self.warp(t)
+        return t * self.alpha_min + (1 - t)
+
+    def sigma(self, t: Tensor) -> Tensor:
+        t = self.warp(t)
+        return t + (1 - t) * self.sigma_min
+
+    def __call__(self, t: Tensor) -> tuple[Tensor, Tensor]:
+        return self.alpha(t), self.sigma(t)
+
+
+class DecaySchedule(RectifiedSchedule):
+    r"""Rectified schedule on the warped time tau = (1 - gamma^t) / (1 - gamma): small gamma spends more of
+    [0, 1] at high signal-to-noise ratios (reference ``azula/noise.py:193-231``)."""
+
+    def __init__(self, alpha_min: float = 1e-3, sigma_min: float = 1e-3, gamma: float = 0.1) -> None:
+        super().__init__(alpha_min, sigma_min)
+        self.gamma = gamma
+
+    def tau(self, t: Tensor) -> Tensor:
+        return (1 - self.gamma**t) / (1 - self.gamma)
+
+    warp = tau

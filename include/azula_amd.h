@@ -195,9 +195,12 @@ int az_affine_act_f32(float* y, const float* x, const float* x1, int64_t c0s, co
 /* Row norms over the channel axis of an NHWC / token tensor (rows, cs), C real channels:
  *   kind 0: azula layer_norm, UNBIASED variance, no affine (azula/nn/layers.py:152-155);
  *   kind 1: RMS norm (azula/nn/layers.py:193-195, torch.nn.RMSNorm in azula/nn/dit.py:52-55);
- * followed by y = n * (1 + a[b, c]) + sh[b, c]  (azula/nn/unet.py:91, azula/nn/dit.py:107).
+ * optionally times a learned per-channel `weight` (NULL = none; the RMSNorm of the JiT plugin,
+ * plugins/jit/_src/util.py:149-163), followed by y = n * (1 + a[b, c]) + sh[b, c]
+ * (azula/nn/unet.py:91, azula/nn/dit.py:107, plugins/jit/_src/model.py:12-13).
  * rows_per_batch maps a row to its batch index for the modulation lookup.                      */
-int az_rownorm_mod_f32(float* y, const float* x, const float* scale, const float* shift, int64_t scale_bstride,
+int az_rownorm_mod_f32(float* y, const float* x, const float* weight, const float* scale, const float* shift,
+                       int64_t scale_bstride,
                        int64_t rows, int64_t rows_per_batch, int64_t C, int64_t cs, int32_t kind, float eps,
                        az_stream_t stream);
 
@@ -260,7 +263,8 @@ int az_pack_conv_weight_f32(float* dst, const float* src, int32_t cout, int32_t 
  * likewise k, v, out -- so one kernel serves the fused-QKV layouts of
  *   azula/nn/attention.py:89-104   '(n H C)' + per-head q/k RMSNorm (qk_rmsnorm = 1) + SDPA (scale = C^-1/2),
  *   plugins/adm/_src/unet.py:338-345  legacy '(H 3 C)' order, scale = C^-1/4 on q and k (pass C^-1/2),
- *   plugins/adm/_src/unet.py:371-379  new '(3 H C)' order.
+ *   plugins/adm/_src/unet.py:371-379  new '(3 H C)' order,
+ *   plugins/jit/_src/model.py:121-142  '(3 H C)' + weighted q/k RMSNorm + 2-D rotary + SDPA.
  * head_dim in {16, 32, 64, 128}; all strides multiples of 4 floats.                               */
 typedef struct AzAttnArgs {
   const float* q;
@@ -280,11 +284,31 @@ typedef struct AzAttnArgs {
    * rotated after the RMS norm.  NULL = no RoPE.                                                */
   const float* rope_cos;
   const float* rope_sin;
+  /* optional learned gains (head_dim floats, shared by all heads) applied to the RMS-normalised q / k
+   * before the rotation (plugins/jit/_src/model.py:108-109,129-133).  NULL = no gain.          */
+  const float* q_weight;
+  const float* k_weight;
 } AzAttnArgs;
 int az_attention_f32(const AzAttnArgs* args, az_stream_t stream);
 
 /* y[r, c] = x[r, 2c] * silu(x[r, 2c+1]), c < cout (SwiGLU, azula/nn/layers.py:89-110); xs / ys = row strides. */
 int az_swiglu_f32(float* y, const float* x, int64_t rows, int64_t cout, int64_t xs, int64_t ys, az_stream_t stream);
+
+/* Token-window helpers for sequences that grow / shrink inside a backbone (JiT in-context class
+ * tokens, plugins/jit/_src/model.py:362-374).  Token tensors are (B, tokens, cs), cs % 4 == 0.
+ *   copy: dst[b, dst_off + i, :] = src[b, src_off + i, :]            i < n   (torch.cat / x[:, k:])
+ *   fill: dst[b, dst_off + j, :] = row[b * row_bstride + :] + pos[j, :]  j < n
+ *         (y_emb.unsqueeze(1).repeat(1, n, 1) + in_context_posemb)                                 */
+int az_token_copy_f32(float* dst, int64_t dst_tokens, int64_t dst_off, const float* src, int64_t src_tokens,
+                      int64_t src_off, int64_t n, int64_t B, int64_t cs, az_stream_t stream);
+int az_token_fill_f32(float* dst, int64_t dst_tokens, int64_t dst_off, int64_t n, const float* row,
+                      int64_t row_bstride, const float* pos, int64_t B, int64_t cs, az_stream_t stream);
+
+/* Sinusoidal timestep embedding (plugins/jit/_src/model.py:59-81): dst[r, 0:half] = cos(t_r f),
+ * dst[r, half:2 half] = sin(t_r f), f_j = exp(-ln(max_period) j / half); t_r = t_dev[r * t_stride]
+ * (t_stride 0: one device scalar, e.g. AzStepCoef.c_time of the current step).                     */
+int az_timestep_embedding_f32(float* dst, int64_t ldd, const float* t_dev, int64_t t_stride, int64_t rows,
+                              int32_t half, float max_period, az_stream_t stream);
 
 /* Patchify NCHW (B, Z, H, W) -> tokens (B, H/p * W/p, cs), feature = z*p*p + a*p + b, scaled by
  * *scale_dev (NULL = 1), pad features zero; and back (azula/nn/layers.py:198-247, azula/nn/vit.py:92-106). */

@@ -380,3 +380,125 @@ def rerandomise_zero_tensors(sd: dict, seed: int = 123) -> int:
             v.copy_(torch.randn(v.shape, generator=g) / math.sqrt(fan_in))
             n += 1
     return n
+
+
+# --------------------------------------------------------------------------- JiT plugin backbone
+JIT_ARCH = {  # plugins/jit/_src/model.py:392-467 (depth, hidden, heads, bottleneck, ctx len, ctx start, patch)
+    "JiT-B/16": (12, 768, 12, 128, 32, 4, 16), "JiT-B/32": (12, 768, 12, 128, 32, 4, 32),
+    "JiT-L/16": (24, 1024, 16, 128, 32, 8, 16), "JiT-L/32": (24, 1024, 16, 128, 32, 8, 32),
+    "JiT-H/16": (32, 1280, 16, 256, 32, 10, 16), "JiT-H/32": (32, 1280, 16, 256, 32, 10, 32),
+}
+
+
+def jit_rms_norm(x: Tensor, weight: Tensor, eps: float = 1e-6) -> Tensor:
+    r"""weight * x * rsqrt(mean(x^2) + eps), statistics in fp32 -- plugins/jit/_src/util.py:149-163."""
+    h = x.to(torch.float32)
+    h = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + eps)
+    return (weight * h).to(x.dtype)
+
+
+def jit_timestep_embedding(t: Tensor, dim: int, max_period: float = 10000.0) -> Tensor:
+    r"""cos block || sin block -- plugins/jit/_src/model.py:59-81."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(t.dtype)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def jit_rope_tables(head_dim: int, grid: int, ctx: int = 0, theta: float = 10000.0):
+    r"""(cos, sin), each (ctx + grid^2, head_dim): the first half of a head rotates with the row index,
+    the second half with the column index, adjacent channel pairs share an angle; context tokens
+    are not rotated (cos 1, sin 0) -- plugins/jit/_src/util.py:100-143 with dim = head_dim / 2."""
+    dim = head_dim // 2
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+    pos = torch.arange(grid) / grid * grid
+    ang = (pos[:, None] * freqs[None]).repeat_interleave(2, dim=-1)  # (grid, dim)
+    full = torch.cat((ang[:, None, :].expand(grid, grid, dim), ang[None, :, :].expand(grid, grid, dim)), dim=-1)
+    full = full.reshape(grid * grid, head_dim)
+    cos, sin = full.cos(), full.sin()
+    if ctx > 0:
+        cos = torch.cat([torch.ones(ctx, head_dim), cos], dim=0)
+        sin = torch.cat([torch.zeros(ctx, head_dim), sin], dim=0)
+    return cos, sin
+
+
+def jit_rotate(t: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
+    r"""t cos + rotate_half(t) sin over adjacent pairs (x0, x1) -> (-x1, x0) -- util.py:32-36,145-146."""
+    pairs = t.unflatten(-1, (-1, 2))
+    rot = torch.stack((-pairs[..., 1], pairs[..., 0]), dim=-1).flatten(-2)
+    return t * cos + rot * sin
+
+
+def jit_pos_embed(hidden: int, grid: int) -> Tensor:
+    r"""Fixed 2-D sin-cos table (grid^2, hidden), fp64 -> fp32 -- plugins/jit/_src/util.py:166-212
+    (column coordinate feeds the first half: "here w goes first")."""
+    import numpy as np
+
+    def one_d(dim, pos):
+        omega = 1.0 / 10000 ** (np.arange(dim // 2, dtype=np.float64) / (dim / 2.0))
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+    gw, gh = np.meshgrid(np.arange(grid, dtype=np.float32), np.arange(grid, dtype=np.float32))
+    emb = np.concatenate([one_d(hidden // 2, gw), one_d(hidden // 2, gh)], axis=1)
+    return torch.from_numpy(emb).float()
+
+
+def jit_attention(sd, key: str, x: Tensor, heads: int, cos: Tensor, sin: Tensor) -> Tensor:
+    r"""Attention.forward -- plugins/jit/_src/model.py:121-147."""
+    B, N, C = x.shape
+    qkv = _linear(sd, key + ".qkv", x).reshape(B, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    q = jit_rotate(jit_rms_norm(q, sd[key + ".q_norm.weight"]), cos, sin)
+    k = jit_rotate(jit_rms_norm(k, sd[key + ".k_norm.weight"]), cos, sin)
+    y = F.scaled_dot_product_attention(q, k, v)
+    return _linear(sd, key + ".proj", y.transpose(1, 2).reshape(B, N, C))
+
+
+def jit_block(sd, key: str, x: Tensor, c: Tensor, heads: int, cos: Tensor, sin: Tensor) -> Tensor:
+    r"""JiTBlock.forward -- plugins/jit/_src/model.py:205-215; SwiGLUFFN :150-163."""
+    mod = _linear(sd, key + ".adaLN_modulation.1", F.silu(c)).chunk(6, dim=-1)
+    shift_a, scale_a, gate_a, shift_m, scale_m, gate_m = (m.unsqueeze(1) for m in mod)
+    h = jit_rms_norm(x, sd[key + ".norm1.weight"]) * (1 + scale_a) + shift_a
+    x = x + gate_a * jit_attention(sd, key + ".attn", h, heads, cos, sin)
+    h = jit_rms_norm(x, sd[key + ".norm2.weight"]) * (1 + scale_m) + shift_m
+    x1, x2 = _linear(sd, key + ".mlp.w12", h).chunk(2, dim=-1)
+    return x + gate_m * _linear(sd, key + ".mlp.w3", F.silu(x1) * x2)
+
+
+def jit_forward(sd, cfg: dict, x: Tensor, t: Tensor, y: Tensor, tap: dict | None = None) -> Tensor:
+    r"""JiT.forward -- plugins/jit/_src/model.py:346-381.  ``cfg``: {model, input_size} or explicit
+    {depth, hidden_size, num_heads, bottleneck_dim, in_context_len, in_context_start, patch_size, input_size}."""
+    if "model" in cfg:
+        depth, hidden, heads, _, ctx, start, p = JIT_ARCH[cfg["model"]]
+    else:
+        depth, hidden, heads, ctx, start, p = (cfg[k] for k in (
+            "depth", "hidden_size", "num_heads", "in_context_len", "in_context_start", "patch_size"))
+    grid = cfg.get("input_size", 256) // p
+    hd = hidden // heads
+    t_emb = jit_timestep_embedding(t, 256)
+    t_emb = _linear(sd, "t_embedder.mlp.2", F.silu(_linear(sd, "t_embedder.mlp.0", t_emb)))
+    y_emb = sd["y_embedder.embedding_table.weight"][y]
+    c = t_emb + y_emb
+    h = F.conv2d(x, sd["x_embedder.proj1.weight"], None, stride=p)
+    h = F.conv2d(h, sd["x_embedder.proj2.weight"], sd["x_embedder.proj2.bias"]).flatten(2).transpose(1, 2)
+    h = h + sd["pos_embed"]
+    rope_img = jit_rope_tables(hd, grid, 0)
+    rope_ctx = jit_rope_tables(hd, grid, ctx)
+    for i in range(depth):
+        if ctx > 0 and i == start:
+            tokens = y_emb.unsqueeze(1).repeat(1, ctx, 1) + sd["in_context_posemb"]
+            h = torch.cat([tokens, h], dim=1)
+        h = jit_block(sd, f"blocks.{i}", h, c, heads, *(rope_img if i < start else rope_ctx))
+        if tap is not None:
+            tap[f"block{i}"] = h
+    h = h[:, ctx:]
+    shift, scale = _linear(sd, "final_layer.adaLN_modulation.1", F.silu(c)).chunk(2, dim=1)
+    h = jit_rms_norm(h, sd["final_layer.norm_final.weight"]) * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
+    h = _linear(sd, "final_layer.linear", h)  # (B, grid^2, p p C) with feature order (p, q, c)
+    B, C = x.shape[0], x.shape[1]
+    h = h.reshape(B, grid, grid, p, p, C)
+    return torch.einsum("nhwpqc->nchpwq", h).reshape(B, C, grid * p, grid * p)

@@ -326,3 +326,22 @@ def sample_pc(mean_fn, x, schedule=vp_schedule, steps: int = 64, corrections: in
         mean = mean_fn(x_t, t, **kwargs)
         x_t = alpha_s * mean + sigma_s / sigma_t * (x_t - alpha_t * mean)
     return x_t
+
+
+# --------------------------------------------------------------------------- JiT plugin denoiser
+def rectified_schedule(t: Tensor, alpha_min: float = 1e-3, sigma_min: float = 1e-3):
+    r"""alpha_t = t alpha_min + (1 - t), sigma_t = t + (1 - t) sigma_min -- azula/noise.py:186-190."""
+    return t * alpha_min + (1 - t), t + (1 - t) * sigma_min
+
+
+def jit_mean(backbone, x_t: Tensor, t: Tensor, label: Tensor | None = None, num_classes: int = 1000,
+             schedule=rectified_schedule) -> Tensor:
+    r"""JITDenoiser.forward -- plugins/jit/__init__.py:60-102: c_in = 1 / (alpha + sigma),
+    c_time = alpha / (alpha + sigma), missing label = the extra "null" class."""
+    alpha_t, sigma_t = schedule(t)
+    alpha_t, sigma_t = _expand(alpha_t, x_t.ndim), _expand(sigma_t, x_t.ndim)
+    c_in = 1 / (alpha_t + sigma_t)
+    c_time = (alpha_t / (alpha_t + sigma_t)).flatten()
+    if label is None:
+        label = torch.as_tensor(num_classes)
+    return backbone(c_in * x_t, c_time, label.expand(x_t.shape[0])).to(x_t)

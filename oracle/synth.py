@@ -21,6 +21,8 @@ def synth_tensor(name: str, shape, gen: torch.Generator) -> torch.Tensor:
             return 0.5 * torch.randn(shape, generator=gen)
         if name.endswith("label_emb.weight"):
             return 0.5 * torch.randn(shape, generator=gen)
+        if name.endswith(("pos_embed", "in_context_posemb", "embedding_table.weight")):  # JiT tables: order one
+            return 0.5 * torch.randn(shape, generator=gen)
         return torch.randn(shape, generator=gen) / math.sqrt(fan_in)
     if name.endswith(".weight"):  # 1-D "weight" = normalisation gain
         return 1.0 + 0.1 * torch.randn(shape, generator=gen)

@@ -5,6 +5,8 @@ Covers the reference's CPU-runnable configuration (BASELINE.json configs[0]: Kar
 reference's own invariant test (tests/test_denoise.py:135-143) and the host coefficient tables.
 """
 
+import math
+
 import pytest
 import torch
 
@@ -12,7 +14,7 @@ from conftest import max_err
 from azula_amd.denoise import DiracPosterior, GaussianPosterior, KarrasDenoiser
 from azula_amd.noise import Schedule, VESchedule, VPSchedule
 from azula_amd.sample import DDIMSampler, DDPMSampler
-from oracle import synth
+from oracle import sampling, synth
 
 
 class ToyMLP(torch.nn.Module):
@@ -270,6 +272,67 @@ def test_multistep_weight_functions_keep_reference_names(golden):
         torch.testing.assert_close(c, g[f"{kind}_w3"][7, :3], rtol=2e-5, atol=1e-7)
     c = S.vABSampler._adams_bashforth(sigma / (alpha + sigma), i=1, n=4)  # n is clipped to i + 1
     torch.testing.assert_close(c, g["vAB_w4"][1, :2], rtol=2e-5, atol=1e-7)
+
+
+def test_schedules_and_simple_denoiser_host():
+    """the remaining closed-form schedules (azula/noise.py:132-231) and SimpleDenoiser
+    (azula/denoise.py:177-230) against the oracle formulas; fused coefficients are Karras with c_skip 0."""
+    from azula_amd.denoise import SimpleDenoiser
+    from azula_amd.noise import CosineSchedule, DecaySchedule, RectifiedSchedule
+
+    t = torch.linspace(0, 1, 17)
+    a, s = RectifiedSchedule(1e-2, 2e-3)(t)
+    oa, os_ = sampling.rectified_schedule(t, 1e-2, 2e-3)
+    assert torch.equal(a, oa) and torch.equal(s, os_)
+    a, s = CosineSchedule()(t)
+    assert torch.equal(a, torch.cos(math.acos(1e-3) * t)) and torch.equal(s, torch.sqrt(1 - a**2 + 1e-3**2))
+    a, s = DecaySchedule(gamma=0.3)(t)
+    tau = (1 - 0.3**t) / (1 - 0.3)
+    assert torch.equal(a, tau * 1e-3 + (1 - tau)) and torch.equal(s, tau + (1 - tau) * 1e-3)
+    assert a[0] == 1 and abs(float(a[-1]) - 1e-3) < 1e-6  # endpoints: clean at t = 0, alpha_min at t = 1
+
+    net = ToyMLP()
+    den = SimpleDenoiser(net, CosineSchedule()).eval()
+    x, tt = torch.randn(4, 5), torch.tensor(0.3)
+    al, sg = den.schedule(tt)
+    want = net(torch.rsqrt(al**2 + sg**2) * x, torch.log(sg / al))
+    assert torch.equal(den(x, tt).mean, want)
+    co = den.host_coefficients(al, sg)
+    assert float(co["c_skip"]) == 0 and float(co["c_out"]) == 1 and torch.equal(co["c_time"], torch.log(sg / al))
+
+
+def test_jit_plugin_host_side(golden):
+    """JiT plugin without a GPU: cards, state_dict compatibility with the reference's parameter shapes (G10),
+    JITDenoiser coefficients, and the loud failure of the backbone on CPU tensors."""
+    from azula_amd.plugins import jit
+    from azula_amd.plugins.jit.model import rotary_tables, sincos_table
+    from azula_amd.plugins.utils import load_cards
+    from oracle import nets
+
+    cards = load_cards(jit)
+    assert set(cards) == {f"jit_{s}_{p}" for s in ("0.1b", "0.5b", "1.0b") for p in (16, 32)}
+    assert cards["jit_0.5b_32"].config == {"model": "JiT-L/32"}
+    with pytest.raises(FileNotFoundError, match="does not download"):
+        jit.load_model("jit_0.1b_16")
+    with pytest.raises(NotImplementedError, match="head_dim"):
+        jit.make_model("JiT-H/16")
+
+    g = golden("g10_jit_ctx")
+    net = jit.JiT(**g.meta["cfg"])
+    shapes = {k: tuple(v) for k, v in g.meta["shapes"].items()}
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == shapes
+    net.load_state_dict(synth.synth_state_dict(shapes, g.meta["weight_seed"]))
+    den = jit.JITDenoiser(net, num_classes=g.meta["cfg"]["num_classes"])
+    al, sg = den.schedule(torch.tensor(0.25))
+    co = den.host_coefficients(al, sg)
+    assert torch.equal(co["c_in"], 1 / (al + sg)) and torch.equal(co["c_time"], al / (al + sg))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        den(g["x"], torch.tensor(0.4))
+    # build-time tables == the reference's buffers (restated in the oracle, pinned by make_golden)
+    assert torch.equal(sincos_table(64, 8), nets.jit_pos_embed(64, 8))
+    cos, sin = rotary_tables(16, 4, 8, 8)
+    ocos, osin = nets.jit_rope_tables(16, 8, 8)
+    assert torch.equal(cos[:, 2], ocos[:, 0::2]) and torch.equal(sin[:, 0], osin[:, 1::2])
 
 
 def test_layers_for_custom_backbones():

@@ -164,3 +164,24 @@ def test_g9_toy_multistep_loops(golden):
     # order-1 zAB is the Euler step and order-1 zEAB/xEAB the DDIM step: same ODE, same answer at fp32 level
     assert max_err(g["zAB_o1"], sampling.sample_euler(mean, g["x1"], steps=g.meta["steps"])) < 1e-4
     assert max_err(g["xEAB_o1"], sampling.sample(mean, g["x1"], steps=g.meta["steps"], eta=0.0)) < 1e-4
+
+
+def test_g10_jit(golden):
+    """JiT backbone, JITDenoiser (label / null class), DDIM and CFG loops on the rectified schedule."""
+    for name in ("jit_ctx", "jit_noctx_hd32"):
+        g = golden("g10_" + name)
+        cfg = g.meta["cfg"]
+        sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"])
+        bb = lambda a, c, l: nets.jit_forward(sd, cfg, a, c, l)  # noqa: E731
+        y = g["y"].long()
+        sc = g["out"].abs().max().item()
+        assert max_err(bb(g["x"], g["t"], y), g["out"]) < 2e-5 * sc, name
+        assert max_err(bb(g["x"], g["t"][:1], y), g["out_shared"]) < 2e-5 * sc, name
+        mean = lambda a, tt, label=None: sampling.jit_mean(bb, a, tt, label, cfg["num_classes"])  # noqa: E731
+        assert max_err(mean(g["x"], torch.tensor(0.4), y), g["mean_t04"]) < 2e-5 * sc
+        assert max_err(mean(g["x"], torch.tensor(0.7)), g["mean_null"]) < 2e-5 * sc
+        x0 = sampling.sample(mean, g["x1"], schedule=sampling.rectified_schedule, steps=8, eta=0.0, label=y)
+        assert max_err(x0, g["ddim8"]) < 1e-4 * max(1.0, g["ddim8"].abs().max().item()), name
+        cm = lambda a, tt: sampling.cfg_mean(mean, a, tt, {"label": y}, {}, g.meta["guidance"])  # noqa: E731
+        x0 = sampling.sample(cm, g["x1"], schedule=sampling.rectified_schedule, steps=6, eta=0.0)
+        assert max_err(x0, g["cfg_ddim6"]) < 2e-4 * max(1.0, g["cfg_ddim6"].abs().max().item()), name
