@@ -56,6 +56,11 @@ CONFIGS = {
         kind="adm", card="imagenet_256x256_cond", batch=4, shape=(3, 256, 256), steps=64, cfg=2.0,
         name="azula.plugins.adm imagenet_256x256_cond (random init) + CFGDenoiser(g=2), DDIMSampler(steps=64)",
     ),
+    # JiT-B/16 pixel-space transformer at 256x256 (131M params, 256 + 32 tokens), class labels
+    "c6": dict(
+        kind="jit", model="JiT-B/16", batch=32, shape=(3, 256, 256), steps=50, labels=True,
+        name="azula.plugins.jit JiT-B/16 3x256x256 (random init), JITDenoiser+RectifiedSchedule, DDIMSampler(steps=50)",
+    ),
     # small variant for quick functional checks of the harness
     "tiny": dict(
         kind="unet", batch=2, shape=(3, 64, 64), steps=8,
@@ -91,6 +96,12 @@ def build_denoiser(cfg, device):
         rerandomise_zero_tensors(den.backbone)
         den = den.to(device).eval()
         return CFGDenoiser(den) if cfg.get("cfg") else den
+    if cfg["kind"] == "jit":
+        from azula_amd.plugins import jit
+
+        den = jit.make_model(cfg["model"], input_size=cfg["shape"][-1])
+        rerandomise_zero_tensors(den.backbone)
+        return den.to(device).eval()
     net = UNet(**cfg["net"]) if cfg["kind"] == "unet" else ViT(**cfg["net"])
     wrapped = TimeModulated(net, cfg["net"]["mod_features"], name=cfg["kind"])
     return KarrasDenoiser(wrapped, VPSchedule()).to(device).eval()
@@ -265,6 +276,9 @@ def main() -> None:
     if cfg.get("cfg"):
         lab = torch.arange(B, device=device) % 1000
         kwargs = dict(positive={"label": lab}, negative={"label": torch.zeros_like(lab)}, guidance=cfg["cfg"])
+
+    if cfg.get("labels"):
+        kwargs = dict(label=torch.arange(B, device=device) % 1000)
 
     def one_pass():
         # 64 graph replays on this rank's shard, then the only collective: all-gather of x0

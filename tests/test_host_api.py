@@ -364,12 +364,13 @@ def test_layers_for_custom_backbones():
 @pytest.mark.parametrize("with_label", [False, True])
 @pytest.mark.parametrize("batch", [(), (64,)])
 def test_samplers_shapes_and_kwargs(with_label, batch):
-    """Mirror of the reference's tests/test_sample.py:57-92 for the samplers this build provides:
+    """Mirror of the reference's tests/test_sample.py:57-92, all 12 sampler configurations:
     init / output shapes, finiteness, and keyword arguments flowing untouched to the backbone."""
     from functools import partial
 
     from azula_amd.nn.layers import SineEncoding
-    from azula_amd.sample import EulerSampler, HeunSampler, ItoSampler
+    from azula_amd.sample import (EulerSampler, HeunSampler, ItoSampler, PCSampler, REABSampler, vABSampler, xEABSampler,
+                                  zABSampler, zEABSampler)
 
     class Dummy(torch.nn.Module):
         def __init__(self):
@@ -383,9 +384,30 @@ def test_samplers_shapes_and_kwargs(with_label, batch):
 
     den = KarrasDenoiser(Dummy(), VPSchedule())
     for S in (partial(DDPMSampler), partial(DDIMSampler, eta=0.0), partial(DDIMSampler, eta=1.0), partial(EulerSampler),
-              partial(HeunSampler), partial(ItoSampler, eta=1.0)):
+              partial(HeunSampler), partial(ItoSampler, eta=1.0), partial(zABSampler), partial(vABSampler),
+              partial(zEABSampler), partial(xEABSampler), partial(REABSampler), partial(PCSampler, corrections=1)):
         sampler = S(den, steps=64, silent=True)
         x1 = sampler.init((*batch, 5))
         assert x1.shape == (*batch, 5) and torch.isfinite(x1).all()
         x0 = sampler(x1, label="cat") if with_label else sampler(x1)
         assert x0.shape == (*batch, 5) and torch.isfinite(x0).all()
+
+
+@pytest.mark.parametrize("batch", [(), (64,)])
+def test_schedule_properties(batch):
+    """Mirror of the reference's tests/test_noise.py:11-43 for the five closed-form schedules: positive scales,
+    signal-to-noise ratio non-increasing in t, alpha_0 == 1."""
+    from azula_amd.noise import CosineSchedule, DecaySchedule, RectifiedSchedule
+
+    torch.manual_seed(0)
+    for S in (VPSchedule, VESchedule, CosineSchedule, RectifiedSchedule, DecaySchedule):
+        schedule = S()
+        assert isinstance(schedule, Schedule)
+        t = torch.rand(batch)
+        alpha_t, sigma_t = schedule(t)
+        assert alpha_t.shape == batch and sigma_t.shape == batch, S
+        assert (alpha_t > 0).all() and (sigma_t > 0).all(), S
+        s = torch.rand_like(t) * t
+        alpha_s, sigma_s = schedule(s)
+        assert (alpha_s / sigma_s >= alpha_t / sigma_t).all(), S
+        assert (schedule(torch.zeros(()))[0] == 1).all(), S
