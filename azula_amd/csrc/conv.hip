@@ -631,6 +631,330 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   }
 }
 
+// =================================================================================================
+// Winograd F(4x4, 3x3): 36 frequency GEMMs per 6x6 input patch / 4x4 output tile, i.e. 2.25 multiplies per
+// output instead of 9 (direct) or 4 (F(2x2,3x3)).  The transforms now contain the constants 2, 4, 5, 8 and
+// the filter transform 1/4 .. 1/24, so this form is NOT exact: its fp32 rounding error is ~20x that of the
+// F(2x2) kernel (still ~1e-5 of the output scale per layer).  It is an opt-in
+// (AZ_WINOGRAD=4) for that reason -- and because, as measured in round 1, it is not yet faster than the
+// F(2x2) kernel at the 256^2 level (both 203 TF/s algorithmic; +5 % at 128^2, +12 % at 64^2): with 18 MFMAs per
+// wave per stage the U/V staging (54 KB of loads, 72 KB of LDS writes, one barrier) is exposed.  Ablations
+// on 4x256x256x256->256: 1536 us; without the gather 1209, without the filter loads 1225, without either
+// 1076, without the two transform passes 1047, without the MFMAs 1192 (MFMA-bound time would be ~570).
+//
+// Block = 64 couts x 32 tiles (= 512 output pixels), K stage = 4 input channels, 8 waves.  Wave (c2, I, J)
+// owns the 3 x 3 frequency block xi in 3I..3I+2, nu in 3J..3J+2 of its 32-cout half as 9 accumulators
+// (144 VGPRs).  Per stage: U chunk 36 KB (plain copy of the pre-transformed filter) + V 18 KB.
+// The input transform is done by all threads in two 1-D passes through an LDS scratch so that no thread ever
+// holds a whole 6x6 patch:
+//   pass A (after the MFMAs of stage s):   thread (tile, patch row r, channel pair) has loaded its 6 pixels
+//       (issued one iteration earlier), applies B^T along the row and writes 6 values to the scratch;
+//   pass B (before the MFMAs of stage s+1): thread (tile, nu, channel pair) reads the 6 rows of column nu,
+//       applies B^T down the column and writes the 6 frequencies (xi, nu) into the V stage buffer.
+// LDS: 2 x (36 + 18) KB stages + 2 x 18 KB scratch = 144 KB -> one workgroup per CU.
+constexpr int W4T = 32;                  // tiles per workgroup
+constexpr int W4C = 64;                  // couts per workgroup
+constexpr int W4K = 4;                   // input channels per stage
+constexpr int W4U_F = W4C * W4K;         // floats per frequency, U
+constexpr int W4V_F = W4T * W4K + 8;     // floats per frequency, V (+8: spreads pass-B writes over the banks)
+constexpr int W4U_STAGE = 36 * W4U_F;    // 9216 floats
+constexpr int W4V_STAGE = 36 * W4V_F;    // 4896 floats
+constexpr int W4_STAGE = W4U_STAGE + W4V_STAGE;
+constexpr int W4_SCRATCH = W4T * 6 * 2 * 6 * 2;  // 4608 floats: [tile][nu][pair][row] f32x2
+constexpr int W4_LDS = 2 * W4_STAGE + 2 * W4_SCRATCH;  // 37440 floats = 146.25 KB
+
+struct Wino4P {
+  AzConvArgs a;
+  int npix;
+  int tiles_h, tiles_w, ntiles;
+  int nkc0, nk;   // 4-channel chunks of source 0, total
+  int kps;        // chunks per split
+  int cblocks;
+  int tblocks;
+};
+
+// 1-D input transform B^T d, points (0, 1, -1, 2, -2, inf).
+template <class T>
+__device__ __forceinline__ void wino4_bt(const T* d, T* o) {
+  const T p = d[4] - 4.f * d[2];
+  const T q = d[3] - 4.f * d[1];
+  const T r = d[4] - d[2];
+  const T s = d[3] - d[1];
+  o[0] = 4.f * (d[0] - d[2]) + r;
+  o[1] = p + q;
+  o[2] = p - q;
+  o[3] = r + 2.f * s;
+  o[4] = r - 2.f * s;
+  o[5] = (d[5] - d[3]) - 4.f * s;
+}
+
+// Partial 1-D output transform: contribution of m[3J .. 3J+2] to A^T m,
+// A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].
+__device__ __forceinline__ void wino4_at_part(int J, float m0, float m1, float m2, float* y) {
+  if (J == 0) {  // columns 0, 1, 2
+    const float s = m1 + m2, d = m1 - m2;
+    y[0] = m0 + s;
+    y[1] = d;
+    y[2] = s;
+    y[3] = d;
+  } else {  // columns 3, 4, 5
+    const float s = m0 + m1, d = m0 - m1;
+    y[0] = s;
+    y[1] = 2.f * d;
+    y[2] = 4.f * s;
+    y[3] = 8.f * d + m2;
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void conv_winograd4_kernel(Wino4P p) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  const AzConvArgs& a = p.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int c2 = wave & 1;          // 32-cout half
+  const int gI = (wave >> 1) & 1;   // xi block
+  const int gJ = wave >> 2;         // nu block
+  const int l31 = lane & 31;
+  const int h = lane >> 5;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  const int tb = wg / p.cblocks;
+  const int cb = wg - tb * p.cblocks;
+  const int t0 = tb * W4T;
+  const int tiles_img = p.tiles_h * p.tiles_w;
+  const int b_first = t0 / tiles_img;
+
+  const int kt_begin = blockIdx.y * p.kps;
+  const int kt_end = min(p.nk, kt_begin + p.kps);
+  const int nst = kt_end - kt_begin;
+
+  const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
+  const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : e * 4); };
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.weight, 0, clamp_bytes((int64_t)p.nk * p.cblocks * W4U_STAGE), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src0 + b_first * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src1 ? a.src1 + b_first * s1_elems : a.src0), 0,
+      a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u, 0x00020000);
+
+  // ---- pass A role: thread -> (tile, patch row, channel pair); 384 of the 512 threads
+  const bool arole = tid < 384;
+  const int a_tile = tid / 12;
+  const int a_row = (tid - a_tile * 12) >> 1;
+  const int a_q = tid & 1;
+  int v_b = -1, v_ih = 0, v_iw0 = 0;
+  if (arole) {
+    const int t = t0 + a_tile;
+    if (t < p.ntiles) {
+      const int b = t / tiles_img;
+      const int r = t - b * tiles_img;
+      const int th = r / p.tiles_w;
+      v_b = b - b_first;
+      v_ih = 4 * th - 1 + a_row;
+      v_iw0 = 4 * (r - th * p.tiles_w) - 1;
+    }
+  }
+  unsigned voffV[6];
+  int cur_src = -1;
+  auto set_src = [&](int src) {
+    cur_src = src;
+    const int cs = src ? a.c1s : a.c0s;
+    const int up = src ? a.up1 : a.up0;
+    const int hs = src ? a.h1 : a.h0;
+    const int ws = src ? a.w1 : a.w0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int iw = v_iw0 + c;
+      const bool ok = v_b >= 0 && (unsigned)v_ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
+      const int pix = (v_b * hs + (v_ih >> up)) * ws + (iw >> up);
+      voffV[c] = ok ? (unsigned)((pix * cs + a_q * 2) * 4) : OOB;
+    }
+  };
+
+  f32x2 rawv[6];   // pass A: this thread's 6 pixels of one patch row (channel pair)
+  float4 rawu[5];  // filter chunk: float4 #(tid + 512 j)
+
+  auto load_v = [&](int kt) {  // kt wave-uniform
+    if (!arole) return;
+    const bool src1 = kt >= p.nkc0;
+    if ((src1 ? 1 : 0) != cur_src) set_src(src1 ? 1 : 0);
+    const unsigned soff = (unsigned)((src1 ? kt - p.nkc0 : kt) * W4K * 4);
+    if (src1) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) rawv[c] = buf_ld2(rs1, voffV[c], soff);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) rawv[c] = buf_ld2(rs0, voffV[c], soff);
+    }
+  };
+  auto load_u = [&](int kt) {
+    const unsigned soff = (unsigned)(((int64_t)kt * p.cblocks + cb) * (W4U_STAGE * 4));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rawu[j] = buf_ld4(rw, (unsigned)((tid + 512 * j) * 16), soff);
+    rawu[4] = buf_ld4(rw, tid < 256 ? (unsigned)((tid + 2048) * 16) : OOB, soff);
+  };
+  auto store_u = [&](int buf) {
+    float* Us = wsm + buf * W4_STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(Us + (tid + 512 * j) * 4) = rawu[j];
+    if (tid < 256) *reinterpret_cast<float4*>(Us + (tid + 2048) * 4) = rawu[4];
+  };
+  // scratch slot of (tile, nu, pair) = 12 floats at 12 * (12 tile + 2 nu + pair); row r at + 2 r
+  auto pass_a = [&](int sb) {
+    if (!arole) return;
+    float* S = wsm + 2 * W4_STAGE + sb * W4_SCRATCH;
+    f32x2 o[6];
+    wino4_bt<f32x2>(rawv, o);
+    const int base = (12 * a_tile + a_q) * 12 + 2 * a_row;
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x2*>(S + base + nu * 24) = o[nu];
+  };
+  auto pass_b = [&](int sb, int buf) {
+    if (!arole) return;
+    const float* S = wsm + 2 * W4_STAGE + sb * W4_SCRATCH + tid * 12;  // thread = (tile, nu, pair) = same split
+    float* Vs = wsm + buf * W4_STAGE + W4U_STAGE;
+    const float4 x0 = *reinterpret_cast<const float4*>(S);
+    const float4 x1 = *reinterpret_cast<const float4*>(S + 4);
+    const float4 x2 = *reinterpret_cast<const float4*>(S + 8);
+    const f32x2 d[6] = {{x0.x, x0.y}, {x0.z, x0.w}, {x1.x, x1.y}, {x1.z, x1.w}, {x2.x, x2.y}, {x2.z, x2.w}};
+    f32x2 o[6];
+    wino4_bt<f32x2>(d, o);
+    const int nu = a_row;  // (tid % 12) >> 1 names nu in this pass
+    const int base = nu * W4V_F + a_tile * W4K + 2 * a_q;
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) *reinterpret_cast<f32x2*>(Vs + xi * 6 * W4V_F + base) = o[xi];
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int f = 0; f < 9; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+  // ---- prologue: stage 0 fully staged, stage 1's patch rows in registers
+  if (nst > 0) {
+    load_v(kt_begin);
+    load_u(kt_begin);
+    pass_a(0);
+    store_u(0);
+    if (nst > 1) load_v(kt_begin + 1);
+  }
+  __syncthreads();
+  if (nst > 0) pass_b(0, 0);
+  if (nst > 1) pass_a(1);
+  __syncthreads();
+  if (nst > 2) load_v(kt_begin + 2);
+
+  // fragment rows: U row = c2*32 + l31, V row = l31; lane half h holds k = 2h, 2h+1
+  const int f0 = (3 * gI) * 6 + 3 * gJ;
+  const int fragA = f0 * W4U_F + (c2 * 32 + l31) * W4K + 2 * h;
+  const int fragB = f0 * W4V_F + l31 * W4K + 2 * h;
+  for (int s = 0; s < nst; ++s) {
+    const int buf = s & 1;
+    // invariant here: stage s complete in buffers `buf`; scratch[(s+1)&1] holds pass-A rows of stage s+1;
+    // rawv holds the patch rows of stage s+2
+    if (s + 1 < nst) {
+      load_u(kt_begin + s + 1);
+      pass_b((s + 1) & 1, buf ^ 1);  // V buffer buf^1 was last read in iteration s-1
+    }
+    const float* Us = wsm + buf * W4_STAGE;
+    const float* Vs = Us + W4U_STAGE;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      f32x2 fa[3], fb[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        fa[j] = *reinterpret_cast<const f32x2*>(Us + (i * 6 + j) * W4U_F + fragA);
+        fb[j] = *reinterpret_cast<const f32x2*>(Vs + (i * 6 + j) * W4V_F + fragB);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        acc[i * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].x, fb[j].x, acc[i * 3 + j], 0, 0, 0);
+        acc[i * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].y, fb[j].y, acc[i * 3 + j], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nst) store_u(buf ^ 1);
+    if (s + 2 < nst) pass_a(s & 1);  // scratch[s&1] (stage s's rows) was consumed by pass B in iteration s-1
+    __syncthreads();
+    if (s + 3 < nst) load_v(kt_begin + s + 3);
+  }
+
+  // ---- output transform + exchange.  Wave (c2, I, J) reduces its 3x3 frequency block to a partial 4x4
+  // output; for each register group g the waves of frequency block g collect the other three partials
+  // through LDS and run the fused epilogue, so all eight waves share the stores.
+  // Lane: tile = l31; couts c2*32 + 8g + 4h + (0..3) in accumulator registers 4g .. 4g+3.
+  const int grp = gI + 2 * gJ;
+  float* xch = wsm;  // [c2][frequency block 0..3][64 values][64 lanes] floats = 128 KB (stage buffers are dead)
+  const int t = t0 + l31;
+  const bool tvalid = t < p.ntiles;
+  const int tt = tvalid ? t : 0;
+  const int ob = tt / tiles_img;
+  const int orr = tt - ob * tiles_img;
+  const int oth = orr / p.tiles_w;
+  const int otw = orr - oth * p.tiles_w;
+#pragma unroll 1
+  for (int g = 0; g < 4; ++g) {  // rolled: each pass consumes registers 0..3, then the accumulators rotate by 4
+    float y[16][4];  // [i*4 + j][r]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float z[3][4];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        wino4_at_part(gJ, acc[i * 3 + 0][r], acc[i * 3 + 1][r], acc[i * 3 + 2][r], z[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float col[4];
+        wino4_at_part(gI, z[0][j], z[1][j], z[2][j], col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i * 4 + j][r] = col[i];
+      }
+    }
+    {  // every wave parks its partial in LDS (slot = its frequency block); the leader's rolled pixel loop
+       // then needs no register indexing and keeps one pixel's epilogue live at a time
+      float* dstx = xch + ((c2 * 4 + grp) * 64) * 64 + lane;
+#pragma unroll
+      for (int v = 0; v < 16; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dstx[(v * 4 + r) * 64] = y[v][r];
+    }
+    __syncthreads();
+    if (grp == g && tvalid) {
+      const int co = cb * W4C + c2 * 32 + 8 * g + 4 * h;
+      if (co < a.cout_s) {
+        const float* srcx = xch + (c2 * 4 * 64) * 64 + lane;
+#pragma unroll 1
+        for (int v = 0; v < 16; ++v) {
+          const int oh = 4 * oth + (v >> 2), ow = 4 * otw + (v & 3);
+          if (oh >= a.hout || ow >= a.wout) continue;
+          float o4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float* q = srcx + (v * 4 + r) * 64;
+            o4[r] = ((q[0] + q[64 * 64]) + q[2 * 64 * 64]) + q[3 * 64 * 64];
+          }
+          const int n = (ob * a.hout + oh) * a.wout + ow;
+          const float4 vv = make_float4(o4[0], o4[1], o4[2], o4[3]);
+          if (a.splitk > 1)
+            *reinterpret_cast<float4*>(a.workspace + ((int64_t)blockIdx.y * p.npix + n) * a.cout_s + co) = vv;
+          else
+            epilogue_store(a, n, co, vv);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 9; ++f)
+      acc[f] = __builtin_shufflevector(acc[f], acc[f], 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -786,6 +1110,86 @@ int az_conv2d_winograd_suggest_splitk(int64_t batch, int32_t hout, int32_t wout,
   const int64_t nk = (cin_s + WK - 1) / WK;
   int64_t want = (256 + blocks - 1) / blocks;
   int64_t maxs = nk / 16;
+  if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want > 16) want = 16;
+  if (blocks >= 192) want = 1;
+  return (int)(want < 1 ? 1 : want);
+}
+
+/* Winograd F(4x4,3x3) path (opt-in, see the kernel's header comment): same AzConvArgs, `weight` packed by
+ * az_winograd4_pack_filter_f32.  Only ksize = 3, stride = 1, pad = 1. */
+int az_conv2d_winograd4_f32(const AzConvArgs* a, az_stream_t stream) {
+  AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
+  AZ_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1, AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
+  AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
+  AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
+  AZ_REQUIRE(((a->hin + a->up0) >> a->up0) <= a->h0 && ((a->win + a->up0) >> a->up0) <= a->w0, AZ_E_SHAPE);
+  if (a->src1)
+    AZ_REQUIRE(((a->hin + a->up1) >> a->up1) <= a->h1 && ((a->win + a->up1) >> a->up1) <= a->w1, AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(a->src0) && AZ_ALIGNED16(a->src1) && AZ_ALIGNED16(a->weight) && AZ_ALIGNED16(a->bias) &&
+                 AZ_ALIGNED16(a->gate) && AZ_ALIGNED16(a->res) && AZ_ALIGNED16(a->workspace),
+             AZ_E_ALIGN);
+  if (!a->dst_nchw) AZ_REQUIRE(AZ_ALIGNED16(a->dst), AZ_E_ALIGN);
+  if (a->dst_nchw) AZ_REQUIRE(a->dst_c > 0 && a->dst_c <= a->cout_s, AZ_E_SHAPE);
+  if (a->gate) AZ_REQUIRE(a->gate_bstride % 4 == 0, AZ_E_ALIGN);
+  if (a->res && a->res_up) AZ_REQUIRE(((a->hout + 1) >> 1) <= a->hres && ((a->wout + 1) >> 1) <= a->wres, AZ_E_SHAPE);
+  AZ_REQUIRE(a->splitk >= 1 && (a->splitk == 1 || a->workspace), AZ_E_SHAPE);
+  const int64_t npix64 = (int64_t)a->batch * a->hout * a->wout;
+  AZ_REQUIRE(npix64 < (1ll << 31), AZ_E_SHAPE);
+
+  Wino4P p;
+  p.a = *a;
+  p.npix = (int)npix64;
+  p.tiles_h = (a->hout + 3) / 4;
+  p.tiles_w = (a->wout + 3) / 4;
+  p.ntiles = a->batch * p.tiles_h * p.tiles_w;
+  p.nkc0 = a->c0s / W4K;
+  p.nk = p.nkc0 + a->c1s / W4K;
+  {
+    const int64_t tiles_img = (int64_t)p.tiles_h * p.tiles_w;
+    const int64_t span = (W4T + tiles_img - 1) / tiles_img + 1;
+    AZ_REQUIRE(span * a->h0 * a->w0 * a->c0s * 4 < (1ll << 31), AZ_E_SHAPE);
+    AZ_REQUIRE(span * a->h1 * a->w1 * a->c1s * 4 < (1ll << 31), AZ_E_SHAPE);
+  }
+  int splitk = a->splitk;
+  if (splitk > p.nk) splitk = p.nk;
+  p.kps = (p.nk + splitk - 1) / splitk;
+  splitk = (p.nk + p.kps - 1) / p.kps;
+  p.a.splitk = splitk;
+  p.cblocks = (a->cout_s + W4C - 1) / W4C;
+  p.tblocks = (p.ntiles + W4T - 1) / W4T;
+  AZ_REQUIRE((int64_t)p.nk * p.cblocks * W4U_STAGE * 4 < (1ll << 32), AZ_E_SHAPE);
+  const int64_t nwg = (int64_t)p.cblocks * p.tblocks;
+  hipStream_t st = az_s(stream);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_winograd4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       W4_LDS * 4);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_winograd4_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), W4_LDS * 4, st, p);
+  int rc = az_launch_status();
+  if (rc != AZ_OK) return rc;
+  if (splitk > 1) {
+    ConvP cp;
+    cp.a = p.a;
+    cp.npix = p.npix;
+    const int grid = az_stream_grid((int64_t)p.npix * (a->cout_s / 4), 256);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, cp);
+    rc = az_launch_status();
+  }
+  return rc;
+}
+
+int az_conv2d_winograd4_suggest_splitk(int64_t batch, int32_t hout, int32_t wout, int32_t cout_s, int32_t cin_s) {
+  const int64_t tiles = batch * ((hout + 3) / 4) * ((wout + 3) / 4);
+  const int64_t blocks = ((tiles + W4T - 1) / W4T) * ((cout_s + W4C - 1) / W4C);
+  const int64_t nk = cin_s / W4K;
+  int64_t want = (256 + blocks - 1) / blocks;
+  int64_t maxs = nk / 32;
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
   if (want > 16) want = 16;

@@ -104,6 +104,47 @@ __global__ __launch_bounds__(256) void winograd_filter_kernel(float* __restrict_
   }
 }
 
+// Winograd F(4x4,3x3) filter transform U = G g G^T (6x6 per filter, interpolation points 0, +-1, +-2, inf;
+// fp64 accumulate, rounded once) in the layout conv_winograd4_kernel streams:
+// [4-cin chunk][64-cout block][36][64][4].
+__global__ __launch_bounds__(256) void winograd4_filter_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                               int cout, int cin, int cin0, int c0s, int nk,
+                                                               int cblocks) {
+  const double G[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                          {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  const int64_t total = (int64_t)nk * cblocks * 36 * 64 * 4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e & 3);
+    const int col = (int)((e >> 2) & 63);
+    const int64_t r0 = e >> 8;
+    const int f = (int)(r0 % 36);
+    const int64_t r = r0 / 36;
+    const int cbk = (int)(r % cblocks);
+    const int kt = (int)(r / cblocks);
+    const int co = cbk * 64 + col;
+    const int pc = kt * 4 + k;  // position in the [source 0 | source 1] channel concatenation
+    int ci = -1;
+    if (pc < c0s) {
+      if (pc < cin0) ci = pc;
+    } else if (pc - c0s < cin - cin0) {
+      ci = cin0 + pc - c0s;
+    }
+    float v = 0.f;
+    if (co < cout && ci >= 0) {
+      const float* g = src + ((int64_t)co * cin + ci) * 9;
+      const int xi = f / 6, nu = f - xi * 6;
+      double acc = 0.0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc += G[xi][a] * (double)g[a * 3 + b] * G[nu][b];
+      v = (float)acc;
+    }
+    dst[e] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -148,6 +189,18 @@ int az_winograd_pack_filter_f32(float* dst, const float* src, int32_t cout, int3
   const int64_t total = (int64_t)nk * cblocks * 16 * 64 * 8;
   hipLaunchKernelGGL(winograd_filter_kernel, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream), dst, src,
                      cout, cin, cin0, nk0, nk, cblocks);
+  return az_launch_status();
+}
+
+int az_winograd4_pack_filter_f32(float* dst, const float* src, int32_t cout, int32_t cin, int32_t cin0, int32_t c0s,
+                                 int32_t nk, int32_t cblocks, az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(cout > 0 && cin > 0 && cin0 >= 0 && cin0 <= cin && c0s >= cin0 && c0s % 4 == 0 &&
+                 nk * 4 >= c0s + (cin - cin0) && cblocks * 64 >= cout,
+             AZ_E_SHAPE);
+  const int64_t total = (int64_t)nk * cblocks * 36 * 64 * 4;
+  hipLaunchKernelGGL(winograd4_filter_kernel, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream), dst, src,
+                     cout, cin, cin0, c0s, nk, cblocks);
   return az_launch_status();
 }
 

@@ -121,9 +121,11 @@ class Act:
         return self.buf.data_ptr()
 
 
-# F(2x2,3x3) for stride-1 3x3 convs (see conv.hip): "1" = where it pays (default), "0" = never,
-# "2" = wherever it is legal (used by the parity tests to push whole networks through it)
+# Winograd for stride-1 3x3 convs (see conv.hip): "1" = exact F(2x2,3x3) where it pays (default), "0" = never,
+# "2" = F(2x2) wherever it is legal (used by the parity tests to push whole networks through it),
+# "4" = the faster but inexact F(4x4,3x3) on layers with >= WINOGRAD4_MIN_TILES tiles, "1" elsewhere
 WINOGRAD = os.environ.get("AZ_WINOGRAD", "1")
+WINOGRAD4_MIN_TILES = int(os.environ.get("AZ_WINOGRAD4_MIN_TILES", "1024"))
 
 
 class ConvWeights:
@@ -146,7 +148,7 @@ class ConvWeights:
         if bias is not None:
             self.bias = torch.zeros(self.cout_s, dtype=torch.float32, device=bld.device)
             self.bias[: self.cout] = bias.detach().to(device=bld.device, dtype=torch.float32)
-        self._direct = self._wino = None
+        self._direct = self._wino = self._wino4 = None
 
     def direct(self) -> torch.Tensor:
         r"""[tap][cout_s][cin_s] (K contiguous), zero padded (az_pack_conv_weight_f32)."""
@@ -173,6 +175,21 @@ class ConvWeights:
             )
             self._wino = packed
         return self._wino
+
+
+    def winograd4(self) -> torch.Tensor:
+        r"""F(4x4,3x3) filter transform (az_winograd4_pack_filter_f32) laid out
+        [4-channel chunk][64-cout block][36 frequencies][64][4]."""
+        if self._wino4 is None:
+            nk = (self.c0s + self.c1s) // 4
+            cb = (self.cout_s + 63) // 64
+            packed = torch.empty(nk * cb * 36 * 64 * 4, dtype=torch.float32, device=self.device)
+            _lib.call(
+                "az_winograd4_pack_filter_f32", packed.data_ptr(), self.w.data_ptr(), self.cout, self.cin, self.cin0,
+                self.c0s, nk, cb, _lib.stream_ptr(),
+            )
+            self._wino4 = packed
+        return self._wino4
 
 
 class Builder:
@@ -233,7 +250,7 @@ class Builder:
         res: Act | None = None,
         res_up: int = 0,
         dst_nchw: torch.Tensor | None = None,
-        winograd: bool | None = None,
+        winograd: bool | int | None = None,
     ) -> Act | None:
         ks, bias = packed.ks, packed.bias
         pad = ks // 2
@@ -273,14 +290,20 @@ class Builder:
         npix = B * hout * wout
         cin_s = a.c0s + a.c1s
         lib = _lib.lib()
-        use_wino = (WINOGRAD != "0") if winograd is None else winograd
-        use_wino = use_wino and ks == 3 and stride == 1
+        legal = ks == 3 and stride == 1
+        tiles4 = B * ((hout + 3) // 4) * ((wout + 3) // 4)
+        use_f4 = legal and (winograd == 4 or (winograd is None and WINOGRAD == "4" and tiles4 >= WINOGRAD4_MIN_TILES))
+        use_wino = legal and not use_f4 and ((WINOGRAD != "0") if winograd is None else bool(winograd))
         if use_wino:
             tiles = B * ((hout + 1) // 2) * ((wout + 1) // 2)
             a.splitk = lib.az_conv2d_winograd_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
-            if winograd is None and WINOGRAD == "1" and tiles < 256:
+            if winograd is None and WINOGRAD in ("1", "4") and tiles < 256:
                 use_wino = False  # < 4 tile blocks (8x8 at batch 4): the direct kernel's split-K is faster
-        if use_wino:
+        if use_f4:
+            a.weight = packed.winograd4().data_ptr()
+            a.splitk = lib.az_conv2d_winograd4_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
+            name = "az_conv2d_winograd4_f32"
+        elif use_wino:
             a.weight = packed.winograd().data_ptr()
             name = "az_conv2d_winograd_f32"
         else:

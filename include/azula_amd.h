@@ -249,6 +249,12 @@ int az_conv2d_f32(const AzConvArgs* args, az_stream_t stream);
  * (azula_amd/engine.py: Builder.pack_winograd); all other fields as az_conv2d_f32.             */
 int az_conv2d_winograd_f32(const AzConvArgs* args, az_stream_t stream);
 int az_conv2d_winograd_suggest_splitk(int64_t batch, int32_t hout, int32_t wout, int32_t cout_s, int32_t cin_s);
+/* Winograd F(4x4,3x3) form (6x6 patches, 36 frequency GEMMs: 2.25 multiplies per output instead of 4 / 9).
+ * NOT exact: the transforms multiply by 2, 4, 5, 8 and the filter transform by 1/4 .. 1/24, so the fp32
+ * rounding error is ~20x that of the F(2x2) kernel (~1e-5 of the output scale per layer).  Opt-in
+ * (AZ_WINOGRAD=4).  `weight` = az_winograd4_pack_filter_f32 output; other fields as az_conv2d_f32.  */
+int az_conv2d_winograd4_f32(const AzConvArgs* args, az_stream_t stream);
+int az_conv2d_winograd4_suggest_splitk(int64_t batch, int32_t hout, int32_t wout, int32_t cout_s, int32_t cin_s);
 /* Suggested split-K factor for a conv shape on this device (pure function of the shape).     */
 int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_t ksize);
 /* torch layout (cout, cin, ks, ks) -> packed [ks*ks][cout_s][cin_s] with zero padding; the
@@ -322,6 +328,11 @@ int az_unpatchify_f32(float* dst, const float* src, int64_t B, int64_t Z, int64_
  * channels [0, cin0) fill chunks [0, nk0), the rest start at chunk nk0 (two-source concat).      */
 int az_winograd_pack_filter_f32(float* dst, const float* src, int32_t cout, int32_t cin, int32_t cin0, int32_t nk0,
                                 int32_t nk, int32_t cblocks, az_stream_t stream);
+
+/* Same for F(4x4,3x3) (points 0, +-1, +-2, inf): [nk chunks of 4 cin][cblocks of 64 cout][36][64][4]; packed
+ * channel position pc maps to input channel pc (pc < cin0) or cin0 + pc - c0s (pc >= c0s).        */
+int az_winograd4_pack_filter_f32(float* dst, const float* src, int32_t cout, int32_t cin, int32_t cin0, int32_t c0s,
+                                 int32_t nk, int32_t cblocks, az_stream_t stream);
 
 /* ------------------------------------------------------------------ hipGraph helpers (host side)
  * Capture everything enqueued on `stream` between begin/end into an executable graph.         */

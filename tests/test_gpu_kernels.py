@@ -323,16 +323,21 @@ CONV_CASES = [
 ]
 
 
-def conv_tol(cin, ks):
-    return 3e-6 * math.sqrt(cin * ks * ks) + 1e-5
+def conv_tol(cin, ks, wino=False):
+    """Direct: exact fp32 fmaf chains.  F(2x2,3x3) only adds/subtracts (3x).  F(4x4,3x3) multiplies by up to 8
+    and its filter transform by 1/24: ~20x the rounding error of F(2x2) (stated in include/azula_amd.h)."""
+    return (3e-6 * math.sqrt(cin * ks * ks) + 1e-5) * {False: 1, True: 3, 4: 40}[wino]
+
+
+WINO_NAME = {False: "az_conv2d_f32", True: "az_conv2d_winograd_f32", 4: "az_conv2d_winograd4_f32"}
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ks,stride", CONV_CASES)
 @pytest.mark.parametrize("splitk", [0, 3])
-@pytest.mark.parametrize("wino", [False, True])
+@pytest.mark.parametrize("wino", [False, True, 4])
 def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk, wino):
     if wino and (ks != 3 or stride != 1):
-        pytest.skip("Winograd F(2x2,3x3) is the stride-1 3x3 path")
+        pytest.skip("Winograd is the stride-1 3x3 path")
     from azula_amd.engine import Act, Builder
 
     g = torch.Generator().manual_seed(Cin * Cout + H)
@@ -343,7 +348,7 @@ def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk, wino):
     bld = Builder(torch.device("cuda"))
     xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, (Cin + 3) // 4 * 4, True)
     y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, stride=stride, winograd=wino)
-    assert bld.tape.ops[-1][2] == ("az_conv2d_winograd_f32" if wino else "az_conv2d_f32")
+    assert bld.tape.ops[-1][2] == WINO_NAME[wino]
     if splitk:
         a = bld.tape.keep[-1]
         a.splitk = splitk
@@ -353,11 +358,11 @@ def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk, wino):
     bld.tape.run()
     out = from_nhwc(y.buf.reshape(B, y.H, y.W, y.cs), Cout)
     assert out.shape == ref.shape
-    assert max_err(out, ref) < conv_tol(Cin, ks) * (3 if wino else 1), max_err(out, ref)
+    assert max_err(out, ref) < conv_tol(Cin, ks, wino), max_err(out, ref)
     assert (y.buf.reshape(B, y.H, y.W, y.cs)[..., Cout:] == 0).all()
 
 
-@pytest.mark.parametrize("wino", [False, True])
+@pytest.mark.parametrize("wino", [False, True, 4])
 def test_conv2d_concat_upsample_narrow_gate_res(az, wino):
     """cat((y, upsample(x)[narrowed])) -> conv -> x0 + c * silu-free epilogue, as azula/nn/unet.py:253-257,93."""
     from azula_amd.engine import Act, Builder
@@ -380,10 +385,10 @@ def test_conv2d_concat_upsample_narrow_gate_res(az, wino):
                    gate=dev(gate), gate_bstride=Cout, res=ra, winograd=wino)
     bld.finish()
     bld.tape.run()
-    assert max_err(from_nhwc(out.buf.reshape(B, H, W, 12), Cout), ref) < conv_tol(Cy + Cx, 3) * (3 if wino else 1)
+    assert max_err(from_nhwc(out.buf.reshape(B, H, W, 12), Cout), ref) < conv_tol(Cy + Cx, 3, wino)
 
 
-@pytest.mark.parametrize("wino", [False, True])
+@pytest.mark.parametrize("wino", [False, True, 4])
 def test_conv2d_nchw_output_and_res_up(az, wino):
     from azula_amd.engine import Act, Builder
 
@@ -402,7 +407,7 @@ def test_conv2d_nchw_output_and_res_up(az, wino):
     up = bld.conv(xa, bld.pack_conv(dev(w2), None), Cin, up0=1, res=xa, res_up=1, winograd=wino)
     bld.finish()
     bld.tape.run()
-    tol = conv_tol(Cin, 3) * (3 if wino else 1)
+    tol = conv_tol(Cin, 3, wino)
     assert max_err(dst, F.conv2d(x, w, b, padding=1)) < tol
     xu = F.interpolate(x, scale_factor=2, mode="nearest")
     assert max_err(from_nhwc(up.buf.reshape(B, 2 * H, 2 * W, 16), Cin), xu + F.conv2d(xu, w2, None, padding=1)) < tol
