@@ -182,6 +182,7 @@ PROTOTYPES: dict[str, list] = {
     "az_transition_f32": [C.POINTER(AzTransitionArgs), c_stream],
     "az_multistep_f32": [C.POINTER(AzMultistepArgs), c_stream],
     "az_scale_f32": [vp, vp, vp, i64, c_stream],
+    "az_silu_f32": [vp, vp, i64, c_stream],
     "az_axpby_f32": [vp, vp, vp, vp, vp, i64, i64, i32, c_stream],
     "az_cfg_combine_f32": [vp, vp, vp, vp, i64, c_stream],
     "az_nchw_to_nhwc_f32": [vp, vp, vp, i64, i64, i64, i64, c_stream],

@@ -970,7 +970,19 @@ int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_
   if (want > maxs) want = maxs;
   if (want > 32) want = 32;
   if (want < 1) want = 1;
-  if (tiles >= 384) want = 1;
+  if (tiles >= 384) {
+    // Enough tiles to fill the chip; split only to repair wave quantisation.  512 resident blocks: e.g. 768
+    // tiles run as 2 rounds at 75 % occupancy, 2 x 768 = 1536 as exactly 3.  Worth the slab traffic only for
+    // deep K (>= 48 K-tiles: the token GEMMs 3072 -> 768 of DiT-B, 2048 -> 768 of JiT-B).
+    want = 1;
+    if (nk >= 48 && tiles < 4096) {
+      auto eff = [&](int64_t s) {
+        const int64_t blocks = tiles * s;
+        return (double)blocks / (double)(((blocks + 511) / 512) * 512);
+      };
+      if (eff(2) >= eff(1) + 0.15) want = 2;
+    }
+  }
   return (int)want;
 }
 

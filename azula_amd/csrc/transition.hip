@@ -293,6 +293,11 @@ void launch_multistep(const AzMultistepArgs* a, hipStream_t s) {
                      a->pred, a->x_t, a->mean, hp, a->coef, a->count);
 }
 
+__global__ __launch_bounds__(256) void silu_kernel(float* __restrict__ y, const float* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = az_silu(x[i]);
+}
+
 __global__ __launch_bounds__(256) void cfg_combine_kernel(float* __restrict__ y, const float* __restrict__ pos,
                                                           const float* __restrict__ neg, const float* __restrict__ g,
                                                           int64_t n) {
@@ -437,6 +442,13 @@ int az_multistep_f32(const AzMultistepArgs* a, az_stream_t stream) {
     case 6: launch_multistep<6>(a, s); break;
     default: launch_multistep<7>(a, s); break;
   }
+  return az_launch_status();
+}
+
+int az_silu_f32(float* y, const float* x, int64_t n, az_stream_t stream) {
+  AZ_REQUIRE(y && x, AZ_E_NULL);
+  AZ_REQUIRE(n > 0, AZ_E_SHAPE);
+  hipLaunchKernelGGL(silu_kernel, dim3(az_stream_grid(n, 256)), dim3(256), 0, az_s(stream), y, x, n);
   return az_launch_status();
 }
 

@@ -7,7 +7,8 @@ same kernels as ``azula_amd.nn.vit``:
 * bottleneck patch embedding = patchify remap + two MFMA GEMMs, the fixed sin-cos positional table
   added in the second GEMM's epilogue;
 * conditioning c = MLP(sinusoid(t)) + label embedding: ``az_timestep_embedding_f32``, the small-M
-  linear kernel, ``az_gather_rows_f32``; per-block 6-way adaLN = one small-M linear on SiLU(c);
+  linear kernel, ``az_gather_rows_f32``; the 6-way adaLN projections of ALL blocks (and the final layer's) are
+  one MFMA GEMM on SiLU(c), issued once per forward;
 * block: weighted RMSNorm + modulate is one row pass (``az_rownorm_mod_f32``); the q/k RMSNorm gains,
   the 2-D rotary embedding and the 1/sqrt(d) scale are folded into the attention kernel's operand loads
   ('(3 H C)' fused-QKV layout read in place); ``x + gate * proj(.)`` and ``x + gate * w3(.)`` are GEMM
@@ -144,6 +145,16 @@ class JiTPlan:
         bld.linear_small(t_emb, Hd, hid, Hd, bld.const(m2.weight), bld.const(m2.bias), B, Hd, Hd, 0, 0)
         tape.add("az_gather_rows_f32", y_emb.data_ptr(), bld.const(table).data_ptr(), self.labels.data_ptr(), B, Hd, table.shape[0])
         tape.add("az_axpby_f32", c.data_ptr(), ones.data_ptr(), t_emb.data_ptr(), ones.data_ptr(), y_emb.data_ptr(), 1, B * Hd, 0)
+        # every adaLN projection reads only SiLU(c): the 6-way projections of all blocks and the final layer's
+        # 2-way one are ONE GEMM (B x Hd) @ (Hd x (6 depth + 2) Hd) on the MFMA kernel, issued once per forward
+        heads_ = [blk.adaLN_modulation[1] for blk in net.blocks] + [net.final_layer.adaLN_modulation[1]]
+        w_all = torch.cat([m.weight.detach() for m in heads_]).to(device)
+        b_all = torch.cat([m.bias.detach() for m in heads_]).to(device)
+        c_act = Act(bld.empty(B * Hd), 1, B, 1, Hd, Hd, True)
+        tape.add("az_silu_f32", c_act.ptr, c.data_ptr(), B * Hd)
+        mods = bld.conv(c_act, bld.pack_conv(w_all, b_all), w_all.shape[0])
+        mods.pinned = True
+        mod, MS = mods.buf, mods.cs  # row stride of the modulation table
 
         # ---- bottleneck patch embedding + fixed positional table  (_src/model.py:16-43,358-359)
         e = net.x_embedder
@@ -164,11 +175,9 @@ class JiTPlan:
                 tape.add("az_token_copy_f32", wide.ptr, L + Lc, Lc, x.ptr, L, 0, L, B, Hd)
                 bld.free(x)
                 x = wide
-            lin = blk.adaLN_modulation[1]
-            mod = bld.empty(B, 6 * Hd)  # shift_a | scale_a | gate_a | shift_m | scale_m | gate_m
-            bld.linear_small(mod, 6 * Hd, c, Hd, bld.const(lin.weight), bld.const(lin.bias), B, 6 * Hd, Hd, 1, 0)
-            n1 = bld.row_norm(x, 1, weight=bld.const(blk.norm1.weight), scale=mod, shift=mod, scale_off=Hd, shift_off=0,
-                              bstride=6 * Hd, eps=1e-6)
+            m0_ = 6 * Hd * i  # this block's columns: shift_a | scale_a | gate_a | shift_m | scale_m | gate_m
+            n1 = bld.row_norm(x, 1, weight=bld.const(blk.norm1.weight), scale=mod, shift=mod, scale_off=m0_ + Hd,
+                              shift_off=m0_, bstride=MS, eps=1e-6)
             at = blk.attn
             qkv = bld.conv(n1, bld.pack_conv(at.qkv.weight, at.qkv.bias), 3 * Hd)
             bld.free(n1)
@@ -178,11 +187,11 @@ class JiTPlan:
                 qk_weight=(bld.const(at.q_norm.weight), bld.const(at.k_norm.weight)),
             )
             bld.free(qkv)
-            x2 = bld.conv(att, bld.pack_conv(at.proj.weight, at.proj.bias), Hd, gate=mod, gate_off=2 * Hd, gate_bstride=6 * Hd, res=x)
+            x2 = bld.conv(att, bld.pack_conv(at.proj.weight, at.proj.bias), Hd, gate=mod, gate_off=m0_ + 2 * Hd, gate_bstride=MS, res=x)
             bld.free(att)
             bld.free(x)
-            n2 = bld.row_norm(x2, 1, weight=bld.const(blk.norm2.weight), scale=mod, shift=mod, scale_off=4 * Hd, shift_off=3 * Hd,
-                              bstride=6 * Hd, eps=1e-6)
+            n2 = bld.row_norm(x2, 1, weight=bld.const(blk.norm2.weight), scale=mod, shift=mod, scale_off=m0_ + 4 * Hd,
+                              shift_off=m0_ + 3 * Hd, bstride=MS, eps=1e-6)
             # silu(x1) * x2 over halves (_src/model.py:159-162) -> interleave rows: pair (x2_c, x1_c)
             w12, b12 = blk.mlp.w12.weight.detach(), blk.mlp.w12.bias.detach()
             half = w12.shape[0] // 2
@@ -193,8 +202,8 @@ class JiTPlan:
             glu = bld.new_act(f1.B, f1.H, f1.W, half)
             tape.add("az_swiglu_f32", glu.ptr, f1.ptr, f1.B * f1.H * f1.W, half, f1.cs, glu.cs)
             bld.free(f1)
-            x = bld.conv(glu, bld.pack_conv(blk.mlp.w3.weight, blk.mlp.w3.bias), Hd, gate=mod, gate_off=5 * Hd,
-                         gate_bstride=6 * Hd, res=x2)
+            x = bld.conv(glu, bld.pack_conv(blk.mlp.w3.weight, blk.mlp.w3.bias), Hd, gate=mod, gate_off=m0_ + 5 * Hd,
+                         gate_bstride=MS, res=x2)
             bld.free(glu)
             bld.free(x2)
         if Lc and net.in_context_start < len(net.blocks):  # x[:, in_context_len:]
@@ -205,11 +214,9 @@ class JiTPlan:
 
         # ---- final layer + unpatchify 'nhwpqc->nchpwq'          (_src/model.py:166-184,331-344)
         fl = net.final_layer
-        lin = fl.adaLN_modulation[1]
-        mod = bld.empty(B, 2 * Hd)
-        bld.linear_small(mod, 2 * Hd, c, Hd, bld.const(lin.weight), bld.const(lin.bias), B, 2 * Hd, Hd, 1, 0)
-        n = bld.row_norm(x, 1, weight=bld.const(fl.norm_final.weight), scale=mod, shift=mod, scale_off=Hd, shift_off=0,
-                         bstride=2 * Hd, eps=1e-6)
+        mf = 6 * Hd * len(net.blocks)  # final layer's columns: shift | scale
+        n = bld.row_norm(x, 1, weight=bld.const(fl.norm_final.weight), scale=mod, shift=mod, scale_off=mf + Hd, shift_off=mf,
+                         bstride=MS, eps=1e-6)
         bld.free(x)
         wl = fl.linear.weight.detach().reshape(p * p, Z, Hd).transpose(0, 1).reshape(Z * p * p, Hd).contiguous()
         bl = fl.linear.bias.detach().reshape(p * p, Z).t().reshape(-1).contiguous()

@@ -125,6 +125,10 @@ int az_multistep_f32(const AzMultistepArgs* args, az_stream_t stream);
 /* y = s * x with s read from device memory (azula/denoise.py:317 c_in * x_t, generic backbones). */
 int az_scale_f32(float* y, const float* x, const float* s_dev, int64_t n, az_stream_t stream);
 
+/* y = silu(x) = x / (1 + exp(-x)): the activation in front of every adaLN projection of the conditioning
+ * vector (plugins/jit/_src/model.py:175-177,199-201), applied once so that all projections become one GEMM. */
+int az_silu_f32(float* y, const float* x, int64_t n, az_stream_t stream);
+
 /* y[r, i] = a[r*a_stride] * x[r, i] + b[r*a_stride] * z[r, i]  with a, b in device memory
  * (a_stride = 0: one scalar pair for all rows; 1: one pair per row = per-sample times t of
  * shape (B,), azula/denoise.py:306-307).  Separately rounded mul/mul/add as
