@@ -56,6 +56,11 @@ CONFIGS = {
         kind="adm", card="imagenet_256x256_cond", batch=4, shape=(3, 256, 256), steps=64, cfg=2.0,
         name="azula.plugins.adm imagenet_256x256_cond (random init) + CFGDenoiser(g=2), DDIMSampler(steps=64)",
     ),
+    # BASELINE.json configs[4] at its stated batch: 32 images on one GPU, two backbone evaluations per step
+    "c5cfg32": dict(
+        kind="adm", card="imagenet_256x256_cond", batch=32, shape=(3, 256, 256), steps=64, cfg=2.0,
+        name="azula.plugins.adm imagenet_256x256_cond (random init) + CFGDenoiser(g=2), DDIMSampler(steps=64), batch 32",
+    ),
     # JiT-B/16 pixel-space transformer at 256x256 (131M params, 256 + 32 tokens), class labels
     "c6": dict(
         kind="jit", model="JiT-B/16", batch=32, shape=(3, 256, 256), steps=50, labels=True,
