@@ -82,6 +82,19 @@ class AzMultistepArgs(C.Structure):
     ]
 
 
+class AzLinearGroup(C.Structure):
+    _fields_ = [
+        ("y", c_f32p),
+        ("x", c_f32p),
+        ("W", c_f32p),
+        ("bias", c_f32p),
+        ("ldy", C.c_int64),
+        ("ldx", C.c_int64),
+        ("N", C.c_int32),
+        ("K", C.c_int32),
+    ]
+
+
 class AzNormFinalizeArgs(C.Structure):
     _fields_ = [
         ("S", c_f32p),
@@ -198,6 +211,7 @@ PROTOTYPES: dict[str, list] = {
     "az_token_copy_f32": [vp, i64, i64, vp, i64, i64, i64, i64, i64, c_stream],
     "az_token_fill_f32": [vp, i64, i64, i64, vp, i64, vp, i64, i64, c_stream],
     "az_timestep_embedding_f32": [vp, i64, vp, i64, i64, i32, f32, c_stream],
+    "az_linear_small_grouped_f32": [vp, i32, i32, i64, i32, i32, c_stream],
     "az_conv2d_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_suggest_splitk": [i64, i32, i32, i32],
     "az_conv2d_winograd_f32": [C.POINTER(AzConvArgs), c_stream],

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from ..engine import Act, Builder, pad4
+from ..engine import Act, Builder, Tape, pad4
 from .. import _lib
 
 __all__ = ["UNet", "UNetBlock"]
@@ -91,8 +91,6 @@ class UNetBlock(nn.Module):
 
 
 def _copy_tape(t):
-    from ..engine import Tape
-
     c = Tape()
     c.extend(t)
     return c
@@ -114,12 +112,13 @@ class UNetPlan:
         L = len(net.hid_blocks)
         stride = net.stride
 
+        mod_jobs: list[tuple] = []  # (first Linear, padded second weight, padded second bias, abc buffer, N)
+
         def block(blk: UNetBlock, x: Act, keep_input: bool) -> Act:
             Cc, cs = blk.channels, pad4(blk.channels)
             # -- modulation triple (a, b, c), each padded to cs
             if blk.mod_features > 0:
                 rows = mod_rows
-                h = bld.empty(rows, D)
                 abc = bld.empty(rows, 3 * cs)
                 l0, l2 = blk.ada_zero[0], blk.ada_zero[2]
                 w2 = torch.zeros(3 * cs, D, dtype=torch.float32, device=device)
@@ -127,8 +126,9 @@ class UNetPlan:
                 for n in range(3):
                     w2[n * cs : n * cs + Cc] = l2.weight.detach()[n * Cc : (n + 1) * Cc]
                     b2[n * cs : n * cs + Cc] = l2.bias.detach()[n * Cc : (n + 1) * Cc]
-                bld.linear_small(h, D, self.mod, D, bld.const(l0.weight), bld.const(l0.bias), rows, D, D, 0, 1)
-                bld.linear_small(abc, 3 * cs, h, D, bld.const(w2), bld.const(b2), rows, 3 * cs, D, 0, 0)
+                # the modulation MLP reads only `mod`: it is not emitted here but batched with every other
+                # block's at the front of the tape (two launches instead of two per block, see below)
+                mod_jobs.append((l0, bld.const(w2), bld.const(b2), abc, 3 * cs))
                 bstride = 3 * cs if rows > 1 else 0
             else:
                 abc = torch.zeros(3 * cs, dtype=torch.float32, device=device)
@@ -189,6 +189,26 @@ class UNetPlan:
             # i > 0: nearest upsampling is folded into the next level's merge conv (up1 = 1)
         bld.finish()
         self.tape = bld.tape
+        if mod_jobs:  # h_i = silu(W0_i mod + b0_i) for all blocks as ONE GEMV; abc_i = W2_i h_i + b2_i as ONE grouped GEMV
+            from .._lib import AzLinearGroup
+
+            nj = len(mod_jobs)
+            w0 = bld.const(torch.cat([j[0].weight.detach() for j in mod_jobs]))
+            b0 = bld.const(torch.cat([j[0].bias.detach() for j in mod_jobs]))
+            h_all = bld.empty(max(mod_rows, 1), nj * D)
+            groups = (AzLinearGroup * nj)()
+            for i, (_, w2, b2, abc, n_out) in enumerate(mod_jobs):
+                g = groups[i]
+                g.y, g.x, g.W, g.bias = abc.data_ptr(), h_all.data_ptr() + 4 * i * D, w2.data_ptr(), b2.data_ptr()
+                g.ldy, g.ldx, g.N, g.K = n_out, nj * D, n_out, D
+            gdev = torch.frombuffer(bytearray(bytes(groups)), dtype=torch.uint8).to(device)
+            pre = Tape()
+            pre.add("az_linear_small_f32", h_all.data_ptr(), nj * D, self.mod.data_ptr(), D, w0.data_ptr(), b0.data_ptr(),
+                    max(mod_rows, 1), nj * D, D, 0, 1)
+            pre.add("az_linear_small_grouped_f32", gdev.data_ptr(), nj, max(j[4] for j in mod_jobs), max(mod_rows, 1), 0, 0,
+                    keep=[gdev, w0, b0, h_all])
+            pre.extend(self.tape)
+            self.tape = pre
 
 
 class UNet(nn.Module):

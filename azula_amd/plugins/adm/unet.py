@@ -130,6 +130,8 @@ class ADMPlan:
                 tbase = tb
             bld.tape.add("az_axpby_f32", emb.data_ptr(), ones.data_ptr(), tbase.data_ptr(), ones.data_ptr(), lab.data_ptr(), 1, B * E, 0)
         ebs = E if emb_rows > 1 else 0  # batch stride of emb rows
+        film_at = len(bld.tape.ops)  # every ResBlock's FiLM projection reads only `emb`: one grouped launch here
+        film_jobs: list[tuple] = []
 
         def resblock(rb: ResBlock, x: Act, x1: Act | None = None) -> Act:
             r"""x (| x1 concatenated) -> block output.  Does not free its inputs."""
@@ -144,7 +146,7 @@ class ADMPlan:
                 w[n * ocs : n * ocs + oc] = lin.weight.detach()[n * oc : (n + 1) * oc]
                 b_[n * ocs : n * ocs + oc] = lin.bias.detach()[n * oc : (n + 1) * oc]
             film = bld.empty(emb_rows, 2 * ocs)
-            bld.linear_small(film, 2 * ocs, emb, E, bld.const(w), bld.const(b_), emb_rows, 2 * ocs, E, 1, 0)
+            film_jobs.append((film, bld.const(w), bld.const(b_), 2 * ocs))
             fbs = 2 * ocs if emb_rows > 1 else 0
             # h = conv(updown(SiLU(GN(x))))
             n1 = bld.group_norm(x, 32, weight=bld.const(gi.weight), bias=bld.const(gi.bias), act=1, pool=int(rb.down), x1=x1)
@@ -221,6 +223,21 @@ class ADMPlan:
         n_ = bld.group_norm(h, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), act=1)
         bld.conv(n_, bld.pack_conv(co.weight, co.bias), net.out_channels, dst_nchw=self.out)
         bld.finish()
+        if film_jobs:
+            from ..._lib import AzLinearGroup, lib
+
+            nj = len(film_jobs)
+            groups = (AzLinearGroup * nj)()
+            for i, (film, w, b_, n_out) in enumerate(film_jobs):
+                g = groups[i]
+                g.y, g.x, g.W, g.bias = film.data_ptr(), emb.data_ptr(), w.data_ptr(), b_.data_ptr()
+                g.ldy, g.ldx, g.N, g.K = n_out, E, n_out, E
+            gdev = torch.frombuffer(bytearray(bytes(groups)), dtype=torch.uint8).to(device)
+            bld.tape.keep.append(gdev)
+            bld.tape.ops.insert(film_at, (
+                lib().az_linear_small_grouped_f32, (gdev.data_ptr(), nj, max(j[3] for j in film_jobs), emb_rows, 1, 0),
+                "az_linear_small_grouped_f32",
+            ))
         self.tape = bld.tape
 
 

@@ -155,6 +155,19 @@ int az_nhwc_to_nchw_f32(float* dst, const float* src, int64_t B, int64_t C, int6
  * act: 0 none, 1 SiLU.  K must be a multiple of 4 or K == 1.  ldy = row stride of y.        */
 int az_linear_small_f32(float* y, int64_t ldy, const float* x, int64_t ldx, const float* W, const float* bias,
                         int64_t M, int64_t N, int64_t K, int32_t in_act, int32_t out_act, az_stream_t stream);
+typedef struct AzLinearGroup {
+  float* y;          /* (M, ldy) */
+  const float* x;    /* (M, ldx); K % 4 == 0, ldx % 4 == 0, 16-byte aligned */
+  const float* W;    /* (N, K) row-major, 16-byte aligned */
+  const float* bias; /* (N) or NULL */
+  int64_t ldy, ldx;
+  int32_t N, K;
+} AzLinearGroup; /* 56 bytes */
+/* The same operation for `ngroups` independent (x, W, bias, y) quadruples sharing M and the activations, in ONE
+ * launch: `groups_dev` is a DEVICE array of descriptors, max_n = max N over the groups.  Used to hoist all
+ * per-block modulation MLPs (azula/nn/unet.py:65-70, one per UNetBlock) to the front of a forward.      */
+int az_linear_small_grouped_f32(const AzLinearGroup* groups_dev, int32_t ngroups, int32_t max_n, int64_t M,
+                                int32_t in_act, int32_t out_act, az_stream_t stream);
 
 /* dst[r, :] = table[idx[r], :]  (label_emb / per-step embedding rows).  idx is int64 on device. */
 int az_gather_rows_f32(float* dst, const float* table, const int64_t* idx, int64_t nrows, int64_t ncols,
