@@ -297,8 +297,8 @@ class Builder:
         if use_wino:
             tiles = B * ((hout + 1) // 2) * ((wout + 1) // 2)
             a.splitk = lib.az_conv2d_winograd_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
-            if winograd is None and WINOGRAD in ("1", "4") and tiles < 256:
-                use_wino = False  # < 4 tile blocks (8x8 at batch 4): the direct kernel's split-K is faster
+            if winograd is None and WINOGRAD in ("1", "4") and tiles < 64:
+                use_wino = False  # less than one 64-tile block (measured: 8x8 at batch < 4): the direct kernel wins
         if use_f4:
             a.weight = packed.winograd4().data_ptr()
             a.splitk = lib.az_conv2d_winograd4_suggest_splitk(B, hout, wout, a.cout_s, cin_s)

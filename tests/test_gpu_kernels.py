@@ -243,6 +243,31 @@ def test_linear_small(az, M, N, K, in_act, out_act):
     assert max_err(y, ref) < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,in_act", [(1, 0), (3, 1)])
+def test_linear_small_grouped(az, M, in_act):
+    """One launch for several independent (x, W, b, y) quadruples of different widths (UNet modulation MLPs,
+    ADM FiLM projections): each group against torch.nn.functional.linear."""
+    g = torch.Generator().manual_seed(M)
+    K, Ns = 64, (12, 256, 40)
+    hid = torch.randn(M, len(Ns) * K, generator=g)
+    Ws = [torch.randn(n, K, generator=g) / 8 for n in Ns]
+    bs = [torch.randn(n, generator=g) for n in Ns]
+    dh = dev(hid)
+    dW, db = [dev(w) for w in Ws], [dev(b) for b in bs]
+    ys = [torch.full((M, n), 7.0, device="cuda") for n in Ns]
+    groups = (az.AzLinearGroup * len(Ns))()
+    for i, n in enumerate(Ns):
+        q = groups[i]
+        q.y, q.x, q.W, q.bias = ys[i].data_ptr(), dh.data_ptr() + 4 * i * K, dW[i].data_ptr(), db[i].data_ptr() if i != 1 else None
+        q.ldy, q.ldx, q.N, q.K = n, len(Ns) * K, n, K
+    gdev = torch.frombuffer(bytearray(bytes(groups)), dtype=torch.uint8).cuda()
+    az.call("az_linear_small_grouped_f32", gdev.data_ptr(), len(Ns), max(Ns), M, in_act, 0, az.stream_ptr())
+    for i, n in enumerate(Ns):
+        x = hid[:, i * K : (i + 1) * K]
+        ref = F.linear(F.silu(x) if in_act else x, Ws[i], bs[i] if i != 1 else None)
+        assert max_err(ys[i], ref) < 2e-5 * max(1.0, ref.abs().max().item()), i
+
+
 @pytest.mark.parametrize(
     "B,Cc,H,W,groups",
     [(2, 32, 16, 16, 8), (2, 8, 16, 16, 8), (1, 12, 9, 7, 3), (2, 256, 32, 32, 32), (1, 2048, 8, 8, 32), (3, 64, 64, 64, 32)],
