@@ -138,11 +138,11 @@ class DiTPlan:
         ptab.pinned = True
 
         x = bld.conv(tokens, bld.pack_conv(net.in_proj.weight, net.in_proj.bias), C_, res=_bcast(ptab))
+        mod_jobs: list[tuple] = []  # (first Linear, padded second weight / bias, abc buffer, N) per modulated block
         for blk in net.blocks:
             cs = pad4(C_)
             if blk.mod_features > 0:
                 rows = mod_rows
-                h = bld.empty(rows, D)
                 abc = bld.empty(rows, 3 * cs)
                 l0, l2 = blk.ada_zero[0], blk.ada_zero[2]
                 w2 = torch.zeros(3 * cs, D, dtype=torch.float32, device=device)
@@ -150,8 +150,7 @@ class DiTPlan:
                 for n in range(3):
                     w2[n * cs : n * cs + C_] = l2.weight.detach()[n * C_ : (n + 1) * C_]
                     b2[n * cs : n * cs + C_] = l2.bias.detach()[n * C_ : (n + 1) * C_]
-                bld.linear_small(h, D, self.mod, D, bld.const(l0.weight), bld.const(l0.bias), rows, D, D, 0, 1)
-                bld.linear_small(abc, 3 * cs, h, D, bld.const(w2), bld.const(b2), rows, 3 * cs, D, 0, 0)
+                mod_jobs.append((l0, bld.const(w2), bld.const(b2), abc, 3 * cs))  # batched at the tape front (below)
                 bstride = 3 * cs if rows > 1 else 0
             else:
                 abc = torch.zeros(3 * cs, dtype=torch.float32, device=device)
@@ -197,6 +196,29 @@ class DiTPlan:
             self.out, self.out_tokens = None, o
         bld.finish()
         self.tape = bld.tape
+        if mod_jobs:  # all blocks' modulation MLPs read only `mod`: one GEMV + one grouped GEMV at the front
+            from .._lib import AzLinearGroup
+            from ..engine import Tape
+
+            nj = len(mod_jobs)
+            w0 = bld.const(torch.cat([j[0].weight.detach() for j in mod_jobs]))
+            b0 = bld.const(torch.cat([j[0].bias.detach() for j in mod_jobs]))
+            rows = max(mod_rows, 1)
+            h_all = bld.empty(rows, nj * D)
+            groups = (AzLinearGroup * nj)()
+            for i, (_, w2, b2, abc, n_out) in enumerate(mod_jobs):
+                g = groups[i]
+                g.y, g.x, g.W, g.bias = abc.data_ptr(), h_all.data_ptr() + 4 * i * D, w2.data_ptr(), b2.data_ptr()
+                g.ldy, g.ldx, g.N, g.K = n_out, nj * D, n_out, D
+            gdev = torch.frombuffer(bytearray(bytes(groups)), dtype=torch.uint8).to(device)
+            pre = Tape()
+            # tape order: patchify (if any) stays first -- it does not depend on `mod` either way
+            pre.add("az_linear_small_f32", h_all.data_ptr(), nj * D, self.mod.data_ptr(), D, w0.data_ptr(), b0.data_ptr(),
+                    rows, nj * D, D, 0, 1)
+            pre.add("az_linear_small_grouped_f32", gdev.data_ptr(), nj, max(j[4] for j in mod_jobs), rows, 0, 0,
+                    keep=[gdev, w0, b0, h_all])
+            pre.extend(self.tape)
+            self.tape = pre
 
 
 class _Bcast:
