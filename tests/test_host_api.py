@@ -6,6 +6,7 @@ reference's own invariant test (tests/test_denoise.py:135-143) and the host coef
 """
 
 import math
+import os
 
 import pytest
 import torch
@@ -411,3 +412,35 @@ def test_schedule_properties(batch):
         alpha_s, sigma_s = schedule(s)
         assert (alpha_s / sigma_s >= alpha_t / sigma_t).all(), S
         assert (schedule(torch.zeros(()))[0] == 1).all(), S
+
+
+def test_hub_cache_semantics(tmp_path):
+    """azula/hub.py:34-124 without the network: sanitised cache names, optional "alg:prefix" hash check, archive
+    extraction into "<file>+x" (what jit.load_model joins "checkpoint-last.pth" onto)."""
+    import hashlib
+    import zipfile
+
+    from azula_amd import hub
+
+    old = hub.get_hub_dir()
+    try:
+        hub.set_hub_dir(str(tmp_path))
+        url = "https://example.org/some dir/jit-b-16?rlkey=abc&dl=1"
+        path = hub.cached_path(url)
+        assert os.path.basename(path) == "https.example.org.some.dir.jit.b.16.rlkey.abc.dl.1"
+        with pytest.raises(FileNotFoundError, match="does not download"):
+            hub.download(url, quiet=True)
+        with zipfile.ZipFile(path, "w") as z:
+            z.writestr("checkpoint-last.pth", b"weights")
+        digest = hashlib.sha256(open(path, "rb").read()).hexdigest()
+        assert hub.download(url, hash_prefix="sha256:" + digest[:10], quiet=True) == path
+        with pytest.raises(AssertionError, match="does not match"):
+            hub.download(url, hash_prefix="sha256:0000", quiet=True)
+        xd = hub.download(url, extract=True, quiet=True)
+        assert xd == path + "+x" and open(os.path.join(xd, "checkpoint-last.pth"), "rb").read() == b"weights"
+        assert hub.download(url, extract=True, quiet=True) == xd  # second call: already unpacked
+        explicit = tmp_path / "elsewhere.bin"
+        explicit.write_bytes(b"x")
+        assert hub.download("ignored://", filename=str(explicit), quiet=True) == str(explicit)
+    finally:
+        hub.set_hub_dir(old)
