@@ -32,7 +32,7 @@ __device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >>
 
 template <int D>
 __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
-  constexpr int DP = D < 32 ? 32 : D;  // padded head dim (whole 32-wide O^T tiles)
+  constexpr int DP = (D + 31) / 32 * 32;  // padded head dim (whole 32-wide O^T tiles)
   constexpr int DT = DP / 32;          // number of 32-wide output tiles
   constexpr int LS = DP + 4;           // LDS row stride (floats)
   constexpr int KJ = D / 8;            // groups of 8 head-dim values in the QK^T contraction
@@ -113,15 +113,21 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
 
   // cooperative K/V tile loader: thread -> (row = tid / CH + pass * rows_per_pass, 16-B chunk)
   constexpr int CH = D / 4;               // chunks per row
-  constexpr int RPP = 256 / CH;           // rows per pass
-  const int lc = tid % CH, lr = tid / CH;
+  // CH a power of two: 256 / CH rows per pass, a row's chunks on CH consecutive lanes.  Otherwise (D = 80:
+  // CH = 20) each wave takes 64 / CH whole rows so that a row never straddles two waves (4 lanes idle).
+  constexpr bool POW2 = (CH & (CH - 1)) == 0;
+  constexpr int RW = 64 / CH;
+  constexpr int RPP = POW2 ? 256 / CH : 4 * RW;  // rows per pass
+  const int lc = POW2 ? tid % CH : lane % CH;
+  const int lr = POW2 ? tid / CH : wave * RW + lane / CH;
+  const bool lactive = POW2 || lane < RW * CH;
 
   for (int k0 = 0; k0 < T; k0 += KT) {
     __syncthreads();  // previous tile fully consumed
 #pragma unroll
     for (int rr = 0; rr < KT; rr += RPP) {
       const int row = rr + lr;
-      if (row < KT) {
+      if (row < KT && lactive) {
         const int key = k0 + row;
         float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
         if (key < T) {
@@ -130,8 +136,18 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
         }
         if (a.qk_rmsnorm) {  // per-key RMS norm: CH consecutive lanes hold one row
           float ss = (kv.x * kv.x + kv.y * kv.y) + (kv.z * kv.z + kv.w * kv.w);
+          if constexpr (POW2) {
 #pragma unroll
-          for (int o = 1; o < CH; o <<= 1) ss += __shfl_xor(ss, o, 64);
+            for (int o = 1; o < CH; o <<= 1) ss += __shfl_xor(ss, o, 64);
+          } else {  // groups of 4 lanes by butterfly, then the CH / 4 group sums of this row
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            const int base = (lane / CH) * CH;
+            float tot = 0.f;
+#pragma unroll
+            for (int j = 0; j < CH / 4; ++j) tot += __shfl(ss, base + 4 * j, 64);
+            ss = tot;
+          }
           const float f = rsqrtf(ss / (float)D + a.eps);
           kv.x *= f;
           kv.y *= f;
@@ -333,7 +349,8 @@ extern "C" {
 int az_attention_f32(const AzAttnArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->q && a->k && a->v && a->out, AZ_E_NULL);
   AZ_REQUIRE(a->batch > 0 && a->heads > 0 && a->tokens > 0, AZ_E_SHAPE);
-  AZ_REQUIRE(a->head_dim == 16 || a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 128, AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(a->head_dim == 16 || a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 80 || a->head_dim == 128,
+             AZ_E_UNSUPPORTED);
   AZ_REQUIRE(AZ_ALIGNED16(a->q) && AZ_ALIGNED16(a->k) && AZ_ALIGNED16(a->v) && AZ_ALIGNED16(a->out), AZ_E_ALIGN);
   const int64_t strides[] = {a->q_bstride, a->q_tstride, a->q_hstride, a->k_bstride, a->k_tstride, a->k_hstride,
                              a->v_bstride, a->v_tstride, a->v_hstride, a->o_bstride, a->o_tstride, a->o_hstride};
@@ -344,6 +361,7 @@ int az_attention_f32(const AzAttnArgs* a, az_stream_t stream) {
     case 16: hipLaunchKernelGGL(attention_kernel<16>, grid, dim3(256), 0, st, *a); break;
     case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, st, *a); break;
     case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, st, *a); break;
+    case 80: hipLaunchKernelGGL(attention_kernel<80>, grid, dim3(256), 0, st, *a); break;
     default: hipLaunchKernelGGL(attention_kernel<128>, grid, dim3(256), 0, st, *a); break;
   }
   return az_launch_status();

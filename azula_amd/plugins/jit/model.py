@@ -284,10 +284,9 @@ class JiT(nn.Module):
         in_context_start: int = 8,
     ) -> None:
         super().__init__()
-        if hidden_size % num_heads or hidden_size // num_heads not in (16, 32, 64, 128):
+        if hidden_size % num_heads or hidden_size // num_heads not in (16, 32, 64, 80, 128):
             raise NotImplementedError(
-                f"head_dim {hidden_size / num_heads:g}: the gfx950 attention kernel is instantiated for 16/32/64/128 "
-                "(JiT-H's 80 is not built yet)"
+                f"head_dim {hidden_size / num_heads:g}: the gfx950 attention kernel is instantiated for 16/32/64/80/128"
             )
         if input_size % patch_size or hidden_size % 8:
             raise ValueError("input_size must be a multiple of patch_size and hidden_size of 8")

@@ -12,7 +12,7 @@ from oracle import nets, synth
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
-CONFIGS = ("jit_ctx", "jit_noctx_hd32")
+CONFIGS = ("jit_ctx", "jit_noctx_hd32", "jit_hd80")
 
 
 @pytest.fixture(scope="module")
@@ -128,7 +128,7 @@ def test_rownorm_with_gain(az):
     assert max_err(y.buf[: x.numel()].view(B, L, Cc), want) < 1e-5
 
 
-@pytest.mark.parametrize("hd", [16, 64])
+@pytest.mark.parametrize("hd", [16, 64, 80])
 def test_attention_with_gains_and_2d_rope(az, hd):
     """'(3 H C)' fused QKV + weighted q/k RMSNorm + JiT's 2-D rotary tables + context tokens."""
     from azula_amd.engine import Builder

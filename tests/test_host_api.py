@@ -316,7 +316,7 @@ def test_jit_plugin_host_side(golden):
     with pytest.raises(FileNotFoundError, match="does not download"):
         jit.load_model("jit_0.1b_16")
     with pytest.raises(NotImplementedError, match="head_dim"):
-        jit.make_model("JiT-H/16")
+        jit.JiT(input_size=32, patch_size=4, hidden_size=96, depth=1, num_heads=2)  # head_dim 48: no kernel
 
     g = golden("g10_jit_ctx")
     net = jit.JiT(**g.meta["cfg"])

@@ -168,7 +168,7 @@ def test_g9_toy_multistep_loops(golden):
 
 def test_g10_jit(golden):
     """JiT backbone, JITDenoiser (label / null class), DDIM and CFG loops on the rectified schedule."""
-    for name in ("jit_ctx", "jit_noctx_hd32"):
+    for name in ("jit_ctx", "jit_noctx_hd32", "jit_hd80"):
         g = golden("g10_" + name)
         cfg = g.meta["cfg"]
         sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"])
