@@ -153,7 +153,7 @@ class KarrasDenoiser(Denoiser):
 
     def _az_fused(self, x: Tensor, kwargs: dict, cur_coef: Tensor):
         compile_ = getattr(self.backbone, "_az_compile", None)
-        if compile_ is None or get_module_dtype(self.backbone) not in (None, torch.float32):
+        if compile_ is None or get_module_dtype(self.backbone) not in (None, torch.float32, torch.float16, torch.bfloat16):
             return None
         program = compile_(x, kwargs, cur_coef)
         if program is None:

@@ -281,15 +281,10 @@ class UNet(nn.Module):
             self._plans[key] = p
         return p
 
-    def _check_device(self, x: Tensor) -> None:
-        if not x.is_cuda:
-            raise RuntimeError(
-                "azula_amd.nn.UNet executes only on an AMD GPU (gfx950 HIP kernels); there is no CPU fallback. "
-                "Move the module and its inputs to 'cuda'."
-            )
-        p = next(self.parameters())
-        if p.device != x.device or p.dtype != torch.float32 or x.dtype != torch.float32:
-            raise RuntimeError("azula_amd.nn.UNet needs fp32 parameters and inputs on the same GPU")
+    def _check_device(self, x: Tensor) -> torch.dtype:
+        from .utils import backbone_io_dtype
+
+        return backbone_io_dtype(self, x, "azula_amd.nn.UNet")
 
     # -- fused sampling (see azula_amd.sample.BackboneProgram) --------------------------------------
     def _program(self, x: Tensor, mod_rows: int):
@@ -323,10 +318,10 @@ class UNet(nn.Module):
     @torch.no_grad()
     def forward(self, x: Tensor, mod: Tensor | None = None, cond: Tensor | None = None) -> Tensor:
         r"""x: (B, C_i, H, W); mod: (D) or (B, D); cond: (B, C_c, H, W) -> (B, C_o, H, W)."""
-        self._check_device(x)
+        out_dtype = self._check_device(x)
         if cond is not None:
             x = torch.cat((x, cond), dim=1)
-        x = x.contiguous()
+        x = x.to(torch.float32).contiguous()
         B, Cin, H, W = x.shape
         assert Cin == self.in_channels + self.cond_channels
         if self.mod_features > 0:
@@ -342,4 +337,4 @@ class UNet(nn.Module):
         if rows:
             p.mod.copy_(mod.reshape(rows, -1))
         p.tape.run(s)
-        return p.out.clone()
+        return p.out.to(out_dtype, copy=True)

@@ -6,7 +6,7 @@ from functools import reduce, wraps
 
 import torch
 
-__all__ = ["get_module_dtype", "promote_dtype", "skip_init"]
+__all__ = ["get_module_dtype", "promote_dtype", "skip_init", "backbone_io_dtype", "HALF_DTYPES"]
 
 
 def get_module_dtype(module: torch.nn.Module) -> torch.dtype | None:
@@ -46,3 +46,29 @@ def promote_dtype(f, min_dtype: torch.dtype = torch.float32):
         return tuple(o.to(dtype=common) for o in outs)
 
     return g
+
+
+HALF_DTYPES = (torch.float16, torch.bfloat16)
+
+
+def backbone_io_dtype(module: torch.nn.Module, x: torch.Tensor, who: str) -> torch.dtype:
+    r"""Validates the (module, input) pair of a compiled backbone and returns the dtype its output must have.
+
+    fp32 modules take fp32 inputs.  A module cast with ``.half()`` / ``.bfloat16()`` (the reference's mixed-precision
+    route: the denoiser casts ``c_in x_t`` to the backbone's dtype and the output back, ``azula/denoise.py:314-320``)
+    is accepted too: its parameters are up-converted ONCE when the plan is built and all arithmetic stays fp32 --
+    there are no fp16 kernels yet, so this path is as fast as fp32 and its result is within the reference's own
+    fp16-vs-fp32 tolerance (``tests/test_nn_unet.py:78-91``) of both the fp16 and the fp32 reference output."""
+    if not x.is_cuda:
+        raise RuntimeError(
+            f"{who} executes only on an AMD GPU (gfx950 HIP kernels); there is no CPU fallback. "
+            "Move the module and its inputs to 'cuda'."
+        )
+    p = next(module.parameters())
+    ok = (p.dtype == torch.float32 and x.dtype == torch.float32) or (p.dtype in HALF_DTYPES and x.dtype in (p.dtype, torch.float32))
+    if p.device != x.device or not ok:
+        raise RuntimeError(
+            f"{who} needs parameters and inputs on the same GPU, fp32 / fp32 or half / (half | fp32); "
+            f"got {p.dtype} on {p.device} and {x.dtype} on {x.device}"
+        )
+    return x.dtype

@@ -264,15 +264,10 @@ class DiT(nn.Module):
     def _param_versions(self) -> tuple:
         return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
 
-    def _check_device(self, x: Tensor) -> None:
-        if not x.is_cuda:
-            raise RuntimeError(
-                f"azula_amd.nn.{type(self).__name__} executes only on an AMD GPU (gfx950 HIP kernels); "
-                "there is no CPU fallback."
-            )
-        p = next(self.parameters())
-        if p.device != x.device or p.dtype != torch.float32 or x.dtype != torch.float32:
-            raise RuntimeError("azula_amd backbones need fp32 parameters and inputs on the same GPU")
+    def _check_device(self, x: Tensor) -> torch.dtype:
+        from .utils import backbone_io_dtype
+
+        return backbone_io_dtype(self, x, f"azula_amd.nn.{type(self).__name__}")
 
     def _mod_rows(self, mod, B: int) -> int:
         if self.mod_features == 0:
@@ -292,11 +287,11 @@ class DiT(nn.Module):
     @torch.no_grad()
     def forward(self, x: Tensor, mod: Tensor | None = None, pos: Tensor | None = None, cond: Tensor | None = None):
         r"""x: (B, L, C_i) tokens -> (B, L, C_o).  ``pos``: (L, P) or None (sequence indices)."""
-        self._check_device(x)
+        out_dtype = self._check_device(x)
         if cond is not None:
             x = torch.cat((x, cond), dim=-1)
         assert x.ndim == 3, "DiT.forward expects (B, L, C) tokens"
-        x = x.contiguous()
+        x = x.to(torch.float32).contiguous()
         B, L, Cin = x.shape
         rows = self._mod_rows(mod, B)
         if pos is None:
@@ -316,7 +311,7 @@ class DiT(nn.Module):
             plan.mod.copy_(mod.to(torch.float32).reshape(rows, -1))
         plan.tape.run()
         o = plan.out_tokens
-        return o.buf.view(B, L, o.cs)[..., : o.C].clone()
+        return o.buf.view(B, L, o.cs)[..., : o.C].to(out_dtype, copy=True)
 
 
 class ViT(DiT):
@@ -369,7 +364,7 @@ class ViT(DiT):
     @torch.no_grad()
     def forward(self, x: Tensor, mod: Tensor | None = None, cond: Tensor | None = None) -> Tensor:
         r"""x: (B, C_i, H, W); mod: (D) or (B, D) -> (B, C_o, H, W)."""
-        self._check_device(x)
+        out_dtype = self._check_device(x)
         assert cond is None, "cond is not implemented on the HIP path"
         B, Z, H, W = x.shape
         assert Z == self.image_in and H % self.patch_size == 0 and W % self.patch_size == 0
@@ -379,7 +374,7 @@ class ViT(DiT):
         if rows:
             plan.mod.copy_(mod.to(torch.float32).reshape(rows, -1))
         plan.tape.run()
-        return plan.out.clone()
+        return plan.out.to(out_dtype, copy=True)
 
     # -- fused sampling ---------------------------------------------------------------------------
     def _az_compile_modulated(self, x: Tensor, mod_rows: int = 1):

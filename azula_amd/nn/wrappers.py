@@ -43,11 +43,22 @@ class TimeModulated(nn.Module):
     def net(self) -> nn.Module:
         return getattr(self, self._net_name)
 
+    def _f32(self) -> list[Tensor]:
+        r"""fp32 views of the embedding MLP's parameters: the parameters themselves, or (module cast to half
+        precision) up-converted copies refreshed when a parameter changes."""
+        ps = [self.time_embedding[0].weight, self.time_embedding[0].bias, self.time_embedding[2].weight, self.time_embedding[2].bias]
+        if ps[0].dtype == torch.float32:
+            return [p.detach() for p in ps]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_f32_key", None) != key:
+            self._f32_cache, self._f32_key = [p.detach().float().contiguous() for p in ps], key
+        return self._f32_cache
+
     def _embed(self, tape_or_none, c_time_buf: Tensor, rows: int, mod_buf: Tensor, hid_buf: Tensor):
-        l0, l2 = self.time_embedding[0], self.time_embedding[2]
+        w0, b0, w2, b2 = self._f32()
         D = self.features
-        args0 = (hid_buf.data_ptr(), D, c_time_buf.data_ptr(), 1, l0.weight.data_ptr(), l0.bias.data_ptr(), rows, D, 1, 0, 1)
-        args2 = (mod_buf.data_ptr(), D, hid_buf.data_ptr(), D, l2.weight.data_ptr(), l2.bias.data_ptr(), rows, D, D, 0, 0)
+        args0 = (hid_buf.data_ptr(), D, c_time_buf.data_ptr(), 1, w0.data_ptr(), b0.data_ptr(), rows, D, 1, 0, 1)
+        args2 = (mod_buf.data_ptr(), D, hid_buf.data_ptr(), D, w2.data_ptr(), b2.data_ptr(), rows, D, D, 0, 0)
         if tape_or_none is None:
             s = _lib.stream_ptr()
             _lib.call("az_linear_small_f32", *args0, s)
@@ -79,7 +90,7 @@ class TimeModulated(nn.Module):
         tape.add("az_coef_c_time_f32", ct.data_ptr(), cur_coef.data_ptr())
         program, mod_buf = inner(x, mod_rows=1)
         self._embed(tape, ct, 1, mod_buf, hid)
-        tape.keep.extend([ct, hid, self.time_embedding[0].weight, self.time_embedding[2].weight])
+        tape.keep.extend([ct, hid, *self._f32()])
         tape.extend(program.tape)
         program.tape = tape
         return program

@@ -136,7 +136,7 @@ class AblatedDenoiser(Denoiser):
         from ...nn.unet import _copy_tape
 
         bb = self.backbone
-        if not isinstance(bb, unet.UNetModel) or x.ndim != 4 or get_module_dtype(bb) != torch.float32:
+        if not isinstance(bb, unet.UNetModel) or x.ndim != 4 or get_module_dtype(bb) not in (torch.float32, torch.float16, torch.bfloat16):
             return None
         B, _, H, W = x.shape
         programs, x_in = [], None

@@ -339,10 +339,10 @@ class UNetModel(nn.Module):
         assert (y is not None) == (self.num_classes is not None), (
             "must specify y if and only if the model is class-conditional"
         )
-        if not x.is_cuda:
-            raise RuntimeError("azula_amd ADM UNetModel executes only on an AMD GPU (no CPU fallback)")
-        assert x.dtype == torch.float32
-        x = x.contiguous()
+        from ...nn.utils import backbone_io_dtype
+
+        out_dtype = backbone_io_dtype(self, x, "azula_amd ADM UNetModel")
+        x = x.to(torch.float32).contiguous()
         B, Cin, H, W = x.shape
         timesteps = timesteps.reshape(-1)
         if torch.is_floating_point(timesteps):
@@ -356,4 +356,4 @@ class UNetModel(nn.Module):
             assert y.shape == (B,)
             p.labels.copy_(y.to(torch.int64))
         p.tape.run(s)
-        return p.out.clone()
+        return p.out.to(out_dtype, copy=True)

@@ -79,7 +79,7 @@ class JITDenoiser(Denoiser):
         from ...sample import BackboneProgram
 
         bb = self.backbone
-        if not isinstance(bb, JiT) or x.ndim != 4 or get_module_dtype(bb) != torch.float32:
+        if not isinstance(bb, JiT) or x.ndim != 4 or get_module_dtype(bb) not in (torch.float32, torch.float16, torch.bfloat16):
             return None
         B = x.shape[0]
         programs, x_in = [], None

@@ -318,18 +318,17 @@ class JiT(nn.Module):
             p = self._plans[key] = JiTPlan(self, B, t_shared, device)
         return p
 
-    def _check(self, x: Tensor) -> None:
-        if not x.is_cuda:
-            raise RuntimeError("azula_amd.plugins.jit.JiT executes only on an AMD GPU (gfx950 HIP kernels); no CPU fallback")
-        w = self.pos_embed
-        if w.device != x.device or w.dtype != torch.float32 or x.dtype != torch.float32:
-            raise RuntimeError("azula_amd backbones need fp32 parameters and inputs on the same GPU")
+    def _check(self, x: Tensor) -> torch.dtype:
+        from ...nn.utils import backbone_io_dtype
+
+        out_dtype = backbone_io_dtype(self, x, "azula_amd.plugins.jit.JiT")
         if tuple(x.shape[1:]) != (self.in_channels, self.input_size, self.input_size):
             raise ValueError(f"expected (B, {self.in_channels}, {self.input_size}, {self.input_size}), got {tuple(x.shape)}")
+        return out_dtype
 
     @torch.no_grad()
     def forward(self, x: Tensor, t: Tensor, y: Tensor) -> Tensor:
-        self._check(x)
+        out_dtype = self._check(x)
         B = x.shape[0]
         t = t.reshape(-1)
         plan = self.plan(B, t.numel() == 1, x.device)
@@ -337,7 +336,7 @@ class JiT(nn.Module):
         plan.t.copy_(t.to(device=x.device, dtype=torch.float32))
         plan.labels.copy_(y.to(device=x.device, dtype=torch.int64).expand(B))
         plan.tape.run()
-        return plan.out.clone()
+        return plan.out.to(out_dtype, copy=True)
 
 
 _ARCH = {  # name: (depth, hidden, heads, bottleneck, context start, patch)   (_src/model.py:384-457)

@@ -195,3 +195,45 @@ def test_multistep_and_pc_samplers_on_gpu(golden):
     ref = sampling.sample_pc(omean, g["x1"], steps=g.meta["pc_steps"], corrections=1, eps_list=eps)
     print("pc", max_err(x0, ref))
     assert max_err(x0, ref) < 5e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("half", [torch.float16, torch.bfloat16])
+def test_half_precision_module_is_accepted(golden, half):
+    """Mirror of the reference's fp16 check (tests/test_nn_unet.py:78-91: q99 < 1e-3, max < 1e-2 between the fp16
+    and the fp32 forward), for a module cast with .half() / .bfloat16(): parameters are up-converted once and the
+    arithmetic stays fp32, so the only error is the rounding of the weights, inputs and outputs."""
+    g = golden("g5_unet_group")
+    net = build_unet(g.meta["cfg"])
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"]))
+    net = net.cuda().eval()
+    x, mod = g["x"].cuda(), g["modB"].cuda()
+    y32 = net(x, mod)
+    net.to(half)
+    y16 = net(x.to(half), mod.to(half))
+    assert y16.dtype == half and y16.shape == y32.shape
+    err = (y32 - y16.float()).abs().flatten()
+    scale = y32.abs().max().item()
+    tol = 1.0 if half == torch.float16 else 8.0  # bf16 has 3 fewer mantissa bits
+    print(half, "q99", torch.quantile(err, 0.99).item(), "max", err.max().item(), "scale", scale)
+    assert torch.quantile(err, 0.99) < 1e-3 * tol * max(1.0, scale) and err.max() < 1e-2 * tol * max(1.0, scale)
+    # and through a denoiser + fused sampler (KarrasDenoiser casts c_in x_t to the module dtype on the generic path)
+    from azula_amd.denoise import KarrasDenoiser
+    from azula_amd.nn import TimeModulated
+    from azula_amd.noise import VPSchedule
+    from azula_amd.sample import DDIMSampler
+
+    g6 = golden("g6_unet_loop")
+    w = TimeModulated(build_unet(g6.meta["cfg"]), g6.meta["cfg"]["mod_features"], name="unet")
+    w.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g6.meta["shapes"].items()}, g6.meta["weight_seed"]))
+    den = KarrasDenoiser(w, VPSchedule()).cuda().eval()
+    x1 = g6["x1"].cuda()
+    ref = DDIMSampler(den, steps=8, silent=True)(x1)
+    den.backbone.to(half)
+    smp = DDIMSampler(den, steps=8, silent=True)
+    x0 = smp(x1)
+    assert x0.dtype == torch.float32 and next(iter(smp._fused_cache.values())).graph is not None
+    q = den(x1, torch.tensor(0.5, device="cuda"))  # generic path: input rounded to the module dtype like the reference
+    assert q.mean.dtype == torch.float32 and torch.isfinite(q.mean).all()
+    rel = (x0 - ref).abs().max().item() / ref.abs().max().item()
+    print(half, "DDIM-8 with half-precision weights vs fp32 weights: rel", rel)
+    assert rel < (2e-2 if half == torch.float16 else 1e-1)
