@@ -212,33 +212,39 @@ __device__ __forceinline__ float4 ld_cat(const float* __restrict__ x, const floa
   return *reinterpret_cast<const float4*>(x1 + pix * (cs - c0s) + (c - c0s));
 }
 
+// y = act(x * S[b, c] + T[b, c]).  HBM-bound (8 B per element) only if the per-element ALU work stays small: a
+// thread owns ONE channel quad for its whole run (the launch makes the thread count a multiple of the quads per pixel,
+// blockIdx.y is the sample), so S / T are loaded once and the loop body has no division -- the first version spent
+// three 64-bit divisions per float4 and ran at 2.5 TB/s.
 template <int ACT>
 __global__ __launch_bounds__(256) void affine_act_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                          const float* __restrict__ x1, int c0s,
                                                          const float* __restrict__ S, const float* __restrict__ T,
-                                                         int64_t B, int64_t HW, int cs) {
+                                                         int HW, int cs) {
   const int q = cs / 4;
-  const int64_t per_b = HW * q;
-  const int64_t total = B * per_b;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t b = e / per_b;
-    const int c4 = (int)(e % q);
-    const float4 v = ld_cat(x, x1, c0s, cs, e / q, c4 * 4);
-    const float4 s = *reinterpret_cast<const float4*>(S + b * cs + c4 * 4);
-    const float4 t = *reinterpret_cast<const float4*>(T + b * cs + c4 * 4);
+  const int b = blockIdx.y;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int c4 = g % q;
+  const int pstride = (gridDim.x * 256) / q;
+  const float4 sc = *reinterpret_cast<const float4*>(S + (int64_t)b * cs + c4 * 4);
+  const float4 t = *reinterpret_cast<const float4*>(T + (int64_t)b * cs + c4 * 4);
+  const int64_t pix0 = (int64_t)b * HW;
+  float4* yb = reinterpret_cast<float4*>(y) + pix0 * q + c4;
+#pragma unroll 2
+  for (int p = g / q; p < HW; p += pstride) {
+    const float4 v = ld_cat(x, x1, c0s, cs, pix0 + p, c4 * 4);
     float4 o;
-    o.x = fmaf(v.x, s.x, t.x);
-    o.y = fmaf(v.y, s.y, t.y);
-    o.z = fmaf(v.z, s.z, t.z);
-    o.w = fmaf(v.w, s.w, t.w);
+    o.x = fmaf(v.x, sc.x, t.x);
+    o.y = fmaf(v.y, sc.y, t.y);
+    o.z = fmaf(v.z, sc.z, t.z);
+    o.w = fmaf(v.w, sc.w, t.w);
     if (ACT == 1) {
       o.x = az_silu(o.x);
       o.y = az_silu(o.y);
       o.z = az_silu(o.z);
       o.w = az_silu(o.w);
     }
-    reinterpret_cast<float4*>(y)[e] = o;
+    yb[(int64_t)p * q] = o;
   }
 }
 
@@ -408,11 +414,23 @@ int az_affine_act_f32(float* y, const float* x, const float* x1, int64_t c0s, co
       hipLaunchKernelGGL(affine_act_pool_kernel<0>, dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, (int)H,
                          (int)W, (int)cs);
   } else {
-    const int grid = az_stream_grid(B * H * W * (cs / 4), 256);
+    AZ_REQUIRE(H * W < (1ll << 31) && B < 65536, AZ_E_SHAPE);
+    // threads per sample: a multiple of the quads per pixel q (so a thread keeps its channel quad), about 8
+    // float4 per thread, at most ~2048 workgroups over the batch
+    const int q = (int)(cs / 4);
+    int qq = q, r256 = 256;
+    while (r256) { const int tmp = qq % r256; qq = r256; r256 = tmp; }  // qq = gcd(q, 256)
+    const int unit = q / qq;  // workgroups per sample must be a multiple of this
+    int64_t want = (H * W * q + 256 * 8 - 1) / (256 * 8);
+    const int64_t cap = (2048 + B - 1) / B;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    const int gx = (int)((want + unit - 1) / unit * unit);
+    dim3 grid((unsigned)gx, (unsigned)B);
     if (act == 1)
-      hipLaunchKernelGGL(affine_act_kernel<1>, dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, H * W, (int)cs);
+      hipLaunchKernelGGL(affine_act_kernel<1>, grid, dim3(256), 0, st, y, x, x1, (int)c0s, S, T, (int)(H * W), (int)cs);
     else
-      hipLaunchKernelGGL(affine_act_kernel<0>, dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, H * W, (int)cs);
+      hipLaunchKernelGGL(affine_act_kernel<0>, grid, dim3(256), 0, st, y, x, x1, (int)c0s, S, T, (int)(H * W), (int)cs);
   }
   return az_launch_status();
 }
