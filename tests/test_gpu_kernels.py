@@ -388,6 +388,53 @@ def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk, wino):
 
 
 @pytest.mark.parametrize("wino", [False, True, 4])
+def test_conv2d_random_shapes(az, wino):
+    """Seeded sweep over ragged shapes (odd sizes, channel counts off the 4 / 8 / 32 grids, batch 1-3, optional second
+    source with nearest-x2 upsampling, SiLU / gate / residual) for the three 3x3 stride-1 algorithms."""
+    import random
+
+    from azula_amd.engine import Act, Builder
+
+    rnd = random.Random(1234 + (7 if wino is True else int(wino)))
+    g = torch.Generator().manual_seed(99)
+    for case in range(10):
+        B = rnd.randint(1, 3)
+        H, W = rnd.randint(3, 21), rnd.randint(3, 21)
+        C0, Cout = rnd.choice([3, 5, 8, 12, 20, 33, 40]), rnd.choice([3, 6, 8, 17, 32, 70])
+        two = rnd.random() < 0.4
+        C1 = rnd.choice([4, 7, 16]) if two else 0
+        act = rnd.choice([0, 1])
+        x0 = torch.randn(B, C0, H, W, generator=g)
+        w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / math.sqrt(9 * (C0 + C1))
+        b = torch.randn(Cout, generator=g)
+        gate, res = torch.randn(B, Cout, generator=g), torch.randn(B, Cout, H, W, generator=g)
+        src = x0
+        bld = Builder(torch.device("cuda"))
+        a0 = Act(to_nhwc(dev(x0)).reshape(-1), B, H, W, C0, (C0 + 3) // 4 * 4, True)
+        kw = {}
+        if two:
+            h1, w1 = (H + 1) // 2, (W + 1) // 2
+            x1 = torch.randn(B, C1, h1, w1, generator=g)
+            up = F.interpolate(x1, scale_factor=(2.0, 2.0), mode="nearest")[:, :, :H, :W]
+            src = torch.cat((x0, up), 1)
+            a1 = Act(to_nhwc(dev(x1)).reshape(-1), B, h1, w1, C1, (C1 + 3) // 4 * 4, True)
+            kw = dict(src1=a1, up1=1, hin=H, win=W)
+        ref = F.conv2d(src, w, b, padding=1)
+        ref = res + gate[:, :, None, None] * (F.silu(ref) if act else ref)
+        cs_o = (Cout + 3) // 4 * 4
+        gpad = torch.zeros(B, cs_o)
+        gpad[:, :Cout] = gate
+        ra = Act(to_nhwc(dev(res)).reshape(-1), B, H, W, Cout, cs_o, True)
+        y = bld.conv(a0, bld.pack_conv(dev(w), dev(b), cin0=C0), Cout, act=act, gate=dev(gpad), gate_bstride=cs_o, res=ra,
+                     winograd=wino, **kw)
+        bld.finish()
+        bld.tape.run()
+        out = from_nhwc(y.buf.reshape(B, H, W, cs_o), Cout)
+        err = max_err(out, ref)
+        assert err < conv_tol(C0 + C1, 3, wino) * max(1.0, ref.abs().max().item()), (case, B, H, W, C0, C1, Cout, act, err)
+
+
+@pytest.mark.parametrize("wino", [False, True, 4])
 def test_conv2d_concat_upsample_narrow_gate_res(az, wino):
     """cat((y, upsample(x)[narrowed])) -> conv -> x0 + c * silu-free epilogue, as azula/nn/unet.py:253-257,93."""
     from azula_amd.engine import Act, Builder
