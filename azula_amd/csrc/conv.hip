@@ -131,6 +131,33 @@ __device__ __forceinline__ void epilogue_store(const AzConvArgs& a, int n, int c
   }
 }
 
+// Epilogue of a 2 x 2 arrangement of 32x32 MFMA accumulators (wave sub-tile 64 couts x 64 pixels): the lane holds,
+// for pixel (lane & 31) of each pixel tile, channels ct*32 + 8*q + 4*(lane >> 5) + [0, 4) in registers 4q .. 4q+3
+// (the C/D layout of the 32x32 MFMAs is the same for f32, bf16 and f16 operands).
+__device__ __forceinline__ void store_acc_tiles(const ConvP& p, const f32x16 (&acc)[2][2], int m0, int n0, int wc, int wp,
+                                                int lane) {
+  const AzConvArgs& a = p.a;
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const int n = n0 + wp * 64 + pt * 32 + (lane & 31);
+    if (n >= p.npix) continue;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = m0 + wc * 64 + ct * 32 + 8 * q + 4 * (lane >> 5);
+        if (co >= a.cout_s) continue;
+        const float4 v =
+            make_float4(acc[ct][pt][4 * q + 0], acc[ct][pt][4 * q + 1], acc[ct][pt][4 * q + 2], acc[ct][pt][4 * q + 3]);
+        if (a.splitk > 1)
+          *reinterpret_cast<float4*>(a.workspace + ((int64_t)blockIdx.y * p.npix + n) * a.cout_s + co) = v;
+        else
+          epilogue_store(a, n, co, v);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * TILE_F];
   const AzConvArgs& a = p.a;
@@ -309,27 +336,209 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds, for pixel (lane & 31) of each pixel tile, channels
-  //      ct*32 + 8*q + 4*(lane >> 5) + [0, 4) in registers 4q .. 4q+3.
+  store_acc_tiles(p, acc, m0, n0, wc, wp, lane);
+}
+
+// =================================================================================================
+// Half-precision-operand variant of the direct kernel, for backbones whose module was cast with .bfloat16() /
+// .half() (the reference's mixed-precision route, azula/denoise.py:314-320): weights are packed once as bf16 / f16,
+// activations stay fp32 in HBM and are rounded to the operand type while they are staged to LDS, products are
+// accumulated in fp32 by v_mfma_f32_32x32x16_{bf16,f16} (16x the fp32 MFMA rate) and the epilogue is the fp32 one.
+// Same tile (128 couts x 128 pixels), K tile = 64 channels of one tap; LDS rows of 64 two-byte values with a 144-byte
+// stride (= the fp32 kernel's 36-dword stride: ds_read_b128 fragments stay conflict-free); the accumulator layout of
+// the 32x32 MFMAs is dtype-independent, so the store code is shared with conv_igemm_kernel.
+constexpr int HBK = 64;                 // k tile (input channels of one tap)
+constexpr int HLDS = 72;                // LDS row stride in 2-byte elements (144 B)
+constexpr int HTILE = (BM + BN) * HLDS; // 2-byte elements per stage
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
+  __shared__ __attribute__((aligned(16))) unsigned short hsm[2 * HTILE];
+  const AzConvArgs& a = p.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wc = wid >> 1;
+  const int wp = wid & 1;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  const int tile_n = wg / p.tiles_m;
+  const int tile_m = wg - tile_n * p.tiles_m;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int kt_begin = blockIdx.y * p.kps;
+  const int kt_end = min(p.nk, kt_begin + p.kps);
+
+  const int hw_out = a.hout * a.wout;
+  const int b_first = n0 / hw_out;
+  const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
+  const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : e); };
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.weight, 0, clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src0 + b_first * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src1 ? a.src1 + b_first * s1_elems : a.src0), 0,
+      a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems * 4) : 0u, 0x00020000);
+
+  // loaders.  Weights: thread -> (16-byte chunk wcc = 8 k-values, rows wr0 + 32 i).  Activations (fp32 in memory):
+  // thread -> (16-byte chunk acc4 = 4 k-values, rows ar0 + 16 i).
+  const int wcc = tid & 7, wr0 = tid >> 3;
+  const int acc4 = tid & 15, ar0 = tid >> 4;
+  unsigned voffW[4];
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
-    const int n = n0 + wp * 64 + pt * 32 + (lane & 31);
-    if (n >= p.npix) continue;
+  for (int i = 0; i < 4; ++i) {
+    const int co = m0 + wr0 + 32 * i;
+    voffW[i] = co < a.cout_s ? (unsigned)((co * p.cin_s + wcc * 8) * 2) : OOB;
+  }
+  int prel[8], ihb[8], iwb[8];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+  for (int i = 0; i < 8; ++i) {
+    const int n = n0 + ar0 + 16 * i;
+    const bool pv = n < p.npix;
+    const int nn = pv ? n : 0;
+    const int b = nn / hw_out;
+    const int rem = nn - b * hw_out;
+    const int oh = rem / a.wout;
+    prel[i] = pv ? b - b_first : -1;
+    ihb[i] = oh * a.stride - a.pad;
+    iwb[i] = (rem - oh * a.wout) * a.stride - a.pad;
+  }
+
+  const int nk_tap = p.nkc0 + p.nkc1;
+  int it_tap = kt_begin / nk_tap;
+  int it_r = kt_begin - it_tap * nk_tap;
+  int it_src = it_r >= p.nkc0 ? 1 : 0;
+  int it_kc = it_src ? it_r - p.nkc0 : it_r;
+  unsigned voffA[8];
+  auto set_tap_src = [&]() __attribute__((always_inline)) {
+    const int ky = it_tap / a.ksize;
+    const int kx = it_tap - ky * a.ksize;
+    const int cs = it_src ? a.c1s : a.c0s;
+    const int up = it_src ? a.up1 : a.up0;
+    const int hs = it_src ? a.h1 : a.h0;
+    const int ws = it_src ? a.w1 : a.w0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = m0 + wc * 64 + ct * 32 + 8 * q + 4 * (lane >> 5);
-        if (co >= a.cout_s) continue;
-        const float4 v =
-            make_float4(acc[ct][pt][4 * q + 0], acc[ct][pt][4 * q + 1], acc[ct][pt][4 * q + 2], acc[ct][pt][4 * q + 3]);
-        if (a.splitk > 1)
-          *reinterpret_cast<float4*>(a.workspace + ((int64_t)blockIdx.y * p.npix + n) * a.cout_s + co) = v;
-        else
-          epilogue_store(a, n, co, v);
+    for (int i = 0; i < 8; ++i) {
+      const int ih = ihb[i] + ky;
+      const int iw = iwb[i] + kx;
+      const bool ok = prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
+      const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> up);
+      voffA[i] = ok ? (unsigned)((pix * cs + acc4 * 4) * 4) : OOB;
+    }
+  };
+
+  float4 ra[4];  // 8 two-byte weights each
+  float4 rb[8];  // 4 fp32 activations each
+  auto load_tile = [&]() __attribute__((always_inline)) {
+    const int cs = it_src ? a.c1s : a.c0s;
+    const int kbase = it_kc * HBK;
+    const int kglob = (it_src ? a.c0s : 0) + kbase;
+    const unsigned soffW = (unsigned)(((int64_t)it_tap * a.cout_s * p.cin_s + kglob) * 2);
+    const unsigned soffA = (unsigned)(kbase * 4);
+    const bool kv = kbase + acc4 * 4 < cs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = buf_ld4(rw, voffW[i], soffW);
+    if (it_src) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rb[i] = buf_ld4(rs1, kv ? voffA[i] : OOB, soffA);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rb[i] = buf_ld4(rs0, kv ? voffA[i] : OOB, soffA);
+    }
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    ++it_kc;
+    if (it_kc == (it_src ? p.nkc1 : p.nkc0)) {
+      it_kc = 0;
+      ++it_src;
+      if (it_src == 2 || p.nkc1 == 0) {
+        it_src = 0;
+        ++it_tap;
+      }
+      set_tap_src();
+    }
+  };
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    unsigned short* As = hsm + buf * HTILE;
+    unsigned short* Bs = As + BM * HLDS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(As + (wr0 + 32 * i) * HLDS + wcc * 8) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4v v = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+      if constexpr (F16) {
+        const f16x4 hv = __builtin_convertvector(v, f16x4);
+        *reinterpret_cast<f16x4*>(Bs + (ar0 + 16 * i) * HLDS + acc4 * 4) = hv;
+      } else {
+        const bf16x4 hv = __builtin_convertvector(v, bf16x4);
+        *reinterpret_cast<bf16x4*>(Bs + (ar0 + 16 * i) * HLDS + acc4 * 4) = hv;
       }
     }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment: row = lane & 31, the lane half (lane >> 5) picks which 8 of the 16 k-values of a K-step
+  const int frag_off = (lane & 31) * HLDS + (lane >> 5) * 8;
+
+  if (kt_begin < kt_end) {
+    set_tap_src();
+    load_tile();
+    store_tile(0);
   }
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    if (more) {
+      advance();
+      load_tile();
+    }
+    const unsigned short* As = hsm + buf * HTILE + (wc * 64) * HLDS + frag_off;
+    const unsigned short* Bs = hsm + buf * HTILE + BM * HLDS + (wp * 64) * HLDS + frag_off;
+#pragma unroll
+    for (int ks = 0; ks < HBK / 16; ++ks) {
+      if constexpr (F16) {
+        const f16x8 a0 = *reinterpret_cast<const f16x8*>(As + ks * 16);
+        const f16x8 a1 = *reinterpret_cast<const f16x8*>(As + 32 * HLDS + ks * 16);
+        const f16x8 b0 = *reinterpret_cast<const f16x8*>(Bs + ks * 16);
+        const f16x8 b1 = *reinterpret_cast<const f16x8*>(Bs + 32 * HLDS + ks * 16);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+      } else {
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(As + ks * 16);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(As + 32 * HLDS + ks * 16);
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bs + ks * 16);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bs + 32 * HLDS + ks * 16);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  store_acc_tiles(p, acc, m0, n0, wc, wp, lane);
 }
 
 // Split-K combine + epilogue: one thread per (pixel, 4 channels).
@@ -986,7 +1195,17 @@ int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_
   return (int)want;
 }
 
-int az_conv2d_f32(const AzConvArgs* a, az_stream_t stream) {
+static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half /* 0 fp32, 1 bf16, 2 f16 operands */);
+
+int az_conv2d_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 0); }
+
+/* Same operation with bf16 / f16 MFMA operands and fp32 accumulation: `weight` is the 2-byte packing of
+ * az_pack_conv_weight_half_f32, activations and outputs stay fp32 (rounded to the operand type inside the kernel).
+ * For modules cast to half precision (azula/denoise.py:314-320); error ~2^-9 (bf16) / 2^-12 (f16) per product.   */
+int az_conv2d_bf16_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 1); }
+int az_conv2d_f16_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 2); }
+
+static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout > 0 && a->wout > 0, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
@@ -1013,8 +1232,9 @@ int az_conv2d_f32(const AzConvArgs* a, az_stream_t stream) {
   p.a = *a;
   p.npix = (int)npix64;
   p.cin_s = a->c0s + a->c1s;
-  p.nkc0 = (a->c0s + BK - 1) / BK;
-  p.nkc1 = (a->c1s + BK - 1) / BK;
+  const int bk = half ? HBK : BK;
+  p.nkc0 = (a->c0s + bk - 1) / bk;
+  p.nkc1 = (a->c1s + bk - 1) / bk;
   p.nk = a->ksize * a->ksize * (p.nkc0 + p.nkc1);
   // 32-bit relative byte offsets inside the kernel: a pixel tile spans at most
   // ceil(BN / (hout*wout)) + 1 samples of either source.
@@ -1035,7 +1255,12 @@ int az_conv2d_f32(const AzConvArgs* a, az_stream_t stream) {
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   AZ_REQUIRE(nwg < (1ll << 31), AZ_E_SHAPE);
   hipStream_t st = az_s(stream);
-  hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
+  if (half == 1)
+    hipLaunchKernelGGL(conv_igemm_half_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
+  else if (half == 2)
+    hipLaunchKernelGGL(conv_igemm_half_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
   int rc = az_launch_status();
   if (rc != AZ_OK) return rc;
   if (splitk > 1) {

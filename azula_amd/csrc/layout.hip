@@ -65,6 +65,36 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(float* __restrict
   }
 }
 
+// Two-byte packing of the same [tap][co][ci_packed] layout for the bf16 / f16 MFMA kernel (round to nearest even).
+template <bool F16>
+__global__ __launch_bounds__(256) void pack_conv_weight_half_kernel(unsigned short* __restrict__ dst,
+                                                                    const float* __restrict__ src, int cout, int cin,
+                                                                    int taps, int cout_s, int cin0, int c0s, int cin_s) {
+  const int64_t total = (int64_t)taps * cout_s * cin_s;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int cip = (int)(e % cin_s);
+    const int co = (int)((e / cin_s) % cout_s);
+    const int tap = (int)(e / ((int64_t)cin_s * cout_s));
+    int ci = -1;
+    if (cip < c0s) {
+      if (cip < cin0) ci = cip;
+    } else {
+      const int r = cip - c0s;
+      if (r < cin - cin0) ci = cin0 + r;
+    }
+    float v = 0.f;
+    if (ci >= 0 && co < cout) v = src[((int64_t)co * cin + ci) * taps + tap];
+    if (F16) {
+      const _Float16 h = (_Float16)v;
+      dst[e] = __builtin_bit_cast(unsigned short, h);
+    } else {
+      const __bf16 h = (__bf16)v;
+      dst[e] = __builtin_bit_cast(unsigned short, h);
+    }
+  }
+}
+
 // Winograd F(2x2,3x3) filter transform U = G g G^T (accumulated in fp64, rounded once) written
 // directly in the layout conv_winograd_kernel streams: [8-cin chunk][64-cout block][16][64][8].
 __global__ __launch_bounds__(256) void winograd_filter_kernel(float* __restrict__ dst, const float* __restrict__ src,
@@ -177,6 +207,21 @@ int az_pack_conv_weight_f32(float* dst, const float* src, int32_t cout, int32_t 
   const int64_t total = (int64_t)ks * ks * cout_s * cin_s;
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream), dst, src,
                      cout, cin, ks * ks, cout_s, cin0, c0s, cin_s);
+  return az_launch_status();
+}
+
+int az_pack_conv_weight_half_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t ks, int32_t cout_s,
+                                 int32_t cin0, int32_t c0s, int32_t cin_s, int32_t f16, az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(cout > 0 && cin > 0 && ks > 0 && cout_s >= cout && cout_s % 4 == 0 && cin_s % 4 == 0, AZ_E_SHAPE);
+  AZ_REQUIRE(cin0 >= 0 && cin0 <= cin && c0s >= cin0 && cin_s >= c0s + (cin - cin0), AZ_E_SHAPE);
+  const int64_t total = (int64_t)ks * ks * cout_s * cin_s;
+  if (f16)
+    hipLaunchKernelGGL(pack_conv_weight_half_kernel<true>, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream),
+                       (unsigned short*)dst, src, cout, cin, ks * ks, cout_s, cin0, c0s, cin_s);
+  else
+    hipLaunchKernelGGL(pack_conv_weight_half_kernel<false>, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream),
+                       (unsigned short*)dst, src, cout, cin, ks * ks, cout_s, cin0, c0s, cin_s);
   return az_launch_status();
 }
 

@@ -149,6 +149,7 @@ class ConvWeights:
             self.bias = torch.zeros(self.cout_s, dtype=torch.float32, device=bld.device)
             self.bias[: self.cout] = bias.detach().to(device=bld.device, dtype=torch.float32)
         self._direct = self._wino = self._wino4 = None
+        self._half: dict = {}
 
     def direct(self) -> torch.Tensor:
         r"""[tap][cout_s][cin_s] (K contiguous), zero padded (az_pack_conv_weight_f32)."""
@@ -161,6 +162,18 @@ class ConvWeights:
             )
             self._direct = packed
         return self._direct
+
+    def direct_half(self, f16: bool) -> torch.Tensor:
+        r"""The direct layout in bf16 (``f16=False``) or IEEE half, for ``az_conv2d_{bf16,f16}_f32``."""
+        if f16 not in self._half:
+            cin_s = self.c0s + self.c1s
+            packed = torch.empty(self.ks * self.ks * self.cout_s * cin_s, dtype=torch.int16, device=self.device)
+            _lib.call(
+                "az_pack_conv_weight_half_f32", packed.data_ptr(), self.w.data_ptr(), self.cout, self.cin, self.ks,
+                self.cout_s, self.cin0, self.c0s, cin_s, int(f16), _lib.stream_ptr(),
+            )
+            self._half[f16] = packed
+        return self._half[f16]
 
     def winograd(self) -> torch.Tensor:
         r"""Filter transform U = G g G^T (az_winograd_pack_filter_f32: fp64 accumulate, one-off) laid out
@@ -195,8 +208,11 @@ class ConvWeights:
 class Builder:
     r"""Emits kernels onto a tape; owns the pool, packed weights and the split-K workspace."""
 
-    def __init__(self, device: torch.device) -> None:
+    def __init__(self, device: torch.device, half: torch.dtype | None = None) -> None:
+        r"""``half``: torch.bfloat16 / torch.float16 routes every conv / token GEMM through the half-operand MFMA
+        kernel (fp32 accumulate, fp32 activations) -- set by the plans of modules cast to half precision."""
         self.device = device
+        self.half = half if half in (torch.bfloat16, torch.float16) else None
         self.tape = Tape()
         self.pool = Pool(device)
         self._ws_need = 0
@@ -290,7 +306,7 @@ class Builder:
         npix = B * hout * wout
         cin_s = a.c0s + a.c1s
         lib = _lib.lib()
-        legal = ks == 3 and stride == 1
+        legal = ks == 3 and stride == 1 and self.half is None  # half-precision modules: the direct bf16 / f16 kernel
         tiles4 = B * ((hout + 3) // 4) * ((wout + 3) // 4)
         use_f4 = legal and (winograd == 4 or (winograd is None and WINOGRAD == "4" and tiles4 >= WINOGRAD4_MIN_TILES))
         use_wino = legal and not use_f4 and ((WINOGRAD != "0") if winograd is None else bool(winograd))
@@ -306,6 +322,10 @@ class Builder:
         elif use_wino:
             a.weight = packed.winograd().data_ptr()
             name = "az_conv2d_winograd_f32"
+        elif self.half is not None:
+            a.weight = packed.direct_half(self.half == torch.float16).data_ptr()
+            a.splitk = lib.az_conv2d_suggest_splitk(npix, a.cout_s, cin_s, ks)
+            name = "az_conv2d_f16_f32" if self.half == torch.float16 else "az_conv2d_bf16_f32"
         else:
             a.weight = packed.direct().data_ptr()
             a.splitk = lib.az_conv2d_suggest_splitk(npix, a.cout_s, cin_s, ks)

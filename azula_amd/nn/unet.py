@@ -101,7 +101,7 @@ class UNetPlan:
 
     def __init__(self, net: "UNet", B: int, H: int, W: int, mod_rows: int, device: torch.device) -> None:
         self.B, self.H, self.W = B, H, W
-        bld = self.bld = Builder(device)
+        bld = self.bld = Builder(device, half=next(net.parameters()).dtype)
         cin = net.in_channels + net.cond_channels
         D = net.mod_features
         self.x_in = Act(torch.empty(B * H * W * pad4(cin), dtype=torch.float32, device=device), B, H, W, cin, pad4(cin), True)

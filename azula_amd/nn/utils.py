@@ -56,9 +56,10 @@ def backbone_io_dtype(module: torch.nn.Module, x: torch.Tensor, who: str) -> tor
 
     fp32 modules take fp32 inputs.  A module cast with ``.half()`` / ``.bfloat16()`` (the reference's mixed-precision
     route: the denoiser casts ``c_in x_t`` to the backbone's dtype and the output back, ``azula/denoise.py:314-320``)
-    is accepted too: its parameters are up-converted ONCE when the plan is built and all arithmetic stays fp32 --
-    there are no fp16 kernels yet, so this path is as fast as fp32 and its result is within the reference's own
-    fp16-vs-fp32 tolerance (``tests/test_nn_unet.py:78-91``) of both the fp16 and the fp32 reference output."""
+    is accepted too: every convolution / token GEMM of its plan then runs on ``v_mfma_f32_32x32x16_{bf16,f16}`` with
+    weights packed in the module's dtype, fp32 accumulation and fp32 activations (``az_conv2d_{bf16,f16}_f32``);
+    norms, attention and the small modulation linears stay fp32 on up-converted parameters.  The result is within the
+    reference's own fp16-vs-fp32 tolerance (``tests/test_nn_unet.py:78-91``) of the fp32 output."""
     if not x.is_cuda:
         raise RuntimeError(
             f"{who} executes only on an AMD GPU (gfx950 HIP kernels); there is no CPU fallback. "

@@ -108,7 +108,7 @@ class DiTPlan:
     r"""Compiled forward for (batch, tokens[, patch geometry], modulation rows)."""
 
     def __init__(self, net: "DiT", B: int, L: int, pos: Tensor, mod_rows: int, device, patch=None) -> None:
-        bld = self.bld = Builder(device)
+        bld = self.bld = Builder(device, half=next(net.parameters()).dtype)
         D, C_ = net.mod_features, net.hid_channels
         self.mod = torch.empty(max(mod_rows, 1), max(D, 1), dtype=torch.float32, device=device)
         self.mod_rows = mod_rows

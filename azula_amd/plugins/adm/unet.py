@@ -91,7 +91,7 @@ class ADMPlan:
 
     def __init__(self, net: "UNetModel", B: int, H: int, W: int, emb_rows: int, device, x_in: Act | None = None,
                  coef_ptr: int | None = None) -> None:
-        bld = self.bld = Builder(device)
+        bld = self.bld = Builder(device, half=next(net.parameters()).dtype)
         mc, E = net.model_channels, 4 * net.model_channels
         self.versions = net._param_versions()
         self.emb_rows = emb_rows

@@ -120,7 +120,7 @@ class JiTPlan:
     r"""Compiled forward for one (batch, shared/per-sample time) signature."""
 
     def __init__(self, net: "JiT", B: int, t_shared: bool, device) -> None:
-        bld = self.bld = Builder(device)
+        bld = self.bld = Builder(device, half=net.pos_embed.dtype)
         Hd, heads, p, Z = net.hidden_size, net.num_heads, net.patch_size, net.in_channels
         S = net.input_size
         grid = S // p

@@ -112,6 +112,9 @@ def build_denoiser(cfg, device):
     return KarrasDenoiser(wrapped, VPSchedule()).to(device).eval()
 
 
+CONV_OPS = ("az_conv2d_f32", "az_conv2d_winograd_f32", "az_conv2d_winograd4_f32", "az_conv2d_bf16_f32", "az_conv2d_f16_f32")
+
+
 def conv_roofline(sampler, device):
     r"""Per-launch HIP-event timing of the dominant kernel (conv_igemm, fp32 MFMA) over one
     backbone forward run eagerly on the launch stream; achieved = sum(flops) / sum(time)."""
@@ -125,7 +128,7 @@ def conv_roofline(sampler, device):
         recs = []
         loop.counter.zero_()
         for fn, args, name in tape.ops:
-            if name in ("az_conv2d_f32", "az_conv2d_winograd_f32"):
+            if name in CONV_OPS:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
                 rc = fn(*args, sptr)
@@ -136,7 +139,7 @@ def conv_roofline(sampler, device):
                 rc = fn(*args, sptr)
             assert rc == 0, (name, rc)
         torch.cuda.synchronize(device)
-    convs = [a[0]._obj for _, a, n in tape.ops if n in ("az_conv2d_f32", "az_conv2d_winograd_f32")]
+    convs = [a[0]._obj for _, a, n in tape.ops if n in CONV_OPS]
     if os.environ.get("AZ_BENCH_DETAIL"):
         for (e0, e1, fl, sk), d in zip(recs, convs):
             t = e0.elapsed_time(e1)
@@ -147,7 +150,8 @@ def conv_roofline(sampler, device):
             )
     out = {}
     for algo in ("az_conv2d_winograd_f32", "az_conv2d_f32"):
-        sel = [(r, d) for r, d in zip(recs, convs) if d._algo == algo]
+        same = (algo,) if algo != "az_conv2d_f32" else ("az_conv2d_f32", "az_conv2d_bf16_f32", "az_conv2d_f16_f32")
+        sel = [(r, d) for r, d in zip(recs, convs) if d._algo in same]
         out[algo] = dict(
             flops=sum(r[2] for r, _ in sel), ms=sum(r[0].elapsed_time(r[1]) for r, _ in sel), launches=len(sel)
         )
@@ -248,6 +252,8 @@ def main() -> None:
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--denoise-steps", type=int, default=0, help="override the config's sampler steps (checks only)")
+    ap.add_argument("--half", choices=["bf16", "f16"], default=None,
+                    help="cast the backbone to half precision (mixed-precision mode; NOT the headline fp32 number)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -269,6 +275,10 @@ def main() -> None:
         cfg["steps"] = args.denoise_steps
         cfg["name"] += f" [steps overridden to {args.denoise_steps}: not a headline number]"
     den = build_denoiser(cfg, device)
+    if args.half:
+        inner = den.denoiser if hasattr(den, "denoiser") else den
+        inner.backbone.to(torch.bfloat16 if args.half == "bf16" else torch.float16)
+        cfg["name"] += f" [backbone cast to {args.half}: MFMA operands {args.half}, fp32 accumulate -- not a headline number]"
     Smp = DDPMSampler if cfg.get("sampler") == "ddpm" else DDIMSampler
     sampler = Smp(den, steps=cfg["steps"], silent=True)
     B = cfg["batch"]
@@ -324,7 +334,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if not args.half else f"{args.half} operands / f32 accumulate",
             "data": "synthetic (random-init weights under seed 0, x1 ~ sampler.init under seed 1)",
             "config": {"workload": cfg["name"], "per_gpu_batch": B, "global_batch": world * B,
                        "denoise_steps": cfg["steps"], "parallelism": f"batch-sharded x{world}, all-gather of x0"},

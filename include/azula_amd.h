@@ -259,6 +259,12 @@ typedef struct AzConvArgs {
   float* workspace;
 } AzConvArgs;
 int az_conv2d_f32(const AzConvArgs* args, az_stream_t stream);
+/* The same operation with bf16 / f16 MFMA operands (v_mfma_f32_32x32x16_{bf16,f16}, 16x the fp32 MFMA rate) and fp32
+ * accumulation, for backbones cast to half precision (azula/denoise.py:314-320 casts c_in x_t to the module dtype;
+ * the reference's own tolerance for that mode is tests/test_nn_unet.py:78-91).  `weight` = az_pack_conv_weight_half_f32
+ * output; src / res / dst stay fp32 tensors -- activations are rounded to the operand type while they are staged.   */
+int az_conv2d_bf16_f32(const AzConvArgs* args, az_stream_t stream);
+int az_conv2d_f16_f32(const AzConvArgs* args, az_stream_t stream);
 /* Winograd F(2x2,3x3) form of the same operation for ksize = 3, stride = 1, pad = 1: 2.25x fewer
  * multiplies in exact fp32 (transforms only add/subtract; the input transform, the 16 frequency
  * GEMMs and the output transform + epilogue are ONE kernel).  `weight` must be the host-side
@@ -339,6 +345,10 @@ int az_patchify_f32(float* dst, const float* src, const float* scale_dev, int64_
                     int64_t p, int64_t cs, az_stream_t stream);
 int az_unpatchify_f32(float* dst, const float* src, int64_t B, int64_t Z, int64_t H, int64_t W, int64_t p, int64_t cs,
                       az_stream_t stream);
+
+/* az_pack_conv_weight_f32's layout in 2-byte elements (f16 != 0: IEEE half, else bfloat16; round to nearest even). */
+int az_pack_conv_weight_half_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t ks, int32_t cout_s,
+                                 int32_t cin0, int32_t c0s, int32_t cin_s, int32_t f16, az_stream_t stream);
 
 /* torch (cout, cin, 3, 3) -> Winograd filter transform U = G g G^T (fp64 accumulate, one rounding) in
  * the layout az_conv2d_winograd_f32 streams: [nk chunks of 8 cin][cblocks of 64 cout][16][64][8]; input

@@ -500,3 +500,31 @@ def test_graph_capture_replay(az):
         graph.launch()
     torch.cuda.synchronize()
     assert (x == 4.0**4).all()
+
+
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks,stride", CONV_CASES + [(2, 768, 2304, 16, 16, 1, 1), (1, 200, 72, 11, 9, 3, 1)])
+def test_conv2d_half_operands(az, B, Cin, Cout, H, W, ks, stride, half):
+    """az_conv2d_{bf16,f16}_f32: bf16 / f16 MFMA operands, fp32 accumulation.  Checked against an fp64 convolution of the
+    SAME rounded operands (the only remaining difference is fp32 accumulation order), and against the unrounded fp32
+    result with the operand-rounding bound."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(Cin * Cout + H + ks)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    b = torch.randn(Cout, generator=g)
+    bld = Builder(torch.device("cuda"), half=half)
+    xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, (Cin + 3) // 4 * 4, True)
+    y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, stride=stride)
+    assert bld.tape.ops[-1][2] == ("az_conv2d_bf16_f32" if half == torch.bfloat16 else "az_conv2d_f16_f32")
+    bld.finish()
+    bld.tape.run()
+    out = from_nhwc(y.buf.reshape(B, y.H, y.W, y.cs), Cout)
+    xr, wr = x.to(half).double(), w.to(half).double()
+    exact = F.conv2d(xr, wr, b.double(), stride=stride, padding=ks // 2).float()
+    assert max_err(out, exact) < conv_tol(Cin, ks), max_err(out, exact)
+    ref = F.conv2d(x, w, b, stride=stride, padding=ks // 2)
+    eps = 2.0**-8 if half == torch.bfloat16 else 2.0**-11
+    assert max_err(out, ref) < 4 * eps * max(1.0, ref.abs().max().item())
+    assert (y.buf.reshape(B, y.H, y.W, y.cs)[..., Cout:] == 0).all()
