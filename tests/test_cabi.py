@@ -48,7 +48,8 @@ def test_python_prototypes_match_header(built_lib):
 def test_struct_layouts_match_c():
     from azula_amd import _lib
 
-    names = ["AzStepCoef", "AzTransitionArgs", "AzNormFinalizeArgs", "AzConvArgs", "AzAttnArgs"]
+    names = ["AzStepCoef", "AzTransitionArgs", "AzMultistepArgs", "AzLinearGroup", "AzNormFinalizeArgs", "AzConvArgs",
+             "AzAttnArgs"]
     prog = '#include <stdio.h>\n#include "azula_amd.h"\nint main(void){' + "".join(
         f'printf("%zu\\n", sizeof({n}));' for n in names
     ) + "return 0;}"
@@ -68,3 +69,26 @@ def test_missing_library_is_loud(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libazula_amd.so")
     with pytest.raises(_lib.AzulaAmdError, match="no CPU/eager fallback"):
         _lib.lib()
+
+
+def test_argument_errors_are_returned_not_raised(built_lib):
+    """Every entry point validates its arguments BEFORE touching the device and reports through its int status
+    (never throws, never exits) -- checkable without a GPU.  Negative codes are AZ_E_*; az_error_string names them."""
+    from azula_amd import _lib
+
+    lib = _lib.lib()
+    assert lib.az_scale_f32(None, None, None, 16, None) == -1  # AZ_E_NULL
+    assert lib.az_axpby_f32(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0, 16, 0, None) == -2  # rows == 0: AZ_E_SHAPE
+    att = _lib.AzAttnArgs(q=0x1000, k=0x1000, v=0x1000, out=0x1000, batch=1, heads=1, tokens=8, head_dim=48)
+    assert lib.az_attention_f32(ctypes.byref(att), None) == -4  # head_dim 48: AZ_E_UNSUPPORTED
+    conv = _lib.AzConvArgs(src0=0x1008, weight=0x1000, dst=0x1000, c0s=8, cout_s=8, batch=1, hin=4, win=4, hout=4, wout=4,
+                           ksize=3, stride=1, pad=1, splitk=1, h0=4, w0=4)
+    assert lib.az_conv2d_f32(ctypes.byref(conv), None) == -3  # src0 not 16-byte aligned: AZ_E_ALIGN
+    conv.src0, conv.stride = 0x1000, 2
+    assert lib.az_conv2d_winograd_f32(ctypes.byref(conv), None) == -4  # Winograd is stride 1 only
+    ms = _lib.AzMultistepArgs(x_s=0x1000, pred=0x1000, x_t=0x1000, mean=0x1000, coef=0x1000, count=16, n_hist=9)
+    assert lib.az_multistep_f32(ctypes.byref(ms), None) == -2
+    for code, word in ((-1, b"NULL"), (-2, b"shape"), (-3, b"align"), (-4, b"unsupported")):
+        assert word.lower() in lib.az_error_string(code).lower()
+    with pytest.raises(_lib.AzulaAmdError, match="az_scale_f32"):
+        _lib.call("az_scale_f32", None, None, None, 16, None)
