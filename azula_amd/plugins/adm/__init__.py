@@ -9,6 +9,8 @@ Reference: ``azula/plugins/adm/__init__.py:33-202`` (Dhariwal & Nichol, 2021).
 
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from collections.abc import Sequence
@@ -139,6 +141,10 @@ class AblatedDenoiser(Denoiser):
         if not isinstance(bb, unet.UNetModel) or x.ndim != 4 or get_module_dtype(bb) not in (torch.float32, torch.float16, torch.bfloat16):
             return None
         B, _, H, W = x.shape
+        if len(kwargs_list) == 2 and bb.num_classes is not None and os.environ.get("AZ_CFG_BATCHED", "1") != "0":
+            batched = self._az_cfg_batched(x, kwargs_list, cur_coef)
+            if batched is not None:
+                return batched
         programs, x_in = [], None
         for i, kw in enumerate(kwargs_list):
             if set(kw) - {"label"}:
@@ -162,6 +168,36 @@ class AblatedDenoiser(Denoiser):
             prog.tape.keep.append(plan)
             programs.append(prog)
         return programs
+
+    def _az_cfg_batched(self, x: Tensor, kwargs_list: list[dict], cur_coef: Tensor):
+        r"""Classifier-free guidance as ONE backbone evaluation on a 2B batch: samples [0, B) carry the
+        positive labels, [B, 2B) the negative ones; the transition kernel fills the first half of the input, one copy
+        duplicates it, and the two halves of the output are its ``F`` / ``F_neg``.  Same arithmetic per sample as two
+        sequential evaluations (the reference's ``cfg.py:60-61``), but the small feature maps fill the chip better."""
+        from ...engine import Tape
+        from ...nn.unet import _copy_tape
+        from ...sample import BackboneProgram
+
+        bb = self.backbone
+        if any(set(kw) - {"label"} or kw.get("label") is None for kw in kwargs_list):
+            return None
+        B, _, H, W = x.shape
+        plan = bb.plan(2 * B, H, W, 2 * B, x.device, coef_ptr=cur_coef.data_ptr(), tag="cfg2b")
+        half_in = B * H * W * plan.x_in.cs
+        one = torch.ones(1, dtype=torch.float32, device=x.device)
+        tape = Tape()
+        tape.add("az_scale_f32", plan.x_in.ptr + 4 * half_in, plan.x_in.ptr, one.data_ptr(), half_in, keep=[one, plan])
+        tape.extend(_copy_tape(plan.tape))
+
+        def prepare(call_kwargs: dict, key: int) -> None:
+            lab = call_kwargs.get("_az_labels", {}).get(key)
+            plan.labels[key * B : (key + 1) * B].copy_(lab.to(torch.int64))
+
+        common = dict(x_in=plan.x_in.buf, x_in_cs=plan.x_in.cs, f_channels=bb.out_channels, f_nhwc=False)
+        return [
+            BackboneProgram(tape=tape, out=plan.out[:B], prepare=lambda kw: prepare(kw, 0), **common),
+            BackboneProgram(tape=Tape(), out=plan.out[B:], prepare=lambda kw: prepare(kw, 1), **common),
+        ]
 
     def _az_fused(self, x: Tensor, kwargs: dict, cur_coef: Tensor):
         from ...sample import FusedDenoiser

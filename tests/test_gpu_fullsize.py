@@ -121,7 +121,9 @@ def test_adm_256_cfg_full_size_properties():
     assert next(iter(smp._fused_cache.values())).graph is not None
     scale = max(1.0, ref.abs().max().item())
     print("ADM-256 CFG(g=0) vs conditional max|d|", max_err(g0, ref), "scale", scale)
-    assert max_err(g0, ref) < 5e-5 * scale
+    # the guided run evaluates both label sets as ONE 2B batch (other tile / split-K choices than the batch-B plan);
+    # ADM's c_out = -100 at t = 1 amplifies those fp32 round-off differences: the ADM trajectory bound applies
+    assert max_err(g0, ref) < 1e-3 * scale
     one = DDIMSampler(plain, steps=STEPS, silent=True)(x1[1:], label=lab[1:])
     # a batch of 1 takes other split-K / tile choices; ADM's c_out = -sigma/alpha = -100 at t = 1 amplifies the fp32
     # round-off differences of the backbone (the same 1e-3 bound as the ADM trajectory tests)
