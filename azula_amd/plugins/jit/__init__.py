@@ -82,6 +82,29 @@ class JITDenoiser(Denoiser):
         if not isinstance(bb, JiT) or x.ndim != 4 or get_module_dtype(bb) not in (torch.float32, torch.float16, torch.bfloat16):
             return None
         B = x.shape[0]
+        if len(kwargs_list) == 2 and os.environ.get("AZ_CFG_BATCHED", "1") != "0" and not any(set(kw) - {"label"} for kw in kwargs_list):
+            # classifier-free guidance as ONE evaluation on a 2B batch: [0, B) positive labels, [B, 2B) negative / null
+            from .model import JiTPlan
+
+            plan = JiTPlan(bb, 2 * B, True, x.device)
+            half = plan.x_nchw[:B].numel()
+            tape = Tape()
+            tape.add("az_coef_c_time_f32", plan.t.data_ptr(), cur_coef.data_ptr())
+            tape.add("az_scale_f32", plan.x_nchw.data_ptr() + 4 * half, plan.x_nchw.data_ptr(), _one(x.device).data_ptr(), half)
+            tape.extend(_copy_tape(plan.tape))
+            tape.keep.append(plan)
+
+            def prepare2(call_kwargs: dict, key: int) -> None:
+                lab = call_kwargs.get("_az_labels", {}).get(key)
+                if lab is None:
+                    lab = torch.as_tensor(self.num_classes)
+                plan.labels[key * B : (key + 1) * B].copy_(lab.to(device=plan.labels.device, dtype=torch.int64).expand(B))
+
+            common = dict(x_in=plan.x_nchw[:B], x_in_cs=0, f_channels=bb.out_channels, f_nhwc=False)
+            return [
+                BackboneProgram(tape=tape, out=plan.out[:B], prepare=lambda kw: prepare2(kw, 0), **common),
+                BackboneProgram(tape=Tape(), out=plan.out[B:], prepare=lambda kw: prepare2(kw, 1), **common),
+            ]
         programs, x_in = [], None
         for i, kw in enumerate(kwargs_list):
             if set(kw) - {"label"}:
