@@ -249,6 +249,261 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
   }
 }
 
+// =================================================================================================
+// Half-precision-operand attention for backbones cast to bf16 / f16 (the conv / GEMM counterpart is
+// conv_igemm_half_kernel): q, k, v and the output stay fp32 tensors; the q/k RMS norms, gains, RoPE and the online
+// softmax run in fp32; the two contractions use v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation.
+//   S^T = K Q^T : A = K rows from LDS (bf16 [key][D+8]), B = the lane's query (D/16 fragments of 8 values, registers)
+//   O^T += V^T P^T : B = the lane's own probabilities -- registers 8s .. 8s+7 of the S^T tile are 8 keys of one
+//       query, i.e. exactly one B fragment if the MFMA's k index is mapped to keys as the C layout orders them;
+//       A = V^T from LDS, stored TRANSPOSED [d][key position] with the keys of every 32-key tile permuted by that
+//       same map (position 16 (r>>3) + 8 h + (r&7) holds key (r&3) + 8 (r>>2) + 4 h), so a fragment is one 16-byte read.
+// With the matrix work 16x cheaper the exponentials bound the kernel: the half mode uses the hardware exp2.
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 abf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 af16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 af16x4 __attribute__((ext_vector_type(4)));
+typedef float af32x8 __attribute__((ext_vector_type(8)));
+typedef float af32x4 __attribute__((ext_vector_type(4)));
+
+template <bool F16>
+struct HalfT {
+  using x8 = abf16x8;
+  using x4 = abf16x4;
+  using x1 = __bf16;
+};
+template <>
+struct HalfT<true> {
+  using x8 = af16x8;
+  using x4 = af16x4;
+  using x1 = _Float16;
+};
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_half(typename HalfT<F16>::x8 a, typename HalfT<F16>::x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int D, bool F16>
+__global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
+  using H8 = typename HalfT<F16>::x8;
+  using H4 = typename HalfT<F16>::x4;
+  using H1 = typename HalfT<F16>::x1;
+  constexpr int DP = (D + 31) / 32 * 32;
+  constexpr int DT = DP / 32;
+  constexpr int KS = D / 16;        // K-steps of the QK^T contraction
+  constexpr int KLS = D + 8;        // K tile row stride (2-byte elements)
+  constexpr int VLS = KT + 8;       // V^T tile row stride
+  __shared__ __attribute__((aligned(16))) unsigned short hsm[KT * KLS + DP * VLS];
+  H1* Ks = reinterpret_cast<H1*>(hsm);
+  H1* Vt = Ks + KT * KLS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int h2 = lane >> 5;
+  const int ql = lane & 31;
+  const int bh = blockIdx.y;
+  const int b = bh / a.heads;
+  const int hd = bh - b * a.heads;
+  const int T = a.tokens;
+  const int qi = blockIdx.x * QT + wave * 32 + ql;
+
+  const float* qp = a.q + (int64_t)b * a.q_bstride + (int64_t)hd * a.q_hstride;
+  const float* kp = a.k + (int64_t)b * a.k_bstride + (int64_t)hd * a.k_hstride;
+  const float* vp = a.v + (int64_t)b * a.v_bstride + (int64_t)hd * a.v_hstride;
+
+  // zero V^T once: rows d >= D (padding of the last 32-wide output tile) are never written again
+  for (int e = tid; e < DP * VLS / 2; e += 256) reinterpret_cast<unsigned*>(Vt)[e] = 0u;
+
+  // ---- Q fragments: lane holds q[qi][16 ks + 8 h2 + (0..7)], scaled (and RMS-normalised, gained, rotated) in fp32
+  H8 qf[KS];
+  {
+    float qv[KS][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qi < T) v = *reinterpret_cast<const float4*>(qp + (int64_t)qi * a.q_tstride + 16 * ks + 8 * h2 + 4 * hh);
+        qv[ks][4 * hh + 0] = v.x;
+        qv[ks][4 * hh + 1] = v.y;
+        qv[ks][4 * hh + 2] = v.z;
+        qv[ks][4 * hh + 3] = v.w;
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    }
+    float f = a.scale;
+    if (a.qk_rmsnorm) {
+      ss += __shfl_xor(ss, 32, 64);
+      f *= rsqrtf(ss / (float)D + a.eps);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = 16 * ks + 8 * h2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        qv[ks][j] *= f;
+        if (a.q_weight != nullptr) qv[ks][j] *= a.q_weight[d0 + j];
+      }
+      if (a.rope_cos != nullptr && qi < T) {
+        const int64_t rb = (int64_t)qi * a.heads * (D / 2) + (int64_t)hd * (D / 2) + d0 / 2;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          const float c = a.rope_cos[rb + pr], sn = a.rope_sin[rb + pr];
+          const float re = qv[ks][2 * pr], im = qv[ks][2 * pr + 1];
+          qv[ks][2 * pr] = re * c - im * sn;
+          qv[ks][2 * pr + 1] = re * sn + im * c;
+        }
+      }
+      const af32x8 v8 = {qv[ks][0], qv[ks][1], qv[ks][2], qv[ks][3], qv[ks][4], qv[ks][5], qv[ks][6], qv[ks][7]};
+      qf[ks] = __builtin_convertvector(v8, H8);
+    }
+  }
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  constexpr int CH = D / 4;
+  constexpr bool POW2 = (CH & (CH - 1)) == 0;
+  constexpr int RW = 64 / CH;
+  constexpr int RPP = POW2 ? 256 / CH : 4 * RW;
+  const int lc = POW2 ? tid % CH : lane % CH;
+  const int lr = POW2 ? tid / CH : wave * RW + lane / CH;
+  const bool lactive = POW2 || lane < RW * CH;
+  constexpr float LOG2E = 1.4426950408889634f;
+
+  for (int k0 = 0; k0 < T; k0 += KT) {
+    __syncthreads();  // previous tile fully consumed (and, first time, the V^T zero fill is complete)
+#pragma unroll
+    for (int rr = 0; rr < KT; rr += RPP) {
+      const int row = rr + lr;
+      if (row < KT && lactive) {
+        const int key = k0 + row;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (key < T) {
+          kv = *reinterpret_cast<const float4*>(kp + (int64_t)key * a.k_tstride + lc * 4);
+          vv = *reinterpret_cast<const float4*>(vp + (int64_t)key * a.v_tstride + lc * 4);
+        }
+        if (a.qk_rmsnorm) {
+          float ss = (kv.x * kv.x + kv.y * kv.y) + (kv.z * kv.z + kv.w * kv.w);
+          if constexpr (POW2) {
+#pragma unroll
+            for (int o = 1; o < CH; o <<= 1) ss += __shfl_xor(ss, o, 64);
+          } else {
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            const int base = (lane / CH) * CH;
+            float tot = 0.f;
+#pragma unroll
+            for (int j = 0; j < CH / 4; ++j) tot += __shfl(ss, base + 4 * j, 64);
+            ss = tot;
+          }
+          const float f = rsqrtf(ss / (float)D + a.eps);
+          kv.x *= f;
+          kv.y *= f;
+          kv.z *= f;
+          kv.w *= f;
+        }
+        if (a.k_weight != nullptr) {
+          const float4 w = *reinterpret_cast<const float4*>(a.k_weight + lc * 4);
+          kv.x *= w.x;
+          kv.y *= w.y;
+          kv.z *= w.z;
+          kv.w *= w.w;
+        }
+        if (a.rope_cos != nullptr && key < T) {
+          const int64_t ro = (int64_t)key * a.heads * (D / 2) + (int64_t)hd * (D / 2) + 2 * lc;
+          const float2 c = *reinterpret_cast<const float2*>(a.rope_cos + ro);
+          const float2 sn = *reinterpret_cast<const float2*>(a.rope_sin + ro);
+          const float r0 = kv.x, i0 = kv.y, r1 = kv.z, i1 = kv.w;
+          kv.x = r0 * c.x - i0 * sn.x;
+          kv.y = r0 * sn.x + i0 * c.x;
+          kv.z = r1 * c.y - i1 * sn.y;
+          kv.w = r1 * sn.y + i1 * c.y;
+        }
+        const af32x4 k4 = {kv.x, kv.y, kv.z, kv.w};
+        *reinterpret_cast<H4*>(Ks + row * KLS + lc * 4) = __builtin_convertvector(k4, H4);
+        // V^T, keys permuted inside their 32-key tile to the order the S^T registers hold them
+        const int kk = row & 31;
+        const int r = (kk & 3) + 4 * (kk >> 3);
+        const int pos = (row & ~31) + 16 * (r >> 3) + 8 * ((kk >> 2) & 1) + (r & 7);
+        const af32x4 v4 = {vv.x, vv.y, vv.z, vv.w};
+        const H4 vh = __builtin_convertvector(v4, H4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Vt[(lc * 4 + j) * VLS + pos] = vh[j];
+      }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int sub = 0; sub < KT / 32; ++sub) {
+      if (k0 + sub * 32 >= T) break;
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      const H1* kr = Ks + (sub * 32 + ql) * KLS + 8 * h2;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) sacc = mfma_half<F16>(*reinterpret_cast<const H8*>(kr + 16 * ks), qf[ks], sacc);
+      float mt = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + sub * 32 + key_of(r, h2);
+        if (key >= T) sacc[r] = -INFINITY;
+        mt = fmaxf(mt, sacc[r]);
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = m_run == -INFINITY ? 0.f : exp2f((m_run - m_new) * LOG2E);
+      float ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = sacc[r] == -INFINITY ? 0.f : exp2f((sacc[r] - m_new) * LOG2E);
+        sacc[r] = pv;
+        ls += pv;
+      }
+      ls += __shfl_xor(ls, 32, 64);
+      l_run = l_run * alpha + ls;
+      m_run = m_new;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const af32x8 p8 = {sacc[8 * s2 + 0], sacc[8 * s2 + 1], sacc[8 * s2 + 2], sacc[8 * s2 + 3],
+                           sacc[8 * s2 + 4], sacc[8 * s2 + 5], sacc[8 * s2 + 6], sacc[8 * s2 + 7]};
+        const H8 pb = __builtin_convertvector(p8, H8);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          const H8 va = *reinterpret_cast<const H8*>(Vt + (ql + 32 * t) * VLS + sub * 32 + 16 * s2 + 8 * h2);
+          oacc[t] = mfma_half<F16>(va, pb, oacc[t]);
+        }
+      }
+    }
+  }
+
+  if (qi < T) {
+    const float inv = 1.f / l_run;
+    float* op = a.out + (int64_t)b * a.o_bstride + (int64_t)hd * a.o_hstride + (int64_t)qi * a.o_tstride;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * t + 8 * g + 4 * h2;
+        if (d < D)
+          *reinterpret_cast<float4*>(op + d) = make_float4(oacc[t][4 * g] * inv, oacc[t][4 * g + 1] * inv,
+                                                            oacc[t][4 * g + 2] * inv, oacc[t][4 * g + 3] * inv);
+      }
+  }
+}
+
 // NCHW (B, Z, H, W) -> tokens (B, L = H/p * W/p, cs) with feature index z*p*p + a*p + b
 // ('... Z (A a) (B b) -> ... A B (Z a b)', azula/nn/layers.py:198-222); optional scale.
 __global__ __launch_bounds__(256) void patchify_kernel(float* __restrict__ dst, const float* __restrict__ src,
@@ -344,7 +599,32 @@ __global__ __launch_bounds__(256) void swiglu_kernel(float* __restrict__ y, cons
 
 }  // namespace
 
+template <bool F16>
+static int attention_half_launch(const AzAttnArgs* a, az_stream_t stream) {
+  AZ_REQUIRE(a && a->q && a->k && a->v && a->out, AZ_E_NULL);
+  AZ_REQUIRE(a->batch > 0 && a->heads > 0 && a->tokens > 0, AZ_E_SHAPE);
+  AZ_REQUIRE(a->head_dim == 16 || a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 80 || a->head_dim == 128,
+             AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(AZ_ALIGNED16(a->q) && AZ_ALIGNED16(a->k) && AZ_ALIGNED16(a->v) && AZ_ALIGNED16(a->out), AZ_E_ALIGN);
+  const int64_t strides[] = {a->q_bstride, a->q_tstride, a->q_hstride, a->k_bstride, a->k_tstride, a->k_hstride,
+                             a->v_bstride, a->v_tstride, a->v_hstride, a->o_bstride, a->o_tstride, a->o_hstride};
+  for (int64_t s : strides) AZ_REQUIRE(s % 4 == 0, AZ_E_ALIGN);
+  dim3 grid((unsigned)((a->tokens + QT - 1) / QT), (unsigned)(a->batch * a->heads));
+  hipStream_t st = az_s(stream);
+  switch (a->head_dim) {
+    case 16: hipLaunchKernelGGL((attention_half_kernel<16, F16>), grid, dim3(256), 0, st, *a); break;
+    case 32: hipLaunchKernelGGL((attention_half_kernel<32, F16>), grid, dim3(256), 0, st, *a); break;
+    case 64: hipLaunchKernelGGL((attention_half_kernel<64, F16>), grid, dim3(256), 0, st, *a); break;
+    case 80: hipLaunchKernelGGL((attention_half_kernel<80, F16>), grid, dim3(256), 0, st, *a); break;
+    default: hipLaunchKernelGGL((attention_half_kernel<128, F16>), grid, dim3(256), 0, st, *a); break;
+  }
+  return az_launch_status();
+}
+
 extern "C" {
+
+int az_attention_bf16_f32(const AzAttnArgs* a, az_stream_t stream) { return attention_half_launch<false>(a, stream); }
+int az_attention_f16_f32(const AzAttnArgs* a, az_stream_t stream) { return attention_half_launch<true>(a, stream); }
 
 int az_attention_f32(const AzAttnArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->q && a->k && a->v && a->out, AZ_E_NULL);

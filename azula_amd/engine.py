@@ -444,7 +444,10 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
         a.q_weight, a.k_weight = qk_weight[0].data_ptr(), qk_weight[1].data_ptr()
         self.tape.keep.extend(qk_weight)
     a._flops = 4 * qkv.B * heads * L * L * dim
-    self.tape.add("az_attention_f32", C.byref(a), keep=[a])
+    name = "az_attention_f32"
+    if self.half is not None:  # module cast to half precision: contractions on the bf16 / f16 MFMA
+        name = "az_attention_f16_f32" if self.half == torch.float16 else "az_attention_bf16_f32"
+    self.tape.add(name, C.byref(a), keep=[a])
     return out
 
 

@@ -319,6 +319,10 @@ typedef struct AzAttnArgs {
   const float* k_weight;
 } AzAttnArgs;
 int az_attention_f32(const AzAttnArgs* args, az_stream_t stream);
+/* The same operation for backbones cast to half precision: q / k / v / out stay fp32 tensors, norms, gains, RoPE and the
+ * online softmax stay fp32, both contractions run on v_mfma_f32_32x32x16_{bf16,f16} (fp32 accumulate); exp via exp2. */
+int az_attention_bf16_f32(const AzAttnArgs* args, az_stream_t stream);
+int az_attention_f16_f32(const AzAttnArgs* args, az_stream_t stream);
 
 /* y[r, c] = x[r, 2c] * silu(x[r, 2c+1]), c < cout (SwiGLU, azula/nn/layers.py:89-110); xs / ys = row strides. */
 int az_swiglu_f32(float* y, const float* x, int64_t rows, int64_t cout, int64_t xs, int64_t ys, az_stream_t stream);

@@ -82,3 +82,45 @@ def test_jit_half_fused_sampling(golden, half):
     rel = (x0 - ref).abs().max().item() / ref.abs().max().item()
     print("jit DDIM-8", half, "rel to fp32 weights", rel)
     assert rel < (2e-2 if half == torch.float16 else 1e-1)
+
+
+@pytest.mark.parametrize("half", HALVES)
+@pytest.mark.parametrize("hd,T,rms,rope", [(64, 256, True, False), (16, 77, False, False), (80, 148, True, True), (32, 130, True, True),
+                                          (128, 64, False, False)])
+def test_attention_half_kernel(half, hd, T, rms, rope):
+    """az_attention_{bf16,f16}_f32 against fp32 SDPA on the same (fp32) q, k, v: '(n H C)' fused-QKV layout, ragged token
+    counts, q/k RMS norm with gains, 2-D rotary tables.  Error budget = operand rounding of q, k, v and P."""
+    import math
+
+    from azula_amd.engine import Builder
+    from oracle import nets
+
+    g = torch.Generator().manual_seed(hd + T)
+    B, heads = 2, 3
+    Cc = heads * hd
+    qkv = torch.randn(B, T, 3 * Cc, generator=g)
+    qw, kw = 1 + 0.2 * torch.randn(hd, generator=g), 1 + 0.2 * torch.randn(hd, generator=g)
+    bld = Builder(torch.device("cuda"), half=half)
+    qa = bld.new_act(B, T, 1, 3 * Cc, pinned=True)
+    qa.buf[: qkv.numel()].copy_(qkv.reshape(-1).cuda())
+    rt = None
+    if rope:
+        ang = torch.rand(T, heads, hd // 2, generator=g) * 6.0
+        rt = (bld.const(torch.cos(ang)), bld.const(torch.sin(ang)))
+    out = bld.attention(qa, heads, "3HC", rms, 1 / math.sqrt(hd), eps=1e-6, rope=rt,
+                        qk_weight=(bld.const(qw), bld.const(kw)) if rms else None)
+    assert bld.tape.ops[-1][2] == ("az_attention_f16_f32" if half == torch.float16 else "az_attention_bf16_f32")
+    bld.finish()
+    bld.tape.run()
+    q, k, v = qkv.reshape(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    if rms:
+        q, k = nets.jit_rms_norm(q, qw), nets.jit_rms_norm(k, kw)
+    if rope:
+        cos = torch.cos(ang).permute(1, 0, 2).repeat_interleave(2, dim=-1)  # (heads, T, hd): pairs share an angle
+        sin = torch.sin(ang).permute(1, 0, 2).repeat_interleave(2, dim=-1)
+        q, k = nets.jit_rotate(q, cos, sin), nets.jit_rotate(k, cos, sin)
+    want = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, T, Cc)
+    err = max_err(out.buf[: want.numel()].view(B, T, Cc), want)
+    tol = (4e-3 if half == torch.float16 else 3e-2) * max(1.0, want.abs().max().item())
+    print(half, hd, T, "max|d|", err, "scale", want.abs().max().item())
+    assert err < tol
