@@ -25,7 +25,6 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from .. import _lib
 from ..engine import Act, Builder, pad4
 
 __all__ = ["DiT", "DiTBlock", "MultiheadSelfAttention", "ViT"]

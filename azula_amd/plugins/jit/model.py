@@ -27,7 +27,6 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from ... import _lib
 from ...engine import Act, Builder
 
 __all__ = ["JiT", "JiT_models"]
