@@ -129,3 +129,27 @@ def test_adm_256_cfg_full_size_properties():
     # round-off differences of the backbone (the same 1e-3 bound as the ADM trajectory tests)
     print("ADM-256 batch 2 vs 1 max|d|", max_err(ref[1:], one))
     assert max_err(ref[1:], one) < 1e-3 * scale
+
+
+def test_odd_image_size_through_both_conv_paths(monkeypatch):
+    """A mid-size UNet on a 3 x 250 x 190 image (ragged Winograd tiles at every level, odd sizes through the stride-2
+    / nearest-upsample / narrow path of azula/nn/unet.py:253-255): Winograd plan == direct plan."""
+    from azula_amd import engine
+    from azula_amd.nn import UNet
+
+    torch.manual_seed(3)
+    net = UNet(3, 3, hid_channels=(64, 128, 256), hid_blocks=(1, 1, 1), norm="group", groups=8, mod_features=64).cuda().eval()
+    for blk in net.modules():  # un-zero the AdaZero gates so that every block contributes
+        if hasattr(blk, "ada_zero") and isinstance(blk.ada_zero, torch.nn.Sequential):
+            blk.ada_zero[-2].weight.data.mul_(100.0)
+    x = torch.randn(2, 3, 250, 190, device="cuda")
+    mod = torch.randn(64, device="cuda")
+    fast = net(x, mod)
+    assert any(n == "az_conv2d_winograd_f32" for _, _, n in next(iter(net._plans.values())).tape.ops)
+    monkeypatch.setattr(engine, "WINOGRAD", "0")
+    net._plans.clear()
+    direct = net(x, mod)
+    net._plans.clear()
+    scale = max(1.0, direct.abs().max().item())
+    print("odd-size UNet: Winograd vs direct max|d|", max_err(fast, direct), "scale", scale)
+    assert fast.shape == (2, 3, 250, 190) and max_err(fast, direct) < 2e-5 * scale
