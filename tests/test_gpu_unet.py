@@ -237,3 +237,19 @@ def test_half_precision_module_is_accepted(golden, half):
     rel = (x0 - ref).abs().max().item() / ref.abs().max().item()
     print(half, "DDIM-8 with half-precision weights vs fp32 weights: rel", rel)
     assert rel < (2e-2 if half == torch.float16 else 1e-1)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 8, 8), (2, 9, 5), (3, 1, 1), (1, 2, 3), (5, 16, 1)])
+def test_degenerate_spatial_sizes(B, H, W):
+    """Four levels on images down to 1 x 1 (every level then sees a single pixel, the stride-2 convs and the
+    nearest-upsample / narrow path of azula/nn/unet.py:253-255 run on 1-pixel maps) against the oracle."""
+    cfg = dict(in_channels=3, out_channels=3, hid_channels=(8, 16, 32, 64), hid_blocks=(1, 1, 1, 1), norm="group", groups=4,
+               mod_features=16)
+    net = build_unet(cfg)
+    sd = synth.synth_state_dict(synth.shapes_of(net.state_dict()), seed=5)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    g = torch.Generator().manual_seed(B * 100 + H * 10 + W)
+    x, mod = torch.randn(B, 3, H, W, generator=g), torch.randn(B, 16, generator=g)
+    ref = nets.unet_forward(sd, cfg, x, mod)
+    assert max_err(net(x.cuda(), mod.cuda()), ref) < 1e-4 * max(1.0, ref.abs().max().item())
