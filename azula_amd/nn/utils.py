@@ -6,7 +6,7 @@ from functools import reduce, wraps
 
 import torch
 
-__all__ = ["get_module_dtype", "promote_dtype", "skip_init", "backbone_io_dtype", "HALF_DTYPES"]
+__all__ = ["get_module_dtype", "get_module_device", "promote_dtype", "skip_init", "checkpoint", "backbone_io_dtype", "HALF_DTYPES"]
 
 
 def get_module_dtype(module: torch.nn.Module) -> torch.dtype | None:
@@ -73,3 +73,32 @@ def backbone_io_dtype(module: torch.nn.Module, x: torch.Tensor, who: str) -> tor
             f"got {p.dtype} on {p.device} and {x.dtype} on {x.device}"
         )
     return x.dtype
+
+
+def get_module_device(module: torch.nn.Module) -> torch.device | None:
+    r"""Device of the first materialised parameter (then buffer) of ``module``, ``None`` if it has none
+    (reference ``azula/nn/utils.py:45-68``; an accelerate hook's ``execution_device`` wins when present)."""
+    for m in module.modules():
+        hook = getattr(m, "_hf_hook", None)
+        if getattr(hook, "execution_device", None) is not None:
+            return hook.execution_device
+        for t in (*m.parameters(recurse=False), *m.buffers(recurse=False)):
+            if t.device.type != "meta":
+                return t.device
+    return None
+
+
+def checkpoint(f, reentrant: bool = False):
+    r"""Activation checkpointing wrapper (reference ``azula/nn/utils.py:123-188``).  A training-time memory tool: on
+    the sampling path gradients are disabled and the wrapped function is simply called; with gradients enabled it
+    defers to ``torch.utils.checkpoint`` (``reentrant`` selects its mode)."""
+
+    @wraps(f)
+    def g(*args, **kwargs):
+        if not torch.is_grad_enabled():
+            return f(*args, **kwargs)
+        import torch.utils.checkpoint as tuc
+
+        return tuc.checkpoint(f, *args, use_reentrant=reentrant, **kwargs)
+
+    return g
