@@ -444,3 +444,50 @@ def test_hub_cache_semantics(tmp_path):
         assert hub.download("ignored://", filename=str(explicit), quiet=True) == str(explicit)
     finally:
         hub.set_hub_dir(old)
+
+
+def test_load_model_from_a_populated_hub_cache(tmp_path, monkeypatch):
+    """SURVEY 8f.4 weight I/O: adm.load_model / jit.load_model read a checkpoint that sits in the reference's hub cache
+    layout (no download).  Tiny stand-in cards keep the files small; the checkpoints use the reference's key patterns
+    (guided-diffusion state_dict; JiT's {"model_ema1": {"net.<key>": ...}} inside an extracted archive)."""
+    import zipfile
+    from types import SimpleNamespace
+
+    from azula_amd import hub
+    from azula_amd.plugins import adm, jit
+
+    old = hub.get_hub_dir()
+    hub.set_hub_dir(str(tmp_path))
+    try:
+        # ---- ADM
+        cfg = dict(image_size=32, num_channels=32, num_res_blocks=1, channel_mult=(1, 2), attention_resolutions=(16,),
+                   num_heads=2, num_head_channels=-1, resblock_updown=True, use_scale_shift_norm=True)
+        url = "https://example.org/diffusion/tiny_adm.pt"
+        src = adm.make_model(**cfg)
+        for p in src.backbone.parameters():
+            p.data.normal_()
+        torch.save(src.backbone.state_dict(), hub.cached_path(url))
+        monkeypatch.setattr(adm, "load_cards", lambda _: {"tiny": SimpleNamespace(url=url, hash=None, config=cfg)})
+        den = adm.load_model("tiny")
+        assert not den.training
+        for (k, a), (_, b) in zip(src.backbone.state_dict().items(), den.backbone.state_dict().items()):
+            assert torch.equal(a, b), k
+        # ---- JiT: archive with checkpoint-last.pth holding EMA weights under a "net." prefix
+        jcfg = dict(input_size=32, patch_size=4, hidden_size=64, depth=2, num_heads=4, bottleneck_dim=16, in_context_len=4,
+                    in_context_start=1, num_classes=10)
+        jurl = "https://example.org/jit/tiny?dl=1"
+        jsrc = jit.JiT(**jcfg)
+        for p in jsrc.parameters():
+            p.data.normal_()
+        ckpt = tmp_path / "checkpoint-last.pth"
+        torch.save({"model_ema1": {"net." + k: v for k, v in jsrc.state_dict().items()}, "model": {}}, ckpt)
+        with zipfile.ZipFile(hub.cached_path(jurl), "w") as z:
+            z.write(ckpt, "checkpoint-last.pth")
+        monkeypatch.setattr(jit, "load_cards", lambda _: {"tiny": SimpleNamespace(url=jurl, hash=None, config={"model": "tiny"})})
+        monkeypatch.setitem(jit.JiT_models, "tiny", lambda **kw: jit.JiT(**jcfg, **kw))
+        jden = jit.load_model("tiny")
+        assert isinstance(jden, jit.JITDenoiser) and jden.num_classes == 10
+        for (k, a), (_, b) in zip(jsrc.state_dict().items(), jden.backbone.state_dict().items()):
+            assert torch.equal(a, b), k
+    finally:
+        hub.set_hub_dir(old)
