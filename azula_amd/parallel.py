@@ -71,8 +71,8 @@ def sample_sharded(sampler: Sampler, x_local: Tensor, *, group=None, gather: boo
         return x0
     x0 = x0.contiguous()
     out = torch.empty((world * x0.shape[0], *x0.shape[1:]), dtype=x0.dtype, device=x0.device)
-    if x0.is_cuda:
-        dist.all_gather_into_tensor(out, x0, group=group)
-    else:
+    if x0.is_cuda and dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, x0, group=group)  # one RCCL all-gather over xGMI
+    else:  # gloo (CPU tests, or a single-GPU rehearsal of the multi-process path)
         dist.all_gather(list(out.chunk(world)), x0, group=group)
     return out

@@ -260,12 +260,16 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % torch.cuda.device_count())  # (modulo: lets a 1-GPU box rehearse N > 1 over gloo)
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        backend = os.environ.get("AZ_DIST_BACKEND", "nccl")  # "nccl" IS RCCL over xGMI on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     torch.set_grad_enabled(False)
 
     from azula_amd.sample import DDIMSampler, DDPMSampler
