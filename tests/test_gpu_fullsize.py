@@ -153,3 +153,29 @@ def test_odd_image_size_through_both_conv_paths(monkeypatch):
     scale = max(1.0, direct.abs().max().item())
     print("odd-size UNet: Winograd vs direct max|d|", max_err(fast, direct), "scale", scale)
     assert fast.shape == (2, 3, 250, 190) and max_err(fast, direct) < 2e-5 * scale
+
+
+@pytest.mark.parametrize("H,Cin,Cout", [(256, 256, 256), (64, 512, 512), (16, 1024, 1024)])
+@pytest.mark.parametrize("algo", ["winograd", "direct"])
+def test_real_layer_shapes_against_torch_cpu(H, Cin, Cout, algo):
+    """The layers that carry C2's FLOPs, at their real shapes (one sample), against torch's CPU fp32 convolution."""
+    import math
+
+    import torch.nn.functional as F
+
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(H + Cin)
+    x = torch.randn(1, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, padding=1)
+    bld = Builder(torch.device("cuda"))
+    xa = Act(x.cuda().permute(0, 2, 3, 1).contiguous().reshape(-1), 1, H, H, Cin, Cin, True)
+    y = bld.conv(xa, bld.pack_conv(w.cuda(), b.cuda()), Cout, winograd=(algo == "winograd"))
+    bld.finish()
+    bld.tape.run()
+    out = y.buf[: Cout * H * H].view(H, H, Cout).permute(2, 0, 1)[None]
+    err = max_err(out, ref)
+    print(algo, H, Cin, "max|d|", err, "scale", ref.abs().max().item())
+    assert err < 1e-5 * max(1.0, ref.abs().max().item())
