@@ -72,9 +72,8 @@ __device__ __forceinline__ f32x2 buf_ld2(__amdgpu_buffer_rsrc_t rsrc, unsigned v
 constexpr unsigned OOB = 0x80000000u;  // any offset >= num_records reads as zero
 
 // Epilogue for 4 consecutive output channels [co, co+4) of output pixel n.
-__device__ __forceinline__ void epilogue_store(const AzConvArgs& a, int n, int co, float4 v) {
+__device__ __forceinline__ void epilogue_store_b(const AzConvArgs& a, int n, int b, int co, float4 v) {  // b = image of pixel n
   const int hw = a.hout * a.wout;
-  const int b = n / hw;
   const int rem = n - b * hw;
   if (a.bias) {
     const float4 bv = ld4(a.bias + co);
@@ -129,6 +128,10 @@ __device__ __forceinline__ void epilogue_store(const AzConvArgs& a, int n, int c
   } else {
     *reinterpret_cast<float4*>(a.dst + (int64_t)n * a.cout_s + co) = v;
   }
+}
+
+__device__ __forceinline__ void epilogue_store(const AzConvArgs& a, int n, int co, float4 v) {
+  epilogue_store_b(a, n, n / (a.hout * a.wout), co, v);
 }
 
 // Epilogue of a 2 x 2 arrangement of 32x32 MFMA accumulators (wave sub-tile 64 couts x 64 pixels): the lane holds,
@@ -584,6 +587,8 @@ constexpr int WK = 8;                  // input channels per stage
 constexpr int WU_STAGE = 16 * WC * WK; // floats
 constexpr int WV_STAGE = 16 * WT * WK;
 constexpr int W_STAGE = WU_STAGE + WV_STAGE;  // 16384 floats = 64 KB; two stages = 128 KB
+constexpr int W_OT = 4 * WC + 4;              // epilogue: floats per tile row of the [tile][pixel][cout] exchange buffer
+constexpr int W_LDS_BYTES = (2 * WT * W_OT + 3 * WT) * 4;  // 133,888 B >= the two K-loop stages
 
 struct WinoP {
   AzConvArgs a;
@@ -801,42 +806,53 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
         y[g][py * 2 + 1][r] = (s[py][1] - s[py][2]) - s[py][3];
       }
     }
-  float* xch = wsm + ((wave & 3) * 64) * 64;  // [64 values][64 lanes] per wave pair
-  if (fh == 1) {
+  // Both frequency halves park their partial outputs in LDS as [tile][pixel][cout] (tile stride padded by 4 floats:
+  // conflict-free ds_write_b128), then ALL 8 waves read rows back so that 16 consecutive lanes store the 256 contiguous
+  // bytes of one output pixel (two full 128-byte lines) instead of 32 bytes of 32 different pixels per instruction.
+  float* obuf = wsm + fh * (WT * W_OT);
+  {
+    float* orow = obuf + (wti * 32 + l31) * W_OT + wco * 32 + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int px = 0; px < 4; ++px)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xch[((g * 4 + px) * 4 + r) * 64 + lane] = y[g][px][r];
+        *reinterpret_cast<float4*>(orow + px * WC + 8 * g) = make_float4(y[g][px][0], y[g][px][1], y[g][px][2], y[g][px][3]);
+  }
+  int* tinfo = reinterpret_cast<int*>(wsm + 2 * WT * W_OT);  // [64] first output pixel of the tile (-1: none), [64] flags, [64] image
+  if (wave < 2 && h == 0) {
+    const int t = t0 + wti * 32 + l31;
+    int n00 = -1, fl = 0, b = 0;
+    if (t < p.ntiles) {
+      b = t / tiles_img;
+      const int rr = t - b * tiles_img;
+      const int th = rr / p.tiles_w;
+      const int tw = rr - th * p.tiles_w;
+      n00 = (b * a.hout + 2 * th) * a.wout + 2 * tw;
+      fl = (2 * th + 1 < a.hout ? 1 : 0) | (2 * tw + 1 < a.wout ? 2 : 0);
+    }
+    tinfo[wti * 32 + l31] = n00;
+    tinfo[WT + wti * 32 + l31] = fl;
+    tinfo[2 * WT + wti * 32 + l31] = b;
   }
   __syncthreads();
-  if (fh == 1) return;
-  const int t = t0 + wti * 32 + l31;
-  if (t >= p.ntiles) return;
-  const int b = t / tiles_img;
-  const int rr = t - b * tiles_img;
-  const int th = rr / p.tiles_w;
-  const int tw = rr - th * p.tiles_w;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int co = cb * WC + wco * 32 + 8 * g + 4 * h;
-    if (co >= a.cout_s) continue;
-#pragma unroll
-    for (int px = 0; px < 4; ++px) {
-      const int oh = 2 * th + (px >> 1), ow = 2 * tw + (px & 1);
-      if (oh >= a.hout || ow >= a.wout) continue;
-      const int n = (b * a.hout + oh) * a.wout + ow;
-      float4 v;
-      v.x = y[g][px][0] + xch[((g * 4 + px) * 4 + 0) * 64 + lane];
-      v.y = y[g][px][1] + xch[((g * 4 + px) * 4 + 1) * 64 + lane];
-      v.z = y[g][px][2] + xch[((g * 4 + px) * 4 + 2) * 64 + lane];
-      v.w = y[g][px][3] + xch[((g * 4 + px) * 4 + 3) * 64 + lane];
-      if (a.splitk > 1)
-        *reinterpret_cast<float4*>(a.workspace + ((int64_t)blockIdx.y * p.npix + n) * a.cout_s + co) = v;
-      else
-        epilogue_store(a, n, co, v);
-    }
+  for (int it = 0; it < 8; ++it) {
+    const int idx = it * 512 + tid;
+    const int cq = idx & 15;
+    const int row = idx >> 4;  // tile * 4 + pixel
+    const int tile = row >> 2, px = row & 3;
+    const int n00 = tinfo[tile], fl = tinfo[WT + tile];
+    const int co = cb * WC + cq * 4;
+    if (n00 < 0 || co >= a.cout_s) continue;
+    if (((px >> 1) & ~fl) | ((px & 1) & ~(fl >> 1))) continue;
+    const int n = n00 + (px >> 1) * a.wout + (px & 1);
+    const float4 v0 = *reinterpret_cast<const float4*>(wsm + tile * W_OT + px * WC + cq * 4);
+    const float4 v1 = *reinterpret_cast<const float4*>(wsm + WT * W_OT + tile * W_OT + px * WC + cq * 4);
+    const float4 v = make_float4(v0.x + v1.x, v0.y + v1.y, v0.z + v1.z, v0.w + v1.w);
+    if (a.splitk > 1)
+      *reinterpret_cast<float4*>(a.workspace + ((int64_t)blockIdx.y * p.npix + n) * a.cout_s + co) = v;
+    else
+      epilogue_store_b(a, n, tinfo[2 * WT + tile], co, v);
   }
 }
 
@@ -1322,11 +1338,11 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_winograd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * W_STAGE * 4);
+                                       W_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_winograd_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 2 * W_STAGE * 4, st, p);
+  hipLaunchKernelGGL(conv_winograd_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), W_LDS_BYTES, st, p);
   int rc = az_launch_status();
   if (rc != AZ_OK) return rc;
   if (splitk > 1) {
