@@ -72,11 +72,26 @@ __device__ __forceinline__ f32x2 buf_ld2(__amdgpu_buffer_rsrc_t rsrc, unsigned v
 constexpr unsigned OOB = 0x80000000u;  // any offset >= num_records reads as zero
 
 // Epilogue for 4 consecutive output channels [co, co+4) of output pixel n.
-__device__ __forceinline__ void epilogue_store_b(const AzConvArgs& a, int n, int b, int co, float4 v) {  // b = image of pixel n
-  const int hw = a.hout * a.wout;
-  const int rem = n - b * hw;
+// The fused epilogue in two halves so that callers can issue the loads of several outputs before the first store (the
+// compiler cannot move a load above a store that might alias it): fetch = the gate / residual reads, apply = bias,
+// activation, gate, residual, store.  The arithmetic order is fixed: ((v + bias) -> act) * gate + res.
+__device__ __forceinline__ int64_t epilogue_res_index(const AzConvArgs& a, int n, int b) {
+  const int rem = n - b * (a.hout * a.wout);
+  if (a.res_up) {
+    const int oh = rem / a.wout, ow = rem - oh * a.wout;
+    return ((int64_t)b * a.hres + (oh >> 1)) * a.wres + (ow >> 1);
+  }
+  return a.res_bcast ? rem : n;
+}
+
+__device__ __forceinline__ void epilogue_fetch(const AzConvArgs& a, int n, int b, int co, float4& gate, float4& res) {
+  if (a.gate) gate = ld4(a.gate + (int64_t)b * a.gate_bstride + co);
+  if (a.res) res = ld4(a.res + epilogue_res_index(a, n, b) * a.cout_s + co);
+}
+
+__device__ __forceinline__ void epilogue_apply_store(const AzConvArgs& a, int n, int b, int co, float4 v, float4 bv,
+                                                     float4 g, float4 r) {  // bv: bias (zeros if none)
   if (a.bias) {
-    const float4 bv = ld4(a.bias + co);
     v.x += bv.x;
     v.y += bv.y;
     v.z += bv.z;
@@ -100,27 +115,20 @@ __device__ __forceinline__ void epilogue_store_b(const AzConvArgs& a, int n, int
     }
   }
   if (a.gate) {
-    const float4 g = ld4(a.gate + (int64_t)b * a.gate_bstride + co);
     v.x *= g.x;
     v.y *= g.y;
     v.z *= g.z;
     v.w *= g.w;
   }
   if (a.res) {
-    int64_t rp;
-    if (a.res_up) {
-      const int oh = rem / a.wout, ow = rem - oh * a.wout;
-      rp = ((int64_t)b * a.hres + (oh >> 1)) * a.wres + (ow >> 1);
-    } else {
-      rp = a.res_bcast ? rem : n;
-    }
-    const float4 r = ld4(a.res + rp * a.cout_s + co);
     v.x += r.x;
     v.y += r.y;
     v.z += r.z;
     v.w += r.w;
   }
   if (a.dst_nchw) {
+    const int hw = a.hout * a.wout;
+    const int rem = n - b * hw;
     const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -130,34 +138,106 @@ __device__ __forceinline__ void epilogue_store_b(const AzConvArgs& a, int n, int
   }
 }
 
+__device__ __forceinline__ void epilogue_store_b(const AzConvArgs& a, int n, int b, int co, float4 v) {  // b = image of pixel n
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f), r = g, bv = g;
+  if (a.bias) bv = ld4(a.bias + co);
+  epilogue_fetch(a, n, b, co, g, r);
+  epilogue_apply_store(a, n, b, co, v, bv, g, r);
+}
+
+// A batch of NB outputs of one thread (same channel quad `co`, pixels n[i] of images b[i]; n[i] < 0: skip): all gate /
+// residual reads are issued first, then the NB stores.
+template <int NB>
+__device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const int (&n)[NB], const int (&b)[NB], int co,
+                                                     const float4 (&v)[NB], int64_t ws_slab) {
+  if (a.splitk > 1) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (n[i] >= 0) *reinterpret_cast<float4*>(a.workspace + (ws_slab + n[i]) * a.cout_s + co) = v[i];
+    return;
+  }
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 bv = a.bias ? ld4(a.bias + co) : z;
+  float4 g[NB], r[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    g[i] = z;
+    r[i] = z;
+    if (n[i] >= 0) epilogue_fetch(a, n[i], b[i], co, g[i], r[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (n[i] >= 0) epilogue_apply_store(a, n[i], b[i], co, v[i], bv, g[i], r[i]);
+}
+
 __device__ __forceinline__ void epilogue_store(const AzConvArgs& a, int n, int co, float4 v) {
   epilogue_store_b(a, n, n / (a.hout * a.wout), co, v);
 }
 
 // Epilogue of a 2 x 2 arrangement of 32x32 MFMA accumulators (wave sub-tile 64 couts x 64 pixels): the lane holds,
 // for pixel (lane & 31) of each pixel tile, channels ct*32 + 8*q + 4*(lane >> 5) + [0, 4) in registers 4q .. 4q+3
-// (the C/D layout of the 32x32 MFMAs is the same for f32, bf16 and f16 operands).
+// (the C/D layout of the 32x32 MFMAs is the same for f32, bf16 and f16 operands).  Stored straight from that layout an
+// instruction writes 32 bytes of 32 different pixels; instead the block's 128 x 128 outputs go through LDS (`obuf`,
+// the operand stages, free after the K loop's last barrier) as [pixel][cout] rows (stride padded by 4 floats:
+// conflict-free ds_write_b128) and are read back so that 32 consecutive lanes store the 512 contiguous bytes of one
+// pixel.  The planar (NCHW) destination keeps the direct form, whose lanes run along pixels.
+constexpr int OSTR = BM + 4;  // floats per pixel row of the exchange buffer
+static_assert((BN * OSTR + BN) * 4 <= 2 * TILE_F * 4, "epilogue exchange buffer must fit in the operand stages");
+
 __device__ __forceinline__ void store_acc_tiles(const ConvP& p, const f32x16 (&acc)[2][2], int m0, int n0, int wc, int wp,
-                                                int lane) {
+                                                int lane, float* obuf) {
   const AzConvArgs& a = p.a;
+  if (a.dst_nchw && a.splitk == 1) {
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
-    const int n = n0 + wp * 64 + pt * 32 + (lane & 31);
-    if (n >= p.npix) continue;
+    for (int pt = 0; pt < 2; ++pt) {
+      const int n = n0 + wp * 64 + pt * 32 + (lane & 31);
+      if (n >= p.npix) continue;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+      for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = m0 + wc * 64 + ct * 32 + 8 * q + 4 * (lane >> 5);
-        if (co >= a.cout_s) continue;
-        const float4 v =
-            make_float4(acc[ct][pt][4 * q + 0], acc[ct][pt][4 * q + 1], acc[ct][pt][4 * q + 2], acc[ct][pt][4 * q + 3]);
-        if (a.splitk > 1)
-          *reinterpret_cast<float4*>(a.workspace + ((int64_t)blockIdx.y * p.npix + n) * a.cout_s + co) = v;
-        else
-          epilogue_store(a, n, co, v);
+        for (int q = 0; q < 4; ++q) {
+          const int co = m0 + wc * 64 + ct * 32 + 8 * q + 4 * (lane >> 5);
+          if (co >= a.cout_s) continue;
+          epilogue_store(a, n, co, make_float4(acc[ct][pt][4 * q + 0], acc[ct][pt][4 * q + 1], acc[ct][pt][4 * q + 2],
+                                               acc[ct][pt][4 * q + 3]));
+        }
       }
     }
+    return;
+  }
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    float* orow = obuf + (wp * 64 + pt * 32 + (lane & 31)) * OSTR + wc * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(orow + ct * 32 + 8 * q) =
+            make_float4(acc[ct][pt][4 * q + 0], acc[ct][pt][4 * q + 1], acc[ct][pt][4 * q + 2], acc[ct][pt][4 * q + 3]);
+  }
+  int* pimg = reinterpret_cast<int*>(obuf + BN * OSTR);  // image index of each pixel of the tile (-1: past the end)
+  if (tid < BN) {
+    const int n = n0 + tid;
+    pimg[tid] = n < p.npix ? n / (a.hout * a.wout) : -1;
+  }
+  __syncthreads();
+  const int cq = tid & (BM / 4 - 1);  // the same channel quad in every iteration (256 % (BM / 4) == 0)
+  const int co = m0 + cq * 4;
+  if (co >= a.cout_s) return;
+  constexpr int NIT = BN * (BM / 4) / 256, NB = 8;
+#pragma unroll 1
+  for (int it0 = 0; it0 < NIT; it0 += NB) {
+    int n[NB], b[NB];
+    float4 v[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int px = ((it0 + i) * 256 + tid) / (BM / 4);
+      b[i] = pimg[px];
+      n[i] = b[i] >= 0 ? n0 + px : -1;
+      v[i] = *reinterpret_cast<const float4*>(obuf + px * OSTR + cq * 4);
+    }
+    epilogue_store_batch<NB>(a, n, b, co, v, (int64_t)blockIdx.y * p.npix);
   }
 }
 
@@ -339,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     __syncthreads();
   }
 
-  store_acc_tiles(p, acc, m0, n0, wc, wp, lane);
+  store_acc_tiles(p, acc, m0, n0, wc, wp, lane, smem);
 }
 
 // =================================================================================================
@@ -541,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
     if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
-  store_acc_tiles(p, acc, m0, n0, wc, wp, lane);
+  store_acc_tiles(p, acc, m0, n0, wc, wp, lane, reinterpret_cast<float*>(hsm));
 }
 
 // Split-K combine + epilogue: one thread per (pixel, 4 channels).
@@ -835,25 +915,24 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
     tinfo[2 * WT + wti * 32 + l31] = b;
   }
   __syncthreads();
+  const int cq = tid & 15;  // the same channel quad in every iteration
+  const int co = cb * WC + cq * 4;
+  if (co >= a.cout_s) return;
+  int on[8], ob[8];
+  float4 ov[8];
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
-    const int idx = it * 512 + tid;
-    const int cq = idx & 15;
-    const int row = idx >> 4;  // tile * 4 + pixel
+    const int row = (it * 512 + tid) >> 4;  // tile * 4 + pixel
     const int tile = row >> 2, px = row & 3;
     const int n00 = tinfo[tile], fl = tinfo[WT + tile];
-    const int co = cb * WC + cq * 4;
-    if (n00 < 0 || co >= a.cout_s) continue;
-    if (((px >> 1) & ~fl) | ((px & 1) & ~(fl >> 1))) continue;
-    const int n = n00 + (px >> 1) * a.wout + (px & 1);
+    ob[it] = tinfo[2 * WT + tile];
+    const bool skip = n00 < 0 || (((px >> 1) & ~fl) | ((px & 1) & ~(fl >> 1)));
+    on[it] = skip ? -1 : n00 + (px >> 1) * a.wout + (px & 1);
     const float4 v0 = *reinterpret_cast<const float4*>(wsm + tile * W_OT + px * WC + cq * 4);
     const float4 v1 = *reinterpret_cast<const float4*>(wsm + WT * W_OT + tile * W_OT + px * WC + cq * 4);
-    const float4 v = make_float4(v0.x + v1.x, v0.y + v1.y, v0.z + v1.z, v0.w + v1.w);
-    if (a.splitk > 1)
-      *reinterpret_cast<float4*>(a.workspace + ((int64_t)blockIdx.y * p.npix + n) * a.cout_s + co) = v;
-    else
-      epilogue_store_b(a, n, tinfo[2 * WT + tile], co, v);
+    ov[it] = make_float4(v0.x + v1.x, v0.y + v1.y, v0.z + v1.z, v0.w + v1.w);
   }
+  epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix);
 }
 
 // =================================================================================================
