@@ -624,6 +624,105 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
   store_acc_tiles(p, acc, m0, n0, wc, wp, lane, reinterpret_cast<float*>(hsm));
 }
 
+// =================================================================================================
+// Narrow-output 3x3 convolution (cout_s == 4: the image head of a UNet, 256 -> 3 channels).  A 128-cout MFMA tile would
+// waste 97 % of the matrix pipe on it and the Winograd form 94 %; with 27 x Cin multiply-adds per output pixel it is a
+// VALU kernel: one thread per output pixel, the workgroup's 18 x 18 input halo staged through LDS in 16-channel chunks
+// (pixel stride padded to 80 B -> conflict-free ds_read_b128), the weights (uniform
+// across the wave) fetched by scalar loads and used as SGPR operands of the FMAs; the next chunk's global loads are in
+// flight during the FMAs and 4 workgroups per CU overlap one another's barriers.  Same fused epilogue as the other kernels (the NCHW destination is coalesced here: lanes = pixels).
+constexpr int HD_T = 16;               // output pixels per workgroup: 16 x 16
+constexpr int HD_HALO = HD_T + 2;
+constexpr int HD_KC = 16;              // input channels per chunk (4 workgroups per CU)
+constexpr int HD_PS = HD_KC + 4;       // LDS pixel stride (floats)
+
+template <int NCO>
+__global__ __launch_bounds__(256) void conv_head_kernel(ConvP p, int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float xs[HD_HALO * HD_HALO * HD_PS];  // 25,920 B
+  const AzConvArgs& a = p.a;
+  const int tid = threadIdx.x;
+  const int tx = tid & (HD_T - 1), ty = tid / HD_T;
+  const int bid = blockIdx.x;
+  const int txb = bid % tiles_x;
+  const int rb = bid / tiles_x;
+  const int tyb = rb % tiles_y;
+  const int b = rb / tiles_y;
+  const int oy0 = tyb * HD_T, ox0 = txb * HD_T;
+  const float* __restrict__ w = a.weight;  // [tap][4][cin_s]
+  const float* __restrict__ src = a.src0 + (int64_t)b * a.h0 * a.w0 * a.c0s;
+  float acc[NCO];
+#pragma unroll
+  for (int co = 0; co < NCO; ++co) acc[co] = 0.f;
+
+  // staging slots of this thread: element e = tid + 256 i of the [324 pixels][8 float4] chunk (chunk-invariant offsets)
+  constexpr int NE = HD_HALO * HD_HALO * (HD_KC / 4);
+  constexpr int NS = (NE + 255) / 256;
+  int goff[NS], loff[NS];  // global float offset (-1: zero padding), LDS float offset (-1: no slot)
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int e = tid + 256 * i;
+    const int pxi = e / (HD_KC / 4), q = e % (HD_KC / 4);
+    const int hy = pxi / HD_HALO, hx = pxi - hy * HD_HALO;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const bool inb = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+    loff[i] = e < NE ? pxi * HD_PS + q * 4 : -1;
+    goff[i] = (e < NE && inb) ? (iy * a.w0 + ix) * a.c0s + q * 4 : -1;
+  }
+
+  float4 v[NS];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+      v[i] = goff[i] >= 0 ? *reinterpret_cast<const float4*>(src + goff[i] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  fetch(0);
+  for (int kc = 0; kc < a.c0s; kc += HD_KC) {
+    __syncthreads();  // the previous chunk has been consumed
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+      if (loff[i] >= 0) *reinterpret_cast<float4*>(xs + loff[i]) = v[i];
+    __syncthreads();
+    if (kc + HD_KC < a.c0s) fetch(kc + HD_KC);  // in flight during this chunk's FMAs
+    float part[NCO];  // per-chunk partial sums (144 terms), added once: shorter rounding chains than one 9 Cin-long sum
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) part[co] = 0.f;
+    // 9 groups (one per tap) of 16 channels: 48 weights in SGPRs (3 x s_load_dwordx16), 4 ds_read_b128, 48 FMAs.  The
+    // group loop is NOT unrolled: hoisted scalar loads would only add lgkmcnt waits (SMEM and LDS share the counter)
+    // -- the other waves of the SIMD cover the one scalar-cache round trip per group.
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = (tap * 11) >> 5;  // tap / 3 for tap < 9
+      const float* xp = xs + ((ty + ky) * HD_HALO + tx + (tap - 3 * ky)) * HD_PS;
+      const float* wt = w + (int64_t)tap * 4 * p.cin_s + kc;
+      float wl[NCO][HD_KC];
+#pragma unroll
+      for (int co = 0; co < NCO; ++co)
+#pragma unroll
+        for (int j = 0; j < HD_KC; ++j) wl[co][j] = wt[co * p.cin_s + j];  // wave-uniform: scalar loads
+#pragma unroll
+      for (int q = 0; q < HD_KC / 4; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(xp + q * 4);
+#pragma unroll
+        for (int co = 0; co < NCO; ++co) {
+          part[co] = fmaf(x.x, wl[co][q * 4 + 0], part[co]);
+          part[co] = fmaf(x.y, wl[co][q * 4 + 1], part[co]);
+          part[co] = fmaf(x.z, wl[co][q * 4 + 2], part[co]);
+          part[co] = fmaf(x.w, wl[co][q * 4 + 3], part[co]);
+        }
+      }
+    }
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) acc[co] += part[co];
+  }
+  const int oy = oy0 + ty, ox = ox0 + tx;
+  if (oy >= a.hout || ox >= a.wout) return;
+  const int n = (b * a.hout + oy) * a.wout + ox;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int co = 0; co < NCO; ++co) o[co] = acc[co];
+  epilogue_store_b(a, n, b, 0, make_float4(o[0], o[1], o[2], o[3]));
+}
+
 // Split-K combine + epilogue: one thread per (pixel, 4 channels).
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvP p) {
   const AzConvArgs& a = p.a;
@@ -1340,6 +1439,20 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     AZ_REQUIRE((int64_t)a->cout_s * p.cin_s * 4 < (1ll << 31), AZ_E_SHAPE);
     AZ_REQUIRE((int64_t)a->ksize * a->ksize * a->cout_s * p.cin_s * 4 < (1ll << 32), AZ_E_SHAPE);
   }
+  hipStream_t st = az_s(stream);
+  if (!half && a->cout_s == 4 && a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->src1 && a->up0 == 0 &&
+      a->c0s % HD_KC == 0 && a->h0 == a->hin && a->w0 == a->win) {
+    // narrow output (image head): VALU kernel, no split-K
+    p.a.splitk = 1;
+    const int tiles_x = (a->wout + HD_T - 1) / HD_T, tiles_y = (a->hout + HD_T - 1) / HD_T;
+    const dim3 grid((unsigned)(tiles_x * tiles_y * a->batch));
+    const int nco = a->dst_nchw ? a->dst_c : 4;
+    if (nco == 1) hipLaunchKernelGGL(conv_head_kernel<1>, grid, dim3(256), 0, st, p, tiles_x, tiles_y);
+    else if (nco == 2) hipLaunchKernelGGL(conv_head_kernel<2>, grid, dim3(256), 0, st, p, tiles_x, tiles_y);
+    else if (nco == 3) hipLaunchKernelGGL(conv_head_kernel<3>, grid, dim3(256), 0, st, p, tiles_x, tiles_y);
+    else hipLaunchKernelGGL(conv_head_kernel<4>, grid, dim3(256), 0, st, p, tiles_x, tiles_y);
+    return az_launch_status();
+  }
   int splitk = a->splitk;
   if (splitk > p.nk) splitk = p.nk;
   p.kps = (p.nk + splitk - 1) / splitk;
@@ -1349,7 +1462,6 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   p.tiles_n = (p.npix + BN - 1) / BN;
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   AZ_REQUIRE(nwg < (1ll << 31), AZ_E_SHAPE);
-  hipStream_t st = az_s(stream);
   if (half == 1)
     hipLaunchKernelGGL(conv_igemm_half_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
   else if (half == 2)

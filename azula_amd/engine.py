@@ -310,6 +310,11 @@ class Builder:
         tiles4 = B * ((hout + 3) // 4) * ((wout + 3) // 4)
         use_f4 = legal and (winograd == 4 or (winograd is None and WINOGRAD == "4" and tiles4 >= WINOGRAD4_MIN_TILES))
         use_wino = legal and not use_f4 and ((WINOGRAD != "0") if winograd is None else bool(winograd))
+        head_wgs = B * ((hout + 15) // 16) * ((wout + 15) // 16)
+        if winograd is None and legal and a.cout_s == 4 and src1 is None and up0 == 0 and a.c0s % 16 == 0 and head_wgs >= 256:
+            # image head (<= 4 output channels) on a map that fills the chip with 16 x 16-pixel workgroups:
+            # az_conv2d_f32 runs its narrow-output VALU kernel (104 vs 342 us at 4 x 256^2, 256 -> 3)
+            use_wino = use_f4 = False
         if use_wino:
             tiles = B * ((hout + 1) // 2) * ((wout + 1) // 2)
             a.splitk = lib.az_conv2d_winograd_suggest_splitk(B, hout, wout, a.cout_s, cin_s)

@@ -258,6 +258,8 @@ typedef struct AzConvArgs {
   int32_t splitk;          /* >= 1; > 1 needs workspace of splitk * B*hout*wout * cout_s floats */
   float* workspace;
 } AzConvArgs;
+/* Narrow outputs (cout_s == 4, 3x3 stride 1 pad 1, one un-upsampled source with c0s % 16 == 0: the image head of
+ * azula/nn/unet.py) run a VALU kernel instead of the 128-cout MFMA tile; splitk is ignored there.              */
 int az_conv2d_f32(const AzConvArgs* args, az_stream_t stream);
 /* The same operation with bf16 / f16 MFMA operands (v_mfma_f32_32x32x16_{bf16,f16}, 16x the fp32 MFMA rate) and fp32
  * accumulation, for backbones cast to half precision (azula/denoise.py:314-320 casts c_in x_t to the module dtype;

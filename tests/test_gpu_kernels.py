@@ -485,6 +485,37 @@ def test_conv2d_nchw_output_and_res_up(az, wino):
     assert max_err(from_nhwc(up.buf.reshape(B, 2 * H, 2 * W, 16), Cin), xu + F.conv2d(xu, w2, None, padding=1)) < tol
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 16, 3, 16, 16), (2, 48, 1, 37, 21), (3, 256, 3, 19, 50), (1, 32, 4, 5, 3), (2, 64, 2, 33, 33)])
+@pytest.mark.parametrize("nchw", [False, True])
+def test_conv2d_narrow_output_kernel(az, B, Cin, Cout, H, W, nchw):
+    """cout_s == 4, 3x3 stride 1, one source with Cin % 16 == 0: az_conv2d_f32 runs conv_head_kernel (the image head
+    of the UNets) -- ragged maps (partial 16 x 16 tiles), 1..4 real channels, both destinations, full epilogue."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    bld = Builder(torch.device("cuda"))
+    xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
+    if nchw:
+        dst = torch.full((B, Cout, H, W), float("nan"), device="cuda")
+        bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, dst_nchw=dst, winograd=False)
+        ref = F.conv2d(x, w, b, padding=1)
+    else:
+        gate, res = torch.randn(B, Cout, generator=g), torch.randn(B, Cout, H, W, generator=g)
+        gpad = torch.zeros(B, 4)
+        gpad[:, :Cout] = gate
+        ra = Act(to_nhwc(dev(res), 4).reshape(-1), B, H, W, Cout, 4, True)
+        y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, act=1, gate=dev(gpad), gate_bstride=4, res=ra, winograd=False)
+        ref = res + gate[:, :, None, None] * F.silu(F.conv2d(x, w, b, padding=1))
+    assert bld.tape.ops[-1][2] == "az_conv2d_f32"
+    bld.finish()
+    bld.tape.run()
+    out = dst if nchw else from_nhwc(y.buf.reshape(B, H, W, 4), Cout)
+    assert max_err(out, ref) < conv_tol(Cin, 3) * max(1.0, ref.abs().max().item())
+
+
 def test_graph_capture_replay(az):
     from azula_amd.engine import StepGraph, Tape
 
