@@ -214,8 +214,10 @@ PROTOTYPES: dict[str, list] = {
     "az_linear_small_grouped_f32": [vp, i32, i32, i64, i32, i32, c_stream],
     "az_conv2d_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_bf16_f32": [C.POINTER(AzConvArgs), c_stream],
+    "az_conv2d_x3_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_f16_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_pack_conv_weight_half_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, c_stream],
+    "az_pack_conv_weight_x3_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, c_stream],
     "az_conv2d_suggest_splitk": [i64, i32, i32, i32],
     "az_conv2d_winograd_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_winograd_suggest_splitk": [i64, i32, i32, i32, i32],

@@ -625,6 +625,227 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
 }
 
 // =================================================================================================
+// fp32 operands on the bf16 matrix pipe ("bf16x3"): every fp32 value is split EXACTLY into three bf16 pieces
+// (x = x1 + x2 + x3: three 8-bit slices of the 24-bit significand, by truncation), and a product is evaluated as the six
+// largest of the nine partial products,  x1 y1 + (x1 y2 + x2 y1) + (x1 y3 + x2 y2 + x3 y1),  each an exact 16-bit
+// product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms are <= 3 * 2^-24 |x y|, i.e. at the level
+// of ONE fp32 rounding of the product; measured against fp64 the result is as accurate as the fp32 MFMA kernel and
+// more accurate than the Winograd form (tests/test_gpu_kernels.py::test_conv2d_x3_accuracy).  Six bf16 MFMAs per 16
+// channels take 6 x 32 cycles against 8 x 64 for v_mfma_f32_32x32x2_f32: 0.375 x the matrix-pipe time.
+// Weights are split once (az_pack_conv_weight_x3_f32: [piece][tap][cout_s][cin_s] bf16); activations stay fp32 in HBM
+// and are split by the loader threads while they are staged (2 ANDs, 2 subtractions, 1.5 byte-permutes per value).
+// Tile 128 couts x 128 pixels, K tile = 32 channels of one tap; LDS: 6 planes of 128 rows x 80 B (conflict-free
+// ds_read_b128 fragments) = 60 KB, single-buffered with register prefetch, two workgroups per CU.
+constexpr int XBK = 32;                       // k tile
+constexpr int XLDS = 40;                      // LDS row stride in 2-byte elements (80 B)
+constexpr int XPLANE = 128 * XLDS;            // 2-byte elements per (operand, piece) plane
+constexpr int X_LDS_BYTES = (BN * OSTR + BN) * 4;  // the epilogue's exchange buffer (68,096 B) >= 6 planes (61,440 B)
+static_assert(6 * XPLANE * 2 <= X_LDS_BYTES, "stage planes must fit under the epilogue buffer");
+
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+  const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+  const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);  // exact: the low 16 significand bits
+  const float r1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+  const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+  const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u);
+  const float s1 = r1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
+  p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // high halves of (x1, x0) = truncated bf16 pair
+  p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  p3 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
+  __shared__ __attribute__((aligned(16))) float xsmf[X_LDS_BYTES / 4];
+  unsigned short* xsm = reinterpret_cast<unsigned short*>(xsmf);
+  const AzConvArgs& a = p.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wc = wid >> 1;
+  const int wp = wid & 1;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  const int tile_n = wg / p.tiles_m;
+  const int tile_m = wg - tile_n * p.tiles_m;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int kt_begin = blockIdx.y * p.kps;
+  const int kt_end = min(p.nk, kt_begin + p.kps);
+
+  const int hw_out = a.hout * a.wout;
+  const int b_first = n0 / hw_out;
+  const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
+  const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
+  const int64_t wplane = (int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s;  // elements per weight piece
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : e); };
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, clamp_bytes(3 * wplane * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src0 + b_first * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src1 ? a.src1 + b_first * s1_elems : a.src0), 0,
+      a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems * 4) : 0u, 0x00020000);
+
+  // loaders: thread -> (8 consecutive k-values kc8, rows r0 + 64 i) of both operands
+  const int kc8 = tid & 3, r0 = tid >> 2;
+  unsigned voffW[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int co = m0 + r0 + 64 * i;
+    voffW[i] = co < a.cout_s ? (unsigned)((co * p.cin_s + kc8 * 8) * 2) : OOB;
+  }
+  int prel[2], ihb[2], iwb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = n0 + r0 + 64 * i;
+    const bool pv = n < p.npix;
+    const int nn = pv ? n : 0;
+    const int b = nn / hw_out;
+    const int rem = nn - b * hw_out;
+    const int oh = rem / a.wout;
+    prel[i] = pv ? b - b_first : -1;
+    ihb[i] = oh * a.stride - a.pad;
+    iwb[i] = (rem - oh * a.wout) * a.stride - a.pad;
+  }
+
+  const int nk_tap = p.nkc0 + p.nkc1;
+  int it_tap = kt_begin / nk_tap;
+  int it_r = kt_begin - it_tap * nk_tap;
+  int it_src = it_r >= p.nkc0 ? 1 : 0;
+  int it_kc = it_src ? it_r - p.nkc0 : it_r;
+  unsigned voffA[2];
+  auto set_tap_src = [&]() __attribute__((always_inline)) {
+    const int ky = it_tap / a.ksize;
+    const int kx = it_tap - ky * a.ksize;
+    const int cs = it_src ? a.c1s : a.c0s;
+    const int up = it_src ? a.up1 : a.up0;
+    const int hs = it_src ? a.h1 : a.h0;
+    const int ws = it_src ? a.w1 : a.w0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ih = ihb[i] + ky;
+      const int iw = iwb[i] + kx;
+      const bool ok = prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
+      const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> up);
+      voffA[i] = ok ? (unsigned)((pix * cs + kc8 * 8) * 4) : OOB;
+    }
+  };
+
+  float4 ra[3][2];  // [piece][row]: 8 two-byte weights each
+  float4 rb[2][2];  // [row][half]: 4 fp32 activations each
+  auto load_tile = [&]() __attribute__((always_inline)) {
+    const int cs = it_src ? a.c1s : a.c0s;
+    const int kbase = it_kc * XBK;
+    const int kglob = (it_src ? a.c0s : 0) + kbase;
+    const int64_t wtap = (int64_t)it_tap * a.cout_s * p.cin_s + kglob;
+    const unsigned soffA = (unsigned)(kbase * 4);
+    const bool kv0 = kbase + kc8 * 8 < cs, kv1 = kbase + kc8 * 8 + 4 < cs;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const unsigned soffW = (unsigned)((pl * wplane + wtap) * 2);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) ra[pl][i] = buf_ld4(rw, voffW[i], soffW);
+    }
+    if (it_src) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        rb[i][0] = buf_ld4(rs1, kv0 ? voffA[i] : OOB, soffA);
+        rb[i][1] = buf_ld4(rs1, kv1 ? voffA[i] + 16u : OOB, soffA);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        rb[i][0] = buf_ld4(rs0, kv0 ? voffA[i] : OOB, soffA);
+        rb[i][1] = buf_ld4(rs0, kv1 ? voffA[i] + 16u : OOB, soffA);
+      }
+    }
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    ++it_kc;
+    if (it_kc == (it_src ? p.nkc1 : p.nkc0)) {
+      it_kc = 0;
+      ++it_src;
+      if (it_src == 2 || p.nkc1 == 0) {
+        it_src = 0;
+        ++it_tap;
+      }
+      set_tap_src();
+    }
+  };
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<float4*>(xsm + pl * XPLANE + (r0 + 64 * i) * XLDS + kc8 * 8) = ra[pl][i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float x[8] = {rb[i][0].x, rb[i][0].y, rb[i][0].z, rb[i][0].w, rb[i][1].x, rb[i][1].y, rb[i][1].z, rb[i][1].w};
+      unsigned q[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<uint4*>(xsm + (3 + pl) * XPLANE + (r0 + 64 * i) * XLDS + kc8 * 8) =
+            make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_off = (lane & 31) * XLDS + (lane >> 5) * 8;
+  const unsigned short* As = xsm + (wc * 64) * XLDS + frag_off;               // + piece * XPLANE + tile * 32 * XLDS
+  const unsigned short* Bs = xsm + 3 * XPLANE + (wp * 64) * XLDS + frag_off;
+
+  if (kt_begin < kt_end) {
+    set_tap_src();
+    load_tile();
+    store_tile();
+  }
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = kt + 1 < kt_end;
+    if (more) {
+      advance();
+      load_tile();  // in flight under the 48 MFMAs below
+    }
+#pragma unroll
+    for (int ks = 0; ks < XBK / 16; ++ks) {
+      bf16x8 fa[3][2], fb[3][2];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          fa[pl][t] = *reinterpret_cast<const bf16x8*>(As + pl * XPLANE + t * 32 * XLDS + ks * 16);
+          fb[pl][t] = *reinterpret_cast<const bf16x8*>(Bs + pl * XPLANE + t * 32 * XLDS + ks * 16);
+        }
+      // smallest partial products first
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+      constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][0], fb[PB[t]][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][0], fb[PB[t]][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][1], fb[PB[t]][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][1], fb[PB[t]][1], acc[1][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // every wave has read this K tile
+    if (more) store_tile();
+    __syncthreads();
+  }
+  store_acc_tiles(p, acc, m0, n0, wc, wp, lane, xsmf);
+}
+
+// =================================================================================================
 // Narrow-output 3x3 convolution (cout_s == 4: the image head of a UNet, 256 -> 3 channels).  A 128-cout MFMA tile would
 // waste 97 % of the matrix pipe on it and the Winograd form 94 %; with 27 x Cin multiply-adds per output pixel it is a
 // VALU kernel: one thread per output pixel, the workgroup's 18 x 18 input halo staged through LDS in 16-channel chunks
@@ -1389,7 +1610,7 @@ int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_
   return (int)want;
 }
 
-static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half /* 0 fp32, 1 bf16, 2 f16 operands */);
+static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half /* 0 fp32, 1 bf16, 2 f16 operands, 3 fp32 as 3 x bf16 */);
 
 int az_conv2d_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 0); }
 
@@ -1398,6 +1619,9 @@ int az_conv2d_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direc
  * For modules cast to half precision (azula/denoise.py:314-320); error ~2^-9 (bf16) / 2^-12 (f16) per product.   */
 int az_conv2d_bf16_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 1); }
 int az_conv2d_f16_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 2); }
+/* fp32 operands evaluated as 3 x bf16 pieces / 6 partial products (see conv_igemm_x3_kernel): `weight` is the packing
+ * of az_pack_conv_weight_x3_f32; fp32-level accuracy at 0.375 x the matrix-pipe time of the fp32 MFMA.              */
+int az_conv2d_x3_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 3); }
 
 static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
@@ -1426,7 +1650,7 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   p.a = *a;
   p.npix = (int)npix64;
   p.cin_s = a->c0s + a->c1s;
-  const int bk = half ? HBK : BK;
+  const int bk = half == 3 ? XBK : (half ? HBK : BK);
   p.nkc0 = (a->c0s + bk - 1) / bk;
   p.nkc1 = (a->c1s + bk - 1) / bk;
   p.nk = a->ksize * a->ksize * (p.nkc0 + p.nkc1);
@@ -1437,7 +1661,7 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     AZ_REQUIRE(span * a->h0 * a->w0 * a->c0s * 4 < (1ll << 31), AZ_E_SHAPE);
     AZ_REQUIRE(span * a->h1 * a->w1 * a->c1s * 4 < (1ll << 31), AZ_E_SHAPE);
     AZ_REQUIRE((int64_t)a->cout_s * p.cin_s * 4 < (1ll << 31), AZ_E_SHAPE);
-    AZ_REQUIRE((int64_t)a->ksize * a->ksize * a->cout_s * p.cin_s * 4 < (1ll << 32), AZ_E_SHAPE);
+    AZ_REQUIRE((int64_t)a->ksize * a->ksize * a->cout_s * p.cin_s * (half == 3 ? 6 : 4) < (1ll << 32), AZ_E_SHAPE);
   }
   hipStream_t st = az_s(stream);
   if (!half && a->cout_s == 4 && a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->src1 && a->up0 == 0 &&
@@ -1466,6 +1690,8 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     hipLaunchKernelGGL(conv_igemm_half_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
   else if (half == 2)
     hipLaunchKernelGGL(conv_igemm_half_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
+  else if (half == 3)
+    hipLaunchKernelGGL(conv_igemm_x3_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
   int rc = az_launch_status();

@@ -95,6 +95,36 @@ __global__ __launch_bounds__(256) void pack_conv_weight_half_kernel(unsigned sho
   }
 }
 
+// Three-piece bf16 split of the same [tap][co][ci_packed] layout for the fp32-on-bf16-pipe kernel (conv_igemm_x3_kernel):
+// dst = [piece][tap][cout_s][cin_s]; w = w1 + w2 + w3 exactly (8-bit slices of the significand, by truncation).
+__global__ __launch_bounds__(256) void pack_conv_weight_x3_kernel(unsigned short* __restrict__ dst,
+                                                                  const float* __restrict__ src, int cout, int cin,
+                                                                  int taps, int cout_s, int cin0, int c0s, int cin_s) {
+  const int64_t total = (int64_t)taps * cout_s * cin_s;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int cip = (int)(e % cin_s);
+    const int co = (int)((e / cin_s) % cout_s);
+    const int tap = (int)(e / ((int64_t)cin_s * cout_s));
+    int ci = -1;
+    if (cip < c0s) {
+      if (cip < cin0) ci = cip;
+    } else {
+      const int r = cip - c0s;
+      if (r < cin - cin0) ci = cin0 + r;
+    }
+    float v = 0.f;
+    if (ci >= 0 && co < cout) v = src[((int64_t)co * cin + ci) * taps + tap];
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const float r1 = v - __builtin_bit_cast(float, u & 0xFFFF0000u);
+    const unsigned u1 = __builtin_bit_cast(unsigned, r1);
+    const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+    dst[e] = (unsigned short)(u >> 16);
+    dst[total + e] = (unsigned short)(u1 >> 16);
+    dst[2 * total + e] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+  }
+}
+
 // Winograd F(2x2,3x3) filter transform U = G g G^T (accumulated in fp64, rounded once) written
 // directly in the layout conv_winograd_kernel streams: [8-cin chunk][64-cout block][16][64][8].
 __global__ __launch_bounds__(256) void winograd_filter_kernel(float* __restrict__ dst, const float* __restrict__ src,
@@ -222,6 +252,17 @@ int az_pack_conv_weight_half_f32(void* dst, const float* src, int32_t cout, int3
   else
     hipLaunchKernelGGL(pack_conv_weight_half_kernel<false>, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream),
                        (unsigned short*)dst, src, cout, cin, ks * ks, cout_s, cin0, c0s, cin_s);
+  return az_launch_status();
+}
+
+int az_pack_conv_weight_x3_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t ks, int32_t cout_s,
+                               int32_t cin0, int32_t c0s, int32_t cin_s, az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(cout > 0 && cin > 0 && ks > 0 && cout_s >= cout && cout_s % 4 == 0 && cin_s % 4 == 0, AZ_E_SHAPE);
+  AZ_REQUIRE(cin0 >= 0 && cin0 <= cin && c0s >= cin0 && cin_s >= c0s + (cin - cin0), AZ_E_SHAPE);
+  const int64_t total = (int64_t)ks * ks * cout_s * cin_s;
+  hipLaunchKernelGGL(pack_conv_weight_x3_kernel, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream),
+                     (unsigned short*)dst, src, cout, cin, ks * ks, cout_s, cin0, c0s, cin_s);
   return az_launch_status();
 }
 

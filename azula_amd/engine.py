@@ -125,6 +125,11 @@ class Act:
 # "2" = F(2x2) wherever it is legal (used by the parity tests to push whole networks through it),
 # "4" = the faster but inexact F(4x4,3x3) on layers with >= WINOGRAD4_MIN_TILES tiles, "1" elsewhere
 WINOGRAD = os.environ.get("AZ_WINOGRAD", "1")
+# How fp32 convolutions / token GEMMs use the matrix pipe: "native" = v_mfma_f32_32x32x2_f32 (default: Winograd + direct
+# kernels), "bf16x3" = operands split exactly into three bf16 pieces, six partial products on the bf16 MFMA
+# (az_conv2d_x3_f32: fp32-level accuracy at 0.375 x the matrix-pipe time; opt-in until it has been reviewed).
+FP32_MFMA = os.environ.get("AZ_FP32_MFMA", "native")
+assert FP32_MFMA in ("native", "bf16x3"), FP32_MFMA
 WINOGRAD4_MIN_TILES = int(os.environ.get("AZ_WINOGRAD4_MIN_TILES", "1024"))
 
 
@@ -148,7 +153,7 @@ class ConvWeights:
         if bias is not None:
             self.bias = torch.zeros(self.cout_s, dtype=torch.float32, device=bld.device)
             self.bias[: self.cout] = bias.detach().to(device=bld.device, dtype=torch.float32)
-        self._direct = self._wino = self._wino4 = None
+        self._direct = self._wino = self._wino4 = self._x3 = None
         self._half: dict = {}
 
     def direct(self) -> torch.Tensor:
@@ -174,6 +179,18 @@ class ConvWeights:
             )
             self._half[f16] = packed
         return self._half[f16]
+
+    def direct_x3(self) -> torch.Tensor:
+        r"""The direct layout as three bf16 planes (w = w1 + w2 + w3 exactly), for ``az_conv2d_x3_f32``."""
+        if self._x3 is None:
+            cin_s = self.c0s + self.c1s
+            packed = torch.empty(3 * self.ks * self.ks * self.cout_s * cin_s, dtype=torch.int16, device=self.device)
+            _lib.call(
+                "az_pack_conv_weight_x3_f32", packed.data_ptr(), self.w.data_ptr(), self.cout, self.cin, self.ks,
+                self.cout_s, self.cin0, self.c0s, cin_s, _lib.stream_ptr(),
+            )
+            self._x3 = packed
+        return self._x3
 
     def winograd(self) -> torch.Tensor:
         r"""Filter transform U = G g G^T (az_winograd_pack_filter_f32: fp64 accumulate, one-off) laid out
@@ -308,13 +325,17 @@ class Builder:
         lib = _lib.lib()
         legal = ks == 3 and stride == 1 and self.half is None  # half-precision modules: the direct bf16 / f16 kernel
         tiles4 = B * ((hout + 3) // 4) * ((wout + 3) // 4)
-        use_f4 = legal and (winograd == 4 or (winograd is None and WINOGRAD == "4" and tiles4 >= WINOGRAD4_MIN_TILES))
-        use_wino = legal and not use_f4 and ((WINOGRAD != "0") if winograd is None else bool(winograd))
         head_wgs = B * ((hout + 15) // 16) * ((wout + 15) // 16)
-        if winograd is None and legal and a.cout_s == 4 and src1 is None and up0 == 0 and a.c0s % 16 == 0 and head_wgs >= 256:
-            # image head (<= 4 output channels) on a map that fills the chip with 16 x 16-pixel workgroups:
-            # az_conv2d_f32 runs its narrow-output VALU kernel (104 vs 342 us at 4 x 256^2, 256 -> 3)
-            use_wino = use_f4 = False
+        # image head (<= 4 output channels) on a map that fills the chip with 16 x 16-pixel workgroups:
+        # az_conv2d_f32 runs its narrow-output VALU kernel (104 vs 342 us at 4 x 256^2, 256 -> 3)
+        head = (winograd is None and legal and a.cout_s == 4 and src1 is None and up0 == 0 and a.c0s % 16 == 0
+                and head_wgs >= 256)
+        use_x3 = self.half is None and (
+            winograd == "x3" or (winograd is None and FP32_MFMA == "bf16x3" and not head and cin_s >= 32 and a.cout_s >= 32)
+        )
+        wino_ok = legal and not head and not use_x3
+        use_f4 = wino_ok and (winograd == 4 or (winograd is None and WINOGRAD == "4" and tiles4 >= WINOGRAD4_MIN_TILES))
+        use_wino = wino_ok and not use_f4 and ((WINOGRAD != "0") if winograd is None else bool(winograd))
         if use_wino:
             tiles = B * ((hout + 1) // 2) * ((wout + 1) // 2)
             a.splitk = lib.az_conv2d_winograd_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
@@ -327,6 +348,10 @@ class Builder:
         elif use_wino:
             a.weight = packed.winograd().data_ptr()
             name = "az_conv2d_winograd_f32"
+        elif use_x3:
+            a.weight = packed.direct_x3().data_ptr()
+            a.splitk = lib.az_conv2d_suggest_splitk(npix, a.cout_s, cin_s, ks)
+            name = "az_conv2d_x3_f32"
         elif self.half is not None:
             a.weight = packed.direct_half(self.half == torch.float16).data_ptr()
             a.splitk = lib.az_conv2d_suggest_splitk(npix, a.cout_s, cin_s, ks)

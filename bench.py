@@ -112,7 +112,8 @@ def build_denoiser(cfg, device):
     return KarrasDenoiser(wrapped, VPSchedule()).to(device).eval()
 
 
-CONV_OPS = ("az_conv2d_f32", "az_conv2d_winograd_f32", "az_conv2d_winograd4_f32", "az_conv2d_bf16_f32", "az_conv2d_f16_f32")
+CONV_OPS = ("az_conv2d_f32", "az_conv2d_winograd_f32", "az_conv2d_winograd4_f32", "az_conv2d_bf16_f32", "az_conv2d_f16_f32",
+            "az_conv2d_x3_f32")
 
 
 def conv_roofline(sampler, device):
@@ -150,7 +151,7 @@ def conv_roofline(sampler, device):
             )
     out = {}
     for algo in ("az_conv2d_winograd_f32", "az_conv2d_f32"):
-        same = (algo,) if algo != "az_conv2d_f32" else ("az_conv2d_f32", "az_conv2d_bf16_f32", "az_conv2d_f16_f32")
+        same = (algo,) if algo != "az_conv2d_f32" else ("az_conv2d_f32", "az_conv2d_bf16_f32", "az_conv2d_f16_f32", "az_conv2d_x3_f32")
         sel = [(r, d) for r, d in zip(recs, convs) if d._algo in same]
         out[algo] = dict(
             flops=sum(r[2] for r, _ in sel), ms=sum(r[0].elapsed_time(r[1]) for r, _ in sel), launches=len(sel)

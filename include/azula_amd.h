@@ -267,6 +267,12 @@ int az_conv2d_f32(const AzConvArgs* args, az_stream_t stream);
  * output; src / res / dst stay fp32 tensors -- activations are rounded to the operand type while they are staged.   */
 int az_conv2d_bf16_f32(const AzConvArgs* args, az_stream_t stream);
 int az_conv2d_f16_f32(const AzConvArgs* args, az_stream_t stream);
+/* fp32 operands on the bf16 matrix pipe ("bf16x3", opt-in: AZ_FP32_MFMA=bf16x3): each fp32 value is split exactly into
+ * three bf16 pieces and a product is the six largest of the nine partial products, accumulated in fp32
+ * (6 x v_mfma_f32_32x32x16_bf16 per 16 channels = 0.375 x the time of 8 x v_mfma_f32_32x32x2_f32).  Error vs fp64 at the
+ * level of the fp32 kernel and below the Winograd form's.  `weight` = az_pack_conv_weight_x3_f32 output; everything else
+ * (fp32 src / res / dst, the fused epilogue) as az_conv2d_f32.  Same reference op: azula/nn/layers.py:48-55 ConvNd.  */
+int az_conv2d_x3_f32(const AzConvArgs* args, az_stream_t stream);
 /* Winograd F(2x2,3x3) form of the same operation for ksize = 3, stride = 1, pad = 1: 2.25x fewer
  * multiplies in exact fp32 (transforms only add/subtract; the input transform, the 16 frequency
  * GEMMs and the output transform + epilogue are ONE kernel).  `weight` must be the host-side
@@ -355,6 +361,10 @@ int az_unpatchify_f32(float* dst, const float* src, int64_t B, int64_t Z, int64_
 /* az_pack_conv_weight_f32's layout in 2-byte elements (f16 != 0: IEEE half, else bfloat16; round to nearest even). */
 int az_pack_conv_weight_half_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t ks, int32_t cout_s,
                                  int32_t cin0, int32_t c0s, int32_t cin_s, int32_t f16, az_stream_t stream);
+/* The same layout as three bf16 planes [piece][tap][cout_s][cin_s] with w = w1 + w2 + w3 exactly (az_conv2d_x3_f32);
+ * dst holds 3 * ks*ks*cout_s*cin_s two-byte elements.                                                              */
+int az_pack_conv_weight_x3_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t ks, int32_t cout_s,
+                               int32_t cin0, int32_t c0s, int32_t cin_s, az_stream_t stream);
 
 /* torch (cout, cin, 3, 3) -> Winograd filter transform U = G g G^T (fp64 accumulate, one rounding) in
  * the layout az_conv2d_winograd_f32 streams: [nk chunks of 8 cin][cblocks of 64 cout][16][64][8]; input

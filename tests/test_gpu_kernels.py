@@ -351,17 +351,17 @@ CONV_CASES = [
 def conv_tol(cin, ks, wino=False):
     """Direct: exact fp32 fmaf chains.  F(2x2,3x3) only adds/subtracts (3x).  F(4x4,3x3) multiplies by up to 8
     and its filter transform by 1/24: ~20x the rounding error of F(2x2) (stated in include/azula_amd.h)."""
-    return (3e-6 * math.sqrt(cin * ks * ks) + 1e-5) * {False: 1, True: 3, 4: 40}[wino]
+    return (3e-6 * math.sqrt(cin * ks * ks) + 1e-5) * {False: 1, True: 3, 4: 40, "x3": 1}[wino]
 
 
-WINO_NAME = {False: "az_conv2d_f32", True: "az_conv2d_winograd_f32", 4: "az_conv2d_winograd4_f32"}
+WINO_NAME = {False: "az_conv2d_f32", True: "az_conv2d_winograd_f32", 4: "az_conv2d_winograd4_f32", "x3": "az_conv2d_x3_f32"}
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ks,stride", CONV_CASES)
 @pytest.mark.parametrize("splitk", [0, 3])
-@pytest.mark.parametrize("wino", [False, True, 4])
+@pytest.mark.parametrize("wino", [False, True, 4, "x3"])
 def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk, wino):
-    if wino and (ks != 3 or stride != 1):
+    if wino in (True, 4) and (ks != 3 or stride != 1):
         pytest.skip("Winograd is the stride-1 3x3 path")
     from azula_amd.engine import Act, Builder
 
@@ -387,7 +387,7 @@ def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk, wino):
     assert (y.buf.reshape(B, y.H, y.W, y.cs)[..., Cout:] == 0).all()
 
 
-@pytest.mark.parametrize("wino", [False, True, 4])
+@pytest.mark.parametrize("wino", [False, True, 4, "x3"])
 def test_conv2d_random_shapes(az, wino):
     """Seeded sweep over ragged shapes (odd sizes, channel counts off the 4 / 8 / 32 grids, batch 1-3, optional second
     source with nearest-x2 upsampling, SiLU / gate / residual) for the three 3x3 stride-1 algorithms."""
@@ -395,7 +395,7 @@ def test_conv2d_random_shapes(az, wino):
 
     from azula_amd.engine import Act, Builder
 
-    rnd = random.Random(1234 + (7 if wino is True else int(wino)))
+    rnd = random.Random(1234 + {False: 0, True: 7, 4: 4, "x3": 3}[wino])
     g = torch.Generator().manual_seed(99)
     for case in range(10):
         B = rnd.randint(1, 3)
@@ -434,7 +434,7 @@ def test_conv2d_random_shapes(az, wino):
         assert err < conv_tol(C0 + C1, 3, wino) * max(1.0, ref.abs().max().item()), (case, B, H, W, C0, C1, Cout, act, err)
 
 
-@pytest.mark.parametrize("wino", [False, True, 4])
+@pytest.mark.parametrize("wino", [False, True, 4, "x3"])
 def test_conv2d_concat_upsample_narrow_gate_res(az, wino):
     """cat((y, upsample(x)[narrowed])) -> conv -> x0 + c * silu-free epilogue, as azula/nn/unet.py:253-257,93."""
     from azula_amd.engine import Act, Builder
@@ -460,7 +460,7 @@ def test_conv2d_concat_upsample_narrow_gate_res(az, wino):
     assert max_err(from_nhwc(out.buf.reshape(B, H, W, 12), Cout), ref) < conv_tol(Cy + Cx, 3, wino)
 
 
-@pytest.mark.parametrize("wino", [False, True, 4])
+@pytest.mark.parametrize("wino", [False, True, 4, "x3"])
 def test_conv2d_nchw_output_and_res_up(az, wino):
     from azula_amd.engine import Act, Builder
 
@@ -514,6 +514,34 @@ def test_conv2d_narrow_output_kernel(az, B, Cin, Cout, H, W, nchw):
     bld.tape.run()
     out = dst if nchw else from_nhwc(y.buf.reshape(B, H, W, 4), Cout)
     assert max_err(out, ref) < conv_tol(Cin, 3) * max(1.0, ref.abs().max().item())
+
+
+def test_conv2d_x3_accuracy(az):
+    """fp32 operands as 3 x bf16 pieces / 6 partial products (az_conv2d_x3_f32) against an fp64 reference, next to the
+    fp32-MFMA direct kernel and the Winograd form on the same layer (Cin = 256, K = 2304): the split path must be at
+    the accuracy level of the direct fp32 kernel (<= 2x its error) and no worse than the Winograd kernel."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cout, H, W = 1, 256, 128, 32, 32
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, 1, 1, generator=g))  # mixed channel scales
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    errs = {}
+    for mode in (False, True, "x3"):
+        bld = Builder(torch.device("cuda"))
+        xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
+        y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, winograd=mode)
+        assert bld.tape.ops[-1][2] == WINO_NAME[mode]
+        bld.finish()
+        bld.tape.run()
+        out = from_nhwc(y.buf.reshape(B, H, W, Cout), Cout).double().cpu()
+        e = (out - ref).abs()
+        errs[mode] = (e.max().item(), e.pow(2).mean().sqrt().item())
+    print("conv error vs fp64 (max, rms):", errs)
+    assert errs["x3"][1] <= 2.0 * errs[False][1] and errs["x3"][0] <= 2.0 * errs[False][0], errs
+    assert errs["x3"][1] <= errs[True][1], errs
 
 
 def test_graph_capture_replay(az):
