@@ -130,6 +130,7 @@ WINOGRAD = os.environ.get("AZ_WINOGRAD", "1")
 # (az_conv2d_x3_f32: fp32-level accuracy at 0.375 x the matrix-pipe time; opt-in until it has been reviewed).
 FP32_MFMA = os.environ.get("AZ_FP32_MFMA", "native")
 assert FP32_MFMA in ("native", "bf16x3"), FP32_MFMA
+X3_MIN_CHANNELS = 32  # bf16x3 only where both channel counts fill a K tile / an MFMA tile
 WINOGRAD4_MIN_TILES = int(os.environ.get("AZ_WINOGRAD4_MIN_TILES", "1024"))
 
 
@@ -331,7 +332,7 @@ class Builder:
         head = (winograd is None and legal and a.cout_s == 4 and src1 is None and up0 == 0 and a.c0s % 16 == 0
                 and head_wgs >= 256)
         use_x3 = self.half is None and (
-            winograd == "x3" or (winograd is None and FP32_MFMA == "bf16x3" and not head and cin_s >= 32 and a.cout_s >= 32)
+            winograd == "x3" or (winograd is None and FP32_MFMA == "bf16x3" and not head and cin_s >= X3_MIN_CHANNELS and a.cout_s >= X3_MIN_CHANNELS)
         )
         wino_ok = legal and not head and not use_x3
         use_f4 = wino_ok and (winograd == 4 or (winograd is None and WINOGRAD == "4" and tiles4 >= WINOGRAD4_MIN_TILES))

@@ -255,7 +255,12 @@ def main() -> None:
     ap.add_argument("--denoise-steps", type=int, default=0, help="override the config's sampler steps (checks only)")
     ap.add_argument("--half", choices=["bf16", "f16"], default=None,
                     help="cast the backbone to half precision (mixed-precision mode; NOT the headline fp32 number)")
+    ap.add_argument("--fp32-mfma", choices=["native", "bf16x3"], default=None,
+                    help="how fp32 convs / GEMMs use the matrix pipe (default: env AZ_FP32_MFMA or native fp32 MFMA); "
+                         "bf16x3 = exact 3-piece bf16 split, 6 partial products, fp32 accumulate (opt-in, NOT the headline)")
     args = ap.parse_args()
+    if args.fp32_mfma:
+        os.environ["AZ_FP32_MFMA"] = args.fp32_mfma  # read by azula_amd.engine at import
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -284,6 +289,11 @@ def main() -> None:
         inner = den.denoiser if hasattr(den, "denoiser") else den
         inner.backbone.to(torch.bfloat16 if args.half == "bf16" else torch.float16)
         cfg["name"] += f" [backbone cast to {args.half}: MFMA operands {args.half}, fp32 accumulate -- not a headline number]"
+    from azula_amd import engine as _engine
+
+    if _engine.FP32_MFMA != "native" and not args.half:
+        cfg["name"] += (f" [AZ_FP32_MFMA={_engine.FP32_MFMA}: fp32 operands split into 3 bf16 pieces, 6 partial products on "
+                        "the bf16 MFMA, fp32 accumulate -- opt-in mode, not the headline number]")
     Smp = DDPMSampler if cfg.get("sampler") == "ddpm" else DDIMSampler
     sampler = Smp(den, steps=cfg["steps"], silent=True)
     B = cfg["batch"]
@@ -339,7 +349,8 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if not args.half else f"{args.half} operands / f32 accumulate",
+            "dtype": (f"{args.half} operands / f32 accumulate" if args.half
+                      else ("f32" if _engine.FP32_MFMA == "native" else f"f32 ({_engine.FP32_MFMA} split on the bf16 MFMA)")),
             "data": "synthetic (random-init weights under seed 0, x1 ~ sampler.init under seed 1)",
             "config": {"workload": cfg["name"], "per_gpu_batch": B, "global_batch": world * B,
                        "denoise_steps": cfg["steps"], "parallelism": f"batch-sharded x{world}, all-gather of x0"},

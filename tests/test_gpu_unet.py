@@ -145,6 +145,27 @@ def test_unet_forward_through_winograd(golden, monkeypatch):
         assert err < 2e-4 * max(1.0, sc)
 
 
+def test_unet_forward_through_bf16x3(golden, monkeypatch):
+    """The same reference vectors with the fp32 convolutions evaluated on the bf16 MFMA as 3 x bf16 pieces / 6 partial
+    products (AZ_FP32_MFMA=bf16x3, az_conv2d_x3_f32): same tolerance as the native fp32 path."""
+    from azula_amd import engine
+
+    monkeypatch.setattr(engine, "FP32_MFMA", "bf16x3")
+    monkeypatch.setattr(engine, "X3_MIN_CHANNELS", 4)  # the golden UNets are narrow
+    for name in ("unet_group", "unet_layer_odd"):
+        g = golden("g5_" + name)
+        cfg = g.meta["cfg"]
+        net = build_unet(cfg)
+        net.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"]))
+        net = net.cuda().eval()
+        y = net(g["x"].cuda(), g["modB"].cuda())
+        plan = next(iter(net._plans.values()))
+        assert any(name_ == "az_conv2d_x3_f32" for _, _, name_ in plan.tape.ops)
+        err, sc = max_err(y, g["y_modB"]), g["y_modB"].abs().max().item()
+        print(name, "bf16x3 max|d| vs reference:", err, "scale", sc)
+        assert err < 1e-4 * max(1.0, sc)
+
+
 def test_next_samplers_on_gpu(golden):
     """Euler and Ito ride the fused transition kernel (folded coefficients), Heun the generic
     two-evaluation step; all against reference-generated vectors (G8)."""

@@ -90,6 +90,30 @@ def test_vit_forward_matches_reference(golden):
         assert err < 1e-4 * max(1.0, sc)
 
 
+def test_vit_ddim50_through_bf16x3(golden, monkeypatch):
+    """DDIM-50 of the golden ViT with every token GEMM on the bf16 MFMA as 3 x bf16 pieces / 6 partial products
+    (AZ_FP32_MFMA=bf16x3): same tolerance as the native fp32 run (hid_channels = 64 >= 32, so the GEMMs qualify)."""
+    from azula_amd import engine
+    from azula_amd.denoise import KarrasDenoiser
+    from azula_amd.nn import TimeModulated
+    from azula_amd.noise import VPSchedule
+    from azula_amd.sample import DDIMSampler
+
+    monkeypatch.setattr(engine, "FP32_MFMA", "bf16x3")
+    g = golden("g6_vit_loop")
+    cfg = g.meta["cfg"]
+    w = TimeModulated(build_vit(cfg), cfg["mod_features"], name="vit")
+    w.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"]))
+    den = KarrasDenoiser(w, VPSchedule()).cuda().eval()
+    smp = DDIMSampler(den, steps=50, silent=True)
+    x0 = smp(g["x1"].cuda())
+    loop = next(iter(smp._fused_cache.values()))
+    assert any(name_ == "az_conv2d_x3_f32" for _, _, name_ in loop.tape.ops)
+    err, sc = max_err(x0, g["ddim50"]), g["ddim50"].abs().max().item()
+    print("ViT DDIM-50 bf16x3 max|d| vs reference:", err, "scale", sc)
+    assert err < 5e-4 * max(1.0, sc)
+
+
 def test_dit_token_forward_matches_oracle(golden):
     from azula_amd.nn import DiT
 
