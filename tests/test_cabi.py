@@ -84,6 +84,9 @@ def test_argument_errors_are_returned_not_raised(built_lib):
     conv = _lib.AzConvArgs(src0=0x1008, weight=0x1000, dst=0x1000, c0s=8, cout_s=8, batch=1, hin=4, win=4, hout=4, wout=4,
                            ksize=3, stride=1, pad=1, splitk=1, h0=4, w0=4)
     assert lib.az_conv2d_f32(ctypes.byref(conv), None) == -3  # src0 not 16-byte aligned: AZ_E_ALIGN
+    assert lib.az_conv2d_x3_f32(ctypes.byref(conv), None) == -3  # the bf16x3 entry shares the validation
+    assert lib.az_pack_conv_weight_x3_f32(None, 0x1000, 8, 8, 3, 8, 8, 8, 8, None) == -1
+    assert lib.az_pack_conv_weight_x3_f32(0x1000, 0x1000, 8, 8, 3, 6, 8, 8, 8, None) == -2  # cout_s < cout / not % 4
     conv.src0, conv.stride = 0x1000, 2
     assert lib.az_conv2d_winograd_f32(ctypes.byref(conv), None) == -4  # Winograd is stride 1 only
     ms = _lib.AzMultistepArgs(x_s=0x1000, pred=0x1000, x_t=0x1000, mean=0x1000, coef=0x1000, count=16, n_hist=9)
