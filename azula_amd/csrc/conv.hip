@@ -977,10 +977,12 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvP p) {
 //   * 8 waves (2 per SIMD, so one wave's MFMAs cover its SIMD partner's loads / transform / barrier
 //     waits): each owns 8 of the 16 frequencies of a (32 couts x 32 tiles) sub-block as 8
 //     accumulators of v_mfma_f32_32x32x2_f32; the output transform A^T M A is linear, so every wave
-//     reduces its 8 frequencies to a partial 2x2 output in registers and the halves meet through
-//     LDS once per workgroup before the same fused epilogue (bias, SiLU, gate, residual, store).
+//     reduces its 8 frequencies to a partial 2x2 output in registers; both halves park it in an LDS
+//     exchange buffer laid out [tile][pixel][cout] and all 8 waves read it back row-wise, so that the
+//     fused epilogue (bias, SiLU, gate, residual, store) writes whole 128-byte lines.
 // Block = 64 couts x 64 tiles (= 256 output pixels), K stage = 8 input channels, XOR-swizzled
-// 8-float LDS rows (conflict-free ds_read_b128 fragments), 2 stages = 128 KB -> one workgroup per CU.
+// 8-float LDS rows (conflict-free ds_read_b128 fragments), 2 stages = 128 KB (131 KB with the padded
+// exchange buffer that reuses them) -> one workgroup per CU.
 constexpr int WT = 64;                 // tiles per workgroup (= 256 output pixels)
 constexpr int WC = 64;                 // output channels per workgroup
 constexpr int WK = 8;                  // input channels per stage
