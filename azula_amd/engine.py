@@ -331,10 +331,7 @@ class Builder:
         # az_conv2d_f32 runs its narrow-output VALU kernel (104 vs 342 us at 4 x 256^2, 256 -> 3)
         head = (winograd is None and legal and a.cout_s == 4 and src1 is None and up0 == 0 and a.c0s % 16 == 0
                 and head_wgs >= 256)
-        use_x3 = self.half is None and (
-            winograd == "x3" or (winograd is None and FP32_MFMA == "bf16x3" and not head and cin_s >= X3_MIN_CHANNELS and a.cout_s >= X3_MIN_CHANNELS)
-        )
-        wino_ok = legal and not head and not use_x3
+        wino_ok = legal and not head and winograd != "x3"
         use_f4 = wino_ok and (winograd == 4 or (winograd is None and WINOGRAD == "4" and tiles4 >= WINOGRAD4_MIN_TILES))
         use_wino = wino_ok and not use_f4 and ((WINOGRAD != "0") if winograd is None else bool(winograd))
         if use_wino:
@@ -342,6 +339,14 @@ class Builder:
             a.splitk = lib.az_conv2d_winograd_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
             if winograd is None and WINOGRAD in ("1", "4") and tiles < 64:
                 use_wino = False  # less than one 64-tile block (measured: 8x8 at batch < 4): the direct kernel wins
+        # bf16x3 mode replaces the DIRECT fp32 kernel (1x1 convs / token GEMMs, stride 2, small maps: 147-181 vs 113-128
+        # TF/s); the 3x3 stride-1 layers stay on the fp32 Winograd kernel, which executes 2.25x fewer multiplies
+        # (221 vs 181 TF/s algorithmic at 4 x 256^2, 256 -> 256).
+        use_x3 = self.half is None and (
+            winograd == "x3"
+            or (winograd is None and FP32_MFMA == "bf16x3" and not head and not use_wino and not use_f4
+                and cin_s >= X3_MIN_CHANNELS and a.cout_s >= X3_MIN_CHANNELS)
+        )
         if use_f4:
             a.weight = packed.winograd4().data_ptr()
             a.splitk = lib.az_conv2d_winograd4_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
