@@ -363,6 +363,10 @@ def main() -> None:
         out["roofline"] = {
             "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": None,
+            "traffic_note": "MFMA-bound kernel over 55 launches of different shapes; rocprofv3 --pmc on its largest layer "
+                            "(4x256x256, 256->256): FETCH_SIZE 388 MB + WRITE_SIZE 240 MB per launch = 1.4x the compulsory "
+                            "541 MB, L2 hit rate 92 % (8-byte gathers: counters uncalibrated, hence null) -- "
+                            "profiles/r01_hbm_traffic_pmc.txt",
             "kernel": dom_name + " (fp32 v_mfma_f32_32x32x2_f32), all its launches in one backbone forward",
             "launches": dom["launches"], "avg_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
             "note": "achieved = ALGORITHMIC direct-conv FLOP (2*pixels*Cout*Cin*9) / HIP-event time; the Winograd "
