@@ -634,10 +634,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
 // channels take 6 x 32 cycles against 8 x 64 for v_mfma_f32_32x32x2_f32: 0.375 x the matrix-pipe time.
 // Weights are split once (az_pack_conv_weight_x3_f32: [piece][tap][cout_s][cin_s] bf16); activations stay fp32 in HBM
 // and are split by the loader threads while they are staged (2 ANDs, 2 subtractions, 1.5 byte-permutes per value).
-// Tile 128 couts x 128 pixels, K tile = 32 channels of one tap; LDS: 6 planes of 128 rows x 80 B (conflict-free
-// ds_read_b128 fragments) = 60 KB, single-buffered with register prefetch, two workgroups per CU.
+// Tile 128 couts x 128 pixels, K tile = 32 channels of one tap; LDS: 6 planes of 128 rows x 64 B = 48 KB, the four
+// 16-byte chunks of a row XOR-swizzled with bits 2..3 of the row so that both the loader's ds_write_b128 (4 rows x 4
+// chunks per 16 lanes) and the fragment ds_read_b128 (16 rows x 1 chunk) are bank-conflict-free (the padded 80-byte
+// rows of the first version had 2-way write conflicts: SQ_LDS_BANK_CONFLICT = 11 % of the kernel time);
+// single-buffered with register prefetch, two workgroups per CU.
 constexpr int XBK = 32;                       // k tile
-constexpr int XLDS = 40;                      // LDS row stride in 2-byte elements (80 B)
+constexpr int XLDS = 32;                      // LDS row = the 32 k-values of a tile (64 B), 16-byte chunks XOR-swizzled by row
 constexpr int XPLANE = 128 * XLDS;            // 2-byte elements per (operand, piece) plane
 constexpr int X_LDS_BYTES = (BN * OSTR + BN) * 4;  // the epilogue's exchange buffer (68,096 B) >= 6 planes (61,440 B)
 static_assert(6 * XPLANE * 2 <= X_LDS_BYTES, "stage planes must fit under the epilogue buffer");
@@ -774,12 +777,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
       set_tap_src();
     }
   };
+  const int wsw = (kc8 ^ ((r0 >> 2) & 3)) * 8;  // swizzled chunk of this thread's rows (r0 and r0 + 64 share bits 2..3)
   auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        *reinterpret_cast<float4*>(xsm + pl * XPLANE + (r0 + 64 * i) * XLDS + kc8 * 8) = ra[pl][i];
+        *reinterpret_cast<float4*>(xsm + pl * XPLANE + (r0 + 64 * i) * XLDS + wsw) = ra[pl][i];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const float x[8] = {rb[i][0].x, rb[i][0].y, rb[i][0].z, rb[i][0].w, rb[i][1].x, rb[i][1].y, rb[i][1].z, rb[i][1].w};
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
       for (int j = 0; j < 4; ++j) split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-        *reinterpret_cast<uint4*>(xsm + (3 + pl) * XPLANE + (r0 + 64 * i) * XLDS + kc8 * 8) =
+        *reinterpret_cast<uint4*>(xsm + (3 + pl) * XPLANE + (r0 + 64 * i) * XLDS + wsw) =
             make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
     }
   };
@@ -801,9 +805,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int frag_off = (lane & 31) * XLDS + (lane >> 5) * 8;
-  const unsigned short* As = xsm + (wc * 64) * XLDS + frag_off;               // + piece * XPLANE + tile * 32 * XLDS
-  const unsigned short* Bs = xsm + 3 * XPLANE + (wp * 64) * XLDS + frag_off;
+  const int frag_row = (lane & 31) * XLDS;
+  const int fsw = ((lane & 31) >> 2) & 3;  // the row's swizzle (tile bases are multiples of 32 rows)
+  const int fch[2] = {((0 + (lane >> 5)) ^ fsw) * 8, ((2 + (lane >> 5)) ^ fsw) * 8};  // K step ks: chunk 2 ks + lane half
+  const unsigned short* As = xsm + (wc * 64) * XLDS + frag_row;               // + piece * XPLANE + tile * 32 * XLDS + chunk
+  const unsigned short* Bs = xsm + 3 * XPLANE + (wp * 64) * XLDS + frag_row;
 
   if (kt_begin < kt_end) {
     set_tap_src();
@@ -824,8 +830,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
       for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          fa[pl][t] = *reinterpret_cast<const bf16x8*>(As + pl * XPLANE + t * 32 * XLDS + ks * 16);
-          fb[pl][t] = *reinterpret_cast<const bf16x8*>(Bs + pl * XPLANE + t * 32 * XLDS + ks * 16);
+          fa[pl][t] = *reinterpret_cast<const bf16x8*>(As + pl * XPLANE + t * 32 * XLDS + fch[ks]);
+          fb[pl][t] = *reinterpret_cast<const bf16x8*>(Bs + pl * XPLANE + t * 32 * XLDS + fch[ks]);
         }
       // smallest partial products first
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
