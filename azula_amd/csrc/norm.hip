@@ -304,11 +304,72 @@ __global__ __launch_bounds__(256) void rownorm_mod_kernel(float* __restrict__ y,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int64_t scale_bstride,
                                                           int64_t rows, int64_t rows_per_batch, int C, int cs,
-                                                          int kind, float eps) {
+                                                          int kind, float eps, int fast) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const bool vec = (C % 4) == 0;
+  // Fast path (token widths of the ViT / DiT / JiT backbones): the row lives in registers (<= 8 float4 per lane), is
+  // read ONCE with 16-byte loads and written with 16-byte stores; the summation order is that of the generic path
+  // below (lane-sequential over c = 4 lane + 256 k, then the wave butterfly), so the results are bit-identical.
+  constexpr int NV = 8;
+  if (fast) {  // host: C % 4 == 0, C == cs, C <= 2048, weight / scale / shift 16-byte aligned rows
+    const int c0 = lane * 4;
+    for (int64_t row = wave; row < rows; row += nwaves) {
+      const float* xr = x + row * cs;
+      float* yr = y + row * cs;
+      const int64_t b = row / rows_per_batch;
+      float4 v[NV];
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int c = c0 + 256 * k;
+        if (c < C) {
+          v[k] = *reinterpret_cast<const float4*>(xr + c);
+          if (kind == 0) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+          else s += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+        }
+      }
+      s = az_wave_sum(s);
+      float mean = 0.f, rstd;
+      if (kind == 0) {
+        mean = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+          if (c0 + 256 * k < C) {
+            const float a0 = v[k].x - mean, a1 = v[k].y - mean, a2 = v[k].z - mean, a3 = v[k].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+          }
+        q = az_wave_sum(q);
+        rstd = rsqrtf(q / (float)(C - 1) + eps);
+      } else {
+        rstd = rsqrtf(s / (float)C + eps);
+      }
+      const float* sc = scale ? scale + b * scale_bstride : nullptr;
+      const float* sh = shift ? shift + b * scale_bstride : nullptr;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int c = c0 + 256 * k;
+        if (c < C) {
+          const float in[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+          float w4[4] = {1.f, 1.f, 1.f, 1.f}, sc4[4] = {0.f, 0.f, 0.f, 0.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (weight) { const float4 t = *reinterpret_cast<const float4*>(weight + c); w4[0] = t.x; w4[1] = t.y; w4[2] = t.z; w4[3] = t.w; }
+          if (sc) { const float4 t = *reinterpret_cast<const float4*>(sc + c); sc4[0] = t.x; sc4[1] = t.y; sc4[2] = t.z; sc4[3] = t.w; }
+          if (sh) { const float4 t = *reinterpret_cast<const float4*>(sh + c); sh4[0] = t.x; sh4[1] = t.y; sh4[2] = t.z; sh4[3] = t.w; }
+          float o4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float o = (in[j] - mean) * rstd;
+            if (weight) o *= w4[j];
+            o4[j] = o * (1.f + sc4[j]) + sh4[j];
+          }
+          *reinterpret_cast<float4*>(yr + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        }
+      }
+    }
+    return;
+  }
   for (int64_t row = wave; row < rows; row += nwaves) {
     const float* xr = x + row * cs;
     float* yr = y + row * cs;
@@ -445,8 +506,10 @@ int az_rownorm_mod_f32(float* y, const float* x, const float* weight, const floa
   AZ_REQUIRE(AZ_ALIGNED16(y) && AZ_ALIGNED16(x), AZ_E_ALIGN);
   int64_t blocks = (rows + 3) / 4;
   if (blocks > 4096) blocks = 4096;
+  const int fast = C % 4 == 0 && C == cs && C <= 2048 && AZ_ALIGNED16(weight) && AZ_ALIGNED16(scale) &&
+                   AZ_ALIGNED16(shift) && scale_bstride % 4 == 0;
   hipLaunchKernelGGL(rownorm_mod_kernel, dim3((unsigned)blocks), dim3(256), 0, az_s(stream), y, x, weight, scale,
-                     shift, scale_bstride, rows, rows_per_batch, (int)C, (int)cs, (int)kind, eps);
+                     shift, scale_bstride, rows, rows_per_batch, (int)C, (int)cs, (int)kind, eps, fast);
   return az_launch_status();
 }
 
