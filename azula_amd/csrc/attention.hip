@@ -122,6 +122,25 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
   const int lr = POW2 ? tid / CH : wave * RW + lane / CH;
   const bool lactive = POW2 || lane < RW * CH;
 
+  // register prefetch of the raw K / V rows of the NEXT tile: issued once the current tile has been staged, in
+  // flight under its MFMAs (the tile loop used to expose one global round trip per 64 keys and workgroup: 181 -> 173 us
+  // on 64 x 12 heads x 256 tokens, although 136 VGPRs now allow 3 instead of 4 waves per SIMD)
+  constexpr int NPS = (KT + RPP - 1) / RPP;
+  float4 pk[NPS], pv[NPS];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int row = ps * RPP + lr;
+      const int key = k0 + row;
+      pk[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pv[ps] = pk[ps];
+      if (row < KT && lactive && key < T) {
+        pk[ps] = *reinterpret_cast<const float4*>(kp + (int64_t)key * a.k_tstride + lc * 4);
+        pv[ps] = *reinterpret_cast<const float4*>(vp + (int64_t)key * a.v_tstride + lc * 4);
+      }
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < T; k0 += KT) {
     __syncthreads();  // previous tile fully consumed
 #pragma unroll
@@ -129,11 +148,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
       const int row = rr + lr;
       if (row < KT && lactive) {
         const int key = k0 + row;
-        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-        if (key < T) {
-          kv = *reinterpret_cast<const float4*>(kp + (int64_t)key * a.k_tstride + lc * 4);
-          vv = *reinterpret_cast<const float4*>(vp + (int64_t)key * a.v_tstride + lc * 4);
-        }
+        float4 kv = pk[rr / RPP], vv = pv[rr / RPP];
         if (a.qk_rmsnorm) {  // per-key RMS norm: CH consecutive lanes hold one row
           float ss = (kv.x * kv.x + kv.y * kv.y) + (kv.z * kv.z + kv.w * kv.w);
           if constexpr (POW2) {
@@ -180,6 +195,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
       }
     }
     __syncthreads();
+    if (k0 + KT < T) fetch(k0 + KT);
 
 #pragma unroll
     for (int sub = 0; sub < KT / 32; ++sub) {

@@ -1,0 +1,27 @@
+r"""Micro-benchmark of az_attention_f32 (fused qkv layout "nHC", q/k RMS norm on):  python tools/attn_micro.py B H T D [reps]"""
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from azula_amd.engine import Act, Builder
+
+B, H, T, D = (int(v) for v in sys.argv[1:5])
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 50
+dev = torch.device("cuda")
+torch.manual_seed(0)
+qkv = torch.randn(B * T * 3 * H * D, device=dev)
+bld = Builder(dev)
+out = bld.attention(Act(qkv, B, T, 1, 3 * H * D, 3 * H * D, True), H, "nHC", True, 1.0 / math.sqrt(D))
+for _ in range(5):
+    bld.tape.run()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    bld.tape.run()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+print(f"attention {B}x{H}x{T}x{D}: {ms * 1e3:.1f} us  {4 * B * H * T * T * D / ms / 1e9:.1f} TF/s")
