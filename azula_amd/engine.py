@@ -371,7 +371,7 @@ class Builder:
             self._ws_users.append(a)
         a._flops = 2 * npix * cout * (src0.C + (src1.C if src1 is not None else 0)) * ks * ks  # algorithmic
         a._algo = name
-        self.tape.add(name, C.byref(a), keep=[a])
+        self.tape.add(name, C.byref(a), keep=[a] if gate is None else [gate, a])  # the descriptor holds raw addresses
         return out
 
     def finish(self) -> None:

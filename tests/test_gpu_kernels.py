@@ -544,6 +544,37 @@ def test_conv2d_x3_accuracy(az):
     assert errs["x3"][1] <= errs[True][1], errs
 
 
+@pytest.mark.parametrize("wino", [False, True, "x3"])
+def test_conv2d_is_deterministic_across_launches(az, wino):
+    """Race screen for the LDS-exchange epilogues and the split-K combine: 12 launches of the same convolution (gate,
+    residual, SiLU; one with split-K) must give bit-identical outputs."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(77)
+    for (B, Cin, Cout, H, W, splitk) in ((2, 96, 160, 40, 36, 0), (1, 256, 192, 16, 16, 4)):
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+        b = torch.randn(Cout, generator=g)
+        gate, res = torch.randn(B, Cout, generator=g), torch.randn(B, Cout, H, W, generator=g)
+        bld = Builder(torch.device("cuda"))
+        xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
+        ra = Act(to_nhwc(dev(res)).reshape(-1), B, H, W, Cout, Cout, True)
+        gd = dev(gate)  # must outlive the tape: the descriptor only holds its address
+        y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, act=1, gate=gd, gate_bstride=Cout, res=ra, winograd=wino)
+        if splitk:
+            a = bld.tape.keep[-1]
+            a.splitk = splitk
+            bld._ws_need = max(bld._ws_need, splitk * B * H * W * y.cs)
+            bld._ws_users.append(a)
+        bld.finish()
+        bld.tape.run()
+        first = y.buf.clone()
+        for _ in range(11):
+            y.buf.fill_(float("nan"))
+            bld.tape.run()
+            assert torch.equal(y.buf, first)
+
+
 def test_graph_capture_replay(az):
     from azula_amd.engine import StepGraph, Tape
 
