@@ -1095,13 +1095,24 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
       if ((src1 ? 1 : 0) != cur_src) set_src(src1 ? 1 : 0);
       const int kc = src1 ? kt - p.nkc0 : kt;
       const unsigned soff = (unsigned)(kc * WK * 4);
-      const bool kv = kc * WK + vq * 2 < (src1 ? a.c1s : a.c0s);
-      if (src1) {
+      const int cs = src1 ? a.c1s : a.c0s;
+      if (kc * WK + WK <= cs) {  // whole chunk inside the source (wave-uniform): no per-lane channel-tail select
+        if (src1) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rv[i] = buf_ld2(rs1, kv ? voffV[i] : OOB, soff);
+          for (int i = 0; i < 16; ++i) rv[i] = buf_ld2(rs1, voffV[i], soff);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) rv[i] = buf_ld2(rs0, voffV[i], soff);
+        }
       } else {
+        const bool kv = kc * WK + vq * 2 < cs;
+        if (src1) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rv[i] = buf_ld2(rs0, kv ? voffV[i] : OOB, soff);
+          for (int i = 0; i < 16; ++i) rv[i] = buf_ld2(rs1, kv ? voffV[i] : OOB, soff);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) rv[i] = buf_ld2(rs0, kv ? voffV[i] : OOB, soff);
+        }
       }
     } else {
       const unsigned soff = (unsigned)(((int64_t)kt * p.cblocks + cb) * (WU_STAGE * 4));
