@@ -8,6 +8,7 @@ path of :mod:`azula_amd` goes through :func:`lib`, which raises if the shared ob
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 import threading
 
@@ -278,6 +279,22 @@ def check(rc: int, what: str) -> None:
 def stream_ptr(device: torch.device | None = None) -> int:
     r"""Raw ``hipStream_t`` of torch's current stream (kernels are stream-ordered with torch ops)."""
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def on_device(fn):
+    r"""Method decorator: runs ``fn(self, x, ...)`` with ``x``'s GPU as the current device.  Kernels and graphs are
+    launched on ``torch.cuda.current_stream()``, i.e. on the CURRENT device's stream; with the latent on ``cuda:1``
+    and ``cuda:0`` current they would otherwise run on GPU 0 against GPU-1 pointers, unordered with the torch ops on
+    GPU 1's stream.  The reference works on any device index (``azula/sample.py:139-161`` is device agnostic)."""
+
+    @functools.wraps(fn)
+    def wrapped(self, x, *args, **kwargs):
+        if torch.is_tensor(x) and x.is_cuda and x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):
+                return fn(self, x, *args, **kwargs)
+        return fn(self, x, *args, **kwargs)
+
+    return wrapped
 
 
 def ptr(t: torch.Tensor | None) -> int | None:

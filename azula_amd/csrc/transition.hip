@@ -27,14 +27,21 @@ __device__ __forceinline__ Coef load_coef(const AzStepCoef* c) {
   return k;
 }
 
+// torch.clip semantics: NaN propagates (fminf / fmaxf alone would turn a NaN mean into the bound and hide a
+// diverging run that the reference shows as NaN -- azula/plugins/adm/__init__.py:131-134).
+__device__ __forceinline__ float clip_nan(float m, float lo, float hi) {
+  const float c = fminf(fmaxf(m, lo), hi);
+  return m != m ? m : c;
+}
+
 // Posterior mean for one element, reference association order, every op rounded on its own.
 template <bool CFG>
 __device__ __forceinline__ float post_mean(const Coef& k, float x, float f, float fn) {
   float m = az_add(az_mul(k.c_skip, x), az_mul(k.c_out, f));
-  m = fminf(fmaxf(m, k.lo), k.hi);
+  m = clip_nan(m, k.lo, k.hi);
   if (CFG) {
     float mn = az_add(az_mul(k.c_skip, x), az_mul(k.c_out, fn));
-    mn = fminf(fmaxf(mn, k.lo), k.hi);
+    mn = clip_nan(mn, k.lo, k.hi);
     m = az_add(m, az_mul(k.g, az_sub(m, mn)));
   }
   return m;

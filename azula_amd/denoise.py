@@ -22,7 +22,7 @@ from . import _lib
 from .nn.utils import get_module_dtype
 from .noise import Schedule
 
-__all__ = ["Posterior", "DiracPosterior", "GaussianPosterior", "Denoiser", "KarrasDenoiser"]
+__all__ = ["Posterior", "DiracPosterior", "GaussianPosterior", "Denoiser", "SimpleDenoiser", "KarrasDenoiser"]
 
 
 class Posterior(abc.ABC):
@@ -127,6 +127,7 @@ class KarrasDenoiser(Denoiser):
         self.schedule = schedule
 
     @torch.no_grad()
+    @_lib.on_device
     def forward(self, x_t: Tensor, t: Tensor, **kwargs) -> DiracPosterior:
         alpha_t, sigma_t = self.schedule(t)
         alpha_t, sigma_t = _expand_like(alpha_t, x_t.ndim), _expand_like(sigma_t, x_t.ndim)
@@ -174,6 +175,7 @@ class SimpleDenoiser(Denoiser):
         self.schedule = schedule
 
     @torch.no_grad()
+    @_lib.on_device
     def forward(self, x_t: Tensor, t: Tensor, **kwargs) -> DiracPosterior:
         alpha_t, sigma_t = self.schedule(t)
         alpha_t, sigma_t = _expand_like(alpha_t, x_t.ndim), _expand_like(sigma_t, x_t.ndim)

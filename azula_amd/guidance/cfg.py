@@ -32,6 +32,7 @@ class CFGDenoiser(Denoiser):
         return self.denoiser.schedule
 
     @torch.no_grad()
+    @_lib.on_device
     def forward(
         self,
         x_t: Tensor,

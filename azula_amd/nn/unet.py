@@ -316,6 +316,7 @@ class UNet(nn.Module):
         return self._program(x, 0)[0]
 
     @torch.no_grad()
+    @_lib.on_device
     def forward(self, x: Tensor, mod: Tensor | None = None, cond: Tensor | None = None) -> Tensor:
         r"""x: (B, C_i, H, W); mod: (D) or (B, D); cond: (B, C_c, H, W) -> (B, C_o, H, W)."""
         out_dtype = self._check_device(x)

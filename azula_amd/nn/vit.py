@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from .. import _lib
 from ..engine import Act, Builder, pad4
 
 __all__ = ["DiT", "DiTBlock", "MultiheadSelfAttention", "ViT"]
@@ -284,6 +285,7 @@ class DiT(nn.Module):
         return p
 
     @torch.no_grad()
+    @_lib.on_device
     def forward(self, x: Tensor, mod: Tensor | None = None, pos: Tensor | None = None, cond: Tensor | None = None):
         r"""x: (B, L, C_i) tokens -> (B, L, C_o).  ``pos``: (L, P) or None (sequence indices)."""
         out_dtype = self._check_device(x)
@@ -361,6 +363,7 @@ class ViT(DiT):
         )
 
     @torch.no_grad()
+    @_lib.on_device
     def forward(self, x: Tensor, mod: Tensor | None = None, cond: Tensor | None = None) -> Tensor:
         r"""x: (B, C_i, H, W); mod: (D) or (B, D) -> (B, C_o, H, W)."""
         out_dtype = self._check_device(x)

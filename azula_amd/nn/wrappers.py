@@ -68,6 +68,7 @@ class TimeModulated(nn.Module):
             tape_or_none.add("az_linear_small_f32", *args2)
 
     @torch.no_grad()
+    @_lib.on_device
     def forward(self, x_t: Tensor, c_time: Tensor, **kwargs) -> Tensor:
         if not x_t.is_cuda:
             raise RuntimeError("azula_amd backbones execute only on an AMD GPU (no CPU fallback)")
@@ -88,7 +89,10 @@ class TimeModulated(nn.Module):
         ct = torch.empty(1, 1, dtype=torch.float32, device=dev)
         hid = torch.empty(1, self.features, dtype=torch.float32, device=dev)
         tape.add("az_coef_c_time_f32", ct.data_ptr(), cur_coef.data_ptr())
-        program, mod_buf = inner(x, mod_rows=1)
+        res = inner(x, mod_rows=1)
+        if res is None or res[0] is None:
+            return None  # unmodulated net, non-image input, cond_channels: the sampler takes the generic loop
+        program, mod_buf = res
         self._embed(tape, ct, 1, mod_buf, hid)
         tape.keep.extend([ct, hid, *self._f32()])
         tape.extend(program.tape)

@@ -83,6 +83,7 @@ class AblatedDenoiser(Denoiser):
         return (-1.0, 1.0) if (not self.training and self.clip_mean) else (-math.inf, math.inf)
 
     @torch.no_grad()
+    @_lib.on_device
     def forward(self, x_t: Tensor, t: Tensor, label: Tensor | None = None, **kwargs) -> GaussianPosterior:
         alpha_t, sigma_t = self.schedule(t)
         alpha_t, sigma_t = _expand_like(alpha_t, x_t.ndim), _expand_like(sigma_t, x_t.ndim)

@@ -334,6 +334,7 @@ class UNetModel(nn.Module):
         return p
 
     @torch.no_grad()
+    @_lib.on_device
     def forward(self, x: Tensor, timesteps: Tensor, y: Tensor | None = None) -> Tensor:
         r"""x: (N, C, H, W); timesteps: (N,) or (1,) integer indices; y: (N,) labels iff class-conditional."""
         assert (y is not None) == (self.num_classes is not None), (

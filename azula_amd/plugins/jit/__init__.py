@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from ... import _lib
 from ...denoise import Denoiser, DiracPosterior, _expand_like, precondition, require_f32_cuda
 from ...hub import download
 from ...nn.utils import get_module_dtype, skip_init
@@ -46,6 +47,7 @@ class JITDenoiser(Denoiser):
         self.num_classes = num_classes
 
     @torch.no_grad()
+    @_lib.on_device
     def forward(self, x_t: Tensor, t: Tensor, label: Tensor | None = None, **kwargs) -> DiracPosterior:
         alpha_t, sigma_t = self.schedule(t)
         alpha_t, sigma_t = _expand_like(alpha_t, x_t.ndim), _expand_like(sigma_t, x_t.ndim)

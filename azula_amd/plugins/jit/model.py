@@ -27,6 +27,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from ... import _lib
 from ...engine import Act, Builder
 
 __all__ = ["JiT", "JiT_models"]
@@ -326,6 +327,7 @@ class JiT(nn.Module):
         return out_dtype
 
     @torch.no_grad()
+    @_lib.on_device
     def forward(self, x: Tensor, t: Tensor, y: Tensor) -> Tensor:
         out_dtype = self._check(x)
         B = x.shape[0]

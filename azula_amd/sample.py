@@ -120,6 +120,7 @@ class Sampler(abc.ABC):
         return tqdm(it, miniters=1, unit="step", ncols=79, ascii=True)
 
     @torch.no_grad()
+    @_lib.on_device
     def __call__(self, x: Tensor, **kwargs) -> Tensor:
         r"""Simulates the reverse process from t_T to t_0 (reference ``azula/sample.py:139-161``)."""
         if x.is_cuda and self._fusable(x):
@@ -237,22 +238,65 @@ class Sampler(abc.ABC):
     def _needs_noise(self) -> bool:
         raise NotImplementedError()
 
+    def _hyper(self) -> tuple:
+        r"""Every scalar hyper-parameter of the sampler (start, stop, steps, eta, temperature, order, ...): whatever
+        feeds ``_kernel_scalars`` / ``_host_table`` is a plain attribute, so a change of any of them is seen."""
+        simple = (int, float, bool, str, type(None), torch.dtype)
+        return tuple(sorted((k, v) for k, v in vars(self).items() if isinstance(v, simple)))
+
     def _call_fused(self, x: Tensor, kwargs: dict) -> Tensor | None:
+        r"""The captured loop is cached per sampler, keyed on everything that is BAKED into it: the latent's shape and
+        device, the structure of the keyword arguments, the step count / noise use, and a fingerprint of the denoiser
+        (address, version counter and dtype of every parameter and buffer, train/eval flags).  The reference re-reads
+        weights, guidance and hyper-parameters on every call (``azula/sample.py:139-161``); so does this: after
+        ``load_state_dict`` / ``.half()`` / ``.train()`` the plan is rebuilt, and values that only live in the
+        coefficient table (guidance, eta, temperature, start / stop, the schedule) are re-uploaded by ``run``."""
         dev = x.device
         g = kwargs.get("guidance")
+        if torch.is_tensor(g) and g.numel() != 1:
+            return None  # per-sample guidance: generic loop
         key = (
-            tuple(x.shape), str(dev), tuple(sorted(kwargs)), self.start, self.stop, self.steps, getattr(self, "eta", None),
-            None if torch.is_tensor(g) else g, id(self.denoiser),
+            tuple(x.shape), str(dev), _kwargs_signature(kwargs), self.steps, self._needs_noise(), self.rng_parity,
+            id(self.denoiser), module_fingerprint(self.denoiser),
         )
         ent = self._fused_cache.get(key)
         if ent is None:
+            self._fused_cache = {}  # drop the stale plan first: one live plan per sampler keeps HBM use bounded
             cur = torch.zeros(COEF_WORDS, dtype=torch.float32, device=dev)
             fused = self.denoiser._az_fused(x, kwargs, cur)
             if fused is None:
                 return None
             ent = _FusedLoop(self, fused, x, cur)
-            self._fused_cache = {key: ent}  # one live plan per sampler keeps HBM use bounded
+            self._fused_cache = {key: ent}
         return ent.run(x, kwargs)
+
+
+def module_fingerprint(module: torch.nn.Module) -> tuple:
+    r"""Identity of a module's state as the compiled plans see it: (address, in-place version, dtype) of every
+    parameter and buffer plus the train/eval flags.  Packed weight copies (direct, Winograd, half) are valid exactly
+    as long as this tuple is unchanged."""
+    tensors = tuple((t.data_ptr(), t._version, t.dtype) for t in (*module.parameters(), *module.buffers()))
+    return tensors + tuple(m.training for m in module.modules())
+
+
+def _schedule_key(sched) -> tuple:
+    r"""Scalar attributes of a schedule object (alpha_min, sigma_min, gamma, ...) and, for ``nn.Module`` schedules,
+    the fingerprint of their tensors."""
+    simple = (int, float, bool, str, type(None))
+    scalars = tuple(sorted((k, v) for k, v in getattr(sched, "__dict__", {}).items() if isinstance(v, simple)))
+    return scalars + (module_fingerprint(sched) if isinstance(sched, torch.nn.Module) else ())
+
+
+def _kwargs_signature(kw) -> tuple:
+    r"""Structure of the keyword arguments (names, nesting, which values are None) -- not their values: label and
+    guidance VALUES are uploaded per call, their presence decides which programs exist."""
+    if isinstance(kw, dict):
+        return tuple((k, _kwargs_signature(v)) for k, v in sorted(kw.items()))
+    if kw is None:
+        return ("none",)
+    if torch.is_tensor(kw):
+        return ("tensor", tuple(kw.shape))
+    return ("value",)
 
 
 class _FusedLoop:
@@ -290,18 +334,19 @@ class _FusedLoop:
         self.graph: StepGraph | None = None
         self.B, self.C, self.inner = B, Cc, inner
 
-    def _upload_table(self) -> None:
+    def _upload_table(self, kwargs: dict) -> None:
         s = self.sampler
-        key = (s.start, s.stop, s.steps, s.dtype, getattr(s, "eta", None), id(s.denoiser.schedule),
-               tuple(sorted(vars(s.denoiser.schedule).items())) if hasattr(s.denoiser.schedule, "__dict__") else None,
-               self.fused.guidance)
+        if len(self.fused.programs) > 1:  # CFG: the guidance VALUE is re-read on every call (reference cfg.py:63-65)
+            self.fused.guidance = float(kwargs.get("guidance", 1.0))
+        sched = s.denoiser.schedule
+        key = (s._hyper(), id(sched), _schedule_key(sched), self.fused.guidance, self.fused.clip)
         if key != self.table_key:
             self.table.copy_(s._host_table(self.fused))
             self.table_key = key
 
     def run(self, x: Tensor, kwargs: dict) -> Tensor:
         s, p0 = self.sampler, self.fused.programs[0]
-        self._upload_table()
+        self._upload_table(kwargs)
         for p in self.fused.programs:
             if p.prepare is not None:
                 p.prepare(kwargs)
@@ -343,6 +388,7 @@ class DDPMSampler(Sampler):
     def _needs_noise(self) -> bool:
         return True
 
+    @_lib.on_device
     def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
         return self._step_impl(x_t, t, s, **kwargs)
 
@@ -365,6 +411,7 @@ class DDIMSampler(Sampler):
         # randn_like (advancing the RNG); `rng_parity` keeps that draw without reading it.
         return self.eta != 0
 
+    @_lib.on_device
     def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
         return self._step_impl(x_t, t, s, **kwargs)
 
@@ -413,6 +460,7 @@ class EulerSampler(Sampler):
         z_t = (x_t - alpha_t * mean) / sigma_t
         return alpha_s / alpha_t * x_t + alpha_s * (sigma_s / alpha_s - sigma_t / alpha_t) * z_t
 
+    @_lib.on_device
     def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
         return self._step_impl(x_t, t, s, **kwargs)
 
@@ -423,6 +471,7 @@ class HeunSampler(EulerSampler):
     runs the generic step loop (each evaluation is the compiled kernel tape, the elementwise
     updates are ``az_axpby_f32``)."""
 
+    @_lib.on_device
     def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
         alpha_s, sigma_s = self.denoiser.schedule(s)
         alpha_t, sigma_t = self.denoiser.schedule(t)
@@ -475,6 +524,7 @@ class ItoSampler(Sampler):
         x_s = x_s + k * (x_t - alpha_t * mean)
         return x_s + k_eps * self._draw_noise(x_s)
 
+    @_lib.on_device
     def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
         return self._step_impl(x_t, t, s, **kwargs)
 
@@ -570,6 +620,7 @@ class _MultistepSampler(Sampler):
         return rows
 
     @torch.no_grad()
+    @_lib.on_device
     def __call__(self, x: Tensor, **kwargs) -> Tensor:
         if self.order < 1 or self.order > _lib.MULTISTEP_MAX_HIST + 1:
             raise ValueError(f"order must be in [1, {_lib.MULTISTEP_MAX_HIST + 1}], got {self.order}")
@@ -727,6 +778,7 @@ class PCSampler(Sampler):
     def _fusable(self, x: Tensor) -> bool:
         return False  # several denoiser evaluations per step: generic loop
 
+    @_lib.on_device
     def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
         alpha_s, sigma_s = self.denoiser.schedule(s)
         alpha_t, sigma_t = self.denoiser.schedule(t)
