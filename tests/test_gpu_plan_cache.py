@@ -132,8 +132,8 @@ def _small_cond_adm():
     from azula_amd.plugins import adm
 
     torch.manual_seed(0)
-    den = adm.make_model(image_size=32, num_channels=32, channel_mult=(1, 2), attention_resolutions=(16,), num_classes=10,
-                         num_res_blocks=1, num_head_channels=16, resblock_updown=True, use_scale_shift_norm=True)
+    den = adm.make_model(image_size=16, num_channels=32, channel_mult=(1, 2), attention_resolutions=(8,), num_classes=10,
+                         num_res_blocks=2, num_head_channels=32, resblock_updown=True, use_scale_shift_norm=True)
     g = torch.Generator().manual_seed(123)
     for _, v in sorted(den.backbone.state_dict().items()):
         if torch.is_floating_point(v) and v.ndim > 1 and not torch.any(v != 0):
@@ -147,7 +147,7 @@ def test_cfg_guidance_value_is_reread_every_call():
 
     den, cfg = _small_cond_adm()
     torch.manual_seed(1)
-    x1 = torch.randn(2, 3, 32, 32, device="cuda")
+    x1 = torch.randn(2, 3, 16, 16, device="cuda")
     pos = {"label": torch.tensor([1, 2], device="cuda")}
     neg = {"label": torch.tensor([0, 0], device="cuda")}
     smp = DDIMSampler(cfg, steps=6, silent=True)
@@ -172,7 +172,7 @@ def test_train_eval_switch_changes_the_clip():
     den, _ = _small_cond_adm()
     assert den.clip_mean
     torch.manual_seed(1)
-    x1 = 3 * torch.randn(2, 3, 32, 32, device="cuda")
+    x1 = 3 * torch.randn(2, 3, 16, 16, device="cuda")
     lab = torch.tensor([1, 2], device="cuda")
     smp = DDIMSampler(den, steps=4, silent=True)
     clipped = smp(x1, label=lab)
