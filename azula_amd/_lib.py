@@ -238,6 +238,8 @@ PROTOTYPES: dict[str, list] = {
     "az_graph_launch": [vp, c_stream],
     "az_graph_destroy": [vp],
     "az_graph_num_nodes": [vp, C.POINTER(i64)],
+    "az_calib_read_f32": [vp, vp, i64, i32, i32, i64, c_stream],
+    "az_calib_write_f32": [vp, i64, f32, c_stream],
 }
 
 _lock = threading.Lock()

@@ -131,7 +131,10 @@ __global__ __launch_bounds__(256) void transition_flat_kernel(const float* __res
 
 // ---- image form: x is (B, C, inner) planar; F may be planar with more channels (ADM: 6 of
 // which 3 are read) or NHWC with channel stride fC; xin may be written NHWC with stride xs_c.
-// One thread owns 4 consecutive pixels of one sample: all accesses are 16 B.
+// One thread owns 4 consecutive pixels of one sample: all accesses are 16 B.  x_s may alias x_t (the captured loop
+// steps in place), so the compiler cannot move a later channel's loads above an earlier channel's stores: every load
+// of a 4-channel chunk (x, F, F_neg, eps: up to 16 x 16 B per thread) is issued BEFORE its first store, as in the flat
+// kernel -- each element is read and written by the same thread only, so this is safe in place.
 template <bool CFG, bool EPS, bool MEAN>
 __global__ __launch_bounds__(256) void transition_image_kernel(AzTransitionArgs a, int64_t quads_per_sample) {
   const Coef k = load_coef(a.coef);
@@ -140,82 +143,94 @@ __global__ __launch_bounds__(256) void transition_image_kernel(AzTransitionArgs 
   const int C = (int)a.channels;
   const int64_t inner = a.inner;
   const int64_t fC = a.f_channels;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
     const int64_t b = q / quads_per_sample;
     const int64_t i0 = (q - b * quads_per_sample) * 4;
     for (int c0 = 0; c0 < C; c0 += 4) {
-      float xs[4][4];  // [channel in chunk][pixel]
-      float4 fpix[4], npix[4];
+      const int nc = C - c0 < 4 ? C - c0 : 4;
+      float4 xv[4], fv[4], nv[4], ev[4];  // [channel in chunk] x 4 pixels
+      // ---- all loads of the chunk
       if (a.f_nhwc) {
+        float4 fpix[4], npix[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int64_t off = (b * inner + i0 + j) * fC + c0;
           fpix[j] = *reinterpret_cast<const float4*>(a.F + off);
-          if (CFG) npix[j] = *reinterpret_cast<const float4*>(a.F_neg + off);
+          npix[j] = CFG ? *reinterpret_cast<const float4*>(a.F_neg + off) : z4;
         }
+        // 4 x 4 transpose: pixel-major -> channel-major
+        fv[0] = make_float4(fpix[0].x, fpix[1].x, fpix[2].x, fpix[3].x);
+        fv[1] = make_float4(fpix[0].y, fpix[1].y, fpix[2].y, fpix[3].y);
+        fv[2] = make_float4(fpix[0].z, fpix[1].z, fpix[2].z, fpix[3].z);
+        fv[3] = make_float4(fpix[0].w, fpix[1].w, fpix[2].w, fpix[3].w);
+        nv[0] = make_float4(npix[0].x, npix[1].x, npix[2].x, npix[3].x);
+        nv[1] = make_float4(npix[0].y, npix[1].y, npix[2].y, npix[3].y);
+        nv[2] = make_float4(npix[0].z, npix[1].z, npix[2].z, npix[3].z);
+        nv[3] = make_float4(npix[0].w, npix[1].w, npix[2].w, npix[3].w);
       }
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
-        const int c = c0 + cc;
-        if (c >= C) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) xs[cc][j] = 0.f;
-          continue;
-        }
-        const int64_t xo = (b * C + c) * inner + i0;
-        const float4 xv = *reinterpret_cast<const float4*>(a.x_t + xo);
-        float4 fv, nv = make_float4(0.f, 0.f, 0.f, 0.f), ev = nv;
-        if (a.f_nhwc) {
-          const float* fp = reinterpret_cast<const float*>(fpix);
-          fv = make_float4(fp[0 * 4 + cc], fp[1 * 4 + cc], fp[2 * 4 + cc], fp[3 * 4 + cc]);
-          if (CFG) {
-            const float* np = reinterpret_cast<const float*>(npix);
-            nv = make_float4(np[0 * 4 + cc], np[1 * 4 + cc], np[2 * 4 + cc], np[3 * 4 + cc]);
+        xv[cc] = z4;
+        ev[cc] = z4;
+        if (!a.f_nhwc) fv[cc] = nv[cc] = z4;
+        if (cc < nc) {
+          const int64_t xo = (b * C + c0 + cc) * inner + i0;
+          xv[cc] = *reinterpret_cast<const float4*>(a.x_t + xo);
+          if (EPS) ev[cc] = *reinterpret_cast<const float4*>(a.eps + xo);
+          if (!a.f_nhwc) {
+            const int64_t fo = (b * fC + c0 + cc) * inner + i0;
+            fv[cc] = *reinterpret_cast<const float4*>(a.F + fo);
+            if (CFG) nv[cc] = *reinterpret_cast<const float4*>(a.F_neg + fo);
           }
-        } else {
-          const int64_t fo = (b * fC + c) * inner + i0;
-          fv = *reinterpret_cast<const float4*>(a.F + fo);
-          if (CFG) nv = *reinterpret_cast<const float4*>(a.F_neg + fo);
         }
-        if (EPS) ev = *reinterpret_cast<const float4*>(a.eps + xo);
-        float4 m, o;
-        m.x = post_mean<CFG>(k, xv.x, fv.x, nv.x);
-        m.y = post_mean<CFG>(k, xv.y, fv.y, nv.y);
-        m.z = post_mean<CFG>(k, xv.z, fv.z, nv.z);
-        m.w = post_mean<CFG>(k, xv.w, fv.w, nv.w);
-        o.x = step_x<EPS>(k, xv.x, m.x, ev.x);
-        o.y = step_x<EPS>(k, xv.y, m.y, ev.y);
-        o.z = step_x<EPS>(k, xv.z, m.z, ev.z);
-        o.w = step_x<EPS>(k, xv.w, m.w, ev.w);
-        *reinterpret_cast<float4*>(a.x_s + xo) = o;
-        if (MEAN) *reinterpret_cast<float4*>(a.mean_out + xo) = m;
-        xs[cc][0] = o.x;
-        xs[cc][1] = o.y;
-        xs[cc][2] = o.z;
-        xs[cc][3] = o.w;
+      }
+      // ---- arithmetic + stores
+      float4 ov[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        ov[cc] = z4;
+        if (cc < nc) {
+          const int64_t xo = (b * C + c0 + cc) * inner + i0;
+          float4 m, o;
+          m.x = post_mean<CFG>(k, xv[cc].x, fv[cc].x, nv[cc].x);
+          m.y = post_mean<CFG>(k, xv[cc].y, fv[cc].y, nv[cc].y);
+          m.z = post_mean<CFG>(k, xv[cc].z, fv[cc].z, nv[cc].z);
+          m.w = post_mean<CFG>(k, xv[cc].w, fv[cc].w, nv[cc].w);
+          o.x = step_x<EPS>(k, xv[cc].x, m.x, ev[cc].x);
+          o.y = step_x<EPS>(k, xv[cc].y, m.y, ev[cc].y);
+          o.z = step_x<EPS>(k, xv[cc].z, m.z, ev[cc].z);
+          o.w = step_x<EPS>(k, xv[cc].w, m.w, ev[cc].w);
+          *reinterpret_cast<float4*>(a.x_s + xo) = o;
+          if (MEAN) *reinterpret_cast<float4*>(a.mean_out + xo) = m;
+          ov[cc] = o;
+        }
       }
       if (a.xin_next != nullptr) {
         if (a.nhwc_pad > 0) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float4 v;
-            v.x = az_mul(k.c_in_next, xs[0][j]);
-            v.y = az_mul(k.c_in_next, xs[1][j]);
-            v.z = az_mul(k.c_in_next, xs[2][j]);
-            v.w = az_mul(k.c_in_next, xs[3][j]);
-            *reinterpret_cast<float4*>(a.xin_next + (b * inner + i0 + j) * a.nhwc_pad + c0) = v;
-          }
+          const float4 p0 = make_float4(az_mul(k.c_in_next, ov[0].x), az_mul(k.c_in_next, ov[1].x),
+                                        az_mul(k.c_in_next, ov[2].x), az_mul(k.c_in_next, ov[3].x));
+          const float4 p1 = make_float4(az_mul(k.c_in_next, ov[0].y), az_mul(k.c_in_next, ov[1].y),
+                                        az_mul(k.c_in_next, ov[2].y), az_mul(k.c_in_next, ov[3].y));
+          const float4 p2 = make_float4(az_mul(k.c_in_next, ov[0].z), az_mul(k.c_in_next, ov[1].z),
+                                        az_mul(k.c_in_next, ov[2].z), az_mul(k.c_in_next, ov[3].z));
+          const float4 p3 = make_float4(az_mul(k.c_in_next, ov[0].w), az_mul(k.c_in_next, ov[1].w),
+                                        az_mul(k.c_in_next, ov[2].w), az_mul(k.c_in_next, ov[3].w));
+          float* dst = a.xin_next + (b * inner + i0) * a.nhwc_pad + c0;
+          *reinterpret_cast<float4*>(dst) = p0;
+          *reinterpret_cast<float4*>(dst + a.nhwc_pad) = p1;
+          *reinterpret_cast<float4*>(dst + 2 * a.nhwc_pad) = p2;
+          *reinterpret_cast<float4*>(dst + 3 * a.nhwc_pad) = p3;
         } else {
 #pragma unroll
           for (int cc = 0; cc < 4; ++cc) {
-            const int c = c0 + cc;
-            if (c >= C) continue;
+            if (cc >= nc) continue;
             float4 v;
-            v.x = az_mul(k.c_in_next, xs[cc][0]);
-            v.y = az_mul(k.c_in_next, xs[cc][1]);
-            v.z = az_mul(k.c_in_next, xs[cc][2]);
-            v.w = az_mul(k.c_in_next, xs[cc][3]);
-            *reinterpret_cast<float4*>(a.xin_next + (b * C + c) * inner + i0) = v;
+            v.x = az_mul(k.c_in_next, ov[cc].x);
+            v.y = az_mul(k.c_in_next, ov[cc].y);
+            v.z = az_mul(k.c_in_next, ov[cc].z);
+            v.w = az_mul(k.c_in_next, ov[cc].w);
+            *reinterpret_cast<float4*>(a.xin_next + (b * C + c0 + cc) * inner + i0) = v;
           }
         }
       }

@@ -13,6 +13,7 @@ sample (``init_sharded`` does the same for ``x_T``).
 
 from __future__ import annotations
 
+import time
 from collections.abc import Sequence
 
 import torch
@@ -49,30 +50,49 @@ def init_sharded(sampler: Sampler, shape: Sequence[int], *, group=None, **kwargs
 
 
 @torch.no_grad()
-def sample_sharded(sampler: Sampler, x_local: Tensor, *, group=None, gather: bool = True, **kwargs) -> Tensor:
+def sample_sharded(sampler: Sampler, x_local: Tensor, *, group=None, gather: bool = True, timings: dict | None = None,
+                   **kwargs) -> Tensor:
     r"""Runs ``sampler`` on this rank's shard and all-gathers ``x0``.
 
     Arguments:
         x_local: This rank's slice of ``x_T`` (see :func:`init_sharded`).
         gather: If False, return the local ``x0`` only.
+        timings: If a dict, the two phases are fenced with device synchronisations and their wall times are
+            ACCUMULATED into ``timings["sample_ms"]`` / ``timings["allgather_ms"]`` (``bench.py`` reports them per rank).
         kwargs: Passed to the sampler (per-sample kwargs such as labels must already be local).
 
     Returns:
         ``x0`` of the full batch, identical on every rank (or the local shard).
     """
     rank, world = _world(group)
+
+    def lap(key: str | None, t0: float) -> float:
+        if timings is None:
+            return 0.0
+        if x_local.is_cuda:
+            torch.cuda.synchronize(x_local.device)
+        t1 = time.perf_counter()
+        if key is not None:
+            timings[key] = timings.get(key, 0.0) + (t1 - t0) * 1e3
+        return t1
+
+    t0 = lap(None, 0.0)
     prev = sampler.shard
     sampler.shard = (rank, world) if world > 1 else None
     try:
         x0 = sampler(x_local, **kwargs)
     finally:
         sampler.shard = prev
-    if world == 1 or not gather:
+    t0 = lap("sample_ms", t0)
+    if not gather or not (dist.is_available() and dist.is_initialized()):
         return x0
+    # the collective runs whenever a process group exists -- also for a world of ONE rank, so that a single GPU
+    # exercises the RCCL code path (tests/test_dist_gpu.py)
     x0 = x0.contiguous()
     out = torch.empty((world * x0.shape[0], *x0.shape[1:]), dtype=x0.dtype, device=x0.device)
     if x0.is_cuda and dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(out, x0, group=group)  # one RCCL all-gather over xGMI
     else:  # gloo (CPU tests, or a single-GPU rehearsal of the multi-process path)
         dist.all_gather(list(out.chunk(world)), x0, group=group)
+    lap("allgather_ms", t0)
     return out

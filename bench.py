@@ -15,6 +15,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -25,6 +26,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 MFMA == fp32 VALU peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0  # HBM3E spec (6.3 TB/s measured achievable)
+# F(2x2,3x3) Winograd executes 4 multiplies per output where the direct form (the ALGORITHMIC count of SURVEY 8d,
+# 2*pixels*Cout*Cin*9) has 9: with the fp32 MFMA pipe 100 % busy it delivers 2.25 x 157.3 algorithmic TFLOP/s.  That is
+# the peak `roofline.frac` is taken against for the Winograd kernel, so frac == executed MFMA FLOP/s / 157.3 <= 1.
+WINOGRAD_GAIN = 2.25
 
 CONFIGS = {
     # BASELINE.json configs[1]: azula.nn.unet ADM-shaped UNet, 3x256x256, DDIM-64, batch 4 per GPU
@@ -114,85 +119,148 @@ def build_denoiser(cfg, device):
 
 CONV_OPS = ("az_conv2d_f32", "az_conv2d_winograd_f32", "az_conv2d_winograd4_f32", "az_conv2d_bf16_f32", "az_conv2d_f16_f32",
             "az_conv2d_x3_f32")
+ATTN_OPS = ("az_attention_f32", "az_attention_bf16_f32", "az_attention_f16_f32")
 
 
-def conv_roofline(sampler, device):
-    r"""Per-launch HIP-event timing of the dominant kernel (conv_igemm, fp32 MFMA) over one
-    backbone forward run eagerly on the launch stream; achieved = sum(flops) / sum(time)."""
+def sampler_kwargs(cfg, device):
+    B = cfg["batch"]
+    if cfg.get("cfg"):
+        lab = torch.arange(B, device=device) % 1000
+        return dict(positive={"label": lab}, negative={"label": torch.zeros_like(lab)}, guidance=cfg["cfg"])
+    if cfg.get("labels"):
+        return dict(label=torch.arange(B, device=device) % 1000)
+    return {}
+
+
+def host_info() -> dict:
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"cpu_model": model, "host_cores": os.cpu_count() or 1, "usable_cores": avail}
+
+
+def tape_profile(sampler, device):
+    r"""Per-launch HIP-event timing of EVERY op of one denoise step (the tape the hipGraph replays), run eagerly on the
+    launch stream.  Returns [(op name, kernel family, ms, algorithmic flops or 0, descriptor)]."""
     loop = next(iter(sampler._fused_cache.values()))
     tape = loop.tape
     stream = torch.cuda.current_stream(device)
     sptr = stream.cuda_stream
     recs = []
-    loop.counter.zero_()
     for rep in range(2):  # first repetition warms caches / clocks
         recs = []
         loop.counter.zero_()
         for fn, args, name in tape.ops:
-            if name in CONV_OPS:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                rc = fn(*args, sptr)
-                e1.record(stream)
-                desc = args[0]._obj
-                recs.append((e0, e1, desc._flops, desc.splitk))
-            else:
-                rc = fn(*args, sptr)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            rc = fn(*args, sptr)
+            e1.record(stream)
             assert rc == 0, (name, rc)
+            desc = getattr(args[0], "_obj", None) if args else None
+            recs.append((name, e0, e1, desc))
         torch.cuda.synchronize(device)
-    convs = [a[0]._obj for _, a, n in tape.ops if n in CONV_OPS]
+    out = []
+    for name, e0, e1, desc in recs:
+        fam = getattr(desc, "_algo", name) if name in CONV_OPS else name
+        out.append((name, fam, e0.elapsed_time(e1), getattr(desc, "_flops", 0) if desc is not None else 0, desc))
     if os.environ.get("AZ_BENCH_DETAIL"):
-        for (e0, e1, fl, sk), d in zip(recs, convs):
-            t = e0.elapsed_time(e1)
-            print(
-                f"conv {d.batch}x{d.hin}x{d.win} cin={d.c0s}+{d.c1s} cout={d.cout_s} k={d.ksize} s={d.stride} "
-                f"splitk={sk} {d._algo[10:-4]}: {t * 1e3:8.1f} us {fl / t / 1e9:7.1f} TF/s",
-                file=sys.stderr,
-            )
-    out = {}
-    for algo in ("az_conv2d_winograd_f32", "az_conv2d_f32"):
-        same = (algo,) if algo != "az_conv2d_f32" else ("az_conv2d_f32", "az_conv2d_bf16_f32", "az_conv2d_f16_f32", "az_conv2d_x3_f32")
-        sel = [(r, d) for r, d in zip(recs, convs) if d._algo in same]
-        out[algo] = dict(
-            flops=sum(r[2] for r, _ in sel), ms=sum(r[0].elapsed_time(r[1]) for r, _ in sel), launches=len(sel)
-        )
-    out["all"] = dict(flops=sum(r[2] for r in recs), ms=sum(r[0].elapsed_time(r[1]) for r in recs), launches=len(recs))
+        for name, fam, ms, fl, d in out:
+            if name in CONV_OPS:
+                print(
+                    f"conv {d.batch}x{d.hin}x{d.win} cin={d.c0s}+{d.c1s} cout={d.cout_s} k={d.ksize} s={d.stride} "
+                    f"splitk={d.splitk} {fam[10:-4]}: {ms * 1e3:8.1f} us {fl / ms / 1e9:7.1f} TF/s", file=sys.stderr)
+            else:
+                print(f"{name}: {ms * 1e3:8.1f} us", file=sys.stderr)
     return out
 
 
-def transition_roofline(device, n=1 << 26):
-    r"""K1 at a size that defeats the 256 MiB Infinity Cache (64 Mi elements = 256 MiB per tensor):
-    DDIM eta=0 form, 12 B/element algorithmic (read x_t, read F, write x_s)."""
-    import ctypes as C
-    from azula_amd import _lib
+KERNEL_OF = {  # C-ABI entry point -> the __global__ kernel it launches (names as rocprofv3 prints them)
+    "az_conv2d_winograd_f32": "conv_winograd_kernel", "az_conv2d_f32": "conv_igemm_kernel", "az_attention_f32": "attention_kernel",
+    "az_conv2d_bf16_f32": "conv_igemm_half_kernel", "az_conv2d_f16_f32": "conv_igemm_half_kernel", "az_conv2d_x3_f32": "conv_igemm_x3_kernel",
+    "az_conv2d_winograd4_f32": "conv_winograd4_kernel",
+}
 
-    x = torch.randn(n, device=device)
-    F = torch.randn(n, device=device)
-    out = torch.empty(n, device=device)
-    row = torch.zeros(16, device=device)
-    row[1], row[2], row[4], row[5], row[6] = 0.4, 0.6, 0.5, 0.7, 0.9
-    row[9], row[10] = -float("inf"), float("inf")
-    a = _lib.AzTransitionArgs(x_t=x.data_ptr(), F=F.data_ptr(), x_s=out.data_ptr(), batch=1, channels=1, inner=n,
-                              f_channels=1, coef=row.data_ptr())
+
+def family_summary(prof):
+    r"""{family: {ms, launches, flops}} over one denoise step + the step total."""
+    fams = {}
+    for _, fam, ms, fl, _ in prof:
+        f = fams.setdefault(fam, {"ms": 0.0, "launches": 0, "flops": 0})
+        f["ms"] += ms
+        f["launches"] += 1
+        f["flops"] += fl
+    return fams
+
+
+def transition_roofline(device):
+    r"""K1 as the captured loops launch it, at a size that defeats the 256 MiB Infinity Cache (96 Mi elements = 384 MiB
+    per tensor): the image form with the NHWC pre-scaled second output (C2: DDIM eta=0, planar 3-channel F; C4: DDPM with
+    eps, F = 3 of ADM's 6 planar channels) and the flat form of the generic loop.  achieved = ALGORITHMIC bytes
+    (12 B/element + 4 B for the c_in' x_s output + 4 B for eps) / HIP-event time per launch."""
+    import ctypes as C
+
+    from azula_amd import _lib
+    from tools.pmc_traffic import TRANSITION_SHAPE, transition_cases
+
+    cases, keep = transition_cases(device)
     stream = torch.cuda.current_stream(device)
-    for _ in range(3):
-        _lib.call("az_transition_f32", C.byref(a), stream.cuda_stream)
-    reps = 20
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(reps):
-        _lib.call("az_transition_f32", C.byref(a), stream.cuda_stream)
-    e1.record(stream)
-    torch.cuda.synchronize(device)
-    ms = e0.elapsed_time(e1) / reps
-    gbs = 12.0 * n / (ms * 1e-3) / 1e9
-    # HBM bytes per launch from rocprofv3 PMC passes of this same kernel and size (FETCH_SIZE doubled per the
-    # gfx950 note + WRITE_SIZE; profiles/r01_hbm_traffic_pmc.txt): equal to the algorithmic bytes, no re-reads
-    pmc_traffic = 805306368 if n == 1 << 26 else None
-    return dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
-                traffic=pmc_traffic, traffic_source="profiles/r01_hbm_traffic_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
-                algorithmic_bytes=12 * n, elements=n, bytes_per_element=12, avg_us=round(ms * 1e3, 2),
-                kernel="transition_flat_kernel (DDIM eta=0)")
+    out = {}
+    B, Cc, inner = TRANSITION_SHAPE
+    n = B * Cc * inner
+    for label, kname, a, alg, note in cases:
+        for _ in range(3):
+            _lib.call("az_transition_f32", C.byref(a), stream.cuda_stream)
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            _lib.call("az_transition_f32", C.byref(a), stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize(device)
+        ms = e0.elapsed_time(e1) / reps
+        gbs = alg / (ms * 1e-3) / 1e9
+        # bytes the kernel must move given the backbone's layouts: the NHWC input has a 4-float channel stride, so the
+        # second output is 16 B/pixel for 3 channels (the zero pad channel is written too)
+        moved = alg + (4 * B * inner * (4 - Cc) if "image" in label else 0)
+        out[label] = dict(bound="hbm", kernel=kname, achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                          frac=round(gbs / PEAK_HBM_GBS, 4), avg_us=round(ms * 1e3, 2), elements=n,
+                          algorithmic_bytes=alg, bytes_per_element=alg // n, layout_bytes=moved, traffic=None, note=note)
+    del cases, keep
+    torch.cuda.empty_cache()
+    return out
+
+
+def pmc_traffic(config: str, live: bool = True, timeout: int = 420):
+    r"""rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, --kernel-trace only) of tools/pmc_traffic.py in a
+    subprocess: calibration kernels, the transition kernels and two eager backbone forwards.  Returns its result dict
+    with "source", or the committed profile of the same tool when the live run is unavailable / disabled."""
+    import subprocess
+
+    committed = os.path.join(ROOT, "profiles", f"r02_traffic_{config}.json")
+    if live and os.environ.get("AZ_BENCH_PMC", "1") != "0":
+        try:
+            res = subprocess.run(
+                [sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), "collect", "--config", config, "--timeout", str(timeout // 2)],
+                cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+            if res.returncode == 0:
+                out = json.loads(res.stdout)
+                out["source"] = "live: rocprofv3 --pmc passes run by bench.py (tools/pmc_traffic.py collect)"
+                return out
+            print(f"[bench] live PMC collection failed: {res.stderr[-800:]}", file=sys.stderr)
+        except Exception as e:  # noqa: BLE001 -- a missing profiler must not cost the bench line
+            print(f"[bench] live PMC collection failed: {e!r}", file=sys.stderr)
+    if os.path.exists(committed):
+        out = json.load(open(committed))
+        out["source"] = f"committed: profiles/{os.path.basename(committed)} (same tool, earlier run)"
+        return out
+    return None
 
 
 def cpu_baseline(denoiser, cfg, budget_s=25.0):
@@ -239,8 +307,12 @@ def cpu_baseline(denoiser, cfg, budget_s=25.0):
         if n >= 2 and el + warm > budget_s or n >= 8:
             break
     s_per_step = el / n
+    hi = host_info()
     return dict(
         value=round(1.0 / (cfg["steps"] * s_per_step), 6), unit="images/s", cores=threads, kind="port",
+        host_cores=hi["host_cores"], usable_cores=hi["usable_cores"], cpu_model=hi["cpu_model"],
+        threads_note=f"torch intra-op threads = {threads}: the fastest of a probe over 8..{avail} threads on the dominant op "
+                     f"(a 256->256 3x3 conv); the host has {hi['host_cores']} logical cores",
         sample=f"{n} DDIM steps of the same UNet at batch 1 ({s_per_step:.2f} s/step, 1 warm-up), extrapolated x{cfg['steps']} steps",
     )
 
@@ -252,6 +324,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic from the committed profile)")
     ap.add_argument("--denoise-steps", type=int, default=0, help="override the config's sampler steps (checks only)")
     ap.add_argument("--half", choices=["bf16", "f16"], default=None,
                     help="cast the backbone to half precision (mixed-precision mode; NOT the headline fp32 number)")
@@ -302,17 +375,12 @@ def main() -> None:
     torch.manual_seed(1)  # same seed on every rank: the full batch is drawn and sliced (parity with 1 GPU)
     x1 = init_sharded(sampler, (world * B, *cfg["shape"]), device=device)  # resident in HBM before timing
 
-    kwargs = {}
-    if cfg.get("cfg"):
-        lab = torch.arange(B, device=device) % 1000
-        kwargs = dict(positive={"label": lab}, negative={"label": torch.zeros_like(lab)}, guidance=cfg["cfg"])
+    kwargs = sampler_kwargs(cfg, device)
+    timings: dict = {}
 
-    if cfg.get("labels"):
-        kwargs = dict(label=torch.arange(B, device=device) % 1000)
-
-    def one_pass():
+    def one_pass(tm=None):
         # 64 graph replays on this rank's shard, then the only collective: all-gather of x0
-        return sample_sharded(sampler, x1, **kwargs)
+        return sample_sharded(sampler, x1, timings=tm, **kwargs)
 
     def fence():
         if world > 1:
@@ -326,12 +394,32 @@ def main() -> None:
     for _ in range(args.steps):
         x0 = one_pass()
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = local_elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
     assert torch.isfinite(x0).all()
+    dist_info = {"world_size": world, "dist_backend": None}
+    if world > 1:
+        # evidence that the collective backend saw every rank (outside the timed region): one extra pass with the two
+        # phases fenced, per-rank times gathered; x0 must hold every rank's shard
+        one_pass(timings)
+        per_rank = torch.tensor([local_elapsed / args.steps * 1e3, timings["sample_ms"], timings["allgather_ms"]], device=device)
+        allr = [torch.zeros_like(per_rank) for _ in range(world)]
+        dist.all_gather(allr, per_rank)
+        devs = [None] * world
+        dist.all_gather_object(devs, f"{torch.cuda.get_device_name(device)} #{device.index}")
+        assert x0.shape[0] == world * B
+        dist_info = {
+            "world_size": dist.get_world_size(), "dist_backend": dist.get_backend(), "ranks_seen": len(allr),
+            "rank_devices": devs,
+            "per_rank_ms_per_step": [round(float(t[0]), 3) for t in allr],
+            "per_rank_sample_ms": [round(float(t[1]), 3) for t in allr],
+            "allgather_ms": round(max(float(t[2]) for t in allr), 3),
+            "allgather_bytes_per_rank": x0.numel() // world * 4,
+            "collective": "all_gather_into_tensor(x0) once per sampling; none inside the loop",
+        }
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -354,29 +442,10 @@ def main() -> None:
             "data": "synthetic (random-init weights under seed 0, x1 ~ sampler.init under seed 1)",
             "config": {"workload": cfg["name"], "per_gpu_batch": B, "global_batch": world * B,
                        "denoise_steps": cfg["steps"], "parallelism": f"batch-sharded x{world}, all-gather of x0"},
+            "dist": dist_info,
+            "host": host_info(),
         }
-        conv = conv_roofline(sampler, device)
-        wino, direct, allc = conv["az_conv2d_winograd_f32"], conv["az_conv2d_f32"], conv["all"]
-        dom, dom_name = (wino, "conv_winograd_kernel") if wino["ms"] >= direct["ms"] else (direct, "conv_igemm_kernel")
-        tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        executed = tf / 2.25 if dom is wino else tf
-        out["roofline"] = {
-            "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": None,
-            "traffic_note": "MFMA-bound kernel over 55 launches of different shapes; rocprofv3 --pmc on its largest layer "
-                            "(4x256x256, 256->256): FETCH_SIZE 388 MB + WRITE_SIZE 240 MB per launch = 1.4x the compulsory "
-                            "541 MB, L2 hit rate 92 % (8-byte gathers: counters uncalibrated, hence null) -- "
-                            "profiles/r01_hbm_traffic_pmc.txt",
-            "kernel": dom_name + " (fp32 v_mfma_f32_32x32x2_f32), all its launches in one backbone forward",
-            "launches": dom["launches"], "avg_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
-            "note": "achieved = ALGORITHMIC direct-conv FLOP (2*pixels*Cout*Cin*9) / HIP-event time; the Winograd "
-                    "F(2x2,3x3) kernel executes 2.25x fewer multiplies in exact fp32, hence frac can exceed 1",
-            "executed_mfma_tflops": round(executed, 2), "executed_frac": round(executed / PEAK_FP32_TFLOPS, 4),
-            "all_convs": {"launches": allc["launches"], "ms_per_forward": round(allc["ms"], 3),
-                          "algorithmic_tflops": round(allc["flops"] / (allc["ms"] * 1e-3) / 1e12, 2),
-                          "flops_per_forward": allc["flops"]},
-        }
-        out["roofline_transition"] = transition_roofline(device)
+        out.update(roofline_report(sampler, device, args, world))
         if world == 1 and not args.no_cpu_baseline and cfg["kind"] == "unet":
             out["cpu_baseline"] = cpu_baseline(den, cfg)
             out["speedup_vs_cpu"] = round(images_per_s / out["cpu_baseline"]["value"], 1)
@@ -384,6 +453,73 @@ def main() -> None:
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline_report(sampler, device, args, world) -> dict:
+    r"""`roofline` (dominant kernel), `roofline_kernels` (every matrix-pipe family of the step), `step_breakdown`
+    and `roofline_transition`, all from HIP events of THIS run; `traffic` from the PMC passes."""
+    prof = tape_profile(sampler, device)
+    fams = family_summary(prof)
+    step_ms = sum(f["ms"] for f in fams.values())
+    pmc = pmc_traffic(args.config, live=world == 1 and not args.half and not args.no_pmc)
+    kernels = {}
+    for fam, f in fams.items():
+        if not f["flops"]:
+            continue
+        wino = fam == "az_conv2d_winograd_f32"
+        peak = PEAK_FP32_TFLOPS * (WINOGRAD_GAIN if wino else 1.0)
+        tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        k = {
+            "bound": "mfma", "kernel": KERNEL_OF.get(fam, fam), "entry": fam, "achieved": round(tf, 2), "peak": round(peak, 1),
+            "unit": "TFLOP/s", "frac": round(tf / peak, 4), "launches": f["launches"], "avg_us": round(f["ms"] * 1e3 / f["launches"], 2),
+            "ms_per_denoise_step": round(f["ms"], 3), "share_of_step": round(f["ms"] / step_ms, 4),
+            "algorithmic_flops_per_step": f["flops"],
+            "executed_mfma_tflops": round(tf / (WINOGRAD_GAIN if wino else 1.0), 2), "mfma_peak": PEAK_FP32_TFLOPS,
+            "traffic": None,
+        }
+        if wino:
+            k["peak_note"] = (f"{PEAK_FP32_TFLOPS} TF/s fp32 MFMA x {WINOGRAD_GAIN}: F(2x2,3x3) executes 4 multiplies per output where the "
+                              "algorithmic (direct) count has 9; frac = executed MFMA FLOP/s / the fp32 MFMA peak")
+        kn = KERNEL_OF.get(fam)
+        if pmc and kn:
+            hit = [v for name, v in pmc.get("forward", {}).items() if re.search(r"(^|::|\s)" + kn + r"[(<]", name)]
+            if hit:
+                k["traffic"] = round(sum(h["traffic_bytes_per_forward"] for h in hit) / sum(h["launches_per_forward"] for h in hit))
+                k["traffic_per_denoise_step"] = round(sum(h["traffic_bytes_per_forward"] for h in hit))
+                k["traffic_raw"] = {"fetch_size_bytes_per_step": round(sum(h["fetch_size_raw_bytes_per_forward"] for h in hit)),
+                                    "write_size_bytes_per_step": round(sum(h["write_size_raw_bytes_per_forward"] for h in hit)),
+                                    "read_factor": hit[0]["read_factor"], "write_factor": hit[0]["write_factor"]}
+                if wino and pmc.get("winograd_compulsory_bytes_per_forward"):
+                    k["compulsory_bytes_per_denoise_step"] = pmc["winograd_compulsory_bytes_per_forward"]
+                    k["traffic_over_compulsory"] = round(k["traffic_per_denoise_step"] / pmc["winograd_compulsory_bytes_per_forward"], 3)
+        kernels[fam] = k
+    dom = max(kernels.values(), key=lambda k: k["ms_per_denoise_step"])
+    roof = dict(dom)
+    roof["kernel"] = f"{dom['kernel']} (fp32 v_mfma_f32_32x32x2_f32), all {dom['launches']} launches of one denoise step"
+    roof["note"] = ("achieved = ALGORITHMIC FLOP (2*pixels*Cout*Cin*k^2; attention 4*B*H*T^2*d) of the kernel's launches in one "
+                    "denoise step / the sum of their HIP-event durations; traffic = HBM-side bytes per launch from rocprofv3 "
+                    "FETCH_SIZE / WRITE_SIZE x the calibration factors measured in the same run")
+    out = {"roofline": roof, "roofline_kernels": kernels}
+    if pmc:
+        out["traffic_source"] = pmc["source"]
+        out["traffic_calibration"] = {k: round(v["factor"], 4) for k, v in pmc["calibration"].items()}
+    other = {fam: round(f["ms"], 4) for fam, f in sorted(fams.items(), key=lambda kv: -kv[1]["ms"]) if not f["flops"]}
+    out["step_breakdown"] = {"eager_sum_ms": round(step_ms, 3), "matrix_ms": round(sum(k["ms_per_denoise_step"] for k in kernels.values()), 3),
+                             "other_ms": other}
+    trans = transition_roofline(device)
+    if pmc:
+        for label, t in trans.items():
+            m = pmc.get("transition", {}).get(label)
+            if m:
+                t["traffic"] = round(m["traffic_bytes"])
+                t["traffic_over_algorithmic"] = round(m["traffic_over_algorithmic"], 4)
+    graph_kernel = "image_ddpm" if getattr(sampler, "_needs_noise", lambda: False)() else "image_ddim"
+    head = dict(trans[graph_kernel])
+    head["variants"] = trans
+    head["which"] = (f"{graph_kernel}: the form this config's captured loop launches, measured at {head['elements']} elements "
+                     "(MALL-defeating); at the config's own size (786 k elements) the launch is latency-bound (~7 us)")
+    out["roofline_transition"] = head
+    return out
 
 
 if __name__ == "__main__":

@@ -386,6 +386,17 @@ int az_graph_launch(AzGraph* g, az_stream_t stream);
 int az_graph_destroy(AzGraph* g);
 int az_graph_num_nodes(AzGraph* g, int64_t* n);
 
+/* ------------------------------------------------------------------ measurement support (not on the sampling path)
+ * Known-traffic kernels that calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters on gfx950 (MI355X_MICROARCH.md,
+ * section HBM: "calibrate on a known byte count in your own access pattern").  `az_calib_read_f32` reads every byte of
+ * `src[0, nbytes)` exactly once: the buffer is rows of `row_bytes`, each read as sectors of `group_bytes` contiguous
+ * bytes by `group_bytes / width` adjacent lanes (`width` = 8 or 16 bytes per lane), the sectors of a row by consecutive
+ * instructions.  `az_calib_write_f32` fills `dst[0, nbytes)` with 16-byte-per-lane stores.  The reference has no
+ * counterpart (it has no native code); used by tools/pmc_traffic.py and bench.py's roofline leg only.               */
+int az_calib_read_f32(const float* src, float* sink, int64_t nbytes, int32_t width, int32_t group_bytes,
+                      int64_t row_bytes, az_stream_t stream);
+int az_calib_write_f32(float* dst, int64_t nbytes, float value, az_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

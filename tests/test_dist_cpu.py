@@ -29,19 +29,26 @@ def make_sampler(kind, steps):
     return DDPMSampler(den, steps=steps, silent=True) if kind == "ddpm" else DDIMSampler(den, eta=0.3, steps=steps, silent=True)
 
 
-def worker(rank, world, port, kind, out_path):
+def worker(rank, world, port, kind, out_path, batch=8):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from azula_amd.parallel import init_sharded, sample_sharded
+        from azula_amd.parallel import init_sharded, sample_sharded, shard_range
 
         smp = make_sampler(kind, 16)
         torch.manual_seed(1)
-        x_local = init_sharded(smp, (8, 5))
-        assert x_local.shape == (4, 5)
+        x_local = init_sharded(smp, (batch, 5))
+        assert x_local.shape == (batch // world, 5)
+        assert shard_range(batch, rank, world) == range(rank * batch // world, (rank + 1) * batch // world)
         torch.manual_seed(2)
-        x0 = sample_sharded(smp, x_local)
-        assert x0.shape == (8, 5)
+        timings = {}
+        x0 = sample_sharded(smp, x_local, timings=timings)
+        assert x0.shape == (batch, 5) and timings["sample_ms"] > 0 and timings["allgather_ms"] > 0
+        # every rank holds the same gathered tensor
+        ref = [torch.empty_like(x0) for _ in range(world)]
+        dist.all_gather(ref, x0)
+        assert all(torch.equal(r, x0) for r in ref)
         if rank == 0:
             torch.save(x0, out_path)
     finally:
@@ -62,6 +69,21 @@ def test_two_rank_sharded_sampling_equals_single_process(tmp_path, kind):
     smp = make_sampler(kind, 16)
     torch.manual_seed(1)
     x1 = smp.init((8, 5))
+    torch.manual_seed(2)
+    ref = smp(x1)
+    assert torch.equal(x0, ref)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_c4_shaped_sharding_256_images(tmp_path, world):
+    """BASELINE configs[3]'s shard arithmetic: a global batch of 256 DDPM trajectories split 8 x 32 (and 4 x 64); every
+    rank draws the FULL-batch noise of each step and keeps its slice, so the gathered x0 is bit-equal to one process."""
+    out = str(tmp_path / "x0.pt")
+    mp.spawn(worker, args=(world, free_port(), "ddpm", out, 256), nprocs=world, join=True)
+    x0 = torch.load(out)
+    smp = make_sampler("ddpm", 16)
+    torch.manual_seed(1)
+    x1 = smp.init((256, 5))
     torch.manual_seed(2)
     ref = smp(x1)
     assert torch.equal(x0, ref)

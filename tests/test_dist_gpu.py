@@ -64,3 +64,48 @@ def test_two_processes_on_one_gpu_equal_single_process(tmp_path):
     # fp32 round-off instead of bit equality
     scale = max(1.0, single.abs().max().item())
     assert (sharded - single).abs().max().item() < 5e-5 * scale
+
+
+def rccl_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" IS RCCL on ROCm
+    try:
+        torch.set_grad_enabled(False)
+        from azula_amd.parallel import init_sharded, sample_sharded
+
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        smp = build()
+        torch.manual_seed(1)
+        x_local = init_sharded(smp, (4, 3, 16, 16), device="cuda")
+        torch.manual_seed(2)
+        timings = {}
+        x0 = sample_sharded(smp, x_local, timings=timings)  # fused loop, then dist.all_gather_into_tensor over RCCL
+        assert x0.shape == (4, 3, 16, 16) and timings["allgather_ms"] > 0
+        # an all-reduce too: the collective bench.py uses for its max-over-ranks clock
+        t = torch.tensor([3.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == 3.0
+        torch.save(x0.cpu(), out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_world_of_one(tmp_path):
+    """RCCL itself: a process group on the `nccl` backend with ONE rank on the GPU box.  Proves that librccl loads, a
+    communicator initialises on this device and `sample_sharded`'s all_gather_into_tensor path executes; the 8-GPU run
+    differs only in the world size (the driver launches it at round end)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "x0.pt")
+    mp.spawn(rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    gathered = torch.load(out)
+    torch.set_grad_enabled(False)
+    smp = build()
+    torch.manual_seed(1)
+    x1 = smp.init((4, 3, 16, 16), device="cuda")
+    torch.manual_seed(2)
+    assert torch.equal(gathered, smp(x1).cpu())

@@ -63,6 +63,7 @@ def test_fused_loop_sees_reloaded_weights(golden):
     p.div_(1.5)
 
     # unchanged state: the plan is re-used (no rebuild per call)
+    smp(x1)
     loop_c = next(iter(smp._fused_cache.values()))
     smp(x1)
     assert next(iter(smp._fused_cache.values())) is loop_c
