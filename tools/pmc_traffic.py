@@ -71,12 +71,12 @@ def transition_cases(device):
     # C2 (azula UNet, DDIM eta=0): planar F with 3 channels, x stepped in place, NHWC (stride 4) pre-scaled input written
     a = transition_args(x_t=x.data_ptr(), F=F3.data_ptr(), x_s=x.data_ptr(), xin_next=xin.data_ptr(), batch=B, channels=Cc,
                         inner=inner, f_channels=3, nhwc_pad=4, coef=row.data_ptr())
-    cases.append(("image_ddim", "transition_image_kernel<false, false, false>", a, 16 * n,
+    cases.append(("image_ddim", "transition_image4_kernel<false, false, false>", a, 16 * n,
                   "read x_t, F; write x_s, c_in' x_s: 16 B/element"))
     # C4 (ADM, DDPM): F = first 3 of 6 planar channels, eps read
     a = transition_args(x_t=x.data_ptr(), F=F6.data_ptr(), eps=eps.data_ptr(), x_s=x.data_ptr(), xin_next=xin.data_ptr(), batch=B,
                         channels=Cc, inner=inner, f_channels=6, nhwc_pad=4, coef=row.data_ptr())
-    cases.append(("image_ddpm", "transition_image_kernel<false, true, false>", a, 20 * n,
+    cases.append(("image_ddpm", "transition_image4_kernel<false, true, false>", a, 20 * n,
                   "read x_t, F, eps; write x_s, c_in' x_s: 20 B/element"))
     # generic-loop / toy path: every tensor flat, no second output
     a = transition_args(x_t=x.data_ptr(), F=F3.data_ptr(), x_s=xs.data_ptr(), batch=1, channels=1, inner=n, f_channels=1,

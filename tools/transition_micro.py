@@ -1,7 +1,8 @@
-r"""Micro-benchmark of az_transition_f32 (flat DDIM eta=0 form) at a MALL-defeating size."""
-import os, sys
+r"""Micro-benchmark of az_transition_f32 in the forms the captured loops launch, at a MALL-defeating size."""
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 
-print(bench.transition_roofline(torch.device("cuda"), n=int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 26))
+for k, v in bench.transition_roofline(torch.device("cuda")).items():
+    print(k, json.dumps({a: v[a] for a in ("kernel", "achieved", "frac", "avg_us")}))
