@@ -86,7 +86,7 @@ def test_ddim_eta1_equals_ddpm_and_fused_equals_generic(c2):
 
 
 def test_dit_b2_full_size_properties():
-    """BASELINE configs[2]: DiT-B/2 on 4 x 32 x 32 latents, batch 64 (here 16 + the split), DDIM."""
+    """BASELINE configs[2] at its stated batch: DiT-B/2 on 4 x 32 x 32 latents, batch 64, DDIM."""
     import bench
     from azula_amd.sample import DDIMSampler
 
@@ -94,12 +94,13 @@ def test_dit_b2_full_size_properties():
     den = bench.build_denoiser(cfg, torch.device("cuda"))
     torch.manual_seed(1)
     smp = DDIMSampler(den, steps=STEPS, silent=True)
-    x1 = smp.init((16, *cfg["shape"]), device="cuda")
+    x1 = smp.init((cfg["batch"], *cfg["shape"]), device="cuda")
+    assert x1.shape[0] == 64
     full = smp(x1)
     assert torch.equal(full, smp(x1))
-    halves = torch.cat([DDIMSampler(den, steps=STEPS, silent=True)(x1[i : i + 8]) for i in (0, 8)])
+    halves = torch.cat([DDIMSampler(den, steps=STEPS, silent=True)(x1[i : i + 32]) for i in (0, 32)])
     scale = max(1.0, full.abs().max().item())
-    print("DiT-B/2 batch 16 vs 8 + 8 max|d|", max_err(full, halves), "scale", scale)
+    print("DiT-B/2 batch 64 vs 32 + 32 max|d|", max_err(full, halves), "scale", scale)
     assert max_err(full, halves) < 5e-5 * scale
 
 
@@ -129,6 +130,78 @@ def test_adm_256_cfg_full_size_properties():
     # round-off differences of the backbone (the same 1e-3 bound as the ADM trajectory tests)
     print("ADM-256 batch 2 vs 1 max|d|", max_err(ref[1:], one))
     assert max_err(ref[1:], one) < 1e-3 * scale
+
+
+def test_adm_256_cfg_at_baseline_batch_32():
+    """BASELINE configs[4] at its stated batch: 32 images, classifier-free guidance = 64 backbone evaluations per step as
+    ONE batch-64 plan.  g = 0 must reproduce the conditional denoiser (azula/guidance/cfg.py:63-65), whose batch-32 plan
+    makes other tile / split-K choices; replay determinism; sample independence (32 = 16 + 16)."""
+    import bench
+    from azula_amd.sample import DDIMSampler
+
+    cfg = dict(bench.CONFIGS["c5cfg32"])
+    guided = bench.build_denoiser(cfg, torch.device("cuda"))
+    plain = guided.denoiser
+    B, steps = cfg["batch"], 2
+    assert B == 32
+    torch.manual_seed(1)
+    x1 = DDIMSampler(plain, steps=steps, silent=True).init((B, *cfg["shape"]), device="cuda")
+    lab = (torch.arange(B, device="cuda") * 31) % 1000
+    ref = DDIMSampler(plain, steps=steps, silent=True)(x1, label=lab)
+    smp = DDIMSampler(guided, steps=steps, silent=True)
+    kw = dict(positive={"label": lab}, negative={"label": torch.zeros_like(lab)})
+    g0 = smp(x1, guidance=0.0, **kw)
+    ent = next(iter(smp._fused_cache.values()))
+    assert ent.graph is not None and len(ent.fused.programs) == 2
+    scale = max(1.0, ref.abs().max().item())
+    print("ADM-256 batch 32: CFG(g=0) vs conditional max|d|", max_err(g0, ref), "scale", scale)
+    assert max_err(g0, ref) < 1e-3 * scale
+    g2 = smp(x1, guidance=2.0, **kw)
+    assert torch.equal(g2, smp(x1, guidance=2.0, **kw)) and not torch.equal(g2, g0)
+    del smp, ent
+    torch.cuda.empty_cache()
+    halves = torch.cat([DDIMSampler(plain, steps=steps, silent=True)(x1[i : i + 16], label=lab[i : i + 16]) for i in (0, 16)])
+    print("ADM-256 batch 32 vs 16 + 16 max|d|", max_err(ref, halves))
+    assert max_err(ref, halves) < 1e-3 * scale
+
+
+def test_adm_256_ddpm_at_the_c4_shard_of_32():
+    """BASELINE configs[3]: ADM 256 x 256 (unconditional), DDPMSampler, the 32-image shard one GPU owns of the 8-way
+    split batch of 256.  DDPM == DDIM(eta = 1) on the same device noise; the sharded draw (full-batch noise, this
+    rank's slice) equals the slice of the single-device run; replay determinism."""
+    import bench
+    from azula_amd.sample import DDIMSampler, DDPMSampler
+
+    cfg = dict(bench.CONFIGS["c4"])
+    den = bench.build_denoiser(cfg, torch.device("cuda"))
+    B, steps = cfg["batch"], 2
+    assert B == 32
+    torch.manual_seed(1)
+    smp = DDPMSampler(den, steps=steps, silent=True)
+    x1 = smp.init((B, *cfg["shape"]), device="cuda")
+    torch.manual_seed(7)
+    a = smp(x1)
+    assert next(iter(smp._fused_cache.values())).graph is not None
+    torch.manual_seed(7)
+    assert torch.equal(a, smp(x1))
+    torch.manual_seed(7)
+    b = DDIMSampler(den, eta=1.0, steps=steps, silent=True)(x1)
+    scale = max(1.0, a.abs().max().item())
+    print("ADM-256 DDPM vs DDIM(eta=1), batch 32: max|d|", max_err(a, b), "scale", scale)
+    assert max_err(a, b) < 1e-4 * scale
+    # rank 1 of a world of 2 over a global batch of 64: draws 64 x noise per step, keeps rows 32..63
+    torch.manual_seed(3)
+    big = DDPMSampler(den, steps=steps, silent=True)
+    x64 = torch.cat([x1, x1.flip(0)])
+    full = big(x64)
+    del big
+    torch.cuda.empty_cache()
+    torch.manual_seed(3)
+    smp.shard = (1, 2)
+    mine = smp(x64[32:])
+    smp.shard = None
+    print("ADM-256 shard (rank 1 of 2) vs rows 32..63 of the batch-64 run: max|d|", max_err(mine, full[32:]))
+    assert max_err(mine, full[32:]) < 1e-3 * scale
 
 
 def test_odd_image_size_through_both_conv_paths(monkeypatch):

@@ -1,0 +1,125 @@
+r"""Oracle parity at the FULL CHANNEL WIDTHS of BASELINE.json's networks, end to end.
+
+The golden fixtures (G5/G6) use channel widths <= 64; the full-size tests (test_gpu_fullsize.py) are self-comparisons.
+This file closes the gap between them: the real channel plans -- azula UNet (256, 256, 512, 512, 1024, 1024) x 2 blocks
+(configs[1]) and ADM imagenet_256x256 (256 x (1, 1, 2, 2, 4, 4), attention at 1/8, 1/16, 1/32; configs[3] / [4]) -- on a
+64 x 64 image, ONE sample, where the CPU oracle needs seconds.  Every layer then runs at its real K (up to 9 x 2048 in the
+merge convolutions): the Winograd kernel with K chunks from both skip sources, direct + split-K at K = 9 x 1024 on the
+4 x 4 / 2 x 2 maps, GroupNorm over 1024 channels, ADM attention with 16 heads.  With ``AZ_WINOGRAD=2`` semantics (forced
+by monkeypatch) every stride-1 3 x 3 layer goes through the Winograd kernel with split-K, down to the 2 x 2 maps.
+
+Tolerances are <= 5 x the errors measured on MI355X (printed by the tests)."""
+
+import pytest
+import torch
+
+from conftest import max_err
+from oracle import nets, sampling
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+RES = 64
+
+
+@pytest.fixture(scope="module")
+def c2_net():
+    import bench
+
+    cfg = dict(bench.CONFIGS["c2"])
+    den = bench.build_denoiser(cfg, torch.device("cuda"))
+    sd = {k: v.detach().cpu() for k, v in den.backbone.state_dict().items()}
+    ncfg = dict(cfg["net"])
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    oracle_mean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, ncfg, a, c), x, t)  # noqa: E731
+    torch.manual_seed(11)
+    x1 = torch.randn(1, 3, RES, RES)
+    ref_mean = oracle_mean(x1, torch.tensor(0.6))
+    ref_x0 = sampling.sample(oracle_mean, x1, steps=3, eta=0.0)
+    return den, x1, ref_mean, ref_x0
+
+
+@pytest.mark.parametrize("policy", ["1", "2", "0"])
+def test_c2_channel_plan_against_the_oracle(c2_net, policy, monkeypatch):
+    from azula_amd import engine
+    from azula_amd.sample import DDIMSampler
+
+    den, x1, ref_mean, ref_x0 = c2_net
+    monkeypatch.setattr(engine, "WINOGRAD", policy)
+    net = den.backbone.net
+    net._plans.clear()
+    mean = den(x1.cuda(), torch.tensor(0.6, device="cuda")).mean
+    ops = [n for _, _, n in next(iter(net._plans.values())).tape.ops]
+    nw, nd = ops.count("az_conv2d_winograd_f32"), ops.count("az_conv2d_f32")
+    if policy == "2":
+        assert nw >= 50 and nd <= 8, (nw, nd)  # only the stride-2 convolutions and the stem / head stay direct
+    elif policy == "0":
+        assert nw == 0
+    else:
+        assert nw >= 20 and nd >= 20, (nw, nd)  # 64^2 .. 16^2 Winograd; 8^2 .. 2^2 direct + split-K at K = 9 x 1024
+    sc = max(1.0, ref_mean.abs().max().item())
+    e1 = max_err(mean, ref_mean)
+    x0 = DDIMSampler(den, steps=3, silent=True)(x1.cuda())
+    e2 = max_err(x0, ref_x0)
+    print(f"C2 widths @{RES}^2 policy {policy}: {nw} winograd / {nd} direct convs; mean max|d| {e1:.3e} (scale {sc:.2f}); "
+          f"DDIM-3 max|d| {e2:.3e} (scale {ref_x0.abs().max().item():.2f})")
+    net._plans.clear()
+    assert e1 < 2e-5 * sc
+    assert e2 < 5e-5 * max(1.0, ref_x0.abs().max().item())
+
+
+@pytest.fixture(scope="module")
+def adm_net():
+    import bench
+    from azula_amd.plugins import adm
+
+    cfg = dict(bench.CONFIGS["c5"])
+    den = bench.build_denoiser(cfg, torch.device("cuda"))
+    card = dict(adm.load_cards(adm)[cfg["card"]].config)
+    sd = {k: v.detach().cpu() for k, v in den.backbone.state_dict().items()}
+    sig = sampling.adm_sigmas(card["discrete_schedule"], card["discrete_steps"])
+    bb = lambda a, i, y=None: nets.adm_unet_forward(sd, card, a, i, y)  # noqa: E731
+    omean = lambda xx, t: sampling.adm_posterior(bb, xx, t, sig)[0]  # noqa: E731
+    sched = lambda t: sampling.vp_schedule(t, 1e-2, 1e-2)  # noqa: E731
+    torch.manual_seed(12)
+    x1 = torch.randn(1, 3, RES, RES)
+    ref_out = bb(x1, torch.tensor([417]))
+    ref_mean = omean(x1, torch.tensor(0.5))
+    ref_x0 = sampling.sample(omean, x1, schedule=sched, steps=3, eta=0.0)
+    return den, x1, ref_out, ref_mean, ref_x0, omean, sched
+
+
+def test_adm_256_widths_against_the_oracle(adm_net):
+    from azula_amd.sample import DDIMSampler
+
+    den, x1, ref_out, ref_mean, ref_x0, _, _ = adm_net
+    out = den.backbone(x1.cuda(), torch.tensor([417], device="cuda"))
+    ops = [n for _, _, n in next(iter(den.backbone._plans.values())).tape.ops]
+    assert ops.count("az_attention_f32") >= 8, "the attention blocks at 1/8, 1/16, 1/32 must be on the tape"
+    so = max(1.0, ref_out.abs().max().item())
+    e0 = max_err(out, ref_out)
+    mean = den(x1.cuda(), torch.tensor(0.5, device="cuda")).mean
+    e1 = max_err(mean, ref_mean)
+    smp = DDIMSampler(den, steps=3, silent=True)
+    x0 = smp(x1.cuda())
+    assert next(iter(smp._fused_cache.values())).graph is not None
+    e2 = max_err(x0, ref_x0)
+    print(f"ADM-256 widths @{RES}^2: backbone max|d| {e0:.3e} (scale {so:.2f}); mean(t=.5) {e1:.3e}; DDIM-3 {e2:.3e} "
+          f"(|x0| <= {ref_x0.abs().max().item():.2f}, c_out = -100 at t = 1)")
+    assert e0 < 5e-5 * so
+    assert e1 < 1e-4
+    assert e2 < 1e-3
+
+
+def test_adm_256_widths_ddpm_against_the_oracle(adm_net):
+    """configs[3]'s sampler (DDPM) at configs[3]'s widths: the oracle is fed the device generator's noise."""
+    from azula_amd.sample import DDPMSampler
+
+    den, x1, _, _, _, omean, sched = adm_net
+    torch.manual_seed(21)
+    eps = [torch.randn(1, 3, RES, RES, device="cuda").cpu() for _ in range(3)]
+    torch.manual_seed(21)
+    x0 = DDPMSampler(den, steps=3, silent=True)(x1.cuda())
+    ref = sampling.sample(omean, x1, schedule=sched, steps=3, eta=None, eps_list=eps)
+    e = max_err(x0, ref)
+    print(f"ADM-256 widths DDPM-3 max|d| {e:.3e} (scale {ref.abs().max().item():.2f})")
+    assert e < 1e-3
