@@ -69,7 +69,12 @@ __device__ __forceinline__ f32x2 buf_ld2(__amdgpu_buffer_rsrc_t rsrc, unsigned v
   return __builtin_bit_cast(f32x2, v);
 }
 
-constexpr unsigned OOB = 0x80000000u;  // any offset >= num_records reads as zero
+// Per-lane offset of a tap that must read as zero (padding, ragged tiles, channel tails).  Every descriptor's
+// num_records is clamped to <= OOB (the `clamp_bytes` lambdas), so this offset is out of range for ANY tensor size; the
+// legitimate offsets of a workgroup are relative to its first sample and validated on the host to stay below 2^31.
+// (Round 1 clamped at 0xFFFFFFF0: with more than 2 GiB of activations behind a workgroup's first sample -- ADM's
+// 512-channel concatenation at 256^2, batch 32 -- the "zero" taps of the first 16 samples read sample b + 16 instead.)
+constexpr unsigned OOB = 0x80000000u;
 
 // Epilogue for 4 consecutive output channels [co, co+4) of output pixel n.
 // The fused epilogue in two halves so that callers can issue the loads of several outputs before the first store (the
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   // Buffer descriptors (wave-uniform: kernel arguments + blockIdx only).
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : e * 4); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > 0x80000000ll ? 0x80000000ll : e * 4); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
   const int b_first = n0 / hw_out;
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : e); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e > 0x80000000ll ? 0x80000000ll : e); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -683,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
   const int64_t wplane = (int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s;  // elements per weight piece
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : e); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e > 0x80000000ll ? 0x80000000ll : e); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, clamp_bytes(3 * wplane * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(a.src0 + b_first * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems * 4), 0x00020000);
@@ -1041,7 +1046,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
 
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : e * 4); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > 0x80000000ll ? 0x80000000ll : e * 4); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)p.nk * p.cblocks * WU_STAGE), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -1377,7 +1382,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd4_kernel(Wino4P p) {
 
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : e * 4); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > 0x80000000ll ? 0x80000000ll : e * 4); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)p.nk * p.cblocks * W4U_STAGE), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -1680,7 +1685,7 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     AZ_REQUIRE(span * a->h0 * a->w0 * a->c0s * 4 < (1ll << 31), AZ_E_SHAPE);
     AZ_REQUIRE(span * a->h1 * a->w1 * a->c1s * 4 < (1ll << 31), AZ_E_SHAPE);
     AZ_REQUIRE((int64_t)a->cout_s * p.cin_s * 4 < (1ll << 31), AZ_E_SHAPE);
-    AZ_REQUIRE((int64_t)a->ksize * a->ksize * a->cout_s * p.cin_s * (half == 3 ? 6 : 4) < (1ll << 32), AZ_E_SHAPE);
+    AZ_REQUIRE((int64_t)a->ksize * a->ksize * a->cout_s * p.cin_s * (half == 3 ? 6 : 4) <= (1ll << 31), AZ_E_SHAPE);
   }
   hipStream_t st = az_s(stream);
   if (!half && a->cout_s == 4 && a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->src1 && a->up0 == 0 &&
@@ -1768,7 +1773,7 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   p.a.splitk = splitk;
   p.cblocks = (a->cout_s + WC - 1) / WC;
   p.tblocks = (p.ntiles + WT - 1) / WT;
-  AZ_REQUIRE((int64_t)p.nk * p.cblocks * WU_STAGE * 4 < (1ll << 32), AZ_E_SHAPE);
+  AZ_REQUIRE((int64_t)p.nk * p.cblocks * WU_STAGE * 4 <= (1ll << 31), AZ_E_SHAPE);
   const int64_t nwg = (int64_t)p.cblocks * p.tblocks;
   hipStream_t st = az_s(stream);
   static bool attr_set = false;
@@ -1849,7 +1854,7 @@ int az_conv2d_winograd4_f32(const AzConvArgs* a, az_stream_t stream) {
   p.a.splitk = splitk;
   p.cblocks = (a->cout_s + W4C - 1) / W4C;
   p.tblocks = (p.ntiles + W4T - 1) / W4T;
-  AZ_REQUIRE((int64_t)p.nk * p.cblocks * W4U_STAGE * 4 < (1ll << 32), AZ_E_SHAPE);
+  AZ_REQUIRE((int64_t)p.nk * p.cblocks * W4U_STAGE * 4 <= (1ll << 31), AZ_E_SHAPE);
   const int64_t nwg = (int64_t)p.cblocks * p.tblocks;
   hipStream_t st = az_s(stream);
   static bool attr_set = false;

@@ -252,3 +252,34 @@ def test_real_layer_shapes_against_torch_cpu(H, Cin, Cout, algo):
     err = max_err(out, ref)
     print(algo, H, Cin, "max|d|", err, "scale", ref.abs().max().item())
     assert err < 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("algo", ["winograd", "direct"])
+def test_zero_padding_with_more_than_2_GiB_behind_the_first_sample(algo):
+    """Regression (round 2): the loaders mark padded taps with an out-of-range buffer offset.  With > 2 GiB of
+    activations behind a workgroup's first sample that offset used to be IN range, so the first samples of a large batch
+    read another sample instead of zeros (ADM at 256^2, batch 32: the first 16 images were wrong by 10 % of the scale).
+    20 x 512 channels x 256^2 = 2.7 GB: every sample of the batch must equal its own batch-1 evaluation, bitwise."""
+    import math
+
+    from azula_amd.engine import Act, Builder
+
+    B, H, Cin, Cout = 20, 256, 512, 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B * H * H * Cin, device="cuda", generator=g)
+    assert x.numel() * 4 > (1 << 31)
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, device="cuda", generator=g)
+
+    def run(xs, nb):
+        bld = Builder(torch.device("cuda"))
+        y = bld.conv(Act(xs, nb, H, H, Cin, Cin, True), bld.pack_conv(w, b), Cout, winograd=(algo == "winograd"))
+        bld.finish()
+        bld.tape.run()
+        return y.buf[: nb * H * H * Cout].view(nb, H, H, Cout).clone()
+
+    full = run(x, B)
+    per = H * H * Cin
+    for i in (0, 3, 4, B - 1):  # round 1's clamp broke samples 0..3 of this shape
+        one = run(x[i * per : (i + 1) * per].clone(), 1)
+        assert torch.equal(full[i : i + 1], one), f"sample {i} of the batch differs from its batch-1 evaluation"
