@@ -33,7 +33,7 @@ def test_adm_backbone_matches_reference(golden, name):
     out = den.backbone(g["x"].cuda(), g["idx"].cuda(), y=y)
     err, sc = max_err(out, g["out"]), g["out"].abs().max().item()
     print(name, "backbone max|d|", err, "scale", sc)
-    assert err < 2e-4 * max(1.0, sc)
+    assert err < 2e-5 * max(1.0, sc)  # measured 3.8e-6 / 2.7e-6 on scale 2.9 / 2.1 (MI355X, round 2)
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -42,9 +42,11 @@ def test_adm_posterior_matches_reference(golden, name):
     den, _, _ = build(g)
     kw = {"label": g["y"].cuda()} if "y" in g else {}
     q = den(g["x"].cuda(), torch.tensor(0.7, device="cuda"), **kw)
-    assert max_err(q.mean, g["mean_t07"]) < 2e-4
+    em, ev = max_err(q.mean, g["mean_t07"]), max_err(q.var, g["var_t07"])
+    print(name, "posterior mean / var max|d|", em, ev)
+    assert em < 5e-5
     assert q.mean.abs().max() <= 1.0  # clipped in eval mode
-    assert max_err(q.var, g["var_t07"]) < 2e-4 * max(1.0, g["var_t07"].abs().max().item())
+    assert ev < 5e-5 * max(1.0, g["var_t07"].abs().max().item())
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -59,7 +61,8 @@ def test_adm_ddim16_fused_matches_reference(golden, name):
     assert next(iter(smp._fused_cache.values())).graph is not None, "fused path not taken"
     err = max_err(x0, g["ddim16"])
     print(name, "DDIM-16 max|d|", err)
-    assert err < 1e-3  # |x0| <= ~1 (means are clipped to [-1, 1]); c_out reaches -100 at t = 1
+    # |x0| <= ~1 (means are clipped to [-1, 1]); c_out reaches -100 at t = 1.  Measured 1.2e-5 / 1.9e-5: bound = 5 x
+    assert err < 1e-4
 
 
 def test_adm_ddpm8_device_rng_matches_oracle(golden):
@@ -76,7 +79,9 @@ def test_adm_ddpm8_device_rng_matches_oracle(golden):
     bb = lambda a, i, y=None: nets.adm_unet_forward(sd, cfg, a, i, y)  # noqa: E731
     omean = lambda xx, t: sampling.adm_posterior(bb, xx, t, sig)[0]  # noqa: E731
     ref = sampling.sample(omean, g["x1"], schedule=lambda t: sampling.vp_schedule(t, 1e-2, 1e-2), steps=8, eta=None, eps_list=eps)
-    assert max_err(x0, ref) < 1e-3
+    err = max_err(x0, ref)
+    print("ADM DDPM-8 max|d| vs oracle", err)
+    assert err < 1e-4
 
 
 def test_cfg_ddim16_fused_and_generic(golden):
@@ -93,7 +98,7 @@ def test_cfg_ddim16_fused_and_generic(golden):
     assert ent.graph is not None and len(ent.fused.programs) == 2
     err = max_err(x0, g["cfg_ddim16"])
     print("CFG DDIM-16 fused max|d|", err)
-    assert err < 2e-3
+    assert err < 1e-3  # measured 2.4e-4 (guidance 2 triples the difference of two evaluations): bound = 4 x
 
     class Loop(DDIMSampler):  # generic path: two denoiser calls + az_cfg_combine per step
         def step(self, x_t, t, s, **kw):
@@ -103,6 +108,6 @@ def test_cfg_ddim16_fused_and_generic(golden):
     # the generic path evaluates the schedule with device libm (as the reference would on a GPU); at
     # t = 1 the ADM preconditioning has c_out = -100, so last-ulp scalar differences are amplified
     print("CFG generic vs fused", max_err(x0g, x0), "generic vs reference", max_err(x0g, g["cfg_ddim16"]))
-    assert max_err(x0g, x0) < 2e-3 and max_err(x0g, g["cfg_ddim16"]) < 2e-3
+    assert max_err(x0g, x0) < 3e-4 and max_err(x0g, g["cfg_ddim16"]) < 1e-3  # measured 5.5e-5 / 2.0e-4
     # schedule passes through the wrapper (reference cfg.py:31-33)
     assert cfgden.schedule is den.schedule
