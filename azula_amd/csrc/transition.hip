@@ -369,8 +369,9 @@ struct MultistepPtrs {
 };
 
 template <int NH>
-__global__ __launch_bounds__(256) void multistep_kernel(float* __restrict__ x_s, float* __restrict__ pred,
-                                                        const float* __restrict__ x_t, const float* __restrict__ mean,
+__global__ __launch_bounds__(256) void multistep_kernel(float* x_s /* may alias x_t (in-place step) */,
+                                                        float* __restrict__ pred, const float* x_t,
+                                                        const float* __restrict__ mean,
                                                         MultistepPtrs hist, const float* __restrict__ coef,
                                                         int64_t n) {
   const float a = coef[0], b = coef[1], p = coef[2], wn = coef[3];

@@ -208,35 +208,71 @@ class Sampler(abc.ABC):
 
     # ---------------------------------------------------------------------------- fused path
     def _fusable(self, x: Tensor) -> bool:
-        cls_step = type(self).step
-        if cls_step not in (DDPMSampler.step, DDIMSampler.step, EulerSampler.step, ItoSampler.step):
-            return False  # user subclass overrides step (guidance samplers), Heun: generic loop
+        if type(self).step not in _FUSED_STEPS:
+            return False  # a user subclass overrides step (guidance samplers ...): generic loop
         return x.dtype == torch.float32 and self.dtype in (None, torch.float32) and x.ndim >= 2
 
+    # -- what a step looks like inside the captured graph ----------------------------------------------------------
+    def _fused_rows(self, t: Tensor, s: Tensor, fused: "FusedDenoiser") -> list[dict]:
+        r"""One dict per DENOISER EVALUATION of the step t -> s, in execution order: the 0-d host scalars of the table
+        row that evaluation reads (``alpha`` / ``sigma``: where the denoiser is evaluated; ``a_t, a_s, k_x, k_eps`` of
+        the kernel form x' = a_s m + k_x (x - a_t m) + k_eps eps; optional ``pad0, pad1``)."""
+        alpha_t, sigma_t, _, _, ka_t, ka_s, k_x, k_eps = self._transition_scalars(t, s)
+        return [dict(alpha=alpha_t, sigma=sigma_t, a_t=ka_t, a_s=ka_s, k_x=k_x, k_eps=k_eps)]
+
+    def _noise_draws(self) -> int:
+        r"""randn_like draws per step that the kernels READ (the reference's generator calls, in order)."""
+        return 1 if self._needs_noise() else 0
+
+    def _fused_structure(self) -> tuple:
+        r"""Everything about the sampler that changes the SHAPE of the captured graph (not just table values)."""
+        return (type(self).__name__, self.steps, self._noise_draws(), self.rng_parity)
+
     def _host_table(self, fused: FusedDenoiser) -> Tensor:
-        r"""(steps, 16) fp32 table of AzStepCoef rows, from 0-d CPU tensors in reference op order."""
+        r"""(steps * rows_per_step, 16) fp32 table of AzStepCoef rows, from 0-d CPU tensors in reference op order."""
         ts = torch.linspace(self.start, self.stop, self.steps + 1, dtype=self.dtype)
-        rows = torch.zeros(self.steps, COEF_WORDS, dtype=torch.float32)
-        irows = rows.view(torch.int32)  # integer slots (time_index, step) are bit-cast in place
         col = {n: i for i, n in enumerate(COEF_FIELDS)}
+        out = []
         for i, (t, s) in enumerate(ts.unfold(0, 2, 1).unbind()):
-            alpha_t, sigma_t, alpha_s, sigma_s, ka_t, ka_s, k_x, k_eps = self._transition_scalars(t, s)
-            co = fused.coefficients(alpha_t, sigma_t)
-            for name, v in co.items():
-                if name == "time_index":
-                    irows[i, col[name]] = int(v)
-                else:
-                    rows[i, col[name]] = v.to(torch.float32)
-            rows[i, col["alpha_t"]], rows[i, col["alpha_s"]] = ka_t, ka_s
-            rows[i, col["k_x"]], rows[i, col["k_eps"]] = k_x, k_eps
-            rows[i, col["clip_lo"]], rows[i, col["clip_hi"]] = fused.clip
-            rows[i, col["guidance"]] = fused.guidance
-            irows[i, col["step"]] = i
-        rows[:-1, col["c_in_next"]] = rows[1:, col["c_in"]]
+            for spec in self._fused_rows(t, s, fused):
+                row = torch.zeros(COEF_WORDS, dtype=torch.float32)
+                irow = row.view(torch.int32)  # integer slots (time_index, step) are bit-cast in place
+                for name, v in fused.coefficients(spec["alpha"], spec["sigma"]).items():
+                    if name == "time_index":
+                        irow[col[name]] = int(v)
+                    else:
+                        row[col[name]] = v.to(torch.float32)
+                row[col["alpha_t"]], row[col["alpha_s"]] = spec["a_t"], spec["a_s"]
+                row[col["k_x"]], row[col["k_eps"]] = spec["k_x"], spec["k_eps"]
+                row[col["clip_lo"]], row[col["clip_hi"]] = fused.clip
+                row[col["guidance"]] = fused.guidance
+                irow[col["step"]] = i
+                row[14], row[15] = spec.get("pad0", 0.0), spec.get("pad1", 0.0)
+                out.append(row)
+        rows = torch.stack(out)
+        rows[:-1, col["c_in_next"]] = rows[1:, col["c_in"]]  # each evaluation pre-scales the NEXT evaluation's input
         return rows
+
+    def _fused_step_tapes(self, loop: "_FusedLoop") -> list[Tape]:
+        r"""The kernels of ONE step (default: one denoiser evaluation + the fused transition, in place on ``loop.x``).
+        Samplers whose steps differ in their buffer addresses return one tape per phase of that cycle."""
+        tape = Tape()
+        loop.add_evaluation(tape)
+        loop.add_transition(tape, x_t=loop.x, x_s=loop.x, eps=loop.noise[0] if loop.noise else None)
+        return [tape]
 
     def _needs_noise(self) -> bool:
         raise NotImplementedError()
+
+    def _draws_unused_noise(self) -> bool:
+        r"""True if the reference's step draws a randn_like that this configuration never reads (DDIM with eta = 0)."""
+        return False
+
+    def _fused_upload_extra(self, loop: "_FusedLoop") -> None:
+        r"""Sampler-specific device tables, refreshed together with the coefficient table."""
+
+    def _fused_reset(self, loop: "_FusedLoop") -> None:
+        r"""Per-call state of the loop's extra buffers (history rings ...)."""
 
     def _hyper(self) -> tuple:
         r"""Every scalar hyper-parameter of the sampler (start, stop, steps, eta, temperature, order, ...): whatever
@@ -256,8 +292,8 @@ class Sampler(abc.ABC):
         if torch.is_tensor(g) and g.numel() != 1:
             return None  # per-sample guidance: generic loop
         key = (
-            tuple(x.shape), str(dev), _kwargs_signature(kwargs), self.steps, self._needs_noise(), self.rng_parity,
-            id(self.denoiser), module_fingerprint(self.denoiser),
+            tuple(x.shape), str(dev), _kwargs_signature(kwargs), self._fused_structure(), id(self.denoiser),
+            module_fingerprint(self.denoiser),
         )
         ent = self._fused_cache.get(key)
         if ent is None:
@@ -300,39 +336,86 @@ def _kwargs_signature(kw) -> tuple:
 
 
 class _FusedLoop:
-    r"""Static buffers + step tape + hipGraph for one (sampler, denoiser, shape)."""
+    r"""Static buffers + step tapes + hipGraphs for one (sampler, denoiser, shape).
+
+    A STEP is ``rows_per_step`` denoiser evaluations, each ``az_step_begin`` (next table row -> ``cur``) + the backbone
+    programs + an elementwise update; the sampler lays its step out on a tape (``Sampler._fused_step_tapes``) and the
+    loop replays the captured graph of ``period`` consecutive steps (1 except for the multistep family, whose history
+    ring makes the buffer addresses cycle with period ``order``)."""
 
     def __init__(self, sampler: Sampler, fused: FusedDenoiser, x: Tensor, cur: Tensor) -> None:
         self.sampler, self.fused, self.cur = sampler, fused, cur
         dev = x.device
         self.x = torch.empty_like(x, memory_format=torch.contiguous_format)
-        # eps is read by the kernel only when some k_eps != 0; with DDIM eta = 0 the draw is still
-        # made (into the same buffer) so that the RNG stream matches the reference, but the
-        # transition then moves 12 B/element instead of 16.
-        self.eps = torch.empty_like(self.x) if (sampler._needs_noise() or sampler.rng_parity) else None
-        self.use_eps = sampler._needs_noise()
+        # noise[k]: the k-th randn_like of a step that a kernel reads.  With DDIM eta = 0 nothing reads it, but the
+        # reference still draws one per step: `rng_parity` keeps that draw (into `dummy`) so that the generator state
+        # after sampling matches, while the transition moves 12 B/element instead of 16.
+        self.noise = [torch.empty_like(self.x) for _ in range(sampler._noise_draws())]
+        self.dummy = torch.empty_like(self.x) if (not self.noise and sampler.rng_parity and sampler._draws_unused_noise()) else None
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.table_key = None
-        self.table = torch.zeros(sampler.steps, COEF_WORDS, dtype=torch.float32, device=dev)
-        p0 = fused.programs[0]
         B = x.shape[0]
         Cc = x.shape[1] if x.ndim > 2 else 1
-        inner = x.numel() // (B * Cc)
-        tape = Tape()
-        tape.add("az_step_begin", cur.data_ptr(), self.table.data_ptr(), self.counter.data_ptr(), sampler.steps)
-        for p in fused.programs:
+        self.B, self.C, self.inner = B, Cc, x.numel() // (B * Cc)
+        self.n_rows = len(sampler._host_table(fused))
+        self.table = torch.zeros(self.n_rows, COEF_WORDS, dtype=torch.float32, device=dev)
+        self.keep: list = []
+        self.step_tapes = sampler._fused_step_tapes(self)
+        self.period = len(self.step_tapes)
+        self.graphs: dict[int, StepGraph] = {}
+
+    # -- tape building blocks (used by Sampler._fused_step_tapes) -----------------------------------------------
+    def add_evaluation(self, tape: Tape) -> None:
+        r"""az_step_begin + every backbone program: F (and F_neg) of the NEXT table row's evaluation."""
+        tape.add("az_step_begin", self.cur.data_ptr(), self.table.data_ptr(), self.counter.data_ptr(), self.n_rows)
+        for p in self.fused.programs:
             tape.extend(p.tape)
+
+    def add_transition(self, tape: Tape, *, x_t: Tensor, x_s: Tensor, eps: Tensor | None = None, mean_out: Tensor | None = None,
+                       write_xin: bool = True) -> None:
+        r"""x_s = a_s m + k_x (x_t - a_t m) + k_eps eps with m = clip(c_skip x_t + c_out F) [CFG-combined], and the next
+        evaluation's pre-scaled backbone input c_in' x_s in the backbone's layout -- one pass (``az_transition_f32``)."""
+        p0 = self.fused.programs[0]
         a = transition_args(
-            x_t=self.x.data_ptr(), F=p0.out.data_ptr(),
-            F_neg=fused.programs[1].out.data_ptr() if len(fused.programs) > 1 else None,
-            eps=self.eps.data_ptr() if self.use_eps else None,
-            x_s=self.x.data_ptr(), xin_next=p0.x_in.data_ptr(), batch=B, channels=Cc, inner=inner,
-            f_channels=p0.f_channels, f_nhwc=int(p0.f_nhwc), nhwc_pad=p0.x_in_cs, coef=cur.data_ptr(),
+            x_t=x_t.data_ptr(), F=p0.out.data_ptr(),
+            F_neg=self.fused.programs[1].out.data_ptr() if len(self.fused.programs) > 1 else None,
+            eps=eps.data_ptr() if eps is not None else None, x_s=x_s.data_ptr(),
+            mean_out=mean_out.data_ptr() if mean_out is not None else None,
+            xin_next=p0.x_in.data_ptr() if write_xin else None, batch=self.B, channels=self.C, inner=self.inner,
+            f_channels=p0.f_channels, f_nhwc=int(p0.f_nhwc), nhwc_pad=p0.x_in_cs if write_xin else 0, coef=self.cur.data_ptr(),
         )
         tape.add("az_transition_f32", C.byref(a), keep=[a])
-        self.tape = tape
-        self.graph: StepGraph | None = None
-        self.B, self.C, self.inner = B, Cc, inner
+
+    def add_input_relayout(self, tape: Tape | None, x: Tensor, scale_ptr: int) -> None:
+        r"""backbone input <- scale * x in the backbone's layout (NHWC with a padded channel stride, or flat)."""
+        p0 = self.fused.programs[0]
+        if p0.x_in_cs > 0:
+            args = ("az_nchw_to_nhwc_f32", p0.x_in.data_ptr(), x.data_ptr(), scale_ptr, self.B, self.C, self.inner, p0.x_in_cs)
+        else:
+            args = ("az_scale_f32", p0.x_in.data_ptr(), x.data_ptr(), scale_ptr, x.numel())
+        if tape is None:
+            _lib.call(*args, _lib.stream_ptr())
+        else:
+            tape.add(*args)
+
+    def coef_ptr(self, name_or_word) -> int:
+        r"""Device address of one float of the current row (``cur``): kernels that take coefficient POINTERS read the
+        step's value through it, so the captured graph needs no per-step update."""
+        w = COEF_FIELDS.index(name_or_word) if isinstance(name_or_word, str) else int(name_or_word)
+        return self.cur.data_ptr() + 4 * w
+
+    # -- compatibility views (bench.py / tools / tests) -------------------------------------------------------------
+    @property
+    def tape(self) -> Tape:
+        return self.step_tapes[0]
+
+    @property
+    def graph(self) -> StepGraph | None:
+        return self.graphs.get(self.period)
+
+    @property
+    def eps(self) -> Tensor | None:
+        return self.noise[0] if self.noise else self.dummy
 
     def _upload_table(self, kwargs: dict) -> None:
         s = self.sampler
@@ -342,34 +425,37 @@ class _FusedLoop:
         key = (s._hyper(), id(sched), _schedule_key(sched), self.fused.guidance, self.fused.clip)
         if key != self.table_key:
             self.table.copy_(s._host_table(self.fused))
+            s._fused_upload_extra(self)
             self.table_key = key
 
     def run(self, x: Tensor, kwargs: dict) -> Tensor:
-        s, p0 = self.sampler, self.fused.programs[0]
+        s = self.sampler
         self._upload_table(kwargs)
         for p in self.fused.programs:
             if p.prepare is not None:
                 p.prepare(kwargs)
         self.x.copy_(x)
         self.counter.zero_()
+        s._fused_reset(self)
         stream = _lib.stream_ptr()
-        # backbone input of step 0: c_in[0] * x_T, in the backbone's layout
-        c_in0 = self.table[0, COEF_FIELDS.index("c_in")]
-        if p0.x_in_cs > 0:
-            _lib.call(
-                "az_nchw_to_nhwc_f32", p0.x_in.data_ptr(), self.x.data_ptr(), c_in0.data_ptr(), self.B, self.C,
-                self.inner, p0.x_in_cs, stream,
-            )
-        else:
-            _lib.call("az_scale_f32", p0.x_in.data_ptr(), self.x.data_ptr(), c_in0.data_ptr(), self.x.numel(), stream)
-        for i in s.progress_bar(range(s.steps)):
-            if self.eps is not None:
-                s._draw_noise(self.eps, out=self.eps)  # same generator calls as the reference's randn_like(x_t)
-            if i == 0 and self.graph is None:
-                self.tape.run(stream)  # first step eagerly (loads code objects), then capture
-                self.graph = StepGraph(self.tape, x.device)
+        # backbone input of the first evaluation: c_in[0] * x_T, in the backbone's layout
+        self.add_input_relayout(None, self.x, self.table[0, COEF_FIELDS.index("c_in")].data_ptr())
+        for g in s.progress_bar(range(0, s.steps, self.period)):
+            n = min(self.period, s.steps - g)
+            for buf in self.noise:
+                s._draw_noise(buf, out=buf)  # same generator calls, in the same order, as the reference's randn_like
+            if self.dummy is not None:
+                s._draw_noise(self.dummy, out=self.dummy)
+            graph = self.graphs.get(n)
+            if graph is None:  # first group of this length: run eagerly (loads code objects), then capture for the next
+                for t in self.step_tapes[:n]:
+                    t.run(stream)
+                cat = Tape()
+                for t in self.step_tapes[:n]:
+                    cat.extend(t)
+                self.graphs[n] = StepGraph(cat, x.device)
             else:
-                self.graph.launch()
+                graph.launch()
         return self.x.clone()
 
 
@@ -410,6 +496,9 @@ class DDIMSampler(Sampler):
         # eta = 0 => tau = 0 => k_eps = 0: the noise term vanishes.  The reference still draws
         # randn_like (advancing the RNG); `rng_parity` keeps that draw without reading it.
         return self.eta != 0
+
+    def _draws_unused_noise(self) -> bool:
+        return self.eta == 0
 
     @_lib.on_device
     def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
@@ -467,9 +556,39 @@ class EulerSampler(Sampler):
 
 class HeunSampler(EulerSampler):
     r"""Explicit Heun (2nd order) sampler (reference ``azula/sample.py:308-352``): an Euler predictor,
-    a second denoiser call at ``s`` and the trapezoidal corrector.  Two backbone evaluations per step;
-    runs the generic step loop (each evaluation is the compiled kernel tape, the elementwise
-    updates are ``az_axpby_f32``)."""
+    a second denoiser call at ``s`` and the trapezoidal corrector.  Two backbone evaluations per step.
+
+    Fused form (one graph replay per step, two table rows): with c = alpha_s (sigma_s/alpha_s - sigma_t/alpha_t),
+
+    * row A (time t): x_p = Euler(x_t, m_t), also keeps m_t (``mean_out``) and x_t;
+    * row B (time s): e = p x_t + q m_t (``az_axpby_f32`` with p, q read from the row's spare words), then the
+      transition kernel on (x_p, F_s) with eps = e, k_eps = 1:
+      x_s = (alpha_s/alpha_t + c/(2 sigma_t)) x_t - c alpha_t/(2 sigma_t) m_t + c/(2 sigma_s) x_p - c alpha_s/(2 sigma_s) m_s,
+      which is the reference's update with z_t, z_s expanded (tolerance-level parity, like Euler)."""
+
+    def _fused_rows(self, t, s, fused):
+        alpha_s, sigma_s = self.denoiser.schedule(s)
+        alpha_t, sigma_t = self.denoiser.schedule(t)
+        A, B = self._euler_coefficients(alpha_t, sigma_t, alpha_s, sigma_s)
+        c = alpha_s * (sigma_s / alpha_s - sigma_t / alpha_t)
+        zero, one = torch.zeros_like(c), torch.ones_like(c)
+        return [
+            dict(alpha=alpha_t, sigma=sigma_t, a_t=zero, a_s=B, k_x=A, k_eps=zero),
+            dict(alpha=alpha_s, sigma=sigma_s, a_t=zero, a_s=-c * alpha_s / (2 * sigma_s), k_x=c / (2 * sigma_s), k_eps=one,
+                 pad0=alpha_s / alpha_t + c / (2 * sigma_t), pad1=-c * alpha_t / (2 * sigma_t)),
+        ]
+
+    def _fused_step_tapes(self, loop):
+        xp, m, e = (torch.empty_like(loop.x) for _ in range(3))
+        loop.keep += [xp, m, e]
+        tape = Tape()
+        loop.add_evaluation(tape)
+        loop.add_transition(tape, x_t=loop.x, x_s=xp, mean_out=m)  # x_p (+ the backbone input c_in(s) x_p), m_t
+        loop.add_evaluation(tape)
+        tape.add("az_axpby_f32", e.data_ptr(), loop.coef_ptr(14), loop.x.data_ptr(), loop.coef_ptr(15), m.data_ptr(), 1,
+                 loop.x.numel(), 0)
+        loop.add_transition(tape, x_t=xp, x_s=loop.x, eps=e)
+        return [tape]
 
     @_lib.on_device
     def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
@@ -619,6 +738,68 @@ class _MultistepSampler(Sampler):
             rows[i, 4 : 4 + len(c) - 1] = q * c[:-1]
         return rows
 
+    # -- fused form: the history ring makes the buffer addresses cycle with period `order`, so ONE graph holds `order`
+    # consecutive steps (ring slot = step mod order, fixed per phase) and is replayed steps / order times (a second,
+    # shorter graph covers the remainder).  Every step uses the full-length kernel (order - 1 history streams); the
+    # warm-up steps simply carry zero weights for the entries that do not exist yet (the ring is zeroed per call).
+    def _needs_noise(self) -> bool:
+        return False
+
+    def _fused_structure(self) -> tuple:
+        return (*super()._fused_structure(), self.order)
+
+    def _fused_rows(self, t, s, fused):
+        alpha_t, sigma_t = self.denoiser.schedule(t)
+        zero = torch.zeros_like(alpha_t)
+        return [dict(alpha=alpha_t, sigma=sigma_t, a_t=zero, a_s=zero, k_x=zero, k_eps=zero)]  # only the mean is used
+
+    def _ring_table(self) -> Tensor:
+        r"""``_device_table`` with the history weights RIGHT-aligned over order - 1 slots (slot k <-> step i - (order-1) + k)."""
+        alpha, sigma = self.denoiser.schedule(torch.linspace(self.start, self.stop, self.steps + 1, dtype=self.dtype))
+        rows = self._device_table(alpha, sigma)
+        nh = self.order - 1
+        out = torch.zeros_like(rows)
+        out[:, :4] = rows[:, :4]
+        for i in range(self.steps):
+            n = min(self.order, i + 1) - 1
+            out[i, 4 + nh - n : 4 + nh] = rows[i, 4 : 4 + n]
+        return out
+
+    def _fused_step_tapes(self, loop):
+        if self.order < 1 or self.order > _lib.MULTISTEP_MAX_HIST + 1:
+            raise ValueError(f"order must be in [1, {_lib.MULTISTEP_MAX_HIST + 1}], got {self.order}")
+        dev, nh = loop.x.device, self.order - 1
+        ncols = 4 + _lib.MULTISTEP_MAX_HIST
+        loop.ring = [torch.zeros_like(loop.x) for _ in range(self.order)]
+        loop.mtable = torch.zeros(self.steps, ncols, dtype=torch.float32, device=dev)
+        mrow = torch.zeros(ncols, dtype=torch.float32, device=dev)
+        mean, scratch = torch.empty_like(loop.x), torch.empty_like(loop.x)
+        loop.keep += [mrow, mean, scratch]
+        tapes = []
+        for j in range(self.order):
+            tape = Tape()
+            loop.add_evaluation(tape)
+            # posterior mean (preconditioning, clip, CFG combine) through the transition kernel's mean output
+            loop.add_transition(tape, x_t=loop.x, x_s=scratch, mean_out=mean, write_xin=False)
+            tape.add("az_gather_step_row_f32", mrow.data_ptr(), loop.mtable.data_ptr(), loop.cur.data_ptr(), 1, ncols, self.steps)
+            args = _lib.AzMultistepArgs()
+            args.x_s, args.x_t, args.mean = loop.x.data_ptr(), loop.x.data_ptr(), mean.data_ptr()
+            args.pred = loop.ring[j].data_ptr()
+            for k in range(nh):  # oldest first: steps i - nh .. i - 1 live in slots (j - nh + k) mod order
+                args.hist[k] = loop.ring[(j - nh + k) % self.order].data_ptr()
+            args.coef, args.count, args.n_hist = mrow.data_ptr(), loop.x.numel(), nh
+            tape.add("az_multistep_f32", C.byref(args), keep=[args])
+            loop.add_input_relayout(tape, loop.x, loop.coef_ptr("c_in_next"))
+            tapes.append(tape)
+        return tapes
+
+    def _fused_upload_extra(self, loop) -> None:
+        loop.mtable.copy_(self._ring_table())
+
+    def _fused_reset(self, loop) -> None:
+        for r in loop.ring:
+            r.zero_()
+
     @torch.no_grad()
     @_lib.on_device
     def __call__(self, x: Tensor, **kwargs) -> Tensor:
@@ -627,6 +808,11 @@ class _MultistepSampler(Sampler):
         time = self.timesteps.to(device=x.device)
         if not x.is_cuda:
             return self._call_host(x, time, kwargs)
+        if type(self).__call__ is _MultistepSampler.__call__ and x.dtype == torch.float32 and x.ndim >= 2 \
+                and self.dtype in (None, torch.float32):
+            out = self._call_fused(x, kwargs)
+            if out is not None:
+                return out
         require_f32_cuda(x, type(self).__name__)
         alpha, sigma = self.denoiser.schedule(self.timesteps.cpu())
         table = self._device_table(alpha, sigma).to(x.device)
@@ -775,8 +961,34 @@ class PCSampler(Sampler):
         self.corrections = corrections
         self.delta = delta
 
-    def _fusable(self, x: Tensor) -> bool:
-        return False  # several denoiser evaluations per step: generic loop
+    # Fused form: corrections + 1 table rows / denoiser evaluations per step, all the kernel's own form
+    # x' = a_s m + k_x (x - a_t m) + k_eps eps, in place; one noise buffer per corrector move, drawn before the replay
+    # in the reference's order (its predictor draws nothing).
+    def _needs_noise(self) -> bool:
+        return self.corrections > 0
+
+    def _noise_draws(self) -> int:
+        return self.corrections
+
+    def _fused_structure(self) -> tuple:
+        return (*super()._fused_structure(), self.corrections)
+
+    def _fused_rows(self, t, s, fused):
+        alpha_s, sigma_s = self.denoiser.schedule(s)
+        alpha_t, sigma_t = self.denoiser.schedule(t)
+        keep, kick = math.sqrt(1 - self.delta), math.sqrt(self.delta)
+        corr = dict(alpha=alpha_t, sigma=sigma_t, a_t=alpha_t, a_s=alpha_t, k_x=keep + 0 * alpha_t, k_eps=kick * sigma_t)
+        pred = dict(alpha=alpha_t, sigma=sigma_t, a_t=alpha_t, a_s=alpha_s, k_x=sigma_s / sigma_t, k_eps=0 * alpha_t)
+        return [corr] * self.corrections + [pred]
+
+    def _fused_step_tapes(self, loop):
+        tape = Tape()
+        for k in range(self.corrections):
+            loop.add_evaluation(tape)
+            loop.add_transition(tape, x_t=loop.x, x_s=loop.x, eps=loop.noise[k])
+        loop.add_evaluation(tape)
+        loop.add_transition(tape, x_t=loop.x, x_s=loop.x)
+        return [tape]
 
     @_lib.on_device
     def step(self, x_t: Tensor, t: Tensor, s: Tensor, **kwargs) -> Tensor:
@@ -793,3 +1005,7 @@ class PCSampler(Sampler):
         if x_t.is_cuda:
             return self._device_kernel(x_t, q_t.mean, alpha_t, alpha_s, sigma_s / sigma_t, 0 * alpha_t, False)
         return alpha_s * q_t.mean + sigma_s / sigma_t * (x_t - alpha_t * q_t.mean)
+
+
+# samplers whose ``step`` the captured loop reproduces (a subclass overriding ``step`` falls back to the generic loop)
+_FUSED_STEPS = (DDPMSampler.step, DDIMSampler.step, EulerSampler.step, HeunSampler.step, ItoSampler.step, PCSampler.step)

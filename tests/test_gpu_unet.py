@@ -167,8 +167,8 @@ def test_unet_forward_through_bf16x3(golden, monkeypatch):
 
 
 def test_next_samplers_on_gpu(golden):
-    """Euler and Ito ride the fused transition kernel (folded coefficients), Heun the generic
-    two-evaluation step; all against reference-generated vectors (G8)."""
+    """Euler and Ito ride the fused transition kernel (folded coefficients); Heun is a two-evaluation step
+    captured as ONE graph (two table rows per step); all against reference-generated vectors (G8)."""
     from azula_amd.sample import EulerSampler, HeunSampler, ItoSampler
 
     g = golden("g8_unet_next_samplers")
@@ -180,9 +180,22 @@ def test_next_samplers_on_gpu(golden):
     assert next(iter(smp._fused_cache.values())).graph is not None
     print("euler16", max_err(x0, g["euler16"]))
     assert max_err(x0, g["euler16"]) < 5e-4 * sc
-    x0 = HeunSampler(den, steps=8, silent=True)(x1)
+    smp = HeunSampler(den, steps=8, silent=True)
+    x0 = smp(x1)
+    loop = next(iter(smp._fused_cache.values()))
+    assert loop.graph is not None and loop.n_rows == 16, "Heun must run as a captured two-evaluation graph"
+    assert sum(n == "az_step_begin" for _, _, n in loop.tape.ops) == 2
     print("heun8", max_err(x0, g["heun8"]))
     assert max_err(x0, g["heun8"]) < 5e-4 * sc
+    assert torch.equal(smp(x1), x0)  # replay determinism
+
+    class GenericHeun(HeunSampler):  # an overridden step() forces the Python-driven loop
+        def step(self, x_t, t, s, **kw):
+            return super().step(x_t, t, s, **kw)
+
+    xg = GenericHeun(den, steps=8, silent=True)(x1)
+    print("heun8 fused vs generic", max_err(x0, xg))
+    assert max_err(x0, xg) < 1e-4 * sc
     # Ito with the device RNG: compare with the oracle fed the same noise
     torch.manual_seed(5)
     eps = [torch.randn_like(x1).cpu() for _ in range(16)]
@@ -204,17 +217,44 @@ def test_multistep_and_pc_samplers_on_gpu(golden):
     x1 = g["x1"].cuda()
     for kind in ("zAB", "vAB", "zEAB", "xEAB", "REAB"):
         want = g[f"{kind}_o3"]
-        x0 = getattr(S, kind + "Sampler")(den, order=3, steps=g.meta["steps"], silent=True)(x1)
+        smp = getattr(S, kind + "Sampler")(den, order=3, steps=g.meta["steps"], silent=True)
+        x0 = smp(x1)
+        loop = next(iter(smp._fused_cache.values()))
+        # ring-slot addresses cycle with period `order`: one graph of 3 steps (+ one for the remainder), replayed
+        assert loop.period == 3 and loop.graph is not None, kind
+        assert set(loop.graphs) == {3} | ({g.meta["steps"] % 3} if g.meta["steps"] % 3 else set())
         err, sc = max_err(x0, want), max(1.0, want.abs().max().item())
         print(kind, "order 3 max|d| vs reference:", err, "scale", sc)
         assert x0.is_cuda and err < 1e-3 * sc, kind
+        assert torch.equal(smp(x1), x0), "the history ring must be reset between calls"
+    # other orders against the oracle (order 1 = no history, order 4 with a remainder group, order 2 even split)
+    for kind, order, steps in (("zAB", 1, 5), ("xEAB", 4, 10), ("zEAB", 2, 8), ("vAB", 8, 9)):
+        smp = getattr(S, kind + "Sampler")(den, order=order, steps=steps, silent=True)
+        x0 = smp(x1)
+        assert next(iter(smp._fused_cache.values())).graph is not None
+        omean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, cfg, a, c), x, t)  # noqa: E731
+        ref = sampling.sample_multistep(omean, g["x1"], kind, order=order, steps=steps)
+        err, sc = max_err(x0, ref), max(1.0, ref.abs().max().item())
+        print(kind, "order", order, "steps", steps, "max|d| vs oracle:", err, "scale", sc)
+        assert err < 1e-3 * sc, (kind, order)
     torch.manual_seed(5)
     eps = [torch.randn_like(x1).cpu() for _ in range(g.meta["pc_steps"])]
     torch.manual_seed(5)
-    x0 = S.PCSampler(den, corrections=1, steps=g.meta["pc_steps"], silent=True)(x1)
+    smp = S.PCSampler(den, corrections=1, steps=g.meta["pc_steps"], silent=True)
+    x0 = smp(x1)
+    loop = next(iter(smp._fused_cache.values()))
+    assert loop.graph is not None and loop.n_rows == 2 * g.meta["pc_steps"], "PC must run as a captured graph"
     omean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, cfg, a, c), x, t)  # noqa: E731
     ref = sampling.sample_pc(omean, g["x1"], steps=g.meta["pc_steps"], corrections=1, eps_list=eps)
     print("pc", max_err(x0, ref))
+    assert max_err(x0, ref) < 5e-4 * max(1.0, ref.abs().max().item())
+    # two corrector moves per step: the noise draws keep the reference's order (two per step, none for the predictor)
+    torch.manual_seed(6)
+    eps = [torch.randn_like(x1).cpu() for _ in range(2 * 4)]
+    torch.manual_seed(6)
+    x0 = S.PCSampler(den, corrections=2, delta=0.05, steps=4, silent=True)(x1)
+    ref = sampling.sample_pc(omean, g["x1"], steps=4, corrections=2, delta=0.05, eps_list=eps)
+    print("pc x2", max_err(x0, ref))
     assert max_err(x0, ref) < 5e-4 * max(1.0, ref.abs().max().item())
 
 
