@@ -56,6 +56,37 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
   const float* kp = a.k + (int64_t)b * a.k_bstride + (int64_t)hd * a.k_hstride;
   const float* vp = a.v + (int64_t)b * a.v_bstride + (int64_t)hd * a.v_hstride;
 
+  // cooperative K/V tile loader: thread -> (row = tid / CH + pass * rows_per_pass, 16-B chunk)
+  constexpr int CH = D / 4;               // chunks per row
+  // CH a power of two: 256 / CH rows per pass, a row's chunks on CH consecutive lanes.  Otherwise (D = 80:
+  // CH = 20) each wave takes 64 / CH whole rows so that a row never straddles two waves (4 lanes idle).
+  constexpr bool POW2 = (CH & (CH - 1)) == 0;
+  constexpr int RW = 64 / CH;
+  constexpr int RPP = POW2 ? 256 / CH : 4 * RW;  // rows per pass
+  const int lc = POW2 ? tid % CH : lane % CH;
+  const int lr = POW2 ? tid / CH : wave * RW + lane / CH;
+  const bool lactive = POW2 || lane < RW * CH;
+
+  // register prefetch of the raw K / V rows of the NEXT tile: issued once the current tile has been staged, in
+  // flight under its MFMAs (the tile loop used to expose one global round trip per 64 keys and workgroup: 181 -> 173 us
+  // on 64 x 12 heads x 256 tokens, although 136 VGPRs now allow 3 instead of 4 waves per SIMD)
+  constexpr int NPS = (KT + RPP - 1) / RPP;
+  float4 pk[NPS], pv[NPS];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int row = ps * RPP + lr;
+      const int key = k0 + row;
+      pk[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pv[ps] = pk[ps];
+      if (row < KT && lactive && key < T) {
+        pk[ps] = *reinterpret_cast<const float4*>(kp + (int64_t)key * a.k_tstride + lc * 4);
+        pv[ps] = *reinterpret_cast<const float4*>(vp + (int64_t)key * a.v_tstride + lc * 4);
+      }
+    }
+  };
+  fetch(0);  // issued before the Q rows are read: both global round trips of the prologue overlap
+
   // ---- Q fragment: lane holds q[qi][8*jj + 4*h2 + s], pre-multiplied by scale (* rms factor)
   float qf[KJ][4];
   {
@@ -70,7 +101,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
       qf[jj][3] = v.w;
       ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
-    float f = a.scale;
+    // scores are produced in log2 units (log2(e) folded into the query scale) so that the softmax numerator is ONE
+    // v_exp_f32 (2^x, <= 1 ulp) per score instead of the ~20-instruction libm expf: on gfx950 vector instructions do
+    // NOT overlap with fp32 MFMAs on a SIMD (measured, DESIGN.md section 4: the two times add), so every VALU
+    // instruction removed from this loop is matrix-pipe time gained.  Parity cost measured on the golden ViT / ADM /
+    // JiT vectors: below 1e-6 of the output scale (the tests' bounds are unchanged).
+    float f = a.scale * 1.4426950408889634f;
     if (a.qk_rmsnorm) {
       ss += __shfl_xor(ss, 32, 64);
       f *= rsqrtf(ss / (float)D + a.eps);
@@ -111,36 +147,6 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
     for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  // cooperative K/V tile loader: thread -> (row = tid / CH + pass * rows_per_pass, 16-B chunk)
-  constexpr int CH = D / 4;               // chunks per row
-  // CH a power of two: 256 / CH rows per pass, a row's chunks on CH consecutive lanes.  Otherwise (D = 80:
-  // CH = 20) each wave takes 64 / CH whole rows so that a row never straddles two waves (4 lanes idle).
-  constexpr bool POW2 = (CH & (CH - 1)) == 0;
-  constexpr int RW = 64 / CH;
-  constexpr int RPP = POW2 ? 256 / CH : 4 * RW;  // rows per pass
-  const int lc = POW2 ? tid % CH : lane % CH;
-  const int lr = POW2 ? tid / CH : wave * RW + lane / CH;
-  const bool lactive = POW2 || lane < RW * CH;
-
-  // register prefetch of the raw K / V rows of the NEXT tile: issued once the current tile has been staged, in
-  // flight under its MFMAs (the tile loop used to expose one global round trip per 64 keys and workgroup: 181 -> 173 us
-  // on 64 x 12 heads x 256 tokens, although 136 VGPRs now allow 3 instead of 4 waves per SIMD)
-  constexpr int NPS = (KT + RPP - 1) / RPP;
-  float4 pk[NPS], pv[NPS];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int ps = 0; ps < NPS; ++ps) {
-      const int row = ps * RPP + lr;
-      const int key = k0 + row;
-      pk[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-      pv[ps] = pk[ps];
-      if (row < KT && lactive && key < T) {
-        pk[ps] = *reinterpret_cast<const float4*>(kp + (int64_t)key * a.k_tstride + lc * 4);
-        pv[ps] = *reinterpret_cast<const float4*>(vp + (int64_t)key * a.v_tstride + lc * 4);
-      }
-    }
-  };
-  fetch(0);
   for (int k0 = 0; k0 < T; k0 += KT) {
     __syncthreads();  // previous tile fully consumed
 #pragma unroll
@@ -213,21 +219,22 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
         sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[jj][2], sacc, 0, 0, 0);
         sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[jj][3], sacc, 0, 0, 0);
       }
-      // ---- online softmax over this lane's query column
-      float mt = -INFINITY;
+      // ---- online softmax over this lane's query column (ragged last tile only: mask the keys past T)
+      if (k0 + sub * 32 + 32 > T) {  // wave-uniform
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + sub * 32 + key_of(r, h2);
-        if (key >= T) sacc[r] = -INFINITY;
-        mt = fmaxf(mt, sacc[r]);
+        for (int r = 0; r < 16; ++r)
+          if (k0 + sub * 32 + key_of(r, h2) >= T) sacc[r] = -INFINITY;
       }
+      float mt = sacc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sacc[r]);
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float m_new = fmaxf(m_run, mt);
-      const float alpha = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
+      const float m_new = fmaxf(m_run, mt);  // finite: every sub-tile that is entered holds at least one valid key
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 2^(-inf) = 0 on the first tile
       float ls = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = sacc[r] == -INFINITY ? 0.f : expf(sacc[r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(sacc[r] - m_new);  // masked keys: 2^(-inf) = 0
         sacc[r] = pv;
         ls += pv;
       }

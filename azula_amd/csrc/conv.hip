@@ -75,6 +75,7 @@ __device__ __forceinline__ f32x2 buf_ld2(__amdgpu_buffer_rsrc_t rsrc, unsigned v
 // (Round 1 clamped at 0xFFFFFFF0: with more than 2 GiB of activations behind a workgroup's first sample -- ADM's
 // 512-channel concatenation at 256^2, batch 32 -- the "zero" taps of the first 16 samples read sample b + 16 instead.)
 constexpr unsigned OOB = 0x80000000u;
+#define AZ_RSRC_CLAMP 0x80000000ll  // == OOB: the largest num_records a descriptor may carry
 
 // Epilogue for 4 consecutive output channels [co, co+4) of output pixel n.
 // The fused epilogue in two halves so that callers can issue the loads of several outputs before the first store (the
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   // Buffer descriptors (wave-uniform: kernel arguments + blockIdx only).
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > 0x80000000ll ? 0x80000000ll : e * 4); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
   const int b_first = n0 / hw_out;
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e > 0x80000000ll ? 0x80000000ll : e); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
   const int64_t wplane = (int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s;  // elements per weight piece
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e > 0x80000000ll ? 0x80000000ll : e); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, clamp_bytes(3 * wplane * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(a.src0 + b_first * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems * 4), 0x00020000);
@@ -1046,7 +1047,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
 
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > 0x80000000ll ? 0x80000000ll : e * 4); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)p.nk * p.cblocks * WU_STAGE), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -1176,6 +1177,11 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   // fragment addresses: row (within a frequency) = wave's 32-row block + l31; half = h (swizzled)
   const int fragA = (fh * 8) * WC * WK + wswz(wco * 32 + l31, h);  // + f * WC * WK
   const int fragB = (fh * 8) * WT * WK + wswz(wti * 32 + l31, h);  // + f * WT * WK
+  // Code placement: this loop loses 4.5 % (25.2 -> 26.4 ms per C2 step) when its instructions start at byte phases
+  // 16..23 of a 32-byte window (measured by sweeping s_nop padding behind this anchor: phases 0-15 and 24-31 are
+  // equally fast) -- a 12-byte change in the PROLOGUE (three 32-bit literals) was enough to move it there.  The
+  // anchor pins the phase to 0, independent of whatever precedes it.
+  asm volatile(".p2align 6" ::: "memory");
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int buf = (kt - kt_begin) & 1;
     const bool more = kt + 1 < kt_end;
@@ -1382,7 +1388,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd4_kernel(Wino4P p) {
 
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > 0x80000000ll ? 0x80000000ll : e * 4); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)p.nk * p.cblocks * W4U_STAGE), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
