@@ -152,6 +152,8 @@ class AzConvArgs(C.Structure):
         ("dst_c", C.c_int32),
         ("splitk", C.c_int32),
         ("workspace", c_f32p),
+        ("pad_mode", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 
@@ -184,6 +186,9 @@ class AzAttnArgs(C.Structure):
         ("rope_sin", c_f32p),
         ("q_weight", c_f32p),
         ("k_weight", c_f32p),
+        ("mask", c_f32p),
+        ("mask_bstride", C.c_int64),
+        ("mask_hstride", C.c_int64),
     ]
 
 

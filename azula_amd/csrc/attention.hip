@@ -55,6 +55,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
   const float* qp = a.q + (int64_t)b * a.q_bstride + (int64_t)hd * a.q_hstride;
   const float* kp = a.k + (int64_t)b * a.k_bstride + (int64_t)hd * a.k_hstride;
   const float* vp = a.v + (int64_t)b * a.v_bstride + (int64_t)hd * a.v_hstride;
+  const uint8_t* mrow = (a.mask != nullptr && qi < T)
+                            ? a.mask + (int64_t)b * a.mask_bstride + (int64_t)hd * a.mask_hstride + (int64_t)qi * T
+                            : nullptr;
 
   // cooperative K/V tile loader: thread -> (row = tid / CH + pass * rows_per_pass, 16-B chunk)
   constexpr int CH = D / 4;               // chunks per row
@@ -225,16 +228,25 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
         for (int r = 0; r < 16; ++r)
           if (k0 + sub * 32 + key_of(r, h2) >= T) sacc[r] = -INFINITY;
       }
+      if (mrow != nullptr) {  // boolean attention mask: one byte per (query, key)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + sub * 32 + key_of(r, h2);
+          if (key < T && mrow[key] == 0) sacc[r] = -INFINITY;
+        }
+      }
       float mt = sacc[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sacc[r]);
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float m_new = fmaxf(m_run, mt);  // finite: every sub-tile that is entered holds at least one valid key
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 2^(-inf) = 0 on the first tile
+      const float m_new = fmaxf(m_run, mt);
+      // -inf only while every key seen so far is masked for this query: subtract 0 then (all terms are 2^(-inf) = 0)
+      const float m_sub = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_sub);  // 2^(-inf) = 0 on the first tile
       float ls = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(sacc[r] - m_new);  // masked keys: 2^(-inf) = 0
+        const float pv = __builtin_amdgcn_exp2f(sacc[r] - m_sub);  // masked keys: 2^(-inf) = 0
         sacc[r] = pv;
         ls += pv;
       }
@@ -336,6 +348,9 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
   const float* qp = a.q + (int64_t)b * a.q_bstride + (int64_t)hd * a.q_hstride;
   const float* kp = a.k + (int64_t)b * a.k_bstride + (int64_t)hd * a.k_hstride;
   const float* vp = a.v + (int64_t)b * a.v_bstride + (int64_t)hd * a.v_hstride;
+  const uint8_t* mrow = (a.mask != nullptr && qi < T)
+                            ? a.mask + (int64_t)b * a.mask_bstride + (int64_t)hd * a.mask_hstride + (int64_t)qi * T
+                            : nullptr;
 
   // zero V^T once: rows d >= D (padding of the last 32-wide output tile) are never written again
   for (int e = tid; e < DP * VLS / 2; e += 256) reinterpret_cast<unsigned*>(Vt)[e] = 0u;
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = k0 + sub * 32 + key_of(r, h2);
-        if (key >= T) sacc[r] = -INFINITY;
+        if (key >= T || (mrow != nullptr && mrow[key] == 0)) sacc[r] = -INFINITY;
         mt = fmaxf(mt, sacc[r]);
       }
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));

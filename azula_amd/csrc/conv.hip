@@ -75,6 +75,16 @@ __device__ __forceinline__ f32x2 buf_ld2(__amdgpu_buffer_rsrc_t rsrc, unsigned v
 // (Round 1 clamped at 0xFFFFFFF0: with more than 2 GiB of activations behind a workgroup's first sample -- ADM's
 // 512-channel concatenation at 256^2, batch 32 -- the "zero" taps of the first 16 samples read sample b + 16 instead.)
 constexpr unsigned OOB = 0x80000000u;
+
+// Circular ("periodic") padding -- azula/nn/unet.py:175-180, torch padding_mode="circular": an out-of-range tap
+// coordinate wraps around the map instead of reading zero.  Only in the per-(tap, source) address setup, never in a K loop.
+__device__ __forceinline__ int wrap_coord(int i, int n, int mode) {
+  if (mode) {
+    i %= n;
+    if (i < 0) i += n;
+  }
+  return i;
+}
 #define AZ_RSRC_CLAMP 0x80000000ll  // == OOB: the largest num_records a descriptor may carry
 
 // Epilogue for 4 consecutive output channels [co, co+4) of output pixel n.
@@ -325,8 +335,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     const int ws = it_src ? a.w1 : a.w0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int ih = ihb[i] + ky;
-      const int iw = iwb[i] + kx;
+      const int ih = wrap_coord(ihb[i] + ky, a.hin, a.pad_mode);
+      const int iw = wrap_coord(iwb[i] + kx, a.win, a.pad_mode);
       const bool ok = prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
       const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> up);
       voffA[i] = ok ? (unsigned)((pix * cs + cc * 4) * 4) : OOB;
@@ -519,8 +529,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
     const int ws = it_src ? a.w1 : a.w0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int ih = ihb[i] + ky;
-      const int iw = iwb[i] + kx;
+      const int ih = wrap_coord(ihb[i] + ky, a.hin, a.pad_mode);
+      const int iw = wrap_coord(iwb[i] + kx, a.win, a.pad_mode);
       const bool ok = prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
       const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> up);
       voffA[i] = ok ? (unsigned)((pix * cs + acc4 * 4) * 4) : OOB;
@@ -734,8 +744,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
     const int ws = it_src ? a.w1 : a.w0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int ih = ihb[i] + ky;
-      const int iw = iwb[i] + kx;
+      const int ih = wrap_coord(ihb[i] + ky, a.hin, a.pad_mode);
+      const int iw = wrap_coord(iwb[i] + kx, a.win, a.pad_mode);
       const bool ok = prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
       const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> up);
       voffA[i] = ok ? (unsigned)((pix * cs + kc8 * 8) * 4) : OOB;
@@ -896,7 +906,7 @@ __global__ __launch_bounds__(256) void conv_head_kernel(ConvP p, int tiles_x, in
     const int e = tid + 256 * i;
     const int pxi = e / (HD_KC / 4), q = e % (HD_KC / 4);
     const int hy = pxi / HD_HALO, hx = pxi - hy * HD_HALO;
-    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const int iy = wrap_coord(oy0 - 1 + hy, a.hin, a.pad_mode), ix = wrap_coord(ox0 - 1 + hx, a.win, a.pad_mode);
     const bool inb = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
     loff[i] = e < NE ? pxi * HD_PS + q * 4 : -1;
     goff[i] = (e < NE && inb) ? (iy * a.w0 + ix) * a.c0s + q * 4 : -1;
@@ -1086,7 +1096,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const int ih = v_ih0 + r, iw = v_iw0 + c;
+        const int ih = wrap_coord(v_ih0 + r, a.hin, a.pad_mode), iw = wrap_coord(v_iw0 + c, a.win, a.pad_mode);
         const bool ok = v_b >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
         const int pix = (v_b * hs + (ih >> up)) * ws + (iw >> up);
         voffV[r * 4 + c] = ok ? (unsigned)((pix * cs + vq * 2) * 4) : OOB;
@@ -1424,9 +1434,10 @@ __global__ __launch_bounds__(512, 2) void conv_winograd4_kernel(Wino4P p) {
     const int ws = src ? a.w1 : a.w0;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      const int iw = v_iw0 + c;
-      const bool ok = v_b >= 0 && (unsigned)v_ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
-      const int pix = (v_b * hs + (v_ih >> up)) * ws + (iw >> up);
+      const int iw = wrap_coord(v_iw0 + c, a.win, a.pad_mode);
+      const int ihw = wrap_coord(v_ih, a.hin, a.pad_mode);
+      const bool ok = v_b >= 0 && (unsigned)ihw < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
+      const int pix = (v_b * hs + (ihw >> up)) * ws + (iw >> up);
       voffV[c] = ok ? (unsigned)((pix * cs + a_q * 2) * 4) : OOB;
     }
   };

@@ -285,6 +285,7 @@ class Builder:
         res_up: int = 0,
         dst_nchw: torch.Tensor | None = None,
         winograd: bool | int | None = None,
+        periodic: bool = False,
     ) -> Act | None:
         ks, bias = packed.ks, packed.bias
         pad = ks // 2
@@ -304,6 +305,7 @@ class Builder:
         a.bias = bias.data_ptr() if bias is not None else None
         a.cout_s = pad4(cout)
         a.ksize, a.stride, a.pad = ks, stride, pad
+        a.pad_mode = 1 if (periodic and pad > 0) else 0
         a.hout, a.wout = hout, wout
         a.act = act
         if gate is not None:
@@ -435,6 +437,49 @@ class Builder:
         return y
 
 
+# ------------------------------------------------------------------------------- AdaZero modulation helpers
+def ada_zero_triple(bld: "Builder", ada_zero, channels: int, D: int, mod_rows: int, mod_jobs: list):
+    r"""(abc buffer, batch stride) of one block's modulation triple (a, b, c), each padded to ``pad4(channels)``.
+    ``ada_zero`` is the block's ``Linear(D, D) -> SiLU -> Linear(D, 3C)`` (then the MLP is queued on ``mod_jobs`` and
+    emitted by :func:`mod_front_tape` for all blocks at once) or its raw ``(3, C, ...)`` parameter
+    (reference ``azula/nn/unet.py:63-75``, ``azula/nn/dit.py:57-68``)."""
+    cs, device = pad4(channels), bld.device
+    if not isinstance(ada_zero, torch.nn.Parameter):
+        abc = bld.empty(max(mod_rows, 1), 3 * cs)
+        l0, l2 = ada_zero[0], ada_zero[2]
+        w2 = torch.zeros(3 * cs, D, dtype=torch.float32, device=device)
+        b2 = torch.zeros(3 * cs, dtype=torch.float32, device=device)
+        for n in range(3):
+            w2[n * cs : n * cs + channels] = l2.weight.detach()[n * channels : (n + 1) * channels]
+            b2[n * cs : n * cs + channels] = l2.bias.detach()[n * channels : (n + 1) * channels]
+        mod_jobs.append((l0, bld.const(w2), bld.const(b2), abc, 3 * cs))
+        return abc, (3 * cs if mod_rows > 1 else 0)
+    abc = torch.zeros(3 * cs, dtype=torch.float32, device=device)
+    for n in range(3):
+        abc[n * cs : n * cs + channels] = ada_zero.detach()[n].flatten()
+    return bld.const(abc), 0
+
+
+def mod_front_tape(bld: "Builder", mod_jobs: list, mod_buf: torch.Tensor, mod_rows: int, D: int) -> Tape:
+    r"""h_i = silu(W0_i mod + b0_i) for ALL queued blocks as one GEMV, abc_i = W2_i h_i + b2_i as one grouped GEMV."""
+    from ._lib import AzLinearGroup
+
+    nj, rows = len(mod_jobs), max(mod_rows, 1)
+    w0 = bld.const(torch.cat([j[0].weight.detach() for j in mod_jobs]))
+    b0 = bld.const(torch.cat([j[0].bias.detach() for j in mod_jobs]))
+    h_all = bld.empty(rows, nj * D)
+    groups = (AzLinearGroup * nj)()
+    for i, (_, w2, b2, abc, n_out) in enumerate(mod_jobs):
+        g = groups[i]
+        g.y, g.x, g.W, g.bias = abc.data_ptr(), h_all.data_ptr() + 4 * i * D, w2.data_ptr(), b2.data_ptr()
+        g.ldy, g.ldx, g.N, g.K = n_out, nj * D, n_out, D
+    gdev = torch.frombuffer(bytearray(bytes(groups)), dtype=torch.uint8).to(bld.device)
+    pre = Tape()
+    pre.add("az_linear_small_f32", h_all.data_ptr(), nj * D, mod_buf.data_ptr(), D, w0.data_ptr(), b0.data_ptr(), rows, nj * D, D, 0, 1)
+    pre.add("az_linear_small_grouped_f32", gdev.data_ptr(), nj, max(j[4] for j in mod_jobs), rows, 0, 0, keep=[gdev, w0, b0, h_all])
+    return pre
+
+
 def transition_args(**kw) -> AzTransitionArgs:
     a = AzTransitionArgs()
     for k, v in kw.items():
@@ -445,7 +490,7 @@ def transition_args(**kw) -> AzTransitionArgs:
 
 # ------------------------------------------------------------------------------- token-path helpers
 def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool, scale: float, eps: float = 1e-5,
-                       rope: tuple | None = None, qk_weight: tuple | None = None) -> Act:
+                       rope: tuple | None = None, qk_weight: tuple | None = None, mask: torch.Tensor | None = None) -> Act:
     r"""softmax(q k^T * scale) v over a fused-QKV token tensor (B, L, 1, 3*heads*dim).
 
     order: "nHC" = azula '(n H C)' (attention.py:90), "H3C" = ADM legacy (unet.py:338),
@@ -479,6 +524,17 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
     if qk_weight is not None:  # learned (dim,) gains of the q / k RMS norms
         a.q_weight, a.k_weight = qk_weight[0].data_ptr(), qk_weight[1].data_ptr()
         self.tape.keep.extend(qk_weight)
+    if mask is not None:  # (L, L), (B | 1, 1 | H, L, L) boolean: True = attend (reference attention.py:97-104)
+        m = mask
+        if m.ndim == 2:
+            m = m[None, None]
+        if m.ndim != 4 or m.shape[-2:] != (L, L) or m.shape[0] not in (1, qkv.B) or m.shape[1] not in (1, heads):
+            raise ValueError(f"attention mask of shape {tuple(mask.shape)} does not broadcast to ({qkv.B}, {heads}, {L}, {L})")
+        m8 = (m != 0).to(device=self.device, dtype=torch.uint8).contiguous()
+        a.mask = m8.data_ptr()
+        a.mask_bstride = m8.stride(0) if m.shape[0] > 1 else 0
+        a.mask_hstride = m8.stride(1) if m.shape[1] > 1 else 0
+        self.tape.keep.append(m8)
     a._flops = 4 * qkv.B * heads * L * L * dim
     name = "az_attention_f32"
     if self.half is not None:  # module cast to half precision: contractions on the bf16 / f16 MFMA

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from ..engine import Act, Builder, Tape, pad4
+from ..engine import Act, Builder, Tape, ada_zero_triple, mod_front_tape, pad4
 from .. import _lib
 
 __all__ = ["UNet", "UNetBlock"]
@@ -64,10 +64,18 @@ class UNetBlock(nn.Module):
         super().__init__()
         if spatial != 2:
             raise NotImplementedError("azula_amd.nn.UNet implements spatial=2 only")
+        if isinstance(kernel_size, int):  # standalone use passes ConvNd's keyword arguments (reference unet.py:76-83)
+            kernel_size = (kernel_size,) * spatial
+        if len(set(kernel_size)) != 1 or kernel_size[0] % 2 == 0 or kwargs.get("stride", 1) not in (1, (1, 1), [1, 1]):
+            raise NotImplementedError("square odd kernels with stride 1 only")
+        pad = kwargs.get("padding", kernel_size[0] // 2)
+        if (pad if isinstance(pad, int) else pad[0]) != kernel_size[0] // 2:
+            raise NotImplementedError("'same' padding (kernel_size // 2) only")
         if norm not in ("layer", "rms", "group"):
             raise NotImplementedError(norm)
-        if kwargs.get("padding_mode", "zeros") != "zeros":
-            raise NotImplementedError("periodic (circular) padding is not implemented on the HIP path")
+        self.periodic = kwargs.get("padding_mode", "zeros") == "circular"
+        if kwargs.get("padding_mode", "zeros") not in ("zeros", "circular"):
+            raise NotImplementedError(f"padding_mode {kwargs['padding_mode']!r}: zeros and circular only")
         self.channels, self.mod_features = channels, mod_features
         self.norm_kind, self.groups = norm, min(groups, channels)
         self.ffn_factor = ffn_factor
@@ -86,8 +94,68 @@ class UNetBlock(nn.Module):
             _conv_holder(ffn_factor * channels, channels, kernel_size),
         )
 
+        self._plans: dict = {}
+
+    def _emit(self, bld: Builder, x: Act, D: int, mod_rows: int, mod_jobs: list, keep_input: bool = False) -> Act:
+        r"""y = (a + 1) norm(x) + b;  y = conv(silu(conv(y)));  out = x + c y   (reference ``unet.py:85-95``): one
+        statistics + one scale/shift pass, two convolutions with SiLU / gate / residual in their epilogues."""
+        Cc, cs = self.channels, pad4(self.channels)
+        abc, bstride = ada_zero_triple(bld, self.ada_zero, Cc, D, mod_rows, mod_jobs)
+        if self.norm_kind == "group":
+            n_ = bld.group_norm(x, self.groups, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
+        else:
+            n_ = bld.row_norm(x, 0 if self.norm_kind == "layer" else 1, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
+        c0, c3 = self.ffn[0], self.ffn[3]
+        h1 = bld.conv(n_, bld.pack_conv(c0.weight, c0.bias), c0.out_channels, act=1, periodic=self.periodic)
+        bld.free(n_)
+        y = bld.conv(h1, bld.pack_conv(c3.weight, c3.bias), c3.out_channels, gate=abc, gate_off=2 * cs, gate_bstride=bstride,
+                     res=x, periodic=self.periodic)
+        bld.free(h1)
+        if not keep_input:
+            bld.free(x)
+        return y
+
+    @torch.no_grad()
+    @_lib.on_device
     def forward(self, x: Tensor, mod: Tensor | None = None) -> Tensor:
-        raise RuntimeError("UNetBlock is executed as part of a compiled UNet plan; call UNet.forward")
+        r"""x: (B, C, H, W); mod: (D) or (B, D) -> (B, C, H, W)   (reference ``azula/nn/unet.py:97-116``)."""
+        from .utils import backbone_io_dtype
+
+        out_dtype = backbone_io_dtype(self, x, "azula_amd.nn.UNetBlock")
+        assert x.ndim == 4 and x.shape[1] == self.channels
+        B, Cc, H, W = x.shape
+        D = self.mod_features
+        rows = 0
+        if D > 0:
+            assert mod is not None, "this block is modulated: pass mod"
+            rows = 1 if mod.ndim == 1 else mod.shape[0]
+            assert rows in (1, B)
+        key = (B, H, W, rows, str(x.device))
+        versions = tuple((p.data_ptr(), p._version, p.dtype) for p in self.parameters())
+        plan = self._plans.get(key)
+        if plan is None or plan[0] != versions:
+            bld = Builder(x.device, half=next(self.parameters()).dtype)
+            xin = bld.new_act(B, H, W, Cc, pinned=True)
+            mod_buf = torch.empty(max(rows, 1), max(D, 1), dtype=torch.float32, device=x.device)
+            jobs: list = []
+            out = self._emit(bld, xin, D, rows, jobs, keep_input=True)
+            bld.finish()
+            tape = bld.tape
+            if jobs:
+                tape = mod_front_tape(bld, jobs, mod_buf, rows, D)
+                tape.extend(bld.tape)
+            res = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
+            tape.add("az_nhwc_to_nchw_f32", res.data_ptr(), out.ptr, B, Cc, H * W, out.cs)
+            plan = (versions, xin, mod_buf, tape, res)
+            self._plans.clear()
+            self._plans[key] = plan
+        _, xin, mod_buf, tape, res = plan
+        xs = x.to(torch.float32).contiguous()
+        _lib.call("az_nchw_to_nhwc_f32", xin.ptr, xs.data_ptr(), None, B, Cc, H * W, xin.cs, _lib.stream_ptr())
+        if rows:
+            mod_buf.copy_(mod.to(torch.float32).reshape(rows, -1))
+        tape.run()
+        return res.to(out_dtype, copy=True)
 
 
 def _copy_tape(t):
@@ -112,47 +180,11 @@ class UNetPlan:
         L = len(net.hid_blocks)
         stride = net.stride
 
-        mod_jobs: list[tuple] = []  # (first Linear, padded second weight, padded second bias, abc buffer, N)
+        mod_jobs: list[tuple] = []  # queued modulation MLPs (ada_zero_triple), emitted together at the tape front
+        per = net.periodic
 
         def block(blk: UNetBlock, x: Act, keep_input: bool) -> Act:
-            Cc, cs = blk.channels, pad4(blk.channels)
-            # -- modulation triple (a, b, c), each padded to cs
-            if blk.mod_features > 0:
-                rows = mod_rows
-                abc = bld.empty(rows, 3 * cs)
-                l0, l2 = blk.ada_zero[0], blk.ada_zero[2]
-                w2 = torch.zeros(3 * cs, D, dtype=torch.float32, device=device)
-                b2 = torch.zeros(3 * cs, dtype=torch.float32, device=device)
-                for n in range(3):
-                    w2[n * cs : n * cs + Cc] = l2.weight.detach()[n * Cc : (n + 1) * Cc]
-                    b2[n * cs : n * cs + Cc] = l2.bias.detach()[n * Cc : (n + 1) * Cc]
-                # the modulation MLP reads only `mod`: it is not emitted here but batched with every other
-                # block's at the front of the tape (two launches instead of two per block, see below)
-                mod_jobs.append((l0, bld.const(w2), bld.const(b2), abc, 3 * cs))
-                bstride = 3 * cs if rows > 1 else 0
-            else:
-                abc = torch.zeros(3 * cs, dtype=torch.float32, device=device)
-                for n in range(3):
-                    abc[n * cs : n * cs + Cc] = blk.ada_zero.detach()[n].flatten()
-                abc = bld.const(abc)
-                bstride = 0
-            # -- y = (a + 1) * norm(x) + b
-            if blk.norm_kind == "group":
-                n_ = bld.group_norm(x, blk.groups, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
-            else:
-                kind = 0 if blk.norm_kind == "layer" else 1
-                n_ = bld.row_norm(x, kind, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
-            c0, c3 = blk.ffn[0], blk.ffn[3]
-            h1 = bld.conv(n_, bld.pack_conv(c0.weight, c0.bias), c0.out_channels, act=1)
-            bld.free(n_)
-            y = bld.conv(
-                h1, bld.pack_conv(c3.weight, c3.bias), c3.out_channels, gate=abc, gate_off=2 * cs,
-                gate_bstride=bstride, res=x,
-            )
-            bld.free(h1)
-            if not keep_input:
-                bld.free(x)
-            return y
+            return blk._emit(bld, x, D, mod_rows, mod_jobs, keep_input)
 
         cur = self.x_in
         skips: list[Act] = []
@@ -160,7 +192,7 @@ class UNetPlan:
             first = net.descent[i][0]
             if i > 0:
                 skips.append(cur)  # output of level i-1 = memory entry (unet.py:226-230)
-            nxt = bld.conv(cur, bld.pack_conv(first.weight, first.bias), first.out_channels, stride=stride if i > 0 else 1)
+            nxt = bld.conv(cur, bld.pack_conv(first.weight, first.bias), first.out_channels, stride=stride if i > 0 else 1, periodic=per)
             cur = nxt
             for j in range(net.hid_blocks[i]):
                 cur = block(net.descent[i][1 + j], cur, keep_input=False)
@@ -173,7 +205,7 @@ class UNetPlan:
                 conv = mods[0]
                 merged = bld.conv(
                     y, bld.pack_conv(conv.weight, conv.bias, cin0=y.C), conv.out_channels, src1=cur, up1=1,
-                    hin=y.H, win=y.W,
+                    hin=y.H, win=y.W, periodic=per,
                 )
                 bld.free(cur)
                 bld.free(y)
@@ -184,29 +216,13 @@ class UNetPlan:
             idx += net.hid_blocks[i]
             if i == 0:
                 conv = mods[idx]
-                bld.conv(cur, bld.pack_conv(conv.weight, conv.bias), conv.out_channels, dst_nchw=self.out)
+                bld.conv(cur, bld.pack_conv(conv.weight, conv.bias), conv.out_channels, dst_nchw=self.out, periodic=per)
                 bld.free(cur)
             # i > 0: nearest upsampling is folded into the next level's merge conv (up1 = 1)
         bld.finish()
         self.tape = bld.tape
         if mod_jobs:  # h_i = silu(W0_i mod + b0_i) for all blocks as ONE GEMV; abc_i = W2_i h_i + b2_i as ONE grouped GEMV
-            from .._lib import AzLinearGroup
-
-            nj = len(mod_jobs)
-            w0 = bld.const(torch.cat([j[0].weight.detach() for j in mod_jobs]))
-            b0 = bld.const(torch.cat([j[0].bias.detach() for j in mod_jobs]))
-            h_all = bld.empty(max(mod_rows, 1), nj * D)
-            groups = (AzLinearGroup * nj)()
-            for i, (_, w2, b2, abc, n_out) in enumerate(mod_jobs):
-                g = groups[i]
-                g.y, g.x, g.W, g.bias = abc.data_ptr(), h_all.data_ptr() + 4 * i * D, w2.data_ptr(), b2.data_ptr()
-                g.ldy, g.ldx, g.N, g.K = n_out, nj * D, n_out, D
-            gdev = torch.frombuffer(bytearray(bytes(groups)), dtype=torch.uint8).to(device)
-            pre = Tape()
-            pre.add("az_linear_small_f32", h_all.data_ptr(), nj * D, self.mod.data_ptr(), D, w0.data_ptr(), b0.data_ptr(),
-                    max(mod_rows, 1), nj * D, D, 0, 1)
-            pre.add("az_linear_small_grouped_f32", gdev.data_ptr(), nj, max(j[4] for j in mod_jobs), max(mod_rows, 1), 0, 0,
-                    keep=[gdev, w0, b0, h_all])
+            pre = mod_front_tape(bld, mod_jobs, self.mod, mod_rows, D)
             pre.extend(self.tape)
             self.tape = pre
 
@@ -235,8 +251,6 @@ class UNet(nn.Module):
         assert len(hid_blocks) == len(hid_channels)
         if spatial != 2:
             raise NotImplementedError("azula_amd.nn.UNet implements spatial=2 only")
-        if periodic:
-            raise NotImplementedError("periodic padding is not implemented on the HIP path")
         if isinstance(kernel_size, int):
             kernel_size = [kernel_size] * spatial
         if isinstance(stride, int):
@@ -249,6 +263,9 @@ class UNet(nn.Module):
         self.hid_channels, self.hid_blocks = tuple(hid_channels), tuple(hid_blocks)
         self.stride = stride[0]
         self.mod_features = kwargs.get("mod_features", 0)
+        self.periodic = bool(periodic)
+        if periodic:  # reference unet.py:175-180: every convolution pads circularly
+            kwargs["padding_mode"] = "circular"
         ks = tuple(kernel_size)
 
         self.descent, self.ascent = nn.ModuleList(), nn.ModuleList()

@@ -26,7 +26,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from .. import _lib
-from ..engine import Act, Builder, pad4
+from ..engine import Act, Builder, Tape, ada_zero_triple, mod_front_tape, pad4
 
 __all__ = ["DiT", "DiTBlock", "MultiheadSelfAttention", "ViT"]
 
@@ -59,6 +59,92 @@ class MultiheadSelfAttention(nn.Module):
             self.theta_proj = None
         self.heads = attention_heads
         self.qk_norm = qk_norm
+        self._plans: dict = {}
+
+    def _emit(self, bld: Builder, y: Act, pos_h: Tensor | None, mask: Tensor | None, res: Act | None = None) -> Act:
+        r"""qkv projection -> attention (q/k RMS norm, RoPE, mask in the kernel) -> y_proj (+ ``res``)."""
+        C_ = self.qkv_proj.in_features
+        qkv = bld.conv(y, bld.pack_conv(self.qkv_proj.weight, self.qkv_proj.bias), 3 * C_)
+        rope = None
+        if self.theta_proj is not None:  # theta = theta_proj(pos) on the host (reference op order), tables on device
+            if pos_h is None:
+                raise ValueError("this attention layer uses RoPE: pass pos")
+            theta = torch.nn.functional.linear(pos_h.to(torch.float32).cpu(), self.theta_proj.weight.detach().float().cpu())
+            rope = (bld.const(torch.cos(theta)), bld.const(torch.sin(theta)))
+        att = bld.attention(qkv, self.heads, "nHC", self.qk_norm, 1.0 / math.sqrt(C_ // self.heads), rope=rope, mask=mask)
+        bld.free(qkv)
+        out = bld.conv(att, bld.pack_conv(self.y_proj.weight, None), C_, res=res)
+        bld.free(att)
+        return out
+
+    @torch.no_grad()
+    @_lib.on_device
+    def forward(self, x: Tensor, pos: Tensor | None = None, mask: Tensor | None = None) -> Tensor:
+        r"""x: (*, L, H C) tokens; pos: (L, P) positions (RoPE only); mask: boolean (L, L) or broadcastable to
+        (B, H, L, L), True = attend -> (*, L, H C)   (reference ``azula/nn/attention.py:72-110``)."""
+        from .utils import backbone_io_dtype
+
+        out_dtype = backbone_io_dtype(self, x, "azula_amd.nn.MultiheadSelfAttention")
+        plan = _token_plan(self, x, pos, mask, 0, lambda bld, xin, pos_h, plan: self._emit(bld, xin, pos_h, mask))
+        return plan.run(x, None).to(out_dtype)
+
+
+class _TokenPlan:
+    r"""One-module plan on a (B, L, C) token tensor: input Act, optional modulation front, output Act."""
+
+    def __init__(self, module: nn.Module, B: int, L: int, Cin: int, pos_h, mod_rows: int, D: int, emit, device) -> None:
+        bld = self.bld = Builder(device, half=next(module.parameters()).dtype)
+        self.versions = _versions(module)
+        self.x_in = bld.new_act(B, L, 1, Cin, pinned=True)
+        self.mod = torch.empty(max(mod_rows, 1), max(D, 1), dtype=torch.float32, device=device)
+        self.mod_jobs: list = []
+        self.mod_rows = mod_rows
+        self.out = emit(bld, self.x_in, pos_h, self)
+        bld.finish()
+        self.tape = bld.tape
+        if self.mod_jobs:
+            pre = mod_front_tape(bld, self.mod_jobs, self.mod, mod_rows, D)
+            pre.extend(self.tape)
+            self.tape = pre
+
+    def run(self, x: Tensor, mod: Tensor | None) -> Tensor:
+        t, (B, L) = self.x_in, (self.x_in.B, self.x_in.H)
+        xf = x.to(torch.float32).reshape(B * L, -1)
+        if t.cs == xf.shape[1]:
+            t.buf.copy_(xf.reshape(-1))
+        else:
+            t.buf.zero_()
+            t.buf.view(B * L, t.cs)[:, : xf.shape[1]].copy_(xf)
+        if self.mod_rows:
+            self.mod.copy_(mod.to(torch.float32).reshape(self.mod_rows, -1))
+        self.tape.run()
+        o = self.out
+        return o.buf.view(B, L, o.cs)[..., : o.C].reshape(*x.shape[:-1], o.C).clone()
+
+
+def _versions(module: nn.Module) -> tuple:
+    return tuple((p.data_ptr(), p._version, p.dtype) for p in module.parameters())
+
+
+def _token_plan(module, x: Tensor, pos, mask, D: int, emit, mod: Tensor | None = None) -> _TokenPlan:
+    r"""Plan cache of a standalone token module, keyed on shapes, positions, mask content and parameter versions."""
+    assert x.ndim >= 2, "expected (*, L, C) tokens"
+    L, Cin = x.shape[-2], x.shape[-1]
+    B = x.numel() // (L * Cin)
+    rows = 0
+    if D > 0:
+        assert mod is not None, "this block is modulated: pass mod"
+        rows = 1 if mod.ndim == 1 else mod.numel() // mod.shape[-1]
+        assert rows in (1, B), "mod must be (D) or (*, D) with the leading shape of x"
+    pos_h = None if pos is None else pos.detach().to("cpu", torch.float32).reshape(L, -1)
+    key = (B, L, Cin, rows, str(x.device), None if pos_h is None else hash(pos_h.numpy().tobytes()),
+           None if mask is None else (tuple(mask.shape), hash(mask.detach().cpu().numpy().tobytes())))
+    plan = module._plans.get(key)
+    if plan is None or plan.versions != _versions(module):
+        module._plans.clear()  # one live plan per standalone module
+        plan = _TokenPlan(module, B, L, Cin, pos_h, rows, D, emit, x.device)
+        module._plans[key] = plan
+    return plan
 
 
 class DiTBlock(nn.Module):
@@ -93,6 +179,45 @@ class DiTBlock(nn.Module):
             nn.Identity() if dropout is None else nn.Dropout(dropout),
             nn.Linear(ffn_factor * channels // (2 if ffn_activation == "swiglu" else 1), channels),
         )
+        self._plans: dict = {}
+
+    def _emit(self, bld: Builder, x: Act, pos_h, mask, D: int, mod_rows: int, mod_jobs: list, keep_input: bool = False) -> Act:
+        r"""y = (a + 1) RMSNorm(x) + b;  y = y + MSA(y);  y = FFN(y);  out = x + c y   (reference ``dit.py:95-112``)."""
+        C_, cs = self.channels, pad4(self.channels)
+        abc, bstride = ada_zero_triple(bld, self.ada_zero, C_, D, mod_rows, mod_jobs)
+        y = bld.row_norm(x, 1, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
+        y2 = self.msa._emit(bld, y, pos_h, mask, res=y)
+        bld.free(y)
+        f0, f3 = self.ffn[0], self.ffn[3]
+        code = {"silu": 1, "relu": 2, "relu2": 3, "swiglu": 0}[self.ffn_activation]
+        f1 = bld.conv(y2, bld.pack_conv(f0.weight, f0.bias), f0.out_features, act=code)
+        bld.free(y2)
+        if self.ffn_activation == "swiglu":  # x1 * silu(x2) over interleaved pairs (layers.py:107-110)
+            glu = bld.new_act(f1.B, f1.H, f1.W, f1.C // 2)
+            bld.tape.add("az_swiglu_f32", glu.ptr, f1.ptr, f1.B * f1.H * f1.W, f1.C // 2, f1.cs, glu.cs)
+            bld.free(f1)
+            f1 = glu
+        out = bld.conv(f1, bld.pack_conv(f3.weight, f3.bias), C_, gate=abc, gate_off=2 * cs, gate_bstride=bstride, res=x)
+        bld.free(f1)
+        if not keep_input:
+            bld.free(x)
+        return out
+
+    @torch.no_grad()
+    @_lib.on_device
+    def forward(self, x: Tensor, mod: Tensor | None = None, pos: Tensor | None = None, mask: Tensor | None = None) -> Tensor:
+        r"""x: (*, L, C); mod: (D) or (*, D); pos: (L, P); mask: boolean, broadcastable to (B, H, L, L) -> (*, L, C)
+        (reference ``azula/nn/dit.py:114-133``)."""
+        from .utils import backbone_io_dtype
+
+        out_dtype = backbone_io_dtype(self, x, "azula_amd.nn.DiTBlock")
+        D = self.mod_features
+
+        def emit(bld, xin, pos_h, plan):
+            return self._emit(bld, xin, pos_h, mask, D, plan.mod_rows, plan.mod_jobs, keep_input=True)
+
+        plan = _token_plan(self, x, pos, mask, D, emit, mod)
+        return plan.run(x, mod).to(out_dtype)
 
 
 def host_sine_encoding(x: Tensor, features: int, omega: float) -> Tensor:
@@ -116,7 +241,7 @@ class DiTPlan:
         cin = net.in_proj.in_features
         cout = net.out_proj.out_features
         if patch is not None:
-            Z, H, W, p = patch
+            Z, H, W, p, pu = patch
             self.x_nchw = torch.empty(B, Z, H, W, dtype=torch.float32, device=device)
             tokens = bld.new_act(B, L, 1, cin, pinned=True)
             bld.tape.add("az_patchify_f32", tokens.ptr, self.x_nchw.data_ptr(), None, B, Z, H, W, p, tokens.cs)
@@ -138,85 +263,23 @@ class DiTPlan:
         ptab.pinned = True
 
         x = bld.conv(tokens, bld.pack_conv(net.in_proj.weight, net.in_proj.bias), C_, res=_bcast(ptab))
-        mod_jobs: list[tuple] = []  # (first Linear, padded second weight / bias, abc buffer, N) per modulated block
+        mod_jobs: list[tuple] = []  # queued modulation MLPs of the blocks, emitted together at the tape front
         for blk in net.blocks:
-            cs = pad4(C_)
-            if blk.mod_features > 0:
-                rows = mod_rows
-                abc = bld.empty(rows, 3 * cs)
-                l0, l2 = blk.ada_zero[0], blk.ada_zero[2]
-                w2 = torch.zeros(3 * cs, D, dtype=torch.float32, device=device)
-                b2 = torch.zeros(3 * cs, dtype=torch.float32, device=device)
-                for n in range(3):
-                    w2[n * cs : n * cs + C_] = l2.weight.detach()[n * C_ : (n + 1) * C_]
-                    b2[n * cs : n * cs + C_] = l2.bias.detach()[n * C_ : (n + 1) * C_]
-                mod_jobs.append((l0, bld.const(w2), bld.const(b2), abc, 3 * cs))  # batched at the tape front (below)
-                bstride = 3 * cs if rows > 1 else 0
-            else:
-                abc = torch.zeros(3 * cs, dtype=torch.float32, device=device)
-                for n in range(3):
-                    abc[n * cs : n * cs + C_] = blk.ada_zero.detach()[n]
-                abc = bld.const(abc)
-                bstride = 0
-            y = bld.row_norm(x, 1, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
-            msa = blk.msa
-            qkv = bld.conv(y, bld.pack_conv(msa.qkv_proj.weight, msa.qkv_proj.bias), 3 * C_)
-            dim = C_ // msa.heads
-            rope = None
-            if msa.theta_proj is not None:  # theta = theta_proj(pos) on the host (reference op order), tables on device
-                theta = torch.nn.functional.linear(pos.to(torch.float32).cpu(), msa.theta_proj.weight.detach().float().cpu())
-                rope = (bld.const(torch.cos(theta)), bld.const(torch.sin(theta)))
-            att = bld.attention(qkv, msa.heads, "nHC", msa.qk_norm, 1.0 / math.sqrt(dim), rope=rope)
-            bld.free(qkv)
-            y2 = bld.conv(att, bld.pack_conv(msa.y_proj.weight, None), C_, res=y)
-            bld.free(att)
-            bld.free(y)
-            f0, f3 = blk.ffn[0], blk.ffn[3]
-            code = {"silu": 1, "relu": 2, "relu2": 3, "swiglu": 0}[blk.ffn_activation]
-            f1 = bld.conv(y2, bld.pack_conv(f0.weight, f0.bias), f0.out_features, act=code)
-            bld.free(y2)
-            if blk.ffn_activation == "swiglu":  # x1 * silu(x2) over interleaved pairs (layers.py:107-110)
-                glu = bld.new_act(f1.B, f1.H, f1.W, f1.C // 2)
-                bld.tape.add("az_swiglu_f32", glu.ptr, f1.ptr, f1.B * f1.H * f1.W, f1.C // 2, f1.cs, glu.cs)
-                bld.free(f1)
-                f1 = glu
-            out = bld.conv(f1, bld.pack_conv(f3.weight, f3.bias), C_, gate=abc, gate_off=2 * cs, gate_bstride=bstride, res=x)
-            bld.free(f1)
-            bld.free(x)
-            x = out
+            x = blk._emit(bld, x, pos, None, D, mod_rows, mod_jobs)
         o = bld.conv(x, bld.pack_conv(net.out_proj.weight, net.out_proj.bias), cout)
         bld.free(x)
-        if patch is not None:
-            Z, H, W, p = patch
-            Zo = cout // (p * p)
-            self.out = torch.empty(B, Zo, H, W, dtype=torch.float32, device=device)
-            bld.tape.add("az_unpatchify_f32", self.out.data_ptr(), o.ptr, B, Zo, H, W, p, o.cs)
+        if patch is not None:  # '... A B (Z a b) -> ... Z (A a) (B b)' with the UNPATCH size (reference vit.py:63-74,104-106)
+            Z, H, W, p, pu = patch
+            Zo, Ho, Wo = cout // (pu * pu), H // p * pu, W // p * pu
+            self.out = torch.empty(B, Zo, Ho, Wo, dtype=torch.float32, device=device)
+            bld.tape.add("az_unpatchify_f32", self.out.data_ptr(), o.ptr, B, Zo, Ho, Wo, pu, o.cs)
             self.out_tokens = None
         else:
             self.out, self.out_tokens = None, o
         bld.finish()
         self.tape = bld.tape
         if mod_jobs:  # all blocks' modulation MLPs read only `mod`: one GEMV + one grouped GEMV at the front
-            from .._lib import AzLinearGroup
-            from ..engine import Tape
-
-            nj = len(mod_jobs)
-            w0 = bld.const(torch.cat([j[0].weight.detach() for j in mod_jobs]))
-            b0 = bld.const(torch.cat([j[0].bias.detach() for j in mod_jobs]))
-            rows = max(mod_rows, 1)
-            h_all = bld.empty(rows, nj * D)
-            groups = (AzLinearGroup * nj)()
-            for i, (_, w2, b2, abc, n_out) in enumerate(mod_jobs):
-                g = groups[i]
-                g.y, g.x, g.W, g.bias = abc.data_ptr(), h_all.data_ptr() + 4 * i * D, w2.data_ptr(), b2.data_ptr()
-                g.ldy, g.ldx, g.N, g.K = n_out, nj * D, n_out, D
-            gdev = torch.frombuffer(bytearray(bytes(groups)), dtype=torch.uint8).to(device)
-            pre = Tape()
-            # tape order: patchify (if any) stays first -- it does not depend on `mod` either way
-            pre.add("az_linear_small_f32", h_all.data_ptr(), nj * D, self.mod.data_ptr(), D, w0.data_ptr(), b0.data_ptr(),
-                    rows, nj * D, D, 0, 1)
-            pre.add("az_linear_small_grouped_f32", gdev.data_ptr(), nj, max(j[4] for j in mod_jobs), rows, 0, 0,
-                    keep=[gdev, w0, b0, h_all])
+            pre = mod_front_tape(bld, mod_jobs, self.mod, mod_rows, D)
             pre.extend(self.tape)
             self.tape = pre
 
@@ -339,17 +402,16 @@ class ViT(DiT):
             unpatch_size = patch_size
         elif isinstance(unpatch_size, int):
             unpatch_size = [unpatch_size] * spatial
-        if len(set(patch_size)) != 1 or list(unpatch_size) != list(patch_size):
-            raise NotImplementedError("square patches with unpatch_size == patch_size only")
-        if cond_channels:
-            raise NotImplementedError("cond_channels is not implemented on the HIP path")
-        p = patch_size[0]
+        assert len(patch_size) == len(unpatch_size) == spatial
+        if len(set(patch_size)) != 1 or len(set(unpatch_size)) != 1:
+            raise NotImplementedError("square patches only (patch_size / unpatch_size may differ from each other)")
+        p, pu = patch_size[0], unpatch_size[0]
         super().__init__(
-            in_channels=p * p * in_channels, out_channels=p * p * out_channels, cond_channels=0,
+            in_channels=p * p * in_channels, out_channels=pu * pu * out_channels, cond_channels=p * p * cond_channels,
             mod_features=mod_features, pos_channels=spatial, hid_channels=hid_channels, hid_blocks=hid_blocks, **kwargs,
         )
-        self.patch_size = p
-        self.image_in, self.image_out = in_channels, out_channels
+        self.patch_size, self.unpatch_size = p, pu
+        self.image_in, self.image_out, self.image_cond = in_channels, out_channels, cond_channels
         self.spatial = spatial
 
     def _vit_plan(self, B: int, H: int, W: int, rows: int, device) -> DiTPlan:
@@ -359,7 +421,7 @@ class ViT(DiT):
         pos = pos.reshape(-1, 2)
         return self._get_plan(
             ("vit", B, H, W, rows, str(device)),
-            lambda: DiTPlan(self, B, Hp * Wp, pos, rows, device, patch=(self.image_in, H, W, p)),
+            lambda: DiTPlan(self, B, Hp * Wp, pos, rows, device, patch=(self.image_in + self.image_cond, H, W, p, self.unpatch_size)),
         )
 
     @torch.no_grad()
@@ -367,12 +429,16 @@ class ViT(DiT):
     def forward(self, x: Tensor, mod: Tensor | None = None, cond: Tensor | None = None) -> Tensor:
         r"""x: (B, C_i, H, W); mod: (D) or (B, D) -> (B, C_o, H, W)."""
         out_dtype = self._check_device(x)
-        assert cond is None, "cond is not implemented on the HIP path"
         B, Z, H, W = x.shape
         assert Z == self.image_in and H % self.patch_size == 0 and W % self.patch_size == 0
+        assert (cond is not None) == (self.image_cond > 0), "pass cond iff the network was built with cond_channels"
         rows = self._mod_rows(mod, B)
         plan = self._vit_plan(B, H, W, rows, x.device)
-        plan.x_nchw.copy_(x)
+        # patchify(x) || patchify(cond) along the token features == patchify of the channel concatenation: the
+        # feature index is (channel, a, b) with the channel slowest (reference vit.py:92-96, layers.py:198-222)
+        plan.x_nchw[:, :Z].copy_(x)
+        if cond is not None:
+            plan.x_nchw[:, Z:].copy_(cond)
         if rows:
             plan.mod.copy_(mod.to(torch.float32).reshape(rows, -1))
         plan.tape.run()
@@ -383,8 +449,8 @@ class ViT(DiT):
         from ..sample import BackboneProgram
         from .unet import _copy_tape
 
-        if self.mod_features == 0 or x.ndim != 4:
-            return None
+        if self.mod_features == 0 or x.ndim != 4 or self.image_cond or self.unpatch_size != self.patch_size:
+            return None  # cond / a different output geometry: the generic step loop (eager forward per step)
         self._check_device(x)
         B, _, H, W = x.shape
         plan = self._vit_plan(B, H, W, mod_rows, x.device)

@@ -257,6 +257,8 @@ typedef struct AzConvArgs {
   int32_t dst_c;
   int32_t splitk;          /* >= 1; > 1 needs workspace of splitk * B*hout*wout * cout_s floats */
   float* workspace;
+  int32_t pad_mode;        /* 0: zero padding; 1: circular ("periodic", azula/nn/unet.py:175-180): taps wrap around the map */
+  int32_t reserved_;
 } AzConvArgs;
 /* Narrow outputs (cout_s == 4, 3x3 stride 1 pad 1, one un-upsampled source with c0s % 16 == 0: the image head of
  * azula/nn/unet.py) run a VALU kernel instead of the 128-cout MFMA tile; splitk is ignored there.              */
@@ -325,6 +327,12 @@ typedef struct AzAttnArgs {
    * before the rotation (plugins/jit/_src/model.py:108-109,129-133).  NULL = no gain.          */
   const float* q_weight;
   const float* k_weight;
+  /* optional boolean attention mask (azula/nn/attention.py:72-104 -> scaled_dot_product_attention(attn_mask=mask)):
+   * one byte per (query, key) pair, non-zero = the query may attend to the key; laid out (tokens, tokens) with a batch
+   * and a head stride in bytes (0 = shared by all samples / heads).  A query whose keys are all masked yields NaN, as
+   * in the reference.  NULL = no mask.                                                                            */
+  const uint8_t* mask;
+  int64_t mask_bstride, mask_hstride;
 } AzAttnArgs;
 int az_attention_f32(const AzAttnArgs* args, az_stream_t stream);
 /* The same operation for backbones cast to half precision: q / k / v / out stay fp32 tensors, norms, gains, RoPE and the

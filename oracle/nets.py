@@ -22,7 +22,10 @@ def _linear(sd, key: str, x: Tensor) -> Tensor:
     return F.linear(x, sd[key + ".weight"], sd.get(key + ".bias"))
 
 
-def _conv(sd, key: str, x: Tensor, stride: int = 1, padding: int = 1) -> Tensor:
+def _conv(sd, key: str, x: Tensor, stride: int = 1, padding: int = 1, periodic: bool = False) -> Tensor:
+    if periodic and padding:  # torch.nn.Conv2d(padding_mode="circular"): F.pad(mode="circular") then an unpadded conv
+        x = F.pad(x, (padding,) * 4, mode="circular")
+        padding = 0
     return F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=stride, padding=padding)
 
 
@@ -57,8 +60,8 @@ def _ada_zero(sd, key: str, mod: Tensor | None, channels: int, trailing: tuple[i
 
 
 # --------------------------------------------------------------------------- azula.nn.unet
-def unet_block(sd, key: str, x: Tensor, mod, norm: str, groups: int) -> Tensor:
-    r"""UNetBlock._forward -- azula/nn/unet.py:85-95."""
+def unet_block(sd, key: str, x: Tensor, mod, norm: str, groups: int, periodic: bool = False) -> Tensor:
+    r"""UNetBlock._forward -- azula/nn/unet.py:85-95 (``periodic``: circular padding, unet.py:175-180)."""
     C = x.shape[1]
     a, b, c = _ada_zero(sd, key + ".ada_zero", mod, C, (C, 1, 1))
     if norm == "group":
@@ -70,9 +73,9 @@ def unet_block(sd, key: str, x: Tensor, mod, norm: str, groups: int) -> Tensor:
     else:
         raise NotImplementedError(norm)
     y = (a + 1) * n + b
-    y = _conv(sd, key + ".ffn.0", y)
+    y = _conv(sd, key + ".ffn.0", y, periodic=periodic)
     y = F.silu(y)
-    y = _conv(sd, key + ".ffn.3", y)
+    y = _conv(sd, key + ".ffn.3", y, periodic=periodic)
     return x + c * y
 
 
@@ -83,28 +86,29 @@ def unet_forward(sd, cfg: dict, x: Tensor, mod: Tensor | None = None, tap: dict 
     """
     hid_blocks = list(cfg["hid_blocks"])
     norm, groups = cfg.get("norm", "layer"), cfg.get("groups", 16)
+    per = cfg.get("periodic", False)
     L = len(hid_blocks)
     memory = []
     for i in range(L):
         memory.append(x if memory else None)
-        x = _conv(sd, f"descent.{i}.0", x, stride=2 if i > 0 else 1)
+        x = _conv(sd, f"descent.{i}.0", x, stride=2 if i > 0 else 1, periodic=per)
         for j in range(hid_blocks[i]):
-            x = unet_block(sd, f"descent.{i}.{1 + j}", x, mod, norm, groups)
+            x = unet_block(sd, f"descent.{i}.{1 + j}", x, mod, norm, groups, per)
         if tap is not None:
             tap[f"descent.{i}"] = x
     for k in range(L):
         i = L - 1 - k  # ascent[0] is the deepest level
         idx = 0
         if i + 1 < L:
-            x = _conv(sd, f"ascent.{k}.0", x)
+            x = _conv(sd, f"ascent.{k}.0", x, periodic=per)
             idx = 1
         for j in range(hid_blocks[i]):
-            x = unet_block(sd, f"ascent.{k}.{idx + j}", x, mod, norm, groups)
+            x = unet_block(sd, f"ascent.{k}.{idx + j}", x, mod, norm, groups, per)
         idx += hid_blocks[i]
         if i > 0:
             x = F.interpolate(x, scale_factor=(2.0, 2.0), mode="nearest")
         else:
-            x = _conv(sd, f"ascent.{k}.{idx}", x)
+            x = _conv(sd, f"ascent.{k}.{idx}", x, periodic=per)
         if tap is not None:
             tap[f"ascent.{k}"] = x
         y = memory.pop()
@@ -140,8 +144,10 @@ def apply_rope(q: Tensor, k: Tensor, theta: Tensor):
     return rot(q), rot(k)
 
 
-def msa_forward(sd, key: str, x: Tensor, heads: int, qk_norm: bool = True, pos: Tensor | None = None) -> Tensor:
-    r"""MultiheadSelfAttention.forward -- azula/nn/attention.py:89-108 (RoPE iff ``theta_proj`` exists)."""
+def msa_forward(sd, key: str, x: Tensor, heads: int, qk_norm: bool = True, pos: Tensor | None = None,
+                mask: Tensor | None = None) -> Tensor:
+    r"""MultiheadSelfAttention.forward -- azula/nn/attention.py:89-108 (RoPE iff ``theta_proj`` exists; ``mask`` is
+    handed to scaled_dot_product_attention as ``attn_mask``)."""
     qkv = _linear(sd, key + ".qkv_proj", x)  # (..., L, (n H C))
     *lead, L, _ = qkv.shape
     qkv = qkv.reshape(*lead, L, 3, heads, -1)
@@ -154,17 +160,17 @@ def msa_forward(sd, key: str, x: Tensor, heads: int, qk_norm: bool = True, pos: 
         theta = F.linear(pos, sd[key + ".theta_proj.weight"])  # ... L (H C)
         theta = theta.unflatten(-1, (heads, -1)).transpose(-2, -3)  # ... H L C
         q, k = apply_rope(q, k, theta)
-    y = F.scaled_dot_product_attention(query=q, key=k, value=v)
+    y = F.scaled_dot_product_attention(query=q, key=k, value=v, attn_mask=mask)
     y = y.transpose(-2, -3).flatten(-2)  # ... L (H C)
     return F.linear(y, sd[key + ".y_proj.weight"])
 
 
-def dit_block(sd, key: str, x: Tensor, mod, heads: int, pos=None, act: str = "silu", qk_norm: bool = True) -> Tensor:
+def dit_block(sd, key: str, x: Tensor, mod, heads: int, pos=None, act: str = "silu", qk_norm: bool = True, mask=None) -> Tensor:
     r"""DiTBlock._forward -- azula/nn/dit.py:95-112 (FFN activations: dit.py:74-85, layers.py:71-110)."""
     C = x.shape[-1]
     a, b, c = _ada_zero(sd, key + ".ada_zero", mod, C, (1, C))
     y = (a + 1) * F.rms_norm(x, (C,), eps=1e-5) + b
-    y = y + msa_forward(sd, key + ".msa", y, heads, qk_norm=qk_norm, pos=pos)
+    y = y + msa_forward(sd, key + ".msa", y, heads, qk_norm=qk_norm, pos=pos, mask=mask)
     y = _linear(sd, key + ".ffn.0", y)
     if act == "silu":
         y = F.silu(y)
@@ -194,19 +200,29 @@ def dit_forward(sd, cfg: dict, x: Tensor, mod=None, pos: Tensor | None = None, t
     return _linear(sd, "out_proj", x)
 
 
-def vit_forward(sd, cfg: dict, x: Tensor, mod=None, tap=None) -> Tensor:
-    r"""ViT.forward -- azula/nn/vit.py:76-108 (Patchify/Unpatchify channel_last,
-    azula/nn/layers.py:198-247).  cfg adds patch_size (int)."""
-    p = cfg["patch_size"]
+def _patchify(x: Tensor, p: int) -> Tensor:
+    r"""'... Z (A a) (B b) -> ... A B (Z a b)' -- azula/nn/layers.py:198-222 (channel_last)."""
     B, Z, H, W = x.shape
-    # '... Z (A a) (B b) -> ... A B (Z a b)'
-    t = x.reshape(B, Z, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, H // p, W // p, Z * p * p)
+    return x.reshape(B, Z, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, H // p, W // p, Z * p * p)
+
+
+def vit_forward(sd, cfg: dict, x: Tensor, mod=None, tap=None, cond: Tensor | None = None) -> Tensor:
+    r"""ViT.forward -- azula/nn/vit.py:76-108 (Patchify/Unpatchify channel_last,
+    azula/nn/layers.py:198-247).  cfg adds patch_size (int), optionally unpatch_size (int); ``cond`` is patchified
+    like ``x`` and concatenated along the token features (vit.py:92-96, dit.py:202-203)."""
+    p = cfg["patch_size"]
+    pu = cfg.get("unpatch_size") or p
+    B, Z, H, W = x.shape
+    t = _patchify(x, p)
     shape = t.shape[1:-1]
     pos = torch.cartesian_prod(*(torch.arange(s, dtype=x.dtype) for s in shape)).reshape(-1, len(shape))
-    y = dit_forward(sd, cfg, t.flatten(1, -2), mod, pos=pos, tap=tap)
+    t = t.flatten(1, -2)
+    if cond is not None:
+        t = torch.cat((t, _patchify(cond, p).flatten(1, -2)), dim=-1)
+    y = dit_forward(sd, cfg, t, mod, pos=pos, tap=tap)
     y = y.unflatten(-2, shape)
-    Zo = y.shape[-1] // (p * p)
-    return y.reshape(B, H // p, W // p, Zo, p, p).permute(0, 3, 1, 4, 2, 5).reshape(B, Zo, H, W)
+    Zo = y.shape[-1] // (pu * pu)
+    return y.reshape(B, H // p, W // p, Zo, pu, pu).permute(0, 3, 1, 4, 2, 5).reshape(B, Zo, H // p * pu, W // p * pu)
 
 
 def time_wrapped_vit(sd, cfg: dict, x: Tensor, c_time: Tensor, **_) -> Tensor:

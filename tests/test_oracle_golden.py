@@ -185,3 +185,29 @@ def test_g10_jit(golden):
         cm = lambda a, tt: sampling.cfg_mean(mean, a, tt, {"label": y}, {}, g.meta["guidance"])  # noqa: E731
         x0 = sampling.sample(cm, g["x1"], schedule=sampling.rectified_schedule, steps=6, eta=0.0)
         assert max_err(x0, g["cfg_ddim6"]) < 2e-4 * max(1.0, g["cfg_ddim6"].abs().max().item()), name
+
+
+def test_g12_blocks_mask_cond_periodic(golden):
+    """Standalone block forwards, the attention mask, ViT cond / unpatch_size and the periodic UNet."""
+    g = golden("g12_blocks_mask_cond_periodic")
+    sh = lambda k: {n: tuple(v) for n, v in g.meta[k].items()}  # noqa: E731
+    mod = g["mod"]
+    msd = {("." + k): v for k, v in synth.synth_state_dict(sh("msa_shapes"), 31).items()}
+    causal, bmask = g["msa_causal"].bool(), g["msa_bmask"].bool()
+    assert max_err(nets.msa_forward(msd, "", g["msa_x"], 4, pos=g["msa_pos"], mask=causal), g["msa_y_causal"]) < 1e-5
+    assert max_err(nets.msa_forward(msd, "", g["msa_x"], 4, pos=g["msa_pos"], mask=bmask), g["msa_y_bmask"]) < 1e-5
+    assert max_err(nets.msa_forward(msd, "", g["msa_x"], 4, pos=g["msa_pos"]), g["msa_y_nomask"]) < 1e-5
+    bsd = {("b." + k): v for k, v in synth.synth_state_dict(sh("dit_shapes"), 32).items()}
+    y = nets.dit_block(bsd, "b", g["msa_x"], g["dit_mod"], 4, pos=g["msa_pos"], act="swiglu", mask=causal)
+    assert max_err(y, g["dit_y"]) < 1e-5
+    usd = {("u." + k): v for k, v in synth.synth_state_dict(sh("ublock_shapes"), 33).items()}
+    assert max_err(nets.unet_block(usd, "u", g["ublock_x"], mod, "group", 4), g["ublock_y"]) < 1e-5
+    vsd = synth.synth_state_dict(sh("vit_shapes"), 35)
+    assert max_err(nets.vit_forward(vsd, g.meta["vit_cfg"], g["vit_x"], mod, cond=g["vit_cond"]), g["vit_y"]) < 1e-5
+    v3 = synth.synth_state_dict(sh("vit3_shapes"), 36)
+    assert max_err(nets.vit_forward(v3, g.meta["vit3_cfg"], g["vit3_x"], mod[0]), g["vit3_y"]) < 1e-5
+    psd = synth.synth_state_dict(sh("punet_shapes"), 37)
+    pcfg = dict(g.meta["punet_cfg"], periodic=True)
+    for name in ("punet_a", "punet_b", "punet_c"):
+        x = g[name + "_x"]
+        assert max_err(nets.unet_forward(psd, pcfg, x, mod[: x.shape[0]]), g[name + "_y"]) < 1e-5
