@@ -22,7 +22,7 @@ def test_standalone_attention_with_masks(golden):
     from azula_amd.nn import MultiheadSelfAttention
 
     g = golden(NAME)
-    msa = MultiheadSelfAttention(32, pos_channels=2, attention_heads=4, rope=True)
+    msa = MultiheadSelfAttention(64, pos_channels=2, attention_heads=4, rope=True)
     msa.load_state_dict(synth.synth_state_dict(shapes(g, "msa_shapes"), 31))
     msa = msa.cuda().eval()
     x, pos = g["msa_x"].cuda(), g["msa_pos"].cuda()
@@ -33,7 +33,7 @@ def test_standalone_attention_with_masks(golden):
         assert y.shape == x.shape and err < 2e-5 * max(1.0, g["msa_y_" + tag].abs().max().item())
     # leading dims other than one batch axis: (2, 1, L, C)
     y4 = msa(x[:, None], pos, g["msa_causal"].bool().cuda())
-    assert y4.shape == (2, 1, 9, 32) and max_err(y4[:, 0], g["msa_y_causal"]) < 2e-5
+    assert y4.shape == (2, 1, 9, 64) and max_err(y4[:, 0], g["msa_y_causal"]) < 2e-5
     # a fully masked query row is NaN, as in the reference's softmax over -inf
     dead = g["msa_causal"].bool().clone()
     dead[3] = False
@@ -45,7 +45,7 @@ def test_attention_mask_through_the_half_precision_kernel(golden):
     from azula_amd.nn import MultiheadSelfAttention
 
     g = golden(NAME)
-    msa = MultiheadSelfAttention(32, pos_channels=2, attention_heads=4, rope=True)
+    msa = MultiheadSelfAttention(64, pos_channels=2, attention_heads=4, rope=True)
     msa.load_state_dict(synth.synth_state_dict(shapes(g, "msa_shapes"), 31))
     msa = msa.cuda().eval().bfloat16()
     y = msa(g["msa_x"].cuda(), g["msa_pos"].cuda(), g["msa_causal"].bool().cuda())
@@ -57,7 +57,7 @@ def test_standalone_dit_block(golden):
     from azula_amd.nn import DiTBlock
 
     g = golden(NAME)
-    blk = DiTBlock(32, mod_features=16, pos_channels=2, attention_heads=4, rope=True, ffn_activation="swiglu")
+    blk = DiTBlock(64, mod_features=16, pos_channels=2, attention_heads=4, rope=True, ffn_activation="swiglu")
     blk.load_state_dict(synth.synth_state_dict(shapes(g, "dit_shapes"), 32))
     blk = blk.cuda().eval()
     x, pos, mask, mod = g["msa_x"].cuda(), g["msa_pos"].cuda(), g["msa_causal"].bool().cuda(), g["dit_mod"].cuda()
