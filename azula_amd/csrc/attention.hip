@@ -229,11 +229,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
           if (k0 + sub * 32 + key_of(r, h2) >= T) sacc[r] = -INFINITY;
       }
       if (mrow != nullptr) {  // boolean attention mask: one byte per (query, key)
+        unsigned char mb[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = k0 + sub * 32 + key_of(r, h2);
-          if (key < T && mrow[key] == 0) sacc[r] = -INFINITY;
+          mb[r] = key < T ? mrow[key] : (unsigned char)1;
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = mb[r] == 0 ? -INFINITY : sacc[r];
       }
       float mt = sacc[0];
 #pragma unroll
@@ -489,13 +492,24 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
       const H1* kr = Ks + (sub * 32 + ql) * KLS + 8 * h2;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) sacc = mfma_half<F16>(*reinterpret_cast<const H8*>(kr + 16 * ks), qf[ks], sacc);
-      float mt = -INFINITY;
+      if (k0 + sub * 32 + 32 > T) {  // ragged last tile (wave-uniform): keys past T
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + sub * 32 + key_of(r, h2);
-        if (key >= T || (mrow != nullptr && mrow[key] == 0)) sacc[r] = -INFINITY;
-        mt = fmaxf(mt, sacc[r]);
+        for (int r = 0; r < 16; ++r)
+          if (k0 + sub * 32 + key_of(r, h2) >= T) sacc[r] = -INFINITY;
       }
+      if (mrow != nullptr) {  // boolean attention mask: one byte per (query, key)
+        unsigned char mb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + sub * 32 + key_of(r, h2);
+          mb[r] = key < T ? mrow[key] : (unsigned char)1;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = mb[r] == 0 ? -INFINITY : sacc[r];
+      }
+      float mt = sacc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sacc[r]);
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
       const float m_new = fmaxf(m_run, mt);
       const float alpha = m_run == -INFINITY ? 0.f : exp2f((m_run - m_new) * LOG2E);

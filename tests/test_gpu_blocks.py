@@ -67,7 +67,7 @@ def test_standalone_dit_block(golden):
     assert max_err(y, g["dit_y"]) < 2e-5 * sc
     assert max_err(blk(x, mod[0], pos, mask), g["dit_y_mod1"]) < 2e-5 * sc  # mod of shape (D)
     assert torch.equal(blk(x, mod, pos, mask), y)  # the cached one-block plan replays deterministically
-    blk.ffn[3].weight.data.mul_(2.0)  # parameter update: the plan is rebuilt
+    blk.ffn[3].weight.mul_(2.0)  # parameter update (version counter bumps): the plan is rebuilt
     assert not torch.equal(blk(x, mod, pos, mask), y)
 
 
