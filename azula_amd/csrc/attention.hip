@@ -685,7 +685,8 @@ int az_attention_f16_f32(const AzAttnArgs* a, az_stream_t stream) { return atten
 int az_attention_f32(const AzAttnArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->q && a->k && a->v && a->out, AZ_E_NULL);
   AZ_REQUIRE(a->batch > 0 && a->heads > 0 && a->tokens > 0, AZ_E_SHAPE);
-  AZ_REQUIRE(a->head_dim == 16 || a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 80 || a->head_dim == 128,
+  AZ_REQUIRE(a->head_dim == 8 || a->head_dim == 16 || a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 80 ||
+                 a->head_dim == 128,
              AZ_E_UNSUPPORTED);
   AZ_REQUIRE(AZ_ALIGNED16(a->q) && AZ_ALIGNED16(a->k) && AZ_ALIGNED16(a->v) && AZ_ALIGNED16(a->out), AZ_E_ALIGN);
   const int64_t strides[] = {a->q_bstride, a->q_tstride, a->q_hstride, a->k_bstride, a->k_tstride, a->k_hstride,
@@ -694,6 +695,7 @@ int az_attention_f32(const AzAttnArgs* a, az_stream_t stream) {
   dim3 grid((unsigned)((a->tokens + QT - 1) / QT), (unsigned)(a->batch * a->heads));
   hipStream_t st = az_s(stream);
   switch (a->head_dim) {
+    case 8: hipLaunchKernelGGL(attention_kernel<8>, grid, dim3(256), 0, st, *a); break;
     case 16: hipLaunchKernelGGL(attention_kernel<16>, grid, dim3(256), 0, st, *a); break;
     case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, st, *a); break;
     case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, st, *a); break;

@@ -304,7 +304,7 @@ int az_pack_conv_weight_f32(float* dst, const float* src, int32_t cout, int32_t 
  *   plugins/adm/_src/unet.py:338-345  legacy '(H 3 C)' order, scale = C^-1/4 on q and k (pass C^-1/2),
  *   plugins/adm/_src/unet.py:371-379  new '(3 H C)' order,
  *   plugins/jit/_src/model.py:121-142  '(3 H C)' + weighted q/k RMSNorm + 2-D rotary + SDPA.
- * head_dim in {16, 32, 64, 80, 128} (80 = JiT-H); all strides multiples of 4 floats.                               */
+ * head_dim in {8 (fp32 only), 16, 32, 64, 80, 128} (80 = JiT-H); all strides multiples of 4 floats.                 */
 typedef struct AzAttnArgs {
   const float* q;
   const float* k;
