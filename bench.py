@@ -513,7 +513,11 @@ def roofline_report(sampler, device, args, world) -> dict:
             if m:
                 t["traffic"] = round(m["traffic_bytes"])
                 t["traffic_over_algorithmic"] = round(m["traffic_over_algorithmic"], 4)
-    graph_kernel = "image_ddpm" if getattr(sampler, "_needs_noise", lambda: False)() else "image_ddim"
+    loop = next(iter(sampler._fused_cache.values()))
+    if loop.fused.programs[0].x_in_cs > 0:  # NHWC backbone input (UNet / ADM): the image form
+        graph_kernel = "image_ddpm" if sampler._needs_noise() else "image_ddim"
+    else:  # flat latents (ViT / JiT)
+        graph_kernel = "flat_ddim_xin"
     head = dict(trans[graph_kernel])
     head["variants"] = trans
     head["which"] = (f"{graph_kernel}: the form this config's captured loop launches, measured at {head['elements']} elements "

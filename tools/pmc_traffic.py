@@ -83,6 +83,11 @@ def transition_cases(device):
                         coef=row.data_ptr())
     cases.append(("flat_ddim", "transition_flat_kernel<false, false, false, false>", a, 12 * n,
                   "read x_t, F; write x_s: 12 B/element"))
+    # ViT / JiT latents: every tensor flat, the pre-scaled backbone input is a second flat output
+    a = transition_args(x_t=x.data_ptr(), F=F3.data_ptr(), x_s=x.data_ptr(), xin_next=xs.data_ptr(), batch=1, channels=1, inner=n,
+                        f_channels=1, coef=row.data_ptr())
+    cases.append(("flat_ddim_xin", "transition_flat_kernel<false, false, true, false>", a, 16 * n,
+                  "read x_t, F; write x_s, c_in' x_s: 16 B/element"))
     return cases, (row, x, F3, F6, eps, xin, xs)
 
 
@@ -148,6 +153,10 @@ def workload(args) -> None:
     # ---- 3. eager backbone forwards of the bench configuration
     if args.forwards > 0:
         loop, cfg = build_loop(args.config, dev)
+        # marker dispatch: everything after the SECOND calib_write_kernel launch belongs to the timed forwards (plan
+        # building launches weight-packing kernels and, for the ViT, one GEMM of its own)
+        mark = torch.zeros(4, device=dev)
+        _lib.call("az_calib_write_f32", mark.data_ptr(), 16, 0.0, stream)
         for _ in range(args.forwards):
             loop.counter.zero_()
             loop.tape.run(stream)
@@ -219,8 +228,7 @@ def collect(args) -> dict:
     for (label, width, group, rowb), v in zip(CALIB_READS, reads):
         calib[label] = {"true_bytes": CALIB_BYTES, "fetch_size_raw_bytes": v * KB, "factor": CALIB_BYTES / (v * KB),
                         "width": width, "group_bytes": group, "row_bytes": rowb}
-    wr = by_kernel("WRITE_SIZE", "calib_write_kernel")
-    assert len(wr) == 1
+    wr = by_kernel("WRITE_SIZE", "calib_write_kernel")[:1]  # (a second, 16-byte launch marks the start of the forwards)
     calib["write16_stream"] = {"true_bytes": CALIB_BYTES, "write_size_raw_bytes": wr[0] * KB, "factor": CALIB_BYTES / (wr[0] * KB)}
     # reads made by the write kernel / writes made by the read kernels (sanity: ~0)
     calib["write16_stream"]["fetch_size_raw_bytes"] = by_kernel("FETCH_SIZE", "calib_write_kernel")[0] * KB
@@ -242,16 +250,25 @@ def collect(args) -> dict:
             "note": t["note"], "fetch_size_raw_bytes": fb, "write_size_raw_bytes": wb, "traffic_bytes": traffic,
             "traffic_over_algorithmic": traffic / t["algorithmic_bytes"],
         }
-    # ---- backbone forward
+    # ---- backbone forward: the dispatches after the marker (second calib_write_kernel launch)
     if manifest["forwards"] > 0:
-        names = sorted({k for _, k, _ in per["FETCH_SIZE"]})
+        def after_marker(counter):
+            rows, seen = per[counter], 0
+            for i, (_, k, _) in enumerate(rows):
+                if "calib_write_kernel" in k:
+                    seen += 1
+                    if seen == 2:
+                        return rows[i + 1:]
+            raise RuntimeError("marker dispatch not found")
+
+        tail = {c: after_marker(c) for c in ("FETCH_SIZE", "WRITE_SIZE")}
+        names = sorted({k for _, k, _ in tail["FETCH_SIZE"]})
         fwd = {}
         for name in names:
-            if any(w in name for w in ("calib_", "transition_", "filter_kernel", "pack_", "at::native", "step_begin")):
-                continue  # calibration / part 2 / one-off weight packing / torch fills
-            fe, wv = by_kernel("FETCH_SIZE", name), by_kernel("WRITE_SIZE", name)
-            if not fe or len(fe) % manifest["forwards"]:
-                continue  # one-off kernels (weight packing, torch fills)
+            fe = [v for _, k, v in tail["FETCH_SIZE"] if k == name]
+            wv = [v for _, k, v in tail["WRITE_SIZE"] if k == name]
+            if not fe or len(fe) % manifest["forwards"] or len(fe) != len(wv):
+                continue
             gather = "winograd" in name
             fr = f8g if gather else f16
             fwd[name] = {
