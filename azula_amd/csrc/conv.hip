@@ -257,8 +257,69 @@ __device__ __forceinline__ void store_acc_tiles(const ConvP& p, const f32x16 (&a
   }
 }
 
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * TILE_F];
+// The same exchange in two halves of 64 pixels (34 KB instead of 68 KB of LDS), for the K-tile-16 instantiation whose
+// operand stages are too small for the whole 128 x 128 tile: the waves of pixel half `hh` park their accumulators,
+// all four waves store.  (NCHW destinations take the direct path of store_acc_tiles: no LDS.)
+constexpr int OBUF_HALF_F = 64 * OSTR + 64;
+__device__ __forceinline__ void store_acc_tiles_halves(const ConvP& p, const f32x16 (&acc)[2][2], int m0, int n0, int wc, int wp,
+                                                        int lane, float* obuf) {
+  const AzConvArgs& a = p.a;
+  if (a.dst_nchw && a.splitk == 1) {
+    store_acc_tiles(p, acc, m0, n0, wc, wp, lane, obuf);
+    return;
+  }
+  const int tid = threadIdx.x;
+  const int cq = tid & (BM / 4 - 1);
+  const int co = m0 + cq * 4;
+  int* pimg = reinterpret_cast<int*>(obuf + 64 * OSTR);
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    if (wp == hh) {
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        float* orow = obuf + (pt * 32 + (lane & 31)) * OSTR + wc * 64 + 4 * (lane >> 5);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(orow + ct * 32 + 8 * q) =
+                make_float4(acc[ct][pt][4 * q + 0], acc[ct][pt][4 * q + 1], acc[ct][pt][4 * q + 2], acc[ct][pt][4 * q + 3]);
+      }
+    }
+    if (tid < 64) {
+      const int n = n0 + hh * 64 + tid;
+      pimg[tid] = n < p.npix ? n / (a.hout * a.wout) : -1;
+    }
+    __syncthreads();
+    if (co < a.cout_s) {
+      constexpr int NB = 64 * (BM / 4) / 256;  // 8 outputs per thread
+      int n[NB], b[NB];
+      float4 v[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int px = (i * 256 + tid) / (BM / 4);
+        b[i] = pimg[px];
+        n[i] = b[i] >= 0 ? n0 + hh * 64 + px : -1;
+        v[i] = *reinterpret_cast<const float4*>(obuf + px * OSTR + cq * 4);
+      }
+      epilogue_store_batch<NB>(a, n, b, co, v, (int64_t)blockIdx.y * p.npix);
+    }
+    __syncthreads();
+  }
+}
+
+// KT = K tile (channels of one tap per stage).  32: 73.7 KB of LDS, two workgroups per CU.  16: 41 KB, THREE per CU --
+// chosen by the host when the tile count quantises badly over 2 x 256 slots (e.g. the 16384 x 768 -> 768 token GEMM:
+// 768 tiles = 3 per CU, i.e. a third of the time one lone workgroup per CU, which cannot keep the matrix pipe full).
+template <int KT>
+__global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP p) {
+  constexpr int LS = KT + 4;                // padded LDS row stride (floats): conflict-free ds_read_b128 fragments
+  constexpr int TF = (BM + BN) * LS;        // floats per stage
+  constexpr int CPR = KT / 4;               // 16-byte chunks per row
+  constexpr int RPP = 256 / CPR;            // rows per loader pass
+  constexpr int NP = 128 / RPP;             // loader passes (per operand)
+  constexpr int SMEM_F = 2 * TF > (KT == 32 ? BN * OSTR + BN : OBUF_HALF_F) ? 2 * TF : (KT == 32 ? BN * OSTR + BN : OBUF_HALF_F);
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
   const AzConvArgs& a = p.a;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -281,8 +342,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   const int kt_end = min(p.nk, kt_begin + p.kps);
 
   // ---- loader coordinates: thread -> (16-B chunk cc along k, rows r0 + 32*i)
-  const int cc = tid & 7;
-  const int r0 = tid >> 3;
+  const int cc = tid % CPR;
+  const int r0 = tid / CPR;
   const int hw_out = a.hout * a.wout;
   const int b_first = n0 / hw_out;  // wave-uniform: offsets are relative to this sample
 
@@ -299,13 +360,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
       a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u, 0x00020000);
 
   // Per-thread constants: weight-row byte offsets, pixel coordinates.
-  unsigned voffW[4];
-  int prel[4], ihb[4], iwb[4];
+  unsigned voffW[NP];
+  int prel[NP], ihb[NP], iwb[NP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int co = m0 + r0 + 32 * i;
+  for (int i = 0; i < NP; ++i) {
+    const int co = m0 + r0 + RPP * i;
     voffW[i] = co < a.cout_s ? (unsigned)((co * p.cin_s + cc * 4) * 4) : OOB;
-    const int n = n0 + r0 + 32 * i;
+    const int n = n0 + r0 + RPP * i;
     const bool pv = n < p.npix;
     const int nn = pv ? n : 0;
     const int b = nn / hw_out;
@@ -324,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   int it_r = kt_begin - it_tap * nk_tap;
   int it_src = it_r >= p.nkc0 ? 1 : 0;
   int it_kc = it_src ? it_r - p.nkc0 : it_r;
-  unsigned voffA[4];
+  unsigned voffA[NP];
 
   auto set_tap_src = [&]() {
     const int ky = it_tap / a.ksize;
@@ -334,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     const int hs = it_src ? a.h1 : a.h0;
     const int ws = it_src ? a.w1 : a.w0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NP; ++i) {
       const int ih = wrap_coord(ihb[i] + ky, a.hin, a.pad_mode);
       const int iw = wrap_coord(iwb[i] + kx, a.win, a.pad_mode);
       const bool ok = prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
@@ -343,23 +404,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     }
   };
 
-  float4 ra[4], rb[4];
+  float4 ra[NP], rb[NP];
 
   auto load_tile = [&]() {
     const int cs = it_src ? a.c1s : a.c0s;
-    const int kbase = it_kc * BK;                        // channel offset inside the source
+    const int kbase = it_kc * KT;                        // channel offset inside the source
     const int kglob = (it_src ? a.c0s : 0) + kbase;      // channel offset in the packed weights
     const unsigned soffW = (unsigned)(((int64_t)it_tap * a.cout_s * p.cin_s + kglob) * 4);
     const unsigned soffA = (unsigned)(kbase * 4);
     const bool kv = kbase + cc * 4 < cs;  // channel tail of this source (lane-dependent only there)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = buf_ld4(rw, voffW[i], soffW);
+    for (int i = 0; i < NP; ++i) ra[i] = buf_ld4(rw, voffW[i], soffW);
     if (it_src) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rb[i] = buf_ld4(rs1, kv ? voffA[i] : OOB, soffA);
+      for (int i = 0; i < NP; ++i) rb[i] = buf_ld4(rs1, kv ? voffA[i] : OOB, soffA);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rb[i] = buf_ld4(rs0, kv ? voffA[i] : OOB, soffA);
+      for (int i = 0; i < NP; ++i) rb[i] = buf_ld4(rs0, kv ? voffA[i] : OOB, soffA);
     }
   };
 
@@ -377,12 +438,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
   };
 
   auto store_tile = [&](int buf) {
-    float* As = smem + buf * TILE_F;
-    float* Bs = As + BM * LDSS;
+    float* As = smem + buf * TF;
+    float* Bs = As + BM * LS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<float4*>(As + (r0 + 32 * i) * LDSS + cc * 4) = ra[i];
-      *reinterpret_cast<float4*>(Bs + (r0 + 32 * i) * LDSS + cc * 4) = rb[i];
+    for (int i = 0; i < NP; ++i) {
+      *reinterpret_cast<float4*>(As + (r0 + RPP * i) * LS + cc * 4) = ra[i];
+      *reinterpret_cast<float4*>(Bs + (r0 + RPP * i) * LS + cc * 4) = rb[i];
     }
   };
 
@@ -394,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int frag_off = (lane & 31) * LDSS + (lane >> 5) * 4;
+  const int frag_off = (lane & 31) * LS + (lane >> 5) * 4;
 
   if (kt_begin < kt_end) {
     set_tap_src();
@@ -411,14 +472,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
       load_tile();  // global loads in flight under the MFMAs below
     }
 
-    const float* As = smem + buf * TILE_F + (wc * 64) * LDSS + frag_off;
-    const float* Bs = smem + buf * TILE_F + BM * LDSS + (wp * 64) * LDSS + frag_off;
+    const float* As = smem + buf * TF + (wc * 64) * LS + frag_off;
+    const float* Bs = smem + buf * TF + BM * LS + (wp * 64) * LS + frag_off;
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
+    for (int kk = 0; kk < KT / 8; ++kk) {
       const float4 a0 = ld4(As + kk * 8);
-      const float4 a1 = ld4(As + 32 * LDSS + kk * 8);
+      const float4 a1 = ld4(As + 32 * LS + kk * 8);
       const float4 b0 = ld4(Bs + kk * 8);
-      const float4 b1 = ld4(Bs + 32 * LDSS + kk * 8);
+      const float4 b1 = ld4(Bs + 32 * LS + kk * 8);
       const float av0[4] = {a0.x, a0.y, a0.z, a0.w};
       const float av1[4] = {a1.x, a1.y, a1.z, a1.w};
       const float bv0[4] = {b0.x, b0.y, b0.z, b0.w};
@@ -435,7 +496,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     __syncthreads();
   }
 
-  store_acc_tiles(p, acc, m0, n0, wc, wp, lane, smem);
+  if constexpr (KT == 32) store_acc_tiles(p, acc, m0, n0, wc, wp, lane, smem);
+  else store_acc_tiles_halves(p, acc, m0, n0, wc, wp, lane, smem);
 }
 
 // =================================================================================================
@@ -1691,7 +1753,25 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   p.a = *a;
   p.npix = (int)npix64;
   p.cin_s = a->c0s + a->c1s;
-  const int bk = half == 3 ? XBK : (half ? HBK : BK);
+  // fp32 direct kernel: K tile 16 with three workgroups per CU when the workgroup count then fills the chip evenly
+  // (see conv_igemm_kernel); AZ_IGEMM_K16 = 0 / 1 forces the choice (A/B measurements)
+  bool k16 = false;
+  if (!half) {
+    static const char* force = getenv("AZ_IGEMM_K16");
+    int sk = a->splitk;
+    const int64_t nk32 = (int64_t)a->ksize * a->ksize * ((a->c0s + BK - 1) / BK + (a->c1s + BK - 1) / BK);
+    if (sk > nk32) sk = (int)nk32;
+    const int64_t wgs = (int64_t)((a->cout_s + BM - 1) / BM) * ((npix64 + BN - 1) / BN) * sk;
+    const int64_t n = (wgs + 255) / 256;  // workgroups on the fullest CU
+    auto cost = [](int64_t n, int slots) {  // in tile times: a lone workgroup keeps the matrix pipe ~65 % busy
+      const int64_t r = n % slots;
+      return (double)(n - r) + (r == 0 ? 0.0 : (r == 1 ? 1.0 / 0.65 : (double)r));
+    };
+    // measured (C3 token GEMMs): the K-16 instantiation is ~6 % slower per tile, so it must win by more than that
+    k16 = n >= 3 && cost(n, 3) * 1.06 + 0.15 < cost(n, 2);
+    if (force) k16 = force[0] == '1';
+  }
+  const int bk = half == 3 ? XBK : (half ? HBK : (k16 ? 16 : BK));
   p.nkc0 = (a->c0s + bk - 1) / bk;
   p.nkc1 = (a->c1s + bk - 1) / bk;
   p.nk = a->ksize * a->ksize * (p.nkc0 + p.nkc1);
@@ -1733,8 +1813,10 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     hipLaunchKernelGGL(conv_igemm_half_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
   else if (half == 3)
     hipLaunchKernelGGL(conv_igemm_x3_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
+  else if (k16)
+    hipLaunchKernelGGL(conv_igemm_kernel<16>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(conv_igemm_kernel<32>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
   int rc = az_launch_status();
   if (rc != AZ_OK) return rc;
   if (splitk > 1) {
