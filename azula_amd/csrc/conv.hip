@@ -25,8 +25,6 @@
 //
 // This file holds two kernels behind the same AzConvArgs: the direct implicit GEMM below (any
 // ksize / stride, linears) and the fused Winograd F(2x2,3x3) kernel further down (3x3 stride 1).
-#include <type_traits>
-
 #include "common.h"
 
 namespace {
@@ -1360,327 +1358,6 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
 }
 
 // =================================================================================================
-// F(2x2, 3x3) with the input staged through an LDS halo ("halo" form; same arithmetic, filters, fragments, MFMAs,
-// output transform and epilogue as conv_winograd_kernel -- only the way the raw 4x4 patches reach the V-role threads
-// differs).  Why: in conv_winograd_kernel every V-role thread gathers its own patch, 16 x 8-byte buffer loads with 64
-// distinct addresses each; the patches of neighbouring tiles overlap (stride 2, size 4), so a 64-tile block issues
-// 1024 pixel loads per stage for 324 distinct pixels, and the CU's texture addresser, not the matrix pipe, paces the
-// V-role waves (rocprofv3: SQ_VMEM_TA_ADDR_FIFO_FULL 1.7e7; ablation on 4 x 256^2, 256 -> 256: 3 wide loads instead of
-// the 16 gathers 1511 -> 1398 us, the same as no gather at all).  Here a workgroup owns an 8 x 8 block of tiles (16 x 16
-// output pixels of ONE image); per stage the 256 V-role threads load its 18 x 18 x 8-channel input halo ONCE (3 x 16 B
-// per thread, 5x fewer load instructions), park it in LDS two stages ahead, and read their patches from there
-// (16 x ds_read_b64, pixel stride 48 B: conflict-free for the 8 tiles x 4 channel pairs of a half-wave).
-//   iteration s:  raw(s+2): registers -> halo s&1 (loaded in iteration s-1) | patch(s+1): halo -> registers
-//                 raw(s+3): global -> registers (in flight for a whole iteration)
-//                 MFMAs of stage s;  transform patch(s+1) -> V stage (s+1)&1;  one barrier
-// LDS: 2 x 64 KB operand stages + 2 x 15.2 KB halo = 158.4 KB (one workgroup per CU, as before).
-// Used for maps of at least 8 x 8 tiles whose tile grid fills its 8 x 8 blocks to >= 85 %; everything else (small
-// maps, where a tile block spans several images) stays on conv_winograd_kernel.
-constexpr int WH_SIDE = 18;                         // halo side: 2 * 8 + 2 input pixels
-constexpr int WH_PIX = WH_SIDE * WH_SIDE;           // 324
-constexpr int WH_PS = 12;                           // floats per halo pixel (8 used): 48-byte stride
-constexpr int WH_RAW_F = WH_PIX * WH_PS;            // floats per halo buffer
-constexpr int WH_LDS_BYTES = (2 * W_STAGE + 2 * WH_RAW_F) * 4;  // 162,176 B
-static_assert(WH_LDS_BYTES <= 160 * 1024 && WH_LDS_BYTES >= W_LDS_BYTES, "halo kernel LDS budget");
-
-struct WinoHP {
-  AzConvArgs a;
-  int npix;
-  int tiles_h, tiles_w;
-  int tbh, tbw;        // tile blocks (8 x 8 tiles) per image, vertically / horizontally
-  int nkc0, nkc1, nk;  // 8-channel chunks per source, total
-  int kps;             // chunks per split
-  int cblocks;         // ceil(cout_s / WC)
-};
-
-__global__ __launch_bounds__(512, 2) void conv_winograd_halo_kernel(WinoHP p) {
-  extern __shared__ __attribute__((aligned(16))) float wsm[];  // 2 * W_STAGE floats of operand stages, then 2 halo buffers
-  const AzConvArgs& a = p.a;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  // (readfirstlane: the role split below is per WAVE; told so, the compiler emits scalar branches and does not order the
-  //  V-role LDS reads behind the U-role loads that share their registers)
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 8 waves = 2 per SIMD: wave w and w+4 share a SIMD
-  const int fh = wave >> 2;         // which 8 of the 16 frequencies
-  const int wco = (wave >> 1) & 1;  // which 32 of the 64 couts
-  const int wti = wave & 1;         // which 32 of the 64 tiles
-  const int l31 = lane & 31;
-  const int h = lane >> 5;
-  float* const halo = wsm + 2 * W_STAGE;
-
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-  const int tb = wg / p.cblocks;
-  const int cb = wg - tb * p.cblocks;
-  const int tb_img = p.tbh * p.tbw;
-  const int bimg = tb / tb_img;               // the image of this workgroup
-  const int tbr = tb - bimg * tb_img;
-  const int th0 = (tbr / p.tbw) * 8;          // first tile row / column of the block
-  const int tw0 = (tbr - (tbr / p.tbw) * p.tbw) * 8;
-
-  const int kt_begin = blockIdx.y * p.kps;
-  const int kt_end = min(p.nk, kt_begin + p.kps);
-
-  const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
-  const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4); };
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)a.weight, 0, clamp_bytes((int64_t)p.nk * p.cblocks * WU_STAGE), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs0 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(a.src0 + bimg * s0_elems), 0, clamp_bytes(s0_elems), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src1 ? a.src1 + bimg * s1_elems : a.src0), 0, a.src1 ? clamp_bytes(s1_elems) : 0u, 0x00020000);
-
-  // ---- roles.  V role (threads 0..255): halo element e = tid + 256 i (pixel e >> 1, 16-byte half e & 1) for the raw
-  //      loads; tile vj = tid >> 2, channel pair vq = tid & 3 for the patch reads / transform.  U role as before.
-  const bool vrole = wave < 4;
-  const int vj = (tid & 255) >> 2;
-  const int vq = tid & 3;
-  const int ih0 = 2 * th0 - 1, iw0 = 2 * tw0 - 1;
-  unsigned roff[3];
-  int rlds[3];
-  int cur_src = -1;
-  auto set_src = [&](int src) {
-    cur_src = src;
-    const int cs = src ? a.c1s : a.c0s;
-    const int up = src ? a.up1 : a.up0;
-    const int ws = src ? a.w1 : a.w0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int e = (tid & 255) + 256 * i;
-      const int pe = e >> 1, hf = e & 1;
-      const int hy = pe / WH_SIDE, hx = pe - hy * WH_SIDE;
-      const int ih = wrap_coord(ih0 + hy, a.hin, a.pad_mode), iw = wrap_coord(iw0 + hx, a.win, a.pad_mode);
-      const bool ok = vrole && pe < WH_PIX && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
-      const int pix = (ih >> up) * ws + (iw >> up);
-      roff[i] = ok ? (unsigned)((pix * cs + hf * 4) * 4) : OOB;
-      rlds[i] = pe < WH_PIX ? pe * WH_PS + hf * 4 : -1;
-    }
-  };
-
-  f32x16 acc[8];
-#pragma unroll
-  for (int f = 0; f < 8; ++f)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-
-  // The K loop is instantiated once per role and entered through a wave-uniform branch: the two roles then share no
-  // variable across a control-flow join inside the loop (with one loop body and per-role branches the compiler parks the
-  // V role's LDS patch reads in temporaries and waits for ALL outstanding loads before the MFMAs, exposing the global
-  // round trip of the halo loads every stage).
-  auto kloop = [&](auto role) {
-  constexpr bool V = decltype(role)::value;
-  f32x2 rv[16];  // V role: raw 4x4 patch of a channel pair; U role: 8 filter float4 (rv[2i], rv[2i+1])
-  float4 rr[3];  // V role: this thread's pieces of the raw halo of the stage after next
-
-  auto load_raw = [&](int kt) {  // V role: halo of stage kt, global -> registers (kt wave-uniform)
-    const bool src1 = kt >= p.nkc0;
-    if ((src1 ? 1 : 0) != cur_src) set_src(src1 ? 1 : 0);
-    const int kc = src1 ? kt - p.nkc0 : kt;
-    const unsigned soff = (unsigned)(kc * WK * 4);
-    const int cs = src1 ? a.c1s : a.c0s;
-    const bool tail = kc * WK + WK > cs;  // wave-uniform: the second 16-byte half of the chunk lies past the source
-    if (src1) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-        rr[i] = buf_ld4(rs1, (tail && ((tid + 256 * i) & 1)) ? OOB : roff[i], soff);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-        rr[i] = buf_ld4(rs0, (tail && ((tid + 256 * i) & 1)) ? OOB : roff[i], soff);
-    }
-  };
-  auto store_raw = [&](int hb) {  // registers -> halo buffer hb
-    float* hp = halo + hb * WH_RAW_F;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      if (rlds[i] >= 0) *reinterpret_cast<float4*>(hp + rlds[i]) = rr[i];
-  };
-  const int poff = ((2 * (vj >> 3)) * WH_SIDE + 2 * (vj & 7)) * WH_PS + 2 * vq;  // patch origin inside a halo buffer
-  auto read_patch = [&](int hb) {  // halo buffer hb -> rv (16 x 8 bytes)
-    const float* hp = halo + hb * WH_RAW_F + poff;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) rv[r * 4 + c] = *reinterpret_cast<const f32x2*>(hp + (r * WH_SIDE + c) * WH_PS);
-  };
-  auto load_u = [&](int kt) {  // U role: filter chunk of stage kt, global -> registers
-    const unsigned soff = (unsigned)(((int64_t)kt * p.cblocks + cb) * (WU_STAGE * 4));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float4 v = buf_ld4(rw, (unsigned)((tid - 256 + 256 * i) * 16), soff);
-      rv[2 * i] = f32x2{v.x, v.y};
-      rv[2 * i + 1] = f32x2{v.z, v.w};
-    }
-  };
-
-  const int voffL = wswz(vj, vq >> 1) + 2 * (vq & 1);  // + f * WT * WK   (V, frequency f)
-  auto store_stage = [&](int buf) {  // V role: transform rv, write the V stage; U role: copy the filter chunk
-    float* Us = wsm + buf * W_STAGE;
-    float* Vs = Us + WU_STAGE;
-    if constexpr (V) {
-      // in-place V = B^T d B (packed fp32 adds); B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const f32x2 d0 = rv[c], d1 = rv[4 + c], d2 = rv[8 + c], d3 = rv[12 + c];
-        rv[c] = d0 - d2;
-        rv[4 + c] = d1 + d2;
-        rv[8 + c] = d2 - d1;
-        rv[12 + c] = d1 - d3;
-      }
-#pragma unroll
-      for (int xi = 0; xi < 4; ++xi) {
-        const f32x2 u0 = rv[4 * xi], u1 = rv[4 * xi + 1], u2 = rv[4 * xi + 2], u3 = rv[4 * xi + 3];
-        *reinterpret_cast<f32x2*>(Vs + (4 * xi + 0) * WT * WK + voffL) = u0 - u2;
-        *reinterpret_cast<f32x2*>(Vs + (4 * xi + 1) * WT * WK + voffL) = u1 + u2;
-        *reinterpret_cast<f32x2*>(Vs + (4 * xi + 2) * WT * WK + voffL) = u2 - u1;
-        *reinterpret_cast<f32x2*>(Vs + (4 * xi + 3) * WT * WK + voffL) = u1 - u3;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int e = tid - 256 + 256 * i;
-        *reinterpret_cast<float4*>(Us + wswz(e >> 1, e & 1)) = make_float4(rv[2 * i].x, rv[2 * i].y, rv[2 * i + 1].x, rv[2 * i + 1].y);
-      }
-    }
-  };
-
-  // ---- prologue: halos of the first two stages in one global round trip, then stage 0 of U / V
-  if (kt_begin < kt_end) {
-    if constexpr (V) {
-      load_raw(kt_begin);
-      store_raw(0);
-      if (kt_begin + 1 < kt_end) {
-        load_raw(kt_begin + 1);
-        store_raw(1);
-      }
-    } else {
-      load_u(kt_begin);
-      store_stage(0);
-    }
-    __syncthreads();
-    if constexpr (V) {
-      read_patch(0);
-      store_stage(0);
-      if (kt_begin + 2 < kt_end) load_raw(kt_begin + 2);  // stays in registers until the first loop iteration parks it
-    }
-  }
-  __syncthreads();
-
-  const int fragA = (fh * 8) * WC * WK + wswz(wco * 32 + l31, h);  // + f * WC * WK
-  const int fragB = (fh * 8) * WT * WK + wswz(wti * 32 + l31, h);  // + f * WT * WK
-  asm volatile(".p2align 6" ::: "memory");  // code placement: see conv_winograd_kernel
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int s = kt - kt_begin;
-    const int buf = s & 1;
-    const bool more = kt + 1 < kt_end;
-    if constexpr (V) {
-      // Order matters to the compiler's waitcnt bookkeeping: (1) park the halo that was loaded a whole iteration ago
-      // (certainly landed: no stall), (2) the patch reads, (3) only then the new global loads -- LDS reads issued behind
-      // outstanding loads would wait for them, a global round trip exposed in front of every stage's MFMAs.
-      if (kt + 2 < kt_end) store_raw(buf);    // raw(kt + 2) -> halo buffer (s + 2) & 1 (its patches were read an iteration ago)
-      if (more) read_patch(buf ^ 1);          // halo of stage kt + 1 (parked one iteration ago, behind a barrier)
-      if (kt + 3 < kt_end) load_raw(kt + 3);  // in flight under this stage's MFMAs and the next one's
-    } else {
-      if (more) load_u(kt + 1);
-    }
-    const float* Us = wsm + buf * W_STAGE;
-    const float* Vs = Us + WU_STAGE;
-    float4 fa[2], fb[2];
-    fa[0] = *reinterpret_cast<const float4*>(Us + fragA);
-    fb[0] = *reinterpret_cast<const float4*>(Vs + fragB);
-#pragma unroll
-    for (int f = 0; f < 8; ++f) {
-      const int cur = f & 1, nxt = cur ^ 1;
-      if (f < 7) {
-        fa[nxt] = *reinterpret_cast<const float4*>(Us + (f + 1) * WC * WK + fragA);
-        fb[nxt] = *reinterpret_cast<const float4*>(Vs + (f + 1) * WT * WK + fragB);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].x, acc[f], 0, 0, 0);
-      acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].y, acc[f], 0, 0, 0);
-      acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].z, fb[cur].z, acc[f], 0, 0, 0);
-      acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].w, fb[cur].w, acc[f], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (more) store_stage(buf ^ 1);
-    __syncthreads();
-  }
-
-  };
-  if (vrole) kloop(std::true_type{});
-  else kloop(std::false_type{});
-
-  // ---- output transform + epilogue: identical to conv_winograd_kernel up to the tile -> pixel map
-  float y[4][4][4];  // [g][pixel py*2+px][r]
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float sxy[2][4];
-#pragma unroll
-      for (int nu = 0; nu < 4; ++nu) {
-        const float ma = acc[nu][4 * g + r], mb = acc[4 + nu][4 * g + r];
-        if (fh == 0) {
-          sxy[0][nu] = ma + mb;
-          sxy[1][nu] = mb;
-        } else {
-          sxy[0][nu] = ma;
-          sxy[1][nu] = -ma - mb;
-        }
-      }
-#pragma unroll
-      for (int py = 0; py < 2; ++py) {
-        y[g][py * 2 + 0][r] = (sxy[py][0] + sxy[py][1]) + sxy[py][2];
-        y[g][py * 2 + 1][r] = (sxy[py][1] - sxy[py][2]) - sxy[py][3];
-      }
-    }
-  float* obuf = wsm + fh * (WT * W_OT);
-  {
-    float* orow = obuf + (wti * 32 + l31) * W_OT + wco * 32 + 4 * h;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int px = 0; px < 4; ++px)
-        *reinterpret_cast<float4*>(orow + px * WC + 8 * g) = make_float4(y[g][px][0], y[g][px][1], y[g][px][2], y[g][px][3]);
-  }
-  int* tinfo = reinterpret_cast<int*>(wsm + 2 * WT * W_OT);
-  if (wave < 2 && h == 0) {
-    const int j = wti * 32 + l31;
-    const int th = th0 + (j >> 3), tw = tw0 + (j & 7);
-    int n00 = -1, fl = 0;
-    if (th < p.tiles_h && tw < p.tiles_w) {
-      n00 = (bimg * a.hout + 2 * th) * a.wout + 2 * tw;
-      fl = (2 * th + 1 < a.hout ? 1 : 0) | (2 * tw + 1 < a.wout ? 2 : 0);
-    }
-    tinfo[j] = n00;
-    tinfo[WT + j] = fl;
-    tinfo[2 * WT + j] = bimg;
-  }
-  __syncthreads();
-  const int cq = tid & 15;
-  const int co = cb * WC + cq * 4;
-  if (co >= a.cout_s) return;
-  int on[8], ob[8];
-  float4 ov[8];
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int row = (it * 512 + tid) >> 4;  // tile * 4 + pixel
-    const int tile = row >> 2, px = row & 3;
-    const int n00 = tinfo[tile], fl = tinfo[WT + tile];
-    ob[it] = tinfo[2 * WT + tile];
-    const bool skip = n00 < 0 || (((px >> 1) & ~fl) | ((px & 1) & ~(fl >> 1)));
-    on[it] = skip ? -1 : n00 + (px >> 1) * a.wout + (px & 1);
-    const float4 v0 = *reinterpret_cast<const float4*>(wsm + tile * W_OT + px * WC + cq * 4);
-    const float4 v1 = *reinterpret_cast<const float4*>(wsm + WT * W_OT + tile * W_OT + px * WC + cq * 4);
-    ov[it] = make_float4(v0.x + v1.x, v0.y + v1.y, v0.z + v1.z, v0.w + v1.w);
-  }
-  epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix);
-}
-
-// =================================================================================================
 // Winograd F(4x4, 3x3): 36 frequency GEMMs per 6x6 input patch / 4x4 output tile, i.e. 2.25 multiplies per
 // output instead of 9 (direct) or 4 (F(2x2,3x3)).  The transforms now contain the constants 2, 4, 5, 8 and
 // the filter transform 1/4 .. 1/24, so this form is NOT exact: its fp32 rounding error is ~20x that of the
@@ -2197,52 +1874,6 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   p.tblocks = (p.ntiles + WT - 1) / WT;
   AZ_REQUIRE((int64_t)p.nk * p.cblocks * WU_STAGE * 4 <= (1ll << 31), AZ_E_SHAPE);
   hipStream_t st = az_s(stream);
-  // Halo form (input staged through LDS once per 8 x 8 tile block): maps of at least 8 x 8 tiles whose tile grid fills
-  // its blocks to >= 85 %.  AZ_WINO_HALO = 0 / 1 forces the choice where legal (A/B measurements).
-  {
-    static const char* force = getenv("AZ_WINO_HALO");
-    const int tbh = (p.tiles_h + 7) / 8, tbw = (p.tiles_w + 7) / 8;
-    const bool legal = p.tiles_h >= 4 && p.tiles_w >= 4 && (int64_t)a->h0 * a->w0 * a->c0s * 4 < (1ll << 31) &&
-                       (int64_t)a->h1 * a->w1 * a->c1s * 4 < (1ll << 31);
-    bool halo = legal && p.tiles_h >= 8 && p.tiles_w >= 8 &&
-                (double)p.tiles_h * p.tiles_w >= 0.85 * (double)(tbh * 8) * (double)(tbw * 8);
-    if (force && legal) halo = force[0] == '1';
-    if (halo) {
-      WinoHP hp;
-      hp.a = p.a;
-      hp.npix = p.npix;
-      hp.tiles_h = p.tiles_h;
-      hp.tiles_w = p.tiles_w;
-      hp.tbh = tbh;
-      hp.tbw = tbw;
-      hp.nkc0 = p.nkc0;
-      hp.nkc1 = p.nkc1;
-      hp.nk = p.nk;
-      hp.kps = p.kps;
-      hp.cblocks = p.cblocks;
-      const int64_t nwg_h = (int64_t)a->batch * tbh * tbw * p.cblocks;
-      AZ_REQUIRE(nwg_h < (1ll << 31), AZ_E_SHAPE);
-      static bool hattr_set = false;
-      if (!hattr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_winograd_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           WH_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        hattr_set = true;
-      }
-      hipLaunchKernelGGL(conv_winograd_halo_kernel, dim3((unsigned)nwg_h, (unsigned)splitk), dim3(512), WH_LDS_BYTES, st, hp);
-      int rc = az_launch_status();
-      if (rc != AZ_OK) return rc;
-      if (splitk > 1) {
-        ConvP cp;
-        cp.a = p.a;
-        cp.npix = p.npix;
-        const int grid = az_stream_grid((int64_t)p.npix * (a->cout_s / 4), 256);
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, cp);
-        rc = az_launch_status();
-      }
-      return rc;
-    }
-  }
   const int64_t nwg = (int64_t)p.cblocks * p.tblocks;
   static bool attr_set = false;
   if (!attr_set) {
