@@ -141,8 +141,13 @@ class ConvWeights:
         w = weight.detach().to(device=bld.device, dtype=torch.float32)
         if w.ndim == 2:
             w = w[:, :, None, None]
-        elif w.ndim == 3:  # Conv1d k=1
+        elif w.ndim == 3 and w.shape[2] == 1:  # Conv1d k=1 (ADM attention projections)
             w = w[:, :, :, None]
+        elif w.ndim == 3:  # Conv1d with k taps on a one-row image: the taps are the middle row of a k x k filter whose
+            k = w.shape[2]  # other rows only ever multiply padding (spatial = 1 UNets, azula/nn/layers.py:25-50)
+            w2 = torch.zeros(w.shape[0], w.shape[1], k, k, dtype=w.dtype, device=w.device)
+            w2[:, :, k // 2, :] = w
+            w = w2
         self.w = w.contiguous()
         self.cout, self.cin, self.ks, kw = self.w.shape
         assert self.ks == kw, "square kernels only"

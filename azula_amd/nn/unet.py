@@ -29,8 +29,11 @@ from .. import _lib
 __all__ = ["UNet", "UNetBlock"]
 
 
-def _conv_holder(cin: int, cout: int, kernel_size, stride=1, identity_init: bool = False) -> nn.Conv2d:
-    conv = nn.Conv2d(cin, cout, kernel_size=kernel_size, stride=stride, padding=tuple(k // 2 for k in kernel_size))
+def _conv_holder(cin: int, cout: int, kernel_size, stride=1, identity_init: bool = False) -> nn.Module:
+    r"""Parameter holder with the reference's shapes: ``Conv2d`` for spatial = 2, ``Conv1d`` for spatial = 1 (``ConvNd``,
+    ``azula/nn/layers.py:25-68``); ``len(kernel_size)`` is the number of spatial dimensions."""
+    Conv = nn.Conv2d if len(kernel_size) == 2 else nn.Conv1d
+    conv = Conv(cin, cout, kernel_size=tuple(kernel_size), stride=stride, padding=tuple(k // 2 for k in kernel_size))
     if identity_init:  # azula/nn/layers.py:53-66: near-identity down/up-sampling convolutions
         center = [k // 2 for k in conv.weight.shape[2:]]
         eye = torch.zeros_like(conv.weight.data[:cin])
@@ -62,11 +65,12 @@ class UNetBlock(nn.Module):
         **kwargs,
     ) -> None:
         super().__init__()
-        if spatial != 2:
-            raise NotImplementedError("azula_amd.nn.UNet implements spatial=2 only")
+        if spatial not in (1, 2):
+            raise NotImplementedError("azula_amd.nn.UNet implements spatial = 1 and 2 (no 3-D convolution kernels)")
         if isinstance(kernel_size, int):  # standalone use passes ConvNd's keyword arguments (reference unet.py:76-83)
             kernel_size = (kernel_size,) * spatial
-        if len(set(kernel_size)) != 1 or kernel_size[0] % 2 == 0 or kwargs.get("stride", 1) not in (1, (1, 1), [1, 1]):
+        kernel_size = tuple(kernel_size)[:spatial] if len(kernel_size) >= spatial else tuple(kernel_size)
+        if len(set(kernel_size)) != 1 or kernel_size[0] % 2 == 0 or kwargs.get("stride", 1) not in (1, (1,), [1], (1, 1), [1, 1]):
             raise NotImplementedError("square odd kernels with stride 1 only")
         pad = kwargs.get("padding", kernel_size[0] // 2)
         if (pad if isinstance(pad, int) else pad[0]) != kernel_size[0] // 2:
@@ -76,7 +80,7 @@ class UNetBlock(nn.Module):
         self.periodic = kwargs.get("padding_mode", "zeros") == "circular"
         if kwargs.get("padding_mode", "zeros") not in ("zeros", "circular"):
             raise NotImplementedError(f"padding_mode {kwargs['padding_mode']!r}: zeros and circular only")
-        self.channels, self.mod_features = channels, mod_features
+        self.channels, self.mod_features, self.spatial = channels, mod_features, spatial
         self.norm_kind, self.groups = norm, min(groups, channels)
         self.ffn_factor = ffn_factor
         if mod_features > 0:
@@ -85,7 +89,7 @@ class UNetBlock(nn.Module):
             )
             self.ada_zero[-2].weight.data.mul_(1e-2)
         else:
-            self.ada_zero = nn.Parameter(torch.randn(3, channels, 1, 1))
+            self.ada_zero = nn.Parameter(torch.randn(3, channels, *(1,) * spatial))
             self.ada_zero.data.mul_(1e-2)
         self.ffn = nn.Sequential(
             _conv_holder(channels, ffn_factor * channels, kernel_size),
@@ -115,13 +119,23 @@ class UNetBlock(nn.Module):
             bld.free(x)
         return y
 
+    def _forward_1d(self, x: Tensor, mod: Tensor | None) -> Tensor:
+        self.spatial = 2
+        try:
+            return self.forward(x[:, :, None], mod)[:, :, 0]
+        finally:
+            self.spatial = 1
+
     @torch.no_grad()
     @_lib.on_device
     def forward(self, x: Tensor, mod: Tensor | None = None) -> Tensor:
-        r"""x: (B, C, H, W); mod: (D) or (B, D) -> (B, C, H, W)   (reference ``azula/nn/unet.py:97-116``)."""
+        r"""x: (B, C, H, W) [(B, C, L) for spatial = 1]; mod: (D) or (B, D) -> like x (reference ``unet.py:97-116``)."""
         from .utils import backbone_io_dtype
 
         out_dtype = backbone_io_dtype(self, x, "azula_amd.nn.UNetBlock")
+        if self.spatial == 1:  # (B, C, L): the same kernels on a one-row image
+            assert x.ndim == 3
+            return self._forward_1d(x, mod)
         assert x.ndim == 4 and x.shape[1] == self.channels
         B, Cc, H, W = x.shape
         D = self.mod_features
@@ -249,12 +263,14 @@ class UNet(nn.Module):
     ) -> None:
         super().__init__()
         assert len(hid_blocks) == len(hid_channels)
-        if spatial != 2:
-            raise NotImplementedError("azula_amd.nn.UNet implements spatial=2 only")
+        if spatial not in (1, 2):
+            raise NotImplementedError("azula_amd.nn.UNet implements spatial = 1 and 2 (no 3-D convolution kernels)")
+        self.spatial = spatial
         if isinstance(kernel_size, int):
             kernel_size = [kernel_size] * spatial
         if isinstance(stride, int):
             stride = [stride] * spatial
+        assert len(kernel_size) == len(stride) == spatial
         if len(set(kernel_size)) != 1 or len(set(stride)) != 1 or kernel_size[0] % 2 == 0:
             raise NotImplementedError("square odd kernels and isotropic strides only")
         if stride[0] != 2:
@@ -335,10 +351,15 @@ class UNet(nn.Module):
     @torch.no_grad()
     @_lib.on_device
     def forward(self, x: Tensor, mod: Tensor | None = None, cond: Tensor | None = None) -> Tensor:
-        r"""x: (B, C_i, H, W); mod: (D) or (B, D); cond: (B, C_c, H, W) -> (B, C_o, H, W)."""
+        r"""x: (B, C_i, H, W); mod: (D) or (B, D); cond: (B, C_c, H, W) -> (B, C_o, H, W).  With ``spatial = 1`` the
+        tensors are (B, C, L): a one-row image through the same kernels (the 1-D filters sit in the middle row of
+        3 x 3 ones, the other rows only ever meet the padding)."""
         out_dtype = self._check_device(x)
         if cond is not None:
             x = torch.cat((x, cond), dim=1)
+        if self.spatial == 1:
+            assert x.ndim == 3, "spatial = 1: expected (B, C, L)"
+            x = x[:, :, None]
         x = x.to(torch.float32).contiguous()
         B, Cin, H, W = x.shape
         assert Cin == self.in_channels + self.cond_channels
@@ -355,4 +376,5 @@ class UNet(nn.Module):
         if rows:
             p.mod.copy_(mod.reshape(rows, -1))
         p.tape.run(s)
-        return p.out.to(out_dtype, copy=True)
+        out = p.out.to(out_dtype, copy=True)
+        return out[:, :, 0] if self.spatial == 1 else out

@@ -378,6 +378,28 @@ class DiT(nn.Module):
         return o.buf.view(B, L, o.cs)[..., : o.C].to(out_dtype, copy=True)
 
 
+def _patchify_nd(x: Tensor, patch: Sequence[int]) -> Tensor:
+    r"""'B Z (A a) (B b) ... -> B A B ... (Z a b ...)'."""
+    B, Z, *dims = x.shape
+    n = len(patch)
+    assert len(dims) == n and all(d % p == 0 for d, p in zip(dims, patch)), (x.shape, patch)
+    x = x.reshape(B, Z, *[v for d, p in zip(dims, patch) for v in (d // p, p)])
+    grid_axes = [2 + 2 * i for i in range(n)]
+    patch_axes = [3 + 2 * i for i in range(n)]
+    x = x.permute(0, *grid_axes, 1, *patch_axes)
+    return x.reshape(B, *[d // p for d, p in zip(dims, patch)], Z * math.prod(patch))
+
+
+def _unpatchify_nd(y: Tensor, patch: Sequence[int]) -> Tensor:
+    r"""'B A B ... (Z a b ...) -> B Z (A a) (B b) ...'."""
+    B, *grid, F = y.shape
+    n = len(patch)
+    Z = F // math.prod(patch)
+    y = y.reshape(B, *grid, Z, *patch)
+    order = [0, 1 + n] + [v for i in range(n) for v in (1 + i, 2 + n + i)]
+    return y.permute(*order).reshape(B, Z, *[g * p for g, p in zip(grid, patch)])
+
+
 class ViT(DiT):
     r"""Modulated ViT-like module on images (reference ``azula/nn/vit.py:22-108``)."""
 
@@ -394,8 +416,6 @@ class ViT(DiT):
         unpatch_size: int | Sequence[int] | None = None,
         **kwargs,
     ) -> None:
-        if spatial != 2:
-            raise NotImplementedError("azula_amd.nn.ViT implements spatial=2 only")
         if isinstance(patch_size, int):
             patch_size = [patch_size] * spatial
         if unpatch_size is None:
@@ -403,14 +423,16 @@ class ViT(DiT):
         elif isinstance(unpatch_size, int):
             unpatch_size = [unpatch_size] * spatial
         assert len(patch_size) == len(unpatch_size) == spatial
-        if len(set(patch_size)) != 1 or len(set(unpatch_size)) != 1:
-            raise NotImplementedError("square patches only (patch_size / unpatch_size may differ from each other)")
-        p, pu = patch_size[0], unpatch_size[0]
         super().__init__(
-            in_channels=p * p * in_channels, out_channels=pu * pu * out_channels, cond_channels=p * p * cond_channels,
-            mod_features=mod_features, pos_channels=spatial, hid_channels=hid_channels, hid_blocks=hid_blocks, **kwargs,
+            in_channels=math.prod(patch_size) * in_channels, out_channels=math.prod(unpatch_size) * out_channels,
+            cond_channels=math.prod(patch_size) * cond_channels, mod_features=mod_features, pos_channels=spatial,
+            hid_channels=hid_channels, hid_blocks=hid_blocks, **kwargs,
         )
-        self.patch_size, self.unpatch_size = p, pu
+        self.patch_shape, self.unpatch_shape = tuple(patch_size), tuple(unpatch_size)
+        # images with square patches take the fused patchify / unpatchify kernels (and the captured sampling graph);
+        # any other geometry (1-D, 3-D, anisotropic patches) rearranges with torch index ops around the token network
+        self.native = spatial == 2 and len(set(patch_size)) == 1 and len(set(unpatch_size)) == 1
+        self.patch_size, self.unpatch_size = patch_size[0], unpatch_size[0]
         self.image_in, self.image_out, self.image_cond = in_channels, out_channels, cond_channels
         self.spatial = spatial
 
@@ -429,9 +451,11 @@ class ViT(DiT):
     def forward(self, x: Tensor, mod: Tensor | None = None, cond: Tensor | None = None) -> Tensor:
         r"""x: (B, C_i, H, W); mod: (D) or (B, D) -> (B, C_o, H, W)."""
         out_dtype = self._check_device(x)
+        assert (cond is not None) == (self.image_cond > 0), "pass cond iff the network was built with cond_channels"
+        if not self.native:
+            return self._forward_rearranged(x, mod, cond)
         B, Z, H, W = x.shape
         assert Z == self.image_in and H % self.patch_size == 0 and W % self.patch_size == 0
-        assert (cond is not None) == (self.image_cond > 0), "pass cond iff the network was built with cond_channels"
         rows = self._mod_rows(mod, B)
         plan = self._vit_plan(B, H, W, rows, x.device)
         # patchify(x) || patchify(cond) along the token features == patchify of the channel concatenation: the
@@ -444,11 +468,25 @@ class ViT(DiT):
         plan.tape.run()
         return plan.out.to(out_dtype, copy=True)
 
+    def _forward_rearranged(self, x: Tensor, mod, cond) -> Tensor:
+        r"""Any number of spatial dimensions / anisotropic patches: ``Patchify`` and ``Unpatchify`` (reference
+        ``azula/nn/layers.py:198-247``, channel_last) as torch reshapes around the compiled token network."""
+        assert x.ndim == 2 + self.spatial and x.shape[1] == self.image_in
+        t = _patchify_nd(x, self.patch_shape)
+        grid = t.shape[1:-1]
+        pos = torch.cartesian_prod(*(torch.arange(n, dtype=torch.float32) for n in grid)).reshape(-1, len(grid))
+        t = t.flatten(1, -2)
+        c = None if cond is None else _patchify_nd(cond, self.patch_shape).flatten(1, -2)
+        y = DiT.forward(self, t, mod, pos=pos, cond=c)
+        return _unpatchify_nd(y.unflatten(1, grid), self.unpatch_shape)
+
     # -- fused sampling ---------------------------------------------------------------------------
     def _az_compile_modulated(self, x: Tensor, mod_rows: int = 1):
         from ..sample import BackboneProgram
         from .unet import _copy_tape
 
+        if not self.native:
+            return None
         if self.mod_features == 0 or x.ndim != 4 or self.image_cond or self.unpatch_size != self.patch_size:
             return None  # cond / a different output geometry: the generic step loop (eager forward per step)
         self._check_device(x)

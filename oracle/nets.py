@@ -23,10 +23,13 @@ def _linear(sd, key: str, x: Tensor) -> Tensor:
 
 
 def _conv(sd, key: str, x: Tensor, stride: int = 1, padding: int = 1, periodic: bool = False) -> Tensor:
-    if periodic and padding:  # torch.nn.Conv2d(padding_mode="circular"): F.pad(mode="circular") then an unpadded conv
-        x = F.pad(x, (padding,) * 4, mode="circular")
+    r"""ConvNd (azula/nn/layers.py:25-50) for 2-D images (B, C, H, W) and 1-D signals (B, C, L)."""
+    n = x.ndim - 2
+    if periodic and padding:  # torch.nn.ConvNd(padding_mode="circular"): F.pad(mode="circular") then an unpadded conv
+        x = F.pad(x, (padding,) * (2 * n), mode="circular")
         padding = 0
-    return F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=stride, padding=padding)
+    conv = F.conv2d if n == 2 else F.conv1d
+    return conv(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=stride, padding=padding)
 
 
 def layer_norm_unbiased(x: Tensor, dim: int, eps: float = 1e-5) -> Tensor:
@@ -63,13 +66,13 @@ def _ada_zero(sd, key: str, mod: Tensor | None, channels: int, trailing: tuple[i
 def unet_block(sd, key: str, x: Tensor, mod, norm: str, groups: int, periodic: bool = False) -> Tensor:
     r"""UNetBlock._forward -- azula/nn/unet.py:85-95 (``periodic``: circular padding, unet.py:175-180)."""
     C = x.shape[1]
-    a, b, c = _ada_zero(sd, key + ".ada_zero", mod, C, (C, 1, 1))
+    a, b, c = _ada_zero(sd, key + ".ada_zero", mod, C, (C, *(1,) * (x.ndim - 2)))
     if norm == "group":
         n = F.group_norm(x, min(groups, C), eps=1e-5)  # affine=False, unet.py:54-60
     elif norm == "layer":
-        n = layer_norm_unbiased(x, dim=-3)
+        n = layer_norm_unbiased(x, dim=1)  # LayerNorm(dim=-spatial-1): the channel axis
     elif norm == "rms":
-        n = rms_norm(x, dim=-3)
+        n = rms_norm(x, dim=1)
     else:
         raise NotImplementedError(norm)
     y = (a + 1) * n + b
@@ -106,7 +109,7 @@ def unet_forward(sd, cfg: dict, x: Tensor, mod: Tensor | None = None, tap: dict 
             x = unet_block(sd, f"ascent.{k}.{idx + j}", x, mod, norm, groups, per)
         idx += hid_blocks[i]
         if i > 0:
-            x = F.interpolate(x, scale_factor=(2.0, 2.0), mode="nearest")
+            x = F.interpolate(x, scale_factor=(2.0,) * (x.ndim - 2), mode="nearest")
         else:
             x = _conv(sd, f"ascent.{k}.{idx}", x, periodic=per)
         if tap is not None:
@@ -200,19 +203,34 @@ def dit_forward(sd, cfg: dict, x: Tensor, mod=None, pos: Tensor | None = None, t
     return _linear(sd, "out_proj", x)
 
 
-def _patchify(x: Tensor, p: int) -> Tensor:
-    r"""'... Z (A a) (B b) -> ... A B (Z a b)' -- azula/nn/layers.py:198-222 (channel_last)."""
-    B, Z, H, W = x.shape
-    return x.reshape(B, Z, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, H // p, W // p, Z * p * p)
+def _patchify(x: Tensor, patch) -> Tensor:
+    r"""'... Z (A a) (B b) ... -> ... A B ... (Z a b ...)' -- azula/nn/layers.py:198-222 (channel_last), any number of
+    spatial dimensions."""
+    B, Z, *dims = x.shape
+    n = len(patch)
+    x = x.reshape(B, Z, *[v for d, p in zip(dims, patch) for v in (d // p, p)])
+    x = x.permute(0, *[2 + 2 * i for i in range(n)], 1, *[3 + 2 * i for i in range(n)])
+    return x.reshape(B, *[d // p for d, p in zip(dims, patch)], Z * math.prod(patch))
+
+
+def _unpatchify(y: Tensor, patch) -> Tensor:
+    r"""The inverse rearrangement -- azula/nn/layers.py:225-247."""
+    B, *grid, Fe = y.shape
+    n = len(patch)
+    Z = Fe // math.prod(patch)
+    y = y.reshape(B, *grid, Z, *patch)
+    return y.permute(0, 1 + n, *[v for i in range(n) for v in (1 + i, 2 + n + i)]).reshape(
+        B, Z, *[g * p for g, p in zip(grid, patch)])
 
 
 def vit_forward(sd, cfg: dict, x: Tensor, mod=None, tap=None, cond: Tensor | None = None) -> Tensor:
-    r"""ViT.forward -- azula/nn/vit.py:76-108 (Patchify/Unpatchify channel_last,
-    azula/nn/layers.py:198-247).  cfg adds patch_size (int), optionally unpatch_size (int); ``cond`` is patchified
-    like ``x`` and concatenated along the token features (vit.py:92-96, dit.py:202-203)."""
-    p = cfg["patch_size"]
-    pu = cfg.get("unpatch_size") or p
-    B, Z, H, W = x.shape
+    r"""ViT.forward -- azula/nn/vit.py:76-108 (Patchify/Unpatchify channel_last, azula/nn/layers.py:198-247).  cfg adds
+    patch_size / optionally unpatch_size (int or one entry per spatial dimension); ``cond`` is patchified like ``x`` and
+    concatenated along the token features (vit.py:92-96, dit.py:202-203)."""
+    n = x.ndim - 2
+    as_shape = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v,) * n  # noqa: E731
+    p = as_shape(cfg["patch_size"])
+    pu = as_shape(cfg.get("unpatch_size") or cfg["patch_size"])
     t = _patchify(x, p)
     shape = t.shape[1:-1]
     pos = torch.cartesian_prod(*(torch.arange(s, dtype=x.dtype) for s in shape)).reshape(-1, len(shape))
@@ -220,9 +238,7 @@ def vit_forward(sd, cfg: dict, x: Tensor, mod=None, tap=None, cond: Tensor | Non
     if cond is not None:
         t = torch.cat((t, _patchify(cond, p).flatten(1, -2)), dim=-1)
     y = dit_forward(sd, cfg, t, mod, pos=pos, tap=tap)
-    y = y.unflatten(-2, shape)
-    Zo = y.shape[-1] // (pu * pu)
-    return y.reshape(B, H // p, W // p, Zo, pu, pu).permute(0, 3, 1, 4, 2, 5).reshape(B, Zo, H // p * pu, W // p * pu)
+    return _unpatchify(y.unflatten(-2, shape), pu)
 
 
 def time_wrapped_vit(sd, cfg: dict, x: Tensor, c_time: Tensor, **_) -> Tensor:

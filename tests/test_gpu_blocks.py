@@ -133,3 +133,36 @@ def test_periodic_unet(golden, policy, monkeypatch):
     ref = nets.unet_forward(sd, dict(hid_channels=(64, 64), hid_blocks=(1, 1), norm="group", groups=8, periodic=True), x, mod)
     out = big.cuda().eval()(x.cuda(), mod.cuda())
     assert max_err(out, ref) < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["unet1d", "unet1d_odd", "unet1d_periodic"])
+def test_unet_on_1d_signals(golden, name):
+    """``spatial = 1`` (azula/nn/unet.py:119-203): (B, C, L) signals run as one-row images through the same conv /
+    GroupNorm kernels; state_dict shapes are the reference's Conv1d ones."""
+    from azula_amd.nn import UNet
+
+    g = golden("g13_spatial")
+    cfg = dict(g.meta[name + "_cfg"])
+    periodic = cfg.pop("periodic")
+    net = UNet(**cfg, spatial=1, periodic=periodic)
+    sh = {n: tuple(v) for n, v in g.meta[name + "_shapes"].items()}
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == sh
+    net.load_state_dict(synth.synth_state_dict(sh, 41))
+    y = net.cuda().eval()(g[name + "_x"].cuda(), g["mod"].cuda())
+    sc = max(1.0, g[name + "_y"].abs().max().item())
+    print(name, "max|d|", max_err(y, g[name + "_y"]), "scale", sc)
+    assert y.shape == g[name + "_y"].shape and max_err(y, g[name + "_y"]) < 2e-5 * sc
+
+
+@pytest.mark.parametrize("name", ["vit1d", "vit3d", "vit2d_aniso"])
+def test_vit_on_other_grids(golden, name):
+    """1-D / 3-D grids and anisotropic patches: torch rearrangement around the compiled token network."""
+    from azula_amd.nn import ViT
+
+    g = golden("g13_spatial")
+    vit = ViT(**g.meta[name + "_cfg"])
+    vit.load_state_dict(synth.synth_state_dict({n: tuple(v) for n, v in g.meta[name + "_shapes"].items()}, 42))
+    y = vit.cuda().eval()(g[name + "_x"].cuda(), g["mod"].cuda())
+    sc = max(1.0, g[name + "_y"].abs().max().item())
+    print(name, "max|d|", max_err(y, g[name + "_y"]), "scale", sc)
+    assert y.shape == g[name + "_y"].shape and max_err(y, g[name + "_y"]) < 2e-5 * sc

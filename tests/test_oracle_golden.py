@@ -211,3 +211,15 @@ def test_g12_blocks_mask_cond_periodic(golden):
     for name in ("punet_a", "punet_b", "punet_c"):
         x = g[name + "_x"]
         assert max_err(nets.unet_forward(psd, pcfg, x, mod[: x.shape[0]]), g[name + "_y"]) < 1e-5
+
+
+def test_g13_other_spatial_dimensions(golden):
+    """UNet on 1-D signals (also periodic) and ViT on 1-D / 3-D grids / anisotropic patches."""
+    g = golden("g13_spatial")
+    mod = g["mod"]
+    for name in ("unet1d", "unet1d_odd", "unet1d_periodic"):
+        sd = synth.synth_state_dict({n: tuple(v) for n, v in g.meta[name + "_shapes"].items()}, 41)
+        assert max_err(nets.unet_forward(sd, g.meta[name + "_cfg"], g[name + "_x"], mod), g[name + "_y"]) < 1e-5
+    for name in ("vit1d", "vit3d", "vit2d_aniso"):
+        sd = synth.synth_state_dict({n: tuple(v) for n, v in g.meta[name + "_shapes"].items()}, 42)
+        assert max_err(nets.vit_forward(sd, g.meta[name + "_cfg"], g[name + "_x"], mod), g[name + "_y"]) < 1e-5
