@@ -244,6 +244,9 @@ PROTOTYPES: dict[str, list] = {
     "az_graph_launch": [vp, c_stream],
     "az_graph_destroy": [vp],
     "az_graph_num_nodes": [vp, C.POINTER(i64)],
+    "az_transition_f64": [C.POINTER(AzTransitionArgs), c_stream],
+    "az_axpby_f64": [vp, vp, vp, vp, vp, i32, i64, i64, i32, c_stream],
+    "az_scale_f64_to_f32": [vp, vp, vp, i64, i64, i32, c_stream],
     "az_calib_read_f32": [vp, vp, i64, i32, i32, i64, c_stream],
     "az_calib_write_f32": [vp, i64, f32, c_stream],
 }

@@ -454,6 +454,59 @@ __global__ void coef_c_time_kernel(float* dst, const AzStepCoef* coef) {
   if (threadIdx.x == 0) dst[0] = coef->c_time;
 }
 
+// ---- fp64 latents.  Sampler(dtype=torch.float64) makes the reference's schedule scalars fp64 tensors of shape
+// (1, ..., 1); multiplied into the latents they promote them to fp64 (azula/denoise.py:306-322, azula/sample.py:210-214,
+// 257-259), so the whole elementwise path of such a sampler is fp64 while the backbone keeps its own dtype.  These
+// kernels are that path: separately rounded fp64 operations in the reference's association order.
+__device__ __forceinline__ double az_dmul(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double az_dadd(double a, double b) { return __dadd_rn(a, b); }
+__device__ __forceinline__ double az_dsub(double a, double b) { return __dsub_rn(a, b); }
+
+struct AzStepCoef64 {  // the fields of AzStepCoef that the flat transition reads, as doubles (same order)
+  double c_in, c_skip, c_out, c_time, alpha_t, alpha_s, k_x, k_eps, c_in_next, clip_lo, clip_hi, guidance;
+};
+
+template <bool EPS, bool MEAN>
+__global__ __launch_bounds__(256) void transition_f64_kernel(const double* x_t, const double* __restrict__ F,
+                                                             const double* __restrict__ eps, double* x_s,
+                                                             double* __restrict__ mean_out, int64_t n,
+                                                             const AzStepCoef64* coef) {
+  const double c_skip = coef->c_skip, c_out = coef->c_out, a_t = coef->alpha_t, a_s = coef->alpha_s, k_x = coef->k_x,
+               k_eps = coef->k_eps, lo = coef->clip_lo, hi = coef->clip_hi;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double x = x_t[i];
+    double m = az_dadd(az_dmul(c_skip, x), az_dmul(c_out, F[i]));
+    const double c = fmin(fmax(m, lo), hi);
+    m = m != m ? m : c;
+    double xs = az_dmul(a_s, m);
+    xs = az_dadd(xs, az_dmul(k_x, az_dsub(x, az_dmul(a_t, m))));
+    if (EPS) xs = az_dadd(xs, az_dmul(k_eps, eps[i]));
+    x_s[i] = xs;
+    if (MEAN) mean_out[i] = m;
+  }
+}
+
+template <bool Z32>
+__global__ __launch_bounds__(256) void axpby_f64_kernel(double* __restrict__ y, const double* __restrict__ a,
+                                                        const double* __restrict__ x, const double* __restrict__ b,
+                                                        const void* __restrict__ z, int64_t rows, int64_t inner,
+                                                        int a_stride) {
+  const int64_t n = rows * inner;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = a_stride ? i / inner : 0;
+    const double zv = Z32 ? (double)reinterpret_cast<const float*>(z)[i] : reinterpret_cast<const double*>(z)[i];
+    y[i] = az_dadd(az_dmul(a[r * a_stride], x[i]), az_dmul(b[r * a_stride], zv));
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_f64_to_f32_kernel(float* __restrict__ y, const double* __restrict__ x,
+                                                               const double* __restrict__ s, int64_t rows,
+                                                               int64_t inner, int s_stride) {
+  const int64_t n = rows * inner;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = (float)az_dmul(s[s_stride ? i / inner : 0], x[i]);  // (c_in * x_t).to(float32), azula/denoise.py:317
+}
+
 template <bool CFG, bool EPS>
 int launch_flat(const AzTransitionArgs* a, int64_t n, hipStream_t st) {
   const int64_t n4 = n / 4;
@@ -580,6 +633,46 @@ int az_multistep_f32(const AzMultistepArgs* a, az_stream_t stream) {
     case 6: launch_multistep<6>(a, s); break;
     default: launch_multistep<7>(a, s); break;
   }
+  return az_launch_status();
+}
+
+int az_transition_f64(const AzTransitionArgs* a, az_stream_t stream) {
+  AZ_REQUIRE(a && a->x_t && a->F && a->x_s && a->coef, AZ_E_NULL);
+  AZ_REQUIRE(a->batch > 0 && a->channels > 0 && a->inner > 0, AZ_E_SHAPE);
+  // flat form only: every tensor (B, C, inner) fp64 in the same layout; no CFG input, no pre-scaled second output
+  AZ_REQUIRE(!a->F_neg && !a->xin_next && !a->f_nhwc && a->nhwc_pad == 0 && a->f_channels == a->channels, AZ_E_UNSUPPORTED);
+  const int64_t n = a->batch * a->channels * a->inner;
+  const double *x = reinterpret_cast<const double*>(a->x_t), *F = reinterpret_cast<const double*>(a->F),
+               *e = reinterpret_cast<const double*>(a->eps);
+  double *xs = reinterpret_cast<double*>(a->x_s), *mo = reinterpret_cast<double*>(a->mean_out);
+  const AzStepCoef64* cf = reinterpret_cast<const AzStepCoef64*>(a->coef);
+  const dim3 grid(az_stream_grid(n, 256));
+  hipStream_t st = az_s(stream);
+  if (e && mo) hipLaunchKernelGGL((transition_f64_kernel<true, true>), grid, dim3(256), 0, st, x, F, e, xs, mo, n, cf);
+  else if (e) hipLaunchKernelGGL((transition_f64_kernel<true, false>), grid, dim3(256), 0, st, x, F, e, xs, mo, n, cf);
+  else if (mo) hipLaunchKernelGGL((transition_f64_kernel<false, true>), grid, dim3(256), 0, st, x, F, e, xs, mo, n, cf);
+  else hipLaunchKernelGGL((transition_f64_kernel<false, false>), grid, dim3(256), 0, st, x, F, e, xs, mo, n, cf);
+  return az_launch_status();
+}
+
+int az_axpby_f64(double* y, const double* a_dev, const double* x, const double* b_dev, const void* z, int32_t z_is_f32,
+                 int64_t rows, int64_t inner, int32_t a_stride, az_stream_t stream) {
+  AZ_REQUIRE(y && a_dev && x && b_dev && z, AZ_E_NULL);
+  AZ_REQUIRE(rows > 0 && inner > 0 && (a_stride == 0 || a_stride == 1), AZ_E_SHAPE);
+  const dim3 grid(az_stream_grid(rows * inner, 256));
+  if (z_is_f32)
+    hipLaunchKernelGGL(axpby_f64_kernel<true>, grid, dim3(256), 0, az_s(stream), y, a_dev, x, b_dev, z, rows, inner, a_stride);
+  else
+    hipLaunchKernelGGL(axpby_f64_kernel<false>, grid, dim3(256), 0, az_s(stream), y, a_dev, x, b_dev, z, rows, inner, a_stride);
+  return az_launch_status();
+}
+
+int az_scale_f64_to_f32(float* y, const double* x, const double* s_dev, int64_t rows, int64_t inner, int32_t s_stride,
+                        az_stream_t stream) {
+  AZ_REQUIRE(y && x && s_dev, AZ_E_NULL);
+  AZ_REQUIRE(rows > 0 && inner > 0 && (s_stride == 0 || s_stride == 1), AZ_E_SHAPE);
+  hipLaunchKernelGGL(scale_f64_to_f32_kernel, dim3(az_stream_grid(rows * inner, 256)), dim3(256), 0, az_s(stream), y, x,
+                     s_dev, rows, inner, s_stride);
   return az_launch_status();
 }
 

@@ -87,6 +87,40 @@ def karras_coefficients(alpha_t: Tensor, sigma_t: Tensor):
     return c_in, c_out, c_skip, c_time
 
 
+def is_wide(*tensors: Tensor) -> bool:
+    r"""True if torch's type promotion makes the elementwise path fp64: a DIMENSIONED fp64 tensor takes part (0-d
+    tensors do not promote).  ``Sampler(dtype=float64)`` gets there through the schedule scalars, which the denoisers
+    expand to shape (1, ..., 1) before multiplying them into x_t (reference ``azula/denoise.py:306-322``)."""
+    return any(t.dtype == torch.float64 and t.ndim > 0 for t in tensors)
+
+
+def _dev64(c: Tensor, device) -> Tensor:
+    return c.reshape(-1).to(device=device, dtype=torch.float64).contiguous()
+
+
+def precondition_wide(x_t: Tensor, c_in: Tensor) -> Tensor:
+    r"""``(c_in * x_t).to(float32)`` with the product taken in fp64 (``az_scale_f64_to_f32``)."""
+    x64 = x_t.to(torch.float64).contiguous()
+    c = _dev64(c_in, x_t.device)
+    rows = x_t.shape[0] if c.numel() > 1 else 1
+    y = torch.empty(x_t.shape, dtype=torch.float32, device=x_t.device)
+    _lib.call("az_scale_f64_to_f32", y.data_ptr(), x64.data_ptr(), c.data_ptr(), rows, x64.numel() // rows,
+              1 if c.numel() > 1 else 0, _lib.stream_ptr())
+    return y
+
+
+def axpby_wide(a: Tensor, x: Tensor, b: Tensor, z: Tensor) -> Tensor:
+    r"""a * x + b * z in fp64 (``az_axpby_f64``); ``z`` may be fp32 (widened element by element, as torch does)."""
+    x64 = x.to(torch.float64).contiguous()
+    z = z.contiguous() if z.dtype in (torch.float32, torch.float64) else z.to(torch.float32).contiguous()
+    a64, b64 = _dev64(a, x.device), _dev64(b, x.device)
+    rows = x.shape[0] if a64.numel() > 1 else 1
+    y = torch.empty_like(x64)
+    _lib.call("az_axpby_f64", y.data_ptr(), a64.data_ptr(), x64.data_ptr(), b64.data_ptr(), z.data_ptr(),
+              int(z.dtype == torch.float32), rows, x64.numel() // rows, 1 if a64.numel() > 1 else 0, _lib.stream_ptr())
+    return y
+
+
 def precondition(x_t: Tensor, c_in: Tensor) -> Tensor:
     r"""c_in * x_t on the device (reference ``azula/denoise.py:317``); c_in is () or (B,)."""
     B = x_t.shape[0] if c_in.numel() > 1 else 1
@@ -139,6 +173,11 @@ class KarrasDenoiser(Denoiser):
             output = self.backbone((c_in * x_t).to(dtype), c_time.to(dtype), **kwargs).to(x_t)
             return DiracPosterior(mean=c_skip * x_t + c_out * output)
 
+        if is_wide(x_t, alpha_t):  # fp64 time grid and / or fp64 latents: the elementwise path is fp64 (see is_wide)
+            x_in = precondition_wide(x_t, c_in)
+            output = self.backbone(x_in.to(dtype), c_time.to(device=x_t.device, dtype=dtype), **kwargs)
+            output = output.to(x_t.dtype)  # .to(x_t): the latents' dtype, before the fp64 scalars promote the sum
+            return DiracPosterior(mean=axpby_wide(c_skip, x_t, c_out, output))
         require_f32_cuda(x_t, "KarrasDenoiser")
         x_t = x_t.contiguous()
         x_in = precondition(x_t, c_in.to(x_t.device))
@@ -184,6 +223,10 @@ class SimpleDenoiser(Denoiser):
         dtype = get_module_dtype(self.backbone) or x_t.dtype
         if not x_t.is_cuda:
             return DiracPosterior(mean=self.backbone((c_in * x_t).to(dtype), c_time.to(dtype), **kwargs).to(x_t))
+        if is_wide(x_t, alpha_t):
+            x_in = precondition_wide(x_t, c_in)
+            output = self.backbone(x_in.to(dtype), c_time.to(device=x_t.device, dtype=dtype), **kwargs)
+            return DiracPosterior(mean=output.to(x_t))
         require_f32_cuda(x_t, "SimpleDenoiser")
         x_in = precondition(x_t.contiguous(), c_in.to(x_t.device))
         output = self.backbone(x_in.to(dtype), c_time.to(device=x_t.device, dtype=dtype), **kwargs)

@@ -148,9 +148,16 @@ class ConvWeights:
             w2 = torch.zeros(w.shape[0], w.shape[1], k, k, dtype=w.dtype, device=w.device)
             w2[:, :, k // 2, :] = w
             w = w2
+        if w.shape[2] != w.shape[3]:  # anisotropic odd kernel (kh, kw): centred in a square one; with 'same' padding the
+            kh, kw_ = w.shape[2], w.shape[3]  # extra zero rows / columns only ever add zeros
+            assert kh % 2 == 1 and kw_ % 2 == 1, "odd kernel sizes only"
+            k = max(kh, kw_)
+            w2 = torch.zeros(w.shape[0], w.shape[1], k, k, dtype=w.dtype, device=w.device)
+            w2[:, :, (k - kh) // 2 : (k - kh) // 2 + kh, (k - kw_) // 2 : (k - kw_) // 2 + kw_] = w
+            w = w2
         self.w = w.contiguous()
         self.cout, self.cin, self.ks, kw = self.w.shape
-        assert self.ks == kw, "square kernels only"
+        assert self.ks == kw
         self.cin0 = self.cin if cin0 is None else cin0
         self.c0s, self.c1s = pad4(self.cin0), pad4(self.cin - self.cin0)
         self.cout_s = pad4(self.cout)

@@ -46,6 +46,13 @@ class CFGDenoiser(Denoiser):
         q_neg = self.denoiser(x_t, t, **negative, **kwargs)
         if not x_t.is_cuda:  # host tensors: reference op sequence
             return DiracPosterior(mean=q_pos.mean + guidance * (q_pos.mean - q_neg.mean))
+        if q_pos.mean.dtype == torch.float64:  # fp64 means (Sampler(dtype=float64)): pos + g * (pos - neg) in fp64
+            from ..denoise import axpby_wide
+
+            one = torch.ones((), dtype=torch.float64)
+            diff = axpby_wide(one, q_pos.mean, -one, q_neg.mean)
+            g64 = torch.as_tensor(guidance, dtype=torch.float64).reshape(())
+            return DiracPosterior(mean=axpby_wide(one, q_pos.mean, g64, diff))
         pos, neg = q_pos.mean.contiguous(), q_neg.mean.contiguous()
         g = torch.as_tensor(guidance, dtype=torch.float32, device=x_t.device).reshape(1)
         mean = torch.empty_like(pos)

@@ -70,10 +70,10 @@ class UNetBlock(nn.Module):
         if isinstance(kernel_size, int):  # standalone use passes ConvNd's keyword arguments (reference unet.py:76-83)
             kernel_size = (kernel_size,) * spatial
         kernel_size = tuple(kernel_size)[:spatial] if len(kernel_size) >= spatial else tuple(kernel_size)
-        if len(set(kernel_size)) != 1 or kernel_size[0] % 2 == 0 or kwargs.get("stride", 1) not in (1, (1,), [1], (1, 1), [1, 1]):
-            raise NotImplementedError("square odd kernels with stride 1 only")
-        pad = kwargs.get("padding", kernel_size[0] // 2)
-        if (pad if isinstance(pad, int) else pad[0]) != kernel_size[0] // 2:
+        if any(k % 2 == 0 for k in kernel_size) or kwargs.get("stride", 1) not in (1, (1,), [1], (1, 1), [1, 1]):
+            raise NotImplementedError("odd kernel sizes with stride 1 only")
+        pad = kwargs.get("padding", tuple(k // 2 for k in kernel_size))
+        if tuple([pad] * len(kernel_size) if isinstance(pad, int) else pad) != tuple(k // 2 for k in kernel_size):
             raise NotImplementedError("'same' padding (kernel_size // 2) only")
         if norm not in ("layer", "rms", "group"):
             raise NotImplementedError(norm)
@@ -271,8 +271,8 @@ class UNet(nn.Module):
         if isinstance(stride, int):
             stride = [stride] * spatial
         assert len(kernel_size) == len(stride) == spatial
-        if len(set(kernel_size)) != 1 or len(set(stride)) != 1 or kernel_size[0] % 2 == 0:
-            raise NotImplementedError("square odd kernels and isotropic strides only")
+        if len(set(stride)) != 1 or any(k % 2 == 0 for k in kernel_size):
+            raise NotImplementedError("odd kernel sizes (anisotropic allowed) and isotropic strides only")
         if stride[0] != 2:
             raise NotImplementedError("stride 2 only (nearest x2 upsampling is folded into the merge conv)")
         self.in_channels, self.out_channels, self.cond_channels = in_channels, out_channels, cond_channels

@@ -91,8 +91,21 @@ class AblatedDenoiser(Denoiser):
         c_in, c_out, c_skip, c_time, c_var = adm_coefficients(alpha_t, sigma_t, sig)
         if not x_t.is_cuda:
             raise RuntimeError("azula_amd ADM denoisers execute only on an AMD GPU (no CPU fallback)")
+        from ...denoise import axpby_wide, is_wide, precondition, precondition_wide
+
+        if is_wide(x_t, alpha_t):  # fp64 time grid / latents: fp64 elementwise path around the fp32 backbone
+            dev = x_t.device
+            x_in = precondition_wide(x_t, c_in)
+            output = self.backbone(x_in, c_time.to(dev), y=label, **kwargs)
+            Cc = x_t.shape[1]
+            eps_hat = output[:, :Cc].to(x_t.dtype).contiguous() if self.learn_var else output.to(x_t.dtype)
+            mean = axpby_wide(c_skip, x_t, c_out, eps_hat)
+            lo, hi = self._clip()
+            if lo > -math.inf:
+                mean = torch.clip(mean, min=lo, max=hi)
+            var = c_var.to(dev) * torch.exp(output[:, Cc:].to(x_t.dtype)) if self.learn_var else c_var.to(dev)
+            return GaussianPosterior(mean=mean, var=var)
         require_f32_cuda(x_t, "AblatedDenoiser")
-        from ...denoise import precondition
 
         dev = x_t.device
         x_t = x_t.contiguous()

@@ -29,7 +29,7 @@ from torch import Tensor
 
 from . import _lib
 from ._lib import COEF_FIELDS, COEF_WORDS
-from .denoise import Denoiser, require_f32_cuda
+from .denoise import Denoiser, axpby_wide, is_wide, require_f32_cuda
 from .engine import StepGraph, Tape, transition_args
 
 __all__ = [
@@ -185,6 +185,8 @@ class Sampler(abc.ABC):
     def _device_kernel(self, x_t: Tensor, mean: Tensor, alpha_t, alpha_s, k_x, k_eps, draw: bool) -> Tensor:
         r"""x_s = alpha_s m + k_x (x_t - alpha_t m) + k_eps eps through ``az_transition_f32``; ``draw=False``
         skips the noise draw and the eps stream (the kernel's EPS=false instantiation)."""
+        if is_wide(x_t, mean):
+            return self._device_kernel_wide(x_t, mean, alpha_t, alpha_s, k_x, k_eps, draw)
         require_f32_cuda(x_t, type(self).__name__)
         dev = x_t.device
         zero = torch.zeros((), device=dev)
@@ -204,6 +206,24 @@ class Sampler(abc.ABC):
             inner=x_c.numel(), f_channels=1, coef=row.data_ptr(),
         )
         _lib.call("az_transition_f32", C.byref(a), _lib.stream_ptr())
+        return x_s
+
+    def _device_kernel_wide(self, x_t: Tensor, mean: Tensor, alpha_t, alpha_s, k_x, k_eps, draw: bool) -> Tensor:
+        r"""The same update in fp64 (``az_transition_f64``): fp64 latents, or an fp64 posterior mean -- what a
+        ``Sampler(dtype=float64)`` produces from its first step on (the reference's promotion, ``azula/sample.py:257-259``).
+        The noise is drawn in ``x_t``'s own dtype, like the reference's ``randn_like(x_t)``."""
+        dev = x_t.device
+        row = torch.zeros(12, dtype=torch.float64, device=dev)
+        names = ["c_in", "c_skip", "c_out", "c_time", "alpha_t", "alpha_s", "k_x", "k_eps", "c_in_next", "clip_lo", "clip_hi", "guidance"]
+        vals = {"c_out": 1.0, "alpha_t": alpha_t, "alpha_s": alpha_s, "k_x": k_x, "k_eps": k_eps, "clip_lo": -math.inf, "clip_hi": math.inf}
+        for name, v in vals.items():
+            row[names.index(name)] = v.to(device=dev, dtype=torch.float64) if torch.is_tensor(v) else v
+        eps = self._draw_noise(x_t.contiguous()).to(torch.float64) if draw else None
+        x64, m64 = x_t.to(torch.float64).contiguous(), mean.to(torch.float64).contiguous()
+        x_s = torch.empty_like(x64)
+        a = transition_args(x_t=x64.data_ptr(), F=m64.data_ptr(), eps=eps.data_ptr() if draw else 0, x_s=x_s.data_ptr(), batch=1,
+                            channels=1, inner=x64.numel(), f_channels=1, coef=row.data_ptr())
+        _lib.call("az_transition_f64", C.byref(a), _lib.stream_ptr())
         return x_s
 
     # ---------------------------------------------------------------------------- fused path
@@ -510,6 +530,8 @@ def _lin2(a: Tensor, x: Tensor, b: Tensor, y: Tensor) -> Tensor:
     r"""a * x + b * y with 0-d coefficient tensors: ``az_axpby_f32`` on device tensors."""
     if not x.is_cuda:
         return a * x + b * y
+    if is_wide(x, y):
+        return axpby_wide(a, x, b, y)
     require_f32_cuda(x, "sampler")
     x, y = x.contiguous(), y.to(x).contiguous()
     out = torch.empty_like(x)
@@ -813,6 +835,10 @@ class _MultistepSampler(Sampler):
             out = self._call_fused(x, kwargs)
             if out is not None:
                 return out
+        if self.dtype == torch.float64 or x.dtype == torch.float64:
+            raise NotImplementedError(
+                f"{type(self).__name__}: the multistep kernel (az_multistep_f32) is fp32; fp64 latents / an fp64 time grid are "
+                "implemented for DDPM, DDIM, Euler, Heun, Ito and PC only")
         require_f32_cuda(x, type(self).__name__)
         alpha, sigma = self.denoiser.schedule(self.timesteps.cpu())
         table = self._device_table(alpha, sigma).to(x.device)

@@ -394,6 +394,20 @@ int az_graph_launch(AzGraph* g, az_stream_t stream);
 int az_graph_destroy(AzGraph* g);
 int az_graph_num_nodes(AzGraph* g, int64_t* n);
 
+/* ------------------------------------------------------------------ fp64 latents
+ * `Sampler(dtype=torch.float64)`: the reference's schedule scalars become fp64 tensors of shape (1, ..., 1) and promote
+ * the latents to fp64 in the preconditioning (azula/denoise.py:306-322) and in every sampler update
+ * (azula/sample.py:210-214, 257-259, 296-303, 343-350, 417-431, 975-993), while the backbone keeps its dtype.
+ *   az_transition_f64:   the flat form of az_transition_f32 on fp64 tensors (x_t, F = posterior mean or backbone output,
+ *                        eps, x_s, mean_out are double*; `coef` points to 12 doubles in AzStepCoef's field order)
+ *   az_axpby_f64:        y = a x + b z, fp64, z read as float (z_is_f32) or double; a, b device scalars or per-row
+ *   az_scale_f64_to_f32: y = (float)(s x)   -- `(c_in * x_t).to(backbone dtype)`, azula/denoise.py:317                */
+int az_transition_f64(const AzTransitionArgs* args, az_stream_t stream);
+int az_axpby_f64(double* y, const double* a_dev, const double* x, const double* b_dev, const void* z, int32_t z_is_f32,
+                 int64_t rows, int64_t inner, int32_t a_stride, az_stream_t stream);
+int az_scale_f64_to_f32(float* y, const double* x, const double* s_dev, int64_t rows, int64_t inner, int32_t s_stride,
+                        az_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement support (not on the sampling path)
  * Known-traffic kernels that calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters on gfx950 (MI355X_MICROARCH.md,
  * section HBM: "calibrate on a known byte count in your own access pattern").  `az_calib_read_f32` reads every byte of

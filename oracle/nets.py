@@ -22,10 +22,16 @@ def _linear(sd, key: str, x: Tensor) -> Tensor:
     return F.linear(x, sd[key + ".weight"], sd.get(key + ".bias"))
 
 
-def _conv(sd, key: str, x: Tensor, stride: int = 1, padding: int = 1, periodic: bool = False) -> Tensor:
-    r"""ConvNd (azula/nn/layers.py:25-50) for 2-D images (B, C, H, W) and 1-D signals (B, C, L)."""
+def _conv(sd, key: str, x: Tensor, stride: int = 1, padding=None, periodic: bool = False) -> Tensor:
+    r"""ConvNd (azula/nn/layers.py:25-50) for 2-D images (B, C, H, W) and 1-D signals (B, C, L); 'same' padding
+    (kernel // 2 per axis, azula/nn/unet.py:170-172) unless given."""
     n = x.ndim - 2
-    if periodic and padding:  # torch.nn.ConvNd(padding_mode="circular"): F.pad(mode="circular") then an unpadded conv
+    if padding is None:
+        padding = tuple(k // 2 for k in sd[key + ".weight"].shape[2:])
+        if len(set(padding)) == 1:
+            padding = padding[0]
+    if periodic and padding:
+        assert isinstance(padding, int)  # torch.nn.ConvNd(padding_mode="circular"): F.pad(mode="circular") then an unpadded conv
         x = F.pad(x, (padding,) * (2 * n), mode="circular")
         padding = 0
     conv = F.conv2d if n == 2 else F.conv1d

@@ -172,16 +172,20 @@ def sample(
     stop: float = 0.0,
     eps_list: list[Tensor] | None = None,
     record_eps: list | None = None,
+    dtype: torch.dtype | None = None,
     **kwargs,
 ) -> Tensor:
     r"""Full reverse loop  -- azula/sample.py:139-161 with step :204-216 / :248-261.
+
+    ``dtype`` is the sampler's ``dtype`` argument (azula/sample.py:69-94): the dtype of the TIME GRID.  With float64 the
+    schedule scalars, expanded to (1, ..., 1) by the denoiser, promote the latents to fp64 from the first step on.
 
     ``mean_fn(x_t, t, **kwargs)`` returns the posterior mean.  One ``randn_like`` per step is
     drawn AFTER the denoiser call (even when tau = 0), exactly as the reference does, unless
     ``eps_list`` supplies the noise.
     """
     x_t = x
-    for i, (t, s) in enumerate(time_pairs(start, stop, steps).unbind()):
+    for i, (t, s) in enumerate(time_pairs(start, stop, steps, dtype).unbind()):
         alpha_s, sigma_s = schedule(s)
         alpha_t, sigma_t = schedule(t)
         mean = mean_fn(x_t, t, **kwargs)

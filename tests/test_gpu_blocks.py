@@ -166,3 +166,18 @@ def test_vit_on_other_grids(golden, name):
     sc = max(1.0, g[name + "_y"].abs().max().item())
     print(name, "max|d|", max_err(y, g[name + "_y"]), "scale", sc)
     assert y.shape == g[name + "_y"].shape and max_err(y, g[name + "_y"]) < 2e-5 * sc
+
+
+def test_unet_anisotropic_kernel(golden):
+    """kernel_size = (3, 5) (azula/nn/unet.py:165-173): the filters sit centred in 5 x 5 ones."""
+    from azula_amd.nn import UNet
+
+    g = golden("g13_spatial")
+    net = UNet(**g.meta["unet_aniso_cfg"], kernel_size=(3, 5))
+    sh = {n: tuple(v) for n, v in g.meta["unet_aniso_shapes"].items()}
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == sh
+    net.load_state_dict(synth.synth_state_dict(sh, 43))
+    y = net.cuda().eval()(g["unet_aniso_x"].cuda(), g["mod"].cuda())
+    sc = max(1.0, g["unet_aniso_y"].abs().max().item())
+    print("UNet kernel (3, 5) max|d|", max_err(y, g["unet_aniso_y"]), "scale", sc)
+    assert max_err(y, g["unet_aniso_y"]) < 2e-5 * sc

@@ -1,0 +1,80 @@
+r"""``Sampler(dtype=torch.float64)`` and fp64 latents on the GPU (G11, reference-generated): the reference's type promotion
+makes the whole elementwise path of such a sampler fp64 while the backbone stays fp32 (azula/sample.py:69-94,
+azula/denoise.py:306-322).  Here: ``az_scale_f64_to_f32`` / ``az_axpby_f64`` / ``az_transition_f64`` around the fp32 backbone
+plans; the output dtype is fp64 like the reference's.  Tolerance: the fp32 backbone's round-off (1e-5 of the scale)."""
+
+import pytest
+import torch
+
+from conftest import max_err
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def unet_denoiser(g):
+    from azula_amd.denoise import KarrasDenoiser
+    from azula_amd.nn import TimeModulated, UNet
+    from azula_amd.noise import VPSchedule
+
+    cfg = g.meta["unet_cfg"]
+    net = UNet(cfg["in_channels"], cfg["out_channels"], hid_channels=cfg["hid_channels"], hid_blocks=cfg["hid_blocks"],
+               norm=cfg["norm"], groups=cfg["groups"], mod_features=cfg["mod_features"])
+    w = TimeModulated(net, cfg["mod_features"], name="unet")
+    w.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["unet_shapes"].items()}, g.meta["unet_weight_seed"]))
+    return KarrasDenoiser(w, VPSchedule()).cuda().eval()
+
+
+def test_fp64_time_grid_matches_reference(golden):
+    from azula_amd.sample import DDIMSampler, EulerSampler, HeunSampler, zABSampler
+
+    g = golden("g11_sampler_dtype")
+    den = unet_denoiser(g)
+    x1 = g["unet_x1"].cuda()
+    x0 = DDIMSampler(den, steps=8, silent=True, dtype=torch.float64)(x1)
+    sc = max(1.0, g["unet_ddim8"].abs().max().item())
+    print("DDIM-8, fp64 grid: max|d|", max_err(x0, g["unet_ddim8"]), "scale", sc)
+    assert x0.dtype == torch.float64 and max_err(x0, g["unet_ddim8"]) < 2e-5 * sc
+    x32 = DDIMSampler(den, steps=8, silent=True)(x1)
+    assert x32.dtype == torch.float32 and max_err(x32, x0) < 1e-4 * sc  # the fp32 sampler agrees to fp32 round-off
+    xh = HeunSampler(den, steps=4, silent=True, dtype=torch.float64)(x1)
+    print("Heun-4, fp64 grid: max|d|", max_err(xh, g["unet_heun4"]))
+    assert xh.dtype == torch.float64 and max_err(xh, g["unet_heun4"]) < 2e-5 * max(1.0, g["unet_heun4"].abs().max().item())
+    xe = EulerSampler(den, steps=6, silent=True, dtype=torch.float64)(x1.double())
+    print("Euler-6, fp64 latents: max|d|", max_err(xe, g["unet_euler6_x64"]))
+    assert xe.dtype == torch.float64 and max_err(xe, g["unet_euler6_x64"]) < 2e-5 * max(1.0, g["unet_euler6_x64"].abs().max().item())
+    with pytest.raises(NotImplementedError):
+        zABSampler(den, order=2, steps=4, silent=True, dtype=torch.float64)(x1)
+
+
+def test_fp64_elementwise_kernels_bit_exact():
+    """az_axpby_f64 / az_scale_f64_to_f32 / az_transition_f64 against torch's fp64 CPU ops, op for op."""
+    import ctypes as C
+
+    from azula_amd import _lib
+    from azula_amd.denoise import axpby_wide, precondition_wide
+    from azula_amd.engine import transition_args
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 5, 7, 9, generator=g, dtype=torch.float64)
+    z32 = torch.randn(3, 5, 7, 9, generator=g)
+    a, b = torch.tensor(0.37, dtype=torch.float64), torch.tensor(-1.9, dtype=torch.float64)
+    assert torch.equal(axpby_wide(a, x.cuda(), b, z32.cuda()).cpu(), a * x + b * z32)
+    ab = torch.randn(3, generator=g, dtype=torch.float64)
+    y = axpby_wide(ab, x.cuda(), 2 * ab, x.cuda().flip(0)).cpu()
+    assert torch.equal(y, ab[:, None, None, None] * x + (2 * ab)[:, None, None, None] * x.flip(0))
+    assert torch.equal(precondition_wide(x.cuda(), a).cpu(), (a * x).to(torch.float32))
+    n = x.numel()
+    m, e = torch.randn(n, generator=g, dtype=torch.float64), torch.randn(n, generator=g, dtype=torch.float64)
+    row = torch.zeros(12, dtype=torch.float64)
+    row[2], row[4], row[5], row[6], row[7], row[9], row[10] = 1.0, 0.3, 0.8, 0.6, 0.2, -float("inf"), float("inf")
+    xs = torch.empty(n, dtype=torch.float64, device="cuda")
+    xf, mc, ec, rc = x.flatten().cuda(), m.cuda(), e.cuda(), row.cuda()
+    arg = transition_args(x_t=xf.data_ptr(), F=mc.data_ptr(), eps=ec.data_ptr(), x_s=xs.data_ptr(), batch=1, channels=1, inner=n,
+                          f_channels=1, coef=rc.data_ptr())
+    _lib.call("az_transition_f64", C.byref(arg), _lib.stream_ptr())
+    ref = 0.8 * m
+    ref = ref + 0.6 * (x.flatten() - 0.3 * m)
+    ref = ref + 0.2 * e
+    assert torch.equal(xs.cpu(), ref)

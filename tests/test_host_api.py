@@ -491,3 +491,19 @@ def test_load_model_from_a_populated_hub_cache(tmp_path, monkeypatch):
             assert torch.equal(a, b), k
     finally:
         hub.set_hub_dir(old)
+
+
+def test_sampler_dtype_float64_promotes_the_latents_like_the_reference(golden):
+    """G11: ``Sampler(dtype=float64)`` -- an fp64 time grid; the (1, ..., 1)-shaped schedule scalars promote the fp32
+    latents, x0 is fp64 (azula/sample.py:69-94, azula/denoise.py:306-322).  Host path: the reference's op sequence."""
+    g = golden("g11_sampler_dtype")
+    net = ToyMLP()
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["toy_shapes"].items()}, g.meta["toy_weight_seed"]))
+    den = KarrasDenoiser(net, VPSchedule()).eval()
+    torch.manual_seed(g.meta["loop_seed"])
+    x0 = DDIMSampler(den, steps=16, silent=True, dtype=torch.float64)(g["toy_x1"])
+    assert x0.dtype == torch.float64
+    torch.testing.assert_close(x0, g["toy_ddim16"], rtol=1e-12, atol=1e-12)
+    torch.manual_seed(g.meta["loop_seed"])
+    x0 = DDPMSampler(den, steps=16, silent=True, dtype=torch.float64)(g["toy_x1"])
+    torch.testing.assert_close(x0, g["toy_ddpm16"], rtol=1e-12, atol=1e-12)
