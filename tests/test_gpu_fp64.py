@@ -60,11 +60,13 @@ def test_fp64_elementwise_kernels_bit_exact():
     x = torch.randn(3, 5, 7, 9, generator=g, dtype=torch.float64)
     z32 = torch.randn(3, 5, 7, 9, generator=g)
     a, b = torch.tensor(0.37, dtype=torch.float64), torch.tensor(-1.9, dtype=torch.float64)
-    assert torch.equal(axpby_wide(a, x.cuda(), b, z32.cuda()).cpu(), a * x + b * z32)
+    # the denoisers' scalars are (1, ..., 1)-SHAPED fp64 tensors: they promote the fp32 operand before the product
+    a4, b4 = a.reshape(1, 1, 1, 1), b.reshape(1, 1, 1, 1)
+    assert torch.equal(axpby_wide(a, x.cuda(), b, z32.cuda()).cpu(), a4 * x + b4 * z32)
     ab = torch.randn(3, generator=g, dtype=torch.float64)
     y = axpby_wide(ab, x.cuda(), 2 * ab, x.cuda().flip(0)).cpu()
     assert torch.equal(y, ab[:, None, None, None] * x + (2 * ab)[:, None, None, None] * x.flip(0))
-    assert torch.equal(precondition_wide(x.cuda(), a).cpu(), (a * x).to(torch.float32))
+    assert torch.equal(precondition_wide(x.cuda(), a).cpu(), (a4 * x).to(torch.float32))
     n = x.numel()
     m, e = torch.randn(n, generator=g, dtype=torch.float64), torch.randn(n, generator=g, dtype=torch.float64)
     row = torch.zeros(12, dtype=torch.float64)
