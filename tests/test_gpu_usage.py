@@ -25,7 +25,7 @@ def test_unusual_but_valid_usages():
     q = den(x, torch.rand(3, device="cuda")); assert q.mean.shape == x.shape and torch.isfinite(q.mean).all()
     # 2. fp64 sampler clock, fp32 latents
     s = DDIMSampler(den, steps=5, silent=True, dtype=torch.float64)
-    x0 = s(s.init(x.shape, device="cuda").float()); assert x0.dtype == torch.float32 and torch.isfinite(x0).all()
+    x0 = s(s.init(x.shape, device="cuda").float()); assert x0.dtype == torch.float64 and torch.isfinite(x0).all()  # promoted like the reference (G11)
     # 3. start/stop other than (1, 0); non-contiguous input
     s = DDPMSampler(den, start=0.8, stop=0.1, steps=4, silent=True)
     x0 = s(x.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)); assert torch.isfinite(x0).all()
