@@ -113,6 +113,9 @@ class AzNormFinalizeArgs(C.Structure):
         ("groups", C.c_int32),
         ("nchunks", C.c_int32),
         ("eps", C.c_float),
+        ("partials1", c_f32p),
+        ("quads_per_group", C.c_int32),
+        ("quads0", C.c_int32),
     ]
 
 
@@ -153,7 +156,8 @@ class AzConvArgs(C.Structure):
         ("splitk", C.c_int32),
         ("workspace", c_f32p),
         ("pad_mode", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("gn_chunks", C.c_int32),
+        ("gn_quads", c_f32p),
     ]
 
 

@@ -105,8 +105,8 @@ __device__ __forceinline__ void epilogue_fetch(const AzConvArgs& a, int n, int b
   if (a.res) res = ld4(a.res + epilogue_res_index(a, n, b) * a.cout_s + co);
 }
 
-__device__ __forceinline__ void epilogue_apply_store(const AzConvArgs& a, int n, int b, int co, float4 v, float4 bv,
-                                                     float4 g, float4 r) {  // bv: bias (zeros if none)
+__device__ __forceinline__ float4 epilogue_apply_store(const AzConvArgs& a, int n, int b, int co, float4 v, float4 bv,
+                                                       float4 g, float4 r) {  // bv: bias (zeros if none); returns what it stored
   if (a.bias) {
     v.x += bv.x;
     v.y += bv.y;
@@ -152,6 +152,7 @@ __device__ __forceinline__ void epilogue_apply_store(const AzConvArgs& a, int n,
   } else {
     *reinterpret_cast<float4*>(a.dst + (int64_t)n * a.cout_s + co) = v;
   }
+  return v;
 }
 
 __device__ __forceinline__ void epilogue_store_b(const AzConvArgs& a, int n, int b, int co, float4 v) {  // b = image of pixel n
@@ -165,7 +166,7 @@ __device__ __forceinline__ void epilogue_store_b(const AzConvArgs& a, int n, int
 // residual reads are issued first, then the NB stores.
 template <int NB>
 __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const int (&n)[NB], const int (&b)[NB], int co,
-                                                     const float4 (&v)[NB], int64_t ws_slab) {
+                                                     const float4 (&v)[NB], int64_t ws_slab, float4* fin = nullptr) {
   if (a.splitk > 1) {
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -183,7 +184,10 @@ __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const 
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i)
-    if (n[i] >= 0) epilogue_apply_store(a, n[i], b[i], co, v[i], bv, g[i], r[i]);
+    if (n[i] >= 0) {
+      const float4 f = epilogue_apply_store(a, n[i], b[i], co, v[i], bv, g[i], r[i]);
+      if (fin) fin[i] = f;  // the stored values: GroupNorm statistics of the output come from here (gn_quads)
+    }
 }
 
 __device__ __forceinline__ void epilogue_store(const AzConvArgs& a, int n, int co, float4 v) {
@@ -1354,7 +1358,61 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
     const float4 v1 = *reinterpret_cast<const float4*>(wsm + WT * W_OT + tile * W_OT + px * WC + cq * 4);
     ov[it] = make_float4(v0.x + v1.x, v0.y + v1.y, v0.z + v1.z, v0.w + v1.w);
   }
-  epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix);
+  if (a.gn_quads == nullptr) {
+    epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix);
+    return;
+  }
+  // ---- GroupNorm statistics of the OUTPUT, for the normalisation that consumes it (the separate statistics pass read
+  // the whole tensor again: 0.38 ms of a C2 step, 10 ms of a C4 step).  The host enables this only when the 64 tiles of
+  // a workgroup lie in one image and cout_s % 64 == 0: every thread owns one channel quad over 8 of the block's 256
+  // pixels; (n, mean, M2) of those 32 values, Chan-combined over the 32 threads of the quad in a fixed order
+  // (deterministic), give one partial per (image, tile block, channel quad) that az_groupnorm_finalize_f32 folds.
+  float4 fin[8];
+  epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix, fin);
+  float cnt = 0.f, sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it)
+    if (on[it] >= 0) {
+      cnt += 4.f;
+      sum += (fin[it].x + fin[it].y) + (fin[it].z + fin[it].w);
+    }
+  const float mean = cnt > 0.f ? sum / cnt : 0.f;
+  float m2 = 0.f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it)
+    if (on[it] >= 0) {
+      const float d0 = fin[it].x - mean, d1 = fin[it].y - mean, d2 = fin[it].z - mean, d3 = fin[it].w - mean;
+      m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  __syncthreads();  // every thread has read its rows of the exchange buffer: reuse it
+  float* sh = wsm;
+  sh[tid] = cnt;
+  sh[512 + tid] = mean;
+  sh[1024 + tid] = m2;
+  __syncthreads();
+  if (tid < 16) {  // cq == tid: fold the 32 threads of this quad, fixed order
+    float an = sh[tid], am = sh[512 + tid], a2 = sh[1024 + tid];
+    for (int k = 1; k < 32; ++k) {
+      const float bn = sh[tid + 16 * k], bm = sh[512 + tid + 16 * k], b2 = sh[1024 + tid + 16 * k];
+      if (bn == 0.f) continue;
+      if (an == 0.f) {
+        an = bn;
+        am = bm;
+        a2 = b2;
+        continue;
+      }
+      const float nn = an + bn, d = bm - am, f = bn / nn;
+      am = am + d * f;
+      a2 = a2 + b2 + d * d * an * f;
+      an = nn;
+    }
+    const int chunk = (t0 - b_first * tiles_img) / WT;
+    float* out = a.gn_quads + ((((int64_t)b_first * a.gn_chunks + chunk) * (a.cout_s / 4)) + (cb * (WC / 4) + tid)) * 4;
+    out[0] = an;
+    out[1] = am;
+    out[2] = a2;
+    out[3] = 0.f;
+  }
 }
 
 // =================================================================================================
@@ -1849,6 +1907,12 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->splitk >= 1 && (a->splitk == 1 || a->workspace), AZ_E_SHAPE);
   const int64_t npix64 = (int64_t)a->batch * a->hout * a->wout;
   AZ_REQUIRE(npix64 < (1ll << 31), AZ_E_SHAPE);
+  if (a->gn_quads) {  // statistics of the output for a following GroupNorm: one tile block = 64 tiles of ONE image
+    const int64_t tiles_img = (int64_t)((a->hout + 1) / 2) * ((a->wout + 1) / 2);
+    AZ_REQUIRE(a->splitk == 1 && !a->dst_nchw && a->cout_s % WC == 0 && tiles_img % WT == 0 &&
+                   a->gn_chunks == tiles_img / WT,
+               AZ_E_UNSUPPORTED);
+  }
 
   WinoP p;
   p.a = *a;

@@ -179,9 +179,24 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(AzNormFinalizeArgs a) {
     return;
   }
   Moments acc = {0.f, 0.f, 0.f};
-  for (int k = lane; k < a.nchunks; k += 64) {
-    const float* p = a.partials + (((int64_t)b * a.nchunks + k) * a.groups + g) * 4;
-    acc = combine(acc, Moments{p[0], p[1], p[2]});
+  if (a.quads_per_group > 0) {
+    // per-(tile block, channel quad) moments written by the producing convolutions' epilogues (AzConvArgs.gn_quads):
+    // group g = quads [g qpg, (g + 1) qpg) of the (possibly two-source) channel axis
+    const int qpg = a.quads_per_group;
+    const int q_lo = g * qpg;
+    const bool second = q_lo >= a.quads0;  // a group never straddles the two sources (checked on the host)
+    const float* base = second ? a.partials1 : a.partials;
+    const int nq = second ? (int)(a.C / 4) - a.quads0 : a.quads0;
+    const int q0 = second ? q_lo - a.quads0 : q_lo;
+    for (int k = lane; k < a.nchunks; k += 64) {
+      const float* p = base + (((int64_t)b * a.nchunks + k) * nq + q0) * 4;
+      for (int j = 0; j < qpg; ++j) acc = combine(acc, Moments{p[4 * j], p[4 * j + 1], p[4 * j + 2]});
+    }
+  } else {
+    for (int k = lane; k < a.nchunks; k += 64) {
+      const float* p = a.partials + (((int64_t)b * a.nchunks + k) * a.groups + g) * 4;
+      acc = combine(acc, Moments{p[0], p[1], p[2]});
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -454,6 +469,12 @@ int az_groupnorm_finalize_f32(const AzNormFinalizeArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->S && a->T && a->partials, AZ_E_NULL);
   AZ_REQUIRE(a->B > 0 && a->C > 0 && a->cs >= a->C && a->groups > 0 && a->C % a->groups == 0 && a->nchunks > 0,
              AZ_E_SHAPE);
+  if (a->quads_per_group > 0) {  // partials from conv epilogues: whole quads per group, groups inside one source
+    const int64_t Cg = a->C / a->groups;
+    AZ_REQUIRE(a->C % 4 == 0 && Cg == 4ll * a->quads_per_group && a->quads0 > 0 && a->quads0 <= a->C / 4 &&
+                   a->quads0 % a->quads_per_group == 0 && (a->quads0 == a->C / 4 || a->partials1 != nullptr),
+               AZ_E_SHAPE);
+  }
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)a->groups + 1, (unsigned)a->B), dim3(64), 0, az_s(stream), *a);
   return az_launch_status();
 }

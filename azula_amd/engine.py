@@ -111,10 +111,11 @@ class Pool:
 class Act:
     r"""An NHWC activation: ``buf`` holds (B, H, W, cs) floats, ``C`` real channels."""
 
-    __slots__ = ("buf", "B", "H", "W", "C", "cs", "pinned")
+    __slots__ = ("buf", "B", "H", "W", "C", "cs", "pinned", "gn_quads")
 
     def __init__(self, buf: torch.Tensor, B: int, H: int, W: int, C_: int, cs: int, pinned: bool = False) -> None:
         self.buf, self.B, self.H, self.W, self.C, self.cs, self.pinned = buf, B, H, W, C_, cs, pinned
+        self.gn_quads = None  # (partials tensor, chunks per image): GroupNorm moments written by the producing conv
 
     @property
     def ptr(self) -> int:
@@ -132,6 +133,8 @@ FP32_MFMA = os.environ.get("AZ_FP32_MFMA", "native")
 assert FP32_MFMA in ("native", "bf16x3"), FP32_MFMA
 X3_MIN_CHANNELS = 32  # bf16x3 only where both channel counts fill a K tile / an MFMA tile
 WINOGRAD4_MIN_TILES = int(os.environ.get("AZ_WINOGRAD4_MIN_TILES", "1024"))
+# GroupNorm statistics from the producing convolution's epilogue ("1", default) or always by the separate pass ("0")
+GN_FUSED = os.environ.get("AZ_GN_FUSED", "1") != "0"
 
 
 class ConvWeights:
@@ -298,6 +301,7 @@ class Builder:
         dst_nchw: torch.Tensor | None = None,
         winograd: bool | int | None = None,
         periodic: bool = False,
+        gn_stats: bool = False,
     ) -> Act | None:
         ks, bias = packed.ks, packed.bias
         pad = ks // 2
@@ -380,6 +384,14 @@ class Builder:
             a.weight = packed.direct().data_ptr()
             a.splitk = lib.az_conv2d_suggest_splitk(npix, a.cout_s, cin_s, ks)
             name = "az_conv2d_f32"
+        if (gn_stats and GN_FUSED and name == "az_conv2d_winograd_f32" and a.splitk == 1 and out is not None and cout == a.cout_s
+                and cout % 64 == 0 and (((hout + 1) // 2) * ((wout + 1) // 2)) % 64 == 0):
+            # the output feeds a GroupNorm: its epilogue also writes per-(tile block, channel quad) moments
+            chunks = (((hout + 1) // 2) * ((wout + 1) // 2)) // 64
+            quads = torch.empty(B * chunks * (cout // 4) * 4, dtype=torch.float32, device=self.device)
+            a.gn_quads, a.gn_chunks = quads.data_ptr(), chunks
+            out.gn_quads = (quads, chunks)
+            self.tape.keep.append(quads)
         if a.splitk > 1:
             self._ws_need = max(self._ws_need, a.splitk * npix * a.cout_s)
             self._ws_users.append(a)
@@ -410,16 +422,28 @@ class Builder:
         input is the channel concatenation [x | x1], read in place (never materialised)."""
         B, HW = x.B, x.H * x.W
         x1p, c0s = None, 0
+        src_quads = [x.gn_quads] + ([x1.gn_quads] if x1 is not None else [])
+        src_channels = [x.C] + ([x1.C] if x1 is not None else [])
         if x1 is not None:
             assert x.C == x.cs and x1.C == x1.cs and (x1.H, x1.W) == (x.H, x.W)
             x1p, c0s = x1.ptr, x.cs
             x = Act(x.buf, x.B, x.H, x.W, x.C + x1.C, x.cs + x1.cs, True)
-        nchunks = int(min(512, max(1, (HW * x.cs * 4) // 65536)))  # ~64 KB of x per workgroup
-        partials = self.empty(B * nchunks * groups * 4)
         S, T = self.empty(B * x.cs), self.empty(B * x.cs)
-        self.tape.add("az_groupnorm_stats_f32", partials.data_ptr(), x.ptr, x1p, c0s, B, HW, x.C, x.cs, groups, nchunks)
         f = AzNormFinalizeArgs()
-        f.S, f.T, f.partials = S.data_ptr(), T.data_ptr(), partials.data_ptr()
+        Cg = x.C // groups
+        fused = src_quads is not None and Cg % 4 == 0 and x.C == x.cs and all(q is not None for q in src_quads) \
+            and len({q[1] for q in src_quads}) == 1 and all((c // 4) % (Cg // 4) == 0 for c in src_channels)
+        if fused:  # every source was produced by a convolution that left its moments: no statistics pass
+            nchunks = src_quads[0][1]
+            f.partials = src_quads[0][0].data_ptr()
+            f.partials1 = src_quads[1][0].data_ptr() if len(src_quads) > 1 else None
+            f.quads_per_group, f.quads0 = Cg // 4, src_channels[0] // 4
+        else:
+            nchunks = int(min(512, max(1, (HW * x.cs * 4) // 65536)))  # ~64 KB of x per workgroup
+            partials = self.empty(B * nchunks * groups * 4)
+            self.tape.add("az_groupnorm_stats_f32", partials.data_ptr(), x.ptr, x1p, c0s, B, HW, x.C, x.cs, groups, nchunks)
+            f.partials = partials.data_ptr()
+        f.S, f.T = S.data_ptr(), T.data_ptr()
         f.weight = weight.data_ptr() if weight is not None else None
         f.bias = bias.data_ptr() if bias is not None else None
         f.scale = scale.data_ptr() + 4 * scale_off if scale is not None else None

@@ -113,7 +113,7 @@ class UNetBlock(nn.Module):
         h1 = bld.conv(n_, bld.pack_conv(c0.weight, c0.bias), c0.out_channels, act=1, periodic=self.periodic)
         bld.free(n_)
         y = bld.conv(h1, bld.pack_conv(c3.weight, c3.bias), c3.out_channels, gate=abc, gate_off=2 * cs, gate_bstride=bstride,
-                     res=x, periodic=self.periodic)
+                     res=x, periodic=self.periodic, gn_stats=self.norm_kind == "group")  # feeds the next block's norm
         bld.free(h1)
         if not keep_input:
             bld.free(x)
@@ -196,6 +196,7 @@ class UNetPlan:
 
         mod_jobs: list[tuple] = []  # queued modulation MLPs (ada_zero_triple), emitted together at the tape front
         per = net.periodic
+        gn = any(isinstance(m, UNetBlock) and m.norm_kind == "group" for m in net.modules())
 
         def block(blk: UNetBlock, x: Act, keep_input: bool) -> Act:
             return blk._emit(bld, x, D, mod_rows, mod_jobs, keep_input)
@@ -206,7 +207,8 @@ class UNetPlan:
             first = net.descent[i][0]
             if i > 0:
                 skips.append(cur)  # output of level i-1 = memory entry (unet.py:226-230)
-            nxt = bld.conv(cur, bld.pack_conv(first.weight, first.bias), first.out_channels, stride=stride if i > 0 else 1, periodic=per)
+            nxt = bld.conv(cur, bld.pack_conv(first.weight, first.bias), first.out_channels, stride=stride if i > 0 else 1, periodic=per,
+                           gn_stats=gn)
             cur = nxt
             for j in range(net.hid_blocks[i]):
                 cur = block(net.descent[i][1 + j], cur, keep_input=False)
@@ -219,7 +221,7 @@ class UNetPlan:
                 conv = mods[0]
                 merged = bld.conv(
                     y, bld.pack_conv(conv.weight, conv.bias, cin0=y.C), conv.out_channels, src1=cur, up1=1,
-                    hin=y.H, win=y.W, periodic=per,
+                    hin=y.H, win=y.W, periodic=per, gn_stats=gn,
                 )
                 bld.free(cur)
                 bld.free(y)

@@ -150,7 +150,7 @@ class ADMPlan:
             fbs = 2 * ocs if emb_rows > 1 else 0
             # h = conv(updown(SiLU(GN(x))))
             n1 = bld.group_norm(x, 32, weight=bld.const(gi.weight), bias=bld.const(gi.bias), act=1, pool=int(rb.down), x1=x1)
-            h = bld.conv(n1, bld.pack_conv(ci.weight, ci.bias), oc, up0=int(rb.up))
+            h = bld.conv(n1, bld.pack_conv(ci.weight, ci.bias), oc, up0=int(rb.up), gn_stats=True)  # -> out_layers' GroupNorm
             bld.free(n1)
             # h = SiLU(GN(h) * (1 + scale) + shift)
             n2 = bld.group_norm(h, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), scale=film, shift=film,
@@ -162,18 +162,18 @@ class ADMPlan:
                 ones, zeros = bld.const(torch.ones(B * x.cs)), bld.const(torch.zeros(B * x.cs))
                 xs = bld.new_act(B, x.H // 2, x.W // 2, x.C)
                 bld.tape.add("az_affine_act_f32", xs.ptr, x.ptr, None, 0, ones.data_ptr(), zeros.data_ptr(), B, x.H, x.W, x.cs, 0, 1)
-                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=xs)
+                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=xs, gn_stats=True)
                 bld.free(xs)
             elif rb.up:
                 assert x1 is None
-                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=x, res_up=1)
+                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=x, res_up=1, gn_stats=True)
             elif isinstance(rb.skip_connection, nn.Identity):
                 assert x1 is None
-                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=x)
+                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=x, gn_stats=True)
             else:
                 sc = rb.skip_connection
                 skip = bld.conv(x, bld.pack_conv(sc.weight, sc.bias, cin0=x.C if x1 is not None else None), oc, src1=x1)
-                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=skip)
+                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=skip, gn_stats=True)
                 bld.free(skip)
             bld.free(n2)
             return out
@@ -195,7 +195,7 @@ class ADMPlan:
         def run(block: nn.Sequential, h: Act, h1: Act | None = None) -> Act:
             for layer in block:
                 if isinstance(layer, nn.Conv2d):
-                    nh = bld.conv(h, bld.pack_conv(layer.weight, layer.bias), layer.out_channels)
+                    nh = bld.conv(h, bld.pack_conv(layer.weight, layer.bias), layer.out_channels, gn_stats=True)
                 elif isinstance(layer, ResBlock):
                     nh = resblock(layer, h, h1)
                 else:

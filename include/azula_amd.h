@@ -203,6 +203,11 @@ typedef struct AzNormFinalizeArgs {
   int64_t B, C, cs;
   int32_t groups, nchunks;
   float eps;
+  /* partials produced by convolution epilogues (AzConvArgs.gn_quads) instead of az_groupnorm_stats_f32:
+   * quads_per_group > 0 selects the layout (B, nchunks, quads, 4) with `quads0` channel quads in `partials` and, for a
+   * two-source input (channel concatenation), the rest in `partials1`; group g folds quads [g qpg, (g + 1) qpg). */
+  const float* partials1;
+  int32_t quads_per_group, quads0;
 } AzNormFinalizeArgs;
 int az_groupnorm_finalize_f32(const AzNormFinalizeArgs* args, az_stream_t stream);
 /* pool: 0 none, 1 = 2x2 average pool of act(.) (needs H, W even; dst is (B, H/2*W/2, cs)).      */
@@ -258,7 +263,11 @@ typedef struct AzConvArgs {
   int32_t splitk;          /* >= 1; > 1 needs workspace of splitk * B*hout*wout * cout_s floats */
   float* workspace;
   int32_t pad_mode;        /* 0: zero padding; 1: circular ("periodic", azula/nn/unet.py:175-180): taps wrap around the map */
-  int32_t reserved_;
+  int32_t gn_chunks;       /* with gn_quads: tile blocks (of 64 Winograd tiles) per image */
+  float* gn_quads;         /* optional (az_conv2d_winograd_f32, splitk 1, cout_s % 64 == 0, 64 | tiles per image): GroupNorm
+                            * moments of the OUTPUT, (batch, gn_chunks, cout_s / 4, 4) floats = (n, mean, M2, 0) per image,
+                            * tile block and channel quad -- consumed by az_groupnorm_finalize_f32 (quads_per_group) so that
+                            * the normalisation that follows needs no statistics pass over the tensor */
 } AzConvArgs;
 /* Narrow outputs (cout_s == 4, 3x3 stride 1 pad 1, one un-upsampled source with c0s % 16 == 0: the image head of
  * azula/nn/unet.py) run a VALU kernel instead of the 128-cout MFMA tile; splitk is ignored there.              */
