@@ -164,9 +164,12 @@ __device__ __forceinline__ void epilogue_store_b(const AzConvArgs& a, int n, int
 
 // A batch of NB outputs of one thread (same channel quad `co`, pixels n[i] of images b[i]; n[i] < 0: skip): all gate /
 // residual reads are issued first, then the NB stores.
-template <int NB>
+// MOM: also accumulate the moments of the STORED values about the first one (mom = {pivot, sum d, sum d^2}) -- on the
+// fly, so that nothing but three registers outlives the stores (keeping the 8 stored float4s alive made the compiler
+// shuffle the gate / residual registers after each load, i.e. wait for every load separately: +5 % on the layer).
+template <int NB, bool MOM = false>
 __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const int (&n)[NB], const int (&b)[NB], int co,
-                                                     const float4 (&v)[NB], int64_t ws_slab, float4* fin = nullptr) {
+                                                     const float4 (&v)[NB], int64_t ws_slab, float* mom = nullptr) {
   if (a.splitk > 1) {
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -186,7 +189,12 @@ __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const 
   for (int i = 0; i < NB; ++i)
     if (n[i] >= 0) {
       const float4 f = epilogue_apply_store(a, n[i], b[i], co, v[i], bv, g[i], r[i]);
-      if (fin) fin[i] = f;  // the stored values: GroupNorm statistics of the output come from here (gn_quads)
+      if constexpr (MOM) {  // GroupNorm statistics of the output come from here (gn_quads)
+        if (i == 0) mom[0] = f.x;
+        const float d0 = f.x - mom[0], d1 = f.y - mom[0], d2 = f.z - mom[0], d3 = f.w - mom[0];
+        mom[1] += (d0 + d1) + (d2 + d3);
+        mom[2] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
     }
 }
 
@@ -1078,7 +1086,7 @@ constexpr int WU_STAGE = 16 * WC * WK; // floats
 constexpr int WV_STAGE = 16 * WT * WK;
 constexpr int W_STAGE = WU_STAGE + WV_STAGE;  // 16384 floats = 64 KB; two stages = 128 KB
 constexpr int W_OT = 4 * WC + 4;              // epilogue: floats per tile row of the [tile][pixel][cout] exchange buffer
-constexpr int W_LDS_BYTES = (2 * WT * W_OT + 3 * WT) * 4;  // 133,888 B >= the two K-loop stages
+constexpr int W_LDS_BYTES = (2 * WT * W_OT + 3 * WT + 384) * 4;  // 135,424 B >= the two K-loop stages (+384: GroupNorm partials)
 
 struct WinoP {
   AzConvArgs a;
@@ -1367,45 +1375,40 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   // a workgroup lie in one image and cout_s % 64 == 0: every thread owns one channel quad over 8 of the block's 256
   // pixels; (n, mean, M2) of those 32 values, Chan-combined over the 32 threads of the quad in a fixed order
   // (deterministic), give one partial per (image, tile block, channel quad) that az_groupnorm_finalize_f32 folds.
-  float4 fin[8];
-  epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix, fin);
-  float cnt = 0.f, sum = 0.f;
-#pragma unroll
-  for (int it = 0; it < 8; ++it)
-    if (on[it] >= 0) {
-      cnt += 4.f;
-      sum += (fin[it].x + fin[it].y) + (fin[it].z + fin[it].w);
-    }
-  const float mean = cnt > 0.f ? sum / cnt : 0.f;
-  float m2 = 0.f;
-#pragma unroll
-  for (int it = 0; it < 8; ++it)
-    if (on[it] >= 0) {
-      const float d0 = fin[it].x - mean, d1 = fin[it].y - mean, d2 = fin[it].z - mean, d3 = fin[it].w - mean;
-      m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    }
-  __syncthreads();  // every thread has read its rows of the exchange buffer: reuse it
-  float* sh = wsm;
-  sh[tid] = cnt;
-  sh[512 + tid] = mean;
-  sh[1024 + tid] = m2;
+  float mom[3] = {0.f, 0.f, 0.f};
+  epilogue_store_batch<8, true>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix, mom);
+  // 32 values per thread (the host admits no ragged tiles here): mean and M2 from the pivoted sums, then Chan's pairwise
+  // combination with EQUAL counts as a fixed tree (deterministic) -- lanes cq + 16 j of a wave by two cross-lane steps,
+  // the 8 waves through LDS past the tile table (no barrier before the writes).
+  float am = mom[0] + mom[1] * (1.f / 32.f);
+  float a2 = mom[2] - mom[1] * mom[1] * (1.f / 32.f);
+  auto chan = [](float& am, float& a2, float bm, float b2, float half_n) {  // both sides hold 2 * half_n values
+    const float d = bm - am;
+    am = am + 0.5f * d;
+    a2 = (a2 + b2) + d * d * half_n;
+  };
+  chan(am, a2, __shfl_xor(am, 16), __shfl_xor(a2, 16), 16.f);
+  chan(am, a2, __shfl_xor(am, 32), __shfl_xor(a2, 32), 32.f);
+  float* sh = reinterpret_cast<float*>(tinfo + 3 * WT);
+  if (lane < 16) {
+    sh[wave * 16 + lane] = am;
+    sh[128 + wave * 16 + lane] = a2;
+  }
   __syncthreads();
-  if (tid < 16) {  // cq == tid: fold the 32 threads of this quad, fixed order
-    float an = sh[tid], am = sh[512 + tid], a2 = sh[1024 + tid];
-    for (int k = 1; k < 32; ++k) {
-      const float bn = sh[tid + 16 * k], bm = sh[512 + tid + 16 * k], b2 = sh[1024 + tid + 16 * k];
-      if (bn == 0.f) continue;
-      if (an == 0.f) {
-        an = bn;
-        am = bm;
-        a2 = b2;
-        continue;
-      }
-      const float nn = an + bn, d = bm - am, f = bn / nn;
-      am = am + d * f;
-      a2 = a2 + b2 + d * d * an * f;
-      an = nn;
+  if (tid < 16) {
+    float wm[8], w2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      wm[k] = sh[k * 16 + tid];
+      w2[k] = sh[128 + k * 16 + tid];
     }
+    float hn = 64.f;  // each wave's partial: 128 values
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1, hn *= 2.f)
+#pragma unroll
+      for (int k = 0; k < 8; k += 2 * o) chan(wm[k], w2[k], wm[k + o], w2[k + o], hn);
+    const float an = 1024.f;
+    am = wm[0], a2 = w2[0];
     const int chunk = (t0 - b_first * tiles_img) / WT;
     float* out = a.gn_quads + ((((int64_t)b_first * a.gn_chunks + chunk) * (a.cout_s / 4)) + (cb * (WC / 4) + tid)) * 4;
     out[0] = an;
@@ -1909,8 +1912,8 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(npix64 < (1ll << 31), AZ_E_SHAPE);
   if (a->gn_quads) {  // statistics of the output for a following GroupNorm: one tile block = 64 tiles of ONE image
     const int64_t tiles_img = (int64_t)((a->hout + 1) / 2) * ((a->wout + 1) / 2);
-    AZ_REQUIRE(a->splitk == 1 && !a->dst_nchw && a->cout_s % WC == 0 && tiles_img % WT == 0 &&
-                   a->gn_chunks == tiles_img / WT,
+    AZ_REQUIRE(a->splitk == 1 && !a->dst_nchw && a->cout_s % WC == 0 && tiles_img % WT == 0 && a->hout % 2 == 0 &&
+                   a->wout % 2 == 0 && a->gn_chunks == tiles_img / WT,  // whole 2 x 2 tiles only: 1024 values per partial
                AZ_E_UNSUPPORTED);
   }
 

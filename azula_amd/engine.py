@@ -385,9 +385,9 @@ class Builder:
             a.splitk = lib.az_conv2d_suggest_splitk(npix, a.cout_s, cin_s, ks)
             name = "az_conv2d_f32"
         if (gn_stats and GN_FUSED and name == "az_conv2d_winograd_f32" and a.splitk == 1 and out is not None and cout == a.cout_s
-                and cout % 64 == 0 and (((hout + 1) // 2) * ((wout + 1) // 2)) % 64 == 0):
+                and cout % 64 == 0 and hout % 2 == 0 and wout % 2 == 0 and ((hout // 2) * (wout // 2)) % 64 == 0):
             # the output feeds a GroupNorm: its epilogue also writes per-(tile block, channel quad) moments
-            chunks = (((hout + 1) // 2) * ((wout + 1) // 2)) // 64
+            chunks = ((hout // 2) * (wout // 2)) // 64
             quads = torch.empty(B * chunks * (cout // 4) * 4, dtype=torch.float32, device=self.device)
             a.gn_quads, a.gn_chunks = quads.data_ptr(), chunks
             out.gn_quads = (quads, chunks)
