@@ -164,9 +164,71 @@ __device__ __forceinline__ void epilogue_store_b(const AzConvArgs& a, int n, int
 
 // A batch of NB outputs of one thread (same channel quad `co`, pixels n[i] of images b[i]; n[i] < 0: skip): all gate /
 // residual reads are issued first, then the NB stores.
-// MOM: also accumulate the moments of the STORED values about the first one (mom = {pivot, sum d, sum d^2}) -- on the
-// fly, so that nothing but three registers outlives the stores (keeping the 8 stored float4s alive made the compiler
-// shuffle the gate / residual registers after each load, i.e. wait for every load separately: +5 % on the layer).
+// Straight-line form of the batch for the NHWC destination with act in {none, SiLU}: (ACT, GATE, RES) are compile-time,
+// so the NB iterations contain no scalar branch -- only exec-masked loads / stores.  With branches in the body the
+// compiler cannot count outstanding memory operations across them and waits with vmcnt(0) at the top of every
+// iteration, i.e. for the previous iteration's STORE to be acknowledged (stores count in vmcnt on gfx9): the store
+// phase of a workgroup was 8 serialised L2 round trips.  RES: 0 none, 1 same pixel, 2 upsampled / broadcast index.
+// MOM: also accumulate the moments of the STORED values about the first one (mom = {pivot, sum d, sum d^2}) on the fly
+// (nothing but three registers outlives the stores).
+template <int NB, bool MOM, int ACT, bool GATE, int RES>
+__device__ __forceinline__ void epilogue_batch_nhwc(const AzConvArgs& a, const int (&n)[NB], const int (&b)[NB], int co,
+                                                    const float4 (&v)[NB], float* mom) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool has_bias = a.bias != nullptr;
+  // unconditional load (from the filter when there is no bias; the value is then unused): a load inside a branch is
+  // waited for at the end of that branch, one more round trip in front of the gate / residual reads
+  const float4 bv = ld4(has_bias ? a.bias + co : reinterpret_cast<const float*>(a.weight));
+  float4 g[NB], r[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    g[i] = z;
+    r[i] = z;
+    if (n[i] >= 0) {
+      if constexpr (GATE) g[i] = ld4(a.gate + (int64_t)b[i] * a.gate_bstride + co);
+      if constexpr (RES == 1) r[i] = ld4(a.res + (int64_t)n[i] * a.cout_s + co);
+      if constexpr (RES == 2) r[i] = ld4(a.res + epilogue_res_index(a, n[i], b[i]) * a.cout_s + co);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    float4 f = v[i];
+    if (has_bias) {  // a select, not a branch: x + 0 would turn -0 into +0
+      f.x += bv.x;
+      f.y += bv.y;
+      f.z += bv.z;
+      f.w += bv.w;
+    }
+    if constexpr (ACT == 1) {
+      f.x = az_silu(f.x);
+      f.y = az_silu(f.y);
+      f.z = az_silu(f.z);
+      f.w = az_silu(f.w);
+    }
+    if constexpr (GATE) {
+      f.x *= g[i].x;
+      f.y *= g[i].y;
+      f.z *= g[i].z;
+      f.w *= g[i].w;
+    }
+    if constexpr (RES != 0) {
+      f.x += r[i].x;
+      f.y += r[i].y;
+      f.z += r[i].z;
+      f.w += r[i].w;
+    }
+    if (n[i] >= 0) *reinterpret_cast<float4*>(a.dst + (int64_t)n[i] * a.cout_s + co) = f;
+    if constexpr (MOM) {  // GroupNorm statistics of the output come from here (gn_quads; the host admits no skipped pixel)
+      if (i == 0) mom[0] = f.x;
+      const float d0 = f.x - mom[0], d1 = f.y - mom[0], d2 = f.z - mom[0], d3 = f.w - mom[0];
+      mom[1] += (d0 + d1) + (d2 + d3);
+      mom[2] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+}
+
+// A batch of NB outputs of one thread (same channel quad `co`, pixels n[i] of images b[i]; n[i] < 0: skip): all gate /
+// residual reads are issued first, then the NB stores.
 template <int NB, bool MOM = false>
 __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const int (&n)[NB], const int (&b)[NB], int co,
                                                      const float4 (&v)[NB], int64_t ws_slab, float* mom = nullptr) {
@@ -175,6 +237,17 @@ __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const 
     for (int i = 0; i < NB; ++i)
       if (n[i] >= 0) *reinterpret_cast<float4*>(a.workspace + (ws_slab + n[i]) * a.cout_s + co) = v[i];
     return;
+  }
+  if (!a.dst_nchw && a.act <= 1) {
+    const int rk = a.res == nullptr ? 0 : (a.res_up || a.res_bcast) ? 2 : 1;
+    switch ((a.act * 2 + (a.gate != nullptr ? 1 : 0)) * 3 + rk) {
+#define AZ_EPI_CASE(ACT, GATE, RES) \
+  case (ACT * 2 + GATE) * 3 + RES:  \
+    return epilogue_batch_nhwc<NB, MOM, ACT, GATE != 0, RES>(a, n, b, co, v, mom);
+      AZ_EPI_CASE(0, 0, 0) AZ_EPI_CASE(0, 0, 1) AZ_EPI_CASE(0, 0, 2) AZ_EPI_CASE(0, 1, 0) AZ_EPI_CASE(0, 1, 1) AZ_EPI_CASE(0, 1, 2)
+      AZ_EPI_CASE(1, 0, 0) AZ_EPI_CASE(1, 0, 1) AZ_EPI_CASE(1, 0, 2) AZ_EPI_CASE(1, 1, 0) AZ_EPI_CASE(1, 1, 1) AZ_EPI_CASE(1, 1, 2)
+#undef AZ_EPI_CASE
+    }
   }
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 bv = a.bias ? ld4(a.bias + co) : z;
@@ -189,7 +262,7 @@ __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const 
   for (int i = 0; i < NB; ++i)
     if (n[i] >= 0) {
       const float4 f = epilogue_apply_store(a, n[i], b[i], co, v[i], bv, g[i], r[i]);
-      if constexpr (MOM) {  // GroupNorm statistics of the output come from here (gn_quads)
+      if constexpr (MOM) {
         if (i == 0) mom[0] = f.x;
         const float d0 = f.x - mom[0], d1 = f.y - mom[0], d2 = f.z - mom[0], d3 = f.w - mom[0];
         mom[1] += (d0 + d1) + (d2 + d3);
