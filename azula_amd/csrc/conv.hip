@@ -1239,15 +1239,26 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
     const int up = src ? a.up1 : a.up0;
     const int hs = src ? a.h1 : a.h0;
     const int ws = src ? a.w1 : a.w0;
+    // the patch address is separable: 4 row parts + 4 column parts (8 wraps / bounds tests, not 32 -- the prologue of a
+    // workgroup was ~1400 instructions of this, 3 % of a Cin = 256 layer)
+    int rpart[4], cpart[4];
+    bool rok[4], cok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ih = wrap_coord(v_ih0 + r, a.hin, a.pad_mode);
+      rok[r] = v_b >= 0 && (unsigned)ih < (unsigned)a.hin;
+      rpart[r] = (v_b * hs + (ih >> up)) * ws * cs * 4;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int iw = wrap_coord(v_iw0 + c, a.win, a.pad_mode);
+      cok[c] = (unsigned)iw < (unsigned)a.win;
+      cpart[c] = ((iw >> up) * cs + vq * 2) * 4;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int ih = wrap_coord(v_ih0 + r, a.hin, a.pad_mode), iw = wrap_coord(v_iw0 + c, a.win, a.pad_mode);
-        const bool ok = v_b >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
-        const int pix = (v_b * hs + (ih >> up)) * ws + (iw >> up);
-        voffV[r * 4 + c] = ok ? (unsigned)((pix * cs + vq * 2) * 4) : OOB;
-      }
+      for (int c = 0; c < 4; ++c) voffV[r * 4 + c] = rok[r] && cok[c] ? (unsigned)(rpart[r] + cpart[c]) : OOB;
   };
 
   f32x2 rv[16];  // V role: raw 4x4 patch of a channel pair; U role: 8 filter float4 (rv[2i], rv[2i+1])
