@@ -618,3 +618,96 @@ def test_conv2d_half_operands(az, B, Cin, Cout, H, W, ks, stride, half):
     eps = 2.0**-8 if half == torch.bfloat16 else 2.0**-11
     assert max_err(out, ref) < 4 * eps * max(1.0, ref.abs().max().item())
     assert (y.buf.reshape(B, y.H, y.W, y.cs)[..., Cout:] == 0).all()
+
+
+@pytest.mark.parametrize("wino", [False, True])
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+@pytest.mark.parametrize("gated", [False, True])
+@pytest.mark.parametrize("res_kind", ["none", "same", "up", "nobias"])
+def test_conv2d_epilogue_forms(az, wino, act, gated, res_kind):
+    """Every (activation, gate, residual) form of the fused epilogue: the NHWC store batch is compiled per combination
+    (conv.hip `epilogue_batch_nhwc`), the rest goes through the generic path; order ((v + bias) -> act) * gate + res."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(100 * act + 10 * gated + len(res_kind))
+    B, Cin, Cout, H, W = 2, 24, 64, 16, 18
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = None if res_kind == "nobias" else torch.randn(Cout, generator=g)
+    gate = torch.randn(B, Cout, generator=g) if gated else None
+    res = {"none": None, "nobias": None, "same": torch.randn(B, Cout, H, W, generator=g),
+           "up": torch.randn(B, Cout, H // 2, W // 2, generator=g)}[res_kind]
+    ref = F.conv2d(x, w, b, padding=1)
+    ref = [ref, F.silu(ref), F.relu(ref), F.relu(ref) ** 2][act]
+    if gated:
+        ref = ref * gate[:, :, None, None]
+    if res is not None:
+        ref = ref + (res if res_kind == "same" else F.interpolate(res, scale_factor=(2.0, 2.0), mode="nearest"))
+    bld = Builder(torch.device("cuda"))
+    xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
+    ra = None
+    if res is not None:
+        ra = Act(to_nhwc(dev(res)).reshape(-1), B, res.shape[2], res.shape[3], Cout, Cout, True)
+    y = bld.conv(xa, bld.pack_conv(dev(w), dev(b) if b is not None else None), Cout, act=act,
+                 gate=dev(gate) if gated else None, gate_bstride=Cout, res=ra, res_up=int(res_kind == "up"), winograd=wino)
+    bld.finish()
+    assert [n for _, _, n in bld.tape.ops if n.startswith("az_conv2d")] == [WINO_NAME[wino]]
+    bld.tape.run()
+    err = max_err(from_nhwc(y.buf.reshape(B, H, W, Cout), Cout), ref)
+    assert err < conv_tol(Cin, 3, wino) * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("form", ["plain", "gate_res", "silu", "concat", "mixed"])
+def test_groupnorm_statistics_from_the_conv_epilogue(az, form, monkeypatch):
+    """AzConvArgs.gn_quads: the Winograd epilogue leaves (n, mean, M2) per (image, 64-tile block, channel quad) and the
+    following GroupNorm skips its statistics pass.  Checked against torch's group_norm of the torch conv, with a large
+    common offset (bias 30, residual mean 50: mean >> std, the case a naive sum-of-squares loses) and against the
+    separate statistics pass on the same convolution output (AZ_GN_FUSED = 0)."""
+    from azula_amd import engine
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(len(form))
+    B, Cin, Cout, H, W, groups = 2, 16, 128, 32, 16, 32  # 16 x 8 tiles = 2 tile blocks per image
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g) + 30.0
+    gate = torch.randn(B, Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g) * 0.5 + 50.0
+    gw, gb = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    conv = F.conv2d(x, w, b, padding=1)
+    if form in ("gate_res", "concat", "mixed"):
+        conv = conv * gate[:, :, None, None] + res
+    elif form == "silu":
+        conv = F.silu(conv)
+    w2 = torch.randn(128, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    conv2 = F.conv2d(x, w2, None, padding=1)
+    two = form in ("concat", "mixed")
+    full = torch.cat((conv, conv2), 1) if two else conv
+    C2 = full.shape[1]
+    gw, gb = torch.randn(C2, generator=g), torch.randn(C2, generator=g)
+    ref = F.silu(F.group_norm(full, groups, gw, gb, eps=1e-5))
+
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(engine, "GN_FUSED", fused)
+        bld = Builder(torch.device("cuda"))
+        xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
+        ra = Act(to_nhwc(dev(res)).reshape(-1), B, H, W, Cout, Cout, True)
+        kw = dict(gate=dev(gate), gate_bstride=Cout, res=ra) if form in ("gate_res", "concat", "mixed") else {}
+        y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, act=int(form == "silu"), winograd=True, gn_stats=True, **kw)
+        y1 = None
+        if two:  # "mixed": the second source carries no moments -> the whole norm falls back to the statistics pass
+            y1 = bld.conv(xa, bld.pack_conv(dev(w2), None), 128, winograd=True, gn_stats=form == "concat")
+        n = bld.group_norm(y, groups, weight=dev(gw), bias=dev(gb), act=1, x1=y1)
+        bld.finish()
+        names = [nm for _, _, nm in bld.tape.ops]
+        assert (y.gn_quads is not None) == fused
+        assert ("az_groupnorm_stats_f32" in names) == (not fused or form == "mixed"), names
+        bld.tape.run()
+        outs[fused] = from_nhwc(n.buf.reshape(B, H, W, C2), C2).clone()
+        bld.tape.run()
+        assert torch.equal(from_nhwc(n.buf.reshape(B, H, W, C2), C2), outs[fused]), "not deterministic"
+    e_ref, e_ab = max_err(outs[True], ref), max_err(outs[True], outs[False])
+    print(f"{form}: fused vs torch {e_ref:.2e}, fused vs separate pass {e_ab:.2e}")
+    assert e_ref < 6e-5 and max_err(outs[False], ref) < 6e-5  # measured 2.9e-6 .. 1.3e-5 (O(1) outputs from data with mean/std up to 100)
+    assert e_ab < 2.5e-5  # measured <= 4.8e-6
