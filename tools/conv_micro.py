@@ -22,7 +22,7 @@ x = Act(torch.randn(B * H * W * Cin, device=dev) * scale, B, H, W, Cin, Cin, Tru
 w = torch.randn(Cout, Cin, ks, ks, device=dev) / (Cin * ks * ks) ** 0.5 * scale
 b = torch.randn(Cout, device=dev)
 wino = {"1": True, "0": False, "4": 4, "x3": "x3"}.get(os.environ.get("AZ_WINO", ""), None)
-y = bld.conv(x, bld.pack_conv(w, b), Cout, stride=stride, act=1, winograd=wino, gn_stats=bool(os.environ.get("AZ_GN")))
+y = bld.conv(x, bld.pack_conv(w, b), Cout, stride=stride, act=int(os.environ.get("AZ_ACT", "1")), winograd=wino, gn_stats=bool(os.environ.get("AZ_GN")))
 bld.finish()
 desc = bld.tape.keep[-1] if hasattr(bld.tape.keep[-1], "_flops") else [k for k in bld.tape.keep if hasattr(k, "_flops")][-1]
 for _ in range(3):
