@@ -55,6 +55,31 @@ class ResBlock(nn.Module):
         self.skip_connection = nn.Identity() if oc == channels else nn.Conv2d(channels, oc, 1)
 
 
+class Downsample(nn.Module):
+    r"""Parameter holder of the ``resblock_updown=False`` downsampling layer: a stride-2 3x3 convolution ``op`` or a
+    2x2 average pool (reference ``_src/unet.py:111-137``)."""
+
+    def __init__(self, channels, use_conv, out_channels=None):
+        super().__init__()
+        self.channels, self.out_channels, self.use_conv = channels, out_channels or channels, use_conv
+        if use_conv:
+            self.op = nn.Conv2d(channels, self.out_channels, 3, stride=2, padding=1)
+        else:
+            assert self.channels == self.out_channels
+            self.op = nn.AvgPool2d(2, 2)
+
+
+class Upsample(nn.Module):
+    r"""Parameter holder of the ``resblock_updown=False`` upsampling layer: nearest x2, then an optional 3x3
+    convolution ``conv`` (reference ``_src/unet.py:82-109``)."""
+
+    def __init__(self, channels, use_conv, out_channels=None):
+        super().__init__()
+        self.channels, self.out_channels, self.use_conv = channels, out_channels or channels, use_conv
+        if use_conv:
+            self.conv = nn.Conv2d(channels, self.out_channels, 3, padding=1)
+
+
 class AttentionBlock(nn.Module):
     r"""Parameter holder: norm, qkv (Conv1d k=1), zero-init proj_out (reference ``_src/unet.py:250-296``)."""
 
@@ -104,6 +129,8 @@ class ADMPlan:
         self.t_idx = torch.zeros(emb_rows, dtype=torch.int64, device=device)
         self.labels = torch.zeros(B, dtype=torch.int64, device=device) if net.num_classes is not None else None
         temb = bld.empty(emb_rows, mc)
+        row0 = torch.zeros(B, dtype=torch.int64, device=device)  # index vector that replicates a single row per sample
+        bld.tape.keep.append(row0)  # (int64: Builder.const would cast it to fp32 and halve its size)
         if coef_ptr is not None:  # fused sampling: row index = the step's time_index, read on the device
             assert emb_rows == 1 or net.num_classes is not None
             bld.tape.add("az_gather_step_row_f32", temb.data_ptr(), self.table.data_ptr(), coef_ptr, 0, mc, net.table_steps)
@@ -126,7 +153,7 @@ class ADMPlan:
             ones = bld.const(torch.ones(1))
             if trow == 1:
                 tb = bld.empty(B, E)
-                bld.tape.add("az_gather_rows_f32", tb.data_ptr(), tbase.data_ptr(), bld.const(torch.zeros(B, dtype=torch.int64)).data_ptr(), B, E, 1)
+                bld.tape.add("az_gather_rows_f32", tb.data_ptr(), tbase.data_ptr(), row0.data_ptr(), B, E, 1)
                 tbase = tb
             bld.tape.add("az_axpby_f32", emb.data_ptr(), ones.data_ptr(), tbase.data_ptr(), ones.data_ptr(), lab.data_ptr(), 1, B * E, 0)
         ebs = E if emb_rows > 1 else 0  # batch stride of emb rows
@@ -140,21 +167,34 @@ class ADMPlan:
             go, co = rb.out_layers[0], rb.out_layers[3]
             # FiLM table: emb_layers = SiLU -> Linear(E, 2*oc); (scale | shift) padded to ocs each
             lin = rb.emb_layers[1]
-            w = torch.zeros(2 * ocs, E, dtype=torch.float32, device=device)
-            b_ = torch.zeros(2 * ocs, dtype=torch.float32, device=device)
-            for n in range(2):
+            nf = 2 if rb.use_scale_shift_norm else 1  # (scale | shift), or the additive embedding alone
+            w = torch.zeros(nf * ocs, E, dtype=torch.float32, device=device)
+            b_ = torch.zeros(nf * ocs, dtype=torch.float32, device=device)
+            for n in range(nf):
                 w[n * ocs : n * ocs + oc] = lin.weight.detach()[n * oc : (n + 1) * oc]
                 b_[n * ocs : n * ocs + oc] = lin.bias.detach()[n * oc : (n + 1) * oc]
-            film = bld.empty(emb_rows, 2 * ocs)
-            film_jobs.append((film, bld.const(w), bld.const(b_), 2 * ocs))
-            fbs = 2 * ocs if emb_rows > 1 else 0
+            film = bld.empty(emb_rows, nf * ocs)
+            film_jobs.append((film, bld.const(w), bld.const(b_), nf * ocs))
+            fbs = nf * ocs if emb_rows > 1 else 0
             # h = conv(updown(SiLU(GN(x))))
             n1 = bld.group_norm(x, 32, weight=bld.const(gi.weight), bias=bld.const(gi.bias), act=1, pool=int(rb.down), x1=x1)
-            h = bld.conv(n1, bld.pack_conv(ci.weight, ci.bias), oc, up0=int(rb.up), gn_stats=True)  # -> out_layers' GroupNorm
+            h = bld.conv(n1, bld.pack_conv(ci.weight, ci.bias), oc, up0=int(rb.up),
+                         gn_stats=rb.use_scale_shift_norm)  # -> out_layers' GroupNorm
             bld.free(n1)
-            # h = SiLU(GN(h) * (1 + scale) + shift)
-            n2 = bld.group_norm(h, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), scale=film, shift=film,
-                                scale_off=0, shift_off=ocs, bstride=fbs, act=1)
+            if rb.use_scale_shift_norm:  # h = SiLU(GN(h) * (1 + scale) + shift)
+                n2 = bld.group_norm(h, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), scale=film, shift=film,
+                                    scale_off=0, shift_off=ocs, bstride=fbs, act=1)
+            else:  # h = SiLU(GN(h + emb_out)), _src/unet.py:244-246: the statistics are those of the SUM -> one more pass
+                eb = film
+                if emb_rows == 1 and B > 1:  # the pass wants one row per sample
+                    eb = bld.empty(B, ocs)
+                    bld.tape.add("az_gather_rows_f32", eb.data_ptr(), film.data_ptr(),
+                                 row0.data_ptr(), B, ocs, 1)
+                he = bld.new_act(B, h.H, h.W, oc)
+                bld.tape.add("az_affine_act_f32", he.ptr, h.ptr, None, 0, bld.const(torch.ones(B * ocs)).data_ptr(),
+                             eb.data_ptr(), B, h.H, h.W, ocs, 0, 0)
+                n2 = bld.group_norm(he, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), act=1)
+                bld.free(he)
             bld.free(h)
             # skip path
             if rb.down:
@@ -198,6 +238,19 @@ class ADMPlan:
                     nh = bld.conv(h, bld.pack_conv(layer.weight, layer.bias), layer.out_channels, gn_stats=True)
                 elif isinstance(layer, ResBlock):
                     nh = resblock(layer, h, h1)
+                elif isinstance(layer, Downsample):
+                    if layer.use_conv:
+                        nh = bld.conv(h, bld.pack_conv(layer.op.weight, layer.op.bias), layer.out_channels, stride=2)
+                    else:  # AvgPool2d(2, 2): the pooling form of the elementwise pass with S = 1, T = 0
+                        nh = bld.new_act(B, h.H // 2, h.W // 2, h.C)
+                        bld.tape.add("az_affine_act_f32", nh.ptr, h.ptr, None, 0, bld.const(torch.ones(B * h.cs)).data_ptr(),
+                                     bld.const(torch.zeros(B * h.cs)).data_ptr(), B, h.H, h.W, h.cs, 0, 1)
+                elif isinstance(layer, Upsample):
+                    if layer.use_conv:  # nearest x2 is a read-side shift of the conv gather
+                        nh = bld.conv(h, bld.pack_conv(layer.conv.weight, layer.conv.bias), layer.out_channels, up0=1)
+                    else:  # nearest x2 alone: the same gather under an identity 1x1 filter (exact: one product per output)
+                        eye = torch.eye(h.C, dtype=torch.float32, device=device)
+                        nh = bld.conv(h, bld.pack_conv(eye, None), h.C, up0=1)
                 else:
                     nh = attention(layer, h)
                 if h1 is None and h not in hs and h is not self.x_in:
@@ -244,8 +297,9 @@ class ADMPlan:
 class UNetModel(nn.Module):
     r"""guided-diffusion ``UNetModel`` (reference ``_src/unet.py:387-634``), gfx950-native forward.
 
-    Supported configuration space = the plugin's cards (``cards.yaml``): ``resblock_updown=True``,
-    ``use_scale_shift_norm=True``, ``dims=2``; anything else raises ``NotImplementedError``.
+    ``dims=2`` (all of the plugin's cards); ``dims`` 1 / 3 raise ``NotImplementedError``.  The cards use
+    ``resblock_updown=True, use_scale_shift_norm=True``; guided-diffusion's defaults (``h + emb`` instead of FiLM,
+    ``Downsample`` / ``Upsample`` layers with or without ``conv_resample``) are built too (G14).
     """
 
     def __init__(
@@ -270,10 +324,8 @@ class UNetModel(nn.Module):
         use_new_attention_order=False,
     ) -> None:
         super().__init__()
-        if dims != 2 or not resblock_updown or not use_scale_shift_norm:
-            raise NotImplementedError(
-                "the HIP path implements dims=2, resblock_updown=True, use_scale_shift_norm=True (all ADM cards)"
-            )
+        if dims != 2:
+            raise NotImplementedError("the HIP path implements dims=2 (all ADM cards); 1-D / 3-D signals are not built")
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
         self.image_size, self.in_channels, self.model_channels = image_size, in_channels, model_channels
@@ -285,7 +337,7 @@ class UNetModel(nn.Module):
             self.label_emb = nn.Embedding(num_classes, E)
 
         def res(ch, oc=None, **kw):
-            return ResBlock(ch, E, dropout, out_channels=oc, use_scale_shift_norm=True, **kw)
+            return ResBlock(ch, E, dropout, out_channels=oc, use_scale_shift_norm=use_scale_shift_norm, **kw)
 
         def attn(ch, heads):
             return AttentionBlock(ch, num_heads=heads, num_head_channels=num_head_channels,
@@ -303,7 +355,8 @@ class UNetModel(nn.Module):
                 self.input_blocks.append(TimestepEmbedSequential(*layers))
                 chans.append(ch)
             if level != len(channel_mult) - 1:
-                self.input_blocks.append(TimestepEmbedSequential(res(ch, ch, down=True)))
+                self.input_blocks.append(TimestepEmbedSequential(
+                    res(ch, ch, down=True) if resblock_updown else Downsample(ch, conv_resample, out_channels=ch)))
                 chans.append(ch)
                 ds *= 2
         self.middle_block = TimestepEmbedSequential(res(ch), attn(ch, num_heads), res(ch))
@@ -316,7 +369,7 @@ class UNetModel(nn.Module):
                 if ds in attention_resolutions:
                     layers.append(attn(ch, num_heads_upsample))
                 if level and i == num_res_blocks:
-                    layers.append(res(ch, ch, up=True))
+                    layers.append(res(ch, ch, up=True) if resblock_updown else Upsample(ch, conv_resample, out_channels=ch))
                     ds //= 2
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
         self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), _zero(nn.Conv2d(ch, out_channels, 3, padding=1)))

@@ -321,12 +321,12 @@ def adm_attention(sd, key: str, x: Tensor, heads: int, new_order: bool) -> Tenso
 def adm_layout(cfg: dict):
     r"""Block list of UNetModel.__init__ -- _src/unet.py:468-600.  Returns
     (input_blocks, middle, output_blocks); each block is a list of
-    ("res", up, down) | ("attn", heads) | ("conv",) layer descriptors."""
+    ("res", up, down) | ("attn", heads) | ("conv",) | ("down", use_conv) | ("up", use_conv) layer descriptors."""
     mc, mult = cfg["num_channels"], cfg["channel_mult"]
     nres = cfg["num_res_blocks"]
     attn_ds = {cfg["image_size"] // r for r in cfg["attention_resolutions"]}  # plugins/adm/__init__.py:182
     updown = cfg.get("resblock_updown", False)
-    assert updown, "conv_resample Down/Upsample variant not restated (no card uses it)"
+    use_conv = cfg.get("conv_resample", True)  # Down/Upsample layers of resblock_updown=False, _src/unet.py:516-518,591-593
     hc = cfg.get("num_head_channels", -1)
 
     def heads(ch):
@@ -343,7 +343,7 @@ def adm_layout(cfg: dict):
             inputs.append(blk)
             chans.append(ch)
         if level != len(mult) - 1:
-            inputs.append([("res", False, True)])
+            inputs.append([("res", False, True)] if updown else [("down", use_conv)])
             chans.append(ch)
             ds *= 2
     middle = [("res", False, False), ("attn", heads(ch)), ("res", False, False)]
@@ -356,7 +356,7 @@ def adm_layout(cfg: dict):
             if ds in attn_ds:
                 blk.append(("attn", heads(ch)))
             if level and i == nres:
-                blk.append(("res", True, False))
+                blk.append(("res", True, False) if updown else ("up", use_conv))
                 ds //= 2
             outputs.append(blk)
     return inputs, middle, outputs
@@ -382,6 +382,12 @@ def adm_unet_forward(sd, cfg: dict, x: Tensor, timesteps: Tensor, y: Tensor | No
                 h = _conv(sd, key, h)
             elif layer[0] == "res":
                 h = adm_resblock(sd, key, h, emb, layer[1], layer[2], ss)
+            elif layer[0] == "down":  # Downsample.forward, _src/unet.py:128-137: stride-2 3x3 conv or AvgPool2d(2, 2)
+                h = F.conv2d(h, sd[key + ".op.weight"], sd[key + ".op.bias"], stride=2, padding=1) if layer[1] else F.avg_pool2d(h, 2, 2)
+            elif layer[0] == "up":  # Upsample.forward, _src/unet.py:101-109: nearest x2, then the optional 3x3 conv
+                h = F.interpolate(h, scale_factor=2, mode="nearest")
+                if layer[1]:
+                    h = F.conv2d(h, sd[key + ".conv.weight"], sd[key + ".conv.bias"], padding=1)
             else:
                 h = adm_attention(sd, key, h, layer[1], new_order)
         return h

@@ -111,3 +111,24 @@ def test_cfg_ddim16_fused_and_generic(golden):
     assert max_err(x0g, x0) < 3e-4 and max_err(x0g, g["cfg_ddim16"]) < 1e-3  # measured 5.5e-5 / 2.0e-4
     # schedule passes through the wrapper (reference cfg.py:31-33)
     assert cfgden.schedule is den.schedule
+
+
+@pytest.mark.parametrize("name", ["adm_plain_conv", "adm_plain_pool", "adm_film_noupdown"])
+def test_adm_options_outside_the_cards(golden, name):
+    """guided-diffusion's default wiring -- ``use_scale_shift_norm=False`` (h + emb), ``resblock_updown=False``
+    (Downsample / Upsample layers, with and without ``conv_resample``) -- against the reference's outputs (G14)."""
+    from azula_amd.sample import DDIMSampler
+
+    g = golden("g14_" + name)
+    den, _, cfg = build(g)
+    y = g["y"].cuda() if "y" in g else None
+    out = den.backbone(g["x"].cuda(), g["idx"].cuda(), y=y)
+    err, sc = max_err(out, g["out"]), g["out"].abs().max().item()
+    kw = {"label": y} if y is not None else {}
+    smp = DDIMSampler(den, steps=8, silent=True)
+    x0 = smp(g["x1"].cuda(), **kw)
+    assert next(iter(smp._fused_cache.values())).graph is not None
+    e2 = max_err(x0, g["ddim8"])
+    print(name, "backbone max|d|", err, "scale", sc, "DDIM-8", e2, "scale", g["ddim8"].abs().max().item())
+    assert err < 2e-5 * max(1.0, sc)  # measured 2.3e-6 .. 2.6e-6 on scale 2.2 .. 2.7
+    assert e2 < 2.5e-4  # measured 2.8e-5 .. 5.0e-5 (means clipped to +-1, c_out = -100 at t = 1)

@@ -223,3 +223,21 @@ def test_g13_other_spatial_dimensions(golden):
     for name in ("vit1d", "vit3d", "vit2d_aniso"):
         sd = synth.synth_state_dict({n: tuple(v) for n, v in g.meta[name + "_shapes"].items()}, 42)
         assert max_err(nets.vit_forward(sd, g.meta[name + "_cfg"], g[name + "_x"], mod), g[name + "_y"]) < 1e-5
+
+
+def test_g14_adm_offcard(golden):
+    """guided-diffusion's default wiring (h + emb, Downsample / Upsample layers with and without conv_resample): the
+    oracle against the reference's outputs (oracle/make_golden.py --only-g14)."""
+    for name in ("adm_plain_conv", "adm_plain_pool", "adm_film_noupdown"):
+        g = golden("g14_" + name)
+        cfg = g.meta["cfg"]
+        sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"])
+        y = g["y"] if "y" in g else None
+        out = nets.adm_unet_forward(sd, cfg, g["x"], g["idx"], y)
+        torch.testing.assert_close(out, g["out"], **TIGHT)
+        sig = sampling.adm_sigmas(cfg["discrete_schedule"], cfg["discrete_steps"])
+        bb = lambda a, i, y=None: nets.adm_unet_forward(sd, cfg, a, i, y)  # noqa: E731
+        omean = lambda xx, t, label=None: sampling.adm_posterior(bb, xx, t, sig, label=label)[0]  # noqa: E731
+        kw = {"label": y} if y is not None else {}
+        x0 = sampling.sample(omean, g["x1"], schedule=lambda t: sampling.vp_schedule(t, 1e-2, 1e-2), steps=8, eta=0.0, **kw)
+        torch.testing.assert_close(x0, g["ddim8"], **TIGHT)
