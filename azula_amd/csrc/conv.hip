@@ -1880,9 +1880,13 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   AZ_REQUIRE((a->hin + 2 * a->pad - a->ksize) / a->stride + 1 == a->hout &&
                  (a->win + 2 * a->pad - a->ksize) / a->stride + 1 == a->wout,
              AZ_E_SHAPE);
-  AZ_REQUIRE(((a->hin + a->up0) >> a->up0) <= a->h0 && ((a->win + a->up0) >> a->up0) <= a->w0, AZ_E_SHAPE);
+  AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
+                 ((a->win + (1 << a->up0) - 1) >> a->up0) <= a->w0,
+             AZ_E_SHAPE);
   if (a->src1)
-    AZ_REQUIRE(((a->hin + a->up1) >> a->up1) <= a->h1 && ((a->win + a->up1) >> a->up1) <= a->w1, AZ_E_SHAPE);
+    AZ_REQUIRE(a->up1 >= 0 && a->up1 <= 4 && ((a->hin + (1 << a->up1) - 1) >> a->up1) <= a->h1 &&
+                 ((a->win + (1 << a->up1) - 1) >> a->up1) <= a->w1,
+             AZ_E_SHAPE);
   AZ_REQUIRE(AZ_ALIGNED16(a->src0) && AZ_ALIGNED16(a->src1) && AZ_ALIGNED16(a->weight) && AZ_ALIGNED16(a->bias) &&
                  AZ_ALIGNED16(a->gate) && AZ_ALIGNED16(a->res) && AZ_ALIGNED16(a->workspace),
              AZ_E_ALIGN);
@@ -1981,9 +1985,13 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
-  AZ_REQUIRE(((a->hin + a->up0) >> a->up0) <= a->h0 && ((a->win + a->up0) >> a->up0) <= a->w0, AZ_E_SHAPE);
+  AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
+                 ((a->win + (1 << a->up0) - 1) >> a->up0) <= a->w0,
+             AZ_E_SHAPE);
   if (a->src1)
-    AZ_REQUIRE(((a->hin + a->up1) >> a->up1) <= a->h1 && ((a->win + a->up1) >> a->up1) <= a->w1, AZ_E_SHAPE);
+    AZ_REQUIRE(a->up1 >= 0 && a->up1 <= 4 && ((a->hin + (1 << a->up1) - 1) >> a->up1) <= a->h1 &&
+                 ((a->win + (1 << a->up1) - 1) >> a->up1) <= a->w1,
+             AZ_E_SHAPE);
   AZ_REQUIRE(AZ_ALIGNED16(a->src0) && AZ_ALIGNED16(a->src1) && AZ_ALIGNED16(a->weight) && AZ_ALIGNED16(a->bias) &&
                  AZ_ALIGNED16(a->gate) && AZ_ALIGNED16(a->res) && AZ_ALIGNED16(a->workspace),
              AZ_E_ALIGN);
@@ -2069,9 +2077,13 @@ int az_conv2d_winograd4_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
-  AZ_REQUIRE(((a->hin + a->up0) >> a->up0) <= a->h0 && ((a->win + a->up0) >> a->up0) <= a->w0, AZ_E_SHAPE);
+  AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
+                 ((a->win + (1 << a->up0) - 1) >> a->up0) <= a->w0,
+             AZ_E_SHAPE);
   if (a->src1)
-    AZ_REQUIRE(((a->hin + a->up1) >> a->up1) <= a->h1 && ((a->win + a->up1) >> a->up1) <= a->w1, AZ_E_SHAPE);
+    AZ_REQUIRE(a->up1 >= 0 && a->up1 <= 4 && ((a->hin + (1 << a->up1) - 1) >> a->up1) <= a->h1 &&
+                 ((a->win + (1 << a->up1) - 1) >> a->up1) <= a->w1,
+             AZ_E_SHAPE);
   AZ_REQUIRE(AZ_ALIGNED16(a->src0) && AZ_ALIGNED16(a->src1) && AZ_ALIGNED16(a->weight) && AZ_ALIGNED16(a->bias) &&
                  AZ_ALIGNED16(a->gate) && AZ_ALIGNED16(a->res) && AZ_ALIGNED16(a->workspace),
              AZ_E_ALIGN);

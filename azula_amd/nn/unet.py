@@ -220,7 +220,7 @@ class UNetPlan:
                 y = skips[i]
                 conv = mods[0]
                 merged = bld.conv(
-                    y, bld.pack_conv(conv.weight, conv.bias, cin0=y.C), conv.out_channels, src1=cur, up1=1,
+                    y, bld.pack_conv(conv.weight, conv.bias, cin0=y.C), conv.out_channels, src1=cur, up1=stride.bit_length() - 1,
                     hin=y.H, win=y.W, periodic=per, gn_stats=gn,
                 )
                 bld.free(cur)
@@ -234,7 +234,7 @@ class UNetPlan:
                 conv = mods[idx]
                 bld.conv(cur, bld.pack_conv(conv.weight, conv.bias), conv.out_channels, dst_nchw=self.out, periodic=per)
                 bld.free(cur)
-            # i > 0: nearest upsampling is folded into the next level's merge conv (up1 = 1)
+            # i > 0: nearest upsampling is folded into the next level's merge conv (up1 = log2 stride)
         bld.finish()
         self.tape = bld.tape
         if mod_jobs:  # h_i = silu(W0_i mod + b0_i) for all blocks as ONE GEMV; abc_i = W2_i h_i + b2_i as ONE grouped GEMV
@@ -275,8 +275,9 @@ class UNet(nn.Module):
         assert len(kernel_size) == len(stride) == spatial
         if len(set(stride)) != 1 or any(k % 2 == 0 for k in kernel_size):
             raise NotImplementedError("odd kernel sizes (anisotropic allowed) and isotropic strides only")
-        if stride[0] != 2:
-            raise NotImplementedError("stride 2 only (nearest x2 upsampling is folded into the merge conv)")
+        if stride[0] not in (1, 2, 4, 8, 16):
+            raise NotImplementedError(
+                "strides 1, 2, 4, 8, 16 only (the nearest upsampling is a right shift of the merge convolution's gather)")
         self.in_channels, self.out_channels, self.cond_channels = in_channels, out_channels, cond_channels
         self.hid_channels, self.hid_blocks = tuple(hid_channels), tuple(hid_blocks)
         self.stride = stride[0]

@@ -242,7 +242,7 @@ typedef struct AzConvArgs {
   const float* src0; /* NHWC (B, h0, w0, c0s) */
   const float* src1; /* NHWC (B, h1, w1, c1s) or NULL */
   int32_t c0s, c1s;  /* channel strides (multiples of 4); input channels = c0s + c1s */
-  int32_t up0, up1;  /* 1: read source through nearest x2 upsampling */
+  int32_t up0, up1;  /* log2 of the nearest upsampling the source is read through (0: none, 1: x2, 2: x4, ... <= 4) */
   int32_t h0, w0, h1, w1; /* stored spatial dims of each source */
   int32_t batch, hin, win; /* logical input dims (after upsampling / narrowing) */
   const float* weight;     /* packed [ks*ks][cout_s][cin_s], cin_s = c0s + c1s */

@@ -96,11 +96,12 @@ def unet_forward(sd, cfg: dict, x: Tensor, mod: Tensor | None = None, tap: dict 
     hid_blocks = list(cfg["hid_blocks"])
     norm, groups = cfg.get("norm", "layer"), cfg.get("groups", 16)
     per = cfg.get("periodic", False)
+    stride = cfg.get("stride", 2)  # isotropic: the downsampling convolutions' stride = the nearest upsampling factor (:181-186)
     L = len(hid_blocks)
     memory = []
     for i in range(L):
         memory.append(x if memory else None)
-        x = _conv(sd, f"descent.{i}.0", x, stride=2 if i > 0 else 1, periodic=per)
+        x = _conv(sd, f"descent.{i}.0", x, stride=stride if i > 0 else 1, periodic=per)
         for j in range(hid_blocks[i]):
             x = unet_block(sd, f"descent.{i}.{1 + j}", x, mod, norm, groups, per)
         if tap is not None:
@@ -115,7 +116,7 @@ def unet_forward(sd, cfg: dict, x: Tensor, mod: Tensor | None = None, tap: dict 
             x = unet_block(sd, f"ascent.{k}.{idx + j}", x, mod, norm, groups, per)
         idx += hid_blocks[i]
         if i > 0:
-            x = F.interpolate(x, scale_factor=(2.0,) * (x.ndim - 2), mode="nearest")
+            x = F.interpolate(x, scale_factor=(float(stride),) * (x.ndim - 2), mode="nearest")
         else:
             x = _conv(sd, f"ascent.{k}.{idx}", x, periodic=per)
         if tap is not None:

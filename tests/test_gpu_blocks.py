@@ -181,3 +181,21 @@ def test_unet_anisotropic_kernel(golden):
     sc = max(1.0, g["unet_aniso_y"].abs().max().item())
     print("UNet kernel (3, 5) max|d|", max_err(y, g["unet_aniso_y"]), "scale", sc)
     assert max_err(y, g["unet_aniso_y"]) < 2e-5 * sc
+
+
+@pytest.mark.parametrize("name", ["s4", "s4_odd", "s1", "s8"])
+def test_unet_other_strides(golden, name):
+    """stride 1 / 4 / 8 (azula/nn/unet.py:159-186): stride-s downsampling convolutions, nearest x s upsampling as a right
+    shift of the merge convolution's gather (AzConvArgs.up1 = log2 s), narrow before the concatenation on odd sizes."""
+    from azula_amd.nn import UNet
+
+    g = golden("g15_strides")
+    net = UNet(**g.meta[name + "_cfg"])
+    sh = {n: tuple(v) for n, v in g.meta[name + "_shapes"].items()}
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == sh
+    net.load_state_dict(synth.synth_state_dict(sh, 51))
+    x = g[name + "_x"]
+    y = net.cuda().eval()(x.cuda(), g["mod"][: x.shape[0]].cuda())
+    sc = max(1.0, g[name + "_y"].abs().max().item())
+    print(name, "max|d|", max_err(y, g[name + "_y"]), "scale", sc)
+    assert y.shape == g[name + "_y"].shape and max_err(y, g[name + "_y"]) < 2e-5 * sc

@@ -241,3 +241,13 @@ def test_g14_adm_offcard(golden):
         kw = {"label": y} if y is not None else {}
         x0 = sampling.sample(omean, g["x1"], schedule=lambda t: sampling.vp_schedule(t, 1e-2, 1e-2), steps=8, eta=0.0, **kw)
         torch.testing.assert_close(x0, g["ddim8"], **TIGHT)
+
+
+def test_g15_strides(golden):
+    g = golden("g15_strides")
+    for name in ("s4", "s4_odd", "s1", "s8"):
+        cfg = g.meta[name + "_cfg"]
+        sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta[name + "_shapes"].items()}, 51)
+        x = g[name + "_x"]
+        y = nets.unet_forward(sd, cfg, x, g["mod"][: x.shape[0]])
+        torch.testing.assert_close(y, g[name + "_y"], **TIGHT)
