@@ -1345,12 +1345,12 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   // fragment addresses: row (within a frequency) = wave's 32-row block + l31; half = h (swizzled)
   const int fragA = (fh * 8) * WC * WK + wswz(wco * 32 + l31, h);  // + f * WC * WK
   const int fragB = (fh * 8) * WT * WK + wswz(wti * 32 + l31, h);  // + f * WT * WK
-  // Code placement: this loop loses 4.5 % (25.2 -> 26.4 ms per C2 step) when its instructions start at byte phases
-  // 16..23 of a 32-byte window (measured by sweeping s_nop padding behind this anchor: phases 0-15 and 24-31 are
-  // equally fast) -- a 12-byte change in the PROLOGUE (three 32-bit literals) was enough to move it there.  The
-  // anchor pins the phase to 0, independent of whatever precedes it.
-  asm volatile(".p2align 6" ::: "memory");
   for (int kt = kt_begin; kt < kt_end; ++kt) {
+    // Code placement: this loop loses 4.5 - 7 % when its body starts at byte phases 16..23 of a 32-byte window (r02:
+    // swept with s_nop padding -- every other phase is equally fast; an innocuous edit of the PROLOGUE, even code that
+    // never executes, moved it there twice).  The anchor sits INSIDE the loop, so the phase of the body no longer depends
+    // on what precedes the loop; its padding (<= 15 s_nop per stage) is noise.  2 s_nop = the fastest phase of the sweep.
+    asm volatile(".p2align 6\n s_nop 0\n s_nop 0" ::: "memory");
     const int buf = (kt - kt_begin) & 1;
     const bool more = kt + 1 < kt_end;
     if (more) load_stage(kt + 1);  // in flight under this stage's MFMAs (and the partner wave's)
