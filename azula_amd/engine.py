@@ -302,6 +302,7 @@ class Builder:
         winograd: bool | int | None = None,
         periodic: bool = False,
         gn_stats: bool = False,
+        out: Act | None = None,
     ) -> Act | None:
         ks, bias = packed.ks, packed.bias
         pad = ks // 2
@@ -333,11 +334,14 @@ class Builder:
                 a.res_bcast = 1
             a.res, a.res_up, a.hres, a.wres = res.ptr, res_up, res.H, res.W
             assert res.cs == a.cout_s
-        out = None
         if dst_nchw is not None:
+            out = None
             a.dst, a.dst_nchw, a.dst_c = dst_nchw.data_ptr(), 1, cout
         else:
-            out = self.new_act(B, hout, wout, cout)
+            if out is None:
+                out = self.new_act(B, hout, wout, cout)
+            else:  # caller-owned destination (a plane range of a volume; may alias `res`: in-place accumulation)
+                assert (out.B, out.H, out.W, out.C, out.cs) == (B, hout, wout, cout, pad4(cout)), "destination shape"
             a.dst = out.ptr
         npix = B * hout * wout
         cin_s = a.c0s + a.c1s

@@ -30,9 +30,9 @@ __all__ = ["UNet", "UNetBlock"]
 
 
 def _conv_holder(cin: int, cout: int, kernel_size, stride=1, identity_init: bool = False) -> nn.Module:
-    r"""Parameter holder with the reference's shapes: ``Conv2d`` for spatial = 2, ``Conv1d`` for spatial = 1 (``ConvNd``,
+    r"""Parameter holder with the reference's shapes: ``Conv1d`` / ``Conv2d`` / ``Conv3d`` for spatial = 1 / 2 / 3 (``ConvNd``,
     ``azula/nn/layers.py:25-68``); ``len(kernel_size)`` is the number of spatial dimensions."""
-    Conv = nn.Conv2d if len(kernel_size) == 2 else nn.Conv1d
+    Conv = {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}[len(kernel_size)]
     conv = Conv(cin, cout, kernel_size=tuple(kernel_size), stride=stride, padding=tuple(k // 2 for k in kernel_size))
     if identity_init:  # azula/nn/layers.py:53-66: near-identity down/up-sampling convolutions
         center = [k // 2 for k in conv.weight.shape[2:]]
@@ -65,12 +65,12 @@ class UNetBlock(nn.Module):
         **kwargs,
     ) -> None:
         super().__init__()
-        if spatial not in (1, 2):
-            raise NotImplementedError("azula_amd.nn.UNet implements spatial = 1 and 2 (no 3-D convolution kernels)")
+        if spatial not in (1, 2, 3):
+            raise NotImplementedError("azula_amd.nn.UNet implements spatial = 1, 2 and 3")
         if isinstance(kernel_size, int):  # standalone use passes ConvNd's keyword arguments (reference unet.py:76-83)
             kernel_size = (kernel_size,) * spatial
         kernel_size = tuple(kernel_size)[:spatial] if len(kernel_size) >= spatial else tuple(kernel_size)
-        if any(k % 2 == 0 for k in kernel_size) or kwargs.get("stride", 1) not in (1, (1,), [1], (1, 1), [1, 1]):
+        if any(k % 2 == 0 for k in kernel_size) or kwargs.get("stride", 1) not in (1, (1,), [1], (1, 1), [1, 1], (1, 1, 1), [1, 1, 1]):
             raise NotImplementedError("odd kernel sizes with stride 1 only")
         pad = kwargs.get("padding", tuple(k // 2 for k in kernel_size))
         if tuple([pad] * len(kernel_size) if isinstance(pad, int) else pad) != tuple(k // 2 for k in kernel_size):
@@ -119,6 +119,46 @@ class UNetBlock(nn.Module):
             bld.free(x)
         return y
 
+    def _forward_3d(self, x: Tensor, mod: Tensor | None, out_dtype) -> Tensor:
+        r"""(B, C, D, H, W): one-block plan on the volume form (see ``unet3d.py``)."""
+        from .unet3d import Vol, block3d
+
+        assert x.ndim == 5 and x.shape[1] == self.channels
+        B, Cc, Dd, H, W = x.shape
+        D = self.mod_features
+        rows = 0
+        if D > 0:
+            assert mod is not None, "this block is modulated: pass mod"
+            rows = 1 if mod.ndim == 1 else mod.shape[0]
+            assert rows in (1, B)
+        key = (B, Dd, H, W, rows, str(x.device))
+        versions = tuple((p.data_ptr(), p._version, p.dtype) for p in self.parameters())
+        plan = self._plans.get(key)
+        if plan is None or plan[0] != versions:
+            bld = Builder(x.device, half=next(self.parameters()).dtype)
+            xa = bld.new_act(B * Dd, H, W, Cc, pinned=True)
+            xin = Vol(xa.buf, B, Dd, H, W, Cc, xa.cs)
+            mod_buf = torch.empty(max(rows, 1), max(D, 1), dtype=torch.float32, device=x.device)
+            jobs: list = []
+            out = block3d(self, bld, xin, D, rows, jobs, keep_input=True)
+            bld.finish()
+            tape = bld.tape
+            if jobs:
+                tape = mod_front_tape(bld, jobs, mod_buf, rows, D)
+                tape.extend(bld.tape)
+            res = torch.empty(B, Cc, Dd, H, W, dtype=torch.float32, device=x.device)
+            tape.add("az_nhwc_to_nchw_f32", res.data_ptr(), out.buf.data_ptr(), B, Cc, Dd * H * W, out.cs)
+            plan = (versions, xin, mod_buf, tape, res)
+            self._plans.clear()
+            self._plans[key] = plan
+        _, xin, mod_buf, tape, res = plan
+        xs = x.to(torch.float32).contiguous()
+        _lib.call("az_nchw_to_nhwc_f32", xin.buf.data_ptr(), xs.data_ptr(), None, B, Cc, Dd * H * W, xin.cs, _lib.stream_ptr())
+        if rows:
+            mod_buf.copy_(mod.to(torch.float32).reshape(rows, -1))
+        tape.run()
+        return res.to(out_dtype, copy=True)
+
     def _forward_1d(self, x: Tensor, mod: Tensor | None) -> Tensor:
         self.spatial = 2
         try:
@@ -136,6 +176,8 @@ class UNetBlock(nn.Module):
         if self.spatial == 1:  # (B, C, L): the same kernels on a one-row image
             assert x.ndim == 3
             return self._forward_1d(x, mod)
+        if self.spatial == 3:
+            return self._forward_3d(x, mod, out_dtype)
         assert x.ndim == 4 and x.shape[1] == self.channels
         B, Cc, H, W = x.shape
         D = self.mod_features
@@ -246,7 +288,8 @@ class UNetPlan:
 class UNet(nn.Module):
     r"""Modulated U-Net (reference ``azula/nn/unet.py:119-259``), gfx950-native forward.
 
-    Arguments are those of ``azula.nn.unet.UNet``; ``spatial`` must be 2 and ``periodic`` False.
+    Arguments are those of ``azula.nn.unet.UNet``: ``spatial`` 1 (one-row images), 2 or 3 (volumes: every 3-D convolution
+    as depth taps of the 2-D kernels, ``unet3d.py``), zero or circular padding, odd kernels, isotropic power-of-two strides.
     """
 
     def __init__(
@@ -265,8 +308,8 @@ class UNet(nn.Module):
     ) -> None:
         super().__init__()
         assert len(hid_blocks) == len(hid_channels)
-        if spatial not in (1, 2):
-            raise NotImplementedError("azula_amd.nn.UNet implements spatial = 1 and 2 (no 3-D convolution kernels)")
+        if spatial not in (1, 2, 3):
+            raise NotImplementedError("azula_amd.nn.UNet implements spatial = 1, 2 and 3")
         self.spatial = spatial
         if isinstance(kernel_size, int):
             kernel_size = [kernel_size] * spatial
@@ -308,6 +351,16 @@ class UNet(nn.Module):
     # -- plan management -----------------------------------------------------------------------
     def _param_versions(self) -> tuple:
         return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+
+    def plan3d(self, B: int, D: int, H: int, W: int, mod_rows: int, device: torch.device):
+        from .unet3d import UNet3DPlan
+
+        key = (B, D, H, W, mod_rows, str(device))
+        p = self._plans.get(key)
+        if p is None or p.versions != self._param_versions():
+            p = UNet3DPlan(self, B, D, H, W, mod_rows, device)
+            self._plans[key] = p
+        return p
 
     def plan(self, B: int, H: int, W: int, mod_rows: int, device: torch.device) -> UNetPlan:
         key = (B, H, W, mod_rows, str(device))
@@ -351,6 +404,25 @@ class UNet(nn.Module):
             return None
         return self._program(x, 0)[0]
 
+    def _forward_3d(self, x: Tensor, mod: Tensor | None, out_dtype) -> Tensor:
+        r"""(B, C, D, H, W) volumes: every 3-D convolution as depth taps of the 2-D kernels (``unet3d.py``)."""
+        assert x.ndim == 5, "spatial = 3: expected (B, C, D, H, W)"
+        B, Cin, D, H, W = x.shape
+        assert Cin == self.in_channels + self.cond_channels
+        rows = 0
+        if self.mod_features > 0:
+            assert mod is not None, "this UNet is modulated: pass mod"
+            mod = mod.to(torch.float32)
+            rows = 1 if mod.ndim == 1 else mod.shape[0]
+            assert rows in (1, B)
+        p = self.plan3d(B, D, H, W, rows, x.device)
+        s = _lib.stream_ptr()
+        _lib.call("az_nchw_to_nhwc_f32", p.x_in.buf.data_ptr(), x.data_ptr(), None, B, Cin, D * H * W, p.x_in.cs, s)
+        if rows:
+            p.mod.copy_(mod.reshape(rows, -1))
+        p.tape.run(s)
+        return p.out.to(out_dtype, copy=True)
+
     @torch.no_grad()
     @_lib.on_device
     def forward(self, x: Tensor, mod: Tensor | None = None, cond: Tensor | None = None) -> Tensor:
@@ -364,6 +436,8 @@ class UNet(nn.Module):
             assert x.ndim == 3, "spatial = 1: expected (B, C, L)"
             x = x[:, :, None]
         x = x.to(torch.float32).contiguous()
+        if self.spatial == 3:
+            return self._forward_3d(x, mod, out_dtype)
         B, Cin, H, W = x.shape
         assert Cin == self.in_channels + self.cond_channels
         if self.mod_features > 0:

@@ -1,0 +1,176 @@
+r"""U-Net on volumes (``spatial = 3``) through the 2-D kernels.
+
+Reference: ``azula/nn/unet.py:119-259`` with ``ConvNd(spatial=3)`` (``azula/nn/layers.py:25-68``), i.e. ``Conv3d`` with
+'same' padding, zero or circular.  A volume is stored (B, D, H, W, C) = B * D channel-padded NHWC planes, and a 3-D
+convolution is the sum over its depth taps of 2-D convolutions of depth-shifted planes,
+
+    out[b, d] = sum_j conv2d(x[b, s d + j - p], w[:, :, j]),
+
+each tap one launch of the 2-D kernel (Winograd / direct, in-plane padding, stride, nearest upsampling, concatenation and
+narrow exactly as for images) that ACCUMULATES in place through the epilogue's residual operand.  The centre tap runs
+first (it exists for every output plane) and carries the bias; a gate distributes over the taps
+(``x + c (sum_j v_j + bias) = x + c (v_0 + bias) + c v_1 + ...``), only the SiLU after a block's first convolution needs a
+pass of its own.  Norms see a volume as one (D H) x W image.  Depth padding is a skipped (zeros) or wrapped (circular)
+plane index -- no padded copies.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from ..engine import Act, Builder, ada_zero_triple, mod_front_tape, pad4
+
+
+class Vol:
+    r"""(B, D, H, W, cs) floats in ``buf``; ``C`` real channels."""
+
+    __slots__ = ("buf", "B", "D", "H", "W", "C", "cs")
+
+    def __init__(self, buf: torch.Tensor, B: int, D: int, H: int, W: int, C: int, cs: int) -> None:
+        self.buf, self.B, self.D, self.H, self.W, self.C, self.cs = buf, B, D, H, W, C, cs
+
+    def planes(self, b: int, d0: int, d1: int) -> Act:
+        n = self.H * self.W * self.cs
+        return Act(self.buf[(b * self.D + d0) * n : (b * self.D + d1) * n], d1 - d0, self.H, self.W, self.C, self.cs, True)
+
+    def image(self) -> Act:
+        r"""The volume as B images of (D H) x W pixels: what the norms and elementwise passes see."""
+        return Act(self.buf, self.B, self.D * self.H, self.W, self.C, self.cs, True)
+
+
+def new_vol(bld: Builder, B: int, D: int, H: int, W: int, C: int) -> Vol:
+    a = bld.new_act(B * D, H, W, C)
+    return Vol(a.buf, B, D, H, W, C, a.cs)
+
+
+def free_vol(bld: Builder, v: Vol) -> None:
+    bld.pool.release(v.buf)
+
+
+def _depth_index(i: int, n: int, periodic: bool) -> int:
+    r"""Plane index of a depth tap: itself, wrapped (circular padding) or -1 (zero padding)."""
+    if 0 <= i < n:
+        return i
+    return i % n if periodic else -1
+
+
+def conv3d(bld: Builder, x: Vol, conv, *, stride: int = 1, periodic: bool = False, x1: Vol | None = None, up1: int = 0,
+           like: Vol | None = None, silu: bool = False, gate=None, gate_off: int = 0, gate_bstride: int = 0,
+           res: Vol | None = None) -> Vol:
+    r"""``conv``: holder of a (Cout, Cin, kd, kh, kw) weight (+ bias).  ``x1`` (read through nearest x 2^up1 upsampling,
+    narrowed to ``like``'s size) is concatenated behind ``x``'s channels.  ``silu``: activation of the sum;
+    ``gate`` / ``res``: out = res + gate * (sum + bias)."""
+    w, bias = conv.weight, conv.bias
+    cout, _, kd, kh, kw = w.shape
+    assert kh == kw or True
+    p = kd // 2
+    Din, Hin, Win = (like.D, like.H, like.W) if like is not None else (x.D, x.H, x.W)
+    Do = (Din + 2 * p - kd) // stride + 1
+    Ho = (Hin + 2 * (kh // 2) - kh) // stride + 1
+    Wo = (Win + 2 * (kw // 2) - kw) // stride + 1
+    out = new_vol(bld, x.B, Do, Ho, Wo, cout)
+    taps = [p] + [j for j in range(kd) if j != p]  # centre first: it exists for every output plane and writes it
+    packs = {j: bld.pack_conv(w[:, :, j], bias if j == p else None, cin0=x.C if x1 is not None else None) for j in taps}
+    for b in range(x.B):
+        g = dict(gate=gate, gate_off=gate_off + b * gate_bstride, gate_bstride=0) if gate is not None else {}
+        if stride == 1 and x1 is None:  # contiguous plane ranges: one launch per (sample, tap[, wrap piece])
+            for j in taps:
+                o = j - p
+                lo, hi = max(0, -o), min(Do, Din - o)  # output planes whose tap lies inside the volume
+                pieces = [(lo, hi, lo + o)] if hi > lo else []
+                if periodic and o != 0 and Din > 0:
+                    if o < 0:  # planes [0, lo) read the last -o planes ... one plane at a time keeps the index arithmetic plain
+                        pieces += [(d, d + 1, (d + o) % Din) for d in range(0, min(lo, Do))]
+                    else:
+                        pieces += [(d, d + 1, (d + o) % Din) for d in range(max(hi, 0), Do)]
+                for d0, d1, s0 in pieces:
+                    dst = out.planes(b, d0, d1)
+                    first = j == p
+                    bld.conv(x.planes(b, s0, s0 + (d1 - d0)), packs[j], cout, periodic=periodic, out=dst,
+                             res=(res.planes(b, d0, d1) if res is not None else None) if first else dst, **g)
+        else:
+            for d in range(Do):
+                for j in taps:
+                    i = _depth_index(stride * d + j - p, Din, periodic)
+                    if i < 0:
+                        continue
+                    dst = out.planes(b, d, d + 1)
+                    first = j == p
+                    kw_ = dict(src1=x1.planes(b, i >> up1, (i >> up1) + 1), up1=up1, hin=Hin, win=Win) if x1 is not None else {}
+                    bld.conv(x.planes(b, i, i + 1), packs[j], cout, stride=stride, periodic=periodic, out=dst,
+                             res=(res.planes(b, d, d + 1) if res is not None else None) if first else dst, **g, **kw_)
+    if silu:
+        bld.tape.add("az_silu_f32", out.buf.data_ptr(), out.buf.data_ptr(), out.buf.numel())
+    return out
+
+
+def block3d(blk, bld: Builder, x: Vol, D_mod: int, mod_rows: int, mod_jobs: list, keep_input: bool = False) -> Vol:
+    r"""UNetBlock on a volume (reference ``unet.py:85-95``)."""
+    Cc, cs = blk.channels, pad4(blk.channels)
+    abc, bstride = ada_zero_triple(bld, blk.ada_zero, Cc, D_mod, mod_rows, mod_jobs)
+    xi = x.image()
+    if blk.norm_kind == "group":
+        n_ = bld.group_norm(xi, blk.groups, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
+    else:
+        n_ = bld.row_norm(xi, 0 if blk.norm_kind == "layer" else 1, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
+    nv = Vol(n_.buf, x.B, x.D, x.H, x.W, Cc, cs)
+    c0, c3 = blk.ffn[0], blk.ffn[3]
+    h1 = conv3d(bld, nv, c0, periodic=blk.periodic, silu=True)
+    bld.free(n_)
+    y = conv3d(bld, h1, c3, periodic=blk.periodic, gate=abc, gate_off=2 * cs, gate_bstride=bstride, res=x)
+    free_vol(bld, h1)
+    if not keep_input:
+        free_vol(bld, x)
+    return y
+
+
+class UNet3DPlan:
+    r"""Compiled forward for one (batch, D, H, W, modulation-rows) signature."""
+
+    def __init__(self, net, B: int, D: int, H: int, W: int, mod_rows: int, device: torch.device) -> None:
+        bld = self.bld = Builder(device, half=next(net.parameters()).dtype)
+        cin = net.in_channels + net.cond_channels
+        Dm = net.mod_features
+        xa = Act(torch.empty(B * D * H * W * pad4(cin), dtype=torch.float32, device=device), B * D, H, W, cin, pad4(cin), True)
+        self.x_in = Vol(xa.buf, B, D, H, W, cin, xa.cs)
+        self.mod = torch.empty(max(mod_rows, 1), max(Dm, 1), dtype=torch.float32, device=device)
+        self.out = torch.empty(B, net.out_channels, D, H, W, dtype=torch.float32, device=device)
+        self.versions = net._param_versions()
+        L = len(net.hid_blocks)
+        stride, per = net.stride, net.periodic
+        up = stride.bit_length() - 1
+        mod_jobs: list[tuple] = []
+        cur = self.x_in
+        skips: list[Vol] = []
+        for i in range(L):
+            first = net.descent[i][0]
+            if i > 0:
+                skips.append(cur)
+            nxt = conv3d(bld, cur, first, stride=stride if i > 0 else 1, periodic=per)
+            cur = nxt
+            for j in range(net.hid_blocks[i]):
+                cur = block3d(net.descent[i][1 + j], bld, cur, Dm, mod_rows, mod_jobs)
+        for k in range(L):
+            i = L - 1 - k
+            mods = net.ascent[k]
+            idx = 0
+            if i + 1 < L:
+                y = skips[i]
+                merged = conv3d(bld, y, mods[0], periodic=per, x1=cur, up1=up, like=y)
+                free_vol(bld, cur)
+                free_vol(bld, y)
+                cur = merged
+                idx = 1
+            for j in range(net.hid_blocks[i]):
+                cur = block3d(mods[idx + j], bld, cur, Dm, mod_rows, mod_jobs)
+            idx += net.hid_blocks[i]
+            if i == 0:
+                head = conv3d(bld, cur, mods[idx], periodic=per)
+                bld.tape.add("az_nhwc_to_nchw_f32", self.out.data_ptr(), head.buf.data_ptr(), B, net.out_channels, D * H * W, head.cs)
+                free_vol(bld, cur)
+        bld.finish()
+        self.tape = bld.tape
+        if mod_jobs:
+            pre = mod_front_tape(bld, mod_jobs, self.mod, mod_rows, Dm)
+            pre.extend(self.tape)
+            self.tape = pre

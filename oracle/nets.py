@@ -23,7 +23,7 @@ def _linear(sd, key: str, x: Tensor) -> Tensor:
 
 
 def _conv(sd, key: str, x: Tensor, stride: int = 1, padding=None, periodic: bool = False) -> Tensor:
-    r"""ConvNd (azula/nn/layers.py:25-50) for 2-D images (B, C, H, W) and 1-D signals (B, C, L); 'same' padding
+    r"""ConvNd (azula/nn/layers.py:25-50) for 1-D signals, 2-D images and 3-D volumes (B, C, *spatial); 'same' padding
     (kernel // 2 per axis, azula/nn/unet.py:170-172) unless given."""
     n = x.ndim - 2
     if padding is None:
@@ -34,7 +34,7 @@ def _conv(sd, key: str, x: Tensor, stride: int = 1, padding=None, periodic: bool
         assert isinstance(padding, int)  # torch.nn.ConvNd(padding_mode="circular"): F.pad(mode="circular") then an unpadded conv
         x = F.pad(x, (padding,) * (2 * n), mode="circular")
         padding = 0
-    conv = F.conv2d if n == 2 else F.conv1d
+    conv = {1: F.conv1d, 2: F.conv2d, 3: F.conv3d}[n]
     return conv(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=stride, padding=padding)
 
 

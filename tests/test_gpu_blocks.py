@@ -199,3 +199,44 @@ def test_unet_other_strides(golden, name):
     sc = max(1.0, g[name + "_y"].abs().max().item())
     print(name, "max|d|", max_err(y, g[name + "_y"]), "scale", sc)
     assert y.shape == g[name + "_y"].shape and max_err(y, g[name + "_y"]) < 2e-5 * sc
+
+
+@pytest.mark.parametrize("name", ["v_even", "v_odd", "v_periodic", "v_layer"])
+def test_unet_on_volumes(golden, name):
+    """``spatial = 3`` (azula/nn/unet.py:119-259 with Conv3d): every 3-D convolution as depth taps of the 2-D kernels
+    accumulating in place (azula_amd/nn/unet3d.py); zero and circular padding, odd sizes (narrow before the concat)."""
+    from azula_amd.nn import UNet
+
+    g = golden("g16_unet3d")
+    cfg = dict(g.meta[name + "_cfg"])
+    periodic = cfg.pop("periodic")
+    net = UNet(**cfg, spatial=3, periodic=periodic)
+    sh = {n: tuple(v) for n, v in g.meta[name + "_shapes"].items()}
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == sh
+    net.load_state_dict(synth.synth_state_dict(sh, 61))
+    x = g[name + "_x"]
+    y = net.cuda().eval()(x.cuda(), g["mod"][: x.shape[0]].cuda())
+    sc = max(1.0, g[name + "_y"].abs().max().item())
+    print(name, "max|d|", max_err(y, g[name + "_y"]), "scale", sc)
+    assert y.shape == g[name + "_y"].shape and max_err(y, g[name + "_y"]) < 2e-5 * sc
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_unet_block_on_a_volume(periodic):
+    """Standalone ``UNetBlock(spatial=3).forward`` (one-block plan on the volume form) against the oracle's block
+    (pinned to the reference for volumes by G16)."""
+    from azula_amd.nn.unet import UNetBlock
+    from oracle import nets
+
+    torch.manual_seed(5)
+    kw = dict(padding_mode="circular") if periodic else {}
+    blk = UNetBlock(12, mod_features=8, norm="group", groups=4, spatial=3, kernel_size=(3, 3, 3), **kw)
+    for p in blk.parameters():
+        p.data.normal_(0, 0.3)
+    x, mod = torch.randn(2, 12, 3, 6, 5), torch.randn(2, 8)
+    sd = {"b." + k: v.detach().clone() for k, v in blk.state_dict().items()}
+    ref = nets.unet_block(sd, "b", x, mod, "group", 4, periodic)
+    y = blk.cuda().eval()(x.cuda(), mod.cuda())
+    sc = max(1.0, ref.abs().max().item())
+    print("UNetBlock 3-D periodic", periodic, "max|d|", max_err(y, ref), "scale", sc)
+    assert y.shape == ref.shape and max_err(y, ref) < 2e-5 * sc
