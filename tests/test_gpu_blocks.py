@@ -240,3 +240,30 @@ def test_unet_block_on_a_volume(periodic):
     sc = max(1.0, ref.abs().max().item())
     print("UNetBlock 3-D periodic", periodic, "max|d|", max_err(y, ref), "scale", sc)
     assert y.shape == ref.shape and max_err(y, ref) < 2e-5 * sc
+
+
+def test_sampling_a_volume_with_a_3d_unet():
+    """KarrasDenoiser(TimeModulated(UNet(spatial=3))) + DDIM on a (B, C, D, H, W) latent: the generic step loop (the
+    captured graph takes 4-D latents) against the oracle's loop around its 3-D network."""
+    from azula_amd.denoise import KarrasDenoiser
+    from azula_amd.nn import UNet
+    from azula_amd.nn.wrappers import TimeModulated
+    from azula_amd.noise import VPSchedule
+    from azula_amd.sample import DDIMSampler
+    from oracle import nets, sampling
+
+    torch.manual_seed(8)
+    cfg = dict(in_channels=2, out_channels=2, hid_channels=(8, 16), hid_blocks=(1, 1), norm="group", groups=4, mod_features=16)
+    bb = TimeModulated(UNet(**cfg, spatial=3), 16, name="unet")
+    for p in bb.parameters():
+        if p.ndim > 1 and not torch.any(p != 0):
+            p.data.normal_(0, 0.1)
+    den = KarrasDenoiser(bb, VPSchedule()).cuda().eval()
+    sd = {k: v.detach().cpu().clone() for k, v in bb.state_dict().items()}
+    x1 = torch.randn(2, 2, 4, 6, 6)
+    omean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, cfg, a, c), x, t)  # noqa: E731
+    ref = sampling.sample(omean, x1, steps=4, eta=0.0)
+    x0 = DDIMSampler(den, steps=4, silent=True)(x1.cuda())
+    sc = max(1.0, ref.abs().max().item())
+    print("3-D DDIM-4 max|d|", max_err(x0, ref), "scale", sc)
+    assert x0.shape == ref.shape and max_err(x0, ref) < 2e-5 * sc
