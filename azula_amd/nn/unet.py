@@ -380,8 +380,17 @@ class UNet(nn.Module):
         from ..sample import BackboneProgram
 
         self._check_device(x)
-        if x.ndim != 4 or self.cond_channels:
+        if self.cond_channels or x.ndim != (5 if self.spatial == 3 else 4):
             return None, None
+        if self.spatial == 3:  # the loop's layouts only know (B, C, inner): a volume is an image of D H x W pixels
+            B, _, Dd, H, W = x.shape
+            p = self.plan3d(B, Dd, H, W, mod_rows, x.device)
+            prog = BackboneProgram(
+                tape=_copy_tape(p.tape), x_in=p.x_in.buf, x_in_cs=p.x_in.cs, out=p.out, f_channels=self.out_channels,
+                f_nhwc=False,
+            )
+            prog.tape.keep.append(p)
+            return prog, p.mod
         B, _, H, W = x.shape
         p = self.plan(B, H, W, mod_rows, x.device)
         prog = BackboneProgram(

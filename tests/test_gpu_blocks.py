@@ -243,8 +243,8 @@ def test_unet_block_on_a_volume(periodic):
 
 
 def test_sampling_a_volume_with_a_3d_unet():
-    """KarrasDenoiser(TimeModulated(UNet(spatial=3))) + DDIM on a (B, C, D, H, W) latent: the generic step loop (the
-    captured graph takes 4-D latents) against the oracle's loop around its 3-D network."""
+    """KarrasDenoiser(TimeModulated(UNet(spatial=3))) + DDIM on a (B, C, D, H, W) latent, captured like the image loop (the
+    transition kernel sees the volume as an image of D H x W pixels), against the oracle's loop around its 3-D network."""
     from azula_amd.denoise import KarrasDenoiser
     from azula_amd.nn import UNet
     from azula_amd.nn.wrappers import TimeModulated
@@ -263,7 +263,9 @@ def test_sampling_a_volume_with_a_3d_unet():
     x1 = torch.randn(2, 2, 4, 6, 6)
     omean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, cfg, a, c), x, t)  # noqa: E731
     ref = sampling.sample(omean, x1, steps=4, eta=0.0)
-    x0 = DDIMSampler(den, steps=4, silent=True)(x1.cuda())
+    smp = DDIMSampler(den, steps=4, silent=True)
+    x0 = smp(x1.cuda())
+    assert next(iter(smp._fused_cache.values())).graph is not None, "the volume loop must be captured"
     sc = max(1.0, ref.abs().max().item())
     print("3-D DDIM-4 max|d|", max_err(x0, ref), "scale", sc)
     assert x0.shape == ref.shape and max_err(x0, ref) < 2e-5 * sc
