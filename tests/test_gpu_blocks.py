@@ -269,3 +269,35 @@ def test_sampling_a_volume_with_a_3d_unet():
     sc = max(1.0, ref.abs().max().item())
     print("3-D DDIM-4 max|d|", max_err(x0, ref), "scale", sc)
     assert x0.shape == ref.shape and max_err(x0, ref) < 2e-5 * sc
+
+
+@pytest.mark.parametrize("case", ["k5_cond", "stride4", "shared_mod", "anisotropic_kernel"])
+def test_unet_on_volumes_more_shapes(case):
+    """spatial = 3 beyond G16's configurations, against the oracle (pinned to the reference for volumes by G16): 5^3
+    kernels with a condition volume, stride 4 on an odd volume, a single modulation vector, a (1, 3, 5) kernel."""
+    from azula_amd.nn import UNet
+    from oracle import nets
+
+    torch.manual_seed({"k5_cond": 1, "stride4": 2, "shared_mod": 3, "anisotropic_kernel": 4}[case])
+    cfg = dict(in_channels=2, out_channels=2, hid_channels=(8, 12), hid_blocks=(1, 1), norm="group", groups=4, mod_features=8)
+    kw, shape, cond, mod = {}, (2, 2, 5, 6, 7), None, torch.randn(2, 8)
+    if case == "k5_cond":
+        kw, cond = dict(kernel_size=5, cond_channels=1), torch.randn(2, 1, 5, 6, 7)
+    elif case == "stride4":
+        kw, shape = dict(stride=4), (1, 2, 9, 10, 6)
+        mod = mod[:1]
+    elif case == "shared_mod":
+        mod = torch.randn(8)
+    else:
+        kw = dict(kernel_size=(1, 3, 5))
+    net = UNet(**cfg, **kw, spatial=3, periodic=case == "shared_mod")
+    for p in net.parameters():
+        p.data.normal_(0, 0.2)
+    x = torch.randn(*shape)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    ocfg = dict(cfg, periodic=case == "shared_mod", stride=kw.get("stride", 2))
+    ref = nets.unet_forward(sd, ocfg, x if cond is None else torch.cat((x, cond), 1), mod)
+    y = net.cuda().eval()(x.cuda(), mod.cuda(), cond=cond.cuda() if cond is not None else None)
+    sc = max(1.0, ref.abs().max().item())
+    print(case, "max|d|", max_err(y, ref), "scale", sc)
+    assert y.shape == ref.shape and max_err(y, ref) < 3e-5 * sc
