@@ -146,6 +146,25 @@ def host_info() -> dict:
     return {"cpu_model": model, "host_cores": os.cpu_count() or 1, "usable_cores": avail}
 
 
+STREAM_BYTES: dict = {}  # id(profile record) -> algorithmic bytes of a memory-bound op (None: not one)
+
+
+def stream_bytes(name, args):
+    r"""Algorithmic HBM bytes of the elementwise / reduction ops of a step (every element once): the normalise pass reads
+    and writes the activation (a quarter of the writes when it pools), the statistics pass reads it, the row norm both."""
+    try:
+        if name == "az_affine_act_f32":  # (y, x, x1, c0s, S, T, B, H, W, cs, act, pool)
+            n = args[6] * args[7] * args[8] * args[9] * 4
+            return n + (n // 4 if args[11] else n)
+        if name == "az_groupnorm_stats_f32":  # (partials, x, x1, c0s, B, HW, C, cs, groups, nchunks)
+            return args[4] * args[5] * args[7] * 4
+        if name == "az_rownorm_mod_f32":  # (y, x, weight, scale, shift, bstride, rows, rows_per_batch, C, cs, kind, eps)
+            return 2 * args[6] * args[9] * 4
+    except Exception:  # noqa: BLE001 -- accounting only
+        pass
+    return None
+
+
 def tape_profile(sampler, device):
     r"""Per-launch HIP-event timing of EVERY op of one denoise step (the tape the hipGraph replays), run eagerly on the
     launch stream.  Returns [(op name, kernel family, ms, algorithmic flops or 0, descriptor)]."""
@@ -167,9 +186,10 @@ def tape_profile(sampler, device):
             recs.append((name, e0, e1, desc))
         torch.cuda.synchronize(device)
     out = []
-    for name, e0, e1, desc in recs:
+    for (name, e0, e1, desc), (_, args, _) in zip(recs, tape.ops):
         fam = getattr(desc, "_algo", name) if name in CONV_OPS else name
         out.append((name, fam, e0.elapsed_time(e1), getattr(desc, "_flops", 0) if desc is not None else 0, desc))
+        STREAM_BYTES[id(out[-1])] = stream_bytes(name, args)
     if os.environ.get("AZ_BENCH_DETAIL"):
         for name, fam, ms, fl, d in out:
             if name in CONV_OPS:
@@ -504,6 +524,21 @@ def roofline_report(sampler, device, args, world) -> dict:
         out["traffic_source"] = pmc["source"]
         out["traffic_calibration"] = {k: round(v["factor"], 4) for k, v in pmc["calibration"].items()}
     other = {fam: round(f["ms"], 4) for fam, f in sorted(fams.items(), key=lambda kv: -kv[1]["ms"]) if not f["flops"]}
+    hbm = {}
+    for rec in prof:
+        nb = STREAM_BYTES.get(id(rec))
+        if nb:
+            h = hbm.setdefault(rec[1], {"bytes": 0, "ms": 0.0, "launches": 0})
+            h["bytes"] += nb
+            h["ms"] += rec[2]
+            h["launches"] += 1
+    out["roofline_hbm_kernels"] = {
+        fam: {"bound": "hbm", "achieved": round(h["bytes"] / (h["ms"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+              "frac": round(h["bytes"] / (h["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launches": h["launches"],
+              "algorithmic_bytes_per_step": h["bytes"], "ms_per_denoise_step": round(h["ms"], 4),
+              "note": "per-launch HIP-event time of the eager tape; a step's activations are partly Infinity-Cache resident "
+                      "(the producer has just written them), so this is an effective rate, not an HBM counter"}
+        for fam, h in hbm.items()}
     out["step_breakdown"] = {"eager_sum_ms": round(step_ms, 3), "matrix_ms": round(sum(k["ms_per_denoise_step"] for k in kernels.values()), 3),
                              "other_ms": other}
     trans = transition_roofline(device)
