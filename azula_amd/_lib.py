@@ -158,6 +158,10 @@ class AzConvArgs(C.Structure):
         ("pad_mode", C.c_int32),
         ("gn_chunks", C.c_int32),
         ("gn_quads", c_f32p),
+        ("aniso", C.c_int32),
+        ("stride_w", C.c_int32),
+        ("up0_w", C.c_int32),
+        ("up1_w", C.c_int32),
     ]
 
 

@@ -87,6 +87,9 @@ __device__ __forceinline__ int wrap_coord(int i, int n, int mode) {
 }
 #define AZ_RSRC_CLAMP 0x80000000ll  // == OOB: the largest num_records a descriptor may carry
 
+// log2 upsampling factor along the width: its own field when the descriptor is anisotropic (validated to [0, 4])
+static inline int az_upw(const AzConvArgs* a, int up, int up_w) { return a->aniso ? (up_w < 0 ? 0 : (up_w > 4 ? 4 : up_w)) : up; }
+
 // Epilogue for 4 consecutive output channels [co, co+4) of output pixel n.
 // The fused epilogue in two halves so that callers can issue the loads of several outputs before the first store (the
 // compiler cannot move a load above a store that might alias it): fetch = the gate / residual reads, apply = bias,
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
     const int ow = rem - oh * a.wout;
     prel[i] = pv ? b - b_first : -1;
     ihb[i] = oh * a.stride - a.pad;
-    iwb[i] = ow * a.stride - a.pad;
+    iwb[i] = ow * (a.aniso ? a.stride_w : a.stride) - a.pad;
   }
 
   // K iterator (wave-uniform): tap -> source -> 32-channel chunk.  The per-lane activation
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
     const int kx = it_tap - ky * a.ksize;
     const int cs = it_src ? a.c1s : a.c0s;
     const int up = it_src ? a.up1 : a.up0;
+    const int upw = a.aniso ? (it_src ? a.up1_w : a.up0_w) : up;
     const int hs = it_src ? a.h1 : a.h0;
     const int ws = it_src ? a.w1 : a.w0;
 #pragma unroll
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
       const int ih = wrap_coord(ihb[i] + ky, a.hin, a.pad_mode);
       const int iw = wrap_coord(iwb[i] + kx, a.win, a.pad_mode);
       const bool ok = prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
-      const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> up);
+      const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> upw);
       voffA[i] = ok ? (unsigned)((pix * cs + cc * 4) * 4) : OOB;
     }
   };
@@ -658,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
     const int oh = rem / a.wout;
     prel[i] = pv ? b - b_first : -1;
     ihb[i] = oh * a.stride - a.pad;
-    iwb[i] = (rem - oh * a.wout) * a.stride - a.pad;
+    iwb[i] = (rem - oh * a.wout) * (a.aniso ? a.stride_w : a.stride) - a.pad;
   }
 
   const int nk_tap = p.nkc0 + p.nkc1;
@@ -672,6 +676,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
     const int kx = it_tap - ky * a.ksize;
     const int cs = it_src ? a.c1s : a.c0s;
     const int up = it_src ? a.up1 : a.up0;
+    const int upw = a.aniso ? (it_src ? a.up1_w : a.up0_w) : up;
     const int hs = it_src ? a.h1 : a.h0;
     const int ws = it_src ? a.w1 : a.w0;
 #pragma unroll
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
       const int ih = wrap_coord(ihb[i] + ky, a.hin, a.pad_mode);
       const int iw = wrap_coord(iwb[i] + kx, a.win, a.pad_mode);
       const bool ok = prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
-      const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> up);
+      const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> upw);
       voffA[i] = ok ? (unsigned)((pix * cs + acc4 * 4) * 4) : OOB;
     }
   };
@@ -873,7 +878,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
     const int oh = rem / a.wout;
     prel[i] = pv ? b - b_first : -1;
     ihb[i] = oh * a.stride - a.pad;
-    iwb[i] = (rem - oh * a.wout) * a.stride - a.pad;
+    iwb[i] = (rem - oh * a.wout) * (a.aniso ? a.stride_w : a.stride) - a.pad;
   }
 
   const int nk_tap = p.nkc0 + p.nkc1;
@@ -887,6 +892,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
     const int kx = it_tap - ky * a.ksize;
     const int cs = it_src ? a.c1s : a.c0s;
     const int up = it_src ? a.up1 : a.up0;
+    const int upw = a.aniso ? (it_src ? a.up1_w : a.up0_w) : up;
     const int hs = it_src ? a.h1 : a.h0;
     const int ws = it_src ? a.w1 : a.w0;
 #pragma unroll
@@ -894,7 +900,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
       const int ih = wrap_coord(ihb[i] + ky, a.hin, a.pad_mode);
       const int iw = wrap_coord(iwb[i] + kx, a.win, a.pad_mode);
       const bool ok = prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
-      const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> up);
+      const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> upw);
       voffA[i] = ok ? (unsigned)((pix * cs + kc8 * 8) * 4) : OOB;
     }
   };
@@ -1876,16 +1882,16 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout > 0 && a->wout > 0, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
-  AZ_REQUIRE(a->ksize >= 1 && a->ksize <= 7 && a->stride >= 1 && a->pad >= 0, AZ_E_SHAPE);
+  AZ_REQUIRE(a->ksize >= 1 && a->ksize <= 7 && a->stride >= 1 && a->pad >= 0 && (!a->aniso || a->stride_w >= 1), AZ_E_SHAPE);
   AZ_REQUIRE((a->hin + 2 * a->pad - a->ksize) / a->stride + 1 == a->hout &&
-                 (a->win + 2 * a->pad - a->ksize) / a->stride + 1 == a->wout,
+                 (a->win + 2 * a->pad - a->ksize) / (a->aniso ? a->stride_w : a->stride) + 1 == a->wout,
              AZ_E_SHAPE);
   AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
-                 ((a->win + (1 << a->up0) - 1) >> a->up0) <= a->w0,
+                 ((a->win + (1 << az_upw(a, a->up0, a->up0_w)) - 1) >> az_upw(a, a->up0, a->up0_w)) <= a->w0,
              AZ_E_SHAPE);
   if (a->src1)
     AZ_REQUIRE(a->up1 >= 0 && a->up1 <= 4 && ((a->hin + (1 << a->up1) - 1) >> a->up1) <= a->h1 &&
-                 ((a->win + (1 << a->up1) - 1) >> a->up1) <= a->w1,
+                 ((a->win + (1 << az_upw(a, a->up1, a->up1_w)) - 1) >> az_upw(a, a->up1, a->up1_w)) <= a->w1,
              AZ_E_SHAPE);
   AZ_REQUIRE(AZ_ALIGNED16(a->src0) && AZ_ALIGNED16(a->src1) && AZ_ALIGNED16(a->weight) && AZ_ALIGNED16(a->bias) &&
                  AZ_ALIGNED16(a->gate) && AZ_ALIGNED16(a->res) && AZ_ALIGNED16(a->workspace),
@@ -1934,7 +1940,7 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     AZ_REQUIRE((int64_t)a->ksize * a->ksize * a->cout_s * p.cin_s * (half == 3 ? 6 : 4) <= (1ll << 31), AZ_E_SHAPE);
   }
   hipStream_t st = az_s(stream);
-  if (!half && a->cout_s == 4 && a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->src1 && a->up0 == 0 &&
+  if (!half && a->cout_s == 4 && a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->src1 && a->up0 == 0 && !a->aniso &&
       a->c0s % HD_KC == 0 && a->h0 == a->hin && a->w0 == a->win) {
     // narrow output (image head): VALU kernel, no split-K
     p.a.splitk = 1;
@@ -1981,16 +1987,16 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
  * ksize = 3, stride = 1, pad = 1. */
 int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
-  AZ_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1, AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->aniso, AZ_E_UNSUPPORTED);  // anisotropic: direct kernel
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
   AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
-                 ((a->win + (1 << a->up0) - 1) >> a->up0) <= a->w0,
+                 ((a->win + (1 << az_upw(a, a->up0, a->up0_w)) - 1) >> az_upw(a, a->up0, a->up0_w)) <= a->w0,
              AZ_E_SHAPE);
   if (a->src1)
     AZ_REQUIRE(a->up1 >= 0 && a->up1 <= 4 && ((a->hin + (1 << a->up1) - 1) >> a->up1) <= a->h1 &&
-                 ((a->win + (1 << a->up1) - 1) >> a->up1) <= a->w1,
+                 ((a->win + (1 << az_upw(a, a->up1, a->up1_w)) - 1) >> az_upw(a, a->up1, a->up1_w)) <= a->w1,
              AZ_E_SHAPE);
   AZ_REQUIRE(AZ_ALIGNED16(a->src0) && AZ_ALIGNED16(a->src1) && AZ_ALIGNED16(a->weight) && AZ_ALIGNED16(a->bias) &&
                  AZ_ALIGNED16(a->gate) && AZ_ALIGNED16(a->res) && AZ_ALIGNED16(a->workspace),
@@ -2073,16 +2079,16 @@ int az_conv2d_winograd_suggest_splitk(int64_t batch, int32_t hout, int32_t wout,
  * az_winograd4_pack_filter_f32.  Only ksize = 3, stride = 1, pad = 1. */
 int az_conv2d_winograd4_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
-  AZ_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1, AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->aniso, AZ_E_UNSUPPORTED);  // anisotropic: direct kernel
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
   AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
-                 ((a->win + (1 << a->up0) - 1) >> a->up0) <= a->w0,
+                 ((a->win + (1 << az_upw(a, a->up0, a->up0_w)) - 1) >> az_upw(a, a->up0, a->up0_w)) <= a->w0,
              AZ_E_SHAPE);
   if (a->src1)
     AZ_REQUIRE(a->up1 >= 0 && a->up1 <= 4 && ((a->hin + (1 << a->up1) - 1) >> a->up1) <= a->h1 &&
-                 ((a->win + (1 << a->up1) - 1) >> a->up1) <= a->w1,
+                 ((a->win + (1 << az_upw(a, a->up1, a->up1_w)) - 1) >> az_upw(a, a->up1, a->up1_w)) <= a->w1,
              AZ_E_SHAPE);
   AZ_REQUIRE(AZ_ALIGNED16(a->src0) && AZ_ALIGNED16(a->src1) && AZ_ALIGNED16(a->weight) && AZ_ALIGNED16(a->bias) &&
                  AZ_ALIGNED16(a->gate) && AZ_ALIGNED16(a->res) && AZ_ALIGNED16(a->workspace),

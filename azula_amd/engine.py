@@ -291,7 +291,7 @@ class Builder:
         up1: int = 0,
         hin: int | None = None,
         win: int | None = None,
-        stride: int = 1,
+        stride: int | tuple = 1,
         act: int = 0,
         gate: torch.Tensor | None = None,
         gate_off: int = 0,
@@ -307,14 +307,19 @@ class Builder:
         ks, bias = packed.ks, packed.bias
         pad = ks // 2
         B = src0.B
+        # (height, width) pairs select the anisotropic descriptor (a stride sequence such as (2, 1), unet.py:159-186)
+        (stride, stride_w), (up0, up0_w), (up1, up1_w) = (v if isinstance(v, (tuple, list)) else (v, v) for v in (stride, up0, up1))
+        aniso = stride != stride_w or up0 != up0_w or up1 != up1_w
         if hin is None:
             hin = src0.H << up0
         if win is None:
-            win = src0.W << up0
+            win = src0.W << up0_w
         hout = (hin + 2 * pad - ks) // stride + 1
-        wout = (win + 2 * pad - ks) // stride + 1
+        wout = (win + 2 * pad - ks) // stride_w + 1
         a = AzConvArgs()
         a.src0, a.c0s, a.up0, a.h0, a.w0 = src0.ptr, src0.cs, up0, src0.H, src0.W
+        if aniso:
+            a.aniso, a.stride_w, a.up0_w, a.up1_w = 1, stride_w, up0_w, up1_w
         if src1 is not None:
             a.src1, a.c1s, a.up1, a.h1, a.w1 = src1.ptr, src1.cs, up1, src1.H, src1.W
         assert (a.c0s, a.c1s) == (packed.c0s, packed.c1s), "weights were packed for different source strides"
@@ -346,12 +351,13 @@ class Builder:
         npix = B * hout * wout
         cin_s = a.c0s + a.c1s
         lib = _lib.lib()
-        legal = ks == 3 and stride == 1 and self.half is None  # half-precision modules: the direct bf16 / f16 kernel
+        # (half-precision modules: the direct bf16 / f16 kernel; one factor per axis: the direct kernel's loaders only)
+        legal = ks == 3 and stride == 1 and not aniso and self.half is None
         tiles4 = B * ((hout + 3) // 4) * ((wout + 3) // 4)
         head_wgs = B * ((hout + 15) // 16) * ((wout + 15) // 16)
         # image head (<= 4 output channels) on a map that fills the chip with 16 x 16-pixel workgroups:
         # az_conv2d_f32 runs its narrow-output VALU kernel (104 vs 342 us at 4 x 256^2, 256 -> 3)
-        head = (winograd is None and legal and a.cout_s == 4 and src1 is None and up0 == 0 and a.c0s % 16 == 0
+        head = (winograd is None and legal and not aniso and a.cout_s == 4 and src1 is None and up0 == 0 and a.c0s % 16 == 0
                 and head_wgs >= 256)
         wino_ok = legal and not head and winograd != "x3"
         use_f4 = wino_ok and (winograd == 4 or (winograd is None and WINOGRAD == "4" and tiles4 >= WINOGRAD4_MIN_TILES))

@@ -235,6 +235,7 @@ class UNetPlan:
         self.versions = net._param_versions()
         L = len(net.hid_blocks)
         stride = net.stride
+        up = stride.bit_length() - 1 if isinstance(stride, int) else tuple(v.bit_length() - 1 for v in stride)
 
         mod_jobs: list[tuple] = []  # queued modulation MLPs (ada_zero_triple), emitted together at the tape front
         per = net.periodic
@@ -262,7 +263,7 @@ class UNetPlan:
                 y = skips[i]
                 conv = mods[0]
                 merged = bld.conv(
-                    y, bld.pack_conv(conv.weight, conv.bias, cin0=y.C), conv.out_channels, src1=cur, up1=stride.bit_length() - 1,
+                    y, bld.pack_conv(conv.weight, conv.bias, cin0=y.C), conv.out_channels, src1=cur, up1=up,
                     hin=y.H, win=y.W, periodic=per, gn_stats=gn,
                 )
                 bld.free(cur)
@@ -316,14 +317,14 @@ class UNet(nn.Module):
         if isinstance(stride, int):
             stride = [stride] * spatial
         assert len(kernel_size) == len(stride) == spatial
-        if len(set(stride)) != 1 or any(k % 2 == 0 for k in kernel_size):
-            raise NotImplementedError("odd kernel sizes (anisotropic allowed) and isotropic strides only")
-        if stride[0] not in (1, 2, 4, 8, 16):
+        if any(k % 2 == 0 for k in kernel_size):
+            raise NotImplementedError("odd kernel sizes only (anisotropic allowed)")
+        if any(s_ not in (1, 2, 4, 8, 16) for s_ in stride):
             raise NotImplementedError(
-                "strides 1, 2, 4, 8, 16 only (the nearest upsampling is a right shift of the merge convolution's gather)")
+                "strides 1, 2, 4, 8, 16 per axis only (the nearest upsampling is a right shift of the merge convolution's gather)")
         self.in_channels, self.out_channels, self.cond_channels = in_channels, out_channels, cond_channels
         self.hid_channels, self.hid_blocks = tuple(hid_channels), tuple(hid_blocks)
-        self.stride = stride[0]
+        self.stride = stride[0] if len(set(stride)) == 1 else tuple(stride)  # int (isotropic) or one per axis
         self.mod_features = kwargs.get("mod_features", 0)
         self.periodic = bool(periodic)
         if periodic:  # reference unet.py:175-180: every convolution pads circularly
@@ -337,7 +338,7 @@ class UNet(nn.Module):
                 do.append(UNetBlock(hid_channels[i], kernel_size=ks, spatial=spatial, **kwargs))
                 up.append(UNetBlock(hid_channels[i], kernel_size=ks, spatial=spatial, **kwargs))
             if i > 0:
-                do.insert(0, _conv_holder(hid_channels[i - 1], hid_channels[i], ks, stride=self.stride, identity_init=identity_init))
+                do.insert(0, _conv_holder(hid_channels[i - 1], hid_channels[i], ks, stride=tuple(stride), identity_init=identity_init))
                 up.append(nn.Upsample(scale_factor=tuple(float(s) for s in stride), mode="nearest"))
             else:
                 do.insert(0, _conv_holder(in_channels + cond_channels, hid_channels[i], ks))

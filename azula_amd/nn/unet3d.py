@@ -54,7 +54,7 @@ def _depth_index(i: int, n: int, periodic: bool) -> int:
     return i % n if periodic else -1
 
 
-def conv3d(bld: Builder, x: Vol, conv, *, stride: int = 1, periodic: bool = False, x1: Vol | None = None, up1: int = 0,
+def conv3d(bld: Builder, x: Vol, conv, *, stride=1, periodic: bool = False, x1: Vol | None = None, up1=0,
            like: Vol | None = None, silu: bool = False, gate=None, gate_off: int = 0, gate_bstride: int = 0,
            res: Vol | None = None) -> Vol:
     r"""``conv``: holder of a (Cout, Cin, kd, kh, kw) weight (+ bias).  ``x1`` (read through nearest x 2^up1 upsampling,
@@ -65,15 +65,17 @@ def conv3d(bld: Builder, x: Vol, conv, *, stride: int = 1, periodic: bool = Fals
     assert kh == kw or True
     p = kd // 2
     Din, Hin, Win = (like.D, like.H, like.W) if like is not None else (x.D, x.H, x.W)
-    Do = (Din + 2 * p - kd) // stride + 1
-    Ho = (Hin + 2 * (kh // 2) - kh) // stride + 1
-    Wo = (Win + 2 * (kw // 2) - kw) // stride + 1
+    sd_, sh_, sw_ = (stride, stride, stride) if isinstance(stride, int) else stride  # per-axis strides
+    ud_, uh_, uw_ = (up1, up1, up1) if isinstance(up1, int) else up1  # per-axis log2 upsampling of x1
+    Do = (Din + 2 * p - kd) // sd_ + 1
+    Ho = (Hin + 2 * (kh // 2) - kh) // sh_ + 1
+    Wo = (Win + 2 * (kw // 2) - kw) // sw_ + 1
     out = new_vol(bld, x.B, Do, Ho, Wo, cout)
     taps = [p] + [j for j in range(kd) if j != p]  # centre first: it exists for every output plane and writes it
     packs = {j: bld.pack_conv(w[:, :, j], bias if j == p else None, cin0=x.C if x1 is not None else None) for j in taps}
     for b in range(x.B):
         g = dict(gate=gate, gate_off=gate_off + b * gate_bstride, gate_bstride=0) if gate is not None else {}
-        if stride == 1 and x1 is None:  # contiguous plane ranges: one launch per (sample, tap[, wrap piece])
+        if (sd_, sh_, sw_) == (1, 1, 1) and x1 is None:  # contiguous plane ranges: one launch per (sample, tap[, wrap piece])
             for j in taps:
                 o = j - p
                 lo, hi = max(0, -o), min(Do, Din - o)  # output planes whose tap lies inside the volume
@@ -91,13 +93,13 @@ def conv3d(bld: Builder, x: Vol, conv, *, stride: int = 1, periodic: bool = Fals
         else:
             for d in range(Do):
                 for j in taps:
-                    i = _depth_index(stride * d + j - p, Din, periodic)
+                    i = _depth_index(sd_ * d + j - p, Din, periodic)
                     if i < 0:
                         continue
                     dst = out.planes(b, d, d + 1)
                     first = j == p
-                    kw_ = dict(src1=x1.planes(b, i >> up1, (i >> up1) + 1), up1=up1, hin=Hin, win=Win) if x1 is not None else {}
-                    bld.conv(x.planes(b, i, i + 1), packs[j], cout, stride=stride, periodic=periodic, out=dst,
+                    kw_ = dict(src1=x1.planes(b, i >> ud_, (i >> ud_) + 1), up1=(uh_, uw_), hin=Hin, win=Win) if x1 is not None else {}
+                    bld.conv(x.planes(b, i, i + 1), packs[j], cout, stride=(sh_, sw_), periodic=periodic, out=dst,
                              res=(res.planes(b, d, d + 1) if res is not None else None) if first else dst, **g, **kw_)
     if silu:
         bld.tape.add("az_silu_f32", out.buf.data_ptr(), out.buf.data_ptr(), out.buf.numel())
@@ -138,7 +140,7 @@ class UNet3DPlan:
         self.versions = net._param_versions()
         L = len(net.hid_blocks)
         stride, per = net.stride, net.periodic
-        up = stride.bit_length() - 1
+        up = stride.bit_length() - 1 if isinstance(stride, int) else tuple(v.bit_length() - 1 for v in stride)
         mod_jobs: list[tuple] = []
         cur = self.x_in
         skips: list[Vol] = []

@@ -268,6 +268,11 @@ typedef struct AzConvArgs {
                             * moments of the OUTPUT, (batch, gn_chunks, cout_s / 4, 4) floats = (n, mean, M2, 0) per image,
                             * tile block and channel quad -- consumed by az_groupnorm_finalize_f32 (quads_per_group) so that
                             * the normalisation that follows needs no statistics pass over the tensor */
+  int32_t aniso;           /* 1: the WIDTH axis has its own stride / upsampling factors (azula/nn/unet.py:159-186 with a
+                            * stride sequence such as (2, 1)); 0: `stride`, `up0`, `up1` apply to both axes.  Direct kernels
+                            * (az_conv2d_f32 / _bf16_f32 / _f16_f32 / _x3_f32) only: the Winograd entries return UNSUPPORTED */
+  int32_t stride_w;        /* with aniso: stride along the width (`stride` is then the height's) */
+  int32_t up0_w, up1_w;    /* with aniso: log2 upsampling of each source along the width */
 } AzConvArgs;
 /* Narrow outputs (cout_s == 4, 3x3 stride 1 pad 1, one un-upsampled source with c0s % 16 == 0: the image head of
  * azula/nn/unet.py) run a VALU kernel instead of the 128-cout MFMA tile; splitk is ignored there.              */

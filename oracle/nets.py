@@ -22,7 +22,7 @@ def _linear(sd, key: str, x: Tensor) -> Tensor:
     return F.linear(x, sd[key + ".weight"], sd.get(key + ".bias"))
 
 
-def _conv(sd, key: str, x: Tensor, stride: int = 1, padding=None, periodic: bool = False) -> Tensor:
+def _conv(sd, key: str, x: Tensor, stride=1, padding=None, periodic: bool = False) -> Tensor:
     r"""ConvNd (azula/nn/layers.py:25-50) for 1-D signals, 2-D images and 3-D volumes (B, C, *spatial); 'same' padding
     (kernel // 2 per axis, azula/nn/unet.py:170-172) unless given."""
     n = x.ndim - 2
@@ -96,7 +96,9 @@ def unet_forward(sd, cfg: dict, x: Tensor, mod: Tensor | None = None, tap: dict 
     hid_blocks = list(cfg["hid_blocks"])
     norm, groups = cfg.get("norm", "layer"), cfg.get("groups", 16)
     per = cfg.get("periodic", False)
-    stride = cfg.get("stride", 2)  # isotropic: the downsampling convolutions' stride = the nearest upsampling factor (:181-186)
+    stride = cfg.get("stride", 2)  # int or one per axis: the downsampling convolutions' stride = the nearest upsampling factor (:159-186)
+    if not isinstance(stride, int):
+        stride = tuple(stride)
     L = len(hid_blocks)
     memory = []
     for i in range(L):
@@ -116,7 +118,7 @@ def unet_forward(sd, cfg: dict, x: Tensor, mod: Tensor | None = None, tap: dict 
             x = unet_block(sd, f"ascent.{k}.{idx + j}", x, mod, norm, groups, per)
         idx += hid_blocks[i]
         if i > 0:
-            x = F.interpolate(x, scale_factor=(float(stride),) * (x.ndim - 2), mode="nearest")
+            x = F.interpolate(x, scale_factor=tuple(float(v) for v in stride) if isinstance(stride, tuple) else (float(stride),) * (x.ndim - 2), mode="nearest")
         else:
             x = _conv(sd, f"ascent.{k}.{idx}", x, periodic=per)
         if tap is not None:

@@ -301,3 +301,24 @@ def test_unet_on_volumes_more_shapes(case):
     sc = max(1.0, ref.abs().max().item())
     print(case, "max|d|", max_err(y, ref), "scale", sc)
     assert y.shape == ref.shape and max_err(y, ref) < 3e-5 * sc
+
+
+@pytest.mark.parametrize("name", ["i21", "i14", "i42_periodic", "v122", "v214"])
+def test_unet_one_stride_per_axis(golden, name):
+    """A stride SEQUENCE (azula/nn/unet.py:159-186): the downsampling convolutions and the nearest upsampling of the merge
+    convolution's gather take one (power-of-two) factor per axis (AzConvArgs.aniso / stride_w / up1_w; depth by plane
+    index on volumes)."""
+    from azula_amd.nn import UNet
+
+    g = golden("g17_anisotropic_strides")
+    cfg = dict(g.meta[name + "_cfg"])
+    cfg["stride"] = tuple(cfg["stride"])
+    net = UNet(**cfg)
+    sh = {n: tuple(v) for n, v in g.meta[name + "_shapes"].items()}
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == sh
+    net.load_state_dict(synth.synth_state_dict(sh, 71))
+    x = g[name + "_x"]
+    y = net.cuda().eval()(x.cuda(), g["mod"][: x.shape[0]].cuda())
+    sc = max(1.0, g[name + "_y"].abs().max().item())
+    print(name, "max|d|", max_err(y, g[name + "_y"]), "scale", sc)
+    assert y.shape == g[name + "_y"].shape and max_err(y, g[name + "_y"]) < 2e-5 * sc
