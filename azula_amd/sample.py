@@ -744,10 +744,10 @@ class _MultistepSampler(Sampler):
     def _weights(cls, u: Tensor, i: int, n: int) -> Tensor:
         return _lagrange_weights(u, i, n, cls._moments)
 
-    def _device_table(self, alpha: Tensor, sigma: Tensor) -> Tensor:
-        r"""(steps, 4 + MAX_HIST) fp32 rows [a, b, p, w_new, w_hist oldest-first] from host scalars."""
+    def _device_table(self, alpha: Tensor, sigma: Tensor, dtype: torch.dtype = torch.float32) -> Tensor:
+        r"""(steps, 4 + MAX_HIST) rows [a, b, p, w_new, w_hist oldest-first] from host scalars (fp32 for the kernel)."""
         u = self._variable(alpha, sigma)
-        rows = torch.zeros(self.steps, 4 + _lib.MULTISTEP_MAX_HIST, dtype=torch.float32)
+        rows = torch.zeros(self.steps, 4 + _lib.MULTISTEP_MAX_HIST, dtype=dtype)
         one, zero = torch.ones((), dtype=torch.float64), torch.zeros((), dtype=torch.float64)
         al, sg = alpha.double(), sigma.double()
         for i in range(self.steps):
@@ -815,6 +815,27 @@ class _MultistepSampler(Sampler):
             tapes.append(tape)
         return tapes
 
+    def _call_wide(self, x: Tensor, time: Tensor, kwargs: dict) -> Tensor:
+        r"""fp64 latents / an fp64 time grid (the reference's promotion makes every elementwise op of the loop fp64 around
+        the fp32 backbone, ``sample.py:69-94``): the same linear form as the fp32 kernel -- pred = a x_t + b mean,
+        x_s = p x_t + w_new pred + sum_j w_j pred_j -- evaluated with ``az_axpby_f64`` from an fp64 coefficient table."""
+        alpha, sigma = self.denoiser.schedule(self.timesteps.cpu())
+        table = self._device_table(alpha, sigma, dtype=torch.float64)
+        ring: list = [None] * self.order
+        x_t = x.to(torch.float64).contiguous()
+        one = torch.ones((), dtype=torch.float64)
+        for i, t in enumerate(self.progress_bar(time[:-1])):
+            mean = self.denoiser(x_t, t, **kwargs).mean
+            row = table[i]
+            pred = axpby_wide(row[0], x_t, row[1], mean)
+            n_hist = min(self.order, i + 1) - 1
+            acc = axpby_wide(row[2], x_t, row[3], pred)
+            for j in range(n_hist):  # oldest first: steps i - n_hist .. i - 1
+                acc = axpby_wide(one, acc, row[4 + j], ring[(i - n_hist + j) % self.order])
+            ring[i % self.order] = pred
+            x_t = acc
+        return x_t
+
     def _fused_upload_extra(self, loop) -> None:
         loop.mtable.copy_(self._ring_table())
 
@@ -836,9 +857,7 @@ class _MultistepSampler(Sampler):
             if out is not None:
                 return out
         if self.dtype == torch.float64 or x.dtype == torch.float64:
-            raise NotImplementedError(
-                f"{type(self).__name__}: the multistep kernel (az_multistep_f32) is fp32; fp64 latents / an fp64 time grid are "
-                "implemented for DDPM, DDIM, Euler, Heun, Ito and PC only")
+            return self._call_wide(x, time, kwargs)
         require_f32_cuda(x, type(self).__name__)
         alpha, sigma = self.denoiser.schedule(self.timesteps.cpu())
         table = self._device_table(alpha, sigma).to(x.device)

@@ -44,8 +44,15 @@ def test_fp64_time_grid_matches_reference(golden):
     xe = EulerSampler(den, steps=6, silent=True, dtype=torch.float64)(x1.double())
     print("Euler-6, fp64 latents: max|d|", max_err(xe, g["unet_euler6_x64"]))
     assert xe.dtype == torch.float64 and max_err(xe, g["unet_euler6_x64"]) < 2e-5 * max(1.0, g["unet_euler6_x64"].abs().max().item())
-    with pytest.raises(NotImplementedError):
-        zABSampler(den, order=2, steps=4, silent=True, dtype=torch.float64)(x1)
+    # the multistep family in fp64 (az_axpby_f64 from an fp64 coefficient table) against its fp32 kernel form
+    from azula_amd.sample import xEABSampler
+
+    for cls, order in ((zABSampler, 2), (xEABSampler, 3)):
+        xa = cls(den, order=order, steps=6, silent=True, dtype=torch.float64)(x1)
+        x32 = cls(den, order=order, steps=6, silent=True)(x1)
+        assert xa.dtype == torch.float64 and x32.dtype == torch.float32
+        print(cls.__name__, "fp64 grid vs fp32 sampler: max|d|", max_err(xa, x32))
+        assert max_err(xa, x32) < 1e-4 * sc  # two precisions of the same integrator around the same fp32 network
 
 
 def test_fp64_elementwise_kernels_bit_exact():
