@@ -322,3 +322,23 @@ def test_unet_one_stride_per_axis(golden, name):
     sc = max(1.0, g[name + "_y"].abs().max().item())
     print(name, "max|d|", max_err(y, g[name + "_y"]), "scale", sc)
     assert y.shape == g[name + "_y"].shape and max_err(y, g[name + "_y"]) < 2e-5 * sc
+
+
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
+def test_unet_on_volumes_half_precision(golden, half):
+    """A volume network cast to half precision runs its plane convolutions on the bf16 / f16 MFMA kernel (fp32 accumulate,
+    in-place accumulation over the depth taps in fp32): against the fp32 reference output at the half-precision bar."""
+    from azula_amd.nn import UNet
+
+    g = golden("g16_unet3d")
+    cfg = dict(g.meta["v_even_cfg"])
+    periodic = cfg.pop("periodic")
+    net = UNet(**cfg, spatial=3, periodic=periodic)
+    net.load_state_dict(synth.synth_state_dict({n: tuple(v) for n, v in g.meta["v_even_shapes"].items()}, 61))
+    x = g["v_even_x"]
+    y = net.cuda().eval().to(half)(x.cuda().to(half), g["mod"][: x.shape[0]].cuda().to(half))
+    ref = g["v_even_y"]
+    sc = max(1.0, ref.abs().max().item())
+    err = max_err(y.float(), ref)
+    print(half, "max|d|", err, "scale", sc)
+    assert y.dtype == half and err < (4e-2 if half == torch.bfloat16 else 5e-3) * sc  # measured 2.1e-2 / 2.5e-3 on scale 2.8
