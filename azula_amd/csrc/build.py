@@ -42,6 +42,23 @@ def hipcc() -> str:
     return exe
 
 
+_FLAG_OK: dict = {}
+
+
+def _supported(flags: list[str]) -> bool:
+    r"""Hidden LLVM options (``-mllvm ...``) abort hipcc versions that lack them ("Unknown command line argument"): probe once
+    with an empty translation unit and build without the flag where it is unknown (a slower schedule, not a broken library)."""
+    key = tuple(flags)
+    if key not in _FLAG_OK:
+        probe = os.path.join(OBJ_DIR, "_flag_probe.hip")
+        with open(probe, "w") as f:
+            f.write("__global__ void az_flag_probe() {}\n")
+        res = subprocess.run([hipcc(), "--offload-arch=gfx950", *flags, "-x", "hip", "-c", probe, "-o", probe + ".o"],
+                             capture_output=True)
+        _FLAG_OK[key] = res.returncode == 0
+    return _FLAG_OK[key]
+
+
 def _stale(target: str, deps: list[str]) -> bool:
     if not os.path.exists(target):
         return True
@@ -59,7 +76,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src, *headers]):
-            cmd = [hipcc(), *FLAGS, *EXTRA_FLAGS.get(s, []), "-x", "hip", "-c", src, "-o", obj]
+            extra = EXTRA_FLAGS.get(s, [])
+            if extra and not _supported(extra):
+                print(f"[azula_amd.build] {s}: this hipcc rejects {' '.join(extra)}; building without it", file=sys.stderr)
+                extra = []
+            cmd = [hipcc(), *FLAGS, *extra, "-x", "hip", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -1912,7 +1912,7 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   // (see conv_igemm_kernel); AZ_IGEMM_K16 = 0 / 1 forces the choice (A/B measurements)
   bool k16 = false;
   if (!half) {
-    static const char* force = getenv("AZ_IGEMM_K16");
+    const char* force = getenv("AZ_IGEMM_K16");  // read per call: tests flip it between plans
     int sk = a->splitk;
     const int64_t nk32 = (int64_t)a->ksize * a->ksize * ((a->c0s + BK - 1) / BK + (a->c1s + BK - 1) / BK);
     if (sk > nk32) sk = (int)nk32;

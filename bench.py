@@ -337,6 +337,23 @@ def cpu_baseline(denoiser, cfg, budget_s=25.0):
     )
 
 
+def self_launch(n: int) -> int:
+    r"""Re-run this command line as `n` ranks (one per GPU) under `torch.distributed.run` on a free 127.0.0.1 port and
+    return its exit code.  Same processes, environment and JSON line as the explicit launcher form of the docstring."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,10 +372,19 @@ def main() -> None:
     if args.fp32_mfma:
         os.environ["AZ_FP32_MFMA"] = args.fp32_mfma  # read by azula_amd.engine at import
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on a free
+        # loopback port; the ranks re-enter main() with RANK / LOCAL_RANK / WORLD_SIZE set and rank 0 prints the line
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: drop WORLD_SIZE from the environment "
+                         "(bench.py then launches its own ranks) or start it with torch.distributed.run --nproc-per-node N")
+    if world > 1 and os.environ.get("AZ_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} over RCCL needs {world} devices, this node shows "
+                         f"{torch.cuda.device_count()} (AZ_DIST_BACKEND=gloo rehearses N ranks on fewer devices)")
     device = torch.device("cuda", local % torch.cuda.device_count())  # (modulo: lets a 1-GPU box rehearse N > 1 over gloo)
     torch.cuda.set_device(device)
     if world > 1:

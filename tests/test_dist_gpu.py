@@ -109,3 +109,23 @@ def test_rccl_backend_world_of_one(tmp_path):
     x1 = smp.init((4, 3, 16, 16), device="cuda")
     torch.manual_seed(2)
     assert torch.equal(gathered, smp(x1).cpu())
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE in the environment (the form the driver uses for
+    N = 1) must start its own ranks and print ONE JSON line; here 2 ranks share the box's GPU over gloo."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["AZ_DIST_BACKEND"] = "gloo"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "2",
+                          "--warmup", "1", "--no-pmc", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dist"]["ranks_seen"] == 2 and out["dist"]["world_size"] == 2
+    assert out["config"]["global_batch"] == 2 * out["config"]["per_gpu_batch"] and out["value"] > 0

@@ -123,3 +123,83 @@ def test_adm_256_widths_ddpm_against_the_oracle(adm_net):
     e = max_err(x0, ref)
     print(f"ADM-256 widths DDPM-3 max|d| {e:.3e} (scale {ref.abs().max().item():.2f})")
     assert e < 1.5e-4  # measured 3.0e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[2]: DiT-B/2 at its REAL width (768 x 12 blocks, 12 heads, patch 2, 4 x 32 x 32 latents -> 256 tokens) and
+# JiT-B/16 (768 x 12, 256 + 32 tokens), against the CPU oracle; the golden fixtures G5 / G6 / G10 are hid-64 networks.
+def k16_modes():
+    return [None, "1"]  # the host's own K-tile choice / the 16-channel K tile forced on every direct-kernel launch
+
+
+@pytest.fixture(scope="module")
+def dit_b2():
+    import bench
+
+    cfg = dict(bench.CONFIGS["c3"])
+    den = bench.build_denoiser(cfg, torch.device("cuda"))
+    sd = {k: v.detach().cpu() for k, v in den.backbone.state_dict().items()}
+    ncfg = dict(cfg["net"])
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    oracle_mean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_vit(sd, ncfg, a, c), x, t)  # noqa: E731
+    torch.manual_seed(13)
+    x1 = torch.randn(2, *cfg["shape"])
+    ref_mean = oracle_mean(x1, torch.tensor(0.6))
+    ref_x0 = sampling.sample(oracle_mean, x1, steps=3, eta=0.0)
+    return den, x1, ref_mean, ref_x0
+
+
+@pytest.mark.parametrize("k16", k16_modes())
+def test_dit_b2_full_width_against_the_oracle(dit_b2, k16, monkeypatch):
+    from azula_amd.sample import DDIMSampler
+
+    den, x1, ref_mean, ref_x0 = dit_b2
+    if k16 is None:
+        monkeypatch.delenv("AZ_IGEMM_K16", raising=False)
+    else:
+        monkeypatch.setenv("AZ_IGEMM_K16", k16)
+    net = den.backbone.net
+    net._plans.clear()
+    mean = den(x1.cuda(), torch.tensor(0.6, device="cuda")).mean
+    ops = [n for _, _, n in next(iter(net._plans.values())).tape.ops]
+    assert ops.count("az_attention_f32") == 12 and ops.count("az_conv2d_f32") >= 4 * 12
+    sc = max(1.0, ref_mean.abs().max().item())
+    e1 = max_err(mean, ref_mean)
+    smp = DDIMSampler(den, steps=3, silent=True)
+    x0 = smp(x1.cuda())
+    assert next(iter(smp._fused_cache.values())).graph is not None
+    e2 = max_err(x0, ref_x0)
+    print(f"DiT-B/2 full width, K16={k16}: mean max|d| {e1:.3e} (scale {sc:.2f}); DDIM-3 max|d| {e2:.3e} "
+          f"(scale {ref_x0.abs().max().item():.2f})")
+    net._plans.clear()
+    assert e1 < 1e-5 * sc
+    assert e2 < 1e-5 * max(1.0, ref_x0.abs().max().item())
+
+
+@pytest.mark.parametrize("k16", k16_modes())
+def test_jit_b16_full_width_against_the_oracle(k16, monkeypatch):
+    import bench
+
+    if k16 is None:
+        monkeypatch.delenv("AZ_IGEMM_K16", raising=False)
+    else:
+        monkeypatch.setenv("AZ_IGEMM_K16", k16)
+    cfg = dict(bench.CONFIGS["c6"])
+    den = bench.build_denoiser(cfg, torch.device("cuda"))
+    sd = {k: v.detach().cpu() for k, v in den.backbone.state_dict().items()}
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    torch.manual_seed(14)
+    x = torch.randn(1, 3, 256, 256)
+    t, y = torch.tensor([0.37]), torch.tensor([207])
+    ref = nets.jit_forward(sd, {"model": cfg["model"], "input_size": 256}, x, t, y)
+    out = den.backbone(x.cuda(), t.cuda(), y.cuda())
+    sc = max(1.0, ref.abs().max().item())
+    e = max_err(out, ref)
+    print(f"JiT-B/16 full width, K16={k16}: backbone max|d| {e:.3e} (scale {sc:.2f})")
+    assert e < 2e-5 * sc
+    bb = lambda a, c, lab: nets.jit_forward(sd, {"model": cfg["model"], "input_size": 256}, a, c, lab)  # noqa: E731
+    ref_mean = sampling.jit_mean(bb, x, torch.tensor(0.4), y)
+    mean = den(x.cuda(), torch.tensor(0.4, device="cuda"), label=y.cuda()).mean
+    e = max_err(mean, ref_mean)
+    print(f"JiT-B/16 full width, K16={k16}: posterior mean max|d| {e:.3e} (scale {ref_mean.abs().max().item():.2f})")
+    assert e < 2e-5 * max(1.0, ref_mean.abs().max().item())

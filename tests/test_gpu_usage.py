@@ -47,3 +47,60 @@ def test_unusual_but_valid_usages():
     g = CFGDenoiser(ad)
     o = DDIMSampler(g, steps=3, silent=True)(xa, positive={"label": lab}, negative={"label": torch.zeros_like(lab)}, guidance=torch.tensor(1.5))
     assert torch.isfinite(o).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[0]'s shape on the GPU: a USER-DEFINED nn.Module backbone (the reference tests' 2-layer MLP) on (64, 5) CUDA
+# latents.  The backbone is opaque to the engine, so Sampler.__call__ runs the generic loop: torch evaluates the module,
+# every step's elementwise work goes through az_transition_f32 on 2-D latents.  Checked against G4 (reference outputs).
+def test_user_defined_mlp_backbone_on_cuda_latents(golden):
+    from conftest import max_err
+    from oracle import sampling, synth
+    from azula_amd import _lib
+    from azula_amd.denoise import KarrasDenoiser
+    from azula_amd.noise import VPSchedule
+    from azula_amd.sample import DDIMSampler, DDPMSampler
+
+    class ToyMLP(torch.nn.Module):  # reference tests/test_sample.py:28-53
+        def __init__(self, features=5):
+            super().__init__()
+            self.l1 = torch.nn.Linear(features, 64)
+            self.l2 = torch.nn.Linear(64, features)
+
+        def forward(self, x_t, t, label=None):
+            f = torch.exp(torch.log(torch.tensor(1e-4)) * torch.linspace(0, 1, 32, dtype=x_t.dtype)).to(x_t.device)
+            e = torch.cat((torch.sin(t.unsqueeze(-1) * f), torch.cos(t.unsqueeze(-1) * f)), dim=-1)
+            return self.l2(torch.relu(self.l1(x_t) + e))
+
+    g = golden("g4_toy_loop")
+    net = ToyMLP()
+    net.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"]))
+    import copy
+
+    den = KarrasDenoiser(copy.deepcopy(net), VPSchedule()).eval().cuda()
+    calls = []
+    real = _lib.call
+    try:
+        _lib.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        x1 = g["x1"].cuda()
+        smp = DDIMSampler(den, steps=64, silent=True)
+        x0 = smp(x1)
+        assert not smp._fused_cache, "an opaque nn.Module must take the generic loop"
+        assert calls.count("az_transition_f32") == 64, "one az_transition_f32 per step on the 2-D latents"
+        e = max_err(x0, g["ddim64"])
+        print("MLP backbone on CUDA (64, 5), DDIM-64 vs the reference's output:", e)
+        assert x0.is_cuda and x0.shape == (64, 5) and e < 2e-5  # CPU path: 1e-5; torch's GPU matmul / sin / cos differ in the last ulp
+
+        torch.manual_seed(5)
+        eps = [torch.randn_like(x1).cpu() for _ in range(64)]
+        torch.manual_seed(5)
+        calls.clear()
+        x0 = DDPMSampler(den, steps=64, silent=True)(x1)
+        assert calls.count("az_transition_f32") == 64
+    finally:
+        _lib.call = real
+    omean = lambda x, t: sampling.karras_mean(lambda a, c: net(a, c), x, t)  # noqa: E731 -- the oracle's Karras mean around the CPU module
+    ref = sampling.sample(omean, g["x1"], steps=64, eta=None, eps_list=eps)
+    e = max_err(x0, ref)
+    print("MLP backbone on CUDA (64, 5), DDPM-64 with the device generator's noise vs the oracle loop:", e)
+    assert e < 5e-5
