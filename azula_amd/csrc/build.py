@@ -52,7 +52,7 @@ def _supported(flags: list[str]) -> bool:
     if key not in _FLAG_OK:
         probe = os.path.join(OBJ_DIR, "_flag_probe.hip")
         with open(probe, "w") as f:
-            f.write("__global__ void az_flag_probe() {}\n")
+            f.write("#include <hip/hip_runtime.h>\n__global__ void az_flag_probe() {}\n")
         res = subprocess.run([hipcc(), "--offload-arch=gfx950", *flags, "-x", "hip", "-c", probe, "-o", probe + ".o"],
                              capture_output=True)
         _FLAG_OK[key] = res.returncode == 0
@@ -68,7 +68,10 @@ def _stale(target: str, deps: list[str]) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
-    headers = [os.path.join(HERE, "common.h"), os.path.join(ROOT, "include", "azula_amd.h")]
+    headers = [os.path.join(HERE, "common.h"), os.path.join(ROOT, "include", "azula_amd.h"), os.path.join(HERE, "wino_kloop.inc")]
+    gen = os.path.join(HERE, "gen_wino_kloop.py")  # the Winograd K loop's instruction stream (committed; regenerated when stale)
+    if _stale(headers[-1], [gen]):
+        subprocess.run([sys.executable, gen], check=True, stdout=subprocess.DEVNULL)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     objs = []
     for s in srcs:

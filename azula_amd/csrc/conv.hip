@@ -1183,6 +1183,13 @@ struct WinoP {
 // ds_write_b128 of the loaders are bank-conflict-free without padding.
 __device__ __forceinline__ int wswz(int row, int half) { return row * WK + 4 * (half ^ ((row >> 3) & 1)); }
 
+#include "wino_kloop.inc"
+constexpr int W_VOFF_BYTES = 256 * 64;  // ASM form: the second source's 16 patch offsets of the 256 gather threads
+
+// ASM = true: the K loop is the hand-scheduled instruction stream of wino_kloop.inc (gen_wino_kloop.py), software
+// pipelined across the barrier; ASM = false: the C++ loop (one barrier per stage behind the stores), kept for A/B runs
+// (AZ_WINOGRAD_ASM=0).  Prologue address arithmetic and the whole epilogue are shared.
+template <bool ASM>
 __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];  // 2 * W_STAGE floats
   const AzConvArgs& a = p.a;
@@ -1342,15 +1349,73 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
+  // fragment addresses: row (within a frequency) = wave's 32-row block + l31; half = h (swizzled)
+  const int fragA = (fh * 8) * WC * WK + wswz(wco * 32 + l31, h);  // + f * WC * WK
+  const int fragB = (fh * 8) * WT * WK + wswz(wti * 32 + l31, h);  // + f * WT * WK
+  if constexpr (ASM) {
+    if (kt_begin < kt_end) {
+      typedef __attribute__((address_space(3))) float lds_float;
+      const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)wsm;
+      const unsigned fragA_b = lds0 + (unsigned)fragA * 4u;
+      const unsigned fragB_b = lds0 + (unsigned)(WU_STAGE + fragB) * 4u;
+      if (vrole) {
+        // patch offsets of the slice's first source -> LDS (parked in stage buffer 1, which nobody writes before the
+        // first barrier), of the second source (if the slice crosses into it) -> the area behind the stages
+        const bool start1 = kt_begin >= p.nkc0;
+        const int kt_switch = (!start1 && kt_end > p.nkc0) ? p.nkc0 : 0x7fffffff;
+        set_src(start1 ? 1 : 0);
+        uint4* pa = reinterpret_cast<uint4*>(reinterpret_cast<char*>(wsm) + W_STAGE * 4 + tid * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pa[q] = make_uint4(voffV[4 * q], voffV[4 * q + 1], voffV[4 * q + 2], voffV[4 * q + 3]);
+        if (kt_switch != 0x7fffffff) {
+          set_src(1);
+          uint4* pb = reinterpret_cast<uint4*>(reinterpret_cast<char*>(wsm) + W_LDS_BYTES + tid * 64);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pb[q] = make_uint4(voffV[4 * q], voffV[4 * q + 1], voffV[4 * q + 2], voffV[4 * q + 3]);
+        }
+        const unsigned ldsA = lds0 + W_STAGE * 4 + tid * 64, ldsB = lds0 + W_LDS_BYTES + tid * 64;
+        const unsigned vst = lds0 + (unsigned)(WU_STAGE + voffL) * 4u;
+        // buffer descriptors as words (the asm cannot address the halves of a 128-bit operand)
+        const uint64_t b0 = (uint64_t)(uintptr_t)(a.src0 + b_first * s0_elems);
+        const uint64_t b1 = (uint64_t)(uintptr_t)(a.src1 ? a.src1 + b_first * s1_elems : a.src0);
+        const unsigned n0 = clamp_bytes((a.batch - b_first) * s0_elems), n1 = a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u;
+        unsigned d0w0 = (unsigned)b0, d0w1 = (unsigned)(b0 >> 32) & 0xffffu, d0w2 = n0;
+        unsigned d1w0 = (unsigned)b1, d1w1 = (unsigned)(b1 >> 32) & 0xffffu, d1w2 = n1;
+        if (start1) d0w0 = d1w0, d0w1 = d1w1, d0w2 = d1w2;
+        const unsigned dflags = 0x00020000u;
+        const int soff0 = (start1 ? kt_begin - p.nkc0 : kt_begin) * (WK * 4);
+        const int tail0 = (a.c0s & (WK - 1)) ? p.nkc0 - 1 : -1;
+        const int tail1 = (a.c1s & (WK - 1)) ? p.nk - 1 : -1;
+        asm volatile(WINO_KLOOP_V_ASM
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(fragA_b), "v"(fragB_b), "v"(vst), "v"(ldsA), "v"(ldsB), "s"(d0w0), "s"(d0w1), "s"(d0w2), "s"(dflags),
+                       "s"(d1w0), "s"(d1w1), "s"(d1w2), "s"(dflags), "s"(kt_begin), "s"(kt_end), "s"(kt_switch), "s"(soff0),
+                       "s"(tail0), "s"(tail1)
+                     : WINO_KLOOP_CLOBBERS);
+      } else {
+        const uint64_t bw = (uint64_t)(uintptr_t)a.weight;
+        const unsigned ww0 = (unsigned)bw, ww1 = (unsigned)(bw >> 32) & 0xffffu;
+        const unsigned ww2 = clamp_bytes((int64_t)p.nk * p.cblocks * WU_STAGE), ww3 = 0x00020000u;
+        const unsigned uvoff = (unsigned)(tid - 256) * 16u;
+        const int e0 = tid - 256;
+        const unsigned ust = lds0 + (unsigned)wswz(e0 >> 1, e0 & 1) * 4u;
+        const unsigned usoff0 = (unsigned)(((int64_t)kt_begin * p.cblocks + cb) * (WU_STAGE * 4));
+        const unsigned ustep = (unsigned)(p.cblocks * (WU_STAGE * 4));
+        asm volatile(WINO_KLOOP_U_ASM
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(fragA_b), "v"(fragB_b), "v"(ust), "v"(uvoff), "s"(ww0), "s"(ww1), "s"(ww2), "s"(ww3), "s"(kt_begin), "s"(kt_end),
+                       "s"(usoff0), "s"(ustep)
+                     : WINO_KLOOP_CLOBBERS);
+      }
+    } else {
+      __syncthreads();
+    }
+  } else {
   if (kt_begin < kt_end) {
     load_stage(kt_begin);
     store_stage(0);
   }
   __syncthreads();
-
-  // fragment addresses: row (within a frequency) = wave's 32-row block + l31; half = h (swizzled)
-  const int fragA = (fh * 8) * WC * WK + wswz(wco * 32 + l31, h);  // + f * WC * WK
-  const int fragB = (fh * 8) * WT * WK + wswz(wti * 32 + l31, h);  // + f * WT * WK
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     // Code placement: this loop loses 4.5 - 7 % when its body starts at byte phases 16..23 of a 32-byte window (r02:
     // swept with s_nop padding -- every other phase is equally fast; an innocuous edit of the PROLOGUE, even code that
@@ -1381,6 +1446,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
     }
     if (more) store_stage(buf ^ 1);
     __syncthreads();
+  }
   }
 
   // ---- output transform.  Y = A^T M A is linear in M, so each wave transforms the 8 frequencies
@@ -2042,12 +2108,20 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   const int64_t nwg = (int64_t)p.cblocks * p.tblocks;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_winograd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_winograd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        W_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)conv_winograd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            W_LDS_BYTES + W_VOFF_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_winograd_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), W_LDS_BYTES, st, p);
+  // AZ_WINOGRAD_ASM=0: the C++ K loop (A/B measurements); default: the hand-scheduled stream
+  const char* asm_env = getenv("AZ_WINOGRAD_ASM");
+  if (asm_env && asm_env[0] == '0')
+    hipLaunchKernelGGL(conv_winograd_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), W_LDS_BYTES, st, p);
+  else
+    hipLaunchKernelGGL(conv_winograd_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), W_LDS_BYTES + W_VOFF_BYTES, st, p);
   int rc = az_launch_status();
   if (rc != AZ_OK) return rc;
   if (splitk > 1) {

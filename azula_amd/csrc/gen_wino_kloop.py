@@ -1,0 +1,369 @@
+r"""Generates ``wino_kloop.inc``: the K loop of ``conv_winograd_kernel`` as two hand-scheduled gfx950 instruction streams
+(one per loader role), wrapped as string-literal macros for ``asm volatile``.
+
+Why: the C++ loop is [loads][32 MFMAs][transform + LDS stores][barrier]: after every barrier the matrix pipe idles for the
+fragment-read latency, both waves of a SIMD then leave the MFMA phase together and stage with an idle pipe
+(5.6 k cycles per 8-channel stage against 4.1 k of MFMA issue).  ``profiles/r03_mfma_overlap.txt`` shows what
+may sit beside ``v_mfma_f32_32x32x2_f32`` for free (<= 4 ds_read_b128, <= 2 ds_write_b64, 1 buffer load, any SALU per
+64-cycle MFMA) and what may not (every VALU instruction costs its own issue time).  So the stream here is software
+pipelined across the barrier:
+
+    iteration t:   s_barrier                                   (S(t) visible; every R(t-1) done)
+                   R(t)[0], R(t)[1]                            fragment reads of frequency groups 0, 1
+                   M(t-1)[6], M(t-1)[7]                        8 MFMAs whose fragments were read BEFORE the barrier
+                   M(t)[0..5] with R(t)[2..7] two groups ahead
+                   beside the first 14 MFMAs: S(t+1) (wait for L(t+1), input transform, LDS stores into the other
+                   buffer) and L(t+2) (global loads, one stage of latency cover), one memory instruction per MFMA gap
+
+The matrix pipe therefore always has MFMAs queued when a wave reaches the barrier and right after it.  Register use is
+fixed (v160..v255, s92..s99: declared as clobbers); accumulators and the few scalar inputs are asm operands.
+
+    python azula_amd/csrc/gen_wino_kloop.py        # rewrites wino_kloop.inc next to this file
+"""
+from __future__ import annotations
+
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+TB = 160
+RV0, VO0, X0, Y0 = 192, 224, 240, 248
+V_FA, V_FB, V_ST, V_OOB = 252, 253, 254, 255
+S_RS, S_SOFF, S_KT, S_CNT, S_TMP = 92, 96, 97, 98, 99
+GROUP_BYTES = 2048  # one frequency of a stage: 64 rows x 8 floats x 4 B
+BUF_XOR = 0x10000   # the two 64 KB stages
+
+
+def fa(s, j=None):
+    return f"v[{TB + 8 * s}:{TB + 8 * s + 3}]" if j is None else f"v{TB + 8 * s + j}"
+
+
+def fb(s, j=None):
+    return f"v[{TB + 8 * s + 4}:{TB + 8 * s + 7}]" if j is None else f"v{TB + 8 * s + 4 + j}"
+
+
+def pair(r):
+    return f"v[{r}:{r + 1}]"
+
+
+def quad(r):
+    return f"v[{r}:{r + 3}]"
+
+
+class Stream:
+    r"""Ordered instruction list with the bookkeeping for `s_waitcnt lgkmcnt(N)`: LDS operations retire in order, so
+    waiting for the reads of fragment set s means allowing as many outstanding operations as were issued after them."""
+
+    def __init__(self):
+        self.lines: list[str] = []
+        self.lds_seq = 0                      # LDS operations issued so far
+        self.set_done_at: dict[int, int] = {}  # fragment set -> lds_seq right after its second read
+
+    def emit(self, text: str):
+        self.lines.append(text)
+
+    def lds(self, text: str):
+        self.lines.append(text)
+        self.lds_seq += 1
+
+    def read_set(self, s: int, group: int):
+        self.lds(f"ds_read_b128 {fa(s)}, v{V_FA} offset:{group * GROUP_BYTES}")
+        self.lds(f"ds_read_b128 {fb(s)}, v{V_FB} offset:{group * GROUP_BYTES}")
+        self.set_done_at[s] = self.lds_seq
+
+    def need_set(self, s: int):
+        n = self.lds_seq - self.set_done_at[s]
+        self.emit(f"s_waitcnt lgkmcnt({min(n, 15)})")
+
+    def drain(self):
+        self.emit("s_waitcnt lgkmcnt(0)")
+        self.set_done_at = {k: 0 for k in self.set_done_at}
+        self.lds_seq = 0
+
+    def mfma(self, acc: int, s: int, j: int):
+        self.emit(f"v_mfma_f32_32x32x2_f32 %{acc}, {fa(s, j)}, {fb(s, j)}, %{acc}")
+
+
+# ------------------------------------------------------------------------------------------------ V role pieces
+def v_pass1_col(c):
+    d0, d1, d2, d3 = RV0 + 2 * c, RV0 + 2 * (4 + c), RV0 + 2 * (8 + c), RV0 + 2 * (12 + c)
+    x = X0 + 2 * c
+    return [
+        f"v_pk_add_f32 {pair(d0)}, {pair(d0)}, {pair(d2)} neg_lo:[0,1] neg_hi:[0,1]",   # o0 = d0 - d2
+        f"v_pk_add_f32 {pair(d3)}, {pair(d1)}, {pair(d3)} neg_lo:[0,1] neg_hi:[0,1]",   # o3 = d1 - d3
+        f"v_pk_add_f32 {pair(x)}, {pair(d1)}, {pair(d2)}",                              # o1 = d1 + d2 -> X[c]
+        f"v_pk_add_f32 {pair(d2)}, {pair(d2)}, {pair(d1)} neg_lo:[0,1] neg_hi:[0,1]",   # o2 = d2 - d1
+    ]
+
+
+def v_row_regs(xi):
+    if xi == 1:
+        return [X0 + 2 * c for c in range(4)]
+    return [RV0 + 2 * (4 * xi + c) for c in range(4)]
+
+
+def v_pass2_row(xi):
+    r"""Row xi of the second transform pass, in place (out1 in a Y temp), and its two LDS stores."""
+    u0, u1, u2, u3 = v_row_regs(xi)
+    y = Y0 + 2 * (xi & 1)
+    valu = [
+        ("valu", f"v_pk_add_f32 {pair(u0)}, {pair(u0)}, {pair(u2)} neg_lo:[0,1] neg_hi:[0,1]"),  # out0 = u0 - u2
+        ("valu", f"v_pk_add_f32 {pair(y)}, {pair(u1)}, {pair(u2)}"),                            # out1 = u1 + u2
+        ("valu", f"v_pk_add_f32 {pair(u2)}, {pair(u2)}, {pair(u1)} neg_lo:[0,1] neg_hi:[0,1]"),  # out2 = u2 - u1
+        ("valu", f"v_pk_add_f32 {pair(u3)}, {pair(u1)}, {pair(u3)} neg_lo:[0,1] neg_hi:[0,1]"),  # out3 = u1 - u3
+    ]
+    wa = ("lds", f"ds_write2st64_b64 v{V_ST}, {pair(u0)}, {pair(y)} offset0:{16 * xi} offset1:{16 * xi + 4}")
+    wb = ("lds", f"ds_write2st64_b64 v{V_ST}, {pair(u2)}, {pair(u3)} offset0:{16 * xi + 8} offset1:{16 * xi + 12}")
+    return valu, wa, wb
+
+
+def v_load(i):
+    return ("vmem", f"buffer_load_dwordx2 {pair(RV0 + 2 * i)}, v{VO0 + i}, s[{S_RS}:{S_RS + 3}], s{S_SOFF} offen")
+
+
+V_OPS = dict(fragA=8, fragB=9, st=10, ldsA=11, ldsB=12, rs0=13, rs1=17, kt_begin=21, kt_end=22, kt_switch=23, soff0=24,
+             tail0=25, tail1=26)
+
+
+def v_load_events(tag):
+    r"""Before the loads of stage s_kt: switch to the second source (descriptor, patch offsets from LDS, channel offset 0)
+    and / or mask the channel pairs beyond a source's last (half) chunk."""
+    o = V_OPS
+    L = []
+    L.append(("salu", f"s_cmp_eq_u32 s{S_KT}, %{o['kt_switch']}"))
+    L.append(("salu", f"s_cbranch_scc0 LVnsw{tag}_%="))
+    for w in range(4):
+        L.append(("salu", f"s_mov_b32 s{S_RS + w}, %{o['rs1'] + w}"))
+    L.append(("salu", f"s_mov_b32 s{S_SOFF}, 0"))
+    for q in range(4):
+        L.append(("ldsx", f"ds_read_b128 {quad(VO0 + 4 * q)}, %{o['ldsB']} offset:{16 * q}"))
+    L.append(("ldsx", "s_waitcnt lgkmcnt(0)"))
+    L.append(("label", f"LVnsw{tag}_%=:"))
+    L.append(("salu", f"s_cmp_eq_u32 s{S_KT}, %{o['tail0']}"))
+    L.append(("salu", f"s_cbranch_scc1 LVtl{tag}_%="))
+    L.append(("salu", f"s_cmp_eq_u32 s{S_KT}, %{o['tail1']}"))
+    L.append(("salu", f"s_cbranch_scc0 LVntl{tag}_%="))
+    L.append(("label", f"LVtl{tag}_%=:"))
+    L.append(("salu", "s_mov_b32 vcc_lo, 0x33333333"))
+    L.append(("salu", "s_mov_b32 vcc_hi, 0x33333333"))
+    for i in range(16):
+        L.append(("valu", f"v_cndmask_b32 v{VO0 + i}, v{V_OOB}, v{VO0 + i}, vcc"))
+    L.append(("label", f"LVntl{tag}_%=:"))
+    return L
+
+
+def v_load_done():
+    return [("salu", f"s_add_u32 s{S_SOFF}, s{S_SOFF}, 32"), ("salu", f"s_add_u32 s{S_KT}, s{S_KT}, 1")]
+
+
+def v_extras(S: bool, L: bool, tag: str):
+    r"""{MFMA index: [(kind, text)]} -- what is issued behind each of the first MFMAs of an iteration.  VALU work comes in
+    bursts (the first vector instruction behind an MFMA costs ~14 cycles, each further one 4-5: profiles/r03_mfma_overlap.txt),
+    memory instructions one per gap (one buffer load per 64 cycles per SIMD is what the texture path takes)."""
+    ex = {k: [] for k in range(32)}
+    if S:
+        ex[0].append(("wait", "s_waitcnt vmcnt(0)"))
+        for c in range(4):
+            ex[c // 2] += [("valu", t) for t in v_pass1_col(c)]
+        for xi in range(4):
+            valu, wa, wb = v_pass2_row(xi)
+            ex[2 + 2 * xi] += valu + [wa]
+            ex[3 + 2 * xi] += [wb]
+    if L:
+        # patch row 1 lives in X after pass 1, so its registers are free first; the other rows follow their stores
+        ex[2] = ex[2] + v_load_events(tag)
+        order = [4, 5, 6, 7, 0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15]
+        for n, i in enumerate(order):
+            ex[2 + n].append(v_load(i))
+        ex[17] += v_load_done()
+    if S:
+        ex[17].append(("valu", f"v_xor_b32 v{V_ST}, 0x{BUF_XOR:x}, v{V_ST}"))
+    return ex
+
+
+# ------------------------------------------------------------------------------------------------ U role pieces
+U_OPS = dict(fragA=8, fragB=9, st=10, voff=11, rw=12, kt_begin=16, kt_end=17, soff0=18, soff_step=19)
+
+
+def u_extras(S: bool, L: bool, tag: str):
+    ex = {k: [] for k in range(32)}
+    o = U_OPS
+    if S:
+        ex[0].append(("wait", "s_waitcnt vmcnt(0)"))
+        for i in range(8):
+            ex[i].append(("lds", f"ds_write_b128 v{V_ST}, {quad(RV0 + 4 * i)} offset:{4096 * i}"))
+    if L:
+        for i in range(8):
+            k = i + 1
+            if i:
+                ex[k].append(("salu", f"s_add_u32 s{S_TMP}, s{S_SOFF}, {4096 * i}"))
+            ex[k].append(("vmem", f"buffer_load_dwordx4 {quad(RV0 + 4 * i)}, %{o['voff']}, s[{S_RS}:{S_RS + 3}], "
+                                  f"s{S_TMP if i else S_SOFF} offen"))
+        ex[8].append(("salu", f"s_add_u32 s{S_SOFF}, s{S_SOFF}, %{o['soff_step']}"))
+    if S:
+        ex[8].append(("valu", f"v_xor_b32 v{V_ST}, 0x{BUF_XOR:x}, v{V_ST}"))
+    return ex
+
+
+# ------------------------------------------------------------------------------------------------ the iteration
+def body(st: Stream, extras: dict):
+    st.drain()
+    st.emit("s_barrier")
+    st.read_set(0, 0)
+    st.read_set(1, 1)
+    k = 0
+
+    def put_extras(k):
+        for kind, text in extras[k]:
+            if kind == "lds":
+                st.lds(text)
+            elif kind == "ldsx":  # self-contained LDS traffic that ends in its own lgkmcnt(0) (rare path)
+                st.emit(text)
+            else:
+                st.emit(text)
+
+    for g, s in ((6, 2), (7, 3)):   # carried groups of the previous stage: their reads completed before the barrier
+        for j in range(4):
+            st.mfma(g, s, j)
+            put_extras(k)
+            k += 1
+    for f in range(6):
+        if f + 2 < 8:
+            st.read_set((f + 2) % 4, f + 2)
+        st.need_set(f % 4)
+        for j in range(4):
+            st.mfma(f, f % 4, j)
+            put_extras(k)
+            k += 1
+    st.emit(f"v_xor_b32 v{V_FA}, 0x{BUF_XOR:x}, v{V_FA}")
+    st.emit(f"v_xor_b32 v{V_FB}, 0x{BUF_XOR:x}, v{V_FB}")
+
+
+def flat(items):
+    return [t for _, t in items]
+
+
+def gen_role(role: str) -> list[str]:
+    V = role == "V"
+    o = V_OPS if V else U_OPS
+    extras = v_extras if V else u_extras
+    st = Stream()
+    e = st.emit
+    # ---- initial state
+    e(f"v_mov_b32 v{V_FA}, %{o['fragA']}")
+    e(f"v_mov_b32 v{V_FB}, %{o['fragB']}")
+    e(f"v_mov_b32 v{V_ST}, %{o['st']}")
+    for w in range(4):
+        e(f"s_mov_b32 s{S_RS + w}, %{(o['rs0'] if V else o['rw']) + w}")
+    e(f"s_mov_b32 s{S_SOFF}, %{o['soff0']}")
+    if V:
+        e(f"v_mov_b32 v{V_OOB}, 0x80000000")
+        e(f"s_mov_b32 s{S_KT}, %{o['kt_begin']}")
+        for q in range(4):
+            e(f"ds_read_b128 {quad(VO0 + 4 * q)}, %{o['ldsA']} offset:{16 * q}")
+    for s in (2, 3):  # the first iteration's "carried" MFMAs multiply zeros
+        for j in range(8):
+            e(f"v_mov_b32 v{TB + 8 * s + j}, 0")
+    e("s_waitcnt lgkmcnt(0)")
+    # ---- prologue stage: L(kt0), S(kt0), L(kt0 + 1)
+    ex = extras(True, True, "p0")
+    if V:
+        for kind, t in v_load_events("p0"):
+            e(t)
+        for i in range(16):
+            e(v_load(i)[1])
+        for t in flat(v_load_done()):
+            e(t)
+        e("s_waitcnt vmcnt(0)")
+        for c in range(4):
+            for t in v_pass1_col(c):
+                e(t)
+        for xi in range(4):
+            valu, wa, wb = v_pass2_row(xi)
+            for kind, t in valu + [wa, wb]:
+                e(t)
+        e(f"v_xor_b32 v{V_ST}, 0x{BUF_XOR:x}, v{V_ST}")
+    else:
+        for i in range(8):
+            if i:
+                e(f"s_add_u32 s{S_TMP}, s{S_SOFF}, {4096 * i}")
+            e(f"buffer_load_dwordx4 {quad(RV0 + 4 * i)}, %{o['voff']}, s[{S_RS}:{S_RS + 3}], s{S_TMP if i else S_SOFF} offen")
+        e(f"s_add_u32 s{S_SOFF}, s{S_SOFF}, %{o['soff_step']}")
+        e("s_waitcnt vmcnt(0)")
+        for i in range(8):
+            e(f"ds_write_b128 v{V_ST}, {quad(RV0 + 4 * i)} offset:{4096 * i}")
+        e(f"v_xor_b32 v{V_ST}, 0x{BUF_XOR:x}, v{V_ST}")
+    del ex
+    # n = kt_end - kt_begin stages; L(kt0 + 1) if n >= 2
+    e(f"s_sub_u32 s{S_CNT}, %{o['kt_end']}, %{o['kt_begin']}")
+    e(f"s_cmp_lt_u32 s{S_CNT}, 2")
+    e(f"s_cbranch_scc1 L{role}last_%=")
+    if V:
+        for kind, t in v_load_events("p1"):
+            e(t)
+        for i in range(16):
+            e(v_load(i)[1])
+        for t in flat(v_load_done()):
+            e(t)
+    else:
+        for i in range(8):
+            if i:
+                e(f"s_add_u32 s{S_TMP}, s{S_SOFF}, {4096 * i}")
+            e(f"buffer_load_dwordx4 {quad(RV0 + 4 * i)}, %{o['voff']}, s[{S_RS}:{S_RS + 3}], s{S_TMP if i else S_SOFF} offen")
+        e(f"s_add_u32 s{S_SOFF}, s{S_SOFF}, %{o['soff_step']}")
+    # ---- steady iterations: n - 2 of them
+    e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 2")
+    e(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    e(f"s_cbranch_scc1 L{role}pen_%=")
+    e(".p2align 6")
+    e(f"L{role}steady_%=:")
+    body(st, extras(True, True, "s"))
+    e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    e(f"s_cmp_lg_u32 s{S_CNT}, 0")
+    e(f"s_cbranch_scc1 L{role}steady_%=")
+    # ---- second-to-last iteration: stores of the last stage, no loads
+    e(f"L{role}pen_%=:")
+    body(st, extras(True, False, "q"))
+    # ---- last iteration
+    e(f"L{role}last_%=:")
+    body(st, extras(False, False, "r"))
+    # ---- the last stage's groups 6, 7; every wave's fragment reads are complete behind this barrier, so the epilogue may
+    #      reuse the stage buffers
+    st.drain()
+    e("s_barrier")
+    for g, s in ((6, 2), (7, 3)):
+        for j in range(4):
+            st.mfma(g, s, j)
+    e("s_nop 15")
+    e("s_nop 7")
+    return st.lines
+
+
+def as_macro(name: str, lines: list[str]) -> str:
+    out = [f"#define {name} \\"]
+    for ln in lines:
+        out.append(f'  "{ln}\\n" \\')
+    out.append('  ""')
+    return "\n".join(out) + "\n"
+
+
+def clobbers() -> str:
+    regs = [f'"v{i}"' for i in range(TB, 256)] + [f'"s{i}"' for i in range(S_RS, S_TMP + 1)] + ['"vcc"', '"scc"', '"memory"']
+    return "#define WINO_KLOOP_CLOBBERS " + ", ".join(regs) + "\n"
+
+
+def generate() -> str:
+    src = ("// generated by gen_wino_kloop.py -- do not edit.  Operand numbering: see V_OPS / U_OPS in the generator and the\n"
+           "// asm statements in conv.hip.\n")
+    src += as_macro("WINO_KLOOP_V_ASM", gen_role("V"))
+    src += as_macro("WINO_KLOOP_U_ASM", gen_role("U"))
+    src += clobbers()
+    return src
+
+
+if __name__ == "__main__":
+    path = os.path.join(HERE, "wino_kloop.inc")
+    text = generate()
+    with open(path, "w") as f:
+        f.write(text)
+    print(path, len(text.splitlines()), "lines")

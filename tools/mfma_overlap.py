@@ -150,9 +150,14 @@ def variants():
         for kind in kinds:
             for k in (1, 2, 4, 6, 8, 12):
                 add(f"B  1 wave/SIMD  order {order:6s} + {k:2d} x {kind} per gap", 256, body(order, kind, k))
+    for order in ("rr", "chain4"):
+        add(f"D  2 waves/SIMD both MFMA only, order {order}", 512, body(order, None, 0), body(order, None, 0), False)
+        for kind in ("v_add", "v_pk_add", "ds_read_b128", "buf_load_x2", "ds_write_b64"):
+            for k in (1, 2, 4, 6):
+                add(f"D  2 waves/SIMD both order {order:6s} + {k} x {kind} per gap", 512, body(order, kind, k), body(order, kind, k), False)
     # C: partner wave = fillers only, diluted with s_nop to several densities
-    for kind in ("v_add", "v_pk_add", "ds_read_b128", "buf_load_x2"):
-        for fill, nops in ((1, 15), (2, 14), (4, 12), (8, 8), (16, 0)):
+    for kind in ("v_add", "v_pk_add", "buf_load_x2"):
+        for fill, nops in ((1, 15), (4, 12), (16, 0)):
             lines = []
             for i in range(8):  # 8 groups of (fill fillers + nops s_nop)
                 lines += [filler(kind, i * fill + j) for j in range(fill)] + ["s_nop 0"] * nops
@@ -162,11 +167,14 @@ def variants():
                 lines.append("s_waitcnt vmcnt(8)")
             add(f"C  2 waves/SIMD wave w MFMA rr | partner {fill:2d} x {kind} + {nops:2d} s_nop", 512, body("rr", None, 0),
                 "\\n\\t".join(lines), True, 8 * fill)
-    for order in ("rr", "chain4"):
-        add(f"D  2 waves/SIMD both MFMA only, order {order}", 512, body(order, None, 0), body(order, None, 0), False)
-        for kind in ("v_add", "v_pk_add", "ds_read_b128", "buf_load_x2", "ds_write_b64"):
-            for k in (1, 2, 4, 6):
-                add(f"D  2 waves/SIMD both order {order:6s} + {k} x {kind} per gap", 512, body(order, kind, k), body(order, kind, k), False)
+    # C2: the same pairing, but the MFMA wave has a real stall in it (one ds_read + s_waitcnt lgkmcnt(0) per 16 MFMAs)
+    for kind in ("v_add", "v_pk_add"):
+        for fill, nops in ((1, 15), (4, 12), (16, 0)):
+            lines = []
+            for i in range(8):
+                lines += [filler(kind, i * fill + j) for j in range(fill)] + ["s_nop 0"] * nops
+            add(f"C2 2 waves/SIMD wave w MFMA rr + 1 LDS round trip | partner {fill:2d} x {kind} + {nops:2d} s_nop", 512,
+                body("rr", None, 0) + "\\n\\tds_read_b128 %20, %26\\n\\ts_waitcnt lgkmcnt(0)", "\\n\\t".join(lines), True, 8 * fill)
     return out
 
 
