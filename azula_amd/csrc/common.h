@@ -28,8 +28,13 @@ __device__ __forceinline__ float az_mul(float a, float b) { return __fmul_rn(a, 
 __device__ __forceinline__ float az_add(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float az_sub(float a, float b) { return __fsub_rn(a, b); }
 
-// Accurate expf (ocml, ~1 ulp): SiLU sits in memory-bound kernels / conv epilogues, the VALU cost is hidden.
-__device__ __forceinline__ float az_silu(float v) { return v / (1.0f + expf(-v)); }
+// SiLU = v * sigmoid(v) as 5 vector instructions: v_exp_f32 and v_rcp_f32 are each within 1 ulp, the result within
+// ~2.5 ulp of v / (1 + expf(-v)) -- same limits (-inf -> NaN, very negative -> -0, +inf -> +inf).  The ocml expf + IEEE
+// division form took ~28 instructions; in a conv epilogue (one workgroup per CU, nothing to hide behind) that was 8 k of a
+// workgroup's 170 k cycles (profiles/r03_wino_timeline.txt), and vector instructions add to matrix time on this chip.
+__device__ __forceinline__ float az_silu(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
 
 // 64-lane butterfly reductions (wave64).
 __device__ __forceinline__ float az_wave_sum(float v) {

@@ -1184,6 +1184,21 @@ struct WinoP {
 __device__ __forceinline__ int wswz(int row, int half) { return row * WK + 4 * (half ^ ((row >> 3) & 1)); }
 
 #include "wino_kloop.inc"
+#ifdef AZ_WINO_TL
+// Experiment builds only (tools/ab_build.py tl -DAZ_WINO_TL; tools/wino_timeline.py): s_memtime stamps of waves 0 and 4 of
+// every workgroup + the hardware id of its CU, to see what a workgroup spends outside its K loop and between workgroups.
+__device__ unsigned long long az_wino_tl[8192 * 2 * 8];
+extern "C" int az_debug_wino_timeline(unsigned long long* host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(az_wino_tl), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+#define TL_STAMP(k)                                                                                           \
+  do {                                                                                                        \
+    if ((threadIdx.x & 255) == 0 && blockIdx.x < 8192 && blockIdx.y == 0)                                      \
+      az_wino_tl[(blockIdx.x * 2 + (threadIdx.x >> 8)) * 8 + (k)] = __builtin_readcyclecounter();              \
+  } while (0)
+#else
+#define TL_STAMP(k)
+#endif
 constexpr int W_VOFF_BYTES = 256 * 64;  // ASM form: the second source's 16 patch offsets of the 256 gather threads
 
 // ASM = true: the K loop is the hand-scheduled instruction stream of wino_kloop.inc (gen_wino_kloop.py), software
@@ -1192,6 +1207,12 @@ constexpr int W_VOFF_BYTES = 256 * 64;  // ASM form: the second source's 16 patc
 template <bool ASM>
 __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];  // 2 * W_STAGE floats
+  TL_STAMP(0);
+#ifdef AZ_WINO_TL
+  if ((threadIdx.x & 255) == 0 && blockIdx.x < 8192 && blockIdx.y == 0)
+    az_wino_tl[(blockIdx.x * 2 + (threadIdx.x >> 8)) * 8 + 7] =
+        ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+#endif
   const AzConvArgs& a = p.a;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1352,6 +1373,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   // fragment addresses: row (within a frequency) = wave's 32-row block + l31; half = h (swizzled)
   const int fragA = (fh * 8) * WC * WK + wswz(wco * 32 + l31, h);  // + f * WC * WK
   const int fragB = (fh * 8) * WT * WK + wswz(wti * 32 + l31, h);  // + f * WT * WK
+  TL_STAMP(1);
   if constexpr (ASM) {
     if (kt_begin < kt_end) {
       typedef __attribute__((address_space(3))) float lds_float;
@@ -1449,6 +1471,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   }
   }
 
+  TL_STAMP(2);
   // ---- output transform.  Y = A^T M A is linear in M, so each wave transforms the 8 frequencies
   // (two xi rows) it owns into a partial 2x2 output; the xi in {2,3} waves hand theirs to their
   // xi in {0,1} partners through LDS (once per workgroup), which add and run the fused epilogue.
@@ -1505,6 +1528,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
     tinfo[2 * WT + wti * 32 + l31] = b;
   }
   __syncthreads();
+  TL_STAMP(3);
   const int cq = tid & 15;  // the same channel quad in every iteration
   const int co = cb * WC + cq * 4;
   if (co >= a.cout_s) return;
@@ -1523,7 +1547,13 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
     ov[it] = make_float4(v0.x + v1.x, v0.y + v1.y, v0.z + v1.z, v0.w + v1.w);
   }
   if (a.gn_quads == nullptr) {
+    TL_STAMP(4);
     epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix);
+    TL_STAMP(5);
+#ifdef AZ_WINO_TL
+    __builtin_amdgcn_s_waitcnt(0);
+    TL_STAMP(6);
+#endif
     return;
   }
   // ---- GroupNorm statistics of the OUTPUT, for the normalisation that consumes it (the separate statistics pass read

@@ -29,7 +29,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 TB = 160
 RV0, VO0, X0, Y0 = 192, 224, 240, 248
 V_FA, V_FB, V_ST, V_OOB = 252, 253, 254, 255
-S_RS, S_SOFF, S_KT, S_CNT, S_TMP = 92, 96, 97, 98, 99
+S_RS, S_SOFF, S_KT, S_CNT, S_TMP, S_FIRST = 92, 96, 97, 98, 99, 100
 GROUP_BYTES = 2048  # one frequency of a stage: 64 rows x 8 floats x 4 B
 BUF_XOR = 0x10000   # the two 64 KB stages
 
@@ -85,8 +85,8 @@ class Stream:
 
 
 # ------------------------------------------------------------------------------------------------ V role pieces
-def v_pass1_col(c):
-    d0, d1, d2, d3 = RV0 + 2 * c, RV0 + 2 * (4 + c), RV0 + 2 * (8 + c), RV0 + 2 * (12 + c)
+def v_pass1_col(c, rv0=RV0):
+    d0, d1, d2, d3 = rv0 + 2 * c, rv0 + 2 * (4 + c), rv0 + 2 * (8 + c), rv0 + 2 * (12 + c)
     x = X0 + 2 * c
     return [
         f"v_pk_add_f32 {pair(d0)}, {pair(d0)}, {pair(d2)} neg_lo:[0,1] neg_hi:[0,1]",   # o0 = d0 - d2
@@ -96,15 +96,15 @@ def v_pass1_col(c):
     ]
 
 
-def v_row_regs(xi):
+def v_row_regs(xi, rv0=RV0):
     if xi == 1:
         return [X0 + 2 * c for c in range(4)]
-    return [RV0 + 2 * (4 * xi + c) for c in range(4)]
+    return [rv0 + 2 * (4 * xi + c) for c in range(4)]
 
 
-def v_pass2_row(xi):
+def v_pass2_row(xi, rv0=RV0):
     r"""Row xi of the second transform pass, in place (out1 in a Y temp), and its two LDS stores."""
-    u0, u1, u2, u3 = v_row_regs(xi)
+    u0, u1, u2, u3 = v_row_regs(xi, rv0)
     y = Y0 + 2 * (xi & 1)
     valu = [
         ("valu", f"v_pk_add_f32 {pair(u0)}, {pair(u0)}, {pair(u2)} neg_lo:[0,1] neg_hi:[0,1]"),  # out0 = u0 - u2
@@ -117,8 +117,8 @@ def v_pass2_row(xi):
     return valu, wa, wb
 
 
-def v_load(i):
-    return ("vmem", f"buffer_load_dwordx2 {pair(RV0 + 2 * i)}, v{VO0 + i}, s[{S_RS}:{S_RS + 3}], s{S_SOFF} offen")
+def v_load(i, rv0=RV0):
+    return ("vmem", f"buffer_load_dwordx2 {pair(rv0 + 2 * i)}, v{VO0 + i}, s[{S_RS}:{S_RS + 3}], s{S_SOFF} offen")
 
 
 V_OPS = dict(fragA=8, fragB=9, st=10, ldsA=11, ldsB=12, rs0=13, rs1=17, kt_begin=21, kt_end=22, kt_switch=23, soff0=24,
@@ -206,9 +206,13 @@ def u_extras(S: bool, L: bool, tag: str):
 
 
 # ------------------------------------------------------------------------------------------------ the iteration
-def body(st: Stream, extras: dict):
+def body(st: Stream, extras: dict, tag: str, prio_head: int = 0):
+    r"""One iteration.  `prio_head` > 0: the wave runs its first `prio_head` MFMA gaps at raised priority (the younger wave of a
+    SIMD otherwise only runs when the older one stalls, so its loads would be issued late in the stage)."""
     st.drain()
     st.emit("s_barrier")
+    if prio_head:
+        st.emit("s_setprio 2")
     st.read_set(0, 0)
     st.read_set(1, 1)
     k = 0
@@ -217,14 +221,18 @@ def body(st: Stream, extras: dict):
         for kind, text in extras[k]:
             if kind == "lds":
                 st.lds(text)
-            elif kind == "ldsx":  # self-contained LDS traffic that ends in its own lgkmcnt(0) (rare path)
+            else:  # "ldsx": self-contained LDS traffic that ends in its own lgkmcnt(0) (rare path)
                 st.emit(text)
-            else:
-                st.emit(text)
+        if prio_head and k == prio_head - 1:
+            st.emit("s_setprio 0")
 
-    for g, s in ((6, 2), (7, 3)):   # carried groups of the previous stage: their reads completed before the barrier
+    # carried groups of the previous stage (their reads completed before the barrier); none in a workgroup's first iteration
+    for g, s in ((6, 2), (7, 3)):
         for j in range(4):
+            st.emit(f"s_cmp_lg_u32 s{S_FIRST}, 0")
+            st.emit(f"s_cbranch_scc1 Lsk{tag}{k}_%=")
             st.mfma(g, s, j)
+            st.emit(f"Lsk{tag}{k}_%=:")
             put_extras(k)
             k += 1
     for f in range(6):
@@ -237,10 +245,15 @@ def body(st: Stream, extras: dict):
             k += 1
     st.emit(f"v_xor_b32 v{V_FA}, 0x{BUF_XOR:x}, v{V_FA}")
     st.emit(f"v_xor_b32 v{V_FB}, 0x{BUF_XOR:x}, v{V_FB}")
+    st.emit(f"s_mov_b32 s{S_FIRST}, 0")
 
 
 def flat(items):
     return [t for _, t in items]
+
+
+# Tunables (environment overrides are for tools/kloop_variant.py A/B builds; the committed .inc is the default)
+PRIO_HEAD = {"V": int(os.environ.get("KL_PRIO_V", "0")), "U": int(os.environ.get("KL_PRIO_U", "0"))}  # U role = waves 4..7 = the younger wave of every SIMD
 
 
 def gen_role(role: str) -> list[str]:
@@ -249,6 +262,24 @@ def gen_role(role: str) -> list[str]:
     extras = v_extras if V else u_extras
     st = Stream()
     e = st.emit
+    P0 = TB  # the prologue's first stage is loaded into the (still unused) fragment registers, the second into RV:
+    #          both global-memory latencies overlap
+
+    def u_loads(rv0):
+        for i in range(8):
+            if i:
+                e(f"s_add_u32 s{S_TMP}, s{S_SOFF}, {4096 * i}")
+            e(f"buffer_load_dwordx4 {quad(rv0 + 4 * i)}, %{o['voff']}, s[{S_RS}:{S_RS + 3}], s{S_TMP if i else S_SOFF} offen")
+        e(f"s_add_u32 s{S_SOFF}, s{S_SOFF}, %{o['soff_step']}")
+
+    def v_loads(rv0, tag):
+        for kind, t in v_load_events(tag):
+            e(t)
+        for i in range(16):
+            e(v_load(i, rv0)[1])
+        for t in flat(v_load_done()):
+            e(t)
+
     # ---- initial state
     e(f"v_mov_b32 v{V_FA}, %{o['fragA']}")
     e(f"v_mov_b32 v{V_FB}, %{o['fragB']}")
@@ -256,77 +287,60 @@ def gen_role(role: str) -> list[str]:
     for w in range(4):
         e(f"s_mov_b32 s{S_RS + w}, %{(o['rs0'] if V else o['rw']) + w}")
     e(f"s_mov_b32 s{S_SOFF}, %{o['soff0']}")
+    e(f"s_mov_b32 s{S_FIRST}, 1")
+    e(f"s_sub_u32 s{S_CNT}, %{o['kt_end']}, %{o['kt_begin']}")   # n stages
     if V:
         e(f"v_mov_b32 v{V_OOB}, 0x80000000")
         e(f"s_mov_b32 s{S_KT}, %{o['kt_begin']}")
         for q in range(4):
             e(f"ds_read_b128 {quad(VO0 + 4 * q)}, %{o['ldsA']} offset:{16 * q}")
-    for s in (2, 3):  # the first iteration's "carried" MFMAs multiply zeros
-        for j in range(8):
-            e(f"v_mov_b32 v{TB + 8 * s + j}, 0")
-    e("s_waitcnt lgkmcnt(0)")
-    # ---- prologue stage: L(kt0), S(kt0), L(kt0 + 1)
-    ex = extras(True, True, "p0")
+        e("s_waitcnt lgkmcnt(0)")
+    # ---- prologue: L(kt0) -> P0, L(kt0 + 1) -> RV (if n >= 2), S(kt0) from P0
     if V:
-        for kind, t in v_load_events("p0"):
-            e(t)
-        for i in range(16):
-            e(v_load(i)[1])
-        for t in flat(v_load_done()):
-            e(t)
-        e("s_waitcnt vmcnt(0)")
+        v_loads(P0, "p0")
+    else:
+        u_loads(P0)
+    e(f"s_cmp_lt_u32 s{S_CNT}, 2")
+    e(f"s_cbranch_scc1 L{role}one_%=")
+    if V:
+        v_loads(RV0, "p1")
+    else:
+        u_loads(RV0)
+    e(f"s_waitcnt vmcnt({16 if V else 8})")
+    e(f"s_branch L{role}st0_%=")
+    e(f"L{role}one_%=:")
+    e("s_waitcnt vmcnt(0)")
+    e(f"L{role}st0_%=:")
+    if V:
         for c in range(4):
-            for t in v_pass1_col(c):
+            for t in v_pass1_col(c, P0):
                 e(t)
         for xi in range(4):
-            valu, wa, wb = v_pass2_row(xi)
+            valu, wa, wb = v_pass2_row(xi, P0)
             for kind, t in valu + [wa, wb]:
                 e(t)
-        e(f"v_xor_b32 v{V_ST}, 0x{BUF_XOR:x}, v{V_ST}")
     else:
         for i in range(8):
-            if i:
-                e(f"s_add_u32 s{S_TMP}, s{S_SOFF}, {4096 * i}")
-            e(f"buffer_load_dwordx4 {quad(RV0 + 4 * i)}, %{o['voff']}, s[{S_RS}:{S_RS + 3}], s{S_TMP if i else S_SOFF} offen")
-        e(f"s_add_u32 s{S_SOFF}, s{S_SOFF}, %{o['soff_step']}")
-        e("s_waitcnt vmcnt(0)")
-        for i in range(8):
-            e(f"ds_write_b128 v{V_ST}, {quad(RV0 + 4 * i)} offset:{4096 * i}")
-        e(f"v_xor_b32 v{V_ST}, 0x{BUF_XOR:x}, v{V_ST}")
-    del ex
-    # n = kt_end - kt_begin stages; L(kt0 + 1) if n >= 2
-    e(f"s_sub_u32 s{S_CNT}, %{o['kt_end']}, %{o['kt_begin']}")
+            e(f"ds_write_b128 v{V_ST}, {quad(P0 + 4 * i)} offset:{4096 * i}")
+    e(f"v_xor_b32 v{V_ST}, 0x{BUF_XOR:x}, v{V_ST}")
+    # ---- n = 1: last; n = 2: pen, last; n >= 3: n - 2 steady iterations first
     e(f"s_cmp_lt_u32 s{S_CNT}, 2")
     e(f"s_cbranch_scc1 L{role}last_%=")
-    if V:
-        for kind, t in v_load_events("p1"):
-            e(t)
-        for i in range(16):
-            e(v_load(i)[1])
-        for t in flat(v_load_done()):
-            e(t)
-    else:
-        for i in range(8):
-            if i:
-                e(f"s_add_u32 s{S_TMP}, s{S_SOFF}, {4096 * i}")
-            e(f"buffer_load_dwordx4 {quad(RV0 + 4 * i)}, %{o['voff']}, s[{S_RS}:{S_RS + 3}], s{S_TMP if i else S_SOFF} offen")
-        e(f"s_add_u32 s{S_SOFF}, s{S_SOFF}, %{o['soff_step']}")
-    # ---- steady iterations: n - 2 of them
     e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 2")
     e(f"s_cmp_eq_u32 s{S_CNT}, 0")
     e(f"s_cbranch_scc1 L{role}pen_%=")
     e(".p2align 6")
     e(f"L{role}steady_%=:")
-    body(st, extras(True, True, "s"))
+    body(st, extras(True, True, "s"), "s", PRIO_HEAD[role])
     e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
     e(f"s_cmp_lg_u32 s{S_CNT}, 0")
     e(f"s_cbranch_scc1 L{role}steady_%=")
     # ---- second-to-last iteration: stores of the last stage, no loads
     e(f"L{role}pen_%=:")
-    body(st, extras(True, False, "q"))
+    body(st, extras(True, False, "q"), "q", PRIO_HEAD[role])
     # ---- last iteration
     e(f"L{role}last_%=:")
-    body(st, extras(False, False, "r"))
+    body(st, extras(False, False, "r"), "r")
     # ---- the last stage's groups 6, 7; every wave's fragment reads are complete behind this barrier, so the epilogue may
     #      reuse the stage buffers
     st.drain()
@@ -348,7 +362,7 @@ def as_macro(name: str, lines: list[str]) -> str:
 
 
 def clobbers() -> str:
-    regs = [f'"v{i}"' for i in range(TB, 256)] + [f'"s{i}"' for i in range(S_RS, S_TMP + 1)] + ['"vcc"', '"scc"', '"memory"']
+    regs = [f'"v{i}"' for i in range(TB, 256)] + [f'"s{i}"' for i in range(S_RS, S_FIRST + 1)] + ['"vcc"', '"scc"', '"memory"']
     return "#define WINO_KLOOP_CLOBBERS " + ", ".join(regs) + "\n"
 
 
