@@ -84,15 +84,26 @@ class Stream:
         self.emit(f"v_mfma_f32_32x32x2_f32 %{acc}, {fa(s, j)}, {fb(s, j)}, %{acc}")
 
 
+SCALAR_ADD = os.environ.get("KL_SCALAR_ADD", "0") == "1"  # A/B: two v_add / v_sub instead of one v_pk_add_f32
+
+
+def pk(dst, a, b, sub=False):
+    r"""dst = a +/- b on a register pair (text; two lines joined by a newline in the scalar form)."""
+    if not SCALAR_ADD:
+        return f"v_pk_add_f32 {pair(dst)}, {pair(a)}, {pair(b)}" + (" neg_lo:[0,1] neg_hi:[0,1]" if sub else "")
+    op = "v_sub_f32" if sub else "v_add_f32"
+    return f"{op} v{dst}, v{a}, v{b}\\n{op} v{dst + 1}, v{a + 1}, v{b + 1}"
+
+
 # ------------------------------------------------------------------------------------------------ V role pieces
 def v_pass1_col(c, rv0=RV0):
     d0, d1, d2, d3 = rv0 + 2 * c, rv0 + 2 * (4 + c), rv0 + 2 * (8 + c), rv0 + 2 * (12 + c)
     x = X0 + 2 * c
     return [
-        f"v_pk_add_f32 {pair(d0)}, {pair(d0)}, {pair(d2)} neg_lo:[0,1] neg_hi:[0,1]",   # o0 = d0 - d2
-        f"v_pk_add_f32 {pair(d3)}, {pair(d1)}, {pair(d3)} neg_lo:[0,1] neg_hi:[0,1]",   # o3 = d1 - d3
-        f"v_pk_add_f32 {pair(x)}, {pair(d1)}, {pair(d2)}",                              # o1 = d1 + d2 -> X[c]
-        f"v_pk_add_f32 {pair(d2)}, {pair(d2)}, {pair(d1)} neg_lo:[0,1] neg_hi:[0,1]",   # o2 = d2 - d1
+        pk(d0, d0, d2, True),   # o0 = d0 - d2
+        pk(d3, d1, d3, True),   # o3 = d1 - d3
+        pk(x, d1, d2),          # o1 = d1 + d2 -> X[c]
+        pk(d2, d2, d1, True),   # o2 = d2 - d1
     ]
 
 
@@ -107,10 +118,10 @@ def v_pass2_row(xi, rv0=RV0):
     u0, u1, u2, u3 = v_row_regs(xi, rv0)
     y = Y0 + 2 * (xi & 1)
     valu = [
-        ("valu", f"v_pk_add_f32 {pair(u0)}, {pair(u0)}, {pair(u2)} neg_lo:[0,1] neg_hi:[0,1]"),  # out0 = u0 - u2
-        ("valu", f"v_pk_add_f32 {pair(y)}, {pair(u1)}, {pair(u2)}"),                            # out1 = u1 + u2
-        ("valu", f"v_pk_add_f32 {pair(u2)}, {pair(u2)}, {pair(u1)} neg_lo:[0,1] neg_hi:[0,1]"),  # out2 = u2 - u1
-        ("valu", f"v_pk_add_f32 {pair(u3)}, {pair(u1)}, {pair(u3)} neg_lo:[0,1] neg_hi:[0,1]"),  # out3 = u1 - u3
+        ("valu", pk(u0, u0, u2, True)),  # out0 = u0 - u2
+        ("valu", pk(y, u1, u2)),         # out1 = u1 + u2
+        ("valu", pk(u2, u2, u1, True)),  # out2 = u2 - u1
+        ("valu", pk(u3, u1, u3, True)),  # out3 = u1 - u3
     ]
     wa = ("lds", f"ds_write2st64_b64 v{V_ST}, {pair(u0)}, {pair(y)} offset0:{16 * xi} offset1:{16 * xi + 4}")
     wb = ("lds", f"ds_write2st64_b64 v{V_ST}, {pair(u2)}, {pair(u3)} offset0:{16 * xi + 8} offset1:{16 * xi + 12}")
@@ -210,7 +221,8 @@ def body(st: Stream, extras: dict, tag: str, prio_head: int = 0):
     r"""One iteration.  `prio_head` > 0: the wave runs its first `prio_head` MFMA gaps at raised priority (the younger wave of a
     SIMD otherwise only runs when the older one stalls, so its loads would be issued late in the stage)."""
     st.drain()
-    st.emit("s_barrier")
+    if "barrier" not in ABL:
+        st.emit("s_barrier")
     if prio_head:
         st.emit("s_setprio 2")
     st.read_set(0, 0)
@@ -219,6 +231,10 @@ def body(st: Stream, extras: dict, tag: str, prio_head: int = 0):
 
     def put_extras(k):
         for kind, text in extras[k]:
+            if (kind == "vmem" and ("vload" in ABL and "dwordx2" in text or "uload" in ABL and "dwordx4" in text)) or \
+                    (kind == "valu" and "vtrans" in ABL and ("v_pk_add" in text or "v_sub_f32" in text or "v_add_f32" in text)) or \
+                    (kind == "lds" and ("vstore" in ABL and "ds_write2st64" in text or "ustore" in ABL and "ds_write_b128" in text)):
+                continue
             if kind == "lds":
                 st.lds(text)
             else:  # "ldsx": self-contained LDS traffic that ends in its own lgkmcnt(0) (rare path)
@@ -252,6 +268,7 @@ def flat(items):
     return [t for _, t in items]
 
 
+ABL = set(os.environ.get("KL_ABLATE", "").split(","))  # timing ablations (WRONG results): vload, uload, vtrans, vstore, ustore, barrier
 # Tunables (environment overrides are for tools/kloop_variant.py A/B builds; the committed .inc is the default)
 PRIO_HEAD = {"V": int(os.environ.get("KL_PRIO_V", "0")), "U": int(os.environ.get("KL_PRIO_U", "0"))}  # U role = waves 4..7 = the younger wave of every SIMD
 
