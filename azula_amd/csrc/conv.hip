@@ -1418,14 +1418,24 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
         const uint64_t bw = (uint64_t)(uintptr_t)a.weight;
         const unsigned ww0 = (unsigned)bw, ww1 = (unsigned)(bw >> 32) & 0xffffu;
         const unsigned ww2 = clamp_bytes((int64_t)p.nk * p.cblocks * WU_STAGE), ww3 = 0x00020000u;
-        const unsigned uvoff = (unsigned)(tid - 256) * 16u;
         const int e0 = tid - 256;
+#ifdef WINO_KLOOP_UDMA
+        // LDS-DMA: lane L of a wave fills slot (wave's first slot + L); slot q holds float4 (q & ~1) | ((q & 1) ^ ((q >> 4) & 1))
+        const unsigned uvoff = (unsigned)((e0 & ~1) | ((e0 & 1) ^ ((e0 >> 4) & 1))) * 16u;
+        const unsigned ust = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wave - 4) * 1024u);
+#else
+        const unsigned uvoff = (unsigned)(tid - 256) * 16u;
         const unsigned ust = lds0 + (unsigned)wswz(e0 >> 1, e0 & 1) * 4u;
+#endif
         const unsigned usoff0 = (unsigned)(((int64_t)kt_begin * p.cblocks + cb) * (WU_STAGE * 4));
         const unsigned ustep = (unsigned)(p.cblocks * (WU_STAGE * 4));
         asm volatile(WINO_KLOOP_U_ASM
                      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+#ifdef WINO_KLOOP_UDMA
+                     : "v"(fragA_b), "v"(fragB_b), "s"(ust), "v"(uvoff), "s"(ww0), "s"(ww1), "s"(ww2), "s"(ww3), "s"(kt_begin), "s"(kt_end),
+#else
                      : "v"(fragA_b), "v"(fragB_b), "v"(ust), "v"(uvoff), "s"(ww0), "s"(ww1), "s"(ww2), "s"(ww3), "s"(kt_begin), "s"(kt_end),
+#endif
                        "s"(usoff0), "s"(ustep)
                      : WINO_KLOOP_CLOBBERS);
       }

@@ -196,9 +196,33 @@ def v_extras(S: bool, L: bool, tag: str):
 U_OPS = dict(fragA=8, fragB=9, st=10, voff=11, rw=12, kt_begin=16, kt_end=17, soff0=18, soff_step=19)
 
 
+UDMA = os.environ.get("KL_UDMA", "0") == "1"  # filter chunk by LDS-DMA (buffer_load ... lds): no staging registers, no ds_write
+S_UST = S_KT  # (the filter role has no stage counter: its SGPR holds the wave's LDS slot in the buffer to fill next)
+
+
+def u_dma(i: int, o) -> list:
+    r"""16 B per lane of filter chunk piece i straight into LDS: M0 = this wave's 1 KB slot, the per-lane SOURCE offset carries
+    the XOR swizzle of the LDS image (the destination of an LDS-DMA is wave-uniform base + 16 x lane)."""
+    L = [("salu", f"s_add_u32 m0, s{S_UST}, {4096 * i}")]
+    if i:
+        L.append(("salu", f"s_add_u32 s{S_TMP}, s{S_SOFF}, {4096 * i}"))
+    else:
+        L.append(("salu", "s_nop 0"))
+    L.append(("vmem", f"buffer_load_dwordx4 %{o['voff']}, s[{S_RS}:{S_RS + 3}], s{S_TMP if i else S_SOFF} offen lds"))
+    return L
+
+
 def u_extras(S: bool, L: bool, tag: str):
     ex = {k: [] for k in range(32)}
     o = U_OPS
+    if UDMA:
+        if S:  # stage t + 1 into the buffer that became free at this iteration's barrier; landed before the next barrier
+            for i in range(8):
+                ex[1 + i] += u_dma(i, o)
+            ex[8].append(("salu", f"s_add_u32 s{S_SOFF}, s{S_SOFF}, %{o['soff_step']}"))
+            ex[8].append(("salu", f"s_xor_b32 s{S_UST}, s{S_UST}, 0x{BUF_XOR:x}"))
+            ex[31].append(("wait", "s_waitcnt vmcnt(0)"))
+        return ex
     if S:
         ex[0].append(("wait", "s_waitcnt vmcnt(0)"))
         for i in range(8):
@@ -300,7 +324,8 @@ def gen_role(role: str) -> list[str]:
     # ---- initial state
     e(f"v_mov_b32 v{V_FA}, %{o['fragA']}")
     e(f"v_mov_b32 v{V_FB}, %{o['fragB']}")
-    e(f"v_mov_b32 v{V_ST}, %{o['st']}")
+    if V or not UDMA:
+        e(f"v_mov_b32 v{V_ST}, %{o['st']}")
     for w in range(4):
         e(f"s_mov_b32 s{S_RS + w}, %{(o['rs0'] if V else o['rw']) + w}")
     e(f"s_mov_b32 s{S_SOFF}, %{o['soff0']}")
@@ -315,15 +340,22 @@ def gen_role(role: str) -> list[str]:
     # ---- prologue: L(kt0) -> P0, L(kt0 + 1) -> RV (if n >= 2), S(kt0) from P0
     if V:
         v_loads(P0, "p0")
+    elif UDMA:
+        e(f"s_mov_b32 s{S_UST}, %{o['st']}")
+        for i in range(8):
+            for kind, t in u_dma(i, o):
+                e(t)
+        e(f"s_add_u32 s{S_SOFF}, s{S_SOFF}, %{o['soff_step']}")
+        e(f"s_xor_b32 s{S_UST}, s{S_UST}, 0x{BUF_XOR:x}")
     else:
         u_loads(P0)
     e(f"s_cmp_lt_u32 s{S_CNT}, 2")
     e(f"s_cbranch_scc1 L{role}one_%=")
     if V:
         v_loads(RV0, "p1")
-    else:
+    elif not UDMA:
         u_loads(RV0)
-    e(f"s_waitcnt vmcnt({16 if V else 8})")
+    e(f"s_waitcnt vmcnt({16 if V else (0 if UDMA else 8)})")
     e(f"s_branch L{role}st0_%=")
     e(f"L{role}one_%=:")
     e("s_waitcnt vmcnt(0)")
@@ -336,7 +368,7 @@ def gen_role(role: str) -> list[str]:
             valu, wa, wb = v_pass2_row(xi, P0)
             for kind, t in valu + [wa, wb]:
                 e(t)
-    else:
+    elif not UDMA:
         for i in range(8):
             e(f"ds_write_b128 v{V_ST}, {quad(P0 + 4 * i)} offset:{4096 * i}")
     e(f"v_xor_b32 v{V_ST}, 0x{BUF_XOR:x}, v{V_ST}")
@@ -379,7 +411,7 @@ def as_macro(name: str, lines: list[str]) -> str:
 
 
 def clobbers() -> str:
-    regs = [f'"v{i}"' for i in range(TB, 256)] + [f'"s{i}"' for i in range(S_RS, S_FIRST + 1)] + ['"vcc"', '"scc"', '"memory"']
+    regs = ['"m0"'] + [f'"v{i}"' for i in range(TB, 256)] + [f'"s{i}"' for i in range(S_RS, S_FIRST + 1)] + ['"vcc"', '"scc"', '"memory"']
     return "#define WINO_KLOOP_CLOBBERS " + ", ".join(regs) + "\n"
 
 
@@ -389,6 +421,8 @@ def generate() -> str:
     src += as_macro("WINO_KLOOP_V_ASM", gen_role("V"))
     src += as_macro("WINO_KLOOP_U_ASM", gen_role("U"))
     src += clobbers()
+    if UDMA:
+        src += "#define WINO_KLOOP_UDMA 1\n"
     return src
 
 
