@@ -14,7 +14,12 @@ dev = torch.device("cuda")
 torch.manual_seed(0)
 qkv = torch.randn(B * T * 3 * H * D, device=dev)
 bld = Builder(dev)
-out = bld.attention(Act(qkv, B, T, 1, 3 * H * D, 3 * H * D, True), H, "nHC", True, 1.0 / math.sqrt(D))
+# AZ_ATTN_OPTS: comma list of  norms (q/k RMS norm, default on), gains (learned q/k gains), rope (rotary tables), order=3HC
+opts = set(os.environ.get("AZ_ATTN_OPTS", "norms").split(","))
+rope = (torch.randn(T, H * D // 2, device=dev), torch.randn(T, H * D // 2, device=dev)) if "rope" in opts else None
+gains = (torch.rand(D, device=dev) + 0.5, torch.rand(D, device=dev) + 0.5) if "gains" in opts else None
+out = bld.attention(Act(qkv, B, T, 1, 3 * H * D, 3 * H * D, True), H, "3HC" if "order=3HC" in opts else "nHC", "norms" in opts,
+                    1.0 / math.sqrt(D), rope=rope, qk_weight=gains)
 for _ in range(5):
     bld.tape.run()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -24,4 +29,5 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(f"attention {B}x{H}x{T}x{D}: {ms * 1e3:.1f} us  {4 * B * H * T * T * D / ms / 1e9:.1f} TF/s")
+tag = ",".join(sorted(opts))
+print(f"attention {B}x{H}x{T}x{D} [{tag}]: {ms * 1e3:.1f} us  {4 * B * H * T * T * D / ms / 1e9:.1f} TF/s")
