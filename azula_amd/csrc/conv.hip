@@ -88,7 +88,7 @@ __device__ __forceinline__ int wrap_coord(int i, int n, int mode) {
 #define AZ_RSRC_CLAMP 0x80000000ll  // == OOB: the largest num_records a descriptor may carry
 
 // log2 upsampling factor along the width: its own field when the descriptor is anisotropic (validated to [0, 4])
-static inline int az_upw(const AzConvArgs* a, int up, int up_w) { return a->aniso ? (up_w < 0 ? 0 : (up_w > 4 ? 4 : up_w)) : up; }
+static inline int az_upw(const AzConvArgs* a, int up, int up_w) { return a->aniso ? up_w : up; }  // (range checked by the callers)
 
 // Epilogue for 4 consecutive output channels [co, co+4) of output pixel n.
 // The fused epilogue in two halves so that callers can issue the loads of several outputs before the first store (the
@@ -1992,6 +1992,7 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   AZ_REQUIRE((a->hin + 2 * a->pad - a->ksize) / a->stride + 1 == a->hout &&
                  (a->win + 2 * a->pad - a->ksize) / (a->aniso ? a->stride_w : a->stride) + 1 == a->wout,
              AZ_E_SHAPE);
+  AZ_REQUIRE(!a->aniso || (a->up0_w >= 0 && a->up0_w <= 4 && a->up1_w >= 0 && a->up1_w <= 4), AZ_E_SHAPE);  // (shift amounts)
   AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
                  ((a->win + (1 << az_upw(a, a->up0, a->up0_w)) - 1) >> az_upw(a, a->up0, a->up0_w)) <= a->w0,
              AZ_E_SHAPE);
@@ -2097,6 +2098,7 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
+  AZ_REQUIRE(!a->aniso || (a->up0_w >= 0 && a->up0_w <= 4 && a->up1_w >= 0 && a->up1_w <= 4), AZ_E_SHAPE);  // (shift amounts)
   AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
                  ((a->win + (1 << az_upw(a, a->up0, a->up0_w)) - 1) >> az_upw(a, a->up0, a->up0_w)) <= a->w0,
              AZ_E_SHAPE);
@@ -2197,6 +2199,7 @@ int az_conv2d_winograd4_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
+  AZ_REQUIRE(!a->aniso || (a->up0_w >= 0 && a->up0_w <= 4 && a->up1_w >= 0 && a->up1_w <= 4), AZ_E_SHAPE);  // (shift amounts)
   AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
                  ((a->win + (1 << az_upw(a, a->up0, a->up0_w)) - 1) >> az_upw(a, a->up0, a->up0_w)) <= a->w0,
              AZ_E_SHAPE);

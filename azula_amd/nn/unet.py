@@ -159,13 +159,6 @@ class UNetBlock(nn.Module):
         tape.run()
         return res.to(out_dtype, copy=True)
 
-    def _forward_1d(self, x: Tensor, mod: Tensor | None) -> Tensor:
-        self.spatial = 2
-        try:
-            return self.forward(x[:, :, None], mod)[:, :, 0]
-        finally:
-            self.spatial = 1
-
     @torch.no_grad()
     @_lib.on_device
     def forward(self, x: Tensor, mod: Tensor | None = None) -> Tensor:
@@ -173,11 +166,14 @@ class UNetBlock(nn.Module):
         from .utils import backbone_io_dtype
 
         out_dtype = backbone_io_dtype(self, x, "azula_amd.nn.UNetBlock")
-        if self.spatial == 1:  # (B, C, L): the same kernels on a one-row image
+        if self.spatial == 1:  # (B, C, L): the same kernels and the same plan cache on a one-row image (no module state is touched)
             assert x.ndim == 3
-            return self._forward_1d(x, mod)
+            return self._forward_2d(x[:, :, None], mod, out_dtype)[:, :, 0]
         if self.spatial == 3:
             return self._forward_3d(x, mod, out_dtype)
+        return self._forward_2d(x, mod, out_dtype)
+
+    def _forward_2d(self, x: Tensor, mod: Tensor | None, out_dtype) -> Tensor:
         assert x.ndim == 4 and x.shape[1] == self.channels
         B, Cc, H, W = x.shape
         D = self.mod_features

@@ -136,12 +136,31 @@ def _token_plan(module, x: Tensor, pos, mask, D: int, emit, mod: Tensor | None =
         assert mod is not None, "this block is modulated: pass mod"
         rows = 1 if mod.ndim == 1 else mod.numel() // mod.shape[-1]
         assert rows in (1, B), "mod must be (D) or (*, D) with the leading shape of x"
-    pos_h = None if pos is None else pos.detach().to("cpu", torch.float32).reshape(L, -1)
-    key = (B, L, Cin, rows, str(x.device), None if pos_h is None else hash(pos_h.numpy().tobytes()),
-           None if mask is None else (tuple(mask.shape), hash(mask.detach().cpu().numpy().tobytes())))
+    # Positions and mask are BAKED into the plan (RoPE tables, mask bytes).  The key holds their CONTENT (bytes compare by
+    # value: no hash-collision reuse); a tensor already seen -- same storage, shape and version counter -- is recognised
+    # without copying it to the host again, so a steady-state forward does not synchronise the device.
+    def ident(t):
+        return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), str(t.dtype), str(t.device))
+
+    seen = module.__dict__.setdefault("_plan_seen", {})
+    ik = (ident(pos), ident(mask))
+    hit = seen.get(ik)  # (content, pos, mask): the tensors are kept alive, so their storage cannot be handed to others
+    content = hit[0] if hit is not None and hit[1] is pos and hit[2] is mask else None
+    pos_h = None
+    if content is None:
+        pos_h = None if pos is None else pos.detach().to("cpu", torch.float32).reshape(L, -1)
+        content = (None if pos_h is None else pos_h.numpy().tobytes(),
+                   None if mask is None else (tuple(mask.shape), mask.detach().cpu().numpy().tobytes()))
+        if len(seen) >= 2:
+            seen.clear()
+        seen[ik] = (content, pos, mask)
+    key = (B, L, Cin, rows, str(x.device), content)
     plan = module._plans.get(key)
     if plan is None or plan.versions != _versions(module):
-        module._plans.clear()  # one live plan per standalone module
+        if plan is not None or len(module._plans) >= 4:
+            module._plans.clear()  # stale parameters, or more than a few live (positions, mask) variants
+        if pos_h is None and pos is not None:
+            pos_h = pos.detach().to("cpu", torch.float32).reshape(L, -1)
         plan = _TokenPlan(module, B, L, Cin, pos_h, rows, D, emit, x.device)
         module._plans[key] = plan
     return plan

@@ -297,8 +297,7 @@ class Sampler(abc.ABC):
     def _hyper(self) -> tuple:
         r"""Every scalar hyper-parameter of the sampler (start, stop, steps, eta, temperature, order, ...): whatever
         feeds ``_kernel_scalars`` / ``_host_table`` is a plain attribute, so a change of any of them is seen."""
-        simple = (int, float, bool, str, type(None), torch.dtype)
-        return tuple(sorted((k, v) for k, v in vars(self).items() if isinstance(v, simple)))
+        return _attr_key(vars(self))
 
     def _call_fused(self, x: Tensor, kwargs: dict) -> Tensor | None:
         r"""The captured loop is cached per sampler, keyed on everything that is BAKED into it: the latent's shape and
@@ -338,9 +337,37 @@ def module_fingerprint(module: torch.nn.Module) -> tuple:
 def _schedule_key(sched) -> tuple:
     r"""Scalar attributes of a schedule object (alpha_min, sigma_min, gamma, ...) and, for ``nn.Module`` schedules,
     the fingerprint of their tensors."""
-    simple = (int, float, bool, str, type(None))
-    scalars = tuple(sorted((k, v) for k, v in getattr(sched, "__dict__", {}).items() if isinstance(v, simple)))
-    return scalars + (module_fingerprint(sched) if isinstance(sched, torch.nn.Module) else ())
+    return _attr_key(getattr(sched, "__dict__", {})) + (module_fingerprint(sched) if isinstance(sched, torch.nn.Module) else ())
+
+
+def _value_key(v):
+    r"""A hashable stand-in for one attribute value, or ``_SKIP``: numbers / strings / dtypes by value, small tensors by
+    VALUE (eta, temperature, alpha_min held as 0-d or short tensors: the reference re-reads them on every call), larger
+    tensors by (address, version), tuples / lists recursively.  Modules and other objects are not hyper-parameters."""
+    if isinstance(v, (int, float, bool, str, type(None), torch.dtype)):
+        return v
+    if torch.is_tensor(v):
+        if v.numel() <= 16:
+            return ("t", tuple(v.shape), str(v.dtype), tuple(v.detach().reshape(-1).tolist()))
+        return ("T", v.data_ptr(), v._version, tuple(v.shape), str(v.dtype))
+    if isinstance(v, (tuple, list)):
+        items = tuple(_value_key(x) for x in v)
+        return _SKIP if any(x is _SKIP for x in items) else ("seq", items)
+    return _SKIP
+
+
+_SKIP = object()
+
+
+def _attr_key(attrs: dict) -> tuple:
+    out = []
+    for k, v in sorted(attrs.items()):
+        if k.startswith("_fused") or isinstance(v, torch.nn.Module):
+            continue
+        kv = _value_key(v)
+        if kv is not _SKIP:
+            out.append((k, kv))
+    return tuple(out)
 
 
 def _kwargs_signature(kw) -> tuple:
