@@ -207,3 +207,32 @@ def test_transition_clip_propagates_nan():
     assert torch.equal(torch.isnan(mean), torch.isnan(ref))
     ok = ~torch.isnan(ref)
     assert torch.equal(mean[ok], ref[ok])
+
+
+def test_tensor_valued_hyper_parameters_reach_the_table(golden):
+    """eta held as a 0-d TENSOR (and a schedule scalar held as a tensor) changed between two calls of the same sampler: the
+    captured loop must re-upload its coefficient table, like the reference re-reads them."""
+    from azula_amd.sample import DDIMSampler
+
+    g = golden("g6_unet_loop")
+    x1 = g["x1"].cuda()
+    den, _ = _unet_denoiser(g)
+    smp = DDIMSampler(den, steps=6, eta=torch.tensor(0.25), silent=True)
+    torch.manual_seed(3)
+    a = smp(x1)
+    smp.eta = torch.tensor(1.0)
+    torch.manual_seed(3)
+    b = smp(x1)
+    torch.manual_seed(3)
+    fresh = DDIMSampler(den, steps=6, eta=1.0, silent=True)(x1)
+    assert len(smp._fused_cache) == 1 and next(iter(smp._fused_cache.values())).graph is not None
+    assert torch.equal(b, fresh) and not torch.equal(a, b)
+    # a schedule scalar as a tensor attribute
+    den.schedule.alpha_min = torch.tensor(1e-2, dtype=torch.float64)
+    torch.manual_seed(3)
+    c = smp(x1)
+    den2, _ = _unet_denoiser(g)
+    den2.schedule.alpha_min = 1e-2
+    torch.manual_seed(3)
+    fresh2 = DDIMSampler(den2, steps=6, eta=1.0, silent=True)(x1)
+    assert max_err(c, fresh2) < 1e-6 * max(1.0, fresh2.abs().max().item()) and not torch.equal(c, b)
