@@ -237,21 +237,23 @@ def transition_roofline(device):
     for label, kname, a, alg, note in cases:
         for _ in range(3):
             _lib.call("az_transition_f32", C.byref(a), stream.cuda_stream)
-        reps = 10
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(reps):
+        reps = 9  # each launch timed on its own: min / median / max (the image form varies by 10 % from box to box and run to run)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for e0, e1 in evs:
+            e0.record(stream)
             _lib.call("az_transition_f32", C.byref(a), stream.cuda_stream)
-        e1.record(stream)
+            e1.record(stream)
         torch.cuda.synchronize(device)
-        ms = e0.elapsed_time(e1) / reps
+        times = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        ms = times[len(times) // 2]
         gbs = alg / (ms * 1e-3) / 1e9
         # bytes the kernel must move given the backbone's layouts: the NHWC input has a 4-float channel stride, so the
         # second output is 16 B/pixel for 3 channels (the zero pad channel is written too)
         moved = alg + (4 * B * inner * (4 - Cc) if "image" in label else 0)
         out[label] = dict(bound="hbm", kernel=kname, achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                           frac=round(gbs / PEAK_HBM_GBS, 4), avg_us=round(ms * 1e3, 2), elements=n,
-                          algorithmic_bytes=alg, bytes_per_element=alg // n, layout_bytes=moved, traffic=None, note=note)
+                          algorithmic_bytes=alg, bytes_per_element=alg // n, layout_bytes=moved, traffic=None, note=note,
+                          reps=reps, frac_min_median_max=[round(alg / (t * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) for t in (times[-1], ms, times[0])])
     del cases, keep
     torch.cuda.empty_cache()
     return out
