@@ -215,6 +215,7 @@ PROTOTYPES: dict[str, list] = {
     "az_cfg_combine_f32": [vp, vp, vp, vp, i64, c_stream],
     "az_nchw_to_nhwc_f32": [vp, vp, vp, i64, i64, i64, i64, c_stream],
     "az_nhwc_to_nchw_f32": [vp, vp, i64, i64, i64, i64, c_stream],
+    "az_upsample_nearest_f32": [vp, vp, i64, i64, i64, i64, i32, i32, i64, i64, c_stream],
     "az_linear_small_f32": [vp, i64, vp, i64, vp, vp, i64, i64, i64, i32, i32, c_stream],
     "az_gather_rows_f32": [vp, vp, vp, i64, i64, i64, c_stream],
     "az_gather_step_row_f32": [vp, vp, vp, i32, i64, i64, c_stream],

@@ -205,6 +205,27 @@ __global__ __launch_bounds__(256) void winograd4_filter_kernel(float* __restrict
   }
 }
 
+
+// Nearest upsampling by an arbitrary integer factor per axis, cropped to (Hout, Wout) (the reference's
+// Upsample(scale_factor = stride) followed by narrow, azula/nn/unet.py:186,250-252): dst[b, y, x, :] = src[b, y / sh, x / sw, :].
+// Power-of-two factors never come here (they are a right shift inside the merge convolution's gather); this pass exists
+// for the other strides (3, 5, 6 ...).  NHWC, one float4 per thread.
+// The source index is ATen's: min(floor(dst * float(1.0 / scale)), in - 1) in fp32 (upsample_nearest with a given scale factor).
+__global__ __launch_bounds__(256) void upsample_nearest_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t total4,
+                                                               int Hin, int Win, int q, float inv_h, float inv_w, int Hout, int Wout) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % q);
+    int64_t r = i / q;
+    const int x = (int)(r % Wout);
+    r /= Wout;
+    const int y = (int)(r % Hout);
+    const int64_t b = r / Hout;
+    const int ys = min((int)floorf(__fmul_rn((float)y, inv_h)), Hin - 1);
+    const int xs = min((int)floorf(__fmul_rn((float)x, inv_w)), Win - 1);
+    reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[((b * Hin + ys) * Win + xs) * q + c4];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -216,6 +237,19 @@ int az_nchw_to_nhwc_f32(float* dst, const float* src, const float* scale_dev, in
   AZ_REQUIRE(AZ_ALIGNED16(dst), AZ_E_ALIGN);
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(az_stream_grid(B * HW, 256)), dim3(256), 0, az_s(stream), dst, src,
                      scale_dev, B, C, HW, cs);
+  return az_launch_status();
+}
+
+int az_upsample_nearest_f32(float* dst, const float* src, int64_t B, int64_t Hin, int64_t Win, int64_t cs, int32_t sh,
+                            int32_t sw, int64_t Hout, int64_t Wout, az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(B > 0 && Hin > 0 && Win > 0 && cs > 0 && cs % 4 == 0 && sh >= 1 && sw >= 1, AZ_E_SHAPE);
+  AZ_REQUIRE(Hout > 0 && Wout > 0 && (Hout + sh - 1) / sh <= Hin && (Wout + sw - 1) / sw <= Win, AZ_E_SHAPE);
+  AZ_REQUIRE(Hin < (1 << 30) && Win < (1 << 30) && Hout < (1 << 30) && Wout < (1 << 30), AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(dst) && AZ_ALIGNED16(src), AZ_E_ALIGN);
+  const int64_t total4 = B * Hout * Wout * (cs / 4);
+  hipLaunchKernelGGL(upsample_nearest_kernel, dim3(az_stream_grid(total4, 256)), dim3(256), 0, az_s(stream), dst, src, total4,
+                     (int)Hin, (int)Win, (int)(cs / 4), (float)(1.0 / sh), (float)(1.0 / sw), (int)Hout, (int)Wout);
   return az_launch_status();
 }
 

@@ -410,6 +410,13 @@ class Builder:
         self.tape.add(name, C.byref(a), keep=[a] if gate is None else [gate, a])  # the descriptor holds raw addresses
         return out
 
+    def upsample_nearest(self, x: Act, sh: int, sw: int, hout: int, wout: int) -> Act:
+        r"""``narrow(Upsample(scale_factor=(sh, sw), mode="nearest")(x), (hout, wout))`` as a pass of its own -- only for
+        factors that are not powers of two (those are a shift inside the consuming convolution's gather)."""
+        y = self.new_act(x.B, hout, wout, x.C)
+        self.tape.add("az_upsample_nearest_f32", y.ptr, x.ptr, x.B, x.H, x.W, x.cs, sh, sw, hout, wout)
+        return y
+
     def finish(self) -> None:
         r"""Allocates the shared split-K workspace and patches it into the recorded convs."""
         if self._ws_need and (self.workspace is None or self.workspace.numel() < self._ws_need):

@@ -231,7 +231,13 @@ class UNetPlan:
         self.versions = net._param_versions()
         L = len(net.hid_blocks)
         stride = net.stride
-        up = stride.bit_length() - 1 if isinstance(stride, int) else tuple(v.bit_length() - 1 for v in stride)
+        # power-of-two strides (<= 16): the decoder's nearest upsampling is a right shift inside the merge convolution's gather;
+        # any other stride: a nearest-upsampling pass of its own in front of the merge convolution (reference unet.py:186,250-254)
+        sv = (stride, stride) if isinstance(stride, int) else tuple(stride)
+        pow2 = all(v in (1, 2, 4, 8, 16) for v in sv)
+        up = 0
+        if pow2:
+            up = stride.bit_length() - 1 if isinstance(stride, int) else tuple(v.bit_length() - 1 for v in stride)
 
         mod_jobs: list[tuple] = []  # queued modulation MLPs (ada_zero_triple), emitted together at the tape front
         per = net.periodic
@@ -258,6 +264,10 @@ class UNetPlan:
             if i + 1 < L:
                 y = skips[i]
                 conv = mods[0]
+                if not pow2:
+                    wide = bld.upsample_nearest(cur, sv[0], sv[1], y.H, y.W)
+                    bld.free(cur)
+                    cur = wide
                 merged = bld.conv(
                     y, bld.pack_conv(conv.weight, conv.bias, cin0=y.C), conv.out_channels, src1=cur, up1=up,
                     hin=y.H, win=y.W, periodic=per, gn_stats=gn,
@@ -286,7 +296,8 @@ class UNet(nn.Module):
     r"""Modulated U-Net (reference ``azula/nn/unet.py:119-259``), gfx950-native forward.
 
     Arguments are those of ``azula.nn.unet.UNet``: ``spatial`` 1 (one-row images), 2 or 3 (volumes: every 3-D convolution
-    as depth taps of the 2-D kernels, ``unet3d.py``), zero or circular padding, odd kernels, isotropic power-of-two strides.
+    as depth taps of the 2-D kernels, ``unet3d.py``), zero or circular padding, odd kernels, any integer stride per axis (powers of
+    two: the upsampling is folded into the merge convolution; others: ``az_upsample_nearest_f32``; volumes: powers of two only).
     """
 
     def __init__(
@@ -315,9 +326,10 @@ class UNet(nn.Module):
         assert len(kernel_size) == len(stride) == spatial
         if any(k % 2 == 0 for k in kernel_size):
             raise NotImplementedError("odd kernel sizes only (anisotropic allowed)")
-        if any(s_ not in (1, 2, 4, 8, 16) for s_ in stride):
-            raise NotImplementedError(
-                "strides 1, 2, 4, 8, 16 per axis only (the nearest upsampling is a right shift of the merge convolution's gather)")
+        if any(int(s_) != s_ or s_ < 1 for s_ in stride):
+            raise ValueError("integer strides >= 1 only")
+        if spatial == 3 and any(s_ not in (1, 2, 4, 8, 16) for s_ in stride):
+            raise NotImplementedError("volumes: strides 1, 2, 4, 8, 16 per axis only")
         self.in_channels, self.out_channels, self.cond_channels = in_channels, out_channels, cond_channels
         self.hid_channels, self.hid_blocks = tuple(hid_channels), tuple(hid_blocks)
         self.stride = stride[0] if len(set(stride)) == 1 else tuple(stride)  # int (isotropic) or one per axis

@@ -146,6 +146,12 @@ int az_cfg_combine_f32(float* y, const float* pos, const float* neg, const float
  * (NULL = 1).  Pad channels are written as 0.  And back.                                  */
 int az_nchw_to_nhwc_f32(float* dst, const float* src, const float* scale_dev, int64_t B, int64_t C, int64_t HW,
                         int64_t cs, az_stream_t stream);
+/* Nearest upsampling by an arbitrary integer factor per axis, cropped to (Hout, Wout): dst[b, y, x, :] = src[b, y / sh, x / sw, :]
+ * on NHWC activations (channel stride cs).  Replaces torch.nn.Upsample(scale_factor=stride, mode="nearest") + torch.narrow of
+ * azula/nn/unet.py:186,250-252 for strides that are not powers of two (those are folded into the merge convolution). */
+int az_upsample_nearest_f32(float* dst, const float* src, int64_t B, int64_t Hin, int64_t Win, int64_t cs, int32_t sh,
+                            int32_t sw, int64_t Hout, int64_t Wout, az_stream_t stream);
+
 int az_nhwc_to_nchw_f32(float* dst, const float* src, int64_t B, int64_t C, int64_t HW, int64_t cs,
                         az_stream_t stream);
 

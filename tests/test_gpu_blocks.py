@@ -201,6 +201,31 @@ def test_unet_other_strides(golden, name):
     assert y.shape == g[name + "_y"].shape and max_err(y, g[name + "_y"]) < 2e-5 * sc
 
 
+@pytest.mark.parametrize("name", ["s3", "s3_odd", "s5", "s23", "s6_periodic"])
+def test_unet_strides_that_are_not_powers_of_two(golden, name):
+    """stride 3 / 5 / (2, 3) / 6 (azula/nn/unet.py:155-186, 250-254): the stride-s convolution on the direct kernel, the nearest
+    x s upsampling + narrow as az_upsample_nearest_f32 in front of the merge convolution (ATen's fp32 source index)."""
+    from azula_amd.nn import UNet
+
+    g = golden("g18_odd_strides")
+    cfg = dict(g.meta[name + "_cfg"])
+    periodic = cfg.pop("periodic")
+    if isinstance(cfg["stride"], list):
+        cfg["stride"] = tuple(cfg["stride"])
+    net = UNet(**cfg, periodic=periodic)
+    sh = {n: tuple(v) for n, v in g.meta[name + "_shapes"].items()}
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == sh
+    net.load_state_dict(synth.synth_state_dict(sh, 61))
+    x = g[name + "_x"]
+    net = net.cuda().eval()
+    y = net(x.cuda(), g["mod"][: x.shape[0]].cuda())
+    ops = [n for _, _, n in next(iter(net._plans.values())).tape.ops]
+    assert "az_upsample_nearest_f32" in ops
+    sc = max(1.0, g[name + "_y"].abs().max().item())
+    print(name, "max|d|", max_err(y, g[name + "_y"]), "scale", sc)
+    assert y.shape == g[name + "_y"].shape and max_err(y, g[name + "_y"]) < 2e-5 * sc
+
+
 @pytest.mark.parametrize("name", ["v_even", "v_odd", "v_periodic", "v_layer"])
 def test_unet_on_volumes(golden, name):
     """``spatial = 3`` (azula/nn/unet.py:119-259 with Conv3d): every 3-D convolution as depth taps of the 2-D kernels

@@ -253,6 +253,16 @@ def test_g15_strides(golden):
         torch.testing.assert_close(y, g[name + "_y"], **TIGHT)
 
 
+def test_g18_odd_strides(golden):
+    g = golden("g18_odd_strides")
+    for name in ("s3", "s3_odd", "s5", "s23", "s6_periodic"):
+        cfg = g.meta[name + "_cfg"]
+        sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta[name + "_shapes"].items()}, 61)
+        x = g[name + "_x"]
+        y = nets.unet_forward(sd, cfg, x, g["mod"][: x.shape[0]])
+        torch.testing.assert_close(y, g[name + "_y"], **TIGHT)
+
+
 def test_g16_unet3d(golden):
     g = golden("g16_unet3d")
     for name in ("v_even", "v_odd", "v_periodic", "v_layer"):
