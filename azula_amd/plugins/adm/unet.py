@@ -115,7 +115,7 @@ class ADMPlan:
     share the timestep and there are no labels, else the batch size."""
 
     def __init__(self, net: "UNetModel", B: int, H: int, W: int, emb_rows: int, device, x_in: Act | None = None,
-                 coef_ptr: int | None = None) -> None:
+                 coef_ptr: int | None = None, frac: bool = False) -> None:
         bld = self.bld = Builder(device, half=next(net.parameters()).dtype)
         mc, E = net.model_channels, 4 * net.model_channels
         self.versions = net._param_versions()
@@ -135,6 +135,11 @@ class ADMPlan:
             assert emb_rows == 1 or net.num_classes is not None
             bld.tape.add("az_gather_step_row_f32", temb.data_ptr(), self.table.data_ptr(), coef_ptr, 0, mc, net.table_steps)
             trow = 1
+        elif frac:  # fractional timesteps (_src/nn.py:90-108 "these may be fractional"): the sinusoid on the device, no table
+            assert mc % 2 == 0, "odd model_channels with fractional timesteps"
+            self.t_frac = torch.zeros(emb_rows, dtype=torch.float32, device=device)
+            bld.tape.add("az_timestep_embedding_f32", temb.data_ptr(), mc, self.t_frac.data_ptr(), 1, emb_rows, mc // 2, 10000.0)
+            trow = emb_rows
         else:
             bld.tape.add("az_gather_rows_f32", temb.data_ptr(), self.table.data_ptr(), self.t_idx.data_ptr(), emb_rows, mc, net.table_steps)
             trow = emb_rows
@@ -378,18 +383,18 @@ class UNetModel(nn.Module):
     def _param_versions(self) -> tuple:
         return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
 
-    def plan(self, B, H, W, emb_rows, device, x_in: Act | None = None, coef_ptr: int | None = None, tag=None) -> ADMPlan:
-        key = (B, H, W, emb_rows, str(device), x_in.ptr if x_in is not None else None, coef_ptr, tag)
+    def plan(self, B, H, W, emb_rows, device, x_in: Act | None = None, coef_ptr: int | None = None, tag=None, frac=False) -> ADMPlan:
+        key = (B, H, W, emb_rows, str(device), x_in.ptr if x_in is not None else None, coef_ptr, tag, frac)
         p = self._plans.get(key)
         if p is None or p.versions != self._param_versions():
-            p = ADMPlan(self, B, H, W, emb_rows, device, x_in=x_in, coef_ptr=coef_ptr)
+            p = ADMPlan(self, B, H, W, emb_rows, device, x_in=x_in, coef_ptr=coef_ptr, frac=frac)
             self._plans[key] = p
         return p
 
     @torch.no_grad()
     @_lib.on_device
     def forward(self, x: Tensor, timesteps: Tensor, y: Tensor | None = None) -> Tensor:
-        r"""x: (N, C, H, W); timesteps: (N,) or (1,) integer indices; y: (N,) labels iff class-conditional."""
+        r"""x: (N, C, H, W); timesteps: (N,) or (1,) integer indices or fractional values; y: (N,) labels iff class-conditional."""
         assert (y is not None) == (self.num_classes is not None), (
             "must specify y if and only if the model is class-conditional"
         )
@@ -399,13 +404,15 @@ class UNetModel(nn.Module):
         x = x.to(torch.float32).contiguous()
         B, Cin, H, W = x.shape
         timesteps = timesteps.reshape(-1)
-        if torch.is_floating_point(timesteps):
-            raise NotImplementedError("fractional timesteps are not implemented (azula passes integer indices)")
+        frac = torch.is_floating_point(timesteps)  # (azula itself passes integer indices; guided-diffusion allows fractions)
         rows = B if (timesteps.numel() > 1 or self.num_classes is not None) else 1
-        p = self.plan(B, H, W, rows, x.device)
+        p = self.plan(B, H, W, rows, x.device, frac=frac)
         s = _lib.stream_ptr()
         _lib.call("az_nchw_to_nhwc_f32", p.x_in.ptr, x.data_ptr(), None, B, Cin, H * W, p.x_in.cs, s)
-        p.t_idx.copy_(timesteps.to(torch.int64).expand(rows) if timesteps.numel() == 1 else timesteps.to(torch.int64))
+        if frac:
+            p.t_frac.copy_(timesteps.to(torch.float32).expand(rows) if timesteps.numel() == 1 else timesteps.to(torch.float32))
+        else:
+            p.t_idx.copy_(timesteps.to(torch.int64).expand(rows) if timesteps.numel() == 1 else timesteps.to(torch.int64))
         if y is not None:
             assert y.shape == (B,)
             p.labels.copy_(y.to(torch.int64))

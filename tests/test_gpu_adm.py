@@ -132,3 +132,26 @@ def test_adm_options_outside_the_cards(golden, name):
     print(name, "backbone max|d|", err, "scale", sc, "DDIM-8", e2, "scale", g["ddim8"].abs().max().item())
     assert err < 2e-5 * max(1.0, sc)  # measured 2.3e-6 .. 2.6e-6 on scale 2.2 .. 2.7
     assert e2 < 2.5e-4  # measured 2.8e-5 .. 5.0e-5 (means clipped to +-1, c_out = -100 at t = 1)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_adm_fractional_timesteps(golden, name):
+    """UNetModel.forward with FRACTIONAL timesteps (plugins/adm/_src/nn.py:90-108): the sinusoid is evaluated on the device
+    (az_timestep_embedding_f32) instead of gathered from the integer table; per-sample and shared times (G19)."""
+    from azula_amd.plugins import adm
+
+    g = golden("g19_adm_fractional")
+    den = adm.make_model(**g.meta[name + "_cfg"])
+    den.backbone.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta[name + "_shapes"].items()}, 9))
+    net = den.backbone.cuda().eval()
+    y = g[name + "_y"].cuda() if name + "_y" in g else None
+    out = net(g[name + "_x"].cuda(), g[name + "_t"].cuda(), y=y)
+    sc = max(1.0, g[name + "_out"].abs().max().item())
+    e = max_err(out, g[name + "_out"])
+    out1 = net(g[name + "_x"].cuda(), torch.tensor([417.75], device="cuda"), y=y)
+    e1 = max_err(out1, g[name + "_out_shared"])
+    print(name, "fractional timesteps max|d|", e, e1, "scale", sc)
+    assert e < 2e-5 * sc and e1 < 2e-5 * sc
+    # the integer path still takes the table
+    ops = [n for _, _, n in net.plan(2, g[name + "_x"].shape[2], g[name + "_x"].shape[3], 2, torch.device("cuda", 0)).tape.ops]
+    assert "az_timestep_embedding_f32" not in ops

@@ -253,6 +253,16 @@ def test_g15_strides(golden):
         torch.testing.assert_close(y, g[name + "_y"], **TIGHT)
 
 
+def test_g19_adm_fractional_timesteps(golden):
+    g = golden("g19_adm_fractional")
+    for name in ("adm_uncond", "adm_cond_neworder"):
+        cfg = g.meta[name + "_cfg"]
+        sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta[name + "_shapes"].items()}, 9)
+        y = g[name + "_y"] if name + "_y" in g else None
+        torch.testing.assert_close(nets.adm_unet_forward(sd, cfg, g[name + "_x"], g[name + "_t"], y), g[name + "_out"], **TIGHT)
+        torch.testing.assert_close(nets.adm_unet_forward(sd, cfg, g[name + "_x"], torch.tensor([417.75]), y), g[name + "_out_shared"], **TIGHT)
+
+
 def test_g18_odd_strides(golden):
     g = golden("g18_odd_strides")
     for name in ("s3", "s3_odd", "s5", "s23", "s6_periodic"):
