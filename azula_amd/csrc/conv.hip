@@ -26,6 +26,7 @@
 // This file holds two kernels behind the same AzConvArgs: the direct implicit GEMM below (any
 // ksize / stride, linears) and the fused Winograd F(2x2,3x3) kernel further down (3x3 stride 1).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -1486,29 +1487,46 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   // (two xi rows) it owns into a partial 2x2 output; the xi in {2,3} waves hand theirs to their
   // xi in {0,1} partners through LDS (once per workgroup), which add and run the fused epilogue.
   // Lane: tile = wti*32 + l31; couts wco*32 + 8*g + 4*h + (0..3) in registers 4g .. 4g+3.
+  // (Two code versions behind a scalar branch on the wave-uniform frequency half, and explicit register PAIRS: the
+  // compiler had if-converted the two cases into 128 v_cndmask around both results and kept every add scalar -- ~450 vector
+  // instructions per thread where 96 packed ones do; vector instructions are not hidden on this chip, section 7c.)
   float y[4][4][4];  // [g][pixel py*2+px][r]
+  auto out_transform = [&](auto FH) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float s[2][4];
+      for (int k = 0; k < 2; ++k) {
+        f32x2 s[2][4];
 #pragma unroll
-      for (int nu = 0; nu < 4; ++nu) {
-        const float ma = acc[nu][4 * g + r], mb = acc[4 + nu][4 * g + r];  // xi = 2*fh, 2*fh + 1
-        if (fh == 0) {
-          s[0][nu] = ma + mb;  // A^T rows: [1 1 1 0], [0 1 -1 -1]
-          s[1][nu] = mb;
-        } else {
-          s[0][nu] = ma;
-          s[1][nu] = -ma - mb;
+        for (int nu = 0; nu < 4; ++nu) {
+          const f32x2 ma = {acc[nu][4 * g + 2 * k], acc[nu][4 * g + 2 * k + 1]};          // xi = 2*fh
+          const f32x2 mb = {acc[4 + nu][4 * g + 2 * k], acc[4 + nu][4 * g + 2 * k + 1]};  // xi = 2*fh + 1
+          if constexpr (decltype(FH)::value == 0) {
+            s[0][nu] = ma + mb;  // A^T rows: [1 1 1 0], [0 1 -1 -1]
+            s[1][nu] = mb;
+          } else {
+            s[0][nu] = ma;
+            s[1][nu] = -ma - mb;
+          }
+        }
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+          const f32x2 y0 = (s[py][0] + s[py][1]) + s[py][2];
+          const f32x2 y1 = (s[py][1] - s[py][2]) - s[py][3];
+          y[g][py * 2 + 0][2 * k] = y0.x;
+          y[g][py * 2 + 0][2 * k + 1] = y0.y;
+          y[g][py * 2 + 1][2 * k] = y1.x;
+          y[g][py * 2 + 1][2 * k + 1] = y1.y;
         }
       }
-#pragma unroll
-      for (int py = 0; py < 2; ++py) {
-        y[g][py * 2 + 0][r] = (s[py][0] + s[py][1]) + s[py][2];
-        y[g][py * 2 + 1][r] = (s[py][1] - s[py][2]) - s[py][3];
-      }
-    }
+  };
+  if (fh == 0) {
+    asm volatile("" ::: "memory");  // (keeps the two versions apart: no if-conversion)
+    out_transform(std::integral_constant<int, 0>{});
+  } else {
+    asm volatile("" ::: "memory");
+    out_transform(std::integral_constant<int, 1>{});
+  }
   // Both frequency halves park their partial outputs in LDS as [tile][pixel][cout] (tile stride padded by 4 floats:
   // conflict-free ds_write_b128), then ALL 8 waves read rows back so that 16 consecutive lanes store the 256 contiguous
   // bytes of one output pixel (two full 128-byte lines) instead of 32 bytes of 32 different pixels per instruction.
