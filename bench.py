@@ -337,6 +337,8 @@ def cpu_baseline(denoiser, cfg, budget_s=25.0):
         threads_note=f"torch intra-op threads = {threads}: the fastest of a probe over 8..{avail} threads on the dominant op "
                      f"(a 256->256 3x3 conv); the host has {hi['host_cores']} logical cores",
         sample=f"{n} DDIM steps of the same UNet at batch 1 ({s_per_step:.2f} s/step, 1 warm-up), extrapolated x{cfg['steps']} steps",
+        caveat=f"batch 1 on {threads} of {hi['host_cores']} logical cores (the GPU leg runs batch {cfg['batch']}): images/s = 1 / (steps x s per "
+               "step and image); a reported baseline, not a target -- the roofline fraction says what the kernels are worth",
     )
 
 

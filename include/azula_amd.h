@@ -13,8 +13,10 @@
  *   - returns 0 on success, a negative AZ_E_* argument error, or a positive hipError_t;
  *   - never allocates, never synchronises, never throws, keeps no mutable global state,
  *     is re-entrant and hipGraph-capturable (workspace is supplied by the caller);
- *   - all tensors are fp32.  "NHWC" tensors have a channel stride that is a multiple of 4
- *     floats (zero-filled pad channels), so every access is a 16-byte vector.
+ *   - tensors are fp32 unless the entry point's name says otherwise (`_f64`: fp64 latents of a Sampler(dtype=float64);
+ *     `_bf16_f32` / `_f16_f32`: half-precision MFMA operands packed by az_pack_conv_weight_half_f32, fp32 activations and
+ *     accumulation).  "NHWC" tensors have a channel stride that is a multiple of 4 floats (zero-filled pad channels), so
+ *     every access is a 16-byte vector.
  */
 #ifndef AZULA_AMD_H
 #define AZULA_AMD_H
