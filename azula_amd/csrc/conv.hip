@@ -381,17 +381,23 @@ __device__ __forceinline__ void store_acc_tiles_halves(const ConvP& p, const f32
     }
     __syncthreads();
     if (co < a.cout_s) {
-      constexpr int NB = 64 * (BM / 4) / 256;  // 8 outputs per thread
-      int n[NB], b[NB];
-      float4 v[NB];
+      // 8 outputs per thread in two batches of 4: the waves of the second pixel half still hold their 64 accumulator
+      // registers here, and with a batch of 8 (values + gate + residual + indices) the 168-register budget of three
+      // workgroups per CU overflowed into scratch (85 spilled registers in round 2's build)
+      constexpr int NB = 4;
+#pragma unroll 1
+      for (int i0 = 0; i0 < 64 * (BM / 4) / 256; i0 += NB) {
+        int n[NB], b[NB];
+        float4 v[NB];
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int px = (i * 256 + tid) / (BM / 4);
-        b[i] = pimg[px];
-        n[i] = b[i] >= 0 ? n0 + hh * 64 + px : -1;
-        v[i] = *reinterpret_cast<const float4*>(obuf + px * OSTR + cq * 4);
+        for (int i = 0; i < NB; ++i) {
+          const int px = ((i0 + i) * 256 + tid) / (BM / 4);
+          b[i] = pimg[px];
+          n[i] = b[i] >= 0 ? n0 + hh * 64 + px : -1;
+          v[i] = *reinterpret_cast<const float4*>(obuf + px * OSTR + cq * 4);
+        }
+        epilogue_store_batch<NB>(a, n, b, co, v, (int64_t)blockIdx.y * p.npix);
       }
-      epilogue_store_batch<NB>(a, n, b, co, v, (int64_t)blockIdx.y * p.npix);
     }
     __syncthreads();
   }
@@ -2047,8 +2053,10 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
       const int64_t r = n % slots;
       return (double)(n - r) + (r == 0 ? 0.0 : (r == 1 ? 1.0 / 0.65 : (double)r));
     };
-    // measured (C3 token GEMMs): the K-16 instantiation is ~6 % slower per tile, so it must win by more than that
-    k16 = n >= 3 && cost(n, 3) * 1.06 + 0.15 < cost(n, 2);
+    // measured (C3 token GEMMs, round 3): per tile the K-16 instantiation now equals the K-32 one (768 -> 3072: 676 vs 670 us;
+    // its epilogue no longer spills), so it is taken whenever three slots per CU quantise better (768 -> 768: 184 vs 221 us,
+    // 768 -> 2304: 519 vs 548 us)
+    k16 = n >= 3 && cost(n, 3) * 1.01 + 0.05 < cost(n, 2);
     if (force) k16 = force[0] == '1';
   }
   const int bk = half == 3 ? XBK : (half ? HBK : (k16 ? 16 : BK));
