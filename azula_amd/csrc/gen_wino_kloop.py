@@ -379,6 +379,8 @@ def gen_role(role: str) -> list[str]:
     e(f"s_cmp_eq_u32 s{S_CNT}, 0")
     e(f"s_cbranch_scc1 L{role}pen_%=")
     e(".p2align 6")
+    for _ in range(int(os.environ.get("KL_PAD", "0"))):  # A/B: byte phase of the loop body inside its 64-byte line
+        e("s_nop 0")
     e(f"L{role}steady_%=:")
     body(st, extras(True, True, "s"), "s", PRIO_HEAD[role])
     e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
