@@ -3,7 +3,7 @@ r"""Generates ``wino_kloop.inc``: the K loop of ``conv_winograd_kernel`` as two 
 
 Why: the C++ loop is [loads][32 MFMAs][transform + LDS stores][barrier]: after every barrier the matrix pipe idles for the
 fragment-read latency, both waves of a SIMD then leave the MFMA phase together and stage with an idle pipe
-(5.6 k cycles per 8-channel stage against 4.1 k of MFMA issue).  ``profiles/r03_mfma_overlap.txt`` shows what
+(5.6 k cycles per 8-channel stage against 4.1 k of MFMA issue).  ``profiles/r03_mfma_valu_overlap.txt`` shows what
 may sit beside ``v_mfma_f32_32x32x2_f32`` for free (<= 4 ds_read_b128, <= 2 ds_write_b64, 1 buffer load, any SALU per
 64-cycle MFMA) and what may not (every VALU instruction costs its own issue time).  So the stream here is software
 pipelined across the barrier:
@@ -12,11 +12,12 @@ pipelined across the barrier:
                    R(t)[0], R(t)[1]                            fragment reads of frequency groups 0, 1
                    M(t-1)[6], M(t-1)[7]                        8 MFMAs whose fragments were read BEFORE the barrier
                    M(t)[0..5] with R(t)[2..7] two groups ahead
-                   beside the first 14 MFMAs: S(t+1) (wait for L(t+1), input transform, LDS stores into the other
+                   beside the first 18 MFMAs: S(t+1) (wait for L(t+1), input transform, LDS stores into the other
                    buffer) and L(t+2) (global loads, one stage of latency cover), one memory instruction per MFMA gap
 
 The matrix pipe therefore always has MFMAs queued when a wave reaches the barrier and right after it.  Register use is
-fixed (v160..v255, s92..s99: declared as clobbers); accumulators and the few scalar inputs are asm operands.
+fixed (v160..v255, s91..s99: declared as clobbers); accumulators and the few scalar inputs are asm operands.
+Environment overrides KL_* (ablations, scalar adds, LDS-DMA filter path, padding) exist for tools/kloop_variant.py A/B builds only.
 
     python azula_amd/csrc/gen_wino_kloop.py        # rewrites wino_kloop.inc next to this file
 """
