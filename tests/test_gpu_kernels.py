@@ -434,6 +434,56 @@ def test_conv2d_random_shapes(az, wino):
         assert err < conv_tol(C0 + C1, 3, wino) * max(1.0, ref.abs().max().item()), (case, B, H, W, C0, C1, Cout, act, err)
 
 
+def test_winograd_stream_fuzz(az):
+    """The hand-scheduled K loop (wino_kloop.inc) over 40 seeded cases that move every event of the stream around: 1 .. 24
+    eight-channel stages (first / steady / second-to-last / last iteration bodies), two sources whose switch falls on any
+    stage, half chunks at the end of either source, split-K slices that start in either source, nearest-x2 upsampling of the
+    second source, zero and circular padding, ragged tile blocks."""
+    import random
+
+    from azula_amd.engine import Act, Builder
+
+    rnd = random.Random(2025)
+    g = torch.Generator().manual_seed(2025)
+    for case in range(40):
+        B = rnd.randint(1, 2)
+        H, W = rnd.randint(4, 24), rnd.randint(4, 24)
+        C0 = rnd.choice([4, 8, 12, 20, 36, 60, 64, 100, 132])
+        two = rnd.random() < 0.5
+        C1 = rnd.choice([4, 8, 12, 28, 64, 68]) if two else 0
+        Cout = rnd.choice([8, 24, 64, 72, 130])
+        periodic = rnd.random() < 0.3
+        up = two and rnd.random() < 0.5 and not periodic
+        splitk = rnd.choice([0, 0, 2, 3, 5])
+        x0 = torch.randn(B, C0, H, W, generator=g)
+        w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / math.sqrt(9 * (C0 + C1))
+        b = torch.randn(Cout, generator=g)
+        src = x0
+        bld = Builder(torch.device("cuda"))
+        a0 = Act(to_nhwc(dev(x0)).reshape(-1), B, H, W, C0, (C0 + 3) // 4 * 4, True)
+        kw = {}
+        if two:
+            h1, w1 = ((H + 1) // 2, (W + 1) // 2) if up else (H, W)
+            x1 = torch.randn(B, C1, h1, w1, generator=g)
+            full = F.interpolate(x1, scale_factor=(2.0, 2.0), mode="nearest")[:, :, :H, :W] if up else x1
+            src = torch.cat((x0, full), 1)
+            a1 = Act(to_nhwc(dev(x1)).reshape(-1), B, h1, w1, C1, (C1 + 3) // 4 * 4, True)
+            kw = dict(src1=a1, up1=1 if up else 0, hin=H, win=W)
+        ref = F.conv2d(F.pad(src, (1, 1, 1, 1), mode="circular"), w, b) if periodic else F.conv2d(src, w, b, padding=1)
+        y = bld.conv(a0, bld.pack_conv(dev(w), dev(b), cin0=C0), Cout, winograd=True, periodic=periodic, **kw)
+        assert bld.tape.ops[-1][2] == "az_conv2d_winograd_f32"
+        if splitk:
+            a = bld.tape.keep[-1]
+            a.splitk = splitk
+            bld._ws_need = max(bld._ws_need, splitk * B * H * W * y.cs)
+            bld._ws_users.append(a)
+        bld.finish()
+        bld.tape.run()
+        out = from_nhwc(y.buf.reshape(B, H, W, y.cs), Cout)
+        err = max_err(out, ref)
+        assert err < conv_tol(C0 + C1, 3, True) * max(1.0, ref.abs().max().item()), (case, B, H, W, C0, C1, Cout, periodic, up, splitk, err)
+
+
 @pytest.mark.parametrize("wino", [False, True, 4, "x3"])
 def test_conv2d_concat_upsample_narrow_gate_res(az, wino):
     """cat((y, upsample(x)[narrowed])) -> conv -> x0 + c * silu-free epilogue, as azula/nn/unet.py:253-257,93."""
