@@ -69,9 +69,12 @@ def _stale(target: str, deps: list[str]) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(HERE, "common.h"), os.path.join(ROOT, "include", "azula_amd.h"), os.path.join(HERE, "wino_kloop.inc")]
-    gen = os.path.join(HERE, "gen_wino_kloop.py")  # the Winograd K loop's instruction stream (committed; regenerated when stale)
-    if _stale(headers[-1], [gen]):
-        subprocess.run([sys.executable, gen], check=True, stdout=subprocess.DEVNULL)
+    headers.append(os.path.join(HERE, "igemm_kloop.inc"))
+    # the hand-scheduled K loops (committed; regenerated when their generators are newer)
+    for inc, gens in ((headers[-2], ["gen_wino_kloop.py"]), (headers[-1], ["gen_igemm_kloop.py", "gen_wino_kloop.py"])):
+        paths = [os.path.join(HERE, g) for g in gens]
+        if _stale(inc, paths):
+            subprocess.run([sys.executable, paths[0]], check=True, stdout=subprocess.DEVNULL)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     objs = []
     for s in srcs:

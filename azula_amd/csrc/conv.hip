@@ -38,6 +38,7 @@ constexpr int BK = 32;    // k tile (input channels of one tap)
 constexpr int LDSS = 36;  // padded LDS row stride in floats (144 B, 16-B aligned)
 constexpr int TILE_F = (BM + BN) * LDSS;
 
+#include "igemm_kloop.inc"
 struct ConvP {
   AzConvArgs a;
   int npix;     // batch * hout * wout
@@ -48,6 +49,7 @@ struct ConvP {
   int kps;      // K-tiles per split
   int tiles_m;  // ceil(cout_s / BM)
   int tiles_n;  // ceil(npix / BN)
+  int asm_loop; // fp32 K-32 kernel: one tap, whole K tiles -> the hand-scheduled K loop (igemm_kloop.inc)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -553,6 +555,52 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
 
   const int frag_off = (lane & 31) * LS + (lane >> 5) * 4;
 
+  bool done = false;
+  if constexpr (KT == 32) {
+    // ONE tap, whole 32-channel K tiles (1 x 1 convolutions / token linears): the K loop as the hand-scheduled stream of
+    // igemm_kloop.inc (gen_igemm_kloop.py) -- the same stage layout, loader coordinates and fragments as the C++ loop below
+    if (p.asm_loop && kt_begin < kt_end) {
+      typedef __attribute__((address_space(3))) float lds_float;
+      const unsigned lds0 = (unsigned)(uintptr_t)(lds_float*)smem;
+      const unsigned fa = lds0 + (unsigned)((wc * 64) * LS + frag_off) * 4u;
+      const unsigned fb = lds0 + (unsigned)(BM * LS + (wp * 64) * LS + frag_off) * 4u;
+      const unsigned stA = lds0 + (unsigned)(r0 * LS + cc * 4) * 4u;
+      const unsigned dA = fa ^ (fa + TF * 4), dB = fb ^ (fb + TF * 4), dS = stA ^ (stA + TF * 4);
+      const bool start1 = kt_begin >= p.nkc0;
+      const int kt_switch = (!start1 && kt_end > p.nkc0) ? p.nkc0 : 0x7fffffff;
+      unsigned vA0[NP], vA1[NP];
+      it_tap = 0;
+      it_src = start1 ? 1 : 0;
+      set_tap_src();
+#pragma unroll
+      for (int i = 0; i < NP; ++i) vA0[i] = voffA[i];
+      it_src = 1;
+      if (kt_switch != 0x7fffffff) set_tap_src();
+#pragma unroll
+      for (int i = 0; i < NP; ++i) vA1[i] = voffA[i];
+      const uint64_t bw = (uint64_t)(uintptr_t)a.weight;
+      const uint64_t b0 = (uint64_t)(uintptr_t)(a.src0 + b_first * s0_elems);
+      const uint64_t b1 = (uint64_t)(uintptr_t)(a.src1 ? a.src1 + b_first * s1_elems : a.src0);
+      const unsigned nw_ = clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s);
+      const unsigned n0_ = clamp_bytes((a.batch - b_first) * s0_elems), n1_ = a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u;
+      unsigned f0 = (unsigned)b0, f1 = (unsigned)(b0 >> 32) & 0xffffu, f2 = n0_;
+      const unsigned g0 = (unsigned)b1, g1 = (unsigned)(b1 >> 32) & 0xffffu, g2 = n1_;
+      if (start1) f0 = g0, f1 = g1, f2 = g2;
+      const unsigned dflags = 0x00020000u;
+      const int nst = kt_end - kt_begin;
+      const unsigned soffW0 = (unsigned)kt_begin * (KT * 4), soffA0 = (unsigned)(start1 ? kt_begin - p.nkc0 : kt_begin) * (KT * 4);
+      asm volatile(IGEMM_KLOOP_ASM
+                   : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
+                   : "v"(fa), "v"(fb), "v"(stA), "v"(dA), "v"(dB), "v"(dS), "v"(voffW[0]), "v"(voffW[1]), "v"(voffW[2]), "v"(voffW[3]),
+                     "v"(vA0[0]), "v"(vA0[1]), "v"(vA0[2]), "v"(vA0[3]), "v"(vA1[0]), "v"(vA1[1]), "v"(vA1[2]), "v"(vA1[3]),
+                     "s"((unsigned)bw), "s"((unsigned)(bw >> 32) & 0xffffu), "s"(nw_), "s"(dflags), "s"(f0), "s"(f1), "s"(f2), "s"(dflags),
+                     "s"(g0), "s"(g1), "s"(g2), "s"(dflags), "s"(nst), "s"(kt_begin), "s"(kt_switch), "s"(soffW0), "s"(soffA0)
+                   : IGEMM_KLOOP_CLOBBERS);
+      done = true;
+    }
+  }
+
+  if (!done) {
   if (kt_begin < kt_end) {
     set_tap_src();
     load_tile();
@@ -565,7 +613,9 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
     const bool more = kt + 1 < kt_end;
     if (more) {
       advance();
+#ifndef AZ_ABL_IGEMM_NOLOAD
       load_tile();  // global loads in flight under the MFMAs below
+#endif
     }
 
     const float* As = smem + buf * TF + (wc * 64) * LS + frag_off;
@@ -588,12 +638,20 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
       }
     }
+#ifndef AZ_ABL_IGEMM_NOSTORE
     if (more) store_tile(buf ^ 1);
     __syncthreads();
+#endif
+  }
   }
 
-  if constexpr (KT == 32) store_acc_tiles(p, acc, m0, n0, wc, wp, lane, smem);
-  else store_acc_tiles_halves(p, acc, m0, n0, wc, wp, lane, smem);
+  // (thread coordinates of the epilogue from an opaque copy of the thread index: nothing derived from it has to survive the
+  // asm statement, whose clobbers leave the compiler v0..v151)
+  int te = threadIdx.x;
+  asm volatile("" : "+v"(te));
+  const int lane_e = te & 63, wc_e = te >> 7, wp_e = (te >> 6) & 1;
+  if constexpr (KT == 32) store_acc_tiles(p, acc, m0, n0, wc_e, wp_e, lane_e, smem);
+  else store_acc_tiles_halves(p, acc, m0, n0, wc_e, wp_e, lane_e, smem);
 }
 
 // =================================================================================================
@@ -2057,7 +2115,16 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     // its epilogue no longer spills), so it is taken whenever three slots per CU quantise better (768 -> 768: 184 vs 221 us,
     // 768 -> 2304: 519 vs 548 us)
     k16 = n >= 3 && cost(n, 3) * 1.01 + 0.05 < cost(n, 2);
+    // one tap, whole 32-channel K tiles: the K-32 kernel runs its hand-scheduled K loop (igemm_kloop.inc), which keeps the
+    // matrix pipe busy from ONE workgroup per CU as well -- it beats the K-16 instantiation on the badly quantised shapes too
+    // (768 -> 768: 178 vs 184 us, 768 -> 2304: 492 vs 519 us).  AZ_IGEMM_ASM=0: the C++ K loop everywhere (A/B measurements)
+    const char* asm_env = getenv("AZ_IGEMM_ASM");
+    const bool asm_ok = a->ksize == 1 && a->c0s % BK == 0 && a->c1s % BK == 0 && !(asm_env && asm_env[0] == '0');
+    if (asm_ok) k16 = false;
     if (force) k16 = force[0] == '1';
+    p.asm_loop = asm_ok && !k16;
+  } else {
+    p.asm_loop = 0;
   }
   const int bk = half == 3 ? XBK : (half ? HBK : (k16 ? 16 : BK));
   p.nkc0 = (a->c0s + bk - 1) / bk;

@@ -1,0 +1,225 @@
+r"""Generates ``igemm_kloop.inc``: the K loop of ``conv_igemm_kernel<32>`` for its simplest and most frequent case -- ONE
+tap (1 x 1 convolutions, ``nn.Linear`` on tokens, ``Conv1d(k=1)``), one or two sources, channel counts that are multiples of
+the 32-channel K tile -- as a hand-scheduled gfx950 instruction stream (the Winograd kernel's recipe, gen_wino_kloop.py).
+
+Why: ablations of the C++ loop on the 16384 x 768 -> 3072 token GEMM (round 3): shipped 670 us; without the LDS stores and the
+barrier 555 us (+20 %); without the global loads 635 us.  The stall structure [loads][64 MFMAs][wait, stores][barrier][fragment
+latency] costs a sixth of the kernel even with two independent workgroups per CU.  The stream:
+
+    iteration t:   s_barrier                         S(t) visible; every R(t-1) done
+                   R(t)[0], R(t)[1]                  fragments of k-groups 0, 1 (4 ds_read_b128 each: a0, a1, b0, b1)
+                   M(t-1)[3]                         16 MFMAs whose fragments were read BEFORE the barrier
+                   M(t)[0..2]                        with R(t)[2], R(t)[3] issued one group (16 MFMAs) ahead
+                   beside the first 9 MFMAs:         S(t+1): s_waitcnt for L(t+1), 8 ds_write_b128 into the other stage;
+                                                     L(t+2): 8 buffer_load_dwordx4 (4 filter rows, 4 pixel rows per thread)
+
+Registers: v152..v254 (4 fragment sets of 16, 8 staging quads, 4 pixel-row offsets, 3 LDS addresses) and s84..s97, declared as clobbers; the four
+accumulators, the 8 (+ 4 for a second source) per-lane row offsets, the buffer descriptors' words and a few scalars are asm
+operands.  The address arithmetic in front of the loop and the fused epilogue stay C++ (conv.hip).
+
+    python azula_amd/csrc/gen_igemm_kloop.py        # rewrites igemm_kloop.inc next to this file
+"""
+from __future__ import annotations
+
+import os
+
+from gen_wino_kloop import Stream, as_macro, quad  # the lgkmcnt bookkeeping and the macro writer are shared
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+TB = 152           # fragment sets: TB + 16 s + {0: a0, 4: a1, 8: b0, 12: b1}   (v152..v215)
+RV = 216           # 8 staging quads: filter rows 0..3, pixel rows 0..3           (v216..v247)
+VOA = 248          # the 4 pixel-row offsets in use (first source: copied from the operands; replaced at the source switch)
+V_FA, V_FB, V_ST = 252, 253, 254
+S_RW, S_RS = 84, 88
+S_SOFFW, S_SOFFA, S_CNT, S_FIRST, S_KT, S_TMP = 92, 93, 94, 95, 96, 97
+LS = 36            # floats per LDS row (conv.hip: KT + 4)
+ROW32 = 32 * LS * 4          # bytes between a thread's loader rows (r0 + 32 i)
+B_OFF = 128 * LS * 4         # the pixel tile sits behind the 128 filter rows
+
+# operands
+OPS = dict(acc=0, fragA=4, fragB=5, st=6, dA=7, dB=8, dS=9, voffW=10, voffA=14, voffA1=18, rw=22, rs0=26, rs1=30, n=34, kt0=35,
+           kt_switch=36, soffW0=37, soffA0=38)
+
+
+def frag(s, which, j=None):
+    base = TB + 16 * s + 4 * which
+    return f"v[{base}:{base + 3}]" if j is None else f"v{base + j}"
+
+
+class GStream(Stream):
+    def read_set(self, s: int, kk: int):
+        off = kk * 32  # 8 floats per k-group
+        self.lds(f"ds_read_b128 {frag(s, 0)}, v{V_FA} offset:{off}")
+        self.lds(f"ds_read_b128 {frag(s, 1)}, v{V_FA} offset:{off + 32 * LS * 4}")
+        self.lds(f"ds_read_b128 {frag(s, 2)}, v{V_FB} offset:{off}")
+        self.lds(f"ds_read_b128 {frag(s, 3)}, v{V_FB} offset:{off + 32 * LS * 4}")
+        self.set_done_at[s] = self.lds_seq
+
+    def group(self, s: int, extras: dict, k0: int, skip_tag: str | None = None):
+        r"""16 MFMAs of one k-group: 4 k-steps x (acc00, acc01, acc10, acc11)."""
+        k = k0
+        for ss in range(4):
+            for a_i, b_i, acc in ((0, 2, 0), (0, 3, 1), (1, 2, 2), (1, 3, 3)):
+                if skip_tag is not None:
+                    self.emit(f"s_cmp_lg_u32 s{S_FIRST}, 0")
+                    self.emit(f"s_cbranch_scc1 LGsk{skip_tag}{k}_%=")
+                self.emit(f"v_mfma_f32_32x32x2_f32 %{acc}, {frag(s, a_i, ss)}, {frag(s, b_i, ss)}, %{acc}")
+                if skip_tag is not None:
+                    self.emit(f"LGsk{skip_tag}{k}_%=:")
+                for kind, text in extras.get(k, []):
+                    if kind == "lds":
+                        self.lds(text)
+                    else:
+                        self.emit(text)
+                k += 1
+
+
+def load(i: int, rv0: int, second: bool = False):
+    o = OPS
+    if i < 4:
+        return f"buffer_load_dwordx4 {quad(rv0 + 4 * i)}, %{o['voffW'] + i}, s[{S_RW}:{S_RW + 3}], s{S_SOFFW} offen"
+    return f"buffer_load_dwordx4 {quad(rv0 + 4 * i)}, v{VOA + i - 4}, s[{S_RS}:{S_RS + 3}], s{S_SOFFA} offen"
+
+
+
+def store(i: int, rv0: int):
+    off = (i % 4) * ROW32 + (B_OFF if i >= 4 else 0)
+    return f"ds_write_b128 v{V_ST}, {quad(rv0 + 4 * i)} offset:{off}"
+
+
+def switch_event(tag: str):
+    r"""In front of the pixel-row loads of stage s_kt: the second source starts (descriptor, row offsets, channel offset 0)."""
+    o = OPS
+    L = [("salu", f"s_cmp_eq_u32 s{S_KT}, %{o['kt_switch']}"), ("salu", f"s_cbranch_scc0 LGns{tag}_%=")]
+    for w in range(4):
+        L.append(("salu", f"s_mov_b32 s{S_RS + w}, %{o['rs1'] + w}"))
+    L.append(("salu", f"s_mov_b32 s{S_SOFFA}, 0"))
+    for i in range(4):
+        L.append(("valu", f"v_mov_b32 v{VOA + i}, %{o['voffA1'] + i}"))
+    L.append(("label", f"LGns{tag}_%=:"))
+    return L
+
+
+def load_done():
+    return [("salu", f"s_add_u32 s{S_SOFFW}, s{S_SOFFW}, 128"), ("salu", f"s_add_u32 s{S_SOFFA}, s{S_SOFFA}, 128"),
+            ("salu", f"s_add_u32 s{S_KT}, s{S_KT}, 1")]
+
+
+def extras(S: bool, L: bool, tag: str):
+    ex = {k: [] for k in range(64)}
+    if S:
+        ex[0].append(("wait", "s_waitcnt vmcnt(0)"))
+        for i in range(8):
+            ex[i].append(("lds", store(i, RV)))
+        ex[8].append(("valu", f"v_xor_b32 v{V_ST}, v{V_ST}, %{OPS['dS']}"))
+    if L:
+        for i in range(8):
+            if i == 4:
+                ex[1 + i] += switch_event(tag)
+            ex[1 + i].append(("vmem", load(i, RV)))
+        ex[9] += load_done()
+    return ex
+
+
+def body(st: GStream, ex: dict, tag: str):
+    st.drain()
+    st.emit("s_barrier")
+    st.read_set(0, 0)
+    st.read_set(1, 1)
+    st.group(3, ex, 0, skip_tag=tag)       # carried: the previous stage's last k-group (none in the first iteration)
+    st.read_set(2, 2)
+    st.need_set(0)
+    st.group(0, ex, 16)
+    st.read_set(3, 3)
+    st.need_set(1)
+    st.group(1, ex, 32)
+    st.need_set(2)
+    st.group(2, ex, 48)
+    st.emit(f"v_xor_b32 v{V_FA}, v{V_FA}, %{OPS['dA']}")
+    st.emit(f"v_xor_b32 v{V_FB}, v{V_FB}, %{OPS['dB']}")
+    st.emit(f"s_mov_b32 s{S_FIRST}, 0")
+
+
+def gen() -> list[str]:
+    o = OPS
+    st = GStream()
+    e = st.emit
+    P0 = TB  # the prologue's first stage lands in fragment sets 0, 1 (8 quads), the second in RV: both latencies overlap
+    e(f"v_mov_b32 v{V_FA}, %{o['fragA']}")
+    e(f"v_mov_b32 v{V_FB}, %{o['fragB']}")
+    e(f"v_mov_b32 v{V_ST}, %{o['st']}")
+    for i in range(4):
+        e(f"v_mov_b32 v{VOA + i}, %{o['voffA'] + i}")
+    for w in range(4):
+        e(f"s_mov_b32 s{S_RW + w}, %{o['rw'] + w}")
+        e(f"s_mov_b32 s{S_RS + w}, %{o['rs0'] + w}")
+    e(f"s_mov_b32 s{S_SOFFW}, %{o['soffW0']}")
+    e(f"s_mov_b32 s{S_SOFFA}, %{o['soffA0']}")
+    e(f"s_mov_b32 s{S_KT}, %{o['kt0']}")
+    e(f"s_mov_b32 s{S_FIRST}, 1")
+    e(f"s_mov_b32 s{S_CNT}, %{o['n']}")
+
+    def loads(rv0, tag):
+        for i in range(8):
+            if i == 4:
+                for kind, t in switch_event(tag):
+                    e(t)
+            e(load(i, rv0))
+        for kind, t in load_done():
+            e(t)
+
+    loads(P0, "p0")
+    e(f"s_cmp_lt_u32 s{S_CNT}, 2")
+    e("s_cbranch_scc1 LGone_%=")
+    loads(RV, "p1")
+    e("s_waitcnt vmcnt(8)")
+    e("s_branch LGst0_%=")
+    e("LGone_%=:")
+    e("s_waitcnt vmcnt(0)")
+    e("LGst0_%=:")
+    for i in range(8):
+        e(store(i, P0))
+    e(f"v_xor_b32 v{V_ST}, v{V_ST}, %{o['dS']}")
+    e(f"s_cmp_lt_u32 s{S_CNT}, 2")
+    e("s_cbranch_scc1 LGlast_%=")
+    e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 2")
+    e(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    e("s_cbranch_scc1 LGpen_%=")
+    e(".p2align 6")
+    e("LGsteady_%=:")
+    body(st, extras(True, True, "s"), "s")
+    e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    e(f"s_cmp_lg_u32 s{S_CNT}, 0")
+    e("s_cbranch_scc1 LGsteady_%=")
+    e("LGpen_%=:")
+    body(st, extras(True, False, "q"), "q")
+    e("LGlast_%=:")
+    body(st, extras(False, False, "r"), "r")
+    # the last stage's k-group 3; every wave's fragment reads are complete behind this barrier (the epilogue reuses the stages)
+    st.drain()
+    e("s_barrier")
+    st.group(3, {}, 0)
+    e("s_nop 15")
+    e("s_nop 7")
+    return st.lines
+
+
+def clobbers() -> str:
+    regs = [f'"v{i}"' for i in range(TB, 256)] + [f'"s{i}"' for i in range(S_RW, S_TMP + 1)] + ['"vcc"', '"scc"', '"memory"']
+    return "#define IGEMM_KLOOP_CLOBBERS " + ", ".join(regs) + "\n"
+
+
+def generate() -> str:
+    src = "// generated by gen_igemm_kloop.py -- do not edit.  Operand numbering: OPS in the generator, the asm statement in conv.hip.\n"
+    src += as_macro("IGEMM_KLOOP_ASM", gen())
+    src += clobbers()
+    return src
+
+
+if __name__ == "__main__":
+    path = os.path.join(HERE, "igemm_kloop.inc")
+    text = generate()
+    with open(path, "w") as f:
+        f.write(text)
+    print(path, len(text.splitlines()), "lines")

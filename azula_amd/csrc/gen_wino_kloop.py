@@ -30,7 +30,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 TB = 160
 RV0, VO0, X0, Y0 = 192, 224, 240, 248
 V_FA, V_FB, V_ST, V_OOB = 252, 253, 254, 255
-S_RS, S_SOFF, S_KT, S_CNT, S_TMP, S_FIRST = 92, 96, 97, 98, 99, 100
+S_FIRST, S_RS, S_SOFF, S_KT, S_CNT, S_TMP = 91, 92, 96, 97, 98, 99  # (s100 / s101 are reserved on this target)
 GROUP_BYTES = 2048  # one frequency of a stage: 64 rows x 8 floats x 4 B
 BUF_XOR = 0x10000   # the two 64 KB stages
 
@@ -414,7 +414,7 @@ def as_macro(name: str, lines: list[str]) -> str:
 
 
 def clobbers() -> str:
-    regs = ['"m0"'] + [f'"v{i}"' for i in range(TB, 256)] + [f'"s{i}"' for i in range(S_RS, S_FIRST + 1)] + ['"vcc"', '"scc"', '"memory"']
+    regs = (['"m0"'] if UDMA else []) + [f'"v{i}"' for i in range(TB, 256)] + [f'"s{i}"' for i in range(S_FIRST, S_TMP + 1)] + ['"vcc"', '"scc"', '"memory"']
     return "#define WINO_KLOOP_CLOBBERS " + ", ".join(regs) + "\n"
 
 
