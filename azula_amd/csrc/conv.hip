@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
     const bool more = kt + 1 < kt_end;
     if (more) {
       advance();
-#ifndef AZ_ABL_IGEMM_NOLOAD
+#ifndef AZ_ABL_IGEMM_NOLOAD  // (timing ablations of this loop, tools/ab_build.py -DAZ_ABL_IGEMM_*: wrong results)
       load_tile();  // global loads in flight under the MFMAs below
 #endif
     }
