@@ -119,6 +119,13 @@ __device__ __forceinline__ float4 epilogue_apply_store(const AzConvArgs& a, int 
     v.z += bv.z;
     v.w += bv.w;
   }
+  if (a.act == 4) {
+    // SwiGLU over interleaved channel pairs, y[c] = x[2c] * silu(x[2c+1]) (azula/nn/layers.py:107-110; JiT's SwiGLUFFN with
+    // its w12 rows interleaved at build time): the output has HALF the channels (row stride cout_s / 2; the host admits no
+    // gate / residual / planar destination here) -- the separate az_swiglu_f32 pass and its 12 B per pair are gone
+    *reinterpret_cast<float2*>(a.dst + (int64_t)n * (a.cout_s / 2) + co / 2) = make_float2(v.x * az_silu(v.y), v.z * az_silu(v.w));
+    return v;
+  }
   if (a.act == 1) {
     v.x = az_silu(v.x);
     v.y = az_silu(v.y);
@@ -211,6 +218,11 @@ __device__ __forceinline__ void epilogue_batch_nhwc(const AzConvArgs& a, const i
       f.z = az_silu(f.z);
       f.w = az_silu(f.w);
     }
+    if constexpr (ACT == 4) {  // SwiGLU over interleaved pairs: half the channels (see epilogue_apply_store)
+      if (n[i] >= 0)
+        *reinterpret_cast<float2*>(a.dst + (int64_t)n[i] * (a.cout_s / 2) + co / 2) = make_float2(f.x * az_silu(f.y), f.z * az_silu(f.w));
+      continue;
+    }
     if constexpr (GATE) {
       f.x *= g[i].x;
       f.y *= g[i].y;
@@ -244,6 +256,7 @@ __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const 
       if (n[i] >= 0) *reinterpret_cast<float4*>(a.workspace + (ws_slab + n[i]) * a.cout_s + co) = v[i];
     return;
   }
+  if (a.act == 4) return epilogue_batch_nhwc<NB, false, 4, false, 0>(a, n, b, co, v, mom);
   if (!a.dst_nchw && a.act <= 1) {
     const int rk = a.res == nullptr ? 0 : (a.res_up || a.res_bcast) ? 2 : 1;
     switch ((a.act * 2 + (a.gate != nullptr ? 1 : 0)) * 3 + rk) {
@@ -2070,6 +2083,8 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout > 0 && a->wout > 0, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
+  AZ_REQUIRE(a->act >= 0 && a->act <= 4, AZ_E_UNSUPPORTED);
+  if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
   AZ_REQUIRE(a->ksize >= 1 && a->ksize <= 7 && a->stride >= 1 && a->pad >= 0 && (!a->aniso || a->stride_w >= 1), AZ_E_SHAPE);
   AZ_REQUIRE((a->hin + 2 * a->pad - a->ksize) / a->stride + 1 == a->hout &&
                  (a->win + 2 * a->pad - a->ksize) / (a->aniso ? a->stride_w : a->stride) + 1 == a->wout,
@@ -2191,6 +2206,8 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
+  AZ_REQUIRE(a->act >= 0 && a->act <= 4, AZ_E_UNSUPPORTED);
+  if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
   AZ_REQUIRE(!a->aniso || (a->up0_w >= 0 && a->up0_w <= 4 && a->up1_w >= 0 && a->up1_w <= 4), AZ_E_SHAPE);  // (shift amounts)
   AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
                  ((a->win + (1 << az_upw(a, a->up0, a->up0_w)) - 1) >> az_upw(a, a->up0, a->up0_w)) <= a->w0,
@@ -2292,6 +2309,8 @@ int az_conv2d_winograd4_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
+  AZ_REQUIRE(a->act >= 0 && a->act <= 4, AZ_E_UNSUPPORTED);
+  if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
   AZ_REQUIRE(!a->aniso || (a->up0_w >= 0 && a->up0_w <= 4 && a->up1_w >= 0 && a->up1_w <= 4), AZ_E_SHAPE);  // (shift amounts)
   AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
                  ((a->win + (1 << az_upw(a, a->up0, a->up0_w)) - 1) >> az_upw(a, a->up0, a->up0_w)) <= a->w0,

@@ -344,7 +344,11 @@ class Builder:
             a.dst, a.dst_nchw, a.dst_c = dst_nchw.data_ptr(), 1, cout
         else:
             if out is None:
-                out = self.new_act(B, hout, wout, cout)
+                if act == 4:  # SwiGLU epilogue: half the channels come out (y[c] = x[2c] * silu(x[2c+1]))
+                    assert cout % 8 == 0 and gate is None and res is None, "SwiGLU epilogue: cout % 8 == 0, no gate / residual"
+                    out = self.new_act(B, hout, wout, cout // 2)
+                else:
+                    out = self.new_act(B, hout, wout, cout)
             else:  # caller-owned destination (a plane range of a volume; may alias `res`: in-place accumulation)
                 assert (out.B, out.H, out.W, out.C, out.cs) == (B, hout, wout, cout, pad4(cout)), "destination shape"
             a.dst = out.ptr

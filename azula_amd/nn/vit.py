@@ -209,9 +209,10 @@ class DiTBlock(nn.Module):
         bld.free(y)
         f0, f3 = self.ffn[0], self.ffn[3]
         code = {"silu": 1, "relu": 2, "relu2": 3, "swiglu": 0}[self.ffn_activation]
-        f1 = bld.conv(y2, bld.pack_conv(f0.weight, f0.bias), f0.out_features, act=code)
+        fused_glu = self.ffn_activation == "swiglu" and f0.out_features % 8 == 0  # SwiGLU in the GEMM's epilogue (act = 4)
+        f1 = bld.conv(y2, bld.pack_conv(f0.weight, f0.bias), f0.out_features, act=4 if fused_glu else code)
         bld.free(y2)
-        if self.ffn_activation == "swiglu":  # x1 * silu(x2) over interleaved pairs (layers.py:107-110)
+        if self.ffn_activation == "swiglu" and not fused_glu:  # x1 * silu(x2) over interleaved pairs (layers.py:107-110)
             glu = bld.new_act(f1.B, f1.H, f1.W, f1.C // 2)
             bld.tape.add("az_swiglu_f32", glu.ptr, f1.ptr, f1.B * f1.H * f1.W, f1.C // 2, f1.cs, glu.cs)
             bld.free(f1)

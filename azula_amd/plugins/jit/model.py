@@ -197,11 +197,15 @@ class JiTPlan:
             half = w12.shape[0] // 2
             w12i = torch.stack((w12[half:], w12[:half]), dim=1).reshape(2 * half, -1).contiguous()
             b12i = torch.stack((b12[half:], b12[:half]), dim=1).reshape(-1).contiguous()
-            f1 = bld.conv(n2, bld.pack_conv(w12i, b12i), 2 * half)
-            bld.free(n2)
-            glu = bld.new_act(f1.B, f1.H, f1.W, half)
-            tape.add("az_swiglu_f32", glu.ptr, f1.ptr, f1.B * f1.H * f1.W, half, f1.cs, glu.cs)
-            bld.free(f1)
+            if half % 4 == 0:  # SwiGLU in the GEMM's epilogue (AzConvArgs.act = 4): no separate pass over the 4096-wide tensor
+                glu = bld.conv(n2, bld.pack_conv(w12i, b12i), 2 * half, act=4)
+                bld.free(n2)
+            else:
+                f1 = bld.conv(n2, bld.pack_conv(w12i, b12i), 2 * half)
+                bld.free(n2)
+                glu = bld.new_act(f1.B, f1.H, f1.W, half)
+                tape.add("az_swiglu_f32", glu.ptr, f1.ptr, f1.B * f1.H * f1.W, half, f1.cs, glu.cs)
+                bld.free(f1)
             x = bld.conv(glu, bld.pack_conv(blk.mlp.w3.weight, blk.mlp.w3.bias), Hd, gate=mod, gate_off=m0_ + 5 * Hd,
                          gate_bstride=MS, res=x2)
             bld.free(glu)

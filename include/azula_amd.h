@@ -258,7 +258,8 @@ typedef struct AzConvArgs {
   int32_t cout_s;          /* output channel stride (multiple of 4) */
   int32_t ksize, stride, pad;
   int32_t hout, wout;
-  int32_t act;             /* 0 none, 1 SiLU, 2 ReLU, 3 ReLU^2 */
+  int32_t act;             /* 0 none, 1 SiLU, 2 ReLU, 3 ReLU^2, 4 SwiGLU over interleaved pairs: dst gets cout_s / 2 channels per
+                              pixel, y[c] = x[2c] * silu(x[2c+1]) (no gate / res / dst_nchw; cout_s % 8 == 0) */
   const float* gate;       /* optional (…, cout_s) */
   int64_t gate_bstride;    /* 0 = shared across the batch */
   const float* res;        /* optional residual, NHWC (B, hres, wres, cout_s) */

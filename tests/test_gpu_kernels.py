@@ -434,6 +434,32 @@ def test_conv2d_random_shapes(az, wino):
         assert err < conv_tol(C0 + C1, 3, wino) * max(1.0, ref.abs().max().item()), (case, B, H, W, C0, C1, Cout, act, err)
 
 
+@pytest.mark.parametrize("wino", [False, True])
+@pytest.mark.parametrize("Cin,Cout,ks", [(32, 64, 1), (20, 24, 3), (64, 256, 1)])
+def test_conv2d_swiglu_epilogue(az, wino, Cin, Cout, ks):
+    """AzConvArgs.act = 4: y[c] = x[2c] * silu(x[2c+1]) applied to the convolution's output in its epilogue (half the
+    channels come out) -- azula/nn/layers.py:107-110 behind a Linear, JiT's SwiGLUFFN."""
+    if wino and ks != 3:
+        pytest.skip("Winograd is the stride-1 3x3 path")
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(Cin + Cout)
+    B, H, W = 2, 9, 7
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    b = torch.randn(Cout, generator=g)
+    full = F.conv2d(x, w, b, padding=ks // 2)
+    ref = full[:, 0::2] * F.silu(full[:, 1::2])
+    bld = Builder(torch.device("cuda"))
+    xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, (Cin + 3) // 4 * 4, True)
+    y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, act=4, winograd=wino)
+    bld.finish()
+    bld.tape.run()
+    assert (y.C, y.cs) == (Cout // 2, Cout // 2)
+    out = from_nhwc(y.buf.reshape(B, H, W, y.cs), Cout // 2)
+    assert max_err(out, ref) < 2 * conv_tol(Cin, ks, wino) * max(1.0, ref.abs().max().item())
+
+
 def test_winograd_stream_fuzz(az):
     """The hand-scheduled K loop (wino_kloop.inc) over 40 seeded cases that move every event of the stream around: 1 .. 24
     eight-channel stages (first / steady / second-to-last / last iteration bodies), two sources whose switch falls on any
