@@ -116,6 +116,8 @@ class AzNormFinalizeArgs(C.Structure):
         ("partials1", c_f32p),
         ("quads_per_group", C.c_int32),
         ("quads0", C.c_int32),
+        ("nchunks1", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

@@ -1218,6 +1218,82 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvP p) {
   }
 }
 
+// The same combine + epilogue with the GroupNorm moments of the OUTPUT (AzConvArgs.gn_quads; split-K layers are the small
+// maps, whose separate statistics launches cost 8 us each -- launch latency, not bandwidth).  One workgroup = one chunk of
+// `cpix` pixels of ONE image; thread -> (channel quad q = tid % Q, pixel slot tid / Q): it owns its quad for every pixel it
+// visits, so its pivoted sums need no cross-thread traffic until the end, where the (at most 256 / Q) slots of a quad are
+// folded with Chan's combination in a fixed order through LDS (deterministic).  Layout of the partials: az_conv2d_winograd_f32's
+// ([image][chunk][quad] x (n, mean, M2, 0)), n = the number of values behind a partial (az_groupnorm_finalize_f32 takes any n).
+__global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(ConvP p, int cpix) {
+  __shared__ float sh[3 * 256];
+  const AzConvArgs& a = p.a;
+  const int Q = a.cout_s / 4;
+  const int hw = a.hout * a.wout;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int slots = Q >= 256 ? 1 : 256 / Q;
+  const int p0 = chunk * cpix, p1 = min(hw, p0 + cpix);
+  for (int q0 = 0; q0 < Q; q0 += 256) {  // (Q > 256: every thread owns several quads in turn)
+    const int q = q0 + (Q >= 256 ? tid : tid % Q);
+    const int slot = Q >= 256 ? 0 : tid / Q;
+    float cnt = 0.f, pivot = 0.f, s1 = 0.f, s2 = 0.f;
+    if (q < Q && slot < slots) {
+      for (int px = p0 + slot; px < p1; px += slots) {
+        const int n = b * hw + px;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int z = 0; z < a.splitk; ++z) {
+          const float4 w = ld4(a.workspace + ((int64_t)z * p.npix + n) * a.cout_s + q * 4);
+          v.x += w.x;
+          v.y += w.y;
+          v.z += w.z;
+          v.w += w.w;
+        }
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f), r = g, bv = g;
+        if (a.bias) bv = ld4(a.bias + q * 4);
+        epilogue_fetch(a, n, b, q * 4, g, r);
+        const float4 f = epilogue_apply_store(a, n, b, q * 4, v, bv, g, r);
+        if (cnt == 0.f) pivot = f.x;
+        const float d0 = f.x - pivot, d1 = f.y - pivot, d2 = f.z - pivot, d3 = f.w - pivot;
+        s1 += (d0 + d1) + (d2 + d3);
+        s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        cnt += 4.f;
+      }
+    }
+    // (n, mean, M2) of this thread's values; then the slots of a quad, in slot order
+    float mean = 0.f, m2 = 0.f;
+    if (cnt > 0.f) {
+      mean = pivot + s1 / cnt;
+      m2 = s2 - s1 * s1 / cnt;
+    }
+    if (slots > 1) {
+      __syncthreads();
+      sh[tid] = cnt;
+      sh[256 + tid] = mean;
+      sh[512 + tid] = m2;
+      __syncthreads();
+      if (slot == 0 && q < Q) {
+        for (int k = 1; k < slots; ++k) {
+          const float nb = sh[k * Q + q], mb = sh[256 + k * Q + q], vb = sh[512 + k * Q + q];
+          if (nb > 0.f) {
+            const float nn = cnt + nb, d = mb - mean;
+            mean = mean + d * (nb / nn);
+            m2 = (m2 + vb) + d * d * (cnt * nb / nn);
+            cnt = nn;
+          }
+        }
+      }
+    }
+    if (slot == 0 && q < Q) {
+      float* out = a.gn_quads + (((int64_t)b * a.gn_chunks + chunk) * Q + q) * 4;
+      out[0] = cnt;
+      out[1] = mean;
+      out[2] = m2;
+      out[3] = 0.f;
+    }
+  }
+}
+
 // =================================================================================================
 // Winograd F(2x2, 3x3) form of the stride-1 3x3 convolution, fully fused:
 //   out tile (2x2) = A^T [ sum_ci U[xi,nu][co][ci] * V[xi,nu][ci] ] A ,  U = G g G^T (offline),  V = B^T d B
@@ -2065,6 +2141,23 @@ int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_
   return (int)want;
 }
 
+// Split-K combine + fused epilogue; with AzConvArgs.gn_quads also the GroupNorm moments of the output, one partial per
+// (image, chunk of ceil(hw / gn_chunks) pixels, channel quad).
+static int launch_splitk_reduce(const ConvP& cp, hipStream_t st) {
+  const AzConvArgs& a = cp.a;
+  if (a.gn_quads != nullptr) {
+    AZ_REQUIRE(a.gn_chunks >= 1 && !a.dst_nchw && a.act != 4, AZ_E_UNSUPPORTED);
+    const int hw = a.hout * a.wout;
+    const int cpix = (hw + a.gn_chunks - 1) / a.gn_chunks;
+    AZ_REQUIRE((int64_t)cpix * (a.gn_chunks - 1) < hw, AZ_E_SHAPE);  // no empty chunk
+    hipLaunchKernelGGL(conv_splitk_reduce_stats_kernel, dim3((unsigned)a.gn_chunks, (unsigned)a.batch), dim3(256), 0, st, cp, cpix);
+  } else {
+    const int grid = az_stream_grid((int64_t)cp.npix * (a.cout_s / 4), 256);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, cp);
+  }
+  return az_launch_status();
+}
+
 static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half /* 0 fp32, 1 bf16, 2 f16 operands, 3 fp32 as 3 x bf16 */);
 
 int az_conv2d_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 0); }
@@ -2173,6 +2266,9 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   p.kps = (p.nk + splitk - 1) / splitk;
   splitk = (p.nk + p.kps - 1) / p.kps;  // no empty splits
   p.a.splitk = splitk;
+  // GroupNorm moments of the output: from the split-K combine only (the direct kernels' own epilogues do not produce them)
+  AZ_REQUIRE(!a->gn_quads || splitk > 1, AZ_E_UNSUPPORTED);
+  p.a.gn_quads = nullptr;
   p.tiles_m = (a->cout_s + BM - 1) / BM;
   p.tiles_n = (p.npix + BN - 1) / BN;
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
@@ -2190,9 +2286,8 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   int rc = az_launch_status();
   if (rc != AZ_OK) return rc;
   if (splitk > 1) {
-    const int grid = az_stream_grid((int64_t)p.npix * (a->cout_s / 4), 256);
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, p);
-    rc = az_launch_status();
+    p.a.gn_quads = a->gn_quads;
+    rc = launch_splitk_reduce(p, st);
   }
   return rc;
 }
@@ -2226,12 +2321,12 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->splitk >= 1 && (a->splitk == 1 || a->workspace), AZ_E_SHAPE);
   const int64_t npix64 = (int64_t)a->batch * a->hout * a->wout;
   AZ_REQUIRE(npix64 < (1ll << 31), AZ_E_SHAPE);
-  if (a->gn_quads) {  // statistics of the output for a following GroupNorm: one tile block = 64 tiles of ONE image
+  if (a->gn_quads && a->splitk == 1) {  // statistics of the output for a following GroupNorm: one tile block = 64 tiles of ONE image
     const int64_t tiles_img = (int64_t)((a->hout + 1) / 2) * ((a->wout + 1) / 2);
-    AZ_REQUIRE(a->splitk == 1 && !a->dst_nchw && a->cout_s % WC == 0 && tiles_img % WT == 0 && a->hout % 2 == 0 &&
+    AZ_REQUIRE(!a->dst_nchw && a->cout_s % WC == 0 && tiles_img % WT == 0 && a->hout % 2 == 0 &&
                    a->wout % 2 == 0 && a->gn_chunks == tiles_img / WT,  // whole 2 x 2 tiles only: 1024 values per partial
                AZ_E_UNSUPPORTED);
-  }
+  }  // (split-K > 1: the moments come from the combine kernel, gn_chunks = pixel chunks per image)
 
   WinoP p;
   p.a = *a;
@@ -2253,6 +2348,8 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   p.kps = (p.nk + splitk - 1) / splitk;
   splitk = (p.nk + p.kps - 1) / p.kps;
   p.a.splitk = splitk;
+  AZ_REQUIRE(!a->gn_quads || (a->splitk == 1) == (splitk == 1), AZ_E_UNSUPPORTED);  // gn_chunks means tile blocks OR pixel chunks
+  if (splitk > 1) p.a.gn_quads = nullptr;  // (the slabs carry no moments: the combine kernel produces them)
   p.cblocks = (a->cout_s + WC - 1) / WC;
   p.tblocks = (p.ntiles + WT - 1) / WT;
   AZ_REQUIRE((int64_t)p.nk * p.cblocks * WU_STAGE * 4 <= (1ll << 31), AZ_E_SHAPE);
@@ -2279,10 +2376,9 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   if (splitk > 1) {
     ConvP cp;
     cp.a = p.a;
+    cp.a.gn_quads = a->gn_quads;
     cp.npix = p.npix;
-    const int grid = az_stream_grid((int64_t)p.npix * (a->cout_s / 4), 256);
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, cp);
-    rc = az_launch_status();
+    rc = launch_splitk_reduce(cp, st);
   }
   return rc;
 }
@@ -2349,6 +2445,8 @@ int az_conv2d_winograd4_f32(const AzConvArgs* a, az_stream_t stream) {
   p.kps = (p.nk + splitk - 1) / splitk;
   splitk = (p.nk + p.kps - 1) / p.kps;
   p.a.splitk = splitk;
+  AZ_REQUIRE(!a->gn_quads || splitk > 1, AZ_E_UNSUPPORTED);
+  p.a.gn_quads = nullptr;
   p.cblocks = (a->cout_s + W4C - 1) / W4C;
   p.tblocks = (p.ntiles + W4T - 1) / W4T;
   AZ_REQUIRE((int64_t)p.nk * p.cblocks * W4U_STAGE * 4 <= (1ll << 31), AZ_E_SHAPE);
@@ -2367,10 +2465,9 @@ int az_conv2d_winograd4_f32(const AzConvArgs* a, az_stream_t stream) {
   if (splitk > 1) {
     ConvP cp;
     cp.a = p.a;
+    cp.a.gn_quads = a->gn_quads;
     cp.npix = p.npix;
-    const int grid = az_stream_grid((int64_t)p.npix * (a->cout_s / 4), 256);
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, cp);
-    rc = az_launch_status();
+    rc = launch_splitk_reduce(cp, st);
   }
   return rc;
 }

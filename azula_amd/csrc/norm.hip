@@ -188,8 +188,9 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(AzNormFinalizeArgs a) {
     const float* base = second ? a.partials1 : a.partials;
     const int nq = second ? (int)(a.C / 4) - a.quads0 : a.quads0;
     const int q0 = second ? q_lo - a.quads0 : q_lo;
-    for (int k = lane; k < a.nchunks; k += 64) {
-      const float* p = base + (((int64_t)b * a.nchunks + k) * nq + q0) * 4;
+    const int nck = second && a.nchunks1 > 0 ? a.nchunks1 : a.nchunks;
+    for (int k = lane; k < nck; k += 64) {
+      const float* p = base + (((int64_t)b * nck + k) * nq + q0) * 4;
       for (int j = 0; j < qpg; ++j) acc = combine(acc, Moments{p[4 * j], p[4 * j + 1], p[4 * j + 2]});
     }
   } else {
@@ -478,7 +479,8 @@ int az_groupnorm_stats_f32(float* partials, const float* x, const float* x1, int
 
 int az_groupnorm_finalize_f32(const AzNormFinalizeArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->S && a->T && a->partials, AZ_E_NULL);
-  AZ_REQUIRE(a->B > 0 && a->C > 0 && a->cs >= a->C && a->groups > 0 && a->C % a->groups == 0 && a->nchunks > 0,
+  AZ_REQUIRE(a->B > 0 && a->C > 0 && a->cs >= a->C && a->groups > 0 && a->C % a->groups == 0 && a->nchunks > 0 &&
+                 a->nchunks1 >= 0,
              AZ_E_SHAPE);
   if (a->quads_per_group > 0) {  // partials from conv epilogues: whole quads per group, groups inside one source
     const int64_t Cg = a->C / a->groups;

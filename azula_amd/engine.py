@@ -135,6 +135,7 @@ X3_MIN_CHANNELS = 32  # bf16x3 only where both channel counts fill a K tile / an
 WINOGRAD4_MIN_TILES = int(os.environ.get("AZ_WINOGRAD4_MIN_TILES", "1024"))
 # GroupNorm statistics from the producing convolution's epilogue ("1", default) or always by the separate pass ("0")
 GN_FUSED = os.environ.get("AZ_GN_FUSED", "1") != "0"
+GN_FUSED_SPLITK = os.environ.get("AZ_GN_FUSED", "1") != "epilogue"  # ("epilogue": only the Winograd epilogue's moments -- A/B)
 
 
 class ConvWeights:
@@ -406,6 +407,20 @@ class Builder:
             a.gn_quads, a.gn_chunks = quads.data_ptr(), chunks
             out.gn_quads = (quads, chunks)
             self.tape.keep.append(quads)
+        elif (gn_stats and GN_FUSED and GN_FUSED_SPLITK and a.splitk > 1 and out is not None and cout == a.cout_s and name != "az_conv2d_winograd4_f32"
+              and not (name == "az_conv2d_f32" and a.cout_s == 4)):
+            # split-K layers (the small maps): the combine kernel leaves the moments, one partial per (image, pixel chunk, quad)
+            hw = hout * wout
+            # a workgroup of the combine kernel = 256 // quads pixel slots; about 2 pixels per thread (each costs splitk
+            # dependent-latency loads: parallelism, not bandwidth, decides), at most 128 partials per image (two finalize passes)
+            cpix = 2 * max(1, 256 // (cout // 4))
+            chunks = max(1, min(128, (hw + cpix - 1) // cpix))
+            while (hw + chunks - 1) // chunks * (chunks - 1) >= hw:
+                chunks -= 1
+            quads = torch.empty(B * chunks * (cout // 4) * 4, dtype=torch.float32, device=self.device)
+            a.gn_quads, a.gn_chunks = quads.data_ptr(), chunks
+            out.gn_quads = (quads, chunks)
+            self.tape.keep.append(quads)
         if a.splitk > 1:
             self._ws_need = max(self._ws_need, a.splitk * npix * a.cout_s)
             self._ws_users.append(a)
@@ -453,11 +468,12 @@ class Builder:
         f = AzNormFinalizeArgs()
         Cg = x.C // groups
         fused = src_quads is not None and Cg % 4 == 0 and x.C == x.cs and all(q is not None for q in src_quads) \
-            and len({q[1] for q in src_quads}) == 1 and all((c // 4) % (Cg // 4) == 0 for c in src_channels)
+            and all((c // 4) % (Cg // 4) == 0 for c in src_channels)
         if fused:  # every source was produced by a convolution that left its moments: no statistics pass
             nchunks = src_quads[0][1]
             f.partials = src_quads[0][0].data_ptr()
-            f.partials1 = src_quads[1][0].data_ptr() if len(src_quads) > 1 else None
+            if len(src_quads) > 1:
+                f.partials1, f.nchunks1 = src_quads[1][0].data_ptr(), src_quads[1][1]
             f.quads_per_group, f.quads0 = Cg // 4, src_channels[0] // 4
         else:
             nchunks = int(min(512, max(1, (HW * x.cs * 4) // 65536)))  # ~64 KB of x per workgroup

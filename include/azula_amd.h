@@ -216,6 +216,8 @@ typedef struct AzNormFinalizeArgs {
    * two-source input (channel concatenation), the rest in `partials1`; group g folds quads [g qpg, (g + 1) qpg). */
   const float* partials1;
   int32_t quads_per_group, quads0;
+  int32_t nchunks1;       /* partials per image in `partials1` (0 = nchunks): the two producers may chunk differently */
+  int32_t reserved0;
 } AzNormFinalizeArgs;
 int az_groupnorm_finalize_f32(const AzNormFinalizeArgs* args, az_stream_t stream);
 /* pool: 0 none, 1 = 2x2 average pool of act(.) (needs H, W even; dst is (B, H/2*W/2, cs)).      */
@@ -272,11 +274,13 @@ typedef struct AzConvArgs {
   int32_t splitk;          /* >= 1; > 1 needs workspace of splitk * B*hout*wout * cout_s floats */
   float* workspace;
   int32_t pad_mode;        /* 0: zero padding; 1: circular ("periodic", azula/nn/unet.py:175-180): taps wrap around the map */
-  int32_t gn_chunks;       /* with gn_quads: tile blocks (of 64 Winograd tiles) per image */
-  float* gn_quads;         /* optional (az_conv2d_winograd_f32, splitk 1, cout_s % 64 == 0, 64 | tiles per image): GroupNorm
-                            * moments of the OUTPUT, (batch, gn_chunks, cout_s / 4, 4) floats = (n, mean, M2, 0) per image,
-                            * tile block and channel quad -- consumed by az_groupnorm_finalize_f32 (quads_per_group) so that
-                            * the normalisation that follows needs no statistics pass over the tensor */
+  int32_t gn_chunks;       /* with gn_quads: partials per image -- splitk 1 (az_conv2d_winograd_f32 only): tile blocks of 64 Winograd
+                            * tiles; splitk > 1 (any conv entry point): chunks of ceil(hout * wout / gn_chunks) pixels */
+  float* gn_quads;         /* optional: GroupNorm moments of the OUTPUT, (batch, gn_chunks, cout_s / 4, 4) floats = (n, mean, M2, 0)
+                            * per image, chunk and channel quad -- from the Winograd kernel's epilogue (splitk 1, cout_s % 64 == 0,
+                            * 64 | tiles per image) or from the split-K combine kernel (splitk > 1); consumed by
+                            * az_groupnorm_finalize_f32 (quads_per_group), so that the normalisation that follows needs no
+                            * statistics pass over the tensor */
   int32_t aniso;           /* 1: the WIDTH axis has its own stride / upsampling factors (azula/nn/unet.py:159-186 with a
                             * stride sequence such as (2, 1)); 0: `stride`, `up0`, `up1` apply to both axes.  Direct kernels
                             * (az_conv2d_f32 / _bf16_f32 / _f16_f32 / _x3_f32) only: the Winograd entries return UNSUPPORTED */

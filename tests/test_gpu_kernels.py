@@ -733,6 +733,70 @@ def test_conv2d_epilogue_forms(az, wino, act, gated, res_kind):
     assert err < conv_tol(Cin, 3, wino) * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize(
+    "case",
+    [  # (B, Cin, Cout, H, W, ks, stride, winograd, form)
+        (2, 256, 128, 8, 8, 3, 1, False, "plain"),
+        (2, 256, 128, 8, 8, 3, 1, False, "gate_res"),
+        (4, 256, 256, 16, 16, 3, 1, True, "silu"),
+        (4, 512, 256, 8, 8, 3, 1, True, "gate_res"),
+        (1, 1024, 96, 6, 6, 1, 1, False, "plain"),       # 24 quads (not a divisor of 256), 36 pixels in 2 ragged chunks
+        (2, 128, 1280, 8, 8, 3, 2, False, "plain"),      # 320 quads: a thread owns two quads in turn; stride 2
+        (2, 256, 128, 8, 8, 3, 1, False, "concat"),
+    ],
+)
+def test_groupnorm_statistics_from_the_splitk_combine(az, case, monkeypatch):
+    """AzConvArgs.gn_quads with splitk > 1 (the small maps): the combine kernel leaves (n, mean, M2) per (image, pixel chunk,
+    channel quad) and the following GroupNorm skips its statistics pass.  Same bar as the Winograd-epilogue test below."""
+    from azula_amd import engine
+    from azula_amd.engine import Act, Builder
+
+    B, Cin, Cout, H, W, ks, stride, wino, form = case
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(B, Cin, H * stride, W * stride, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(ks * ks * Cin)
+    b = torch.randn(Cout, generator=g) + 30.0
+    gate = torch.randn(B, Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g) * 0.5 + 50.0
+    conv = F.conv2d(x, w, b, padding=ks // 2, stride=stride)
+    assert conv.shape[-2:] == (H, W)
+    if form in ("gate_res", "concat"):
+        conv = conv * gate[:, :, None, None] + res
+    elif form == "silu":
+        conv = F.silu(conv)
+    w2 = torch.randn(64, Cin, ks, ks, generator=g) / math.sqrt(ks * ks * Cin)
+    two = form == "concat"
+    full = torch.cat((conv, F.conv2d(x, w2, None, padding=ks // 2, stride=stride)), 1) if two else conv
+    C2, groups = full.shape[1], 6 if two else 8  # (a group never straddles the two sources)
+    gw, gb = torch.randn(C2, generator=g), torch.randn(C2, generator=g)
+    ref = F.silu(F.group_norm(full, groups, gw, gb, eps=1e-5))
+
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(engine, "GN_FUSED", fused)
+        bld = Builder(torch.device("cuda"))
+        xa = Act(to_nhwc(dev(x)).reshape(-1), B, H * stride, W * stride, Cin, Cin, True)
+        ra = Act(to_nhwc(dev(res)).reshape(-1), B, H, W, Cout, Cout, True)
+        kw = dict(gate=dev(gate), gate_bstride=Cout, res=ra) if form in ("gate_res", "concat") else {}
+        y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, act=int(form == "silu"), stride=stride, winograd=wino, gn_stats=True, **kw)
+        y1 = bld.conv(xa, bld.pack_conv(dev(w2), None), 64, stride=stride, winograd=wino, gn_stats=True) if two else None
+        n = bld.group_norm(y, groups, weight=dev(gw), bias=dev(gb), act=1, x1=y1)
+        bld.finish()
+        convs = [args[0]._obj for _, args, nm in bld.tape.ops if nm.startswith("az_conv2d")]
+        assert all(c.splitk > 1 for c in convs), [c.splitk for c in convs]
+        names = [nm for _, _, nm in bld.tape.ops]
+        assert (y.gn_quads is not None) == fused
+        assert ("az_groupnorm_stats_f32" in names) == (not fused), names
+        bld.tape.run()
+        outs[fused] = from_nhwc(n.buf.reshape(B, H, W, C2), C2).clone()
+        bld.tape.run()
+        assert torch.equal(from_nhwc(n.buf.reshape(B, H, W, C2), C2), outs[fused]), "not deterministic"
+    e_ref, e_ab = max_err(outs[True], ref), max_err(outs[True], outs[False])
+    print(f"{case}: fused vs torch {e_ref:.2e}, fused vs separate pass {e_ab:.2e}")
+    assert e_ref < 6e-5 and max_err(outs[False], ref) < 6e-5
+    assert e_ab < 2.5e-5
+
+
 @pytest.mark.parametrize("form", ["plain", "gate_res", "silu", "concat", "mixed"])
 def test_groupnorm_statistics_from_the_conv_epilogue(az, form, monkeypatch):
     """AzConvArgs.gn_quads: the Winograd epilogue leaves (n, mean, M2) per (image, 64-tile block, channel quad) and the
