@@ -164,6 +164,9 @@ class AzConvArgs(C.Structure):
         ("stride_w", C.c_int32),
         ("up0_w", C.c_int32),
         ("up1_w", C.c_int32),
+        ("in_affine", c_f32p),
+        ("in_act", C.c_int32),
+        ("reserved1", C.c_int32),
     ]
 
 

@@ -1451,8 +1451,10 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
 
   f32x2 rv[16];  // V role: raw 4x4 patch of a channel pair; U role: 8 filter float4 (rv[2i], rv[2i+1])
 
+  int staged_kt = 0;  // (C++ loop) the stage whose raw patch sits in rv
   auto load_stage = [&](int kt) {  // kt is wave-uniform: descriptor choice stays provably uniform
     const bool src1 = kt >= p.nkc0;
+    staged_kt = kt;
     if (vrole) {
       if ((src1 ? 1 : 0) != cur_src) set_src(src1 ? 1 : 0);
       const int kc = src1 ? kt - p.nkc0 : kt;
@@ -1492,6 +1494,18 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
     float* Us = wsm + buf * W_STAGE;
     float* Vs = Us + WU_STAGE;
     if (vrole) {
+      if (a.in_affine != nullptr) {
+        // the input is act(x * scale + shift) (the GroupNorm apply pass, fused); padding positions stay zero
+        const float* sp = a.in_affine + ((int64_t)(b_first + (v_b < 0 ? 0 : v_b)) * a.c0s + staged_kt * WK + vq * 2);
+        const f32x2 sc = *reinterpret_cast<const f32x2*>(sp);
+        const f32x2 sh = *reinterpret_cast<const f32x2*>(sp + (int64_t)a.batch * a.c0s);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          f32x2 v = rv[i] * sc + sh;
+          if (a.in_act == 1) v = f32x2{az_silu(v.x), az_silu(v.y)};
+          rv[i] = voffV[i] == OOB ? f32x2{0.f, 0.f} : v;
+        }
+      }
       // in-place V = B^T d B (packed fp32 adds); B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -1562,12 +1576,26 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
         const int soff0 = (start1 ? kt_begin - p.nkc0 : kt_begin) * (WK * 4);
         const int tail0 = (a.c0s & (WK - 1)) ? p.nkc0 - 1 : -1;
         const int tail1 = (a.c1s & (WK - 1)) ? p.nk - 1 : -1;
-        asm volatile(WINO_KLOOP_V_ASM
-                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
-                     : "v"(fragA_b), "v"(fragB_b), "v"(vst), "v"(ldsA), "v"(ldsB), "s"(d0w0), "s"(d0w1), "s"(d0w2), "s"(dflags),
-                       "s"(d1w0), "s"(d1w1), "s"(d1w2), "s"(dflags), "s"(kt_begin), "s"(kt_end), "s"(kt_switch), "s"(soff0),
-                       "s"(tail0), "s"(tail1)
-                     : WINO_KLOOP_CLOBBERS);
+        // in_affine: [scale | shift], (batch, c0s) each; per-lane offset of the thread's image and channel pair
+        const uint64_t baf = (uint64_t)(uintptr_t)a.in_affine;
+        const unsigned af_lo = (unsigned)baf, af_hi = (unsigned)(baf >> 32);
+        const unsigned af_delta = a.in_affine ? (unsigned)(a.batch * a.c0s * 4) : 0u;
+        const unsigned af_voff = (unsigned)(((b_first + (v_b < 0 ? 0 : v_b)) * a.c0s + vq * 2) * 4);
+        if (a.in_affine != nullptr) {  // (a second stream: the plain one carries no branch for this)
+          asm volatile(WINO_KLOOP_VA_ASM
+                       : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                       : "v"(fragA_b), "v"(fragB_b), "v"(vst), "v"(ldsA), "v"(ldsB), "s"(d0w0), "s"(d0w1), "s"(d0w2), "s"(dflags),
+                         "s"(d1w0), "s"(d1w1), "s"(d1w2), "s"(dflags), "s"(kt_begin), "s"(kt_end), "s"(kt_switch), "s"(soff0),
+                         "s"(tail0), "s"(tail1), "v"(af_voff), "s"(af_lo), "s"(af_hi), "s"(af_delta)
+                       : WINO_KLOOP_VA_CLOBBERS);
+        } else {
+          asm volatile(WINO_KLOOP_V_ASM
+                       : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                       : "v"(fragA_b), "v"(fragB_b), "v"(vst), "v"(ldsA), "v"(ldsB), "s"(d0w0), "s"(d0w1), "s"(d0w2), "s"(dflags),
+                         "s"(d1w0), "s"(d1w1), "s"(d1w2), "s"(dflags), "s"(kt_begin), "s"(kt_end), "s"(kt_switch), "s"(soff0),
+                         "s"(tail0), "s"(tail1), "v"(af_voff), "s"(af_lo), "s"(af_hi), "s"(af_delta)
+                       : WINO_KLOOP_CLOBBERS);
+        }
       } else {
         const uint64_t bw = (uint64_t)(uintptr_t)a.weight;
         const unsigned ww0 = (unsigned)bw, ww1 = (unsigned)(bw >> 32) & 0xffffu;
@@ -2172,6 +2200,7 @@ int az_conv2d_f16_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_d
 int az_conv2d_x3_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 3); }
 
 static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
+  AZ_REQUIRE(!a || !a->in_affine, AZ_E_UNSUPPORTED);  // (the Winograd kernel's gather only)
   AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout > 0 && a->wout > 0, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
@@ -2303,6 +2332,10 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
   AZ_REQUIRE(a->act >= 0 && a->act <= 4, AZ_E_UNSUPPORTED);
   if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
+  if (a->in_affine)  // the normalisation apply pass inside the gather
+    AZ_REQUIRE(!a->src1 && a->c0s % 8 == 0 && a->up0 == 0 && (a->in_act == 0 || a->in_act == 1) && AZ_ALIGNED16(a->in_affine) &&
+                   (int64_t)a->batch * a->c0s * 8 < (1ll << 31),
+               AZ_E_UNSUPPORTED);
   AZ_REQUIRE(!a->aniso || (a->up0_w >= 0 && a->up0_w <= 4 && a->up1_w >= 0 && a->up1_w <= 4), AZ_E_SHAPE);  // (shift amounts)
   AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
                  ((a->win + (1 << az_upw(a, a->up0, a->up0_w)) - 1) >> az_upw(a, a->up0, a->up0_w)) <= a->w0,
@@ -2367,7 +2400,7 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   }
   // AZ_WINOGRAD_ASM=0: the C++ K loop (A/B measurements); default: the hand-scheduled stream
   const char* asm_env = getenv("AZ_WINOGRAD_ASM");
-  if (asm_env && asm_env[0] == '0')
+  if ((asm_env && asm_env[0] == '0') || (a->in_affine && a->in_act != 0))  // (the stream has the plain affine only)
     hipLaunchKernelGGL(conv_winograd_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), W_LDS_BYTES, st, p);
   else
     hipLaunchKernelGGL(conv_winograd_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), W_LDS_BYTES + W_VOFF_BYTES, st, p);
@@ -2407,6 +2440,7 @@ int az_conv2d_winograd4_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
   AZ_REQUIRE(a->act >= 0 && a->act <= 4, AZ_E_UNSUPPORTED);
   if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
+  AZ_REQUIRE(!a->in_affine, AZ_E_UNSUPPORTED);
   AZ_REQUIRE(!a->aniso || (a->up0_w >= 0 && a->up0_w <= 4 && a->up1_w >= 0 && a->up1_w <= 4), AZ_E_SHAPE);  // (shift amounts)
   AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
                  ((a->win + (1 << az_upw(a, a->up0, a->up0_w)) - 1) >> az_upw(a, a->up0, a->up0_w)) <= a->w0,

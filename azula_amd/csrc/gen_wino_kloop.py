@@ -28,9 +28,12 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 TB = 160
+SP, TP = 156, 158   # input affine (AzConvArgs.in_affine): scale / shift of the thread's channel pair for the stage being transformed
 RV0, VO0, X0, Y0 = 192, 224, 240, 248
 V_FA, V_FB, V_ST, V_OOB = 252, 253, 254, 255
 S_FIRST, S_RS, S_SOFF, S_KT, S_CNT, S_TMP = 91, 92, 96, 97, 98, 99  # (s100 / s101 are reserved on this target)
+S_AF, S_AFT, S_AFS, S_ALLV = 84, 88, 89, 90  # in_affine: descriptor s[84:87], byte distance scale -> shift (0 = no affine), soffset temp,
+#                                             1 = this wave's patches have no padding position
 GROUP_BYTES = 2048  # one frequency of a stage: 64 rows x 8 floats x 4 B
 BUF_XOR = 0x10000   # the two 64 KB stages
 
@@ -134,7 +137,44 @@ def v_load(i, rv0=RV0):
 
 
 V_OPS = dict(fragA=8, fragB=9, st=10, ldsA=11, ldsB=12, rs0=13, rs1=17, kt_begin=21, kt_end=22, kt_switch=23, soff0=24,
-             tail0=25, tail1=26)
+             tail0=25, tail1=26, af_voff=27, af_lo=28, af_hi=29, af_delta=30)
+
+
+AFFINE = False   # set by gen_role: the V stream with AzConvArgs.in_affine (a second asm statement; the plain stream has no trace of it --
+#                  a TAKEN scalar branch costs the wave ~50 cycles, four skipped blocks per stage were 2 % of the kernel)
+OOL: list = []   # out-of-line blocks of the stream being generated (emitted behind its last instruction)
+
+
+S_MASK = 52      # in_affine: s[52:83] = 16 lane masks, position i valid (not padding) for the lane
+
+
+def v_affine_col(c, tag, rv0=RV0):
+    r"""In-place y = x * scale + shift on column c of the raw patch (4 positions x a channel pair).  Padding positions (patch
+    offset = OOB: negative) must stay zero -- the convolution pads the NORMALISED tensor: their lanes are switched off for the
+    FMA (the load left 0 there) by scalar moves of precomputed lane masks into EXEC; the VALU instructions of this stream are
+    not hidden behind the MFMAs (each costs its issue time), scalar ones are."""
+    if not AFFINE:
+        return []
+    L = []
+    for r in range(4):
+        i = 4 * r + c
+        d = rv0 + 2 * i
+        L.append(("salu", f"s_mov_b64 exec, s[{S_MASK + 2 * i}:{S_MASK + 2 * i + 1}]"))
+        L.append(("valu", f"v_pk_fma_f32 {pair(d)}, {pair(d)}, {pair(SP)}, {pair(TP)}"))
+    L.append(("salu", "s_mov_b64 exec, -1"))
+    return L
+
+
+def v_affine_loads(tag, back=0):
+    r"""scale / shift pairs of the NEXT stage to transform (soffset: the stage's channel offset, `back` bytes behind s_soff)."""
+    if not AFFINE:
+        return []
+    o = V_OPS
+    L = [("salu", f"s_sub_u32 s{S_AFS}, s{S_SOFF}, {back}")]
+    L.append(("vmem", f"buffer_load_dwordx2 {pair(SP)}, %{o['af_voff']}, s[{S_AF}:{S_AF + 3}], s{S_AFS} offen"))
+    L.append(("salu", f"s_add_u32 s{S_AFS}, s{S_AFS}, s{S_AFT}"))
+    L.append(("vmem", f"buffer_load_dwordx2 {pair(TP)}, %{o['af_voff']}, s[{S_AF}:{S_AF + 3}], s{S_AFS} offen"))
+    return L
 
 
 def v_load_events(tag):
@@ -176,6 +216,7 @@ def v_extras(S: bool, L: bool, tag: str):
     if S:
         ex[0].append(("wait", "s_waitcnt vmcnt(0)"))
         for c in range(4):
+            ex[c // 2] += v_affine_col(c, tag)
             ex[c // 2] += [("valu", t) for t in v_pass1_col(c)]
         for xi in range(4):
             valu, wa, wb = v_pass2_row(xi)
@@ -188,6 +229,7 @@ def v_extras(S: bool, L: bool, tag: str):
         for n, i in enumerate(order):
             ex[2 + n].append(v_load(i))
         ex[17] += v_load_done()
+        ex[18] += v_affine_loads(tag, back=32)   # (s_soff already points at the stage after the one just requested)
     if S:
         ex[17].append(("valu", f"v_xor_b32 v{V_ST}, 0x{BUF_XOR:x}, v{V_ST}"))
     return ex
@@ -298,7 +340,10 @@ ABL = set(os.environ.get("KL_ABLATE", "").split(","))  # timing ablations (WRONG
 PRIO_HEAD = {"V": int(os.environ.get("KL_PRIO_V", "0")), "U": int(os.environ.get("KL_PRIO_U", "0"))}  # U role = waves 4..7 = the younger wave of every SIMD
 
 
-def gen_role(role: str) -> list[str]:
+def gen_role(role: str, affine: bool = False) -> list[str]:
+    global AFFINE
+    AFFINE = affine
+    OOL.clear()
     V = role == "V"
     o = V_OPS if V else U_OPS
     extras = v_extras if V else u_extras
@@ -335,9 +380,20 @@ def gen_role(role: str) -> list[str]:
     if V:
         e(f"v_mov_b32 v{V_OOB}, 0x80000000")
         e(f"s_mov_b32 s{S_KT}, %{o['kt_begin']}")
+        if affine:  # raw buffer over [scale | shift] (bounds unchecked: every lane reads channels of its own image), first pairs
+            e(f"s_mov_b32 s{S_AF}, %{o['af_lo']}")
+            e(f"s_and_b32 s{S_AF + 1}, %{o['af_hi']}, 0xffff")
+            e(f"s_mov_b32 s{S_AF + 2}, 0x7fffffff")
+            e(f"s_mov_b32 s{S_AF + 3}, 0x00020000")
+            e(f"s_mov_b32 s{S_AFT}, %{o['af_delta']}")
+            for kind, t in v_affine_loads("i", back=0):
+                e(t)
         for q in range(4):
             e(f"ds_read_b128 {quad(VO0 + 4 * q)}, %{o['ldsA']} offset:{16 * q}")
         e("s_waitcnt lgkmcnt(0)")
+        if affine:  # lane masks of the valid (non-padding) patch positions
+            for i in range(16):
+                e(f"v_cmp_le_i32 s[{S_MASK + 2 * i}:{S_MASK + 2 * i + 1}], 0, v{VO0 + i}")
     # ---- prologue: L(kt0) -> P0, L(kt0 + 1) -> RV (if n >= 2), S(kt0) from P0
     if V:
         v_loads(P0, "p0")
@@ -363,8 +419,14 @@ def gen_role(role: str) -> list[str]:
     e(f"L{role}st0_%=:")
     if V:
         for c in range(4):
+            for kind, t in v_affine_col(c, "p", P0):
+                e(t)
             for t in v_pass1_col(c, P0):
                 e(t)
+        # (s_soff: one or two stages were requested; the second one's scale / shift sit 32 bytes behind it -- or nowhere
+        # when the slice has a single stage: the load is then harmless and unused)
+        for kind, t in v_affine_loads("q", back=32):
+            e(t)
         for xi in range(4):
             valu, wa, wb = v_pass2_row(xi, P0)
             for kind, t in valu + [wa, wb]:
@@ -402,6 +464,12 @@ def gen_role(role: str) -> list[str]:
             st.mfma(g, s, j)
     e("s_nop 15")
     e("s_nop 7")
+    if OOL:
+        e(f"s_branch L{role}end_%=")
+        for blk in OOL:
+            for t in blk:
+                e(t)
+        e(f"L{role}end_%=:")
     return st.lines
 
 
@@ -414,14 +482,17 @@ def as_macro(name: str, lines: list[str]) -> str:
 
 
 def clobbers() -> str:
-    regs = (['"m0"'] if UDMA else []) + [f'"v{i}"' for i in range(TB, 256)] + [f'"s{i}"' for i in range(S_FIRST, S_TMP + 1)] + ['"vcc"', '"scc"', '"memory"']
-    return "#define WINO_KLOOP_CLOBBERS " + ", ".join(regs) + "\n"
+    tail = ['"vcc"', '"scc"', '"memory"']
+    plain = (['"m0"'] if UDMA else []) + [f'"v{i}"' for i in range(TB, 256)] + [f'"s{i}"' for i in range(S_FIRST, S_TMP + 1)] + tail
+    aff = [f'"v{i}"' for i in range(SP, 256)] + [f'"s{i}"' for i in range(S_MASK, S_TMP + 1)] + tail
+    return ("#define WINO_KLOOP_CLOBBERS " + ", ".join(plain) + "\n" + "#define WINO_KLOOP_VA_CLOBBERS " + ", ".join(aff) + "\n")
 
 
 def generate() -> str:
     src = ("// generated by gen_wino_kloop.py -- do not edit.  Operand numbering: see V_OPS / U_OPS in the generator and the\n"
            "// asm statements in conv.hip.\n")
     src += as_macro("WINO_KLOOP_V_ASM", gen_role("V"))
+    src += as_macro("WINO_KLOOP_VA_ASM", gen_role("V", affine=True))
     src += as_macro("WINO_KLOOP_U_ASM", gen_role("U"))
     src += clobbers()
     if UDMA:

@@ -29,8 +29,9 @@ __device__ __forceinline__ Moments combine(Moments a, Moments b) {
   return r;
 }
 
-// Fast path: group size Cg % 4 == 0 and the slice of `qs` float4 channel-chunks divides 256.
-// grid = (nchunks, B, slices); slice z covers float4 chunks [z*256, z*256 + qs).
+// Fast path: group size Cg % 4 == 0; a slice = `qs` <= 256 float4 channel-chunks holding whole groups, qs | C / 4 (768 and
+// 1536 channels -- the ADM decoder's concatenations -- run as 192-chunk slices on 192 of the 256 threads).
+// grid = (nchunks, B, slices); slice z covers float4 chunks [z*qs, (z+1)*qs).
 // Two-source form: logical channels [0, c0s) live in x (stride c0s), [c0s, cs) in x1 (stride cs - c0s):
 // the skip concatenation of the ADM decoder (plugins/adm/_src/unet.py:631) is never materialised.
 __global__ __launch_bounds__(256) void gn_stats_vec_kernel(float* __restrict__ partials,
@@ -41,14 +42,14 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(float* __restrict__ p
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, b = blockIdx.y, z = blockIdx.z;
   const int Cg = C / groups;
-  const int cq = z * 256 + (tid % qs);  // float4 chunk index along channels
+  const int cq = z * qs + (tid % qs);   // float4 chunk index along channels
   const int pl = tid / qs;              // pixel lane
-  const int ppi = 256 / qs;             // pixels per iteration
+  const int ppi = 256 / qs;             // pixels per iteration (threads >= qs * ppi idle)
   const int64_t ppc = (HW + nchunks - 1) / nchunks;
   const int64_t p0 = (int64_t)chunk * ppc;
   const int64_t p1 = p0 + ppc < HW ? p0 + ppc : HW;
   const int c = cq * 4;
-  const bool live = c < C;
+  const bool live = c < C && pl < ppi;
   float s1 = 0.f, s2 = 0.f, cnt = 0.f, shift = 0.f;
   if (live) {
     const bool second = x1 != nullptr && c >= c0s;
@@ -95,12 +96,13 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(float* __restrict__ p
     sh_m2[tid] = acc.m2;
   }
   __syncthreads();
-  const int g_lo = (z * 1024) / Cg;
+  const int c_lo = z * qs * 4;
+  const int g_lo = c_lo / Cg;
   const int g = g_lo + tid;
-  const int c_hi = z * 1024 + qs * 4 < C ? z * 1024 + qs * 4 : C;
-  if (g < groups && g * Cg < c_hi && (g + 1) * Cg > z * 1024) {
-    // a group never straddles slices when Cg divides 1024 (checked on the host)
-    const int q_lo = (g * Cg) / 4 - z * 256, q_hi = ((g + 1) * Cg) / 4 - z * 256;
+  const int c_hi = c_lo + qs * 4 < C ? c_lo + qs * 4 : C;
+  if (g < groups && g * Cg < c_hi && (g + 1) * Cg > c_lo) {
+    // a group never straddles slices: Cg divides 4 qs (checked on the host)
+    const int q_lo = (g * Cg) / 4 - z * qs, q_hi = ((g + 1) * Cg) / 4 - z * qs;
     Moments acc = {0.f, 0.f, 0.f};
     for (int t = q_lo; t < q_hi; ++t) acc = combine(acc, Moments{sh_n[t], sh_mean[t], sh_m2[t]});
     float* out = partials + (((int64_t)b * nchunks + chunk) * groups + g) * 4;
@@ -463,10 +465,16 @@ int az_groupnorm_stats_f32(float* partials, const float* x, const float* x1, int
   AZ_REQUIRE(AZ_ALIGNED16(x), AZ_E_ALIGN);
   const int Cg = (int)(C / groups);
   const int q = (int)(cs / 4);
-  const int qs = q < 256 ? q : 256;
-  const bool fast = (Cg % 4 == 0) && (256 % qs == 0) && (q <= 256 || (q % 256 == 0 && 1024 % Cg == 0));
+  int qs = 0;  // float4 chunks per slice: the largest divisor of q, at most 256, that holds whole groups
+  if (Cg % 4 == 0 && C == cs) {
+    for (int d = q < 256 ? q : 256; d >= Cg / 4 && qs == 0; --d)
+      if (q % d == 0 && (4 * d) % Cg == 0) qs = d;
+  } else if (Cg % 4 == 0 && q <= 256) {
+    qs = q;  // (padded channel stride: one slice, the pad chunk is not live)
+  }
+  const bool fast = qs >= 32 || (qs > 0 && qs == q);  // (narrow slices of a wide tensor: the generic kernel)
   if (fast) {
-    dim3 grid((unsigned)nchunks, (unsigned)B, (unsigned)((q + 255) / 256));
+    dim3 grid((unsigned)nchunks, (unsigned)B, (unsigned)(q / qs));
     hipLaunchKernelGGL(gn_stats_vec_kernel, grid, dim3(256), 0, az_s(stream), partials, x, x1, (int)c0s, HW, (int)C,
                        (int)cs, (int)groups, (int)nchunks, qs);
   } else {

@@ -111,11 +111,13 @@ class Pool:
 class Act:
     r"""An NHWC activation: ``buf`` holds (B, H, W, cs) floats, ``C`` real channels."""
 
-    __slots__ = ("buf", "B", "H", "W", "C", "cs", "pinned", "gn_quads")
+    __slots__ = ("buf", "B", "H", "W", "C", "cs", "pinned", "gn_quads", "affine")
 
     def __init__(self, buf: torch.Tensor, B: int, H: int, W: int, C_: int, cs: int, pinned: bool = False) -> None:
         self.buf, self.B, self.H, self.W, self.C, self.cs, self.pinned = buf, B, H, W, C_, cs, pinned
         self.gn_quads = None  # (partials tensor, chunks per image): GroupNorm moments written by the producing conv
+        self.affine = None    # ([scale | shift] tensor, act): a normalisation whose apply pass has not run -- the values are
+        #                       act(buf * scale + shift); Builder.conv evaluates it inside the Winograd gather or materialises it
 
     @property
     def ptr(self) -> int:
@@ -135,6 +137,8 @@ X3_MIN_CHANNELS = 32  # bf16x3 only where both channel counts fill a K tile / an
 WINOGRAD4_MIN_TILES = int(os.environ.get("AZ_WINOGRAD4_MIN_TILES", "1024"))
 # GroupNorm statistics from the producing convolution's epilogue ("1", default) or always by the separate pass ("0")
 GN_FUSED = os.environ.get("AZ_GN_FUSED", "1") != "0"
+# GroupNorm apply pass (y = x * S + T) inside the consuming Winograd convolution's gather ("0": always the separate pass)
+AFFINE_FUSED = os.environ.get("AZ_AFFINE_FUSED", "1") != "0"
 GN_FUSED_SPLITK = os.environ.get("AZ_GN_FUSED", "1") != "epilogue"  # ("epilogue": only the Winograd epilogue's moments -- A/B)
 
 
@@ -399,6 +403,14 @@ class Builder:
             a.weight = packed.direct().data_ptr()
             a.splitk = lib.az_conv2d_suggest_splitk(npix, a.cout_s, cin_s, ks)
             name = "az_conv2d_f32"
+        tmp_src = None
+        if src0.affine is not None:  # a normalisation whose apply pass has not run (group_norm(lazy=True))
+            ST, in_act = src0.affine
+            if name == "az_conv2d_winograd_f32" and src1 is None and up0 == 0 and a.c0s % 8 == 0:
+                a.in_affine, a.in_act = ST.data_ptr(), in_act
+            else:
+                tmp_src = self.materialize(src0)
+                a.src0 = tmp_src.ptr
         if (gn_stats and GN_FUSED and name == "az_conv2d_winograd_f32" and a.splitk == 1 and out is not None and cout == a.cout_s
                 and cout % 64 == 0 and hout % 2 == 0 and wout % 2 == 0 and ((hout // 2) * (wout // 2)) % 64 == 0):
             # the output feeds a GroupNorm: its epilogue also writes per-(tile block, channel quad) moments
@@ -427,6 +439,8 @@ class Builder:
         a._flops = 2 * npix * cout * (src0.C + (src1.C if src1 is not None else 0)) * ks * ks  # algorithmic
         a._algo = name
         self.tape.add(name, C.byref(a), keep=[a] if gate is None else [gate, a])  # the descriptor holds raw addresses
+        if tmp_src is not None:
+            self.free(tmp_src)
         return out
 
     def upsample_nearest(self, x: Act, sh: int, sw: int, hout: int, wout: int) -> Act:
@@ -450,9 +464,17 @@ class Builder:
             bias.data_ptr() if bias is not None else None, M, N, K, in_act, out_act,
         )
 
+    def materialize(self, x: Act) -> Act:
+        r"""The apply pass of a lazy normalisation (``Act.affine``) as a tensor of its own."""
+        ST, act = x.affine
+        n = x.B * x.cs
+        y = self.new_act(x.B, x.H, x.W, x.C)
+        self.tape.add("az_affine_act_f32", y.ptr, x.ptr, None, 0, ST.data_ptr(), ST.data_ptr() + 4 * n, x.B, x.H, x.W, x.cs, act, 0)
+        return y
+
     def group_norm(
         self, x: Act, groups: int, *, weight=None, bias=None, scale=None, shift=None, scale_off=0, shift_off=0,
-        bstride=0, act=0, pool=0, eps=1e-5, x1: Act | None = None,
+        bstride=0, act=0, pool=0, eps=1e-5, x1: Act | None = None, lazy: bool = False,
     ) -> Act:
         r"""y = act((GN(x)*w + b) * (1 + scale) + shift), optionally 2x2 average pooled.  With ``x1`` the
         input is the channel concatenation [x | x1], read in place (never materialised)."""
@@ -464,7 +486,8 @@ class Builder:
             assert x.C == x.cs and x1.C == x1.cs and (x1.H, x1.W) == (x.H, x.W)
             x1p, c0s = x1.ptr, x.cs
             x = Act(x.buf, x.B, x.H, x.W, x.C + x1.C, x.cs + x1.cs, True)
-        S, T = self.empty(B * x.cs), self.empty(B * x.cs)
+        ST = self.empty(2 * B * x.cs)  # [scale | shift]: one buffer (AzConvArgs.in_affine reads both through one descriptor)
+        S, T = ST[: B * x.cs], ST[B * x.cs :]
         f = AzNormFinalizeArgs()
         Cg = x.C // groups
         fused = src_quads is not None and Cg % 4 == 0 and x.C == x.cs and all(q is not None for q in src_quads) \
@@ -488,6 +511,12 @@ class Builder:
         f.scale_bstride = bstride
         f.B, f.C, f.cs, f.groups, f.nchunks, f.eps = B, x.C, x.cs, groups, nchunks, eps
         self.tape.add("az_groupnorm_finalize_f32", C.byref(f), keep=[f])
+        if (lazy and AFFINE_FUSED and x1 is None and not pool and act == 0 and x.C == x.cs and x.cs % 8 == 0
+                and self.half is None):
+            # no apply pass: the consumer (Builder.conv) reads x and applies scale / shift itself
+            y = Act(x.buf, B, x.H, x.W, x.C, x.cs, True)
+            y.affine = (ST, act)
+            return y
         if pool:
             y = self.new_act(B, x.H // 2, x.W // 2, x.C)
         else:

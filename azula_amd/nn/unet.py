@@ -106,7 +106,7 @@ class UNetBlock(nn.Module):
         Cc, cs = self.channels, pad4(self.channels)
         abc, bstride = ada_zero_triple(bld, self.ada_zero, Cc, D, mod_rows, mod_jobs)
         if self.norm_kind == "group":
-            n_ = bld.group_norm(x, self.groups, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
+            n_ = bld.group_norm(x, self.groups, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride, lazy=True)
         else:
             n_ = bld.row_norm(x, 0 if self.norm_kind == "layer" else 1, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
         c0, c3 = self.ffn[0], self.ffn[3]

@@ -254,7 +254,24 @@ def transition_roofline(device):
                           frac=round(gbs / PEAK_HBM_GBS, 4), avg_us=round(ms * 1e3, 2), elements=n,
                           algorithmic_bytes=alg, bytes_per_element=alg // n, layout_bytes=moved, traffic=None, note=note,
                           reps=reps, frac_min_median_max=[round(alg / (t * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) for t in (times[-1], ms, times[0])])
-    del cases, keep
+    # what a plain copy reaches on THIS box for the same bytes (the practical ceiling of a streaming kernel: the guide
+    # quotes 6.29 TB/s for a float4 copy; boxes measured here 5.4 .. 5.6 at sizes that defeat the Infinity Cache)
+    src = torch.empty(2 * n, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(9)]
+    for e0, e1 in evs:
+        e0.record(stream)
+        dst.copy_(src)
+        e1.record(stream)
+    torch.cuda.synchronize(device)
+    ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[4]
+    gbs = 16 * n / (ms * 1e-3) / 1e9
+    out["copy_same_bytes"] = dict(bound="hbm", kernel="torch Tensor.copy_ (device to device), 16 B/element: the image form's algorithmic bytes",
+                                  achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
+                                  avg_us=round(ms * 1e3, 2), elements=n)
+    del cases, keep, src, dst
     torch.cuda.empty_cache()
     return out
 

@@ -286,6 +286,13 @@ typedef struct AzConvArgs {
                             * (az_conv2d_f32 / _bf16_f32 / _f16_f32 / _x3_f32) only: the Winograd entries return UNSUPPORTED */
   int32_t stride_w;        /* with aniso: stride along the width (`stride` is then the height's) */
   int32_t up0_w, up1_w;    /* with aniso: log2 upsampling of each source along the width */
+  const float* in_affine;  /* optional, az_conv2d_winograd_f32 only: (2, batch, c0s) floats [scale | shift]; the convolution's input
+                            * is x * scale[b, c] + shift[b, c] (in_act 1: SiLU of that), evaluated on the raw patch values inside the gather --
+                            * the GroupNorm apply pass that would write the normalised tensor (az_affine_act_f32) disappears.
+                            * Padding stays ZERO (the reference pads the normalised tensor: azula/nn/unet.py:85-92,
+                            * plugins/adm/_src/unet.py:196-203).  Needs a single source, c0s % 8 == 0, up0 == 0 */
+  int32_t in_act;          /* with in_affine: 0 none, 1 SiLU */
+  int32_t reserved1;
 } AzConvArgs;
 /* Narrow outputs (cout_s == 4, 3x3 stride 1 pad 1, one un-upsampled source with c0s % 16 == 0: the image head of
  * azula/nn/unet.py) run a VALU kernel instead of the 128-cout MFMA tile; splitk is ignored there.              */

@@ -270,7 +270,9 @@ def test_linear_small_grouped(az, M, in_act):
 
 @pytest.mark.parametrize(
     "B,Cc,H,W,groups",
-    [(2, 32, 16, 16, 8), (2, 8, 16, 16, 8), (1, 12, 9, 7, 3), (2, 256, 32, 32, 32), (1, 2048, 8, 8, 32), (3, 64, 64, 64, 32)],
+    [(2, 32, 16, 16, 8), (2, 8, 16, 16, 8), (1, 12, 9, 7, 3), (2, 256, 32, 32, 32), (1, 2048, 8, 8, 32), (3, 64, 64, 64, 32),
+     # slices that do not divide 256 threads: 192 float4 chunks (ADM's 768 = 512 + 256), 2 x 192 (1536), 24, 2 x 160 (1280)
+     (2, 768, 16, 16, 32), (1, 1536, 8, 8, 32), (2, 96, 16, 16, 8), (1, 1280, 8, 8, 32), (1, 1152, 8, 8, 32)],
 )
 @pytest.mark.parametrize("affine,mod", [(False, True), (True, True), (True, False)])
 def test_groupnorm_mod_silu(az, B, Cc, H, W, groups, affine, mod):
@@ -297,6 +299,25 @@ def test_groupnorm_mod_silu(az, B, Cc, H, W, groups, affine, mod):
     out = from_nhwc(y.buf.reshape(B, H, W, cs), Cc)
     assert max_err(out, ref) < 2e-5
     assert (y.buf.reshape(B, H, W, cs)[..., Cc:] == 0).all()
+
+
+@pytest.mark.parametrize("c0,c1,groups", [(512, 256, 32), (1024, 512, 32), (64, 32, 8), (256, 256, 32)])
+def test_groupnorm_two_sources(az, c0, c1, groups):
+    """GroupNorm over the channel concatenation [x | x1] read in place (plugins/adm/_src/unet.py:631), separate statistics pass."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(c0 + c1)
+    B, H, W = 2, 8, 8
+    x, x1 = torch.randn(B, c0, H, W, generator=g) + 0.5, torch.randn(B, c1, H, W, generator=g) * 2.0 - 1.0
+    w, b = torch.randn(c0 + c1, generator=g), torch.randn(c0 + c1, generator=g)
+    ref = F.silu(F.group_norm(torch.cat((x, x1), 1), groups, w, b, eps=1e-5))
+    bld = Builder(torch.device("cuda"))
+    xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, c0, c0, True)
+    xb = Act(to_nhwc(dev(x1)).reshape(-1), B, H, W, c1, c1, True)
+    y = bld.group_norm(xa, groups, weight=dev(w), bias=dev(b), act=1, x1=xb)
+    assert "az_groupnorm_stats_f32" in [n for _, _, n in bld.tape.ops]
+    bld.tape.run()
+    assert max_err(from_nhwc(y.buf.reshape(B, H, W, c0 + c1), c0 + c1), ref) < 2e-5
 
 
 def test_groupnorm_avgpool(az):
@@ -508,6 +529,56 @@ def test_winograd_stream_fuzz(az):
         out = from_nhwc(y.buf.reshape(B, H, W, y.cs), Cout)
         err = max_err(out, ref)
         assert err < conv_tol(C0 + C1, 3, True) * max(1.0, ref.abs().max().item()), (case, B, H, W, C0, C1, Cout, periodic, up, splitk, err)
+
+
+@pytest.mark.parametrize("asm", ["1", "0"])
+@pytest.mark.parametrize("in_act", [0, 1])
+def test_winograd_input_affine(az, asm, in_act, monkeypatch):
+    """AzConvArgs.in_affine: conv(act(x * scale[b, c] + shift[b, c])) with the affine evaluated inside the Winograd gather
+    (the GroupNorm apply pass, fused: azula/nn/unet.py:85-92).  Zero padding pads the NORMALISED tensor; circular padding
+    wraps it.  24 seeded cases: 1 .. 20 stages, ragged tile blocks, tile blocks that span several images, split-K slices, both
+    K loops (the hand-scheduled stream / the C++ loop)."""
+    import random
+
+    from azula_amd.engine import Act, Builder
+
+    monkeypatch.setenv("AZ_WINOGRAD_ASM", asm)
+    rnd = random.Random(77 + in_act)
+    g = torch.Generator().manual_seed(77 + in_act)
+    for case in range(24):
+        B = rnd.randint(1, 5)
+        H, W = rnd.choice([(4, 4), (6, 10), (16, 16), (9, 7), (24, 20), (32, 32)])
+        C0 = 8 * rnd.choice([1, 2, 3, 5, 8, 20])
+        Cout = rnd.choice([8, 24, 64, 72, 130])
+        periodic = rnd.random() < 0.3
+        splitk = rnd.choice([0, 0, 2, 3])
+        x = torch.randn(B, C0, H, W, generator=g) * 2.0 + 1.0
+        sc, sh = torch.randn(B, C0, generator=g), torch.randn(B, C0, generator=g) * 3.0  # (shift != 0: padding must stay zero)
+        w = torch.randn(Cout, C0, 3, 3, generator=g) / math.sqrt(9 * C0)
+        b = torch.randn(Cout, generator=g)
+        n = x * sc[:, :, None, None] + sh[:, :, None, None]
+        if in_act:
+            n = F.silu(n)
+        ref = F.conv2d(F.pad(n, (1, 1, 1, 1), mode="circular"), w, b) if periodic else F.conv2d(n, w, b, padding=1)
+        bld = Builder(torch.device("cuda"))
+        a0 = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, C0, C0, True)
+        a0.affine = (dev(torch.cat((sc.reshape(-1), sh.reshape(-1)))), in_act)
+        y = bld.conv(a0, bld.pack_conv(dev(w), dev(b)), Cout, winograd=True, periodic=periodic)
+        assert [nm for _, _, nm in bld.tape.ops] == ["az_conv2d_winograd_f32"]  # no apply pass
+        if splitk:
+            a = bld.tape.keep[-1]
+            a.splitk = splitk
+            bld._ws_need = max(bld._ws_need, splitk * B * H * W * y.cs)
+            bld._ws_users.append(a)
+        bld.finish()
+        bld.tape.run()
+        out = from_nhwc(y.buf.reshape(B, H, W, y.cs), Cout)
+        err = max_err(out, ref)
+        assert err < conv_tol(C0, 3, True) * max(1.0, ref.abs().max().item(), n.abs().max().item()), (case, B, H, W, C0, Cout, periodic, splitk, err)
+    # every other entry point rejects the field instead of ignoring it
+    a = bld.tape.keep[-1]
+    a.splitk = 1
+    assert az.lib().az_conv2d_f32(C.byref(a), az.stream_ptr()) == -4  # AZ_E_UNSUPPORTED
 
 
 @pytest.mark.parametrize("wino", [False, True, 4, "x3"])
