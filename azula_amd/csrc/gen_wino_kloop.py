@@ -177,29 +177,41 @@ def v_affine_loads(tag, back=0):
     return L
 
 
+OOL_EVENTS = os.environ.get("KL_OOL_EVENTS", "1") == "1"  # events out of line: the common path takes no branch
+
+
 def v_load_events(tag):
     r"""Before the loads of stage s_kt: switch to the second source (descriptor, patch offsets from LDS, channel offset 0)
-    and / or mask the channel pairs beyond a source's last (half) chunk."""
+    and / or mask the channel pairs beyond a source's last (half) chunk.  Both are rare: their code sits behind the stream's
+    last instruction, so that the common path falls through untaken branches."""
     o = V_OPS
+    sw = [f"s_mov_b32 s{S_RS + w}, %{o['rs1'] + w}" for w in range(4)] + [f"s_mov_b32 s{S_SOFF}, 0"]
+    sw += [f"ds_read_b128 {quad(VO0 + 4 * q)}, %{o['ldsB']} offset:{16 * q}" for q in range(4)] + ["s_waitcnt lgkmcnt(0)"]
+    tl = ["s_mov_b32 vcc_lo, 0x33333333", "s_mov_b32 vcc_hi, 0x33333333"]
+    tl += [f"v_cndmask_b32 v{VO0 + i}, v{V_OOB}, v{VO0 + i}, vcc" for i in range(16)]
     L = []
+    if OOL_EVENTS:
+        L.append(("salu", f"s_cmp_eq_u32 s{S_KT}, %{o['kt_switch']}"))
+        L.append(("salu", f"s_cbranch_scc1 LVsw{tag}_%="))
+        L.append(("label", f"LVnsw{tag}_%=:"))
+        L.append(("salu", f"s_cmp_eq_u32 s{S_KT}, %{o['tail0']}"))
+        L.append(("salu", f"s_cbranch_scc1 LVtl{tag}_%="))
+        L.append(("salu", f"s_cmp_eq_u32 s{S_KT}, %{o['tail1']}"))
+        L.append(("salu", f"s_cbranch_scc1 LVtl{tag}_%="))
+        L.append(("label", f"LVntl{tag}_%=:"))
+        OOL.append([f"LVsw{tag}_%=:"] + sw + [f"s_branch LVnsw{tag}_%="])
+        OOL.append([f"LVtl{tag}_%=:"] + tl + [f"s_branch LVntl{tag}_%="])
+        return L
     L.append(("salu", f"s_cmp_eq_u32 s{S_KT}, %{o['kt_switch']}"))
     L.append(("salu", f"s_cbranch_scc0 LVnsw{tag}_%="))
-    for w in range(4):
-        L.append(("salu", f"s_mov_b32 s{S_RS + w}, %{o['rs1'] + w}"))
-    L.append(("salu", f"s_mov_b32 s{S_SOFF}, 0"))
-    for q in range(4):
-        L.append(("ldsx", f"ds_read_b128 {quad(VO0 + 4 * q)}, %{o['ldsB']} offset:{16 * q}"))
-    L.append(("ldsx", "s_waitcnt lgkmcnt(0)"))
+    L += [("ldsx", t) for t in sw]
     L.append(("label", f"LVnsw{tag}_%=:"))
     L.append(("salu", f"s_cmp_eq_u32 s{S_KT}, %{o['tail0']}"))
     L.append(("salu", f"s_cbranch_scc1 LVtl{tag}_%="))
     L.append(("salu", f"s_cmp_eq_u32 s{S_KT}, %{o['tail1']}"))
     L.append(("salu", f"s_cbranch_scc0 LVntl{tag}_%="))
     L.append(("label", f"LVtl{tag}_%=:"))
-    L.append(("salu", "s_mov_b32 vcc_lo, 0x33333333"))
-    L.append(("salu", "s_mov_b32 vcc_hi, 0x33333333"))
-    for i in range(16):
-        L.append(("valu", f"v_cndmask_b32 v{VO0 + i}, v{V_OOB}, v{VO0 + i}, vcc"))
+    L += [("valu", t) for t in tl]
     L.append(("label", f"LVntl{tag}_%=:"))
     return L
 
