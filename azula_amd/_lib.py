@@ -234,6 +234,7 @@ PROTOTYPES: dict[str, list] = {
     "az_timestep_embedding_f32": [vp, i64, vp, i64, i64, i32, f32, c_stream],
     "az_linear_small_grouped_f32": [vp, i32, i32, i64, i32, i32, c_stream],
     "az_conv2d_f32": [C.POINTER(AzConvArgs), c_stream],
+    "az_conv2d_stem_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_bf16_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_x3_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_f16_f32": [C.POINTER(AzConvArgs), c_stream],

@@ -1197,6 +1197,128 @@ __global__ __launch_bounds__(256) void conv_head_kernel(ConvP p, int tiles_x, in
   epilogue_store_b(a, n, b, 0, make_float4(o[0], o[1], o[2], o[3]));
 }
 
+// =================================================================================================
+// Image stem: 3x3, stride 1, pad 1 convolution of a PLANAR source with <= 4 channels (the latent itself: (B, C, H, W) as the
+// sampler holds it) into the NHWC activation.  27 multiplies per output: no matrix work (the Winograd kernel spent 144 us of a
+// C2 step on its one-stage K loop here; the store of 4 x 256 x 256 x 256 floats alone is 50 us).  A wave owns 64 channel
+// quads (256 output channels) with their 27 float4 of weights in registers and walks the pixels of its part of an 8 x 32
+// pixel tile, four at a time (the 3 x 6 window of a channel is read once per four pixels): lanes = consecutive channels, so a
+// store is one contiguous 1 KB line, and the input values are wave-uniform (LDS broadcast reads).  Packed fp32 FMAs
+// (2 x 27 per pixel and quad).  The GroupNorm moments of the output (AzConvArgs.gn_quads) cost 10 VALU per pixel: a lane keeps
+// its quad for all its pixels (pivoted sums), the four waves of a tile are folded through LDS in a fixed order.
+// Because the source is the latent's own layout, the sampling loop needs no NHWC copy of it: the transition kernel writes
+// c_in' x_s planar (its flat form, 16 B per element, no pad channel).
+constexpr int ST_TH = 8, ST_TW = 32;  // pixel tile of a workgroup
+template <int CI>
+__global__ __launch_bounds__(256) void conv_stem_kernel(ConvP p, int tiles_w, int tiles_img) {
+  __shared__ float xs[CI][ST_TH + 2][ST_TW + 4];
+  __shared__ float red[3][4][64];
+  const AzConvArgs& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / tiles_img;
+  const int t = blockIdx.x - b * tiles_img;
+  const int th = t / tiles_w, tw = t - th * tiles_w;
+  const int H = a.hin, W = a.win;
+  for (int e = tid; e < CI * (ST_TH + 2) * (ST_TW + 2); e += 256) {
+    const int c = e / ((ST_TH + 2) * (ST_TW + 2));
+    const int r2 = e - c * ((ST_TH + 2) * (ST_TW + 2));
+    const int r = r2 / (ST_TW + 2), col = r2 - r * (ST_TW + 2);
+    const int ih = wrap_coord(th * ST_TH - 1 + r, H, a.pad_mode);
+    const int iw = wrap_coord(tw * ST_TW - 1 + col, W, a.pad_mode);
+    const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    xs[c][r][col] = ok ? a.src0[(((int64_t)b * CI + c) * H + ih) * W + iw] : 0.f;
+  }
+  __syncthreads();
+  const int Q = a.cout_s / 4;
+  for (int q0 = 0; q0 < Q; q0 += 64) {
+    const int q = q0 + lane;
+    const bool live = q < Q;
+    f32x2 w[9 * CI][2];
+#pragma unroll
+    for (int k = 0; k < 9 * CI; ++k) {
+      const float4 v = live ? ld4(a.weight + (int64_t)k * a.cout_s + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      w[k][0] = f32x2{v.x, v.y};
+      w[k][1] = f32x2{v.z, v.w};
+    }
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias && live) bv = ld4(a.bias + q * 4);
+    float cnt = 0.f, pivot = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int g = 0; g < 16; ++g) {  // the wave's rows 2 wave, 2 wave + 1; 8 groups of 4 pixels per row
+      const int r = 2 * wave + (g >> 3), c0 = (g & 7) * 4;
+      const int oh = th * ST_TH + r;
+      if (oh >= H || tw * ST_TW + c0 >= W) continue;  // (wave-uniform)
+      f32x2 acc[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j][0] = f32x2{bv.x, bv.y}, acc[j][1] = f32x2{bv.z, bv.w};
+#pragma unroll
+      for (int c = 0; c < CI; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          float xv[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) xv[i] = xs[c][r + ky][c0 + i];
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int k = (ky * 3 + kx) * CI + c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x2 x2 = f32x2{xv[j + kx], xv[j + kx]};
+              acc[j][0] = __builtin_elementwise_fma(w[k][0], x2, acc[j][0]);
+              acc[j][1] = __builtin_elementwise_fma(w[k][1], x2, acc[j][1]);
+            }
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ow = tw * ST_TW + c0 + j;
+        if (ow >= W || !live) continue;
+        float4 o = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+        if (a.act == 1) o = make_float4(az_silu(o.x), az_silu(o.y), az_silu(o.z), az_silu(o.w));
+        *reinterpret_cast<float4*>(a.dst + (((int64_t)b * H + oh) * W + ow) * a.cout_s + q * 4) = o;
+        if (a.gn_quads != nullptr) {
+          if (cnt == 0.f) pivot = o.x;
+          const float d0 = o.x - pivot, d1 = o.y - pivot, d2 = o.z - pivot, d3 = o.w - pivot;
+          s1 += (d0 + d1) + (d2 + d3);
+          s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          cnt += 4.f;
+        }
+      }
+    }
+    if (a.gn_quads != nullptr) {  // (n, mean, M2) per lane, then waves 1..3 into wave 0 (Chan, fixed order)
+      float mean = 0.f, m2 = 0.f;
+      if (cnt > 0.f) {
+        mean = pivot + s1 / cnt;
+        m2 = s2 - s1 * s1 / cnt;
+      }
+      __syncthreads();
+      red[0][wave][lane] = cnt;
+      red[1][wave][lane] = mean;
+      red[2][wave][lane] = m2;
+      __syncthreads();
+      if (wave == 0 && live) {
+        for (int k = 1; k < 4; ++k) {
+          const float nb = red[0][k][lane], mb = red[1][k][lane], vb = red[2][k][lane];
+          if (nb > 0.f) {
+            if (cnt > 0.f) {
+              const float nn = cnt + nb, d = mb - mean;
+              mean = mean + d * (nb / nn);
+              m2 = (m2 + vb) + d * d * (cnt * nb / nn);
+              cnt = nn;
+            } else {
+              cnt = nb, mean = mb, m2 = vb;
+            }
+          }
+        }
+        float* out = a.gn_quads + (((int64_t)b * tiles_img + t) * Q + q) * 4;
+        out[0] = cnt;
+        out[1] = mean;
+        out[2] = m2;
+        out[3] = 0.f;
+      }
+    }
+  }
+}
+
 // Split-K combine + epilogue: one thread per (pixel, 4 channels).
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvP p) {
   const AzConvArgs& a = p.a;
@@ -2189,6 +2311,36 @@ static int launch_splitk_reduce(const ConvP& cp, hipStream_t st) {
 static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half /* 0 fp32, 1 bf16, 2 f16 operands, 3 fp32 as 3 x bf16 */);
 
 int az_conv2d_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 0); }
+
+/* Image stem (conv_stem_kernel): src0 = (batch, c0s, hin, win) PLANAR fp32 with c0s in 1..4 channels, weight =
+ * (3, 3, c0s, cout_s) floats (tap-major, output channels contiguous), 3x3 / stride 1 / pad 1 (zero or circular), optional
+ * bias, act 0 / 1, NHWC destination, optional gn_quads with gn_chunks = ceil(hin / 8) * ceil(win / 32) partials per image. */
+int az_conv2d_stem_f32(const AzConvArgs* a, az_stream_t stream) {
+  AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
+  AZ_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->aniso && !a->src1 && a->c1s == 0 && a->up0 == 0 && !a->gate &&
+                 !a->res && !a->dst_nchw && !a->in_affine && a->splitk <= 1 && (a->act == 0 || a->act == 1),
+             AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(a->c0s >= 1 && a->c0s <= 4 && a->cout_s > 0 && a->cout_s % 4 == 0 && a->batch > 0 && a->hin > 0 && a->win > 0 &&
+                 a->hout == a->hin && a->wout == a->win && a->h0 == a->hin && a->w0 == a->win,
+             AZ_E_SHAPE);
+  AZ_REQUIRE((int64_t)a->batch * a->hin * a->win * a->cout_s < (1ll << 40), AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(a->weight) && AZ_ALIGNED16(a->bias) && AZ_ALIGNED16(a->dst) && AZ_ALIGNED16(a->gn_quads), AZ_E_ALIGN);
+  const int tiles_h = (a->hin + ST_TH - 1) / ST_TH, tiles_w = (a->win + ST_TW - 1) / ST_TW;
+  const int tiles_img = tiles_h * tiles_w;
+  AZ_REQUIRE((int64_t)a->batch * tiles_img < (1ll << 31), AZ_E_SHAPE);
+  if (a->gn_quads) AZ_REQUIRE(a->gn_chunks == tiles_img, AZ_E_SHAPE);
+  ConvP p{};
+  p.a = *a;
+  const dim3 grid((unsigned)(a->batch * tiles_img));
+  hipStream_t st = az_s(stream);
+  switch (a->c0s) {
+    case 1: hipLaunchKernelGGL(conv_stem_kernel<1>, grid, dim3(256), 0, st, p, tiles_w, tiles_img); break;
+    case 2: hipLaunchKernelGGL(conv_stem_kernel<2>, grid, dim3(256), 0, st, p, tiles_w, tiles_img); break;
+    case 3: hipLaunchKernelGGL(conv_stem_kernel<3>, grid, dim3(256), 0, st, p, tiles_w, tiles_img); break;
+    default: hipLaunchKernelGGL(conv_stem_kernel<4>, grid, dim3(256), 0, st, p, tiles_w, tiles_img); break;
+  }
+  return az_launch_status();
+}
 
 /* Same operation with bf16 / f16 MFMA operands and fp32 accumulation: `weight` is the 2-byte packing of
  * az_pack_conv_weight_half_f32, activations and outputs stay fp32 (rounded to the operand type inside the kernel).

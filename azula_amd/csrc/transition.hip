@@ -64,7 +64,17 @@ __global__ __launch_bounds__(256) void transition_flat_kernel(const float* __res
                                                               const float* __restrict__ Fn,
                                                               const float* __restrict__ eps, float* x_s,
                                                               float* __restrict__ xin, float* __restrict__ mean_out,
-                                                              int64_t n4, int64_t n, const AzStepCoef* coef) {
+                                                              int64_t n4, int64_t n, const AzStepCoef* coef,
+                                                              int64_t xstep, int64_t fstep) {
+  // blockIdx.y = image, only when F carries more planar channels per image than x (ADM: 6, the first 3 are read): every
+  // image is then a flat problem of its own (xstep / fstep elements apart); otherwise gridDim.y = 1 and the steps are 0
+  x_t += blockIdx.y * xstep;
+  x_s += blockIdx.y * xstep;
+  F += blockIdx.y * fstep;
+  if (CFG) Fn += blockIdx.y * fstep;
+  if (EPS) eps += blockIdx.y * xstep;
+  if (XIN) xin += blockIdx.y * xstep;
+  if (MEAN) mean_out += blockIdx.y * xstep;
   const Coef k = load_coef(coef);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   auto one = [&](int64_t i, float4 xv, float4 fv, float4 nv, float4 ev) {
@@ -512,15 +522,20 @@ __global__ __launch_bounds__(256) void scale_f64_to_f32_kernel(float* __restrict
 
 template <bool CFG, bool EPS>
 int launch_flat(const AzTransitionArgs* a, int64_t n, hipStream_t st) {
+  const bool per_image = a->f_channels != a->channels;
+  const int64_t xstep = per_image ? a->channels * a->inner : 0, fstep = per_image ? a->f_channels * a->inner : 0;
+  const unsigned gy = per_image ? (unsigned)a->batch : 1u;
+  if (per_image) n = xstep;
   const int64_t n4 = n / 4;
   // one workgroup per TF_UN * 256 float4 (16 KB of every stream), at most 16384 of them (measured: 5.6-5.75 TB/s from
   // 512 workgroups up; the fewest loop iterations win by a little)
   int64_t g64 = (n4 + TF_UN * 256 - 1) / (TF_UN * 256);
-  const int grid = (int)(g64 < 1 ? 1 : (g64 > 16384 ? 16384 : g64));
+  const int64_t gcap = 16384 / gy < 1 ? 1 : 16384 / gy;
+  const int grid = (int)(g64 < 1 ? 1 : (g64 > gcap ? gcap : g64));
   const bool xin = a->xin_next != nullptr, mean = a->mean_out != nullptr;
 #define AZ_FLAT(X, M)                                                                                          \
-  hipLaunchKernelGGL((transition_flat_kernel<CFG, EPS, X, M>), dim3(grid), dim3(256), 0, st, a->x_t, a->F, a->F_neg, \
-                     a->eps, a->x_s, a->xin_next, a->mean_out, n4, n, a->coef)
+  hipLaunchKernelGGL((transition_flat_kernel<CFG, EPS, X, M>), dim3(grid, gy), dim3(256), 0, st, a->x_t, a->F, a->F_neg, \
+                     a->eps, a->x_s, a->xin_next, a->mean_out, n4, n, a->coef, xstep, fstep)
   if (xin && mean) AZ_FLAT(true, true);
   else if (xin) AZ_FLAT(true, false);
   else if (mean) AZ_FLAT(false, true);
@@ -580,7 +595,9 @@ int az_transition_f32(const AzTransitionArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->batch > 0 && a->channels > 0 && a->inner > 0 && a->f_channels >= a->channels, AZ_E_SHAPE);
   const int64_t n = a->batch * a->channels * a->inner;
   const bool cfg = a->F_neg != nullptr, eps = a->eps != nullptr;
-  const bool flat = !a->f_nhwc && a->nhwc_pad == 0 && a->f_channels == a->channels;
+  // flat: every tensor planar in x's layout; F may carry more channels per image if the images stay 16-byte aligned
+  const bool flat = !a->f_nhwc && a->nhwc_pad == 0 &&
+                    (a->f_channels == a->channels || ((a->channels * a->inner) % 4 == 0 && (a->f_channels * a->inner) % 4 == 0 && a->batch < 65536));
   AZ_REQUIRE(AZ_ALIGNED16(a->x_t) && AZ_ALIGNED16(a->F) && AZ_ALIGNED16(a->x_s), AZ_E_ALIGN);
   AZ_REQUIRE(AZ_ALIGNED16(a->F_neg) && AZ_ALIGNED16(a->eps) && AZ_ALIGNED16(a->xin_next) && AZ_ALIGNED16(a->mean_out),
              AZ_E_ALIGN);

@@ -138,6 +138,8 @@ WINOGRAD4_MIN_TILES = int(os.environ.get("AZ_WINOGRAD4_MIN_TILES", "1024"))
 # GroupNorm statistics from the producing convolution's epilogue ("1", default) or always by the separate pass ("0")
 GN_FUSED = os.environ.get("AZ_GN_FUSED", "1") != "0"
 # GroupNorm apply pass (y = x * S + T) inside the consuming Winograd convolution's gather ("0": always the separate pass)
+# The first convolution reads the latent planar (az_conv2d_stem_f32) instead of an NHWC copy of it ("0": the NHWC path)
+STEM_PLANAR = os.environ.get("AZ_STEM_PLANAR", "1") != "0"
 AFFINE_FUSED = os.environ.get("AZ_AFFINE_FUSED", "1") != "0"
 GN_FUSED_SPLITK = os.environ.get("AZ_GN_FUSED", "1") != "epilogue"  # ("epilogue": only the Winograd epilogue's moments -- A/B)
 
@@ -188,6 +190,14 @@ class ConvWeights:
             )
             self._direct = packed
         return self._direct
+
+    def stem(self) -> torch.Tensor:
+        r"""(3, 3, cin, cout_s): tap-major, output channels contiguous (``az_conv2d_stem_f32``)."""
+        if getattr(self, "_stem", None) is None:
+            w = torch.zeros(self.ks, self.ks, self.cin, self.cout_s, dtype=torch.float32, device=self.device)
+            w[..., : self.cout] = self.w.permute(2, 3, 1, 0)
+            self._stem = w.contiguous()
+        return self._stem
 
     def direct_half(self, f16: bool) -> torch.Tensor:
         r"""The direct layout in bf16 (``f16=False``) or IEEE half, for ``az_conv2d_{bf16,f16}_f32``."""
@@ -441,6 +451,31 @@ class Builder:
         self.tape.add(name, C.byref(a), keep=[a] if gate is None else [gate, a])  # the descriptor holds raw addresses
         if tmp_src is not None:
             self.free(tmp_src)
+        return out
+
+    def conv_stem(self, x: torch.Tensor, B: int, cin: int, H: int, W: int, packed: "ConvWeights", cout: int, *,
+                  periodic: bool = False, gn_stats: bool = False) -> Act:
+        r"""The network's first 3 x 3 convolution reading its <= 4 input channels PLANAR -- ``x`` is the (B, cin, H, W) latent
+        as the sampler holds it (``az_conv2d_stem_f32``): no NHWC copy of the latent, no matrix kernel for 27 multiplies."""
+        assert packed.ks == 3 and 1 <= cin <= 4 and packed.cin == cin and cout % 4 == 0 and self.half is None
+        a = AzConvArgs()
+        a.src0, a.c0s, a.h0, a.w0 = x.data_ptr(), cin, H, W
+        a.batch, a.hin, a.win, a.hout, a.wout = B, H, W, H, W
+        a.weight = packed.stem().data_ptr()
+        a.bias = packed.bias.data_ptr() if packed.bias is not None else None
+        a.cout_s, a.ksize, a.stride, a.pad, a.splitk = cout, 3, 1, 1, 1
+        a.pad_mode = 1 if periodic else 0
+        out = self.new_act(B, H, W, cout)
+        a.dst = out.ptr
+        if gn_stats and GN_FUSED:
+            chunks = ((H + 7) // 8) * ((W + 31) // 32)
+            quads = torch.empty(B * chunks * (cout // 4) * 4, dtype=torch.float32, device=self.device)
+            a.gn_quads, a.gn_chunks = quads.data_ptr(), chunks
+            out.gn_quads = (quads, chunks)
+            self.tape.keep.append(quads)
+        a._flops = 0  # (27 multiplies per output on the vector ALUs: a store-bound pass, accounted by its bytes in bench.py)
+        a._algo = "az_conv2d_stem_f32"
+        self.tape.add("az_conv2d_stem_f32", C.byref(a), keep=[a, x])
         return out
 
     def upsample_nearest(self, x: Act, sh: int, sw: int, hout: int, wout: int) -> Act:

@@ -24,7 +24,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from ..engine import Act, Builder, Tape, ada_zero_triple, mod_front_tape, pad4
-from .. import _lib
+from .. import _lib, engine
 
 __all__ = ["UNet", "UNetBlock"]
 
@@ -224,7 +224,15 @@ class UNetPlan:
         bld = self.bld = Builder(device, half=next(net.parameters()).dtype)
         cin = net.in_channels + net.cond_channels
         D = net.mod_features
-        self.x_in = Act(torch.empty(B * H * W * pad4(cin), dtype=torch.float32, device=device), B, H, W, cin, pad4(cin), True)
+        first = net.descent[0][0]
+        # <= 4 input channels through a 3 x 3 first convolution: it reads the latent PLANAR (x_in is then the loop's own
+        # (B, C, H, W) layout: channel stride 0 in the fused protocol), see Builder.conv_stem
+        self.planar = (engine.STEM_PLANAR and net.spatial == 2 and cin <= 4 and tuple(first.weight.shape[2:]) == (3, 3)
+                       and first.out_channels % 4 == 0 and bld.half is None)
+        if self.planar:
+            self.x_in = Act(torch.empty(B * cin * H * W, dtype=torch.float32, device=device), B, H, W, cin, 0, True)
+        else:
+            self.x_in = Act(torch.empty(B * H * W * pad4(cin), dtype=torch.float32, device=device), B, H, W, cin, pad4(cin), True)
         self.mod = torch.empty(max(mod_rows, 1), max(D, 1), dtype=torch.float32, device=device)
         self.mod_rows = mod_rows
         self.out = torch.empty(B, net.out_channels, H, W, dtype=torch.float32, device=device)
@@ -252,8 +260,12 @@ class UNetPlan:
             first = net.descent[i][0]
             if i > 0:
                 skips.append(cur)  # output of level i-1 = memory entry (unet.py:226-230)
-            nxt = bld.conv(cur, bld.pack_conv(first.weight, first.bias), first.out_channels, stride=stride if i > 0 else 1, periodic=per,
-                           gn_stats=gn)
+            if i == 0 and self.planar:
+                nxt = bld.conv_stem(cur.buf, B, cin, H, W, bld.pack_conv(first.weight, first.bias), first.out_channels, periodic=per,
+                                    gn_stats=gn)
+            else:
+                nxt = bld.conv(cur, bld.pack_conv(first.weight, first.bias), first.out_channels, stride=stride if i > 0 else 1,
+                               periodic=per, gn_stats=gn)
             cur = nxt
             for j in range(net.hid_blocks[i]):
                 cur = block(net.descent[i][1 + j], cur, keep_input=False)
@@ -467,7 +479,10 @@ class UNet(nn.Module):
             rows = 0
         p = self.plan(B, H, W, rows, x.device)
         s = _lib.stream_ptr()
-        _lib.call("az_nchw_to_nhwc_f32", p.x_in.ptr, x.data_ptr(), None, B, Cin, H * W, p.x_in.cs, s)
+        if p.planar:
+            p.x_in.buf.copy_(x.reshape(-1))
+        else:
+            _lib.call("az_nchw_to_nhwc_f32", p.x_in.ptr, x.data_ptr(), None, B, Cin, H * W, p.x_in.cs, s)
         if rows:
             p.mod.copy_(mod.reshape(rows, -1))
         p.tape.run(s)

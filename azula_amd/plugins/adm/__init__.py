@@ -197,7 +197,7 @@ class AblatedDenoiser(Denoiser):
             return None
         B, _, H, W = x.shape
         plan = bb.plan(2 * B, H, W, 2 * B, x.device, coef_ptr=cur_coef.data_ptr(), tag="cfg2b")
-        half_in = B * H * W * plan.x_in.cs
+        half_in = B * H * W * (plan.x_in.cs if plan.x_in.cs > 0 else plan.x_in.C)  # (channel stride 0: the planar latent layout)
         one = torch.ones(1, dtype=torch.float32, device=x.device)
         tape = Tape()
         tape.add("az_scale_f32", plan.x_in.ptr + 4 * half_in, plan.x_in.ptr, one.data_ptr(), half_in, keep=[one, plan])

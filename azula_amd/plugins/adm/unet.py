@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from ... import _lib
+from ... import _lib, engine
 from ...engine import Act, Builder, pad4
 
 __all__ = ["UNetModel"]
@@ -121,9 +121,16 @@ class ADMPlan:
         self.versions = net._param_versions()
         self.emb_rows = emb_rows
         cin = net.in_channels
-        self.x_in = x_in if x_in is not None else Act(
-            torch.empty(B * H * W * pad4(cin), dtype=torch.float32, device=device), B, H, W, cin, pad4(cin), True
-        )
+        c_first = net.input_blocks[0][0]
+        # the first convolution reads the latent PLANAR (x_in = the loop's own (B, C, H, W) layout, channel stride 0): Builder.conv_stem
+        self.planar = (engine.STEM_PLANAR and cin <= 4 and isinstance(c_first, nn.Conv2d) and tuple(c_first.weight.shape[2:]) == (3, 3)
+                       and c_first.out_channels % 4 == 0 and bld.half is None and (x_in is None or x_in.cs == 0))
+        if x_in is not None:
+            self.x_in = x_in
+        elif self.planar:
+            self.x_in = Act(torch.empty(B * cin * H * W, dtype=torch.float32, device=device), B, H, W, cin, 0, True)
+        else:
+            self.x_in = Act(torch.empty(B * H * W * pad4(cin), dtype=torch.float32, device=device), B, H, W, cin, pad4(cin), True)
         self.out = torch.empty(B, net.out_channels, H, W, dtype=torch.float32, device=device)
         self.table = bld.const(timestep_embedding_table(net.table_steps, mc))
         self.t_idx = torch.zeros(emb_rows, dtype=torch.int64, device=device)
@@ -239,7 +246,9 @@ class ADMPlan:
 
         def run(block: nn.Sequential, h: Act, h1: Act | None = None) -> Act:
             for layer in block:
-                if isinstance(layer, nn.Conv2d):
+                if isinstance(layer, nn.Conv2d) and h is self.x_in and self.planar:
+                    nh = bld.conv_stem(h.buf, B, cin, H, W, bld.pack_conv(layer.weight, layer.bias), layer.out_channels, gn_stats=True)
+                elif isinstance(layer, nn.Conv2d):
                     nh = bld.conv(h, bld.pack_conv(layer.weight, layer.bias), layer.out_channels, gn_stats=True)
                 elif isinstance(layer, ResBlock):
                     nh = resblock(layer, h, h1)
@@ -408,7 +417,10 @@ class UNetModel(nn.Module):
         rows = B if (timesteps.numel() > 1 or self.num_classes is not None) else 1
         p = self.plan(B, H, W, rows, x.device, frac=frac)
         s = _lib.stream_ptr()
-        _lib.call("az_nchw_to_nhwc_f32", p.x_in.ptr, x.data_ptr(), None, B, Cin, H * W, p.x_in.cs, s)
+        if p.planar:
+            p.x_in.buf.copy_(x.reshape(-1))
+        else:
+            _lib.call("az_nchw_to_nhwc_f32", p.x_in.ptr, x.data_ptr(), None, B, Cin, H * W, p.x_in.cs, s)
         if frac:
             p.t_frac.copy_(timesteps.to(torch.float32).expand(rows) if timesteps.numel() == 1 else timesteps.to(torch.float32))
         else:

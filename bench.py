@@ -158,6 +158,9 @@ def stream_bytes(name, args):
             return n + (n // 4 if args[11] else n)
         if name == "az_groupnorm_stats_f32":  # (partials, x, x1, c0s, B, HW, C, cs, groups, nchunks)
             return args[4] * args[5] * args[7] * 4
+        if name == "az_conv2d_stem_f32":  # (descriptor): the planar latent read once, the NHWC activation written once
+            d = args[0]._obj
+            return d.batch * d.hin * d.win * (d.c0s + d.cout_s) * 4
         if name == "az_rownorm_mod_f32":  # (y, x, weight, scale, shift, bstride, rows, rows_per_batch, C, cs, kind, eps)
             return 2 * args[6] * args[9] * 4
     except Exception:  # noqa: BLE001 -- accounting only
@@ -203,7 +206,7 @@ def tape_profile(sampler, device):
 
 KERNEL_OF = {  # C-ABI entry point -> the __global__ kernel it launches (names as rocprofv3 prints them)
     "az_conv2d_winograd_f32": "conv_winograd_kernel", "az_conv2d_f32": "conv_igemm_kernel", "az_attention_f32": "attention_kernel",
-    "az_conv2d_bf16_f32": "conv_igemm_half_kernel", "az_conv2d_f16_f32": "conv_igemm_half_kernel", "az_conv2d_x3_f32": "conv_igemm_x3_kernel",
+    "az_conv2d_stem_f32": "conv_stem_kernel", "az_conv2d_bf16_f32": "conv_igemm_half_kernel", "az_conv2d_f16_f32": "conv_igemm_half_kernel", "az_conv2d_x3_f32": "conv_igemm_x3_kernel",
     "az_conv2d_winograd4_f32": "conv_winograd4_kernel",
 }
 
@@ -599,8 +602,8 @@ def roofline_report(sampler, device, args, world) -> dict:
     loop = next(iter(sampler._fused_cache.values()))
     if loop.fused.programs[0].x_in_cs > 0:  # NHWC backbone input (UNet / ADM): the image form
         graph_kernel = "image_ddpm" if sampler._needs_noise() else "image_ddim"
-    else:  # flat latents (ViT / JiT)
-        graph_kernel = "flat_ddim_xin"
+    else:  # every tensor in the latent's own layout (ViT / JiT tokens; UNet / ADM with the planar stem convolution)
+        graph_kernel = "flat_ddpm_xin" if sampler._needs_noise() else "flat_ddim_xin"
     head = dict(trans[graph_kernel])
     head["variants"] = trans
     head["which"] = (f"{graph_kernel}: the form this config's captured loop launches, measured at {head['elements']} elements "

@@ -297,6 +297,12 @@ typedef struct AzConvArgs {
 /* Narrow outputs (cout_s == 4, 3x3 stride 1 pad 1, one un-upsampled source with c0s % 16 == 0: the image head of
  * azula/nn/unet.py) run a VALU kernel instead of the 128-cout MFMA tile; splitk is ignored there.              */
 int az_conv2d_f32(const AzConvArgs* args, az_stream_t stream);
+/* The image stem -- the network's first convolution, 3x3 / stride 1 / pad 1 over <= 4 input channels (azula/nn/unet.py:142-150
+ * `UNet.in_conv`-style first layer, plugins/adm/_src/unet.py:469-471 `input_blocks[0]`) -- reading its source PLANAR, i.e. the
+ * latent (batch, c0s, hin, win) exactly as azula's samplers hold it, so that no NHWC copy of the latent exists: src0 planar
+ * with c0s = 1..4 channels; weight = (3, 3, c0s, cout_s) floats; bias, act 0 / 1, pad_mode, gn_quads (gn_chunks =
+ * ceil(hin / 8) * ceil(win / 32)) as in az_conv2d_f32; every other option must be unset. */
+int az_conv2d_stem_f32(const AzConvArgs* args, az_stream_t stream);
 /* The same operation with bf16 / f16 MFMA operands (v_mfma_f32_32x32x16_{bf16,f16}, 16x the fp32 MFMA rate) and fp32
  * accumulation, for backbones cast to half precision (azula/denoise.py:314-320 casts c_in x_t to the module dtype;
  * the reference's own tolerance for that mode is tests/test_nn_unet.py:78-91).  `weight` = az_pack_conv_weight_half_f32

@@ -531,6 +531,34 @@ def test_winograd_stream_fuzz(az):
         assert err < conv_tol(C0 + C1, 3, True) * max(1.0, ref.abs().max().item()), (case, B, H, W, C0, C1, Cout, periodic, up, splitk, err)
 
 
+@pytest.mark.parametrize("cin", [1, 2, 3, 4])
+@pytest.mark.parametrize("B,H,W,cout,periodic", [(2, 16, 32, 64, False), (3, 9, 37, 24, False), (1, 40, 70, 320, True), (2, 5, 3, 8, True)])
+def test_conv2d_stem(az, cin, B, H, W, cout, periodic):
+    """az_conv2d_stem_f32: the first 3 x 3 convolution reading its <= 4 input channels planar (the latent's own layout), NHWC
+    out, with the GroupNorm moments of its output -- against torch.conv2d and torch.group_norm (ragged tiles, more than 256
+    output channels, circular padding)."""
+    from azula_amd.engine import Builder
+
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g) + 3.0
+    ref = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="circular"), w, b) if periodic else F.conv2d(x, w, b, padding=1)
+    groups = 2  # (whole channel quads per group: the moments come from the stem kernel)
+    gw, gb = torch.randn(cout, generator=g), torch.randn(cout, generator=g)
+    ref_n = F.group_norm(ref, groups, gw, gb, eps=1e-5)
+    bld = Builder(torch.device("cuda"))
+    y = bld.conv_stem(dev(x).contiguous(), B, cin, H, W, bld.pack_conv(dev(w), dev(b)), cout, periodic=periodic, gn_stats=True)
+    n = bld.group_norm(y, groups, weight=dev(gw), bias=dev(gb))
+    bld.finish()
+    names = [nm for _, _, nm in bld.tape.ops]
+    assert names[0] == "az_conv2d_stem_f32" and "az_groupnorm_stats_f32" not in names
+    bld.tape.run()
+    out = from_nhwc(y.buf.reshape(B, H, W, cout), cout)
+    assert max_err(out, ref) < 2e-6 * max(1.0, ref.abs().max().item())
+    assert max_err(from_nhwc(n.buf.reshape(B, H, W, cout), cout), ref_n) < 2e-5
+
+
 @pytest.mark.parametrize("asm", ["1", "0"])
 @pytest.mark.parametrize("in_act", [0, 1])
 def test_winograd_input_affine(az, asm, in_act, monkeypatch):

@@ -88,6 +88,11 @@ def transition_cases(device):
                         f_channels=1, coef=row.data_ptr())
     cases.append(("flat_ddim_xin", "transition_flat_kernel<false, false, true, false>", a, 16 * n,
                   "read x_t, F; write x_s, c_in' x_s: 16 B/element"))
+    # ADM with the planar stem (C4 / C5, DDPM): F = first 3 of 6 planar channels per image, eps read, planar second output
+    a = transition_args(x_t=x.data_ptr(), F=F6.data_ptr(), eps=eps.data_ptr(), x_s=x.data_ptr(), xin_next=xs.data_ptr(), batch=B,
+                        channels=Cc, inner=inner, f_channels=6, coef=row.data_ptr())
+    cases.append(("flat_ddpm_xin", "transition_flat_kernel<false, true, true, false>", a, 20 * n,
+                  "read x_t, F (3 of 6 planar channels), eps; write x_s, c_in' x_s: 20 B/element"))
     return cases, (row, x, F3, F6, eps, xin, xs)
 
 
