@@ -180,39 +180,88 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(AzNormFinalizeArgs a) {
     }
     return;
   }
-  Moments acc = {0.f, 0.f, 0.f};
+  // items of this (b, group): partials (n, mean, M2, 0), 16 bytes each.  Folded by two passes of plain sums -- N = sum n,
+  // mean = sum(n mean) / N, then M2 = sum(M2_i + n_i (mean_i - mean)^2) -- instead of a chain of pairwise Chan merges with a
+  // division each: the launch is pure latency (up to 1024 partials per group on the large maps: 10 - 19 us as a chain).
+  // Fixed order, commutative butterfly sums: deterministic, every lane ends with the same bits.
+  const float* base;
+  int items, qpg = 1, nq = 0, nck = a.nchunks;
   if (a.quads_per_group > 0) {
-    // per-(tile block, channel quad) moments written by the producing convolutions' epilogues (AzConvArgs.gn_quads):
-    // group g = quads [g qpg, (g + 1) qpg) of the (possibly two-source) channel axis
-    const int qpg = a.quads_per_group;
+    // per-(chunk, channel quad) moments written by the producing convolutions (AzConvArgs.gn_quads): group g = quads
+    // [g qpg, (g + 1) qpg) of the (possibly two-source) channel axis; a group never straddles the two sources (host check)
+    qpg = a.quads_per_group;
     const int q_lo = g * qpg;
-    const bool second = q_lo >= a.quads0;  // a group never straddles the two sources (checked on the host)
-    const float* base = second ? a.partials1 : a.partials;
-    const int nq = second ? (int)(a.C / 4) - a.quads0 : a.quads0;
-    const int q0 = second ? q_lo - a.quads0 : q_lo;
-    const int nck = second && a.nchunks1 > 0 ? a.nchunks1 : a.nchunks;
-    for (int k = lane; k < nck; k += 64) {
-      const float* p = base + (((int64_t)b * nck + k) * nq + q0) * 4;
-      for (int j = 0; j < qpg; ++j) acc = combine(acc, Moments{p[4 * j], p[4 * j + 1], p[4 * j + 2]});
-    }
+    const bool second = q_lo >= a.quads0;
+    nq = second ? (int)(a.C / 4) - a.quads0 : a.quads0;
+    nck = second && a.nchunks1 > 0 ? a.nchunks1 : a.nchunks;
+    base = (second ? a.partials1 : a.partials) + ((int64_t)b * nck * nq + (second ? q_lo - a.quads0 : q_lo)) * 4;
+    items = nck * qpg;
   } else {
-    for (int k = lane; k < a.nchunks; k += 64) {
-      const float* p = a.partials + (((int64_t)b * a.nchunks + k) * a.groups + g) * 4;
-      acc = combine(acc, Moments{p[0], p[1], p[2]});
-    }
+    base = a.partials + ((int64_t)b * a.nchunks * a.groups + g) * 4;
+    nq = a.groups;
+    items = a.nchunks;
+  }
+  // the per-channel factors of the first 64 channels of the group: requested before the reduction, so that their latency
+  // overlaps the partials' (the launch is two dependent memory round trips otherwise)
+  float w0 = 1.f, bi0 = 0.f, sc0 = 1.f, sh0 = 0.f;
+  if (lane < Cg) {
+    const int c = g * Cg + lane;
+    if (a.weight) w0 = a.weight[c];
+    if (a.bias) bi0 = a.bias[c];
+    if (a.scale) sc0 = 1.f + a.scale[(int64_t)b * a.scale_bstride + c];
+    if (a.shift) sh0 = a.shift[(int64_t)b * a.scale_bstride + c];
+  }
+  auto item = [&](int i) {  // i -> (chunk k, quad j of the group)
+    const int k = i / qpg, j = i - k * qpg;
+    return *reinterpret_cast<const float4*>(base + ((int64_t)k * nq + j) * 4);
+  };
+  float4 keep[4];  // the first four items of a lane stay in registers for the second pass
+  float N = 0.f, M1 = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = lane + 64 * u;
+    keep[u] = i < items ? item(i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    N += keep[u].x;
+    M1 += keep[u].x * keep[u].y;
+  }
+  for (int i = lane + 256; i < items; i += 64) {
+    const float4 v = item(i);
+    N += v.x;
+    M1 += v.x * v.y;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    Moments other;
-    other.n = __shfl_xor(acc.n, o, 64);
-    other.mean = __shfl_xor(acc.mean, o, 64);
-    other.m2 = __shfl_xor(acc.m2, o, 64);
-    // combine in a lane-symmetric order so that every lane ends with identical bits
-    acc = (lane & o) ? combine(other, acc) : combine(acc, other);
+    N += __shfl_xor(N, o, 64);
+    M1 += __shfl_xor(M1, o, 64);
   }
+  Moments acc;
+  acc.n = N;
+  acc.mean = M1 / N;
+  float M2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float d = keep[u].y - acc.mean;
+    M2 += keep[u].z + keep[u].x * d * d;
+  }
+  for (int i = lane + 256; i < items; i += 64) {
+    const float4 v = item(i);
+    const float d = v.y - acc.mean;
+    M2 += v.z + v.x * d * d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) M2 += __shfl_xor(M2, o, 64);
+  acc.m2 = M2;
   const float var = acc.m2 / acc.n;  // biased, as torch.nn.GroupNorm
   const float rstd = rsqrtf(var + a.eps);
-  for (int j = lane; j < Cg; j += 64) {
+  if (lane < Cg) {
+    const int c = g * Cg + lane;
+    a.S[(int64_t)b * a.cs + c] = rstd * w0 * sc0;
+    a.T[(int64_t)b * a.cs + c] = (bi0 - acc.mean * rstd * w0) * sc0 + sh0;
+  }
+  for (int j = lane + 64; j < Cg; j += 64) {
     const int c = g * Cg + j;
     const float w = a.weight ? a.weight[c] : 1.f;
     const float bi = a.bias ? a.bias[c] : 0.f;
