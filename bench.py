@@ -211,6 +211,35 @@ KERNEL_OF = {  # C-ABI entry point -> the __global__ kernel it launches (names a
 }
 
 
+def family_back_to_back(sampler, device, fams):
+    r"""{family: ms} -- every launch of a matrix family of one denoise step, in tape order, inside ONE HIP-event pair (median
+    of 3): the per-launch event pairs of `tape_profile` cost the GPU ~10 us of idle per launch that neither the captured graph
+    nor rocprofv3's kernel durations contain (eager sum 22.9 ms vs 21.7 ms per captured C2 step, Winograd 396 vs 376 us per
+    launch in the rocprofv3 table of the same run); back to back the two agree."""
+    loop = next(iter(sampler._fused_cache.values()))
+    stream = torch.cuda.current_stream(device)
+    sptr = stream.cuda_stream
+    out = {}
+    for fam in fams:
+        ops = []
+        for fn, args, name in loop.tape.ops:
+            desc = getattr(args[0], "_obj", None) if args else None
+            if (getattr(desc, "_algo", name) if name in CONV_OPS else name) == fam:
+                ops.append((fn, args))
+        times = []
+        for rep in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for fn, args in ops:
+                assert fn(*args, sptr) == 0
+            e1.record(stream)
+            torch.cuda.synchronize(device)
+            if rep:
+                times.append(e0.elapsed_time(e1))
+        out[fam] = sorted(times)[1]
+    return out
+
+
 def family_summary(prof):
     r"""{family: {ms, launches, flops}} over one denoise step + the step total."""
     fams = {}
@@ -534,16 +563,20 @@ def roofline_report(sampler, device, args, world) -> dict:
     step_ms = sum(f["ms"] for f in fams.values())
     pmc = pmc_traffic(args.config, live=world == 1 and not args.half and not args.no_pmc)
     kernels = {}
+    b2b = family_back_to_back(sampler, device, [fam for fam, f in fams.items() if f["flops"]])
     for fam, f in fams.items():
         if not f["flops"]:
             continue
         wino = fam == "az_conv2d_winograd_f32"
         peak = PEAK_FP32_TFLOPS * (WINOGRAD_GAIN if wino else 1.0)
+        f = dict(f, ms_event_pairs=f["ms"], ms=b2b[fam])  # the family's launches back to back inside one event pair
         tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
         k = {
             "bound": "mfma", "kernel": KERNEL_OF.get(fam, fam), "entry": fam, "achieved": round(tf, 2), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(tf / peak, 4), "launches": f["launches"], "avg_us": round(f["ms"] * 1e3 / f["launches"], 2),
-            "ms_per_denoise_step": round(f["ms"], 3), "share_of_step": round(f["ms"] / step_ms, 4),
+            "ms_per_denoise_step": round(f["ms"], 3), "share_of_step": round(f["ms_event_pairs"] / step_ms, 4),
+            "avg_us_with_event_pairs": round(f["ms_event_pairs"] * 1e3 / f["launches"], 2),
+            "timing": "all launches of the family of one denoise step, tape order, one HIP-event pair, median of 3 (avg_us_with_event_pairs: one pair per launch, ~10 us of idle each)",
             "algorithmic_flops_per_step": f["flops"],
             "executed_mfma_tflops": round(tf / (WINOGRAD_GAIN if wino else 1.0), 2), "mfma_peak": PEAK_FP32_TFLOPS,
             "traffic": None,
