@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
       const unsigned fb = lds0 + (unsigned)(BM * LS + (wp * 64) * LS + frag_off) * 4u;
       const unsigned stA = lds0 + (unsigned)(r0 * LS + cc * 4) * 4u;
       const unsigned dA = fa ^ (fa + TF * 4), dB = fb ^ (fb + TF * 4), dS = stA ^ (stA + TF * 4);
-      const bool start1 = kt_begin >= p.nkc0;
+      const bool start1 = p.asm_loop == 1 && kt_begin >= p.nkc0;  // (one tap: the slice starts in the second source)
       const int kt_switch = (!start1 && kt_end > p.nkc0) ? p.nkc0 : 0x7fffffff;
       unsigned vA0[NP], vA1[NP];
       it_tap = 0;
@@ -602,13 +602,44 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
       const unsigned dflags = 0x00020000u;
       const int nst = kt_end - kt_begin;
       const unsigned soffW0 = (unsigned)kt_begin * (KT * 4), soffA0 = (unsigned)(start1 ? kt_begin - p.nkc0 : kt_begin) * (KT * 4);
-      asm volatile(IGEMM_KLOOP_ASM
-                   : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
-                   : "v"(fa), "v"(fb), "v"(stA), "v"(dA), "v"(dB), "v"(dS), "v"(voffW[0]), "v"(voffW[1]), "v"(voffW[2]), "v"(voffW[3]),
-                     "v"(vA0[0]), "v"(vA0[1]), "v"(vA0[2]), "v"(vA0[3]), "v"(vA1[0]), "v"(vA1[1]), "v"(vA1[2]), "v"(vA1[3]),
-                     "s"((unsigned)bw), "s"((unsigned)(bw >> 32) & 0xffffu), "s"(nw_), "s"(dflags), "s"(f0), "s"(f1), "s"(f2), "s"(dflags),
-                     "s"(g0), "s"(g1), "s"(g2), "s"(dflags), "s"(nst), "s"(kt_begin), "s"(kt_switch), "s"(soffW0), "s"(soffA0)
-                   : IGEMM_KLOOP_CLOBBERS);
+      if (p.asm_loop == 2) {
+        // several taps (3 x 3 ... convolutions at any stride), ONE source, no upsampling, zero padding: a pixel row's offset is
+        // linear in the tap -- base (window corner) + (ky W + kx) cs 4 -- wherever the tap is inside the image; a bit mask per
+        // row says where (the stream turns the others into the out-of-bounds offset at every tap change)
+        const int ks = a.ksize, tap0 = kt_begin / p.nkc0, kc0 = kt_begin - tap0 * p.nkc0;
+        const int ky0 = tap0 / ks, kx0 = tap0 - ky0 * ks;
+        unsigned pbase[NP], vmask[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          pbase[i] = (unsigned)((((prel[i] * a.h0 + ihb[i]) * a.w0 + iwb[i]) * a.c0s + cc * 4) * 4);
+          unsigned m = 0;
+          for (int t = 0; t < ks * ks; ++t) {
+            const int ih = ihb[i] + t / ks, iw = iwb[i] + t % ks;
+            if (prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win) m |= 1u << t;
+          }
+          vmask[i] = m;
+        }
+        const unsigned tap_kt = (unsigned)p.nkc0;
+        const unsigned wadj = (unsigned)(a.cout_s * p.cin_s * 4 - p.nkc0 * (KT * 4));
+        const unsigned cs4 = (unsigned)(a.c0s * 4), row_adj = (unsigned)((a.w0 - ks) * a.c0s * 4);
+        const unsigned packed = (unsigned)ks | (unsigned)tap0 << 8 | (unsigned)kx0 << 16 | (unsigned)ky0 << 24;
+        const unsigned soffW0t = (unsigned)(((int64_t)tap0 * a.cout_s * p.cin_s + kc0 * KT) * 4), soffA0t = (unsigned)(kc0 * (KT * 4));
+        asm volatile(IGEMM_KLOOP_TAPS_ASM
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
+                     : "v"(fa), "v"(fb), "v"(stA), "v"(dA), "v"(dB), "v"(dS), "v"(voffW[0]), "v"(voffW[1]), "v"(voffW[2]), "v"(voffW[3]),
+                       "v"(pbase[0]), "v"(pbase[1]), "v"(pbase[2]), "v"(pbase[3]), "v"(vmask[0]), "v"(vmask[1]), "v"(vmask[2]), "v"(vmask[3]),
+                       "s"((unsigned)bw), "s"((unsigned)(bw >> 32) & 0xffffu), "s"(nw_), "s"(dflags), "s"(f0), "s"(f1), "s"(f2), "s"(dflags),
+                       "s"(tap_kt), "s"(wadj), "s"(cs4), "s"(row_adj), "s"(nst), "s"(kt_begin), "s"(packed), "s"(soffW0t), "s"(soffA0t)
+                     : IGEMM_KLOOP_TAPS_CLOBBERS);
+      } else {
+        asm volatile(IGEMM_KLOOP_ASM
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
+                     : "v"(fa), "v"(fb), "v"(stA), "v"(dA), "v"(dB), "v"(dS), "v"(voffW[0]), "v"(voffW[1]), "v"(voffW[2]), "v"(voffW[3]),
+                       "v"(vA0[0]), "v"(vA0[1]), "v"(vA0[2]), "v"(vA0[3]), "v"(vA1[0]), "v"(vA1[1]), "v"(vA1[2]), "v"(vA1[3]),
+                       "s"((unsigned)bw), "s"((unsigned)(bw >> 32) & 0xffffu), "s"(nw_), "s"(dflags), "s"(f0), "s"(f1), "s"(f2), "s"(dflags),
+                       "s"(g0), "s"(g1), "s"(g2), "s"(dflags), "s"(nst), "s"(kt_begin), "s"(kt_switch), "s"(soffW0), "s"(soffA0)
+                     : IGEMM_KLOOP_CLOBBERS);
+      }
       done = true;
     }
   }
@@ -2409,9 +2440,16 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     // (768 -> 768: 178 vs 184 us, 768 -> 2304: 492 vs 519 us).  AZ_IGEMM_ASM=0: the C++ K loop everywhere (A/B measurements)
     const char* asm_env = getenv("AZ_IGEMM_ASM");
     const bool asm_ok = a->ksize == 1 && a->c0s % BK == 0 && a->c1s % BK == 0 && !(asm_env && asm_env[0] == '0');
-    if (asm_ok) k16 = false;
+    // several taps: the stream's taps variant (pixel-row offsets linear in the tap + a validity mask per row); it needs ONE
+    // source, no upsampling, zero padding, isotropic strides, at most 32 taps, and pays from 16 stages per split-K slice on
+    // (measured: 256^2 stride-2 256 -> 256: 672 -> 633 us, 128^2: 343 -> 328; 9-stage slices of an 8 x 8 map: 63 -> 66).
+    // AZ_IGEMM_ASM=1: one-tap stream only (A/B)
+    const bool taps_ok = a->ksize > 1 && a->ksize * a->ksize <= 32 && !a->src1 && a->c0s % BK == 0 && a->up0 == 0 &&
+                         a->pad_mode == 0 && !a->aniso && !(asm_env && asm_env[0]) && nk32 / (sk < 1 ? 1 : sk) >= 16 &&
+                         (int64_t)a->h0 * a->w0 * a->c0s * 4 * a->batch < (1ll << 31);
+    if (asm_ok || taps_ok) k16 = false;
     if (force) k16 = force[0] == '1';
-    p.asm_loop = asm_ok && !k16;
+    p.asm_loop = k16 ? 0 : (asm_ok ? 1 : (taps_ok ? 2 : 0));
   } else {
     p.asm_loop = 0;
   }

@@ -33,6 +33,9 @@ VOA = 248          # the 4 pixel-row offsets in use (first source: copied from t
 V_FA, V_FB, V_ST = 252, 253, 254
 S_RW, S_RS = 84, 88
 S_SOFFW, S_SOFFA, S_CNT, S_FIRST, S_KT, S_TMP = 92, 93, 94, 95, 96, 97
+S_NEXT, S_DELTA, S_TAP, S_KX, S_KS = 98, 99, 80, 81, 82   # taps variant: next tap boundary (stage index), byte offset of the tap, tap, kx, ks
+V_TMP, V_OOB = 255, 151   # (taps variant)
+TAPS = False  # set by gen(): the multi-tap variant (3 x 3 ... convolutions, ONE source, no upsampling, zero padding)
 LS = 36            # floats per LDS row (conv.hip: KT + 4)
 ROW32 = 32 * LS * 4          # bytes between a thread's loader rows (r0 + 32 i)
 B_OFF = 128 * LS * 4         # the pixel tile sits behind the 128 filter rows
@@ -101,6 +104,42 @@ def switch_event(tag: str):
     return L
 
 
+def tap_offsets():
+    r"""The 4 pixel-row offsets of the current tap: base + tap offset where the tap is inside the image for that row (bit s_tap of
+    the row's mask), the out-of-bounds offset (the load returns 0: zero padding) elsewhere."""
+    o = OPS
+    L = []
+    for i in range(4):
+        L.append(("valu", f"v_add_u32 v{VOA + i}, s{S_DELTA}, %{o['voffA'] + i}"))
+        L.append(("valu", f"v_lshrrev_b32 v{V_TMP}, s{S_TAP}, %{o['voffA1'] + i}"))
+        L.append(("valu", f"v_and_b32 v{V_TMP}, 1, v{V_TMP}"))
+        L.append(("valu", f"v_cmp_ne_u32 vcc, 0, v{V_TMP}"))
+        L.append(("valu", f"v_cndmask_b32 v{VOA + i}, v{V_OOB}, v{VOA + i}, vcc"))
+    return L
+
+
+def tap_event(tag: str):
+    r"""Taps variant, in front of the loads of stage s_kt: the next tap starts -- its weights sit one (cout_s x cin_s) plane
+    further (rs1 word 1 = that step minus what the channel walk added), the channel offset restarts, the pixel rows move by
+    one column (cs4 bytes) or to the next row of the window."""
+    o = OPS
+    L = [("salu", f"s_cmp_eq_u32 s{S_KT}, s{S_NEXT}"), ("salu", f"s_cbranch_scc0 LGnt{tag}_%=")]
+    L.append(("salu", f"s_add_u32 s{S_NEXT}, s{S_NEXT}, %{o['rs1']}"))
+    L.append(("salu", f"s_add_u32 s{S_SOFFW}, s{S_SOFFW}, %{o['rs1'] + 1}"))
+    L.append(("salu", f"s_mov_b32 s{S_SOFFA}, 0"))
+    L.append(("salu", f"s_add_u32 s{S_TAP}, s{S_TAP}, 1"))
+    L.append(("salu", f"s_add_u32 s{S_KX}, s{S_KX}, 1"))
+    L.append(("salu", f"s_add_u32 s{S_DELTA}, s{S_DELTA}, %{o['rs1'] + 2}"))
+    L.append(("salu", f"s_cmp_eq_u32 s{S_KX}, s{S_KS}"))
+    L.append(("salu", f"s_cbranch_scc0 LGsr{tag}_%="))
+    L.append(("salu", f"s_mov_b32 s{S_KX}, 0"))
+    L.append(("salu", f"s_add_u32 s{S_DELTA}, s{S_DELTA}, %{o['rs1'] + 3}"))
+    L.append(("label", f"LGsr{tag}_%=:"))
+    L += tap_offsets()
+    L.append(("label", f"LGnt{tag}_%=:"))
+    return L
+
+
 def load_done():
     return [("salu", f"s_add_u32 s{S_SOFFW}, s{S_SOFFW}, 128"), ("salu", f"s_add_u32 s{S_SOFFA}, s{S_SOFFA}, 128"),
             ("salu", f"s_add_u32 s{S_KT}, s{S_KT}, 1")]
@@ -115,7 +154,9 @@ def extras(S: bool, L: bool, tag: str):
         ex[8].append(("valu", f"v_xor_b32 v{V_ST}, v{V_ST}, %{OPS['dS']}"))
     if L:
         for i in range(8):
-            if i == 4:
+            if i == 0 and TAPS:
+                ex[1 + i] += tap_event(tag)
+            if i == 4 and not TAPS:
                 ex[1 + i] += switch_event(tag)
             ex[1 + i].append(("vmem", load(i, RV)))
         ex[9] += load_done()
@@ -141,7 +182,9 @@ def body(st: GStream, ex: dict, tag: str):
     st.emit(f"s_mov_b32 s{S_FIRST}, 0")
 
 
-def gen() -> list[str]:
+def gen(taps: bool = False) -> list[str]:
+    global TAPS
+    TAPS = taps
     o = OPS
     st = GStream()
     e = st.emit
@@ -149,11 +192,29 @@ def gen() -> list[str]:
     e(f"v_mov_b32 v{V_FA}, %{o['fragA']}")
     e(f"v_mov_b32 v{V_FB}, %{o['fragB']}")
     e(f"v_mov_b32 v{V_ST}, %{o['st']}")
-    for i in range(4):
-        e(f"v_mov_b32 v{VOA + i}, %{o['voffA'] + i}")
+    if not taps:
+        for i in range(4):
+            e(f"v_mov_b32 v{VOA + i}, %{o['voffA'] + i}")
     for w in range(4):
         e(f"s_mov_b32 s{S_RW + w}, %{o['rw'] + w}")
         e(f"s_mov_b32 s{S_RS + w}, %{o['rs0'] + w}")
+    if taps:  # operand kt_switch = ks | tap0 << 8 | kx0 << 16 | ky0 << 24; rs1 words = (stages per tap, weight step, cs4, row step)
+        e(f"v_mov_b32 v{V_OOB}, 0x80000000")
+        e(f"s_and_b32 s{S_KS}, %{o['kt_switch']}, 0xff")
+        e(f"s_lshr_b32 s{S_TAP}, %{o['kt_switch']}, 8")
+        e(f"s_and_b32 s{S_TAP}, s{S_TAP}, 0xff")
+        e(f"s_lshr_b32 s{S_KX}, %{o['kt_switch']}, 16")
+        e(f"s_and_b32 s{S_KX}, s{S_KX}, 0xff")
+        e(f"s_lshr_b32 s{S_TMP}, %{o['kt_switch']}, 24")             # ky0
+        e(f"s_mul_i32 s{S_DELTA}, s{S_KS}, %{o['rs1'] + 2}")          # ks * cs4
+        e(f"s_add_u32 s{S_DELTA}, s{S_DELTA}, %{o['rs1'] + 3}")      # + row step = one image row in bytes
+        e(f"s_mul_i32 s{S_DELTA}, s{S_DELTA}, s{S_TMP}")              # ky0 rows
+        e(f"s_mul_i32 s{S_TMP}, s{S_KX}, %{o['rs1'] + 2}")
+        e(f"s_add_u32 s{S_DELTA}, s{S_DELTA}, s{S_TMP}")              # + kx0 columns
+        e(f"s_add_u32 s{S_NEXT}, s{S_TAP}, 1")
+        e(f"s_mul_i32 s{S_NEXT}, s{S_NEXT}, %{o['rs1']}")             # first stage of the next tap
+        for kind, t in tap_offsets():
+            e(t)
     e(f"s_mov_b32 s{S_SOFFW}, %{o['soffW0']}")
     e(f"s_mov_b32 s{S_SOFFA}, %{o['soffA0']}")
     e(f"s_mov_b32 s{S_KT}, %{o['kt0']}")
@@ -162,7 +223,10 @@ def gen() -> list[str]:
 
     def loads(rv0, tag):
         for i in range(8):
-            if i == 4:
+            if i == 0 and taps:
+                for kind, t in tap_event(tag):
+                    e(t)
+            if i == 4 and not taps:
                 for kind, t in switch_event(tag):
                     e(t)
             e(load(i, rv0))
@@ -206,13 +270,16 @@ def gen() -> list[str]:
 
 
 def clobbers() -> str:
-    regs = [f'"v{i}"' for i in range(TB, 256)] + [f'"s{i}"' for i in range(S_RW, S_TMP + 1)] + ['"vcc"', '"scc"', '"memory"']
-    return "#define IGEMM_KLOOP_CLOBBERS " + ", ".join(regs) + "\n"
+    tail = ['"vcc"', '"scc"', '"memory"']
+    regs = [f'"v{i}"' for i in range(TB, 256)] + [f'"s{i}"' for i in range(S_RW, S_TMP + 1)] + tail
+    taps = [f'"v{i}"' for i in range(V_OOB, 256)] + [f'"s{i}"' for i in range(S_TAP, S_DELTA + 1)] + tail
+    return "#define IGEMM_KLOOP_CLOBBERS " + ", ".join(regs) + "\n#define IGEMM_KLOOP_TAPS_CLOBBERS " + ", ".join(taps) + "\n"
 
 
 def generate() -> str:
     src = "// generated by gen_igemm_kloop.py -- do not edit.  Operand numbering: OPS in the generator, the asm statement in conv.hip.\n"
     src += as_macro("IGEMM_KLOOP_ASM", gen())
+    src += as_macro("IGEMM_KLOOP_TAPS_ASM", gen(taps=True))
     src += clobbers()
     return src
 
