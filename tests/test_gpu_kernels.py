@@ -531,6 +531,47 @@ def test_winograd_stream_fuzz(az):
         assert err < conv_tol(C0 + C1, 3, True) * max(1.0, ref.abs().max().item()), (case, B, H, W, C0, C1, Cout, periodic, up, splitk, err)
 
 
+def test_direct_taps_stream_fuzz(az):
+    """The taps variant of the direct kernel's hand-scheduled K loop (igemm_kloop.inc, IGEMM_KLOOP_TAPS_ASM: k x k convolutions
+    at any stride, one source, zero padding, channels in whole 32-channel K tiles, >= 16 stages per split-K slice) over 30
+    seeded cases: 3 x 3 and 5 x 5, strides 1 .. 3, ragged pixel / channel tiles, images smaller than the window, split-K
+    slices that start in the middle of a tap."""
+    import random
+
+    from azula_amd.engine import Act, Builder
+
+    rnd = random.Random(4242)
+    g = torch.Generator().manual_seed(4242)
+    for case in range(30):
+        ks = rnd.choice([3, 3, 5])
+        Cin = 32 * rnd.choice([2, 3, 5, 8] if ks == 3 else [1, 2, 3])
+        stride = rnd.choice([1, 2, 2, 3])
+        B = rnd.randint(1, 3)
+        H, W = rnd.randint(2, 40), rnd.randint(2, 40)
+        Cout = rnd.choice([8, 24, 128, 136, 260])
+        nk = ks * ks * (Cin // 32)
+        splitk = rnd.choice([s_ for s_ in (1, 2, 3) if nk // s_ >= 16])
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(ks * ks * Cin)
+        b = torch.randn(Cout, generator=g)
+        ref = F.conv2d(x, w, b, padding=ks // 2, stride=stride)
+        bld = Builder(torch.device("cuda"))
+        xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
+        y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, stride=stride, winograd=False)
+        a = bld.tape.keep[-1]
+        assert bld.tape.ops[-1][2] == "az_conv2d_f32"
+        a.splitk = splitk
+        if splitk > 1:
+            bld._ws_need = max(bld._ws_need, splitk * B * y.H * y.W * y.cs)
+            if a not in bld._ws_users:
+                bld._ws_users.append(a)
+        bld.finish()
+        bld.tape.run()
+        out = from_nhwc(y.buf.reshape(B, y.H, y.W, y.cs), Cout)
+        err = max_err(out, ref)
+        assert err < conv_tol(Cin, ks, False) * max(1.0, ref.abs().max().item()), (case, B, H, W, Cin, Cout, ks, stride, splitk, err)
+
+
 @pytest.mark.parametrize("cin", [1, 2, 3, 4])
 @pytest.mark.parametrize("B,H,W,cout,periodic", [(2, 16, 32, 64, False), (3, 9, 37, 24, False), (1, 40, 70, 320, True), (2, 5, 3, 8, True)])
 def test_conv2d_stem(az, cin, B, H, W, cout, periodic):
