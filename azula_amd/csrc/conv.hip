@@ -1188,9 +1188,9 @@ __global__ __launch_bounds__(256) void conv_head_kernel(ConvP p, int tiles_x, in
       if (loff[i] >= 0) *reinterpret_cast<float4*>(xs + loff[i]) = v[i];
     __syncthreads();
     if (kc + HD_KC < a.c0s) fetch(kc + HD_KC);  // in flight during this chunk's FMAs
-    float part[NCO];  // per-chunk partial sums (144 terms), added once: shorter rounding chains than one 9 Cin-long sum
+    f32x2 part[NCO];  // per-chunk partial sums (2 x 72 terms, packed FMAs), added once: shorter rounding chains than one 9 Cin-long sum
 #pragma unroll
-    for (int co = 0; co < NCO; ++co) part[co] = 0.f;
+    for (int co = 0; co < NCO; ++co) part[co] = f32x2{0.f, 0.f};
     // 9 groups (one per tap) of 16 channels: 48 weights in SGPRs (3 x s_load_dwordx16), 4 ds_read_b128, 48 FMAs.  The
     // group loop is NOT unrolled: hoisted scalar loads would only add lgkmcnt waits (SMEM and LDS share the counter)
     // -- the other waves of the SIMD cover the one scalar-cache round trip per group.
@@ -1209,15 +1209,13 @@ __global__ __launch_bounds__(256) void conv_head_kernel(ConvP p, int tiles_x, in
         const float4 x = *reinterpret_cast<const float4*>(xp + q * 4);
 #pragma unroll
         for (int co = 0; co < NCO; ++co) {
-          part[co] = fmaf(x.x, wl[co][q * 4 + 0], part[co]);
-          part[co] = fmaf(x.y, wl[co][q * 4 + 1], part[co]);
-          part[co] = fmaf(x.z, wl[co][q * 4 + 2], part[co]);
-          part[co] = fmaf(x.w, wl[co][q * 4 + 3], part[co]);
+          part[co] = __builtin_elementwise_fma(f32x2{x.x, x.y}, f32x2{wl[co][q * 4 + 0], wl[co][q * 4 + 1]}, part[co]);
+          part[co] = __builtin_elementwise_fma(f32x2{x.z, x.w}, f32x2{wl[co][q * 4 + 2], wl[co][q * 4 + 3]}, part[co]);
         }
       }
     }
 #pragma unroll
-    for (int co = 0; co < NCO; ++co) acc[co] += part[co];
+    for (int co = 0; co < NCO; ++co) acc[co] += part[co].x + part[co].y;
   }
   const int oy = oy0 + ty, ox = ox0 + tx;
   if (oy >= a.hout || ox >= a.wout) return;
