@@ -54,9 +54,37 @@ __global__ __launch_bounds__(256) void calib_write_kernel(float* __restrict__ ds
     reinterpret_cast<float4*>(dst)[i] = v;
 }
 
+// Matrix pipe only: every wave issues `iters` x 8 independent v_mfma_f32_32x32x2_f32 on registers -- no memory, no LDS, no
+// vector work.  What this sustains is the chip's fp32 MFMA rate under its power limit (the guide's 157.3 TF/s is 256 CUs x
+// 256 FLOP per cycle at 2.4 GHz; under a dense MFMA load the clock settles near 2.0 GHz).
+typedef float f32x16c __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void calib_mfma_kernel(float* sink, int iters, float a0, float b0) {
+  f32x16c acc[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+  const float a = a0 * (1.0f + (float)(threadIdx.x & 7) * 0.125f), b = b0;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[f], 0, 0, 0);
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) t += acc[f][0] + acc[f][15];
+  if (t == -1.f) sink[0] = t;  // (never true: keeps the accumulators alive)
+}
+
 }  // namespace
 
 extern "C" {
+
+int az_calib_mfma_f32(float* sink, int32_t workgroups, int32_t iters, float a, float b, az_stream_t stream) {
+  AZ_REQUIRE(sink, AZ_E_NULL);
+  AZ_REQUIRE(workgroups > 0 && iters > 0, AZ_E_SHAPE);
+  hipLaunchKernelGGL(calib_mfma_kernel, dim3((unsigned)workgroups), dim3(256), 0, az_s(stream), sink, iters, a, b);
+  return az_launch_status();
+}
 
 int az_calib_read_f32(const float* src, float* sink, int64_t nbytes, int32_t width, int32_t group_bytes,
                       int64_t row_bytes, az_stream_t stream) {

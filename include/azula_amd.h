@@ -458,6 +458,9 @@ int az_scale_f64_to_f32(float* y, const double* x, const double* s_dev, int64_t 
 int az_calib_read_f32(const float* src, float* sink, int64_t nbytes, int32_t width, int32_t group_bytes,
                       int64_t row_bytes, az_stream_t stream);
 int az_calib_write_f32(float* dst, int64_t nbytes, float value, az_stream_t stream);
+/* `workgroups` x 4 waves, each issuing iters x 8 independent v_mfma_f32_32x32x2_f32 on registers (4096 FLOP each): the fp32
+ * MFMA rate the chip SUSTAINS under its power limit, which bench.py reports beside the nominal 157.3 TF/s peak. */
+int az_calib_mfma_f32(float* sink, int32_t workgroups, int32_t iters, float a, float b, az_stream_t stream);
 
 #ifdef __cplusplus
 }
