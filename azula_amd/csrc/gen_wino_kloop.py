@@ -88,6 +88,11 @@ class Stream:
         self.emit(f"v_mfma_f32_32x32x2_f32 %{acc}, {fa(s, j)}, {fb(s, j)}, %{acc}")
 
 
+# MFMA gaps of the transform's vector work: pass 1 per patch column, pass 2 per row (a burst pays one pipe switch, ~10 cycles)
+# (measured on the 256^2 / 64^2 layers, same box: pass 1 in two bursts + pass 2 a row per store gap 1256 / 336 us; pass 1 in one
+# burst, rows 0-1 and rows 2-3 in one each 1229 - 1245 / 327 - 331 us)
+P1_GAPS = [int(v) for v in os.environ.get("KL_P1", "0,0,0,0").split(",")]
+P2_GAPS = [int(v) for v in os.environ.get("KL_P2", "1,1,5,5").split(",")]
 SCALAR_ADD = os.environ.get("KL_SCALAR_ADD", "0") == "1"  # A/B: two v_add / v_sub instead of one v_pk_add_f32
 
 
@@ -228,11 +233,12 @@ def v_extras(S: bool, L: bool, tag: str):
     if S:
         ex[0].append(("wait", "s_waitcnt vmcnt(0)"))
         for c in range(4):
-            ex[c // 2] += v_affine_col(c, tag)
-            ex[c // 2] += [("valu", t) for t in v_pass1_col(c)]
-        for xi in range(4):
+            ex[P1_GAPS[c]] += v_affine_col(c, tag)
+            ex[P1_GAPS[c]] += [("valu", t) for t in v_pass1_col(c)]
+        for xi in range(4):  # (a row's stores stay in gaps 2 + 2 xi, 3 + 2 xi; its adds may run earlier, in a larger burst)
             valu, wa, wb = v_pass2_row(xi)
-            ex[2 + 2 * xi] += valu + [wa]
+            ex[P2_GAPS[xi]] += valu
+            ex[2 + 2 * xi] += [wa]
             ex[3 + 2 * xi] += [wb]
     if L:
         # patch row 1 lives in X after pass 1, so its registers are free first; the other rows follow their stores
