@@ -248,7 +248,7 @@ def v_extras(S: bool, L: bool, tag: str):
             ex[2 + n].append(v_load(i))
         ex[17] += v_load_done()
         ex[18] += v_affine_loads(tag, back=32)   # (s_soff already points at the stage after the one just requested)
-    if S:
+    if S and not XOR_AT_END:
         ex[17].append(("valu", f"v_xor_b32 v{V_ST}, 0x{BUF_XOR:x}, v{V_ST}"))
     return ex
 
@@ -296,13 +296,16 @@ def u_extras(S: bool, L: bool, tag: str):
             ex[k].append(("vmem", f"buffer_load_dwordx4 {quad(RV0 + 4 * i)}, %{o['voff']}, s[{S_RS}:{S_RS + 3}], "
                                   f"s{S_TMP if i else S_SOFF} offen"))
         ex[8].append(("salu", f"s_add_u32 s{S_SOFF}, s{S_SOFF}, %{o['soff_step']}"))
-    if S:
+    if S and not XOR_AT_END:
         ex[8].append(("valu", f"v_xor_b32 v{V_ST}, 0x{BUF_XOR:x}, v{V_ST}"))
     return ex
 
 
 # ------------------------------------------------------------------------------------------------ the iteration
-def body(st: Stream, extras: dict, tag: str, prio_head: int = 0):
+XOR_AT_END = os.environ.get("KL_XOR_END", "1") == "1"
+
+
+def body(st: Stream, extras: dict, tag: str, prio_head: int = 0, stores: bool = True):
     r"""One iteration.  `prio_head` > 0: the wave runs its first `prio_head` MFMA gaps at raised priority (the younger wave of a
     SIMD otherwise only runs when the older one stalls, so its loads would be issued late in the stage)."""
     st.drain()
@@ -346,6 +349,8 @@ def body(st: Stream, extras: dict, tag: str, prio_head: int = 0):
             k += 1
     st.emit(f"v_xor_b32 v{V_FA}, 0x{BUF_XOR:x}, v{V_FA}")
     st.emit(f"v_xor_b32 v{V_FB}, 0x{BUF_XOR:x}, v{V_FB}")
+    if XOR_AT_END and stores:  # the store address toggles with the fragment addresses: one burst, one pipe switch
+        st.emit(f"v_xor_b32 v{V_ST}, 0x{BUF_XOR:x}, v{V_ST}")
     st.emit(f"s_mov_b32 s{S_FIRST}, 0")
 
 
@@ -472,7 +477,7 @@ def gen_role(role: str, affine: bool = False) -> list[str]:
     body(st, extras(True, False, "q"), "q", PRIO_HEAD[role])
     # ---- last iteration
     e(f"L{role}last_%=:")
-    body(st, extras(False, False, "r"), "r")
+    body(st, extras(False, False, "r"), "r", 0, stores=False)
     # ---- the last stage's groups 6, 7; every wave's fragment reads are complete behind this barrier, so the epilogue may
     #      reuse the stage buffers
     st.drain()
