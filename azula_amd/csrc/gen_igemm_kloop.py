@@ -145,13 +145,17 @@ def load_done():
             ("salu", f"s_add_u32 s{S_KT}, s{S_KT}, 1")]
 
 
+XOR_AT_END = os.environ.get("KG_XOR_END", "1") == "1"  # the store-address toggle beside the fragment-address toggles: one burst
+
+
 def extras(S: bool, L: bool, tag: str):
     ex = {k: [] for k in range(64)}
     if S:
         ex[0].append(("wait", "s_waitcnt vmcnt(0)"))
         for i in range(8):
             ex[i].append(("lds", store(i, RV)))
-        ex[8].append(("valu", f"v_xor_b32 v{V_ST}, v{V_ST}, %{OPS['dS']}"))
+        if not XOR_AT_END:
+            ex[8].append(("valu", f"v_xor_b32 v{V_ST}, v{V_ST}, %{OPS['dS']}"))
     if L:
         for i in range(8):
             if i == 0 and TAPS:
@@ -163,7 +167,7 @@ def extras(S: bool, L: bool, tag: str):
     return ex
 
 
-def body(st: GStream, ex: dict, tag: str):
+def body(st: GStream, ex: dict, tag: str, stores: bool = True):
     st.drain()
     st.emit("s_barrier")
     st.read_set(0, 0)
@@ -179,6 +183,8 @@ def body(st: GStream, ex: dict, tag: str):
     st.group(2, ex, 48)
     st.emit(f"v_xor_b32 v{V_FA}, v{V_FA}, %{OPS['dA']}")
     st.emit(f"v_xor_b32 v{V_FB}, v{V_FB}, %{OPS['dB']}")
+    if XOR_AT_END and stores:
+        st.emit(f"v_xor_b32 v{V_ST}, v{V_ST}, %{OPS['dS']}")
     st.emit(f"s_mov_b32 s{S_FIRST}, 0")
 
 
@@ -259,7 +265,7 @@ def gen(taps: bool = False) -> list[str]:
     e("LGpen_%=:")
     body(st, extras(True, False, "q"), "q")
     e("LGlast_%=:")
-    body(st, extras(False, False, "r"), "r")
+    body(st, extras(False, False, "r"), "r", stores=False)
     # the last stage's k-group 3; every wave's fragment reads are complete behind this barrier (the epilogue reuses the stages)
     st.drain()
     e("s_barrier")
