@@ -78,6 +78,13 @@ CONFIGS = {
                  mod_features=64),
         name="tiny UNet 3x64x64 (harness check only)",
     ),
+    # azula.nn.unet with spatial = 3 (azula/nn/unet.py:119-203 on volumes): every 3-D convolution as depth taps of the 2-D kernels
+    "vol": dict(
+        kind="unet", batch=2, shape=(1, 32, 64, 64), steps=16,
+        net=dict(in_channels=1, out_channels=1, hid_channels=(64, 128, 256), hid_blocks=(2, 2, 2), norm="group", groups=16,
+                 mod_features=256, spatial=3),
+        name="azula.nn.unet UNet(spatial=3) 1x32x64x64 volumes, hid (64, 128, 256) x 2 blocks, KarrasDenoiser+VPSchedule, DDIMSampler(steps=16)",
+    ),
 }
 
 
