@@ -991,3 +991,27 @@ def test_groupnorm_statistics_from_the_conv_epilogue(az, form, monkeypatch):
     print(f"{form}: fused vs torch {e_ref:.2e}, fused vs separate pass {e_ab:.2e}")
     assert e_ref < 6e-5 and max_err(outs[False], ref) < 6e-5  # measured 2.9e-6 .. 1.3e-5 (O(1) outputs from data with mean/std up to 100)
     assert e_ab < 2.5e-5  # measured <= 4.8e-6
+
+
+def test_calibration_kernels(az):
+    """Measurement support of bench.py / tools/pmc_traffic.py (never on the sampling path): the known-traffic kernels touch
+    what they say and the matrix-pipe kernel sustains a plausible fp32 MFMA rate (the guide's peak is 157.3 TF/s)."""
+    n = 1 << 22
+    src = torch.arange(n, device="cuda", dtype=torch.float32)
+    sink = torch.zeros(64, device="cuda")
+    dst = torch.empty(n, device="cuda")
+    az.call("az_calib_write_f32", dst.data_ptr(), 4 * n, 2.5, az.stream_ptr())
+    assert (dst == 2.5).all()
+    az.call("az_calib_read_f32", src.data_ptr(), sink.data_ptr(), 4 * n, 16, 64, 4096, az.stream_ptr())
+    wgs, iters = 512, 2000
+    for _ in range(2):
+        az.call("az_calib_mfma_f32", sink.data_ptr(), wgs, iters, 1.0, 0.5, az.stream_ptr())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    az.call("az_calib_mfma_f32", sink.data_ptr(), wgs, iters, 1.0, 0.5, az.stream_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    tf = wgs * 4 * iters * 8 * 4096 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    print(f"az_calib_mfma_f32: {tf:.1f} TF/s")
+    assert 60.0 < tf < 165.0
+
