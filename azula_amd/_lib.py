@@ -167,6 +167,8 @@ class AzConvArgs(C.Structure):
         ("in_affine", c_f32p),
         ("in_act", C.c_int32),
         ("reserved1", C.c_int32),
+        ("depth", C.c_int32),
+        ("depth_shift", C.c_int32),
     ]
 
 

@@ -459,12 +459,13 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
 
   // Buffer descriptors (wave-uniform: kernel arguments + blockIdx only).
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
+  const int dshift = a.depth > 0 ? a.depth_shift : 0;  // volumes: the source plane of image b is b + depth_shift (masked per image)
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
   auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src0 + b_first * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems), 0x00020000);
+      (void*)(a.src0 + (b_first + dshift) * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(a.src1 ? a.src1 + b_first * s1_elems : a.src0), 0,
       a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u, 0x00020000);
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
   // Per-thread constants: weight-row byte offsets, pixel coordinates.
   unsigned voffW[NP];
   int prel[NP], ihb[NP], iwb[NP];
+  bool pdok[NP];  // AzConvArgs.depth: the source plane (image + depth_shift) lies inside the image's volume
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int co = m0 + r0 + RPP * i;
@@ -484,6 +486,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
     const int oh = rem / a.wout;
     const int ow = rem - oh * a.wout;
     prel[i] = pv ? b - b_first : -1;
+    pdok[i] = a.depth <= 0 || (unsigned)(b % a.depth + a.depth_shift) < (unsigned)a.depth;
     ihb[i] = oh * a.stride - a.pad;
     iwb[i] = ow * (a.aniso ? a.stride_w : a.stride) - a.pad;
   }
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
     for (int i = 0; i < NP; ++i) {
       const int ih = wrap_coord(ihb[i] + ky, a.hin, a.pad_mode);
       const int iw = wrap_coord(iwb[i] + kx, a.win, a.pad_mode);
-      const bool ok = prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
+      const bool ok = prel[i] >= 0 && pdok[i] && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
       const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> upw);
       voffA[i] = ok ? (unsigned)((pix * cs + cc * 4) * 4) : OOB;
     }
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
 #pragma unroll
       for (int i = 0; i < NP; ++i) vA1[i] = voffA[i];
       const uint64_t bw = (uint64_t)(uintptr_t)a.weight;
-      const uint64_t b0 = (uint64_t)(uintptr_t)(a.src0 + b_first * s0_elems);
+      const uint64_t b0 = (uint64_t)(uintptr_t)(a.src0 + (b_first + dshift) * s0_elems);
       const uint64_t b1 = (uint64_t)(uintptr_t)(a.src1 ? a.src1 + b_first * s1_elems : a.src0);
       const unsigned nw_ = clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s);
       const unsigned n0_ = clamp_bytes((a.batch - b_first) * s0_elems), n1_ = a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u;
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
           unsigned m = 0;
           for (int t = 0; t < ks * ks; ++t) {
             const int ih = ihb[i] + t / ks, iw = iwb[i] + t % ks;
-            if (prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win) m |= 1u << t;
+            if (prel[i] >= 0 && pdok[i] && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win) m |= 1u << t;
           }
           vmask[i] = m;
         }
@@ -1543,11 +1546,12 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
 
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
+  const int dshift = a.depth > 0 ? a.depth_shift : 0;  // volumes: the source plane of image b is b + depth_shift (masked per image)
   auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)p.nk * p.cblocks * WU_STAGE), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src0 + b_first * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems), 0x00020000);
+      (void*)(a.src0 + (b_first + dshift) * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(a.src1 ? a.src1 + b_first * s1_elems : a.src0), 0,
       a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u, 0x00020000);
@@ -1559,6 +1563,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   const int vj = (tid & 255) >> 2;  // tile within the block
   const int vq = tid & 3;           // which channel pair of the 8
   int v_b = -1, v_ih0 = 0, v_iw0 = 0;
+  bool v_dok = true;  // AzConvArgs.depth: the source plane (image + depth_shift) lies inside the image's volume
   if (vrole) {
     const int t = t0 + vj;
     if (t < p.ntiles) {
@@ -1568,6 +1573,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
       v_b = b - b_first;
       v_ih0 = 2 * th - 1;
       v_iw0 = 2 * (r - th * p.tiles_w) - 1;
+      v_dok = a.depth <= 0 || (unsigned)(b % a.depth + a.depth_shift) < (unsigned)a.depth;
     }
   }
   unsigned voffV[16];
@@ -1585,7 +1591,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ih = wrap_coord(v_ih0 + r, a.hin, a.pad_mode);
-      rok[r] = v_b >= 0 && (unsigned)ih < (unsigned)a.hin;
+      rok[r] = v_b >= 0 && v_dok && (unsigned)ih < (unsigned)a.hin;
       rpart[r] = (v_b * hs + (ih >> up)) * ws * cs * 4;
     }
 #pragma unroll
@@ -1717,7 +1723,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
         const unsigned ldsA = lds0 + W_STAGE * 4 + tid * 64, ldsB = lds0 + W_LDS_BYTES + tid * 64;
         const unsigned vst = lds0 + (unsigned)(WU_STAGE + voffL) * 4u;
         // buffer descriptors as words (the asm cannot address the halves of a 128-bit operand)
-        const uint64_t b0 = (uint64_t)(uintptr_t)(a.src0 + b_first * s0_elems);
+        const uint64_t b0 = (uint64_t)(uintptr_t)(a.src0 + (b_first + dshift) * s0_elems);
         const uint64_t b1 = (uint64_t)(uintptr_t)(a.src1 ? a.src1 + b_first * s1_elems : a.src0);
         const unsigned n0 = clamp_bytes((a.batch - b_first) * s0_elems), n1 = a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u;
         unsigned d0w0 = (unsigned)b0, d0w1 = (unsigned)(b0 >> 32) & 0xffffu, d0w2 = n0;
@@ -2347,7 +2353,7 @@ int az_conv2d_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direc
 int az_conv2d_stem_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
   AZ_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->aniso && !a->src1 && a->c1s == 0 && a->up0 == 0 && !a->gate &&
-                 !a->res && !a->dst_nchw && !a->in_affine && a->splitk <= 1 && (a->act == 0 || a->act == 1),
+                 !a->res && !a->dst_nchw && !a->in_affine && a->depth == 0 && a->splitk <= 1 && (a->act == 0 || a->act == 1),
              AZ_E_UNSUPPORTED);
   AZ_REQUIRE(a->c0s >= 1 && a->c0s <= 4 && a->cout_s > 0 && a->cout_s % 4 == 0 && a->batch > 0 && a->hin > 0 && a->win > 0 &&
                  a->hout == a->hin && a->wout == a->win && a->h0 == a->hin && a->w0 == a->win,
@@ -2382,6 +2388,10 @@ int az_conv2d_x3_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_di
 
 static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   AZ_REQUIRE(!a || !a->in_affine, AZ_E_UNSUPPORTED);  // (the Winograd kernel's gather only)
+  if (a && a->depth != 0)  // one depth tap of a 3-D convolution: fp32 direct kernel, single source
+    AZ_REQUIRE(half == 0 && a->depth > 0 && !a->src1 && a->batch % a->depth == 0 && a->depth_shift > -a->depth &&
+                   a->depth_shift < a->depth && a->cout_s != 4 && (!a->gate || a->gate_bstride == 0),
+               AZ_E_UNSUPPORTED);
   AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout > 0 && a->wout > 0, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
@@ -2520,6 +2530,10 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
   AZ_REQUIRE(a->act >= 0 && a->act <= 4, AZ_E_UNSUPPORTED);
   if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
+  if (a->depth != 0)  // one depth tap of a 3-D convolution
+    AZ_REQUIRE(a->depth > 0 && !a->src1 && a->batch % a->depth == 0 && a->depth_shift > -a->depth && a->depth_shift < a->depth &&
+                   (!a->gate || a->gate_bstride == 0),
+               AZ_E_UNSUPPORTED);
   if (a->in_affine)  // the normalisation apply pass inside the gather
     AZ_REQUIRE(!a->src1 && a->c0s % 8 == 0 && a->up0 == 0 && (a->in_act == 0 || a->in_act == 1) && AZ_ALIGNED16(a->in_affine) &&
                    (int64_t)a->batch * a->c0s * 8 < (1ll << 31),
@@ -2628,7 +2642,7 @@ int az_conv2d_winograd4_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
   AZ_REQUIRE(a->act >= 0 && a->act <= 4, AZ_E_UNSUPPORTED);
   if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
-  AZ_REQUIRE(!a->in_affine, AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(!a->in_affine && a->depth == 0, AZ_E_UNSUPPORTED);
   AZ_REQUIRE(!a->aniso || (a->up0_w >= 0 && a->up0_w <= 4 && a->up1_w >= 0 && a->up1_w <= 4), AZ_E_SHAPE);  // (shift amounts)
   AZ_REQUIRE(a->up0 >= 0 && a->up0 <= 4 && ((a->hin + (1 << a->up0) - 1) >> a->up0) <= a->h0 &&
                  ((a->win + (1 << az_upw(a, a->up0, a->up0_w)) - 1) >> az_upw(a, a->up0, a->up0_w)) <= a->w0,

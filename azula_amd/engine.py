@@ -318,6 +318,7 @@ class Builder:
         periodic: bool = False,
         gn_stats: bool = False,
         out: Act | None = None,
+        depth: tuple | None = None,
     ) -> Act | None:
         ks, bias = packed.ks, packed.bias
         pad = ks // 2
@@ -339,6 +340,9 @@ class Builder:
             a.src1, a.c1s, a.up1, a.h1, a.w1 = src1.ptr, src1.cs, up1, src1.H, src1.W
         assert (a.c0s, a.c1s) == (packed.c0s, packed.c1s), "weights were packed for different source strides"
         a.batch, a.hin, a.win = B, hin, win
+        if depth is not None:  # (planes per volume, depth tap offset): one depth tap of a 3-D convolution over all planes at once
+            assert src1 is None and self.half is None and B % depth[0] == 0
+            a.depth, a.depth_shift = depth
         a.bias = bias.data_ptr() if bias is not None else None
         a.cout_s = pad4(cout)
         a.ksize, a.stride, a.pad = ks, stride, pad
@@ -377,9 +381,9 @@ class Builder:
         # image head (<= 4 output channels) on a map that fills the chip with 16 x 16-pixel workgroups:
         # az_conv2d_f32 runs its narrow-output VALU kernel (104 vs 342 us at 4 x 256^2, 256 -> 3)
         head = (winograd is None and legal and not aniso and a.cout_s == 4 and src1 is None and up0 == 0 and a.c0s % 16 == 0
-                and head_wgs >= 256)
+                and head_wgs >= 256 and depth is None)
         wino_ok = legal and not head and winograd != "x3"
-        use_f4 = wino_ok and (winograd == 4 or (winograd is None and WINOGRAD == "4" and tiles4 >= WINOGRAD4_MIN_TILES))
+        use_f4 = wino_ok and depth is None and (winograd == 4 or (winograd is None and WINOGRAD == "4" and tiles4 >= WINOGRAD4_MIN_TILES))
         use_wino = wino_ok and not use_f4 and ((WINOGRAD != "0") if winograd is None else bool(winograd))
         if use_wino:
             tiles = B * ((hout + 1) // 2) * ((wout + 1) // 2)
@@ -389,7 +393,7 @@ class Builder:
         # bf16x3 mode replaces the DIRECT fp32 kernel (1x1 convs / token GEMMs, stride 2, small maps: 147-181 vs 113-128
         # TF/s); the 3x3 stride-1 layers stay on the fp32 Winograd kernel, which executes 2.25x fewer multiplies
         # (221 vs 181 TF/s algorithmic at 4 x 256^2, 256 -> 256).
-        use_x3 = self.half is None and (
+        use_x3 = self.half is None and depth is None and (
             winograd == "x3"
             or (winograd is None and FP32_MFMA == "bf16x3" and not head and not use_wino and not use_f4
                 and cin_s >= X3_MIN_CHANNELS and a.cout_s >= X3_MIN_CHANNELS)

@@ -73,6 +73,19 @@ def conv3d(bld: Builder, x: Vol, conv, *, stride=1, periodic: bool = False, x1: 
     out = new_vol(bld, x.B, Do, Ho, Wo, cout)
     taps = [p] + [j for j in range(kd) if j != p]  # centre first: it exists for every output plane and writes it
     packs = {j: bld.pack_conv(w[:, :, j], bias if j == p else None, cin0=x.C if x1 is not None else None) for j in taps}
+    if ((sd_, sh_, sw_) == (1, 1, 1) and x1 is None and not periodic and bld.half is None and cout > 4
+            and (gate is None or gate_bstride == 0 or x.B == 1)):
+        # ONE launch per depth tap for all planes of all samples (AzConvArgs.depth): the kernels' loaders take a plane whose tap
+        # falls outside its volume as zeros; a gate must be shared by the samples; the taps accumulate in place through `res`
+        g = dict(gate=gate, gate_off=gate_off, gate_bstride=0) if gate is not None else {}
+        allx = Act(x.buf, x.B * x.D, x.H, x.W, x.C, x.cs, True)
+        allo = Act(out.buf, out.B * out.D, out.H, out.W, out.C, out.cs, True)
+        allr = Act(res.buf, res.B * res.D, res.H, res.W, res.C, res.cs, True) if res is not None else None
+        for j in taps:
+            bld.conv(allx, packs[j], cout, out=allo, res=allr if j == p else allo, depth=(Din, j - p), **g)
+        if silu:
+            bld.tape.add("az_silu_f32", out.buf.data_ptr(), out.buf.data_ptr(), out.buf.numel())
+        return out
     for b in range(x.B):
         g = dict(gate=gate, gate_off=gate_off + b * gate_bstride, gate_bstride=0) if gate is not None else {}
         if (sd_, sh_, sw_) == (1, 1, 1) and x1 is None:  # contiguous plane ranges: one launch per (sample, tap[, wrap piece])

@@ -293,6 +293,12 @@ typedef struct AzConvArgs {
                             * plugins/adm/_src/unet.py:196-203).  Needs a single source, c0s % 8 == 0, up0 == 0 */
   int32_t in_act;          /* with in_affine: 0 none, 1 SiLU */
   int32_t reserved1;
+  int32_t depth;           /* > 0 (az_conv2d_f32, az_conv2d_winograd_f32; single source): the `batch` images are the planes of
+                            * batch / depth volumes, and this launch is ONE DEPTH TAP of a 3-D convolution (azula/nn/layers.py:25-68
+                            * with spatial = 3): image b reads source plane b + depth_shift, taken as zeros where
+                            * (b % depth) + depth_shift falls outside [0, depth) -- the zero padding along the depth axis; a gate
+                            * must be shared by the batch (gate_bstride 0).  The taps accumulate through `res` = `dst` */
+  int32_t depth_shift;
 } AzConvArgs;
 /* Narrow outputs (cout_s == 4, 3x3 stride 1 pad 1, one un-upsampled source with c0s % 16 == 0: the image head of
  * azula/nn/unet.py) run a VALU kernel instead of the 128-cout MFMA tile; splitk is ignored there.              */
