@@ -500,7 +500,7 @@ class Builder:
     def linear_small(self, y, ldy, x, ldx, W, bias, M, N, K, in_act=0, out_act=0, y_off=0) -> None:
         self.tape.add(
             "az_linear_small_f32", y.data_ptr() + 4 * y_off, ldy, x.data_ptr(), ldx, W.data_ptr(),
-            bias.data_ptr() if bias is not None else None, M, N, K, in_act, out_act,
+            bias.data_ptr() if bias is not None else None, M, N, K, in_act, out_act, keep=[y, x, W, bias],
         )
 
     def materialize(self, x: Act) -> Act:
@@ -549,7 +549,8 @@ class Builder:
         f.shift = shift.data_ptr() + 4 * shift_off if shift is not None else None
         f.scale_bstride = bstride
         f.B, f.C, f.cs, f.groups, f.nchunks, f.eps = B, x.C, x.cs, groups, nchunks, eps
-        self.tape.add("az_groupnorm_finalize_f32", C.byref(f), keep=[f])
+        # (the descriptor holds raw addresses: the tensors behind them must live as long as the tape)
+        self.tape.add("az_groupnorm_finalize_f32", C.byref(f), keep=[f, weight, bias, scale, shift])
         if (lazy and AFFINE_FUSED and x1 is None and not pool and act == 0 and x.C == x.cs and x.cs % 8 == 0
                 and self.half is None):
             # no apply pass: the consumer (Builder.conv) reads x and applies scale / shift itself
@@ -573,7 +574,7 @@ class Builder:
             "az_rownorm_mod_f32", y.ptr, x.ptr, weight.data_ptr() if weight is not None else None,
             scale.data_ptr() + 4 * scale_off if scale is not None else None,
             shift.data_ptr() + 4 * shift_off if shift is not None else None,
-            bstride, rows, x.H * x.W, x.C, x.cs, kind, eps,
+            bstride, rows, x.H * x.W, x.C, x.cs, kind, eps, keep=[weight, scale, shift],
         )
         return y
 
