@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(a.src0 + (b_first + dshift) * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src1 ? a.src1 + b_first * s1_elems : a.src0), 0,
+      (void*)(a.src1 ? a.src1 + (b_first + dshift) * s1_elems : a.src0), 0,
       a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u, 0x00020000);
 
   // Per-thread constants: weight-row byte offsets, pixel coordinates.
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
       for (int i = 0; i < NP; ++i) vA1[i] = voffA[i];
       const uint64_t bw = (uint64_t)(uintptr_t)a.weight;
       const uint64_t b0 = (uint64_t)(uintptr_t)(a.src0 + (b_first + dshift) * s0_elems);
-      const uint64_t b1 = (uint64_t)(uintptr_t)(a.src1 ? a.src1 + b_first * s1_elems : a.src0);
+      const uint64_t b1 = (uint64_t)(uintptr_t)(a.src1 ? a.src1 + (b_first + dshift) * s1_elems : a.src0);
       const unsigned nw_ = clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s);
       const unsigned n0_ = clamp_bytes((a.batch - b_first) * s0_elems), n1_ = a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u;
       unsigned f0 = (unsigned)b0, f1 = (unsigned)(b0 >> 32) & 0xffffu, f2 = n0_;
@@ -1553,7 +1553,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(a.src0 + (b_first + dshift) * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src1 ? a.src1 + b_first * s1_elems : a.src0), 0,
+      (void*)(a.src1 ? a.src1 + (b_first + dshift) * s1_elems : a.src0), 0,
       a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u, 0x00020000);
 
   // ---- loader roles: waves 0..3 (threads 0..255) gather + transform one (tile, channel pair) each
@@ -1724,7 +1724,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
         const unsigned vst = lds0 + (unsigned)(WU_STAGE + voffL) * 4u;
         // buffer descriptors as words (the asm cannot address the halves of a 128-bit operand)
         const uint64_t b0 = (uint64_t)(uintptr_t)(a.src0 + (b_first + dshift) * s0_elems);
-        const uint64_t b1 = (uint64_t)(uintptr_t)(a.src1 ? a.src1 + b_first * s1_elems : a.src0);
+        const uint64_t b1 = (uint64_t)(uintptr_t)(a.src1 ? a.src1 + (b_first + dshift) * s1_elems : a.src0);
         const unsigned n0 = clamp_bytes((a.batch - b_first) * s0_elems), n1 = a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u;
         unsigned d0w0 = (unsigned)b0, d0w1 = (unsigned)(b0 >> 32) & 0xffffu, d0w2 = n0;
         unsigned d1w0 = (unsigned)b1, d1w1 = (unsigned)(b1 >> 32) & 0xffffu, d1w2 = n1;
@@ -2388,8 +2388,8 @@ int az_conv2d_x3_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_di
 
 static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   AZ_REQUIRE(!a || !a->in_affine, AZ_E_UNSUPPORTED);  // (the Winograd kernel's gather only)
-  if (a && a->depth != 0)  // one depth tap of a 3-D convolution: fp32 direct kernel, single source
-    AZ_REQUIRE(half == 0 && a->depth > 0 && !a->src1 && a->batch % a->depth == 0 && a->depth_shift > -a->depth &&
+  if (a && a->depth != 0)  // one depth tap of a 3-D convolution: fp32 direct kernel (both sources hold `batch` planes)
+    AZ_REQUIRE(half == 0 && a->depth > 0 && a->batch % a->depth == 0 && a->depth_shift > -a->depth &&
                    a->depth_shift < a->depth && a->cout_s != 4 && (!a->gate || a->gate_bstride == 0),
                AZ_E_UNSUPPORTED);
   AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
@@ -2531,7 +2531,7 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->act >= 0 && a->act <= 4, AZ_E_UNSUPPORTED);
   if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
   if (a->depth != 0)  // one depth tap of a 3-D convolution
-    AZ_REQUIRE(a->depth > 0 && !a->src1 && a->batch % a->depth == 0 && a->depth_shift > -a->depth && a->depth_shift < a->depth &&
+    AZ_REQUIRE(a->depth > 0 && a->batch % a->depth == 0 && a->depth_shift > -a->depth && a->depth_shift < a->depth &&
                    (!a->gate || a->gate_bstride == 0),
                AZ_E_UNSUPPORTED);
   if (a->in_affine)  // the normalisation apply pass inside the gather

@@ -341,7 +341,7 @@ class Builder:
         assert (a.c0s, a.c1s) == (packed.c0s, packed.c1s), "weights were packed for different source strides"
         a.batch, a.hin, a.win = B, hin, win
         if depth is not None:  # (planes per volume, depth tap offset): one depth tap of a 3-D convolution over all planes at once
-            assert src1 is None and self.half is None and B % depth[0] == 0
+            assert (src1 is None or src1.B == B) and self.half is None and B % depth[0] == 0
             a.depth, a.depth_shift = depth
         a.bias = bias.data_ptr() if bias is not None else None
         a.cout_s = pad4(cout)

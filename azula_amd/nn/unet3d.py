@@ -7,7 +7,9 @@ convolution is the sum over its depth taps of 2-D convolutions of depth-shifted 
     out[b, d] = sum_j conv2d(x[b, s d + j - p], w[:, :, j]),
 
 each tap one launch of the 2-D kernel (Winograd / direct, in-plane padding, stride, nearest upsampling, concatenation and
-narrow exactly as for images) that ACCUMULATES in place through the epilogue's residual operand.  The centre tap runs
+narrow exactly as for images) over ALL planes of all samples (``AzConvArgs.depth``: a plane whose tap leaves its volume reads
+zeros; odd depths, circular padding and half-precision modules: one launch per sample / plane) that ACCUMULATES in place
+through the epilogue's residual operand.  The centre tap runs
 first (it exists for every output plane) and carries the bias; a gate distributes over the taps
 (``x + c (sum_j v_j + bias) = x + c (v_0 + bias) + c v_1 + ...``), only the SiLU after a block's first convolution needs a
 pass of its own.  Norms see a volume as one (D H) x W image.  Depth padding is a skipped (zeros) or wrapped (circular)
@@ -73,16 +75,38 @@ def conv3d(bld: Builder, x: Vol, conv, *, stride=1, periodic: bool = False, x1: 
     out = new_vol(bld, x.B, Do, Ho, Wo, cout)
     taps = [p] + [j for j in range(kd) if j != p]  # centre first: it exists for every output plane and writes it
     packs = {j: bld.pack_conv(w[:, :, j], bias if j == p else None, cin0=x.C if x1 is not None else None) for j in taps}
-    if ((sd_, sh_, sw_) == (1, 1, 1) and x1 is None and not periodic and bld.half is None and cout > 4
-            and (gate is None or gate_bstride == 0 or x.B == 1)):
-        # ONE launch per depth tap for all planes of all samples (AzConvArgs.depth): the kernels' loaders take a plane whose tap
-        # falls outside its volume as zeros; a gate must be shared by the samples; the taps accumulate in place through `res`
+    # ---- ONE launch per depth tap for all planes of all samples (AzConvArgs.depth: the kernels' loaders take a plane whose
+    # tap leaves its volume as zeros; the taps accumulate in place through `res`).  A stride-2 depth axis computes every plane
+    # and keeps the even ones (twice the work of a layer that is a few per cent of the network, for 3 launches instead of
+    # 3 Do B); a source read through depth upsampling (the decoder's merge convolutions) gets its planes duplicated first.
+    fast = (not periodic and bld.half is None and cout > 4 and (gate is None or gate_bstride == 0 or x.B == 1)
+            and (sd_ == 1 or (sd_ == 2 and Din % 2 == 0 and gate is None and res is None and not silu))
+            and (x1 is None or (ud_ == 0 and x1.D == Din) or (ud_ == 1 and 2 * x1.D == Din)))
+    if fast:
         g = dict(gate=gate, gate_off=gate_off, gate_bstride=0) if gate is not None else {}
-        allx = Act(x.buf, x.B * x.D, x.H, x.W, x.C, x.cs, True)
-        allo = Act(out.buf, out.B * out.D, out.H, out.W, out.C, out.cs, True)
-        allr = Act(res.buf, res.B * res.D, res.H, res.W, res.C, res.cs, True) if res is not None else None
+        planes = lambda v: Act(v.buf, v.B * v.D, v.H, v.W, v.C, v.cs, True)  # noqa: E731
+        x1u, kw_ = None, {}
+        if x1 is not None:
+            src1 = x1
+            if ud_ == 1:  # nearest x2 along the depth axis: plane d of the wide volume = plane d >> 1
+                x1u = new_vol(bld, x1.B, Din, x1.H, x1.W, x1.C)
+                n = x1.H * x1.W * x1.cs
+                for half_ in (0, 1):
+                    bld.tape.add("az_token_copy_f32", x1u.buf.data_ptr(), 2, half_, x1.buf.data_ptr(), 1, 0, 1, x1.B * x1.D, n)
+                src1 = x1u
+            kw_ = dict(src1=planes(src1), up1=(uh_, uw_), hin=Hin, win=Win)
+        full = out if sd_ == 1 else new_vol(bld, x.B, Din, Ho, Wo, cout)
+        allo = planes(full)
+        allr = planes(res) if res is not None else None
         for j in taps:
-            bld.conv(allx, packs[j], cout, out=allo, res=allr if j == p else allo, depth=(Din, j - p), **g)
+            bld.conv(planes(x), packs[j], cout, stride=(sh_, sw_), out=allo, res=allr if j == p else allo, depth=(Din, j - p),
+                     **g, **kw_)
+        if sd_ == 2:  # out[d] = full[2 d]
+            n = Ho * Wo * out.cs
+            bld.tape.add("az_token_copy_f32", out.buf.data_ptr(), 1, 0, full.buf.data_ptr(), 2, 0, 1, x.B * Do, n)
+            free_vol(bld, full)
+        if x1u is not None:
+            free_vol(bld, x1u)
         if silu:
             bld.tape.add("az_silu_f32", out.buf.data_ptr(), out.buf.data_ptr(), out.buf.numel())
         return out

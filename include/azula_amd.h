@@ -293,7 +293,7 @@ typedef struct AzConvArgs {
                             * plugins/adm/_src/unet.py:196-203).  Needs a single source, c0s % 8 == 0, up0 == 0 */
   int32_t in_act;          /* with in_affine: 0 none, 1 SiLU */
   int32_t reserved1;
-  int32_t depth;           /* > 0 (az_conv2d_f32, az_conv2d_winograd_f32; single source): the `batch` images are the planes of
+  int32_t depth;           /* > 0 (az_conv2d_f32, az_conv2d_winograd_f32; every source holds `batch` planes): the `batch` images are the planes of
                             * batch / depth volumes, and this launch is ONE DEPTH TAP of a 3-D convolution (azula/nn/layers.py:25-68
                             * with spatial = 3): image b reads source plane b + depth_shift, taken as zeros where
                             * (b % depth) + depth_shift falls outside [0, depth) -- the zero padding along the depth axis; a gate
