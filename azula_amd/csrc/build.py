@@ -1,6 +1,6 @@
 r"""Builds ``libazula_amd.so`` (gfx950 HIP kernels + C ABI) in-tree with hipcc.
 
-    python -m azula_amd.csrc.build [--force] [--verbose]
+    python -m azula_amd.csrc.build [--force] [--verbose] [--regen]
 
 No torch, no cmake: one ``hipcc -shared -fPIC`` per source file (cached on mtime) and a final link.
 The resulting ``.so`` sits next to the sources so that it travels with the tree.
@@ -50,11 +50,14 @@ def _supported(flags: list[str]) -> bool:
     with an empty translation unit and build without the flag where it is unknown (a slower schedule, not a broken library)."""
     key = tuple(flags)
     if key not in _FLAG_OK:
-        probe = os.path.join(OBJ_DIR, "_flag_probe.hip")
-        with open(probe, "w") as f:
-            f.write("#include <hip/hip_runtime.h>\n__global__ void az_flag_probe() {}\n")
-        res = subprocess.run([hipcc(), "--offload-arch=gfx950", *flags, "-x", "hip", "-c", probe, "-o", probe + ".o"],
-                             capture_output=True)
+        import tempfile
+
+        with tempfile.TemporaryDirectory(prefix="azula_amd_probe_") as tmp:  # (never inside the source tree)
+            probe = os.path.join(tmp, "flag_probe.hip")
+            with open(probe, "w") as f:
+                f.write("#include <hip/hip_runtime.h>\n__global__ void az_flag_probe() {}\n")
+            res = subprocess.run([hipcc(), "--offload-arch=gfx950", *flags, "-x", "hip", "-c", probe, "-o", probe + ".o"],
+                                 capture_output=True)
         _FLAG_OK[key] = res.returncode == 0
     return _FLAG_OK[key]
 
@@ -66,15 +69,17 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, regen: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(HERE, "common.h"), os.path.join(ROOT, "include", "azula_amd.h"), os.path.join(HERE, "wino_kloop.inc")]
     headers.append(os.path.join(HERE, "igemm_kloop.inc"))
-    # the hand-scheduled K loops (committed; regenerated when their generators are newer)
-    for inc, gens in ((headers[-2], ["gen_wino_kloop.py"]), (headers[-1], ["gen_igemm_kloop.py", "gen_wino_kloop.py"])):
-        paths = [os.path.join(HERE, g) for g in gens]
-        if _stale(inc, paths):
-            subprocess.run([sys.executable, paths[0]], check=True, stdout=subprocess.DEVNULL)
+    # The hand-scheduled K loops are COMMITTED sources.  A build never rewrites them (mtime order after a checkout is arbitrary
+    # and an install may be read-only); it only writes one that is missing.  Developers regenerate with `--regen` (or by running
+    # the generator), and tests/test_cabi.py checks that the committed text is exactly what the generators emit.
+    for inc, gen in ((headers[-2], "gen_wino_kloop.py"), (headers[-1], "gen_igemm_kloop.py")):
+        if regen or not os.path.exists(inc):
+            env = {k: v for k, v in os.environ.items() if k != "AZ_KLOOP_AB"}
+            subprocess.run([sys.executable, os.path.join(HERE, gen)], check=True, stdout=subprocess.DEVNULL, env=env)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     objs = []
     for s in srcs:
@@ -99,4 +104,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True, regen="--regen" in sys.argv))

@@ -28,10 +28,14 @@ __device__ __forceinline__ float az_mul(float a, float b) { return __fmul_rn(a, 
 __device__ __forceinline__ float az_add(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float az_sub(float a, float b) { return __fsub_rn(a, b); }
 
-// SiLU = v * sigmoid(v) as 5 vector instructions: v_exp_f32 and v_rcp_f32 are each within 1 ulp, the result within
-// ~2.5 ulp of v / (1 + expf(-v)) -- same limits (-inf -> NaN, very negative -> -0, +inf -> +inf).  The ocml expf + IEEE
-// division form took ~28 instructions; in a conv epilogue (one workgroup per CU, nothing to hide behind) that was 8 k of a
-// workgroup's 170 k cycles (profiles/r03_wino_timeline.txt), and vector instructions add to matrix time on this chip.
+// SiLU = v * sigmoid(v) as 5 vector instructions (every SiLU of the library: conv epilogues, affine_act, small linears,
+// modulation MLPs).  v_exp_f32 and v_rcp_f32 are each within 1 ulp, but the fp32 rounding of v * log2(e) in front of the
+// exponential gives exp(-v) a RELATIVE error of about |v| * 6e-8, so the bound is absolute, not relative: for v >= 0 the result
+// is within ~3 ulp of v / (1 + expf(-v)); for negative v (result ~ v * exp(v), tiny) the relative error grows like |v| * 1e-7
+// (about 17 ulp at v = -20) while the absolute error stays below 1e-7 * |v| * exp(v) <= 4e-8, and results whose reciprocal is
+// subnormal flush to -0.  Limits: -inf -> NaN, very negative -> -0, +inf -> +inf.  The ocml expf + IEEE division form took
+// ~28 instructions; in a conv epilogue (one workgroup per CU, nothing to hide behind) that was 8 k of a workgroup's 170 k
+// cycles (profiles/r03_wino_timeline.txt), and vector instructions add to matrix time on this chip.
 __device__ __forceinline__ float az_silu(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
 }

@@ -38,7 +38,11 @@ constexpr int BK = 32;    // k tile (input channels of one tap)
 constexpr int LDSS = 36;  // padded LDS row stride in floats (144 B, 16-B aligned)
 constexpr int TILE_F = (BM + BN) * LDSS;
 
+#ifdef AZ_IGEMM_KLOOP_INC  // A/B builds (tools/kloop_variant.py): a variant stream generated outside the source tree
+#include AZ_IGEMM_KLOOP_INC
+#else
 #include "igemm_kloop.inc"
+#endif
 struct ConvP {
   AzConvArgs a;
   int npix;     // batch * hout * wout
@@ -460,15 +464,20 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
   // Buffer descriptors (wave-uniform: kernel arguments + blockIdx only).
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int dshift = a.depth > 0 ? a.depth_shift : 0;  // volumes: the source plane of image b is b + depth_shift (masked per image)
+  // The descriptors stay INSIDE the allocation whatever the shift: they start at plane b_base = max(b_first + dshift, 0) and end
+  // at the last plane; a lane's plane index is taken relative to b_base (b_adj <= 0 is the part of a negative shift the base
+  // could not absorb -- only lanes whose plane is masked anyway (pdok / v_dok false) would land below 0).
+  const int b_base = max(b_first + dshift, 0);
+  const int b_adj = b_first + dshift - b_base;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
   auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src0 + (b_first + dshift) * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems), 0x00020000);
+      (void*)(a.src0 + b_base * s0_elems), 0, clamp_bytes((a.batch - b_base) * s0_elems), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src1 ? a.src1 + (b_first + dshift) * s1_elems : a.src0), 0,
-      a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u, 0x00020000);
+      (void*)(a.src1 ? a.src1 + b_base * s1_elems : a.src0), 0,
+      a.src1 ? clamp_bytes((a.batch - b_base) * s1_elems) : 0u, 0x00020000);
 
   // Per-thread constants: weight-row byte offsets, pixel coordinates.
   unsigned voffW[NP];
@@ -513,7 +522,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
       const int ih = wrap_coord(ihb[i] + ky, a.hin, a.pad_mode);
       const int iw = wrap_coord(iwb[i] + kx, a.win, a.pad_mode);
       const bool ok = prel[i] >= 0 && pdok[i] && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
-      const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> upw);
+      const int pix = ((prel[i] + b_adj) * hs + (ih >> up)) * ws + (iw >> upw);
       voffA[i] = ok ? (unsigned)((pix * cs + cc * 4) * 4) : OOB;
     }
   };
@@ -595,10 +604,10 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
 #pragma unroll
       for (int i = 0; i < NP; ++i) vA1[i] = voffA[i];
       const uint64_t bw = (uint64_t)(uintptr_t)a.weight;
-      const uint64_t b0 = (uint64_t)(uintptr_t)(a.src0 + (b_first + dshift) * s0_elems);
-      const uint64_t b1 = (uint64_t)(uintptr_t)(a.src1 ? a.src1 + (b_first + dshift) * s1_elems : a.src0);
+      const uint64_t b0 = (uint64_t)(uintptr_t)(a.src0 + b_base * s0_elems);
+      const uint64_t b1 = (uint64_t)(uintptr_t)(a.src1 ? a.src1 + b_base * s1_elems : a.src0);
       const unsigned nw_ = clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s);
-      const unsigned n0_ = clamp_bytes((a.batch - b_first) * s0_elems), n1_ = a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u;
+      const unsigned n0_ = clamp_bytes((a.batch - b_base) * s0_elems), n1_ = a.src1 ? clamp_bytes((a.batch - b_base) * s1_elems) : 0u;
       unsigned f0 = (unsigned)b0, f1 = (unsigned)(b0 >> 32) & 0xffffu, f2 = n0_;
       const unsigned g0 = (unsigned)b1, g1 = (unsigned)(b1 >> 32) & 0xffffu, g2 = n1_;
       if (start1) f0 = g0, f1 = g1, f2 = g2;
@@ -614,7 +623,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
         unsigned pbase[NP], vmask[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-          pbase[i] = (unsigned)((((prel[i] * a.h0 + ihb[i]) * a.w0 + iwb[i]) * a.c0s + cc * 4) * 4);
+          pbase[i] = (unsigned)(((((prel[i] + b_adj) * a.h0 + ihb[i]) * a.w0 + iwb[i]) * a.c0s + cc * 4) * 4);
           unsigned m = 0;
           for (int t = 0; t < ks * ks; ++t) {
             const int ih = ihb[i] + t / ks, iw = iwb[i] + t % ks;
@@ -1491,7 +1500,11 @@ struct WinoP {
 // ds_write_b128 of the loaders are bank-conflict-free without padding.
 __device__ __forceinline__ int wswz(int row, int half) { return row * WK + 4 * (half ^ ((row >> 3) & 1)); }
 
+#ifdef AZ_WINO_KLOOP_INC
+#include AZ_WINO_KLOOP_INC
+#else
 #include "wino_kloop.inc"
+#endif
 #ifdef AZ_WINO_TL
 // Experiment builds only (tools/ab_build.py tl -DAZ_WINO_TL; tools/wino_timeline.py): s_memtime stamps of waves 0 and 4 of
 // every workgroup + the hardware id of its CU, to see what a workgroup spends outside its K loop and between workgroups.
@@ -1547,14 +1560,19 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
   const int dshift = a.depth > 0 ? a.depth_shift : 0;  // volumes: the source plane of image b is b + depth_shift (masked per image)
+  // The descriptors stay INSIDE the allocation whatever the shift: they start at plane b_base = max(b_first + dshift, 0) and end
+  // at the last plane; a lane's plane index is taken relative to b_base (b_adj <= 0 is the part of a negative shift the base
+  // could not absorb -- only lanes whose plane is masked anyway (pdok / v_dok false) would land below 0).
+  const int b_base = max(b_first + dshift, 0);
+  const int b_adj = b_first + dshift - b_base;
   auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4); };
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)p.nk * p.cblocks * WU_STAGE), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src0 + (b_first + dshift) * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems), 0x00020000);
+      (void*)(a.src0 + b_base * s0_elems), 0, clamp_bytes((a.batch - b_base) * s0_elems), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src1 ? a.src1 + (b_first + dshift) * s1_elems : a.src0), 0,
-      a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u, 0x00020000);
+      (void*)(a.src1 ? a.src1 + b_base * s1_elems : a.src0), 0,
+      a.src1 ? clamp_bytes((a.batch - b_base) * s1_elems) : 0u, 0x00020000);
 
   // ---- loader roles: waves 0..3 (threads 0..255) gather + transform one (tile, channel pair) each
   //      (16 x 8-byte loads); waves 4..7 stream the pre-transformed filter chunk (8 x 16 B each).
@@ -1592,7 +1610,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
     for (int r = 0; r < 4; ++r) {
       const int ih = wrap_coord(v_ih0 + r, a.hin, a.pad_mode);
       rok[r] = v_b >= 0 && v_dok && (unsigned)ih < (unsigned)a.hin;
-      rpart[r] = (v_b * hs + (ih >> up)) * ws * cs * 4;
+      rpart[r] = ((v_b + b_adj) * hs + (ih >> up)) * ws * cs * 4;
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1723,9 +1741,9 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
         const unsigned ldsA = lds0 + W_STAGE * 4 + tid * 64, ldsB = lds0 + W_LDS_BYTES + tid * 64;
         const unsigned vst = lds0 + (unsigned)(WU_STAGE + voffL) * 4u;
         // buffer descriptors as words (the asm cannot address the halves of a 128-bit operand)
-        const uint64_t b0 = (uint64_t)(uintptr_t)(a.src0 + (b_first + dshift) * s0_elems);
-        const uint64_t b1 = (uint64_t)(uintptr_t)(a.src1 ? a.src1 + (b_first + dshift) * s1_elems : a.src0);
-        const unsigned n0 = clamp_bytes((a.batch - b_first) * s0_elems), n1 = a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems) : 0u;
+        const uint64_t b0 = (uint64_t)(uintptr_t)(a.src0 + b_base * s0_elems);
+        const uint64_t b1 = (uint64_t)(uintptr_t)(a.src1 ? a.src1 + b_base * s1_elems : a.src0);
+        const unsigned n0 = clamp_bytes((a.batch - b_base) * s0_elems), n1 = a.src1 ? clamp_bytes((a.batch - b_base) * s1_elems) : 0u;
         unsigned d0w0 = (unsigned)b0, d0w1 = (unsigned)(b0 >> 32) & 0xffffu, d0w2 = n0;
         unsigned d1w0 = (unsigned)b1, d1w1 = (unsigned)(b1 >> 32) & 0xffffu, d1w2 = n1;
         if (start1) d0w0 = d1w0, d0w1 = d1w1, d0w2 = d1w2;

@@ -23,7 +23,7 @@ from __future__ import annotations
 
 import os
 
-from gen_wino_kloop import Stream, as_macro, quad  # the lgkmcnt bookkeeping and the macro writer are shared
+from gen_wino_kloop import _AB, Stream, as_macro, main, quad  # the lgkmcnt bookkeeping and the macro writer are shared
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -145,7 +145,7 @@ def load_done():
             ("salu", f"s_add_u32 s{S_KT}, s{S_KT}, 1")]
 
 
-XOR_AT_END = os.environ.get("KG_XOR_END", "1") == "1"  # the store-address toggle beside the fragment-address toggles: one burst
+XOR_AT_END = _AB.get("KG_XOR_END", "1") == "1"  # the store-address toggle beside the fragment-address toggles: one burst
 
 
 def extras(S: bool, L: bool, tag: str):
@@ -291,8 +291,4 @@ def generate() -> str:
 
 
 if __name__ == "__main__":
-    path = os.path.join(HERE, "igemm_kloop.inc")
-    text = generate()
-    with open(path, "w") as f:
-        f.write(text)
-    print(path, len(text.splitlines()), "lines")
+    raise SystemExit(main("igemm_kloop.inc", generate))

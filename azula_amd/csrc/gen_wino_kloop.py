@@ -17,15 +17,21 @@ pipelined across the barrier:
 
 The matrix pipe therefore always has MFMAs queued when a wave reaches the barrier and right after it.  Register use is
 fixed (v160..v255, s91..s99: declared as clobbers); accumulators and the few scalar inputs are asm operands.
-Environment overrides KL_* (ablations, scalar adds, LDS-DMA filter path, padding) exist for tools/kloop_variant.py A/B builds only.
+Environment overrides KL_* (ablations, scalar adds, LDS-DMA filter path, padding) exist for tools/kloop_variant.py A/B builds
+only and are ignored unless AZ_KLOOP_AB=1.
 
-    python azula_amd/csrc/gen_wino_kloop.py        # rewrites wino_kloop.inc next to this file
+    python azula_amd/csrc/gen_wino_kloop.py              # rewrites wino_kloop.inc next to this file (developer command)
+    python azula_amd/csrc/gen_wino_kloop.py --out PATH   # writes a variant elsewhere (A/B builds)
+    python azula_amd/csrc/gen_wino_kloop.py --check      # exit 1 if the committed .inc is not what the generator emits
 """
 from __future__ import annotations
 
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# The KL_* overrides below (ablations, scalar adds, LDS-DMA filter path, padding) are honoured ONLY when AZ_KLOOP_AB=1 is set
+# as well (tools/kloop_variant.py does): a user's environment must never change the shipped instruction stream.
+_AB = os.environ if os.environ.get("AZ_KLOOP_AB") == "1" else {}
 
 TB = 160
 SP, TP = 156, 158   # input affine (AzConvArgs.in_affine): scale / shift of the thread's channel pair for the stage being transformed
@@ -91,9 +97,9 @@ class Stream:
 # MFMA gaps of the transform's vector work: pass 1 per patch column, pass 2 per row (a burst pays one pipe switch, ~10 cycles)
 # (measured on the 256^2 / 64^2 layers, same box: pass 1 in two bursts + pass 2 a row per store gap 1256 / 336 us; pass 1 in one
 # burst, rows 0-1 and rows 2-3 in one each 1229 - 1245 / 327 - 331 us)
-P1_GAPS = [int(v) for v in os.environ.get("KL_P1", "0,0,0,0").split(",")]
-P2_GAPS = [int(v) for v in os.environ.get("KL_P2", "1,1,5,5").split(",")]
-SCALAR_ADD = os.environ.get("KL_SCALAR_ADD", "0") == "1"  # A/B: two v_add / v_sub instead of one v_pk_add_f32
+P1_GAPS = [int(v) for v in _AB.get("KL_P1", "0,0,0,0").split(",")]
+P2_GAPS = [int(v) for v in _AB.get("KL_P2", "1,1,5,5").split(",")]
+SCALAR_ADD = _AB.get("KL_SCALAR_ADD", "0") == "1"  # A/B: two v_add / v_sub instead of one v_pk_add_f32
 
 
 def pk(dst, a, b, sub=False):
@@ -182,7 +188,7 @@ def v_affine_loads(tag, back=0):
     return L
 
 
-OOL_EVENTS = os.environ.get("KL_OOL_EVENTS", "1") == "1"  # events out of line: the common path takes no branch
+OOL_EVENTS = _AB.get("KL_OOL_EVENTS", "1") == "1"  # events out of line: the common path takes no branch
 
 
 def v_load_events(tag):
@@ -257,7 +263,7 @@ def v_extras(S: bool, L: bool, tag: str):
 U_OPS = dict(fragA=8, fragB=9, st=10, voff=11, rw=12, kt_begin=16, kt_end=17, soff0=18, soff_step=19)
 
 
-UDMA = os.environ.get("KL_UDMA", "0") == "1"  # filter chunk by LDS-DMA (buffer_load ... lds): no staging registers, no ds_write
+UDMA = _AB.get("KL_UDMA", "0") == "1"  # filter chunk by LDS-DMA (buffer_load ... lds): no staging registers, no ds_write
 S_UST = S_KT  # (the filter role has no stage counter: its SGPR holds the wave's LDS slot in the buffer to fill next)
 
 
@@ -302,7 +308,7 @@ def u_extras(S: bool, L: bool, tag: str):
 
 
 # ------------------------------------------------------------------------------------------------ the iteration
-XOR_AT_END = os.environ.get("KL_XOR_END", "1") == "1"
+XOR_AT_END = _AB.get("KL_XOR_END", "1") == "1"
 
 
 def body(st: Stream, extras: dict, tag: str, prio_head: int = 0, stores: bool = True):
@@ -358,9 +364,9 @@ def flat(items):
     return [t for _, t in items]
 
 
-ABL = set(os.environ.get("KL_ABLATE", "").split(","))  # timing ablations (WRONG results): vload, uload, vtrans, vstore, ustore, barrier
+ABL = set(_AB.get("KL_ABLATE", "").split(","))  # timing ablations (WRONG results): vload, uload, vtrans, vstore, ustore, barrier
 # Tunables (environment overrides are for tools/kloop_variant.py A/B builds; the committed .inc is the default)
-PRIO_HEAD = {"V": int(os.environ.get("KL_PRIO_V", "0")), "U": int(os.environ.get("KL_PRIO_U", "0"))}  # U role = waves 4..7 = the younger wave of every SIMD
+PRIO_HEAD = {"V": int(_AB.get("KL_PRIO_V", "0")), "U": int(_AB.get("KL_PRIO_U", "0"))}  # U role = waves 4..7 = the younger wave of every SIMD
 
 
 def gen_role(role: str, affine: bool = False) -> list[str]:
@@ -465,7 +471,7 @@ def gen_role(role: str, affine: bool = False) -> list[str]:
     e(f"s_cmp_eq_u32 s{S_CNT}, 0")
     e(f"s_cbranch_scc1 L{role}pen_%=")
     e(".p2align 6")
-    for _ in range(int(os.environ.get("KL_PAD", "0"))):  # A/B: byte phase of the loop body inside its 64-byte line
+    for _ in range(int(_AB.get("KL_PAD", "0"))):  # A/B: byte phase of the loop body inside its 64-byte line
         e("s_nop 0")
     e(f"L{role}steady_%=:")
     body(st, extras(True, True, "s"), "s", PRIO_HEAD[role])
@@ -523,9 +529,22 @@ def generate() -> str:
     return src
 
 
-if __name__ == "__main__":
-    path = os.path.join(HERE, "wino_kloop.inc")
-    text = generate()
+def main(default_name: str, gen) -> int:
+    import sys
+
+    path = os.path.join(HERE, default_name)
+    if "--out" in sys.argv:
+        path = sys.argv[sys.argv.index("--out") + 1]
+    text = gen()
+    if "--check" in sys.argv:
+        same = os.path.exists(path) and open(path).read() == text
+        print(path, "up to date" if same else "DIFFERS from the generator's output")
+        return 0 if same else 1
     with open(path, "w") as f:
         f.write(text)
     print(path, len(text.splitlines()), "lines")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main("wino_kloop.inc", generate))

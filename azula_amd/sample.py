@@ -348,7 +348,20 @@ def _value_key(v):
         return v
     if torch.is_tensor(v):
         if v.numel() <= 16:
-            return ("t", tuple(v.shape), str(v.dtype), tuple(v.detach().reshape(-1).tolist()))
+            # `.tolist()` on a device tensor is a blocking sync: read the value only when the tensor's identity
+            # (object, storage address, version counter) changes.  Writes through `.data` do not bump the version counter and
+            # are NOT tracked -- neither here nor by the (address, version) key of larger tensors (documented in DESIGN.md).
+            ident = (v.data_ptr(), v._version, tuple(v.shape), v.dtype, v.device)
+            hit = _SMALL_VALUES.get(id(v))
+            if hit is None or hit[0] != ident or hit[1]() is not v:
+                import weakref
+
+                if len(_SMALL_VALUES) > 256:
+                    for k in [k for k, h in _SMALL_VALUES.items() if h[1]() is None]:
+                        del _SMALL_VALUES[k]
+                hit = (ident, weakref.ref(v), tuple(v.detach().reshape(-1).tolist()))
+                _SMALL_VALUES[id(v)] = hit
+            return ("t", tuple(v.shape), str(v.dtype), hit[2])
         return ("T", v.data_ptr(), v._version, tuple(v.shape), str(v.dtype))
     if isinstance(v, (tuple, list)):
         items = tuple(_value_key(x) for x in v)
@@ -357,6 +370,7 @@ def _value_key(v):
 
 
 _SKIP = object()
+_SMALL_VALUES: dict = {}  # id(tensor) -> ((address, version, shape, dtype, device), weakref, value tuple)
 
 
 def _attr_key(attrs: dict) -> tuple:

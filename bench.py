@@ -363,31 +363,52 @@ def pmc_traffic(config: str, live: bool = True, timeout: int = 420):
     return None
 
 
-def cpu_baseline(denoiser, cfg, budget_s=25.0):
-    r"""The oracle (CPU restatement of azula's op sequence, bit-checked against the reference in the
-    build container) timed on this host: DDIM steps of the same network at batch 1."""
+def physical_cores() -> int:
+    r"""Physical cores this process may run on: distinct (socket, core) pairs of /proc/cpuinfo among the CPUs of the affinity
+    mask (SMT siblings share a pair); falls back to the usable logical count."""
+    avail = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    pairs, cpu, phys = set(), None, 0
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k = k.strip()
+                if k == "processor":
+                    cpu = int(v)
+                elif k == "physical id":
+                    phys = int(v)
+                elif k == "core id" and cpu in avail:
+                    pairs.add((phys, int(v)))
+    except (OSError, ValueError):
+        pass
+    return len(pairs) or len(avail)
+
+
+def cpu_baseline(denoiser, cfg, budget_s=60.0):
+    r"""The oracle (CPU restatement of azula's op sequence, bit-checked against the reference in the build container) timed
+    on this host: full DDIM steps of the same network at the GPU leg's batch, >= 2 timed steps after one warm-up, at two
+    thread counts -- the host's physical cores (SURVEY 8d asks for every core; SMT siblings only oversubscribe the FMA
+    units) and the fastest count of a probe on the dominant op.  `value` is the faster of the two; both are reported."""
     from oracle import nets, sampling
 
     sd = {k: v.detach().cpu() for k, v in denoiser.backbone.state_dict().items()}
     ncfg = dict(cfg["net"])
-    # Use the thread count that is fastest on this host for the dominant op (a 256->256 3x3 conv):
-    # os.cpu_count() may exceed the cores this process may run on, and oversubscription is slow.
+    B = cfg["batch"]
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    probe_x, probe_w = torch.randn(1, 256, 128, 128), torch.randn(256, 256, 3, 3)
-    best, threads = None, 1
-    for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, 128, avail)}):
+    phys = min(physical_cores(), avail)
+    probe_x, probe_w = torch.randn(B, 256, 128, 128), torch.randn(256, 256, 3, 3)
+    probe = {}
+    for nt in sorted({min(avail, c) for c in (16, 32, 64, 128, phys)}):
         torch.set_num_threads(nt)
         torch.nn.functional.conv2d(probe_x, probe_w, padding=1)
         t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(2):
             torch.nn.functional.conv2d(probe_x, probe_w, padding=1)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best:
-            best, threads = dt, nt
-    torch.set_num_threads(threads)
+        probe[nt] = (time.perf_counter() - t0) / 2
+    best = min(probe, key=probe.get)
     mean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, ncfg, a, c), x, t)  # noqa: E731
     torch.manual_seed(1)
-    x = torch.randn(1, *cfg["shape"])
+    x = torch.randn(B, *cfg["shape"])
     pairs = sampling.time_pairs(steps=cfg["steps"])
     a_t, s_t = sampling.vp_schedule(pairs[0, 0])
     a_s, s_s = sampling.vp_schedule(pairs[0, 1])
@@ -396,26 +417,33 @@ def cpu_baseline(denoiser, cfg, budget_s=25.0):
         m = mean(x, pairs[0, 0])
         return sampling.transition(x, m, torch.zeros_like(x), a_t, s_t, a_s, s_s, 0.0)
 
-    t0 = time.perf_counter()
-    one_step(x)  # warm-up
-    warm = time.perf_counter() - t0
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one_step(x)
-        n += 1
-        el = time.perf_counter() - t0
-        if n >= 2 and el + warm > budget_s or n >= 8:
-            break
-    s_per_step = el / n
+    runs = []
+    settings = [phys] if best == phys else [phys, best]
+    for nt in settings:
+        torch.set_num_threads(nt)
+        t0 = time.perf_counter()
+        one_step(x)  # warm-up
+        warm = time.perf_counter() - t0
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one_step(x)
+            n += 1
+            el = time.perf_counter() - t0
+            if n >= 2 and (el + warm > budget_s / len(settings) or n >= 6):
+                break
+        runs.append(dict(threads=nt, which="physical cores" if nt == phys else "fastest of the conv probe", timed_steps=n,
+                         s_per_step=round(el / n, 3), images_per_s=round(B / (cfg["steps"] * el / n), 6)))
+    top = max(runs, key=lambda r: r["images_per_s"])
     hi = host_info()
     return dict(
-        value=round(1.0 / (cfg["steps"] * s_per_step), 6), unit="images/s", cores=threads, kind="port",
-        host_cores=hi["host_cores"], usable_cores=hi["usable_cores"], cpu_model=hi["cpu_model"],
-        threads_note=f"torch intra-op threads = {threads}: the fastest of a probe over 8..{avail} threads on the dominant op "
-                     f"(a 256->256 3x3 conv); the host has {hi['host_cores']} logical cores",
-        sample=f"{n} DDIM steps of the same UNet at batch 1 ({s_per_step:.2f} s/step, 1 warm-up), extrapolated x{cfg['steps']} steps",
-        caveat=f"batch 1 on {threads} of {hi['host_cores']} logical cores (the GPU leg runs batch {cfg['batch']}): images/s = 1 / (steps x s per "
-               "step and image); a reported baseline, not a target -- the roofline fraction says what the kernels are worth",
+        value=top["images_per_s"], unit="images/s", cores=top["threads"], kind="port", batch=B,
+        host_cores=hi["host_cores"], usable_cores=hi["usable_cores"], physical_cores=phys, cpu_model=hi["cpu_model"],
+        runs=runs, probe_s_per_conv={str(k): round(v, 4) for k, v in probe.items()},
+        threads_note=f"torch intra-op threads: {phys} = the physical cores of this host ({hi['host_cores']} logical) and {best} = the fastest of a "
+                     f"probe over {sorted(probe)} threads on the dominant op (a 256->256 3x3 conv at batch {B}); value = the faster run",
+        sample=f"{top['timed_steps']} full DDIM steps of the same UNet at batch {B} ({top['s_per_step']:.2f} s/step on {top['threads']} threads, "
+               f"1 warm-up step), extrapolated x{cfg['steps']} steps",
+        caveat="a reported baseline, not a target -- the roofline fraction says what the kernels are worth",
     )
 
 
@@ -549,6 +577,11 @@ def main() -> None:
             "collective": "all_gather_into_tensor(x0) once per sampling; none inside the loop",
         }
 
+    if world > 1:
+        # every collective of the bench is done: ranks > 0 leave now instead of idling in a barrier while rank 0 profiles
+        # (tape profile, calibration kernels, PMC passes, transition sweeps: tens of seconds on one GPU)
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         images_per_s = world * B * args.steps / elapsed
@@ -573,19 +606,17 @@ def main() -> None:
             "dist": dist_info,
             "host": host_info(),
         }
-        out.update(roofline_report(sampler, device, args, world))
+        out.update(roofline_report(sampler, device, args, world, ms_per_step / cfg["steps"]))
         if world == 1 and not args.no_cpu_baseline and cfg["kind"] == "unet":
             out["cpu_baseline"] = cpu_baseline(den, cfg)
             out["speedup_vs_cpu"] = round(images_per_s / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
-def roofline_report(sampler, device, args, world) -> dict:
+def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
     r"""`roofline` (dominant kernel), `roofline_kernels` (every matrix-pipe family of the step), `step_breakdown`
-    and `roofline_transition`, all from HIP events of THIS run; `traffic` from the PMC passes."""
+    and `roofline_transition`, all from HIP events of THIS run; `traffic` from the PMC passes.  `graph_step_ms` is the
+    wall time of one captured denoise step in the timed region (the one clock every share is taken against)."""
     prof = tape_profile(sampler, device)
     fams = family_summary(prof)
     step_ms = sum(f["ms"] for f in fams.values())
@@ -602,9 +633,14 @@ def roofline_report(sampler, device, args, world) -> dict:
         k = {
             "bound": "mfma", "kernel": KERNEL_OF.get(fam, fam), "entry": fam, "achieved": round(tf, 2), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(tf / peak, 4), "launches": f["launches"], "avg_us": round(f["ms"] * 1e3 / f["launches"], 2),
-            "ms_per_denoise_step": round(f["ms"], 3), "share_of_step": round(f["ms_event_pairs"] / step_ms, 4),
+            "ms_per_denoise_step": round(f["ms"], 3), "share_of_step": round(f["ms"] / graph_step_ms, 4),
             "avg_us_with_event_pairs": round(f["ms_event_pairs"] * 1e3 / f["launches"], 2),
-            "timing": "all launches of the family of one denoise step, tape order, one HIP-event pair, median of 3 (avg_us_with_event_pairs: one pair per launch, ~10 us of idle each)",
+            "timing": "ms_per_denoise_step / avg_us / frac: all launches of the family of one denoise step, tape order, ONE HIP-event pair, "
+                      "median of 3 -- the family replayed out of graph order with warm caches, so an upper bound on its rate; it agrees with "
+                      "the rocprofv3 kernel durations of the same command (profiles/), which is what a reader should check it against.  "
+                      "share_of_step = that time / the captured graph's wall time per denoise step (timed region).  "
+                      "frac_from_graph_step: the conservative figure, see there.  avg_us_with_event_pairs: one pair per launch (~10 us of idle each)",
+            "algorithmic_over_nominal": round(tf / PEAK_FP32_TFLOPS, 4),
             "algorithmic_flops_per_step": f["flops"],
             "executed_mfma_tflops": round(tf / (WINOGRAD_GAIN if wino else 1.0), 2), "mfma_peak": PEAK_FP32_TFLOPS,
             "traffic": None,
@@ -626,7 +662,14 @@ def roofline_report(sampler, device, args, world) -> dict:
                     k["traffic_over_compulsory"] = round(k["traffic_per_denoise_step"] / pmc["winograd_compulsory_bytes_per_forward"], 3)
         kernels[fam] = k
     dom = max(kernels.values(), key=lambda k: k["ms_per_denoise_step"])
+    # The conservative reading: charge the dominant family with everything of the captured step that the other
+    # families' back-to-back times and the other ops' event times do not explain (launch gaps, cold caches, graph order).
+    rest = sum(k["ms_per_denoise_step"] for k in kernels.values() if k is not dom) + sum(f["ms"] for f in fams.values() if not f["flops"])
+    dom_ms_graph = max(graph_step_ms - rest, dom["ms_per_denoise_step"])
+    dom["frac_from_graph_step"] = round(dom["algorithmic_flops_per_step"] / (dom_ms_graph * 1e-3) / 1e12 / dom["peak"], 4)
+    dom["ms_per_denoise_step_from_graph_step"] = round(dom_ms_graph, 3)
     roof = dict(dom)
+    roof["graph_ms_per_denoise_step"] = round(graph_step_ms, 3)
     if not args.half and dom["kernel"] != "attention_kernel":
         sus = sustained_mfma_tflops(device)
         roof["sustained_mfma_tflops"] = round(sus, 1)

@@ -95,3 +95,19 @@ def test_argument_errors_are_returned_not_raised(built_lib):
         assert word.lower() in lib.az_error_string(code).lower()
     with pytest.raises(_lib.AzulaAmdError, match="az_scale_f32"):
         _lib.call("az_scale_f32", None, None, None, 16, None)
+
+
+def test_committed_kloop_streams_are_the_generators_output(monkeypatch):
+    r"""wino_kloop.inc / igemm_kloop.inc are committed sources that a build never rewrites: they must be exactly what their
+    generators emit, and a user's KL_* / KG_* environment must not change that (only AZ_KLOOP_AB=1 A/B builds honour them)."""
+    import subprocess
+    import sys
+
+    csrc = os.path.join(ROOT, "azula_amd", "csrc")
+    env = dict(os.environ, KL_ABLATE="vload,uload", KL_SCALAR_ADD="1", KG_XOR_END="0")
+    env.pop("AZ_KLOOP_AB", None)
+    for gen in ("gen_wino_kloop.py", "gen_igemm_kloop.py"):
+        res = subprocess.run([sys.executable, os.path.join(csrc, gen), "--check"], env=env, capture_output=True, text=True)
+        assert res.returncode == 0, res.stdout + res.stderr
+    tracked = subprocess.run(["git", "ls-files", "azula_amd/csrc/_obj", "azula_amd/csrc/_ab"], cwd=ROOT, capture_output=True, text=True)
+    assert tracked.returncode != 0 or tracked.stdout.strip() == "", "build by-products are tracked: " + tracked.stdout

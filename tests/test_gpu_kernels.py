@@ -456,6 +456,42 @@ def test_conv2d_random_shapes(az, wino):
 
 
 @pytest.mark.parametrize("wino", [False, True])
+@pytest.mark.parametrize("shift", [-2, -1, 1, 2])
+@pytest.mark.parametrize("Cin,H,W", [(32, 16, 16), (64, 12, 20), (20, 9, 7)])
+def test_conv2d_depth_tap_between_poisoned_neighbours(az, wino, shift, Cin, H, W):
+    """One depth tap of a 3-D convolution (AzConvArgs.depth / depth_shift: image b reads plane b + shift of its own volume, a
+    plane outside the volume reads zeros) with NaN-filled memory directly in front of and behind the source: the buffer
+    descriptors must stay inside the allocation whatever the shift (their base used to move by `shift` planes, so
+    only the per-lane masks stood between a tap and its neighbours).  32- / 64-channel cases take the hand-scheduled streams."""
+    from azula_amd.engine import Act, Builder
+
+    D, V, Cout = 3, 2, 64
+    B = D * V
+    g = torch.Generator().manual_seed(Cin + H + shift)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    full = F.conv2d(x, w, None, padding=1)
+    ref = b[None, :, None, None].expand(B, Cout, H, W).clone()
+    for i in range(B):
+        if 0 <= i % D + shift < D:
+            ref[i] += full[i + shift]
+    cs = (Cin + 3) // 4 * 4
+    n = B * H * W * cs
+    guard = 2 * H * W * cs + 4096
+    arena = torch.full((n + 2 * guard,), float("nan"), device="cuda")
+    arena[guard:guard + n] = to_nhwc(dev(x)).reshape(-1)
+    bld = Builder(torch.device("cuda"))
+    xa = Act(arena[guard:guard + n], B, H, W, Cin, cs, True)
+    y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, winograd=wino, depth=(D, shift))
+    bld.finish()
+    bld.tape.run()
+    out = from_nhwc(y.buf.reshape(B, H, W, y.cs), Cout)
+    assert torch.isfinite(out).all()
+    assert max_err(out, ref) < conv_tol(Cin, 3, wino), max_err(out, ref)
+
+
+@pytest.mark.parametrize("wino", [False, True])
 @pytest.mark.parametrize("Cin,Cout,ks", [(32, 64, 1), (20, 24, 3), (64, 256, 1)])
 def test_conv2d_swiglu_epilogue(az, wino, Cin, Cout, ks):
     """AzConvArgs.act = 4: y[c] = x[2c] * silu(x[2c+1]) applied to the convolution's output in its epilogue (half the
