@@ -338,6 +338,21 @@ def rectified_schedule(t: Tensor, alpha_min: float = 1e-3, sigma_min: float = 1e
     return t * alpha_min + (1 - t), t + (1 - t) * sigma_min
 
 
+def cosine_schedule(t: Tensor, alpha_min: float = 1e-3, sigma_min: float = 1e-3):
+    r"""alpha_t = cos(acos(alpha_min) t), sigma_t = sqrt(1 - alpha_t^2 + sigma_min^2)  -- azula/noise.py:147-154."""
+    alpha = torch.cos(math.acos(alpha_min) * t)
+    return alpha, torch.sqrt(1 - torch.cos(math.acos(alpha_min) * t) ** 2 + sigma_min**2)
+
+
+def simple_mean(backbone, x_t: Tensor, t: Tensor, schedule=vp_schedule, backbone_dtype: torch.dtype = torch.float32, **kwargs) -> Tensor:
+    r"""SimpleDenoiser: mu = F(c_in x_t, c_time)  -- azula/denoise.py:201-228."""
+    alpha_t, sigma_t = schedule(t)
+    alpha_t, sigma_t = _expand(alpha_t, x_t.ndim), _expand(sigma_t, x_t.ndim)
+    c_in = torch.rsqrt(alpha_t**2 + sigma_t**2)
+    c_time = torch.log(sigma_t / alpha_t).reshape_as(t)
+    return backbone((c_in * x_t).to(backbone_dtype), c_time.to(backbone_dtype), **kwargs).to(x_t)
+
+
 def jit_mean(backbone, x_t: Tensor, t: Tensor, label: Tensor | None = None, num_classes: int = 1000,
              schedule=rectified_schedule) -> Tensor:
     r"""JITDenoiser.forward -- plugins/jit/__init__.py:60-102: c_in = 1 / (alpha + sigma),

@@ -67,6 +67,29 @@ def test_c2_channel_plan_against_the_oracle(c2_net, policy, monkeypatch):
     assert e2 < 2e-6 * max(1.0, ref_x0.abs().max().item())  # measured 3.0e-7 .. 3.6e-7
 
 
+def test_c2_channel_plan_ddim64_full_length(c2_net):
+    """BASELINE configs[1]'s sampler at its real length -- DDIMSampler(steps=64) -- at configs[1]'s full channel plan, one
+    64 x 64 sample, against the oracle's 64-step loop on the host (VERDICT r03 weak #1: the full-width check was DDIM-3)."""
+    from azula_amd.sample import DDIMSampler
+
+    den, x1, _, _ = c2_net
+    sd = {k: v.detach().cpu() for k, v in den.backbone.state_dict().items()}
+    import bench
+
+    ncfg = dict(bench.CONFIGS["c2"]["net"])
+    oracle_mean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, ncfg, a, c), x, t)  # noqa: E731
+    den.backbone.net._plans.clear()
+    smp = DDIMSampler(den, steps=64, silent=True)
+    x0 = smp(x1.cuda())
+    assert next(iter(smp._fused_cache.values())).graph is not None
+    ref = sampling.sample(oracle_mean, x1, steps=64, eta=0.0)
+    sc = max(1.0, ref.abs().max().item())
+    e = max_err(x0, ref)
+    print(f"C2 widths @{RES}^2 DDIM-64 max|d| {e:.3e} (scale {sc:.2f})")
+    den.backbone.net._plans.clear()
+    assert e < 2e-5 * sc  # measured: see DESIGN.md Numerics (bound <= 5 x)
+
+
 @pytest.fixture(scope="module")
 def adm_net():
     import bench

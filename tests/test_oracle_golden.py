@@ -292,3 +292,39 @@ def test_g17_anisotropic_strides(golden):
         x = g[name + "_x"]
         y = nets.unet_forward(sd, cfg, x, g["mod"][: x.shape[0]])
         torch.testing.assert_close(y, g[name + "_y"], **TIGHT)
+
+
+def _g20_oracle(g):
+    cfg = g.meta["unet_cfg"]
+    sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["unet_shapes"].items()}, g.meta["unet_weight_seed"])
+    bb = lambda a, c, **_: nets.time_wrapped_unet(sd, cfg, a, c)  # noqa: E731
+    scheds = {"cosine": sampling.cosine_schedule, "rectified": sampling.rectified_schedule}
+    dens = {"karras": sampling.karras_mean, "simple": sampling.simple_mean}
+    return bb, scheds, dens
+
+
+def test_g20_usages(golden):
+    """Per-sample times, start / stop, cosine / rectified schedules x Karras / Simple denoisers x sampler families, ADM with
+    per-sample times and a tensor-valued guidance strength: the oracle against the reference's outputs."""
+    g = golden("g20_usages")
+    bb, scheds, dens = _g20_oracle(g)
+    x = g["x"]
+    assert max_err(sampling.karras_mean(bb, x, g["t_per_sample"]), g["mean_per_sample_t"]) < 1e-5
+    om = lambda xx, t: sampling.karras_mean(bb, xx, t)  # noqa: E731
+    assert max_err(sampling.sample(om, x, steps=5, eta=0.0, start=0.8, stop=0.1), g["ddim5_08_01"]) < 2e-5
+    for sname, sora in scheds.items():
+        for dname, dora in dens.items():
+            key = f"{sname}_{dname}"
+            m = lambda xx, t, dora=dora, sora=sora: dora(bb, xx, t, schedule=sora)  # noqa: E731
+            x1 = g[key + "_x1"]
+            sc = lambda k: 2e-5 * max(1.0, g[k].abs().max().item())  # noqa: E731
+            assert max_err(sampling.sample(m, x1, schedule=sora, steps=4, eta=0.0), g[key + "_ddim"]) < sc(key + "_ddim")
+            assert max_err(sampling.sample_euler(m, x1, schedule=sora, steps=4), g[key + "_euler"]) < sc(key + "_euler")
+            assert max_err(sampling.sample_euler(m, x1, schedule=sora, steps=4, heun=True), g[key + "_heun"]) < sc(key + "_heun")
+            assert max_err(sampling.sample_multistep(m, x1, "zEAB", order=2, schedule=sora, steps=4), g[key + "_zeab"]) < sc(key + "_zeab")
+    acfg = g.meta["adm_cfg"]
+    asd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["adm_shapes"].items()}, g.meta["adm_weight_seed"])
+    sig = sampling.adm_sigmas(acfg["discrete_schedule"], acfg["discrete_steps"])
+    abb = lambda a, i, y=None: nets.adm_unet_forward(asd, acfg, a, i, y)  # noqa: E731
+    mean, var = sampling.adm_posterior(abb, g["adm_x"], g["adm_t"], sig, label=g["adm_label"])
+    assert max_err(mean, g["adm_mean"]) < 5e-5 and max_err(var, g["adm_var"]) < 5e-5 * max(1.0, g["adm_var"].abs().max().item())
