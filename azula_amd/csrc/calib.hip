@@ -58,21 +58,39 @@ __global__ __launch_bounds__(256) void calib_write_kernel(float* __restrict__ ds
 // vector work.  What this sustains is the chip's fp32 MFMA rate under its power limit (the guide's 157.3 TF/s is 256 CUs x
 // 256 FLOP per cycle at 2.4 GHz; under a dense MFMA load the clock settles near 2.0 GHz).
 typedef float f32x16c __attribute__((ext_vector_type(16)));
+// RANDOM = false: every MFMA of a lane multiplies the same two values (a0 scaled by the lane, b0) -- the multiplier inputs and
+// operand buses barely toggle, and the chip draws ~690 W.  RANDOM = true: 8 + 8 per-lane pseudo-random operands in [-1, 1),
+// a different pair for each of the 8 accumulator chains, so consecutive MFMAs (and the 16 passes inside one) see unrelated
+// bit patterns as a real GEMM does: the power the matrix pipe draws on real data is what caps the clock (tools/power_probe.py).
+template <bool RANDOM>
 __global__ __launch_bounds__(256) void calib_mfma_kernel(float* sink, int iters, float a0, float b0) {
   f32x16c acc[8];
 #pragma unroll
   for (int f = 0; f < 8; ++f)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-  const float a = a0 * (1.0f + (float)(threadIdx.x & 7) * 0.125f), b = b0;
+  float a[8], b[8];
+  unsigned h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    if (RANDOM) {
+      h = h * 1664525u + 1013904223u;
+      a[f] = a0 * ((float)(int)(h >> 8) * (1.f / 8388608.f) - 1.f);
+      h = h * 1664525u + 1013904223u;
+      b[f] = b0 * ((float)(int)(h >> 8) * (1.f / 8388608.f) - 1.f);
+    } else {
+      a[f] = a0 * (1.0f + (float)(threadIdx.x & 7) * 0.125f);
+      b[f] = b0;
+    }
+  }
   for (int i = 0; i < iters; ++i) {
 #pragma unroll
-    for (int f = 0; f < 8; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[f], 0, 0, 0);
+    for (int f = 0; f < 8; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[f], b[f], acc[f], 0, 0, 0);
   }
   float t = 0.f;
 #pragma unroll
   for (int f = 0; f < 8; ++f) t += acc[f][0] + acc[f][15];
-  if (t == -1.f) sink[0] = t;  // (never true: keeps the accumulators alive)
+  if (t == -1.2345e37f) sink[0] = t;  // (never true: keeps the accumulators alive)
 }
 
 }  // namespace
@@ -82,7 +100,14 @@ extern "C" {
 int az_calib_mfma_f32(float* sink, int32_t workgroups, int32_t iters, float a, float b, az_stream_t stream) {
   AZ_REQUIRE(sink, AZ_E_NULL);
   AZ_REQUIRE(workgroups > 0 && iters > 0, AZ_E_SHAPE);
-  hipLaunchKernelGGL(calib_mfma_kernel, dim3((unsigned)workgroups), dim3(256), 0, az_s(stream), sink, iters, a, b);
+  hipLaunchKernelGGL(calib_mfma_kernel<false>, dim3((unsigned)workgroups), dim3(256), 0, az_s(stream), sink, iters, a, b);
+  return az_launch_status();
+}
+
+int az_calib_mfma_random_f32(float* sink, int32_t workgroups, int32_t iters, float a, float b, az_stream_t stream) {
+  AZ_REQUIRE(sink, AZ_E_NULL);
+  AZ_REQUIRE(workgroups > 0 && iters > 0, AZ_E_SHAPE);
+  hipLaunchKernelGGL(calib_mfma_kernel<true>, dim3((unsigned)workgroups), dim3(256), 0, az_s(stream), sink, iters, a, b);
   return az_launch_status();
 }
 

@@ -26,6 +26,8 @@
 // This file holds two kernels behind the same AzConvArgs: the direct implicit GEMM below (any
 // ksize / stride, linears) and the fused Winograd F(2x2,3x3) kernel further down (3x3 stride 1).
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -1492,6 +1494,7 @@ struct WinoP {
   int kps;             // chunks per split
   int cblocks;         // ceil(cout_s / WC)
   int tblocks;         // ceil(ntiles / WT)
+  int gt, gc;          // workgroup order: rectangles of gt tile blocks x gc cout blocks, tile block fastest inside (1, cblocks: cout fastest)
 };
 
 
@@ -1548,8 +1551,16 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   const int bid = blockIdx.x;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
   const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-  const int tb = wg / p.cblocks;
-  const int cb = wg - tb * p.cblocks;
+  // An XCD runs 32 workgroups at a time out of its contiguous range of `wg`: make them a RECTANGLE of gt tile blocks x gc cout
+  // blocks (host: 8 x 4 where the grid allows), so that its L2 fetches 8 tile blocks' patches and 4 cout blocks' filter chunks
+  // per stage instead of 2 and 16 on the 1024-channel layers (a filter chunk is 2 - 4 x the bytes of a tile block's patches).
+  const int rsz = p.gt * p.gc;
+  const int rect = wg / rsz, rin = wg - rect * rsz;
+  const int rcols = p.cblocks / p.gc;
+  const int rrow = rect / rcols;
+  const int rin_c = rin / p.gt;
+  const int tb = rrow * p.gt + (rin - rin_c * p.gt);
+  const int cb = (rect - rrow * rcols) * p.gc + rin_c;
   const int t0 = tb * WT;
   const int tiles_img = p.tiles_h * p.tiles_w;
   const int b_first = t0 / tiles_img;
@@ -2605,6 +2616,22 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   if (splitk > 1) p.a.gn_quads = nullptr;  // (the slabs carry no moments: the combine kernel produces them)
   p.cblocks = (a->cout_s + WC - 1) / WC;
   p.tblocks = (p.ntiles + WT - 1) / WT;
+  {
+    // workgroup order (see the kernel): rectangles of gt x gc = 32 workgroups when both grid sides divide, cout blocks fastest
+    // otherwise (gt = 1, gc = cblocks).  AZ_WINO_RECT="gt,gc" overrides (A/B runs); "1,0" = cout fastest everywhere.
+    static int env_gt = -1, env_gc = -1;
+    if (env_gt < 0) {
+      const char* e = getenv("AZ_WINO_RECT");
+      env_gt = 0, env_gc = 0;
+      if (e) sscanf(e, "%d,%d", &env_gt, &env_gc);
+    }
+    int gt = env_gt > 0 ? env_gt : 8, gc = env_gt > 0 ? (env_gc > 0 ? env_gc : p.cblocks) : 4;
+    while (gc > 1 && p.cblocks % gc) gc >>= 1;
+    if (env_gt <= 0) gt = 32 / gc;
+    while (gt > 1 && p.tblocks % gt) gt >>= 1;
+    if (p.cblocks % gc || p.tblocks % gt) gt = 1, gc = p.cblocks;
+    p.gt = gt, p.gc = gc;
+  }
   AZ_REQUIRE((int64_t)p.nk * p.cblocks * WU_STAGE * 4 <= (1ll << 31), AZ_E_SHAPE);
   hipStream_t st = az_s(stream);
   const int64_t nwg = (int64_t)p.cblocks * p.tblocks;

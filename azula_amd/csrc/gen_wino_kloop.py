@@ -77,7 +77,8 @@ class Stream:
         self.lds_seq += 1
 
     def read_set(self, s: int, group: int):
-        self.lds(f"ds_read_b128 {fa(s)}, v{V_FA} offset:{group * GROUP_BYTES}")
+        if "afrag" not in ABL:  # (timing ablation: the filter fragments never read -- what keeping U out of LDS would save)
+            self.lds(f"ds_read_b128 {fa(s)}, v{V_FA} offset:{group * GROUP_BYTES}")
         self.lds(f"ds_read_b128 {fb(s)}, v{V_FB} offset:{group * GROUP_BYTES}")
         self.set_done_at[s] = self.lds_seq
 
@@ -364,7 +365,7 @@ def flat(items):
     return [t for _, t in items]
 
 
-ABL = set(_AB.get("KL_ABLATE", "").split(","))  # timing ablations (WRONG results): vload, uload, vtrans, vstore, ustore, barrier
+ABL = set(_AB.get("KL_ABLATE", "").split(","))  # timing ablations (WRONG results): vload, uload, vtrans, vstore, ustore, barrier, afrag
 # Tunables (environment overrides are for tools/kloop_variant.py A/B builds; the committed .inc is the default)
 PRIO_HEAD = {"V": int(_AB.get("KL_PRIO_V", "0")), "U": int(_AB.get("KL_PRIO_U", "0"))}  # U role = waves 4..7 = the younger wave of every SIMD
 

@@ -218,24 +218,28 @@ KERNEL_OF = {  # C-ABI entry point -> the __global__ kernel it launches (names a
 }
 
 
-def sustained_mfma_tflops(device):
-    r"""The fp32 MFMA rate the chip sustains under its power limit: az_calib_mfma_f32 (registers only, 4 waves per SIMD),
-    median of 5 launches of ~1.5 ms.  Context for `roofline.frac`, which stays relative to the guide's nominal 157.3 TF/s."""
+def sustained_mfma_tflops(device, random_operands=False):
+    r"""The fp32 MFMA rate the matrix pipe sustains ALONE (registers only, 2 waves per SIMD), median of 5 launches of ~1.5 ms:
+    `az_calib_mfma_f32` on constant operands (nothing toggles: ~690 W, the clock stays at 2.4 GHz) or `az_calib_mfma_random_f32`
+    on per-lane pseudo-random operands (the bit activity of a real GEMM: the 1400 W cap then sets the clock).  Context for
+    `roofline.frac`, which stays relative to the guide's nominal 157.3 TF/s."""
     from azula_amd import _lib
 
     sink = torch.zeros(4, device=device)
     stream = torch.cuda.current_stream(device)
     wgs, iters = 256 * 2, 3000   # two workgroups per CU = 2 waves per SIMD, ~1.3 ms
     flops = wgs * 4 * iters * 8 * 4096
+    entry = "az_calib_mfma_random_f32" if random_operands else "az_calib_mfma_f32"
     times = []
     for rep in range(7):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        _lib.call("az_calib_mfma_f32", sink.data_ptr(), wgs, iters, 1.0, 0.5, stream.cuda_stream)
+        for _ in range(4 if random_operands else 1):  # (a few ms back to back: the power controller needs time to react)
+            _lib.call(entry, sink.data_ptr(), wgs, iters, 1.0, 0.5, stream.cuda_stream)
         e1.record(stream)
         torch.cuda.synchronize(device)
         if rep >= 2:
-            times.append(e0.elapsed_time(e1))
+            times.append(e0.elapsed_time(e1) / (4 if random_operands else 1))
     return flops / (sorted(times)[2] * 1e-3) / 1e12
 
 
@@ -672,11 +676,15 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
     roof["graph_ms_per_denoise_step"] = round(graph_step_ms, 3)
     if not args.half and dom["kernel"] != "attention_kernel":
         sus = sustained_mfma_tflops(device)
+        sus_rnd = sustained_mfma_tflops(device, random_operands=True)
         roof["sustained_mfma_tflops"] = round(sus, 1)
+        roof["sustained_mfma_tflops_random_operands"] = round(sus_rnd, 1)
         roof["frac_of_sustained"] = round(dom["executed_mfma_tflops"] / sus, 4)
-        roof["sustained_note"] = ("az_calib_mfma_f32: v_mfma_f32_32x32x2_f32 on registers only, 2 waves per SIMD, measured in this run (also "
-                                  "155.8 TF/s over 65 ms): the matrix pipe ALONE holds the nominal peak on this chip; the clock only drops (to "
-                                  "~2.15 GHz) when LDS, texture-path and vector work run beside it; `frac` stays relative to the nominal peak")
+        roof["frac_of_sustained_random_operands"] = round(dom["executed_mfma_tflops"] / sus_rnd, 4)
+        roof["sustained_note"] = ("v_mfma_f32_32x32x2_f32 on registers only, 2 waves per SIMD, measured in this run: az_calib_mfma_f32 "
+                                  "multiplies constants (no bit activity, ~690 W: the pipe holds the nominal peak), "
+                                  "az_calib_mfma_random_f32 per-lane random operands (the activity of real data: the 1400 W cap sets the "
+                                  "clock -- tools/power_probe.py, profiles/r04_power_probe.txt); `frac` stays relative to the nominal peak")
     roof["kernel"] = f"{dom['kernel']} (fp32 v_mfma_f32_32x32x2_f32), all {dom['launches']} launches of one denoise step"
     roof["note"] = ("achieved = ALGORITHMIC FLOP (2*pixels*Cout*Cin*k^2; attention 4*B*H*T^2*d) of the kernel's launches in one "
                     "denoise step / the sum of their HIP-event durations; traffic = HBM-side bytes per launch from rocprofv3 "

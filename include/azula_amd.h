@@ -467,6 +467,11 @@ int az_calib_write_f32(float* dst, int64_t nbytes, float value, az_stream_t stre
 /* `workgroups` x 4 waves, each issuing iters x 8 independent v_mfma_f32_32x32x2_f32 on registers (4096 FLOP each): the fp32
  * MFMA rate the chip SUSTAINS under its power limit, which bench.py reports beside the nominal 157.3 TF/s peak. */
 int az_calib_mfma_f32(float* sink, int32_t workgroups, int32_t iters, float a, float b, az_stream_t stream);
+/* The same instruction stream on per-lane PSEUDO-RANDOM operands (uniform in [-a, a) x [-b, b), a different pair per
+ * accumulator chain).  `az_calib_mfma_f32` multiplies the same two constants forever, which toggles almost nothing (~690 W on
+ * MI355X); on random bit patterns the matrix pipe alone draws what a real GEMM's does, and the 1400 W cap -- not the 2.4 GHz
+ * clock -- sets the rate (tools/power_probe.py).  bench.py reports both as the context of `roofline.frac`. */
+int az_calib_mfma_random_f32(float* sink, int32_t workgroups, int32_t iters, float a, float b, az_stream_t stream);
 
 #ifdef __cplusplus
 }

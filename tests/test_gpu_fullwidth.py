@@ -87,7 +87,7 @@ def test_c2_channel_plan_ddim64_full_length(c2_net):
     e = max_err(x0, ref)
     print(f"C2 widths @{RES}^2 DDIM-64 max|d| {e:.3e} (scale {sc:.2f})")
     den.backbone.net._plans.clear()
-    assert e < 2e-5 * sc  # measured: see DESIGN.md Numerics (bound <= 5 x)
+    assert e < 3.4e-6 * sc  # measured 2.6e-6 on scale 3.88 = 6.8e-7 relative (MI355X, round 4): bound = 5 x
 
 
 @pytest.fixture(scope="module")

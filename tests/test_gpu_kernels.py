@@ -1050,4 +1050,11 @@ def test_calibration_kernels(az):
     tf = wgs * 4 * iters * 8 * 4096 / (e0.elapsed_time(e1) * 1e-3) / 1e12
     print(f"az_calib_mfma_f32: {tf:.1f} TF/s")
     assert 20.0 < tf < 170.0  # (a loose sanity bound: a cold clock has shown 74 TF/s on a first launch)
+    e0.record()
+    az.call("az_calib_mfma_random_f32", sink.data_ptr(), wgs, iters, 1.0, 0.5, az.stream_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    tf = wgs * 4 * iters * 8 * 4096 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    print(f"az_calib_mfma_random_f32: {tf:.1f} TF/s")
+    assert 20.0 < tf < 170.0
 
