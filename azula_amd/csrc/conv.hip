@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
   const int b_base = max(b_first + dshift, 0);
   const int b_adj = b_first + dshift - b_base;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e <= 0 ? 0 : (e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4)); };  // (e <= 0: a depth shift past the last plane)
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -1576,7 +1576,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   // could not absorb -- only lanes whose plane is masked anyway (pdok / v_dok false) would land below 0).
   const int b_base = max(b_first + dshift, 0);
   const int b_adj = b_first + dshift - b_base;
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e <= 0 ? 0 : (e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4)); };  // (e <= 0: a depth shift past the last plane)
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)p.nk * p.cblocks * WU_STAGE), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -2102,7 +2102,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd4_kernel(Wino4P p) {
 
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e <= 0 ? 0 : (e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4)); };  // (e <= 0: a depth shift past the last plane)
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)p.nk * p.cblocks * W4U_STAGE), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
