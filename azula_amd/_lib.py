@@ -169,6 +169,16 @@ class AzConvArgs(C.Structure):
         ("reserved1", C.c_int32),
         ("depth", C.c_int32),
         ("depth_shift", C.c_int32),
+        ("qk_head_dim", C.c_int32),
+        ("qk_heads", C.c_int32),
+        ("qk_tokens", C.c_int32),
+        ("qk_rmsnorm", C.c_int32),
+        ("qk_eps", C.c_float),
+        ("qk_reserved", C.c_int32),
+        ("qk_q_weight", c_f32p),
+        ("qk_k_weight", c_f32p),
+        ("qk_rope_cos", c_f32p),
+        ("qk_rope_sin", c_f32p),
     ]
 
 

@@ -251,6 +251,76 @@ __device__ __forceinline__ void epilogue_batch_nhwc(const AzConvArgs& a, const i
   }
 }
 
+// act 5: the tile is part of a fused q | k | v projection ('(3 H C)' channels); q and k are prepared for the attention kernel
+// here, once: RMS norm over the head's channels, learned gains, RoPE (azula/nn/attention.py:92-95).  A thread holds the channel
+// quad `co` of pixels (tokens) n[i]; the D / 4 quads of a (token, head) sit on D / 4 adjacent lanes (the exchange buffer is read
+// back with a pixel's 32 quads on 32 consecutive lanes and tiles start at multiples of 128 channels), so the sum of squares is a
+// butterfly over 8 / 16 / 32 lanes.  Every lane takes part in the shuffles (v lanes and skipped pixels compute values they drop).
+template <int NB>
+__device__ __forceinline__ void epilogue_batch_qk(const AzConvArgs& a, const int (&n)[NB], const int (&b)[NB], int co,
+                                                  const float4 (&v)[NB]) {
+  const int D = a.qk_head_dim, HC = a.qk_heads * D;
+  const int which = co / HC;  // 0: q, 1: k, 2: v
+  const int cw = co - which * HC;
+  const int head = cw / D, d = cw - head * D;
+  const bool qk = which < 2;
+  const bool has_bias = a.bias != nullptr;
+  const float4 bv = ld4(has_bias ? a.bias + co : reinterpret_cast<const float*>(a.weight));
+  const float* gp = which == 0 ? a.qk_q_weight : a.qk_k_weight;
+  const bool has_gain = qk && gp != nullptr;
+  const float4 gw = ld4(has_gain ? gp + d : reinterpret_cast<const float*>(a.weight));
+  const bool rope = qk && a.qk_rope_cos != nullptr;
+  float2 rc[NB], rs[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    rc[i] = make_float2(1.f, 1.f);
+    rs[i] = make_float2(0.f, 0.f);
+    if (rope && n[i] >= 0) {
+      const int64_t ro = ((int64_t)(n[i] - b[i] * a.qk_tokens) * a.qk_heads + head) * (D / 2) + d / 2;
+      rc[i] = *reinterpret_cast<const float2*>(a.qk_rope_cos + ro);
+      rs[i] = *reinterpret_cast<const float2*>(a.qk_rope_sin + ro);
+    }
+  }
+  const float inv_d = 1.f / (float)D;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    float4 f = v[i];
+    if (has_bias) {
+      f.x += bv.x;
+      f.y += bv.y;
+      f.z += bv.z;
+      f.w += bv.w;
+    }
+    if (a.qk_rmsnorm) {  // (wave-uniform)
+      float ss = (f.x * f.x + f.y * f.y) + (f.z * f.z + f.w * f.w);
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      ss += __shfl_xor(ss, 4, 64);
+      if (D >= 64) ss += __shfl_xor(ss, 8, 64);
+      if (D >= 128) ss += __shfl_xor(ss, 16, 64);
+      const float r = qk ? rsqrtf(ss * inv_d + a.qk_eps) : 1.f;
+      f.x *= r;
+      f.y *= r;
+      f.z *= r;
+      f.w *= r;
+    }
+    if (has_gain) {
+      f.x *= gw.x;
+      f.y *= gw.y;
+      f.z *= gw.z;
+      f.w *= gw.w;
+    }
+    if (rope) {
+      const float r0 = f.x, i0 = f.y, r1 = f.z, i1 = f.w;
+      f.x = r0 * rc[i].x - i0 * rs[i].x;
+      f.y = r0 * rs[i].x + i0 * rc[i].x;
+      f.z = r1 * rc[i].y - i1 * rs[i].y;
+      f.w = r1 * rs[i].y + i1 * rc[i].y;
+    }
+    if (n[i] >= 0) *reinterpret_cast<float4*>(a.dst + (int64_t)n[i] * a.cout_s + co) = f;
+  }
+}
+
 // A batch of NB outputs of one thread (same channel quad `co`, pixels n[i] of images b[i]; n[i] < 0: skip): all gate /
 // residual reads are issued first, then the NB stores.
 template <int NB, bool MOM = false>
@@ -263,6 +333,7 @@ __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const 
     return;
   }
   if (a.act == 4) return epilogue_batch_nhwc<NB, false, 4, false, 0>(a, n, b, co, v, mom);
+  if (a.act == 5) return epilogue_batch_qk<NB>(a, n, b, co, v);
   if (!a.dst_nchw && a.act <= 1) {
     const int rk = a.res == nullptr ? 0 : (a.res_up || a.res_bcast) ? 2 : 1;
     switch ((a.act * 2 + (a.gate != nullptr ? 1 : 0)) * 3 + rk) {
@@ -2425,8 +2496,17 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout > 0 && a->wout > 0, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
-  AZ_REQUIRE(a->act >= 0 && a->act <= 4, AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(a->act >= 0 && a->act <= 5, AZ_E_UNSUPPORTED);
   if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
+  if (a->act == 5) {  // q / k preparation of a fused qkv projection (epilogue_batch_qk)
+    AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->splitk <= 1 && a->depth == 0, AZ_E_UNSUPPORTED);
+    AZ_REQUIRE((a->qk_head_dim == 32 || a->qk_head_dim == 64 || a->qk_head_dim == 128) && a->qk_heads > 0 &&
+                   a->cout_s == 3 * a->qk_heads * a->qk_head_dim && a->qk_tokens > 0 && a->hout * a->wout == a->qk_tokens,
+               AZ_E_SHAPE);
+    AZ_REQUIRE((a->qk_rope_cos == nullptr) == (a->qk_rope_sin == nullptr), AZ_E_NULL);
+    AZ_REQUIRE(AZ_ALIGNED16(a->qk_q_weight) && AZ_ALIGNED16(a->qk_k_weight) && AZ_ALIGNED16(a->qk_rope_cos) && AZ_ALIGNED16(a->qk_rope_sin),
+               AZ_E_ALIGN);
+  }
   AZ_REQUIRE(a->ksize >= 1 && a->ksize <= 7 && a->stride >= 1 && a->pad >= 0 && (!a->aniso || a->stride_w >= 1), AZ_E_SHAPE);
   AZ_REQUIRE((a->hin + 2 * a->pad - a->ksize) / a->stride + 1 == a->hout &&
                  (a->win + 2 * a->pad - a->ksize) / (a->aniso ? a->stride_w : a->stride) + 1 == a->wout,

@@ -111,11 +111,12 @@ class Pool:
 class Act:
     r"""An NHWC activation: ``buf`` holds (B, H, W, cs) floats, ``C`` real channels."""
 
-    __slots__ = ("buf", "B", "H", "W", "C", "cs", "pinned", "gn_quads", "affine")
+    __slots__ = ("buf", "B", "H", "W", "C", "cs", "pinned", "gn_quads", "affine", "qk_prepared")
 
     def __init__(self, buf: torch.Tensor, B: int, H: int, W: int, C_: int, cs: int, pinned: bool = False) -> None:
         self.buf, self.B, self.H, self.W, self.C, self.cs, self.pinned = buf, B, H, W, C_, cs, pinned
         self.gn_quads = None  # (partials tensor, chunks per image): GroupNorm moments written by the producing conv
+        self.qk_prepared = False  # a fused qkv projection whose q / k are already normalised / gained / rotated (AzConvArgs.act = 5)
         self.affine = None    # ([scale | shift] tensor, act): a normalisation whose apply pass has not run -- the values are
         #                       act(buf * scale + shift); Builder.conv evaluates it inside the Winograd gather or materialises it
 
@@ -135,6 +136,8 @@ FP32_MFMA = os.environ.get("AZ_FP32_MFMA", "native")
 assert FP32_MFMA in ("native", "bf16x3"), FP32_MFMA
 X3_MIN_CHANNELS = 32  # bf16x3 only where both channel counts fill a K tile / an MFMA tile
 WINOGRAD4_MIN_TILES = int(os.environ.get("AZ_WINOGRAD4_MIN_TILES", "1024"))
+# q / k RMS norm, gains and RoPE of an attention layer in the epilogue of its qkv projection ("0": inside the attention kernel)
+QK_PREP = os.environ.get("AZ_QK_PREP", "1") != "0"
 # GroupNorm statistics from the producing convolution's epilogue ("1", default) or always by the separate pass ("0")
 GN_FUSED = os.environ.get("AZ_GN_FUSED", "1") != "0"
 # GroupNorm apply pass (y = x * S + T) inside the consuming Winograd convolution's gather ("0": always the separate pass)
@@ -319,6 +322,7 @@ class Builder:
         gn_stats: bool = False,
         out: Act | None = None,
         depth: tuple | None = None,
+        qk_prep: dict | None = None,
     ) -> Act | None:
         ks, bias = packed.ks, packed.bias
         pad = ks // 2
@@ -447,6 +451,23 @@ class Builder:
             a.gn_quads, a.gn_chunks = quads.data_ptr(), chunks
             out.gn_quads = (quads, chunks)
             self.tape.keep.append(quads)
+        if (qk_prep is not None and QK_PREP and name in ("az_conv2d_f32", "az_conv2d_bf16_f32", "az_conv2d_f16_f32", "az_conv2d_x3_f32")
+                and a.splitk == 1 and act == 0 and gate is None and res is None and out is not None and a.cout_s == cout
+                and qk_prep["head_dim"] in (32, 64, 128) and cout == 3 * qk_prep["heads"] * qk_prep["head_dim"]):
+            # the fused q | k | v projection of an attention layer: q / k RMS norm, gains and RoPE in THIS epilogue, once per
+            # layer, instead of in every workgroup of the attention kernel (three per head at 288 tokens: 123 -> 163 us)
+            a.act = 5
+            a.qk_head_dim, a.qk_heads, a.qk_tokens = qk_prep["head_dim"], qk_prep["heads"], hout * wout
+            a.qk_rmsnorm, a.qk_eps = int(qk_prep["rmsnorm"]), qk_prep["eps"]
+            keep = []
+            if qk_prep.get("weight") is not None:
+                a.qk_q_weight, a.qk_k_weight = (t.data_ptr() for t in qk_prep["weight"])
+                keep += list(qk_prep["weight"])
+            if qk_prep.get("rope") is not None:
+                a.qk_rope_cos, a.qk_rope_sin = (t.data_ptr() for t in qk_prep["rope"])
+                keep += list(qk_prep["rope"])
+            self.tape.keep.extend(keep)
+            out.qk_prepared = True
         if a.splitk > 1:
             self._ws_need = max(self._ws_need, a.splitk * npix * a.cout_s)
             self._ws_users.append(a)
@@ -660,6 +681,9 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
         setattr(a, n + "_hstride", hs)
     a.o_bstride, a.o_tstride, a.o_hstride = L * out.cs, out.cs, dim
     a.scale, a.qk_rmsnorm, a.eps = scale, int(qk_rmsnorm), eps
+    if qkv.qk_prepared:  # the projection's epilogue has normalised / gained / rotated q and k already (Builder.conv(qk_prep=...))
+        assert order in ("nHC", "3HC")
+        a.qk_rmsnorm, rope, qk_weight = 0, None, None
     if rope is not None:  # (cos, sin) tables of shape (L, heads * dim / 2)
         a.rope_cos, a.rope_sin = rope[0].data_ptr(), rope[1].data_ptr()
         self.tape.keep.extend(rope)

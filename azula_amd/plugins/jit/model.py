@@ -179,13 +179,13 @@ class JiTPlan:
             n1 = bld.row_norm(x, 1, weight=bld.const(blk.norm1.weight), scale=mod, shift=mod, scale_off=m0_ + Hd,
                               shift_off=m0_, bstride=MS, eps=1e-6)
             at = blk.attn
-            qkv = bld.conv(n1, bld.pack_conv(at.qkv.weight, at.qkv.bias), 3 * Hd)
+            rope_i = rope_img if i < net.in_context_start else rope_ctx
+            gains = (bld.const(at.q_norm.weight), bld.const(at.k_norm.weight))
+            # q / k RMS norm, gains and RoPE in the projection's epilogue, once per layer (head_dim 80 of JiT-H: in the attention kernel)
+            qkv = bld.conv(n1, bld.pack_conv(at.qkv.weight, at.qkv.bias), 3 * Hd,
+                           qk_prep=dict(heads=heads, head_dim=hd, rmsnorm=True, eps=1e-6, rope=rope_i, weight=gains))
             bld.free(n1)
-            att = bld.attention(
-                qkv, heads, "3HC", True, 1.0 / math.sqrt(hd), eps=1e-6,
-                rope=rope_img if i < net.in_context_start else rope_ctx,
-                qk_weight=(bld.const(at.q_norm.weight), bld.const(at.k_norm.weight)),
-            )
+            att = bld.attention(qkv, heads, "3HC", True, 1.0 / math.sqrt(hd), eps=1e-6, rope=rope_i, qk_weight=gains)
             bld.free(qkv)
             x2 = bld.conv(att, bld.pack_conv(at.proj.weight, at.proj.bias), Hd, gate=mod, gate_off=m0_ + 2 * Hd, gate_bstride=MS, res=x)
             bld.free(att)

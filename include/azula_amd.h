@@ -261,7 +261,8 @@ typedef struct AzConvArgs {
   int32_t ksize, stride, pad;
   int32_t hout, wout;
   int32_t act;             /* 0 none, 1 SiLU, 2 ReLU, 3 ReLU^2, 4 SwiGLU over interleaved pairs: dst gets cout_s / 2 channels per
-                              pixel, y[c] = x[2c] * silu(x[2c+1]) (no gate / res / dst_nchw; cout_s % 8 == 0) */
+                              pixel, y[c] = x[2c] * silu(x[2c+1]) (no gate / res / dst_nchw; cout_s % 8 == 0), 5 q / k preparation
+                              of a fused qkv projection (the qk_* fields at the end of this struct) */
   const float* gate;       /* optional (…, cout_s) */
   int64_t gate_bstride;    /* 0 = shared across the batch */
   const float* res;        /* optional residual, NHWC (B, hres, wres, cout_s) */
@@ -299,6 +300,23 @@ typedef struct AzConvArgs {
                             * (b % depth) + depth_shift falls outside [0, depth) -- the zero padding along the depth axis; a gate
                             * must be shared by the batch (gate_bstride 0).  The taps accumulate through `res` = `dst` */
   int32_t depth_shift;
+  /* act 5 (az_conv2d_f32 and its half / x3 forms, NHWC destination, no gate / res / gn_quads, splitk 1): the output is a fused
+   * q | k | v projection laid out '(3 H C)' (azula/nn/attention.py:90, plugins/jit/_src/model.py) with cout_s = 3 * qk_heads *
+   * qk_head_dim, and the epilogue prepares q and k for the attention kernel ONCE -- per (token, head): RMS norm over the head's
+   * channels (qk_rmsnorm 1; azula/nn/attention.py:92-93), the learned gains qk_q_weight / qk_k_weight ((head_dim) each or NULL),
+   * the rotation of adjacent (re, im) channel pairs by qk_rope_cos / qk_rope_sin ((qk_tokens, qk_heads * head_dim / 2) or NULL;
+   * attention.py:94-95) -- instead of every workgroup of az_attention_f32 repeating it for all keys of its head.  The v third
+   * only gets the bias.  head_dim 32, 64 or 128; a pixel index is batch * qk_tokens + token. */
+  int32_t qk_head_dim;
+  int32_t qk_heads;
+  int32_t qk_tokens;
+  int32_t qk_rmsnorm;
+  float qk_eps;
+  int32_t qk_reserved;
+  const float* qk_q_weight;
+  const float* qk_k_weight;
+  const float* qk_rope_cos;
+  const float* qk_rope_sin;
 } AzConvArgs;
 /* Narrow outputs (cout_s == 4, 3x3 stride 1 pad 1, one un-upsampled source with c0s % 16 == 0: the image head of
  * azula/nn/unet.py) run a VALU kernel instead of the 128-cout MFMA tile; splitk is ignored there.              */

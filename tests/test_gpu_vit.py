@@ -36,6 +36,61 @@ def test_attention_kernel(B, H, T, D, order, rms):
     assert max_err(got, ref) < 2e-5, max_err(got, ref)
 
 
+@pytest.mark.parametrize("B,H,T,D", [(2, 4, 48, 32), (2, 3, 288, 64), (1, 2, 100, 128), (3, 12, 64, 64)])
+@pytest.mark.parametrize("rms,gains,rope", [(True, False, False), (True, True, True), (False, False, True)])
+@pytest.mark.parametrize("half", [None, torch.bfloat16])
+def test_qk_preparation_in_the_projection_epilogue(B, H, T, D, rms, gains, rope, half):
+    """AzConvArgs.act = 5: the fused q | k | v projection's epilogue applies the q / k RMS norm, the learned gains and RoPE
+    once per layer (azula/nn/attention.py:92-95); the attention kernel then takes q and k as they are.  Checked against
+    torch (linear -> rms_norm -> gain -> rotate -> SDPA) and against the in-kernel path (AZ_QK_PREP off)."""
+    from azula_amd import engine
+    from azula_amd.engine import Act, Builder
+
+    Cin, HC = 64, H * D
+    g = torch.Generator().manual_seed(B * T + D + H)
+    x = torch.randn(B, T, Cin, generator=g)
+    w = torch.randn(3 * HC, Cin, generator=g) / math.sqrt(Cin)
+    bias = torch.randn(3 * HC, generator=g) * 0.1
+    qw, kw = (1 + 0.2 * torch.randn(D, generator=g) for _ in range(2))
+    theta = torch.randn(T, H * D // 2, generator=g) * 2
+    qkv = F.linear(x, w, bias)
+    q, k, v = (t.reshape(B, T, H, D).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+    if rms:
+        q, k = F.rms_norm(q, (D,), eps=1e-6), F.rms_norm(k, (D,), eps=1e-6)
+    if gains:
+        q, k = q * qw, k * kw
+    if rope:
+        cs, sn = (f(theta).reshape(T, H, D // 2).transpose(0, 1) for f in (torch.cos, torch.sin))
+
+        def rot(t):
+            re, im = t[..., 0::2], t[..., 1::2]
+            return torch.stack((re * cs - im * sn, re * sn + im * cs), dim=-1).flatten(-2)
+
+        q, k = rot(q), rot(k)
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, T, HC)
+    outs = {}
+    for mode in (True, False):
+        engine.QK_PREP = mode
+        try:
+            bld = Builder(torch.device("cuda"))
+            bld.half = half
+            xa = Act(x.cuda().reshape(-1), B, T, 1, Cin, Cin, True)
+            tabs = (bld.const(torch.cos(theta)), bld.const(torch.sin(theta))) if rope else None
+            gw = (bld.const(qw), bld.const(kw)) if gains else None
+            prep = dict(heads=H, head_dim=D, rmsnorm=rms, eps=1e-6, rope=tabs, weight=gw)
+            y = bld.conv(xa, bld.pack_conv(w.cuda(), bias.cuda()), 3 * HC, qk_prep=prep)
+            assert y.qk_prepared == mode and bld.tape.keep and (bld.tape.ops[-1][1][0]._obj.act == (5 if mode else 0))
+            out = bld.attention(y, H, "3HC", rms, 1.0 / math.sqrt(D), eps=1e-6, rope=tabs, qk_weight=gw)
+            bld.finish()
+            bld.tape.run()
+            outs[mode] = out.buf.reshape(B, T, HC).clone()
+        finally:
+            engine.QK_PREP = True
+    tol = 3e-5 if half is None else 3e-2
+    e_ref, e_ab = max_err(outs[True], ref), max_err(outs[True], outs[False])
+    assert e_ref < tol and e_ab < tol, (e_ref, e_ab)
+
+
 def test_attention_spiked_scores():
     """Online-softmax rescale path: one key dominates from a late tile (guide rule 26)."""
     from azula_amd.engine import Act, Builder
