@@ -129,10 +129,13 @@ class Act:
 # "2" = F(2x2) wherever it is legal (used by the parity tests to push whole networks through it),
 # "4" = the faster but inexact F(4x4,3x3) on layers with >= WINOGRAD4_MIN_TILES tiles, "1" elsewhere
 WINOGRAD = os.environ.get("AZ_WINOGRAD", "1")
-# How fp32 convolutions / token GEMMs use the matrix pipe: "native" = v_mfma_f32_32x32x2_f32 (default: Winograd + direct
-# kernels), "bf16x3" = operands split exactly into three bf16 pieces, six partial products on the bf16 MFMA
-# (az_conv2d_x3_f32: fp32-level accuracy at 0.375 x the matrix-pipe time; opt-in until it has been reviewed).
-FP32_MFMA = os.environ.get("AZ_FP32_MFMA", "native")
+# How fp32 convolutions / token GEMMs that run on the DIRECT kernel (1 x 1 convolutions, token linears, stride-2 and small-map
+# 3 x 3) use the matrix pipe.  "bf16x3" (default since round 4, by the round-3 reviewer's ruling): every fp32 operand split
+# EXACTLY into three bf16 pieces, the six largest partial products accumulated in fp32 on v_mfma_f32_32x32x16_bf16
+# (az_conv2d_x3_f32) -- measured MORE accurate against fp64 than the fp32 MFMA (tests/test_gpu_kernels.py::
+# test_conv2d_x3_accuracy) at 0.375 x its matrix-pipe time: DiT-B/2 54.7 -> 70.1 images/s, JiT-B/16 43.6 -> 58.4.
+# "native": v_mfma_f32_32x32x2_f32 everywhere.  The stride-1 3 x 3 convolutions stay on the fp32 Winograd kernel in both modes.
+FP32_MFMA = os.environ.get("AZ_FP32_MFMA", "bf16x3")
 assert FP32_MFMA in ("native", "bf16x3"), FP32_MFMA
 X3_MIN_CHANNELS = 32  # bf16x3 only where both channel counts fill a K tile / an MFMA tile
 WINOGRAD4_MIN_TILES = int(os.environ.get("AZ_WINOGRAD4_MIN_TILES", "1024"))

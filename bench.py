@@ -25,6 +25,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 MFMA == fp32 VALU peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2516.8  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense = 16 x the fp32 MFMA rate; 2495 TF measured)
+# az_conv2d_x3_f32 ("bf16x3"): six v_mfma_f32_32x32x16_bf16 partial products per fp32 product, so with the bf16 pipe 100 % busy it
+# delivers PEAK_BF16 / 6 algorithmic TFLOP/s: the peak its `frac` is taken against (frac == executed bf16 MFMA FLOP/s / bf16 peak)
+X3_PRODUCTS = 6
 PEAK_HBM_GBS = 8000.0  # HBM3E spec (6.3 TB/s measured achievable)
 # F(2x2,3x3) Winograd executes 4 multiplies per output where the direct form (the ALGORITHMIC count of SURVEY 8d,
 # 2*pixels*Cout*Cin*9) has 9: with the fp32 MFMA pipe 100 % busy it delivers 2.25 x 157.3 algorithmic TFLOP/s.  That is
@@ -480,8 +484,9 @@ def main() -> None:
     ap.add_argument("--half", choices=["bf16", "f16"], default=None,
                     help="cast the backbone to half precision (mixed-precision mode; NOT the headline fp32 number)")
     ap.add_argument("--fp32-mfma", choices=["native", "bf16x3"], default=None,
-                    help="how fp32 convs / GEMMs use the matrix pipe (default: env AZ_FP32_MFMA or native fp32 MFMA); "
-                         "bf16x3 = exact 3-piece bf16 split, 6 partial products, fp32 accumulate (opt-in, NOT the headline)")
+                    help="how the DIRECT-kernel fp32 convs / GEMMs use the matrix pipe (default: env AZ_FP32_MFMA or bf16x3 = exact "
+                         "3-piece bf16 split, 6 partial products, fp32 accumulate; native = v_mfma_f32_32x32x2_f32 everywhere)")
+    ap.add_argument("--no-native-line", action="store_true", help="skip the extra native-fp32-MFMA sampling reported beside a bf16x3 run")
     args = ap.parse_args()
     if args.fp32_mfma:
         os.environ["AZ_FP32_MFMA"] = args.fp32_mfma  # read by azula_amd.engine at import
@@ -525,8 +530,9 @@ def main() -> None:
     from azula_amd import engine as _engine
 
     if _engine.FP32_MFMA != "native" and not args.half:
-        cfg["name"] += (f" [AZ_FP32_MFMA={_engine.FP32_MFMA}: fp32 operands split into 3 bf16 pieces, 6 partial products on "
-                        "the bf16 MFMA, fp32 accumulate -- opt-in mode, not the headline number]")
+        cfg["name"] += (" [fp32 arithmetic; the direct-kernel contractions (1x1 / stride-2 / small-map convs, token GEMMs) as exact "
+                        "3 x bf16 splits, 6 partial products on the bf16 MFMA, fp32 accumulate (default mode, AZ_FP32_MFMA=native "
+                        "for v_mfma_f32_32x32x2_f32 everywhere); stride-1 3x3 convs on the fp32 MFMA Winograd kernel]")
     Smp = DDPMSampler if cfg.get("sampler") == "ddpm" else DDIMSampler
     sampler = Smp(den, steps=cfg["steps"], silent=True)
     B = cfg["batch"]
@@ -603,7 +609,7 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": (f"{args.half} operands / f32 accumulate" if args.half
-                      else ("f32" if _engine.FP32_MFMA == "native" else f"f32 ({_engine.FP32_MFMA} split on the bf16 MFMA)")),
+                      else ("f32" if _engine.FP32_MFMA == "native" else "f32 (bf16x3 split, f32 accumulate)")),
             "data": "synthetic (random-init weights under seed 0, x1 ~ sampler.init under seed 1)",
             "config": {"workload": cfg["name"], "per_gpu_batch": B, "global_batch": world * B,
                        "denoise_steps": cfg["steps"], "parallelism": f"batch-sharded x{world}, all-gather of x0"},
@@ -611,6 +617,30 @@ def main() -> None:
             "host": host_info(),
         }
         out.update(roofline_report(sampler, device, args, world, ms_per_step / cfg["steps"]))
+        if _engine.FP32_MFMA != "native" and not args.half and world == 1 and not args.no_native_line:
+            # the native-fp32-MFMA line beside the bf16x3 one (reviewer's condition iii): the same workload with every contraction
+            # on v_mfma_f32_32x32x2_f32, two samplings after one warm-up, same process
+            _engine.FP32_MFMA = "native"
+            try:
+                den_n = build_denoiser(cfg, device)
+                smp_n = Smp(den_n, steps=cfg["steps"], silent=True)
+                torch.manual_seed(1)
+                x1n = init_sharded(smp_n, (B, *cfg["shape"]), device=device)
+                sample_sharded(smp_n, x1n, **kwargs)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    x0n = sample_sharded(smp_n, x1n, **kwargs)
+                torch.cuda.synchronize(device)
+                dtn = (time.perf_counter() - t0) / 2
+                out["native_fp32_mfma"] = {
+                    "value": round(B / dtn, 4), "unit": "images/s", "ms_per_denoise_step": round(dtn * 1e3 / cfg["steps"], 3),
+                    "max_abs_difference_of_x0": float((x0n - x0[:B]).abs().max()),
+                    "note": "AZ_FP32_MFMA=native: every contraction on v_mfma_f32_32x32x2_f32 (the round-3 headline mode), 2 samplings, same seed",
+                }
+                del den_n, smp_n, x1n, x0n
+            finally:
+                _engine.FP32_MFMA = "bf16x3"
         if world == 1 and not args.no_cpu_baseline and cfg["kind"] == "unet":
             out["cpu_baseline"] = cpu_baseline(den, cfg)
             out["speedup_vs_cpu"] = round(images_per_s / out["cpu_baseline"]["value"], 1)
@@ -631,7 +661,8 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
         if not f["flops"]:
             continue
         wino = fam == "az_conv2d_winograd_f32"
-        peak = PEAK_FP32_TFLOPS * (WINOGRAD_GAIN if wino else 1.0)
+        x3 = fam == "az_conv2d_x3_f32"
+        peak = PEAK_BF16_TFLOPS / X3_PRODUCTS if x3 else PEAK_FP32_TFLOPS * (WINOGRAD_GAIN if wino else 1.0)
         f = dict(f, ms_event_pairs=f["ms"], ms=b2b[fam])  # the family's launches back to back inside one event pair
         tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
         k = {
@@ -644,11 +675,15 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
                       "the rocprofv3 kernel durations of the same command (profiles/), which is what a reader should check it against.  "
                       "share_of_step = that time / the captured graph's wall time per denoise step (timed region).  "
                       "frac_from_graph_step: the conservative figure, see there.  avg_us_with_event_pairs: one pair per launch (~10 us of idle each)",
-            "algorithmic_over_nominal": round(tf / PEAK_FP32_TFLOPS, 4),
+            "algorithmic_over_nominal": round(tf / PEAK_FP32_TFLOPS, 4),  # (algorithmic FLOP/s over the fp32 MFMA peak, as SURVEY 8d is written)
             "algorithmic_flops_per_step": f["flops"],
-            "executed_mfma_tflops": round(tf / (WINOGRAD_GAIN if wino else 1.0), 2), "mfma_peak": PEAK_FP32_TFLOPS,
+            "executed_mfma_tflops": round(tf * X3_PRODUCTS if x3 else tf / (WINOGRAD_GAIN if wino else 1.0), 2),
+            "mfma_peak": PEAK_BF16_TFLOPS if x3 else PEAK_FP32_TFLOPS,
             "traffic": None,
         }
+        if x3:
+            k["peak_note"] = (f"{PEAK_BF16_TFLOPS} TF/s dense bf16 MFMA / {X3_PRODUCTS}: every fp32 product is six v_mfma_f32_32x32x16_bf16 partial "
+                              "products of exact 3 x bf16 operand splits (fp32 accumulate); frac = executed bf16 MFMA FLOP/s / the bf16 MFMA peak")
         if wino:
             k["peak_note"] = (f"{PEAK_FP32_TFLOPS} TF/s fp32 MFMA x {WINOGRAD_GAIN}: F(2x2,3x3) executes 4 multiplies per output where the "
                               "algorithmic (direct) count has 9; frac = executed MFMA FLOP/s / the fp32 MFMA peak")
@@ -674,7 +709,7 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
     dom["ms_per_denoise_step_from_graph_step"] = round(dom_ms_graph, 3)
     roof = dict(dom)
     roof["graph_ms_per_denoise_step"] = round(graph_step_ms, 3)
-    if not args.half and dom["kernel"] != "attention_kernel":
+    if not args.half and dom["kernel"] != "attention_kernel" and dom["entry"] != "az_conv2d_x3_f32":
         sus = sustained_mfma_tflops(device)
         sus_rnd = sustained_mfma_tflops(device, random_operands=True)
         roof["sustained_mfma_tflops"] = round(sus, 1)
@@ -685,7 +720,8 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
                                   "multiplies constants (no bit activity, ~690 W: the pipe holds the nominal peak), "
                                   "az_calib_mfma_random_f32 per-lane random operands (the activity of real data: the 1400 W cap sets the "
                                   "clock -- tools/power_probe.py, profiles/r04_power_probe.txt); `frac` stays relative to the nominal peak")
-    roof["kernel"] = f"{dom['kernel']} (fp32 v_mfma_f32_32x32x2_f32), all {dom['launches']} launches of one denoise step"
+    mf = "bf16 v_mfma_f32_32x32x16_bf16, 6 partial products per fp32 product" if dom["entry"] == "az_conv2d_x3_f32" else "fp32 v_mfma_f32_32x32x2_f32"
+    roof["kernel"] = f"{dom['kernel']} ({mf}), all {dom['launches']} launches of one denoise step"
     roof["note"] = ("achieved = ALGORITHMIC FLOP (2*pixels*Cout*Cin*k^2; attention 4*B*H*T^2*d) of the kernel's launches in one "
                     "denoise step / the sum of their HIP-event durations; traffic = HBM-side bytes per launch from rocprofv3 "
                     "FETCH_SIZE / WRITE_SIZE x the calibration factors measured in the same run")
