@@ -1152,7 +1152,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
       const float x[8] = {rb[i][0].x, rb[i][0].y, rb[i][0].z, rb[i][0].w, rb[i][1].x, rb[i][1].y, rb[i][1].z, rb[i][1].w};
       unsigned q[3][4];
 #pragma unroll
+#ifdef AZ_X3_NOSPLIT  // timing ablation (WRONG results): what would activations that arrive pre-split cost?
+      for (int j = 0; j < 4; ++j) q[0][j] = q[1][j] = q[2][j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x[2 * j + 1]), __builtin_bit_cast(unsigned, x[2 * j]), 0x07060302u);
+#else
       for (int j = 0; j < 4; ++j) split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);
+#endif
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
         *reinterpret_cast<uint4*>(xsm + (3 + pl) * XPLANE + (r0 + 64 * i) * XLDS + wsw) =

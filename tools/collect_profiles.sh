@@ -1,8 +1,8 @@
 #!/bin/bash
-# End-of-round evidence, on the GPU box:  bash tools/collect_profiles.sh r03   ->  gpurun_out/<tag>_*  (copy into profiles/)
+# End-of-round evidence, on the GPU box:  bash tools/collect_profiles.sh r04   ->  gpurun_out/<tag>_*  (copy into profiles/)
 #   bench lines of every configuration, rocprofv3 --kernel-trace --stats tables of C2 / C3 / C5 / C6 (same command as the
 #   bench line, fewer steps), the PMC traffic collection of C2 (tools/pmc_traffic.py, also run live by the default bench.py).
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -20,8 +20,10 @@ python bench.py --config c5 --steps 2 --warmup 1 --no-pmc > gpurun_out/${TAG}_be
 python bench.py --config c5cfg32 --steps 1 --warmup 1 --no-pmc > gpurun_out/${TAG}_bench_c5cfg32.json 2> gpurun_out/b_c5cfg32.err
 python bench.py --config c6 --steps 2 --warmup 1 --no-pmc > gpurun_out/${TAG}_bench_c6.json 2> gpurun_out/b_c6.err
 python bench.py --config c4 --denoise-steps 4 --steps 1 --warmup 0 --no-pmc > gpurun_out/${TAG}_bench_c4_4steps.json 2> gpurun_out/b_c4.err
+python bench.py --config vol --steps 3 --warmup 1 --no-pmc > gpurun_out/${TAG}_bench_vol.json 2> gpurun_out/b_vol.err
+[ "$2" = "c4full" ] && python bench.py --config c4 --steps 1 --warmup 0 --no-pmc --no-native-line > gpurun_out/${TAG}_bench_c4_full.json 2> gpurun_out/b_c4full.err
 head -6 gpurun_out/${TAG}_c2_kernel_stats.txt
-for c in c2 c3 c5 c5cfg32 c6 c4_4steps; do python - <<PY
+for c in c2 c3 c5 c5cfg32 c6 c4_4steps vol c4_full; do python - <<PY
 import json
 try:
     d = json.load(open("gpurun_out/${TAG}_bench_$c.json"))
