@@ -179,6 +179,8 @@ class AzConvArgs(C.Structure):
         ("qk_k_weight", c_f32p),
         ("qk_rope_cos", c_f32p),
         ("qk_rope_sin", c_f32p),
+        ("depth_wrap", C.c_int32),
+        ("depth_reserved", C.c_int32),
     ]
 
 

@@ -96,6 +96,27 @@ __device__ __forceinline__ int wrap_coord(int i, int n, int mode) {
 }
 #define AZ_RSRC_CLAMP 0x80000000ll  // == OOB: the largest num_records a descriptor may carry
 
+// AzConvArgs.depth (one depth tap of a 3-D convolution over all planes of all volumes): the source plane of image b is
+// b + depth_shift inside b's own volume -- outside it the tap reads zeros (`ok` false) or, with depth_wrap (circular padding
+// along the depth axis), the plane at the other end of the volume.
+__device__ __forceinline__ int az_depth_plane(const AzConvArgs& a, int b, bool& ok) {
+  ok = true;
+  if (a.depth <= 0) return b;
+  const int bd = b % a.depth;
+  int sb = bd + a.depth_shift;
+  if (a.depth_wrap) sb = sb < 0 ? sb + a.depth : (sb >= a.depth ? sb - a.depth : sb);
+  else ok = (unsigned)sb < (unsigned)a.depth;
+  return b - bd + sb;
+}
+// First plane the descriptors of a tile start at (they then run to the last plane, inside the allocation whatever the shift):
+// zero padding: the first image's source plane (clamped at 0); circular: the start of the first image's volume.
+__device__ __forceinline__ int az_depth_base(const AzConvArgs& a, int b_first) {
+  if (a.depth <= 0) return b_first;
+  if (a.depth_wrap) return b_first - b_first % a.depth;
+  const int s = b_first + a.depth_shift;
+  return s > 0 ? s : 0;
+}
+
 // log2 upsampling factor along the width: its own field when the descriptor is anisotropic (validated to [0, 4])
 static inline int az_upw(const AzConvArgs* a, int up, int up_w) { return a->aniso ? up_w : up; }  // (range checked by the callers)
 
@@ -536,12 +557,8 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
 
   // Buffer descriptors (wave-uniform: kernel arguments + blockIdx only).
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
-  const int dshift = a.depth > 0 ? a.depth_shift : 0;  // volumes: the source plane of image b is b + depth_shift (masked per image)
-  // The descriptors stay INSIDE the allocation whatever the shift: they start at plane b_base = max(b_first + dshift, 0) and end
-  // at the last plane; a lane's plane index is taken relative to b_base (b_adj <= 0 is the part of a negative shift the base
-  // could not absorb -- only lanes whose plane is masked anyway (pdok / v_dok false) would land below 0).
-  const int b_base = max(b_first + dshift, 0);
-  const int b_adj = b_first + dshift - b_base;
+  // (depth taps: per-lane source planes are taken relative to b_base; lanes whose plane is masked may land anywhere)
+  const int b_base = az_depth_base(a, b_first);
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
   auto clamp_bytes = [](int64_t e) { return (unsigned)(e <= 0 ? 0 : (e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4)); };  // (e <= 0: a depth shift past the last plane)
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
@@ -556,6 +573,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
   unsigned voffW[NP];
   int prel[NP], ihb[NP], iwb[NP];
   bool pdok[NP];  // AzConvArgs.depth: the source plane (image + depth_shift) lies inside the image's volume
+  int psrc[NP];   // source plane of the pixel's image, relative to b_base (== prel without depth taps)
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int co = m0 + r0 + RPP * i;
@@ -568,7 +586,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
     const int oh = rem / a.wout;
     const int ow = rem - oh * a.wout;
     prel[i] = pv ? b - b_first : -1;
-    pdok[i] = a.depth <= 0 || (unsigned)(b % a.depth + a.depth_shift) < (unsigned)a.depth;
+    psrc[i] = az_depth_plane(a, b, pdok[i]) - b_base;
     ihb[i] = oh * a.stride - a.pad;
     iwb[i] = ow * (a.aniso ? a.stride_w : a.stride) - a.pad;
   }
@@ -595,7 +613,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
       const int ih = wrap_coord(ihb[i] + ky, a.hin, a.pad_mode);
       const int iw = wrap_coord(iwb[i] + kx, a.win, a.pad_mode);
       const bool ok = prel[i] >= 0 && pdok[i] && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
-      const int pix = ((prel[i] + b_adj) * hs + (ih >> up)) * ws + (iw >> upw);
+      const int pix = (psrc[i] * hs + (ih >> up)) * ws + (iw >> upw);
       voffA[i] = ok ? (unsigned)((pix * cs + cc * 4) * 4) : OOB;
     }
   };
@@ -696,7 +714,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
         unsigned pbase[NP], vmask[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-          pbase[i] = (unsigned)(((((prel[i] + b_adj) * a.h0 + ihb[i]) * a.w0 + iwb[i]) * a.c0s + cc * 4) * 4);
+          pbase[i] = (unsigned)((((psrc[i] * a.h0 + ihb[i]) * a.w0 + iwb[i]) * a.c0s + cc * 4) * 4);
           unsigned m = 0;
           for (int t = 0; t < ks * ks; ++t) {
             const int ih = ihb[i] + t / ks, iw = iwb[i] + t % ks;
@@ -826,14 +844,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
   const int b_first = n0 / hw_out;
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e <= 0 ? 0 : (e > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e)); };
+  const int b_base = az_depth_base(a, b_first);  // (depth taps: per-lane source planes are taken relative to b_base)
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src0 + b_first * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems * 4), 0x00020000);
+      (void*)(a.src0 + b_base * s0_elems), 0, clamp_bytes((a.batch - b_base) * s0_elems * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src1 ? a.src1 + b_first * s1_elems : a.src0), 0,
-      a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems * 4) : 0u, 0x00020000);
+      (void*)(a.src1 ? a.src1 + b_base * s1_elems : a.src0), 0,
+      a.src1 ? clamp_bytes((a.batch - b_base) * s1_elems * 4) : 0u, 0x00020000);
 
   // loaders.  Weights: thread -> (16-byte chunk wcc = 8 k-values, rows wr0 + 32 i).  Activations (fp32 in memory):
   // thread -> (16-byte chunk acc4 = 4 k-values, rows ar0 + 16 i).
@@ -854,7 +873,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
     const int b = nn / hw_out;
     const int rem = nn - b * hw_out;
     const int oh = rem / a.wout;
-    prel[i] = pv ? b - b_first : -1;
+    bool dok;
+    const int ps = az_depth_plane(a, b, dok) - b_base;
+    prel[i] = pv && dok ? ps : -1;  // (source plane relative to the descriptor's first one; -1: reads zeros)
     ihb[i] = oh * a.stride - a.pad;
     iwb[i] = (rem - oh * a.wout) * (a.aniso ? a.stride_w : a.stride) - a.pad;
   }
@@ -1045,13 +1066,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
   const int64_t wplane = (int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s;  // elements per weight piece
-  auto clamp_bytes = [](int64_t e) { return (unsigned)(e > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e); };
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e <= 0 ? 0 : (e > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e)); };
+  const int b_base = az_depth_base(a, b_first);  // (depth taps: per-lane source planes are taken relative to b_base)
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, clamp_bytes(3 * wplane * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src0 + b_first * s0_elems), 0, clamp_bytes((a.batch - b_first) * s0_elems * 4), 0x00020000);
+      (void*)(a.src0 + b_base * s0_elems), 0, clamp_bytes((a.batch - b_base) * s0_elems * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src1 ? a.src1 + b_first * s1_elems : a.src0), 0,
-      a.src1 ? clamp_bytes((a.batch - b_first) * s1_elems * 4) : 0u, 0x00020000);
+      (void*)(a.src1 ? a.src1 + b_base * s1_elems : a.src0), 0,
+      a.src1 ? clamp_bytes((a.batch - b_base) * s1_elems * 4) : 0u, 0x00020000);
 
   // loaders: thread -> (8 consecutive k-values kc8, rows r0 + 64 i) of both operands
   const int kc8 = tid & 3, r0 = tid >> 2;
@@ -1070,7 +1092,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
     const int b = nn / hw_out;
     const int rem = nn - b * hw_out;
     const int oh = rem / a.wout;
-    prel[i] = pv ? b - b_first : -1;
+    bool dok;
+    const int ps = az_depth_plane(a, b, dok) - b_base;
+    prel[i] = pv && dok ? ps : -1;  // (source plane relative to the descriptor's first one; -1: reads zeros)
     ihb[i] = oh * a.stride - a.pad;
     iwb[i] = (rem - oh * a.wout) * (a.aniso ? a.stride_w : a.stride) - a.pad;
   }
@@ -1645,12 +1669,8 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
 
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
-  const int dshift = a.depth > 0 ? a.depth_shift : 0;  // volumes: the source plane of image b is b + depth_shift (masked per image)
-  // The descriptors stay INSIDE the allocation whatever the shift: they start at plane b_base = max(b_first + dshift, 0) and end
-  // at the last plane; a lane's plane index is taken relative to b_base (b_adj <= 0 is the part of a negative shift the base
-  // could not absorb -- only lanes whose plane is masked anyway (pdok / v_dok false) would land below 0).
-  const int b_base = max(b_first + dshift, 0);
-  const int b_adj = b_first + dshift - b_base;
+  // (depth taps: per-lane source planes are taken relative to b_base; lanes whose plane is masked may land anywhere)
+  const int b_base = az_depth_base(a, b_first);
   auto clamp_bytes = [](int64_t e) { return (unsigned)(e <= 0 ? 0 : (e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4)); };  // (e <= 0: a depth shift past the last plane)
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)p.nk * p.cblocks * WU_STAGE), 0x00020000);
@@ -1666,7 +1686,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   const bool vrole = tid < 256;
   const int vj = (tid & 255) >> 2;  // tile within the block
   const int vq = tid & 3;           // which channel pair of the 8
-  int v_b = -1, v_ih0 = 0, v_iw0 = 0;
+  int v_b = -1, v_bs = 0, v_ih0 = 0, v_iw0 = 0;  // v_bs: the tile's source plane relative to b_base
   bool v_dok = true;  // AzConvArgs.depth: the source plane (image + depth_shift) lies inside the image's volume
   if (vrole) {
     const int t = t0 + vj;
@@ -1677,7 +1697,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
       v_b = b - b_first;
       v_ih0 = 2 * th - 1;
       v_iw0 = 2 * (r - th * p.tiles_w) - 1;
-      v_dok = a.depth <= 0 || (unsigned)(b % a.depth + a.depth_shift) < (unsigned)a.depth;
+      v_bs = az_depth_plane(a, b, v_dok) - b_base;
     }
   }
   unsigned voffV[16];
@@ -1696,7 +1716,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
     for (int r = 0; r < 4; ++r) {
       const int ih = wrap_coord(v_ih0 + r, a.hin, a.pad_mode);
       rok[r] = v_b >= 0 && v_dok && (unsigned)ih < (unsigned)a.hin;
-      rpart[r] = ((v_b + b_adj) * hs + (ih >> up)) * ws * cs * 4;
+      rpart[r] = (v_bs * hs + (ih >> up)) * ws * cs * 4;
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -2492,10 +2512,14 @@ int az_conv2d_x3_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_di
 
 static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   AZ_REQUIRE(!a || !a->in_affine, AZ_E_UNSUPPORTED);  // (the Winograd kernel's gather only)
-  if (a && a->depth != 0)  // one depth tap of a 3-D convolution: fp32 direct kernel (both sources hold `batch` planes)
-    AZ_REQUIRE(half == 0 && a->depth > 0 && a->batch % a->depth == 0 && a->depth_shift > -a->depth &&
-                   a->depth_shift < a->depth && a->cout_s != 4 && (!a->gate || a->gate_bstride == 0),
+  if (a && a->depth != 0)  // one depth tap of a 3-D convolution (both sources hold `batch` planes)
+    AZ_REQUIRE(a->depth > 0 && a->batch % a->depth == 0 && a->depth_shift > -a->depth && a->depth_shift < a->depth &&
+                   a->cout_s != 4 && (!a->gate || a->gate_bstride == 0) && (a->depth_wrap == 0 || a->depth_wrap == 1),
                AZ_E_UNSUPPORTED);
+  if (a && a->depth > 0) {  // 32-bit offsets from the descriptor's first plane: a tile's images + the planes a tap may reach back
+    const int64_t span = (int64_t)BN / ((int64_t)a->hout * a->wout) + 2 + a->depth;
+    AZ_REQUIRE(span * a->h0 * a->w0 * a->c0s * 4 < (1ll << 31) && span * a->h1 * a->w1 * a->c1s * 4 < (1ll << 31), AZ_E_SHAPE);
+  }
   AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout > 0 && a->wout > 0, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
@@ -2643,10 +2667,15 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
   AZ_REQUIRE(a->act >= 0 && a->act <= 4, AZ_E_UNSUPPORTED);
   if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
-  if (a->depth != 0)  // one depth tap of a 3-D convolution
+  if (a->depth != 0) {  // one depth tap of a 3-D convolution
     AZ_REQUIRE(a->depth > 0 && a->batch % a->depth == 0 && a->depth_shift > -a->depth && a->depth_shift < a->depth &&
-                   (!a->gate || a->gate_bstride == 0),
+                   (!a->gate || a->gate_bstride == 0) && (a->depth_wrap == 0 || a->depth_wrap == 1),
                AZ_E_UNSUPPORTED);
+    // 32-bit offsets from the descriptor's first plane: a tile block's images + the planes a tap may reach back
+    const int64_t tiles_img = (int64_t)((a->hout + 1) / 2) * ((a->wout + 1) / 2);
+    const int64_t span = (WT + tiles_img - 1) / tiles_img + 2 + a->depth;
+    AZ_REQUIRE(span * a->h0 * a->w0 * a->c0s * 4 < (1ll << 31) && span * a->h1 * a->w1 * a->c1s * 4 < (1ll << 31), AZ_E_SHAPE);
+  }
   if (a->in_affine)  // the normalisation apply pass inside the gather
     AZ_REQUIRE(!a->src1 && a->c0s % 8 == 0 && a->up0 == 0 && (a->in_act == 0 || a->in_act == 1) && AZ_ALIGNED16(a->in_affine) &&
                    (int64_t)a->batch * a->c0s * 8 < (1ll << 31),

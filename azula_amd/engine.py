@@ -347,9 +347,10 @@ class Builder:
             a.src1, a.c1s, a.up1, a.h1, a.w1 = src1.ptr, src1.cs, up1, src1.H, src1.W
         assert (a.c0s, a.c1s) == (packed.c0s, packed.c1s), "weights were packed for different source strides"
         a.batch, a.hin, a.win = B, hin, win
-        if depth is not None:  # (planes per volume, depth tap offset): one depth tap of a 3-D convolution over all planes at once
-            assert (src1 is None or src1.B == B) and self.half is None and B % depth[0] == 0
-            a.depth, a.depth_shift = depth
+        if depth is not None:  # (planes per volume, depth tap offset[, circular]): one depth tap of a 3-D convolution over all planes at once
+            assert (src1 is None or src1.B == B) and B % depth[0] == 0
+            a.depth, a.depth_shift = depth[0], depth[1]
+            a.depth_wrap = int(bool(depth[2])) if len(depth) > 2 else 0
         a.bias = bias.data_ptr() if bias is not None else None
         a.cout_s = pad4(cout)
         a.ksize, a.stride, a.pad = ks, stride, pad
@@ -400,7 +401,7 @@ class Builder:
         # bf16x3 mode replaces the DIRECT fp32 kernel (1x1 convs / token GEMMs, stride 2, small maps: 147-181 vs 113-128
         # TF/s); the 3x3 stride-1 layers stay on the fp32 Winograd kernel, which executes 2.25x fewer multiplies
         # (221 vs 181 TF/s algorithmic at 4 x 256^2, 256 -> 256).
-        use_x3 = self.half is None and depth is None and (
+        use_x3 = self.half is None and (
             winograd == "x3"
             or (winograd is None and FP32_MFMA == "bf16x3" and not head and not use_wino and not use_f4
                 and cin_s >= X3_MIN_CHANNELS and a.cout_s >= X3_MIN_CHANNELS)

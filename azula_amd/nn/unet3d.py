@@ -6,10 +6,10 @@ convolution is the sum over its depth taps of 2-D convolutions of depth-shifted 
 
     out[b, d] = sum_j conv2d(x[b, s d + j - p], w[:, :, j]),
 
-each tap one launch of the 2-D kernel (Winograd / direct, in-plane padding, stride, nearest upsampling, concatenation and
-narrow exactly as for images) over ALL planes of all samples (``AzConvArgs.depth``: a plane whose tap leaves its volume reads
-zeros; odd depths, circular padding and half-precision modules: one launch per sample / plane) that ACCUMULATES in place
-through the epilogue's residual operand.  The centre tap runs
+each tap one launch of the 2-D kernel (Winograd / direct / bf16x3 / half-precision, in-plane padding, stride, nearest
+upsampling, concatenation and narrow exactly as for images) over ALL planes of all samples (``AzConvArgs.depth``: a plane whose
+tap leaves its volume reads zeros, or -- ``depth_wrap``, circular padding -- the plane at the other end of the volume; round 4:
+also for odd depths and half-precision modules) that ACCUMULATES in place through the epilogue's residual operand.  The centre tap runs
 first (it exists for every output plane) and carries the bias; a gate distributes over the taps
 (``x + c (sum_j v_j + bias) = x + c (v_0 + bias) + c v_1 + ...``), only the SiLU after a block's first convolution needs a
 pass of its own.  Norms see a volume as one (D H) x W image.  Depth padding is a skipped (zeros) or wrapped (circular)
@@ -79,31 +79,44 @@ def conv3d(bld: Builder, x: Vol, conv, *, stride=1, periodic: bool = False, x1: 
     # tap leaves its volume as zeros; the taps accumulate in place through `res`).  A stride-2 depth axis computes every plane
     # and keeps the even ones (twice the work of a layer that is a few per cent of the network, for 3 launches instead of
     # 3 Do B); a source read through depth upsampling (the decoder's merge convolutions) gets its planes duplicated first.
-    fast = (not periodic and bld.half is None and cout > 4 and (gate is None or gate_bstride == 0 or x.B == 1)
-            and (sd_ == 1 or (sd_ == 2 and Din % 2 == 0 and gate is None and res is None and not silu))
-            and (x1 is None or (ud_ == 0 and x1.D == Din) or (ud_ == 1 and 2 * x1.D == Din)))
+    fast = (cout > 4 and (gate is None or gate_bstride == 0 or x.B == 1)
+            and (sd_ == 1 or (sd_ == 2 and gate is None and res is None and not silu))
+            and (x1 is None or (ud_ == 0 and x1.D == Din) or (ud_ == 1 and (Din + 1) // 2 <= x1.D)))
     if fast:
         g = dict(gate=gate, gate_off=gate_off, gate_bstride=0) if gate is not None else {}
         planes = lambda v: Act(v.buf, v.B * v.D, v.H, v.W, v.C, v.cs, True)  # noqa: E731
         x1u, kw_ = None, {}
         if x1 is not None:
             src1 = x1
-            if ud_ == 1:  # nearest x2 along the depth axis: plane d of the wide volume = plane d >> 1
+            if ud_ == 1:  # nearest x2 along the depth axis (narrowed to Din planes): plane d of the wide volume = plane d >> 1
                 x1u = new_vol(bld, x1.B, Din, x1.H, x1.W, x1.C)
                 n = x1.H * x1.W * x1.cs
-                for half_ in (0, 1):
-                    bld.tape.add("az_token_copy_f32", x1u.buf.data_ptr(), 2, half_, x1.buf.data_ptr(), 1, 0, 1, x1.B * x1.D, n)
+                if 2 * x1.D == Din:  # one launch per parity over all samples
+                    for half_ in (0, 1):
+                        bld.tape.add("az_token_copy_f32", x1u.buf.data_ptr(), 2, half_, x1.buf.data_ptr(), 1, 0, 1, x1.B * x1.D, n)
+                else:  # odd depth (the reference narrows the upsampled volume, unet.py:253-255): per sample
+                    for b_ in range(x1.B):
+                        for half_ in (0, 1):
+                            cnt = (Din - half_ + 1) // 2
+                            if cnt > 0:
+                                bld.tape.add("az_token_copy_f32", x1u.buf.data_ptr() + 4 * b_ * Din * n, 2, half_,
+                                             x1.buf.data_ptr() + 4 * b_ * x1.D * n, 1, 0, 1, cnt, n)
                 src1 = x1u
             kw_ = dict(src1=planes(src1), up1=(uh_, uw_), hin=Hin, win=Win)
         full = out if sd_ == 1 else new_vol(bld, x.B, Din, Ho, Wo, cout)
         allo = planes(full)
         allr = planes(res) if res is not None else None
         for j in taps:
-            bld.conv(planes(x), packs[j], cout, stride=(sh_, sw_), out=allo, res=allr if j == p else allo, depth=(Din, j - p),
-                     **g, **kw_)
+            bld.conv(planes(x), packs[j], cout, stride=(sh_, sw_), out=allo, res=allr if j == p else allo, depth=(Din, j - p, periodic),
+                     periodic=periodic, **g, **kw_)
         if sd_ == 2:  # out[d] = full[2 d]
             n = Ho * Wo * out.cs
-            bld.tape.add("az_token_copy_f32", out.buf.data_ptr(), 1, 0, full.buf.data_ptr(), 2, 0, 1, x.B * Do, n)
+            if Din % 2 == 0:
+                bld.tape.add("az_token_copy_f32", out.buf.data_ptr(), 1, 0, full.buf.data_ptr(), 2, 0, 1, x.B * Do, n)
+            else:  # odd depth: the samples' planes do not pair up across the batch
+                for b_ in range(x.B):
+                    bld.tape.add("az_token_copy_f32", out.buf.data_ptr() + 4 * b_ * Do * n, 1, 0,
+                                 full.buf.data_ptr() + 4 * b_ * Din * n, 2, 0, 1, Do, n)
             free_vol(bld, full)
         if x1u is not None:
             free_vol(bld, x1u)

@@ -317,6 +317,9 @@ typedef struct AzConvArgs {
   const float* qk_k_weight;
   const float* qk_rope_cos;
   const float* qk_rope_sin;
+  int32_t depth_wrap;      /* with depth: 1 = circular padding along the depth axis (azula/nn/layers.py:25-68 with
+                            * padding_mode "circular": a tap that leaves the volume reads the plane at its other end) */
+  int32_t depth_reserved;
 } AzConvArgs;
 /* Narrow outputs (cout_s == 4, 3x3 stride 1 pad 1, one un-upsampled source with c0s % 16 == 0: the image head of
  * azula/nn/unet.py) run a VALU kernel instead of the 128-cout MFMA tile; splitk is ignored there.              */
