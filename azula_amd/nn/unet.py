@@ -309,7 +309,7 @@ class UNet(nn.Module):
 
     Arguments are those of ``azula.nn.unet.UNet``: ``spatial`` 1 (one-row images), 2 or 3 (volumes: every 3-D convolution
     as depth taps of the 2-D kernels, ``unet3d.py``), zero or circular padding, odd kernels, any integer stride per axis (powers of
-    two: the upsampling is folded into the merge convolution; others: ``az_upsample_nearest_f32``; volumes: powers of two only).
+    two: the upsampling is folded into the merge convolution; others: ``az_upsample_nearest_f32``; volumes: the same in-plane + a gather of whole planes along the depth axis).
     """
 
     def __init__(
@@ -340,8 +340,6 @@ class UNet(nn.Module):
             raise NotImplementedError("odd kernel sizes only (anisotropic allowed)")
         if any(int(s_) != s_ or s_ < 1 for s_ in stride):
             raise ValueError("integer strides >= 1 only")
-        if spatial == 3 and any(s_ not in (1, 2, 4, 8, 16) for s_ in stride):
-            raise NotImplementedError("volumes: strides 1, 2, 4, 8, 16 per axis only")
         self.in_channels, self.out_channels, self.cond_channels = in_channels, out_channels, cond_channels
         self.hid_channels, self.hid_blocks = tuple(hid_channels), tuple(hid_blocks)
         self.stride = stride[0] if len(set(stride)) == 1 else tuple(stride)  # int (isotropic) or one per axis

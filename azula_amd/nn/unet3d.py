@@ -80,7 +80,7 @@ def conv3d(bld: Builder, x: Vol, conv, *, stride=1, periodic: bool = False, x1: 
     # and keeps the even ones (twice the work of a layer that is a few per cent of the network, for 3 launches instead of
     # 3 Do B); a source read through depth upsampling (the decoder's merge convolutions) gets its planes duplicated first.
     fast = (cout > 4 and (gate is None or gate_bstride == 0 or x.B == 1)
-            and (sd_ == 1 or (sd_ == 2 and gate is None and res is None and not silu))
+            and (sd_ == 1 or (gate is None and res is None and not silu))
             and (x1 is None or (ud_ == 0 and x1.D == Din) or (ud_ == 1 and (Din + 1) // 2 <= x1.D)))
     if fast:
         g = dict(gate=gate, gate_off=gate_off, gate_bstride=0) if gate is not None else {}
@@ -103,20 +103,25 @@ def conv3d(bld: Builder, x: Vol, conv, *, stride=1, periodic: bool = False, x1: 
                                              x1.buf.data_ptr() + 4 * b_ * x1.D * n, 1, 0, 1, cnt, n)
                 src1 = x1u
             kw_ = dict(src1=planes(src1), up1=(uh_, uw_), hin=Hin, win=Win)
-        full = out if sd_ == 1 else new_vol(bld, x.B, Din, Ho, Wo, cout)
+        full = out if sd_ == 1 else new_vol(bld, x.B, Din, Ho, Wo, cout)  # (a strided depth axis: every plane, then every sd-th kept)
         allo = planes(full)
         allr = planes(res) if res is not None else None
         for j in taps:
             bld.conv(planes(x), packs[j], cout, stride=(sh_, sw_), out=allo, res=allr if j == p else allo, depth=(Din, j - p, periodic),
                      periodic=periodic, **g, **kw_)
-        if sd_ == 2:  # out[d] = full[2 d]
+        if sd_ > 1:  # out[d] = full[sd d]
             n = Ho * Wo * out.cs
-            if Din % 2 == 0:
-                bld.tape.add("az_token_copy_f32", out.buf.data_ptr(), 1, 0, full.buf.data_ptr(), 2, 0, 1, x.B * Do, n)
-            else:  # odd depth: the samples' planes do not pair up across the batch
+            if Din % sd_ == 0:
+                bld.tape.add("az_token_copy_f32", out.buf.data_ptr(), 1, 0, full.buf.data_ptr(), sd_, 0, 1, x.B * Do, n)
+            else:  # the samples' planes do not group up across the batch: per sample, the last (partial) group apart
                 for b_ in range(x.B):
-                    bld.tape.add("az_token_copy_f32", out.buf.data_ptr() + 4 * b_ * Do * n, 1, 0,
-                                 full.buf.data_ptr() + 4 * b_ * Din * n, 2, 0, 1, Do, n)
+                    whole = Din // sd_
+                    if whole:
+                        bld.tape.add("az_token_copy_f32", out.buf.data_ptr() + 4 * b_ * Do * n, 1, 0,
+                                     full.buf.data_ptr() + 4 * b_ * Din * n, sd_, 0, 1, whole, n)
+                    if Do > whole:  # plane sd * whole exists (Din % sd != 0) and is the last output plane
+                        bld.tape.add("az_token_copy_f32", out.buf.data_ptr() + 4 * (b_ * Do + whole) * n, 1, 0,
+                                     full.buf.data_ptr() + 4 * (b_ * Din + sd_ * whole) * n, 1, 0, 1, 1, n)
             free_vol(bld, full)
         if x1u is not None:
             free_vol(bld, x1u)
@@ -156,6 +161,27 @@ def conv3d(bld: Builder, x: Vol, conv, *, stride=1, periodic: bool = False, x1: 
     return out
 
 
+def upsample3d_nearest(bld: Builder, x: Vol, factors, like: Vol) -> Vol:
+    r"""``narrow(Upsample(scale_factor=factors, mode="nearest")(x), like's size)`` for factors that are not powers of two:
+    in-plane by ``az_upsample_nearest_f32`` on every plane, along the depth axis by a gather of whole planes with ATen's
+    source index ``min(floor(d * float32(1 / s)), D - 1)`` (``az_gather_rows_f32``, index table built on the host)."""
+    sd_, sh_, sw_ = factors
+    planes = Act(x.buf, x.B * x.D, x.H, x.W, x.C, x.cs, True)
+    wide = bld.upsample_nearest(planes, sh_, sw_, like.H, like.W) if (sh_, sw_) != (1, 1) or (x.H, x.W) != (like.H, like.W) else planes
+    if sd_ == 1 and x.D == like.D:
+        return Vol(wide.buf, x.B, x.D, like.H, like.W, x.C, x.cs)
+    inv = torch.tensor(1.0 / sd_, dtype=torch.float32)
+    src = torch.clamp(torch.floor(torch.arange(like.D, dtype=torch.float32) * inv).to(torch.int64), max=x.D - 1)
+    idx = (torch.arange(x.B)[:, None] * x.D + src[None, :]).reshape(-1)
+    out = new_vol(bld, x.B, like.D, like.H, like.W, x.C)
+    n = like.H * like.W * x.cs
+    idx_dev = idx.to(bld.device)
+    bld.tape.add("az_gather_rows_f32", out.buf.data_ptr(), wide.buf.data_ptr(), idx_dev.data_ptr(), x.B * like.D, n, x.B * x.D, keep=[idx_dev])
+    if wide is not planes:
+        bld.free(wide)
+    return out
+
+
 def block3d(blk, bld: Builder, x: Vol, D_mod: int, mod_rows: int, mod_jobs: list, keep_input: bool = False) -> Vol:
     r"""UNetBlock on a volume (reference ``unet.py:85-95``)."""
     Cc, cs = blk.channels, pad4(blk.channels)
@@ -190,7 +216,9 @@ class UNet3DPlan:
         self.versions = net._param_versions()
         L = len(net.hid_blocks)
         stride, per = net.stride, net.periodic
-        up = stride.bit_length() - 1 if isinstance(stride, int) else tuple(v.bit_length() - 1 for v in stride)
+        sv = (stride,) * 3 if isinstance(stride, int) else tuple(stride)
+        pow2 = all(v in (1, 2, 4, 8, 16) for v in sv)
+        up = tuple(v.bit_length() - 1 for v in sv) if pow2 else 0
         mod_jobs: list[tuple] = []
         cur = self.x_in
         skips: list[Vol] = []
@@ -208,6 +236,10 @@ class UNet3DPlan:
             idx = 0
             if i + 1 < L:
                 y = skips[i]
+                if not pow2:  # Upsample(scale_factor=stride, "nearest") + narrow as tensors of their own (reference unet.py:186,250-255)
+                    wide = upsample3d_nearest(bld, cur, sv, y)
+                    free_vol(bld, cur)
+                    cur = wide
                 merged = conv3d(bld, y, mods[0], periodic=per, x1=cur, up1=up, like=y)
                 free_vol(bld, cur)
                 free_vol(bld, y)

@@ -246,6 +246,29 @@ def test_unet_on_volumes(golden, name):
     assert y.shape == g[name + "_y"].shape and max_err(y, g[name + "_y"]) < 2e-5 * sc
 
 
+@pytest.mark.parametrize("name", ["s3", "s3_ragged", "s312", "s135_periodic"])
+def test_unet_on_volumes_with_strides_that_are_not_powers_of_two(golden, name):
+    """``UNet(spatial=3, stride=3 | (3, 1, 2) | (1, 3, 5))`` (azula/nn/unet.py:159-186,250-255): the strided convolutions keep every
+    s-th plane of a depth-tap launch, the decoder's ``Upsample(nearest) + narrow`` is an in-plane pass + a gather of whole planes
+    with ATen's source index (G21: reference outputs; sizes that do not divide, zero and circular padding)."""
+    from azula_amd.nn import UNet
+
+    g = golden("g21_unet3d_odd_strides")
+    cfg = dict(g.meta[name + "_cfg"])
+    periodic = cfg.pop("periodic")
+    if isinstance(cfg["stride"], list):
+        cfg["stride"] = tuple(cfg["stride"])
+    net = UNet(**cfg, spatial=3, periodic=periodic)
+    sh = {n: tuple(v) for n, v in g.meta[name + "_shapes"].items()}
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == sh
+    net.load_state_dict(synth.synth_state_dict(sh, 62))
+    x = g[name + "_x"]
+    y = net.cuda().eval()(x.cuda(), g["mod"][: x.shape[0]].cuda())
+    sc = max(1.0, g[name + "_y"].abs().max().item())
+    print(name, "max|d|", max_err(y, g[name + "_y"]), "scale", sc)
+    assert y.shape == g[name + "_y"].shape and max_err(y, g[name + "_y"]) < 2e-5 * sc
+
+
 @pytest.mark.parametrize("periodic", [False, True])
 def test_unet_block_on_a_volume(periodic):
     """Standalone ``UNetBlock(spatial=3).forward`` (one-block plan on the volume form) against the oracle's block

@@ -283,6 +283,16 @@ def test_g16_unet3d(golden):
         torch.testing.assert_close(y, g[name + "_y"], **TIGHT)
 
 
+def test_g21_unet3d_odd_strides(golden):
+    g = golden("g21_unet3d_odd_strides")
+    for name in ("s3", "s3_ragged", "s312", "s135_periodic"):
+        cfg = g.meta[name + "_cfg"]
+        sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta[name + "_shapes"].items()}, 62)
+        x = g[name + "_x"]
+        y = nets.unet_forward(sd, cfg, x, g["mod"][: x.shape[0]])
+        torch.testing.assert_close(y, g[name + "_y"], **TIGHT)
+
+
 def test_g17_anisotropic_strides(golden):
     g = golden("g17_anisotropic_strides")
     for name in ("i21", "i14", "i42_periodic", "v122", "v214"):
