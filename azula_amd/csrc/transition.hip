@@ -346,6 +346,14 @@ __global__ void step_begin_kernel(AzStepCoef* cur, const AzStepCoef* table, int3
   }
 }
 
+// fp64 row of the step that az_step_begin has just started (the counter already points at the next one)
+__global__ void step_row_f64_kernel(double* cur, const double* table, const int32_t* counter, int32_t n_rows, int32_t words) {
+  int32_t s = *counter - 1;
+  if (s < 0) s = 0;
+  if (s >= n_rows) s = n_rows - 1;
+  if ((int)threadIdx.x < words) cur[threadIdx.x] = table[(int64_t)s * words + threadIdx.x];
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                     const float* __restrict__ s, int64_t n4, int64_t n) {
   const float k = *s;
@@ -587,6 +595,14 @@ int az_step_begin(AzStepCoef* cur, const AzStepCoef* table, int32_t* step_counte
   AZ_REQUIRE(cur && table && step_counter, AZ_E_NULL);
   AZ_REQUIRE(n_steps > 0, AZ_E_SHAPE);
   hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, az_s(stream), cur, table, step_counter, n_steps);
+  return az_launch_status();
+}
+
+int az_step_row_f64(double* cur, const double* table, const int32_t* step_counter, int32_t n_rows, int32_t words,
+                    az_stream_t stream) {
+  AZ_REQUIRE(cur && table && step_counter, AZ_E_NULL);
+  AZ_REQUIRE(n_rows > 0 && words > 0 && words <= 64, AZ_E_SHAPE);
+  hipLaunchKernelGGL(step_row_f64_kernel, dim3(1), dim3(64), 0, az_s(stream), cur, table, step_counter, n_rows, words);
   return az_launch_status();
 }
 

@@ -20,6 +20,7 @@ from __future__ import annotations
 import abc
 import ctypes as C
 import math
+import os
 from collections.abc import Iterable, Sequence
 from dataclasses import dataclass, field
 from typing import Callable
@@ -31,6 +32,8 @@ from . import _lib
 from ._lib import COEF_FIELDS, COEF_WORDS
 from .denoise import Denoiser, axpby_wide, is_wide, require_f32_cuda
 from .engine import StepGraph, Tape, transition_args
+
+WIDE_FUSED = os.environ.get("AZ_WIDE_FUSED", "1") != "0"  # captured loop for Sampler(dtype=float64) ("0": the generic fp64 loop)
 
 __all__ = [
     "Sampler", "DDPMSampler", "DDIMSampler", "EulerSampler", "HeunSampler", "ItoSampler", "zABSampler", "vABSampler",
@@ -230,7 +233,39 @@ class Sampler(abc.ABC):
     def _fusable(self, x: Tensor) -> bool:
         if type(self).step not in _FUSED_STEPS:
             return False  # a user subclass overrides step (guidance samplers ...): generic loop
-        return x.dtype == torch.float32 and self.dtype in (None, torch.float32) and x.ndim >= 2
+        if x.ndim < 2:
+            return False
+        if x.dtype == torch.float32 and self.dtype in (None, torch.float32):
+            return True
+        # fp64 time grid (fp32 or fp64 latents): the captured loop with fp64 elementwise kernels (_FusedLoopWide) for the
+        # samplers whose step is one evaluation + one transition
+        return self._wide_fusable(x)
+
+    def _wide_fusable(self, x: Tensor) -> bool:
+        return (self.dtype == torch.float64 and x.dtype in (torch.float32, torch.float64) and type(self).__name__ in ("DDPMSampler", "DDIMSampler")
+                and type(self)._fused_step_tapes is Sampler._fused_step_tapes and WIDE_FUSED)
+
+    def _host_table_wide(self, fused: "FusedDenoiser") -> Tensor:
+        r"""(steps, 24) fp64: per step the denoiser's row [c_in, c_skip, c_out, c_time, ...] and the transition's row
+        [.., c_skip = 0, c_out = 1, alpha_t, alpha_s, k_x, k_eps, .., clip_lo = -inf, clip_hi = inf, ..] in the field order of
+        ``az_transition_f64``'s coefficient row -- the 0-d host scalars of the fp64 time grid, in the reference's op order."""
+        names = ["c_in", "c_skip", "c_out", "c_time", "alpha_t", "alpha_s", "k_x", "k_eps", "c_in_next", "clip_lo", "clip_hi", "guidance"]
+        ts = torch.linspace(self.start, self.stop, self.steps + 1, dtype=self.dtype)
+        out = []
+        for t, s in ts.unfold(0, 2, 1).unbind():
+            (spec,) = self._fused_rows(t, s, fused)
+            row = torch.zeros(24, dtype=torch.float64)
+            co = fused.coefficients(spec["alpha"], spec["sigma"])
+            for n in ("c_in", "c_skip", "c_out", "c_time"):
+                row[names.index(n)] = co[n].to(torch.float64)
+            row[names.index("clip_lo")], row[names.index("clip_hi")] = -math.inf, math.inf
+            b = 12
+            row[b + names.index("c_out")] = 1.0
+            row[b + names.index("alpha_t")], row[b + names.index("alpha_s")] = spec["a_t"].to(torch.float64), spec["a_s"].to(torch.float64)
+            row[b + names.index("k_x")], row[b + names.index("k_eps")] = spec["k_x"].to(torch.float64), spec["k_eps"].to(torch.float64)
+            row[b + names.index("clip_lo")], row[b + names.index("clip_hi")] = -math.inf, math.inf
+            out.append(row)
+        return torch.stack(out)
 
     # -- what a step looks like inside the captured graph ----------------------------------------------------------
     def _fused_rows(self, t: Tensor, s: Tensor, fused: "FusedDenoiser") -> list[dict]:
@@ -310,18 +345,27 @@ class Sampler(abc.ABC):
         g = kwargs.get("guidance")
         if torch.is_tensor(g) and g.numel() != 1:
             return None  # per-sample guidance: generic loop
+        wide = not (x.dtype == torch.float32 and self.dtype in (None, torch.float32))
         key = (
             tuple(x.shape), str(dev), _kwargs_signature(kwargs), self._fused_structure(), id(self.denoiser),
-            module_fingerprint(self.denoiser),
+            module_fingerprint(self.denoiser), str(x.dtype), wide,
         )
         ent = self._fused_cache.get(key)
         if ent is None:
             self._fused_cache = {}  # drop the stale plan first: one live plan per sampler keeps HBM use bounded
             cur = torch.zeros(COEF_WORDS, dtype=torch.float32, device=dev)
-            fused = self.denoiser._az_fused(x, kwargs, cur)
+            fused = self.denoiser._az_fused(torch.empty(x.shape, dtype=torch.float32, device=dev) if wide else x, kwargs, cur)
             if fused is None:
                 return None
-            ent = _FusedLoop(self, fused, x, cur)
+            if wide:
+                p0 = fused.programs[0]
+                Cc = x.shape[1] if x.ndim > 2 else 1
+                if (len(fused.programs) != 1 or p0.x_in_cs != 0 or p0.f_nhwc or p0.f_channels != Cc or p0.prepare is not None
+                        or fused.clip != (-math.inf, math.inf)):
+                    return None  # (CFG, ADM's clipped 6-channel output, NHWC hand-over: the generic fp64 loop)
+                ent = _FusedLoopWide(self, fused, x, cur)
+            else:
+                ent = _FusedLoop(self, fused, x, cur)
             self._fused_cache = {key: ent}
         return ent.run(x, kwargs)
 
@@ -515,6 +559,81 @@ class _FusedLoop:
                 for t in self.step_tapes[:n]:
                     cat.extend(t)
                 self.graphs[n] = StepGraph(cat, x.device)
+            else:
+                graph.launch()
+        return self.x.clone()
+
+
+class _FusedLoopWide(_FusedLoop):
+    r"""The captured loop for ``Sampler(dtype=torch.float64)`` (reference ``azula/sample.py:69-94``, ``azula/denoise.py:306-322``):
+    the schedule scalars are fp64 tensors of shape (1, ..., 1), so the latents and every elementwise statement of a step are
+    fp64 while the backbone keeps fp32.  Per step: ``az_step_begin`` (fp32 row: the backbone's time embedding) +
+    ``az_step_row_f64`` (fp64 rows) -> ``az_scale_f64_to_f32`` (backbone input) -> backbone tape -> ``az_axpby_f64`` (posterior
+    mean) -> ``az_transition_f64`` -- the kernels of the generic fp64 loop, reading their coefficients through pointers into
+    the device-resident current row, as ONE hipGraph per step.  Noise is drawn in the dtype of x_t like the reference's
+    ``randn_like(x_t)``: fp32 in the first step of an fp32 input (x_t is promoted by that step), fp64 afterwards."""
+
+    WORDS = 24
+
+    def __init__(self, sampler: "Sampler", fused: FusedDenoiser, x: Tensor, cur: Tensor) -> None:
+        dev = x.device
+        self.in_dtype = x.dtype
+        self.cur64 = torch.zeros(self.WORDS, dtype=torch.float64, device=dev)
+        n_rows = len(sampler._host_table(fused))
+        self.table64 = torch.zeros(n_rows, self.WORDS, dtype=torch.float64, device=dev)
+        self.mean64 = torch.empty(x.shape, dtype=torch.float64, device=dev)
+        super().__init__(sampler, fused, torch.empty(x.shape, dtype=torch.float64, device=dev), cur)
+        n32 = len(self.noise) if x.dtype == torch.float32 else 0
+        self.noise32 = [torch.empty(x.shape, dtype=torch.float32, device=dev) for _ in range(n32)]
+        self.dummy32 = torch.empty(x.shape, dtype=torch.float32, device=dev) if (self.dummy is not None and x.dtype == torch.float32) else None
+
+    def _c64(self, name: str, second: bool = False) -> int:
+        names = ["c_in", "c_skip", "c_out", "c_time", "alpha_t", "alpha_s", "k_x", "k_eps", "c_in_next", "clip_lo", "clip_hi", "guidance"]
+        return self.cur64.data_ptr() + 8 * (names.index(name) + (12 if second else 0))
+
+    def add_evaluation(self, tape: Tape) -> None:
+        p0 = self.fused.programs[0]
+        tape.add("az_step_begin", self.cur.data_ptr(), self.table.data_ptr(), self.counter.data_ptr(), self.n_rows)
+        tape.add("az_step_row_f64", self.cur64.data_ptr(), self.table64.data_ptr(), self.counter.data_ptr(), self.n_rows, self.WORDS)
+        tape.add("az_scale_f64_to_f32", p0.x_in.data_ptr(), self.x.data_ptr(), self._c64("c_in"), 1, self.x.numel(), 0)
+        tape.extend(p0.tape)
+
+    def add_transition(self, tape: Tape, *, x_t: Tensor, x_s: Tensor, eps: Tensor | None = None, mean_out: Tensor | None = None,
+                       write_xin: bool = True) -> None:
+        p0 = self.fused.programs[0]
+        n = x_t.numel()
+        tape.add("az_axpby_f64", self.mean64.data_ptr(), self._c64("c_skip"), x_t.data_ptr(), self._c64("c_out"), p0.out.data_ptr(), 1, 1, n, 0)
+        a = transition_args(x_t=x_t.data_ptr(), F=self.mean64.data_ptr(), eps=eps.data_ptr() if eps is not None else None,
+                            x_s=x_s.data_ptr(), batch=1, channels=1, inner=n, f_channels=1, coef=self.cur64.data_ptr() + 8 * 12)
+        tape.add("az_transition_f64", C.byref(a), keep=[a])
+
+    def _upload_table(self, kwargs: dict) -> None:
+        before = self.table_key
+        super()._upload_table(kwargs)
+        if self.table_key != before:
+            self.table64.copy_(self.sampler._host_table_wide(self.fused))
+
+    def run(self, x: Tensor, kwargs: dict) -> Tensor:
+        s = self.sampler
+        self._upload_table(kwargs)
+        self.x.copy_(x)  # (fp32 -> fp64 is exact: what the first fp64 multiplication of the reference's step does)
+        self.counter.zero_()
+        stream = _lib.stream_ptr()
+        for g in s.progress_bar(range(s.steps)):
+            first32 = g == 0 and self.in_dtype == torch.float32
+            for k, buf in enumerate(self.noise):
+                if first32:
+                    s._draw_noise(self.noise32[k], out=self.noise32[k])
+                    buf.copy_(self.noise32[k])
+                else:
+                    s._draw_noise(buf, out=buf)
+            if self.dummy is not None:
+                d = self.dummy32 if first32 else self.dummy
+                s._draw_noise(d, out=d)
+            graph = self.graphs.get(1)
+            if graph is None:
+                self.step_tapes[0].run(stream)
+                self.graphs[1] = StepGraph(self.step_tapes[0], x.device)
             else:
                 graph.launch()
         return self.x.clone()

@@ -470,6 +470,11 @@ int az_graph_num_nodes(AzGraph* g, int64_t* n);
  *   az_axpby_f64:        y = a x + b z, fp64, z read as float (z_is_f32) or double; a, b device scalars or per-row
  *   az_scale_f64_to_f32: y = (float)(s x)   -- `(c_in * x_t).to(backbone dtype)`, azula/denoise.py:317                */
 int az_transition_f64(const AzTransitionArgs* args, az_stream_t stream);
+/* Captured loop with fp64 latents (round 4): cur[0, words) = table[*step_counter - 1][0, words) -- the fp64 coefficients of the
+ * step az_step_begin has just started (the fp32 row feeds the backbone's time embedding, this one az_scale_f64_to_f32 /
+ * az_axpby_f64 / az_transition_f64 through pointers into `cur`), so that ONE graph serves every step.  words <= 64. */
+int az_step_row_f64(double* cur, const double* table, const int32_t* step_counter, int32_t n_rows, int32_t words,
+                    az_stream_t stream);
 int az_axpby_f64(double* y, const double* a_dev, const double* x, const double* b_dev, const void* z, int32_t z_is_f32,
                  int64_t rows, int64_t inner, int32_t a_stride, az_stream_t stream);
 int az_scale_f64_to_f32(float* y, const double* x, const double* s_dev, int64_t rows, int64_t inner, int32_t s_stride,

@@ -55,6 +55,44 @@ def test_fp64_time_grid_matches_reference(golden):
         assert max_err(xa, x32) < 1e-4 * sc  # two precisions of the same integrator around the same fp32 network
 
 
+@pytest.mark.parametrize("in_dtype", [torch.float32, torch.float64])
+def test_fp64_clock_runs_as_a_captured_loop(golden, in_dtype, monkeypatch):
+    """``DDIMSampler / DDPMSampler(dtype=float64)``: one hipGraph per step (az_step_row_f64 + az_scale_f64_to_f32 + backbone +
+    az_axpby_f64 + az_transition_f64) instead of the per-statement loop -- equal to that loop to fp64 round-off (same kernels,
+    the same generator draws: fp32 in the first step of an fp32 input, fp64 afterwards) and within the fp32 backbone's
+    round-off of the reference's output (G11)."""
+    from azula_amd import sample as S
+
+    g = golden("g11_sampler_dtype")
+    den = unet_denoiser(g)
+    x1 = g["unet_x1"].cuda().to(in_dtype)
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(S, "WIDE_FUSED", fused)
+        smp = S.DDIMSampler(den, steps=8, silent=True, dtype=torch.float64)
+        ddim = smp(x1)
+        if fused:
+            loop = next(iter(smp._fused_cache.values()))
+            assert isinstance(loop, S._FusedLoopWide) and loop.graphs[1].num_nodes >= len(loop.tape)
+            assert torch.equal(smp(x1), ddim)  # replay
+        else:
+            assert not smp._fused_cache
+        torch.manual_seed(77)
+        ddpm = S.DDPMSampler(den, steps=6, silent=True, dtype=torch.float64)(x1)
+        torch.manual_seed(77)
+        eta = S.DDIMSampler(den, steps=6, eta=0.5, silent=True, dtype=torch.float64)(x1)
+        outs[fused] = (ddim, ddpm, eta)
+    for a, b, what in zip(outs[True], outs[False], ("DDIM-8", "DDPM-6", "DDIM-6 eta 0.5")):
+        # (not bit-equal: the per-statement loop evaluates the schedule with the DEVICE's fp64 libm, the captured loop reads the
+        # host table -- the reference's CPU values; measured 1.8e-15)
+        assert a.dtype == torch.float64 and max_err(a, b) < 1e-12, (what, max_err(a, b))
+    if in_dtype == torch.float32:
+        sc = max(1.0, g["unet_ddim8"].abs().max().item())
+        e = max_err(outs[True][0], g["unet_ddim8"])
+        print("captured fp64 loop, DDIM-8 vs the reference:", e, "scale", sc)
+        assert e < 2e-5 * sc
+
+
 def test_fp64_elementwise_kernels_bit_exact():
     """az_axpby_f64 / az_scale_f64_to_f32 / az_transition_f64 against torch's fp64 CPU ops, op for op."""
     import ctypes as C
