@@ -326,14 +326,14 @@ __global__ __launch_bounds__(256) void affine_act_kernel(float* __restrict__ y, 
   for (; p < HW; p += pstride) yb[(int64_t)p * q] = apply(ld_cat(x, x1, c0s, cs, pix0 + p, c4 * 4));
 }
 
-template <int ACT>
+template <int ACT, int PH>  // PH = rows of the pooling window: 2 (AvgPool2d(2, 2)) or 1 (AvgPool1d(2) on a one-row image)
 __global__ __launch_bounds__(256) void affine_act_pool_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                               const float* __restrict__ x1, int c0s,
                                                               const float* __restrict__ S,
                                                               const float* __restrict__ T, int64_t B, int H, int W,
                                                               int cs) {
   const int q = cs / 4;
-  const int Ho = H / 2, Wo = W / 2;
+  const int Ho = H / PH, Wo = W / 2;
   const int64_t per_b = (int64_t)Ho * Wo * q;
   const int64_t total = B * per_b;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -347,10 +347,10 @@ __global__ __launch_bounds__(256) void affine_act_pool_kernel(float* __restrict_
     const float4 t = *reinterpret_cast<const float4*>(T + b * cs + c4 * 4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
+    for (int dy = 0; dy < PH; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
-        const int64_t pix = (b * H + (2 * oh + dy)) * W + (2 * ow + dx);
+        const int64_t pix = (b * H + (PH * oh + dy)) * W + (2 * ow + dx);
         const float4 v = ld_cat(x, x1, c0s, cs, pix, c4 * 4);
         float4 o;
         o.x = fmaf(v.x, s.x, t.x);
@@ -368,10 +368,11 @@ __global__ __launch_bounds__(256) void affine_act_pool_kernel(float* __restrict_
         acc.z += o.z;
         acc.w += o.w;
       }
-    acc.x *= 0.25f;
-    acc.y *= 0.25f;
-    acc.z *= 0.25f;
-    acc.w *= 0.25f;
+    constexpr float inv = PH == 2 ? 0.25f : 0.5f;
+    acc.x *= inv;
+    acc.y *= inv;
+    acc.z *= inv;
+    acc.w *= inv;
     reinterpret_cast<float4*>(y)[e] = acc;
   }
 }
@@ -556,14 +557,21 @@ int az_affine_act_f32(float* y, const float* x, const float* x1, int64_t c0s, co
   AZ_REQUIRE(B > 0 && H > 0 && W > 0 && cs > 0 && cs % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE(AZ_ALIGNED16(y) && AZ_ALIGNED16(x) && AZ_ALIGNED16(S) && AZ_ALIGNED16(T), AZ_E_ALIGN);
   hipStream_t st = az_s(stream);
-  if (pool) {
+  if (pool == 2) {  // width only: AvgPool1d(2) of a (B, C, L) signal held as a one-row image
+    AZ_REQUIRE(W % 2 == 0, AZ_E_SHAPE);
+    const int grid = az_stream_grid(B * H * (W / 2) * (cs / 4), 256);
+    if (act == 1)
+      hipLaunchKernelGGL((affine_act_pool_kernel<1, 1>), dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, (int)H, (int)W, (int)cs);
+    else
+      hipLaunchKernelGGL((affine_act_pool_kernel<0, 1>), dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, (int)H, (int)W, (int)cs);
+  } else if (pool) {
     AZ_REQUIRE(H % 2 == 0 && W % 2 == 0, AZ_E_SHAPE);
     const int grid = az_stream_grid(B * (H / 2) * (W / 2) * (cs / 4), 256);
     if (act == 1)
-      hipLaunchKernelGGL(affine_act_pool_kernel<1>, dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, (int)H,
+      hipLaunchKernelGGL((affine_act_pool_kernel<1, 2>), dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, (int)H,
                          (int)W, (int)cs);
     else
-      hipLaunchKernelGGL(affine_act_pool_kernel<0>, dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, (int)H,
+      hipLaunchKernelGGL((affine_act_pool_kernel<0, 2>), dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, (int)H,
                          (int)W, (int)cs);
   } else {
     AZ_REQUIRE(H * W < (1ll << 31) && B < 65536, AZ_E_SHAPE);

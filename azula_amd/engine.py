@@ -582,8 +582,8 @@ class Builder:
             y = Act(x.buf, B, x.H, x.W, x.C, x.cs, True)
             y.affine = (ST, act)
             return y
-        if pool:
-            y = self.new_act(B, x.H // 2, x.W // 2, x.C)
+        if pool:  # 1: 2x2, 2: along the width only (a 1-D signal held as a one-row image)
+            y = self.new_act(B, x.H // 2 if pool == 1 else x.H, x.W // 2, x.C)
         else:
             y = self.new_act(B, x.H, x.W, x.C)
         self.tape.add(

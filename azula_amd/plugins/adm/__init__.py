@@ -152,9 +152,9 @@ class AblatedDenoiser(Denoiser):
         from ...nn.unet import _copy_tape
 
         bb = self.backbone
-        if not isinstance(bb, unet.UNetModel) or x.ndim != 4 or get_module_dtype(bb) not in (torch.float32, torch.float16, torch.bfloat16):
+        if not isinstance(bb, unet.UNetModel) or x.ndim != bb.dims + 2 or get_module_dtype(bb) not in (torch.float32, torch.float16, torch.bfloat16):
             return None
-        B, _, H, W = x.shape
+        B, (H, W) = x.shape[0], _map_size(x)
         if len(kwargs_list) == 2 and bb.num_classes is not None and os.environ.get("AZ_CFG_BATCHED", "1") != "0":
             batched = self._az_cfg_batched(x, kwargs_list, cur_coef)
             if batched is not None:
@@ -195,7 +195,7 @@ class AblatedDenoiser(Denoiser):
         bb = self.backbone
         if any(set(kw) - {"label"} or kw.get("label") is None for kw in kwargs_list):
             return None
-        B, _, H, W = x.shape
+        B, (H, W) = x.shape[0], _map_size(x)
         plan = bb.plan(2 * B, H, W, 2 * B, x.device, coef_ptr=cur_coef.data_ptr(), tag="cfg2b")
         half_in = B * H * W * (plan.x_in.cs if plan.x_in.cs > 0 else plan.x_in.C)  # (channel stride 0: the planar latent layout)
         one = torch.ones(1, dtype=torch.float32, device=x.device)
@@ -220,6 +220,11 @@ class AblatedDenoiser(Denoiser):
         if programs is None:
             return None
         return FusedDenoiser(coefficients=self.host_coefficients, programs=programs, clip=self._clip())
+
+
+def _map_size(x: Tensor) -> tuple[int, int]:
+    r"""(H, W) of the feature map a latent is run as: a (B, C, L) signal (``dims=1``) is a one-row image."""
+    return (1, x.shape[2]) if x.ndim == 3 else (x.shape[2], x.shape[3])
 
 
 def load_model(name: str, **kwargs) -> Denoiser:

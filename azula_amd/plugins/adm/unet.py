@@ -15,7 +15,10 @@ compiled tape on the channel-padded NHWC layout:
 * AttentionBlock (``:289-296``): GN -> 1x1 QKV GEMM -> flash attention (legacy ``(H 3 C)`` or new
   ``(3 H C)`` order, scale folded) -> zero-init 1x1 ``proj_out`` + residual epilogue;
 * the sinusoidal timestep embedding (``_src/nn.py:90-108``) is a host table indexed on the
-  device by the step's ``time_index``.
+  device by the step's ``time_index``;
+* ``dims=1`` (``conv_nd`` / ``avg_pool_nd``, ``_src/nn.py:50-77``): a (B, C, L) signal is a one-row image -- a 3-tap
+  ``Conv1d`` filter is the middle row of a 3x3 one (the rows above and below only ever meet the zero padding), stride 2 /
+  nearest x2 / the average pool act along the width alone (the anisotropic descriptor, pooling mode 2).
 """
 
 from __future__ import annotations
@@ -32,6 +35,9 @@ from ...engine import Act, Builder, pad4
 __all__ = ["UNetModel"]
 
 
+_CONV = {1: nn.Conv1d, 2: nn.Conv2d}  # conv_nd, reference _src/nn.py:50-61 (3-D signals are not built)
+
+
 def _zero(m: nn.Module) -> nn.Module:
     for p in m.parameters():
         p.detach().zero_()
@@ -42,42 +48,44 @@ class ResBlock(nn.Module):
     r"""Parameter holder: in_layers (GN, SiLU, conv), emb_layers (SiLU, Linear), out_layers
     (GN, SiLU, Dropout, zero-init conv), skip_connection (reference ``_src/unet.py:140-225``)."""
 
-    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_scale_shift_norm=False, up=False, down=False):
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_scale_shift_norm=False, up=False, down=False,
+                 dims=2):
         super().__init__()
         self.channels, self.out_channels = channels, out_channels or channels
         self.up, self.down, self.use_scale_shift_norm = up, down, use_scale_shift_norm
         oc = self.out_channels
-        self.in_layers = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(), nn.Conv2d(channels, oc, 3, padding=1))
+        conv = _CONV[dims]
+        self.in_layers = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(), conv(channels, oc, 3, padding=1))
         self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, 2 * oc if use_scale_shift_norm else oc))
         self.out_layers = nn.Sequential(
-            nn.GroupNorm(32, oc), nn.SiLU(), nn.Dropout(p=dropout), _zero(nn.Conv2d(oc, oc, 3, padding=1))
+            nn.GroupNorm(32, oc), nn.SiLU(), nn.Dropout(p=dropout), _zero(conv(oc, oc, 3, padding=1))
         )
-        self.skip_connection = nn.Identity() if oc == channels else nn.Conv2d(channels, oc, 1)
+        self.skip_connection = nn.Identity() if oc == channels else conv(channels, oc, 1)
 
 
 class Downsample(nn.Module):
     r"""Parameter holder of the ``resblock_updown=False`` downsampling layer: a stride-2 3x3 convolution ``op`` or a
     2x2 average pool (reference ``_src/unet.py:111-137``)."""
 
-    def __init__(self, channels, use_conv, out_channels=None):
+    def __init__(self, channels, use_conv, out_channels=None, dims=2):
         super().__init__()
         self.channels, self.out_channels, self.use_conv = channels, out_channels or channels, use_conv
         if use_conv:
-            self.op = nn.Conv2d(channels, self.out_channels, 3, stride=2, padding=1)
+            self.op = _CONV[dims](channels, self.out_channels, 3, stride=2, padding=1)
         else:
             assert self.channels == self.out_channels
-            self.op = nn.AvgPool2d(2, 2)
+            self.op = nn.AvgPool1d(2, 2) if dims == 1 else nn.AvgPool2d(2, 2)
 
 
 class Upsample(nn.Module):
     r"""Parameter holder of the ``resblock_updown=False`` upsampling layer: nearest x2, then an optional 3x3
     convolution ``conv`` (reference ``_src/unet.py:82-109``)."""
 
-    def __init__(self, channels, use_conv, out_channels=None):
+    def __init__(self, channels, use_conv, out_channels=None, dims=2):
         super().__init__()
         self.channels, self.out_channels, self.use_conv = channels, out_channels or channels, use_conv
         if use_conv:
-            self.conv = nn.Conv2d(channels, self.out_channels, 3, padding=1)
+            self.conv = _CONV[dims](channels, self.out_channels, 3, padding=1)
 
 
 class AttentionBlock(nn.Module):
@@ -121,9 +129,28 @@ class ADMPlan:
         self.versions = net._param_versions()
         self.emb_rows = emb_rows
         cin = net.in_channels
+        one_d = net.dims == 1  # (B, C, L) signals: H = 1, every resampling acts along the width alone
+        assert not one_d or H == 1
+        up2 = (0, 1) if one_d else 1  # log2 of the nearest upsampling per axis
+        down2 = (1, 2) if one_d else 2  # stride per axis
+        pool2 = 2 if one_d else 1  # az_affine_act_f32's pooling mode: 1x2 or 2x2
+        wino = False if one_d else None  # (a one-row map: the direct kernel; F(2x2, 3x3) would compute a second, discarded row)
+
+        def packed(conv, **kw):
+            r"""Filter of a ConvNd layer; a 3-tap Conv1d becomes the middle row of a 3x3 filter."""
+            w = conv.weight
+            if w.ndim == 3 and w.shape[-1] == 3:
+                w2 = torch.zeros(*w.shape[:2], 3, 3, dtype=w.dtype, device=w.device)
+                w2[:, :, 1, :] = w.detach()
+                w = w2
+            return bld.pack_conv(w, conv.bias, **kw)
+
+        def halved(a: Act) -> tuple[int, int]:
+            return (a.H, a.W // 2) if one_d else (a.H // 2, a.W // 2)
+
         c_first = net.input_blocks[0][0]
         # the first convolution reads the latent PLANAR (x_in = the loop's own (B, C, H, W) layout, channel stride 0): Builder.conv_stem
-        self.planar = (engine.STEM_PLANAR and cin <= 4 and isinstance(c_first, nn.Conv2d) and tuple(c_first.weight.shape[2:]) == (3, 3)
+        self.planar = (engine.STEM_PLANAR and cin <= 4 and isinstance(c_first, (nn.Conv1d, nn.Conv2d)) and c_first.weight.shape[-1] == 3
                        and c_first.out_channels % 4 == 0 and bld.half is None and (x_in is None or x_in.cs == 0))
         if x_in is not None:
             self.x_in = x_in
@@ -189,8 +216,8 @@ class ADMPlan:
             film_jobs.append((film, bld.const(w), bld.const(b_), nf * ocs))
             fbs = nf * ocs if emb_rows > 1 else 0
             # h = conv(updown(SiLU(GN(x))))
-            n1 = bld.group_norm(x, 32, weight=bld.const(gi.weight), bias=bld.const(gi.bias), act=1, pool=int(rb.down), x1=x1)
-            h = bld.conv(n1, bld.pack_conv(ci.weight, ci.bias), oc, up0=int(rb.up),
+            n1 = bld.group_norm(x, 32, weight=bld.const(gi.weight), bias=bld.const(gi.bias), act=1, pool=pool2 if rb.down else 0, x1=x1)
+            h = bld.conv(n1, packed(ci), oc, up0=up2 if rb.up else 0, winograd=wino,
                          gn_stats=rb.use_scale_shift_norm)  # -> out_layers' GroupNorm
             bld.free(n1)
             if rb.use_scale_shift_norm:  # h = SiLU(GN(h) * (1 + scale) + shift)
@@ -212,20 +239,20 @@ class ADMPlan:
             if rb.down:
                 assert x1 is None
                 ones, zeros = bld.const(torch.ones(B * x.cs)), bld.const(torch.zeros(B * x.cs))
-                xs = bld.new_act(B, x.H // 2, x.W // 2, x.C)
-                bld.tape.add("az_affine_act_f32", xs.ptr, x.ptr, None, 0, ones.data_ptr(), zeros.data_ptr(), B, x.H, x.W, x.cs, 0, 1)
-                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=xs, gn_stats=True)
+                xs = bld.new_act(B, *halved(x), x.C)
+                bld.tape.add("az_affine_act_f32", xs.ptr, x.ptr, None, 0, ones.data_ptr(), zeros.data_ptr(), B, x.H, x.W, x.cs, 0, pool2)
+                out = bld.conv(n2, packed(co), oc, res=xs, gn_stats=True, winograd=wino)
                 bld.free(xs)
             elif rb.up:
                 assert x1 is None
-                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=x, res_up=1, gn_stats=True)
+                out = bld.conv(n2, packed(co), oc, res=x, res_up=1, gn_stats=True, winograd=wino)  # (one row: oh >> 1 = 0)
             elif isinstance(rb.skip_connection, nn.Identity):
                 assert x1 is None
-                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=x, gn_stats=True)
+                out = bld.conv(n2, packed(co), oc, res=x, gn_stats=True, winograd=wino)
             else:
                 sc = rb.skip_connection
-                skip = bld.conv(x, bld.pack_conv(sc.weight, sc.bias, cin0=x.C if x1 is not None else None), oc, src1=x1)
-                out = bld.conv(n2, bld.pack_conv(co.weight, co.bias), oc, res=skip, gn_stats=True)
+                skip = bld.conv(x, packed(sc, cin0=x.C if x1 is not None else None), oc, src1=x1)
+                out = bld.conv(n2, packed(co), oc, res=skip, gn_stats=True, winograd=wino)
                 bld.free(skip)
             bld.free(n2)
             return out
@@ -246,25 +273,25 @@ class ADMPlan:
 
         def run(block: nn.Sequential, h: Act, h1: Act | None = None) -> Act:
             for layer in block:
-                if isinstance(layer, nn.Conv2d) and h is self.x_in and self.planar:
-                    nh = bld.conv_stem(h.buf, B, cin, H, W, bld.pack_conv(layer.weight, layer.bias), layer.out_channels, gn_stats=True)
-                elif isinstance(layer, nn.Conv2d):
-                    nh = bld.conv(h, bld.pack_conv(layer.weight, layer.bias), layer.out_channels, gn_stats=True)
+                if isinstance(layer, (nn.Conv1d, nn.Conv2d)) and h is self.x_in and self.planar:
+                    nh = bld.conv_stem(h.buf, B, cin, H, W, packed(layer), layer.out_channels, gn_stats=True)
+                elif isinstance(layer, (nn.Conv1d, nn.Conv2d)):
+                    nh = bld.conv(h, packed(layer), layer.out_channels, gn_stats=True, winograd=wino)
                 elif isinstance(layer, ResBlock):
                     nh = resblock(layer, h, h1)
                 elif isinstance(layer, Downsample):
                     if layer.use_conv:
-                        nh = bld.conv(h, bld.pack_conv(layer.op.weight, layer.op.bias), layer.out_channels, stride=2)
-                    else:  # AvgPool2d(2, 2): the pooling form of the elementwise pass with S = 1, T = 0
-                        nh = bld.new_act(B, h.H // 2, h.W // 2, h.C)
+                        nh = bld.conv(h, packed(layer.op), layer.out_channels, stride=down2)
+                    else:  # AvgPoolNd(2, 2): the pooling form of the elementwise pass with S = 1, T = 0
+                        nh = bld.new_act(B, *halved(h), h.C)
                         bld.tape.add("az_affine_act_f32", nh.ptr, h.ptr, None, 0, bld.const(torch.ones(B * h.cs)).data_ptr(),
-                                     bld.const(torch.zeros(B * h.cs)).data_ptr(), B, h.H, h.W, h.cs, 0, 1)
+                                     bld.const(torch.zeros(B * h.cs)).data_ptr(), B, h.H, h.W, h.cs, 0, pool2)
                 elif isinstance(layer, Upsample):
                     if layer.use_conv:  # nearest x2 is a read-side shift of the conv gather
-                        nh = bld.conv(h, bld.pack_conv(layer.conv.weight, layer.conv.bias), layer.out_channels, up0=1)
+                        nh = bld.conv(h, packed(layer.conv), layer.out_channels, up0=up2, winograd=wino)
                     else:  # nearest x2 alone: the same gather under an identity 1x1 filter (exact: one product per output)
                         eye = torch.eye(h.C, dtype=torch.float32, device=device)
-                        nh = bld.conv(h, bld.pack_conv(eye, None), h.C, up0=1)
+                        nh = bld.conv(h, bld.pack_conv(eye, None), h.C, up0=up2)
                 else:
                     nh = attention(layer, h)
                 if h1 is None and h not in hs and h is not self.x_in:
@@ -288,7 +315,7 @@ class ADMPlan:
             h = nh
         go, co = net.out[0], net.out[2]
         n_ = bld.group_norm(h, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), act=1)
-        bld.conv(n_, bld.pack_conv(co.weight, co.bias), net.out_channels, dst_nchw=self.out)
+        bld.conv(n_, packed(co), net.out_channels, dst_nchw=self.out, winograd=wino)
         bld.finish()
         if film_jobs:
             from ..._lib import AzLinearGroup, lib
@@ -311,7 +338,8 @@ class ADMPlan:
 class UNetModel(nn.Module):
     r"""guided-diffusion ``UNetModel`` (reference ``_src/unet.py:387-634``), gfx950-native forward.
 
-    ``dims=2`` (all of the plugin's cards); ``dims`` 1 / 3 raise ``NotImplementedError``.  The cards use
+    ``dims=2`` (all of the plugin's cards) and ``dims=1`` ((B, C, L) signals, run as one-row images); ``dims=3`` raises
+    ``NotImplementedError``.  The cards use
     ``resblock_updown=True, use_scale_shift_norm=True``; guided-diffusion's defaults (``h + emb`` instead of FiLM,
     ``Downsample`` / ``Upsample`` layers with or without ``conv_resample``) are built too (G14).
     """
@@ -338,8 +366,10 @@ class UNetModel(nn.Module):
         use_new_attention_order=False,
     ) -> None:
         super().__init__()
-        if dims != 2:
-            raise NotImplementedError("the HIP path implements dims=2 (all ADM cards); 1-D / 3-D signals are not built")
+        if dims not in (1, 2):
+            raise NotImplementedError("the HIP path implements dims=2 (all ADM cards) and dims=1; 3-D signals are not built")
+        self.dims = dims
+        conv = _CONV[dims]
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
         self.image_size, self.in_channels, self.model_channels = image_size, in_channels, model_channels
@@ -351,14 +381,14 @@ class UNetModel(nn.Module):
             self.label_emb = nn.Embedding(num_classes, E)
 
         def res(ch, oc=None, **kw):
-            return ResBlock(ch, E, dropout, out_channels=oc, use_scale_shift_norm=use_scale_shift_norm, **kw)
+            return ResBlock(ch, E, dropout, out_channels=oc, use_scale_shift_norm=use_scale_shift_norm, dims=dims, **kw)
 
         def attn(ch, heads):
             return AttentionBlock(ch, num_heads=heads, num_head_channels=num_head_channels,
                                   use_new_attention_order=use_new_attention_order)
 
         ch = int(channel_mult[0] * model_channels)
-        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(nn.Conv2d(in_channels, ch, 3, padding=1))])
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(conv(in_channels, ch, 3, padding=1))])
         chans, ds = [ch], 1
         for level, mult in enumerate(channel_mult):
             for _ in range(num_res_blocks):
@@ -370,7 +400,7 @@ class UNetModel(nn.Module):
                 chans.append(ch)
             if level != len(channel_mult) - 1:
                 self.input_blocks.append(TimestepEmbedSequential(
-                    res(ch, ch, down=True) if resblock_updown else Downsample(ch, conv_resample, out_channels=ch)))
+                    res(ch, ch, down=True) if resblock_updown else Downsample(ch, conv_resample, out_channels=ch, dims=dims)))
                 chans.append(ch)
                 ds *= 2
         self.middle_block = TimestepEmbedSequential(res(ch), attn(ch, num_heads), res(ch))
@@ -383,10 +413,10 @@ class UNetModel(nn.Module):
                 if ds in attention_resolutions:
                     layers.append(attn(ch, num_heads_upsample))
                 if level and i == num_res_blocks:
-                    layers.append(res(ch, ch, up=True) if resblock_updown else Upsample(ch, conv_resample, out_channels=ch))
+                    layers.append(res(ch, ch, up=True) if resblock_updown else Upsample(ch, conv_resample, out_channels=ch, dims=dims))
                     ds //= 2
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
-        self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), _zero(nn.Conv2d(ch, out_channels, 3, padding=1)))
+        self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), _zero(conv(ch, out_channels, 3, padding=1)))
         self._plans: dict = {}
 
     def _param_versions(self) -> tuple:
@@ -403,7 +433,8 @@ class UNetModel(nn.Module):
     @torch.no_grad()
     @_lib.on_device
     def forward(self, x: Tensor, timesteps: Tensor, y: Tensor | None = None) -> Tensor:
-        r"""x: (N, C, H, W); timesteps: (N,) or (1,) integer indices or fractional values; y: (N,) labels iff class-conditional."""
+        r"""x: (N, C, H, W) [dims = 1: (N, C, L)]; timesteps: (N,) or (1,) integer indices or fractional values; y: (N,) labels
+        iff class-conditional."""
         assert (y is not None) == (self.num_classes is not None), (
             "must specify y if and only if the model is class-conditional"
         )
@@ -411,6 +442,10 @@ class UNetModel(nn.Module):
 
         out_dtype = backbone_io_dtype(self, x, "azula_amd ADM UNetModel")
         x = x.to(torch.float32).contiguous()
+        assert x.ndim == self.dims + 2, f"dims={self.dims}: expected a {self.dims + 2}-d input, got {tuple(x.shape)}"
+        shape = x.shape
+        if self.dims == 1:
+            x = x[:, :, None, :]
         B, Cin, H, W = x.shape
         timesteps = timesteps.reshape(-1)
         frac = torch.is_floating_point(timesteps)  # (azula itself passes integer indices; guided-diffusion allows fractions)
@@ -429,4 +464,4 @@ class UNetModel(nn.Module):
             assert y.shape == (B,)
             p.labels.copy_(y.to(torch.int64))
         p.tape.run(s)
-        return p.out.to(out_dtype, copy=True)
+        return p.out.reshape(B, self.out_channels, *shape[2:]).to(out_dtype, copy=True)

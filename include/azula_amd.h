@@ -220,7 +220,8 @@ typedef struct AzNormFinalizeArgs {
   int32_t reserved0;
 } AzNormFinalizeArgs;
 int az_groupnorm_finalize_f32(const AzNormFinalizeArgs* args, az_stream_t stream);
-/* pool: 0 none, 1 = 2x2 average pool of act(.) (needs H, W even; dst is (B, H/2*W/2, cs)).      */
+/* pool: 0 none, 1 = 2x2 average pool of act(.) (needs H, W even; dst is (B, H/2*W/2, cs)), 2 = 1x2 (width only: AvgPool1d(2) of
+ * a signal held as a one-row image, plugins/adm/_src/nn.py:64-77 with dims = 1; dst is (B, H*W/2, cs)). */
 int az_affine_act_f32(float* y, const float* x, const float* x1, int64_t c0s, const float* S, const float* T,
                       int64_t B, int64_t H, int64_t W, int64_t cs, int32_t act, int32_t pool, az_stream_t stream);
 

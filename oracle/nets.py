@@ -275,16 +275,18 @@ def _gn32(sd, key: str, x: Tensor) -> Tensor:
 
 
 def adm_resblock(sd, key: str, x: Tensor, emb: Tensor, up: bool, down: bool, scale_shift: bool) -> Tensor:
-    r"""ResBlock._forward -- azula/plugins/adm/_src/unet.py:227-247."""
+    r"""ResBlock._forward -- azula/plugins/adm/_src/unet.py:227-247 (dims = 1: (B, C, L) signals, dims = 2: images)."""
+    n = x.ndim - 2
+    pool = F.avg_pool1d if n == 1 else F.avg_pool2d  # avg_pool_nd, _src/nn.py:64-77
     h = F.silu(_gn32(sd, key + ".in_layers.0", x))
     if up:  # :104-106 nearest x2 on both branches
         h = F.interpolate(h, scale_factor=2, mode="nearest")
         x = F.interpolate(x, scale_factor=2, mode="nearest")
-    elif down:  # :133 AvgPool2d(2, 2)
-        h = F.avg_pool2d(h, 2, 2)
-        x = F.avg_pool2d(x, 2, 2)
+    elif down:  # :133 AvgPoolNd(2, 2)
+        h = pool(h, 2, 2)
+        x = pool(x, 2, 2)
     h = _conv(sd, key + ".in_layers.2", h)
-    emb_out = _linear(sd, key + ".emb_layers.1", F.silu(emb))[..., None, None]
+    emb_out = _linear(sd, key + ".emb_layers.1", F.silu(emb))[(...,) + (None,) * n]  # :236-237
     if scale_shift:
         scale, shift = torch.chunk(emb_out, 2, dim=1)
         h = _gn32(sd, key + ".out_layers.0", h) * (1 + scale) + shift
@@ -293,8 +295,7 @@ def adm_resblock(sd, key: str, x: Tensor, emb: Tensor, up: bool, down: bool, sca
         h = h + emb_out
         h = _conv(sd, key + ".out_layers.3", F.silu(_gn32(sd, key + ".out_layers.0", h)))
     if key + ".skip_connection.weight" in sd:
-        w = sd[key + ".skip_connection.weight"]
-        x = F.conv2d(x, w, sd[key + ".skip_connection.bias"], padding=w.shape[-1] // 2)
+        x = _conv(sd, key + ".skip_connection", x)
     return x + h
 
 
@@ -385,12 +386,12 @@ def adm_unet_forward(sd, cfg: dict, x: Tensor, timesteps: Tensor, y: Tensor | No
                 h = _conv(sd, key, h)
             elif layer[0] == "res":
                 h = adm_resblock(sd, key, h, emb, layer[1], layer[2], ss)
-            elif layer[0] == "down":  # Downsample.forward, _src/unet.py:128-137: stride-2 3x3 conv or AvgPool2d(2, 2)
-                h = F.conv2d(h, sd[key + ".op.weight"], sd[key + ".op.bias"], stride=2, padding=1) if layer[1] else F.avg_pool2d(h, 2, 2)
+            elif layer[0] == "down":  # Downsample.forward, _src/unet.py:128-137: stride-2 3-tap conv or AvgPoolNd(2, 2)
+                h = _conv(sd, key + ".op", h, stride=2) if layer[1] else (F.avg_pool1d if h.ndim == 3 else F.avg_pool2d)(h, 2, 2)
             elif layer[0] == "up":  # Upsample.forward, _src/unet.py:101-109: nearest x2, then the optional 3x3 conv
                 h = F.interpolate(h, scale_factor=2, mode="nearest")
                 if layer[1]:
-                    h = F.conv2d(h, sd[key + ".conv.weight"], sd[key + ".conv.bias"], padding=1)
+                    h = _conv(sd, key + ".conv", h)
             else:
                 h = adm_attention(sd, key, h, layer[1], new_order)
         return h

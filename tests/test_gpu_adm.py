@@ -184,6 +184,37 @@ def test_adm_options_outside_the_cards(golden, name):
     assert e2 < 2.5e-4  # measured 2.8e-5 .. 5.0e-5 (means clipped to +-1, c_out = -100 at t = 1)
 
 
+@pytest.mark.parametrize("name", ["adm_1d_film_updown", "adm_1d_plain_conv", "adm_1d_plain_pool"])
+def test_adm_on_one_dimensional_signals(golden, name):
+    """``UNetModel(dims=1)`` (conv_nd / avg_pool_nd, plugins/adm/_src/nn.py:50-77): (B, C, L) signals run as one-row images --
+    Conv1d filters in the middle row of 3x3 ones, stride 2 / nearest x2 / the average pool along the width alone (G22)."""
+    from azula_amd.sample import DDIMSampler
+
+    g = golden("g22_" + name)
+    den, _, cfg = build(g)
+    assert g["x"].ndim == 3
+    y = g["y"].cuda() if "y" in g else None
+    out = den.backbone(g["x"].cuda(), g["idx"].cuda(), y=y)
+    assert out.shape == g["out"].shape
+    err, sc = max_err(out, g["out"]), g["out"].abs().max().item()
+    kw = {"label": y} if y is not None else {}
+    smp = DDIMSampler(den, steps=8, silent=True)
+    x0 = smp(g["x1"].cuda(), **kw)
+    assert x0.shape == g["ddim8"].shape
+    assert next(iter(smp._fused_cache.values())).graph is not None  # the captured loop, not the generic one
+    e2 = max_err(x0, g["ddim8"])
+    print(name, "backbone max|d|", err, "scale", sc, "DDIM-8", e2, "scale", g["ddim8"].abs().max().item())
+    assert err < 2e-5 * max(1.0, sc)
+    assert e2 < 2.5e-4
+    # the posterior (generic call path) on the same signal
+    post = den(g["x1"].cuda(), torch.tensor(0.5, device="cuda"), **kw)
+    assert post.mean.shape == g["x1"].shape and torch.isfinite(post.mean).all()
+    with pytest.raises(NotImplementedError):
+        from azula_amd.plugins import adm
+
+        adm.make_model(**{**cfg, "dims": 3})
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_adm_fractional_timesteps(golden, name):
     """UNetModel.forward with FRACTIONAL timesteps (plugins/adm/_src/nn.py:90-108): the sinusoid is evaluated on the device

@@ -334,6 +334,26 @@ def test_groupnorm_avgpool(az):
     assert max_err(from_nhwc(y.buf.reshape(B, H // 2, W // 2, Cc), Cc), ref) < 2e-5
 
 
+@pytest.mark.parametrize("H", [1, 3])
+def test_groupnorm_avgpool_along_the_width(az, H):
+    """Pooling mode 2: AvgPool1d(2) of a signal held as a one-row image (avg_pool_nd, plugins/adm/_src/nn.py:64-77); rows
+    are never mixed."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(4)
+    B, Cc, W = 2, 64, 48
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w, b = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    ref = F.avg_pool2d(F.silu(F.group_norm(x, 32, w, b, eps=1e-5)), (1, 2), (1, 2))
+    if H == 1:
+        assert torch.equal(ref[:, :, 0], F.avg_pool1d(F.silu(F.group_norm(x[:, :, 0], 32, w, b, eps=1e-5)), 2, 2))
+    bld = Builder(torch.device("cuda"))
+    y = bld.group_norm(Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cc, Cc, True), 32, weight=dev(w), bias=dev(b), act=1, pool=2)
+    assert (y.H, y.W) == (H, W // 2)
+    bld.tape.run()
+    assert max_err(from_nhwc(y.buf.reshape(B, H, W // 2, Cc), Cc), ref) < 2e-5
+
+
 @pytest.mark.parametrize("kind", [0, 1])
 @pytest.mark.parametrize("Cc", [5, 64, 768, 1000])
 def test_rownorm_mod(az, kind, Cc):

@@ -225,11 +225,16 @@ def test_g13_other_spatial_dimensions(golden):
         assert max_err(nets.vit_forward(sd, g.meta[name + "_cfg"], g[name + "_x"], mod), g[name + "_y"]) < 1e-5
 
 
-def test_g14_adm_offcard(golden):
-    """guided-diffusion's default wiring (h + emb, Downsample / Upsample layers with and without conv_resample): the
-    oracle against the reference's outputs (oracle/make_golden.py --only-g14)."""
-    for name in ("adm_plain_conv", "adm_plain_pool", "adm_film_noupdown"):
-        g = golden("g14_" + name)
+ADM_FIXTURES = [("g14_" + n) for n in ("adm_plain_conv", "adm_plain_pool", "adm_film_noupdown")] + [
+    ("g22_" + n) for n in ("adm_1d_film_updown", "adm_1d_plain_conv", "adm_1d_plain_pool")
+]
+
+
+def test_g14_g22_adm_offcard_and_1d(golden):
+    """guided-diffusion's default wiring (h + emb, Downsample / Upsample layers with and without conv_resample; G14) and
+    ``dims=1`` signals (G22): the oracle against the reference's outputs (oracle/make_golden.py --only-g14 / --only-g22)."""
+    for fixture in ADM_FIXTURES:
+        g = golden(fixture)
         cfg = g.meta["cfg"]
         sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"])
         y = g["y"] if "y" in g else None
