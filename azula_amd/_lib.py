@@ -281,6 +281,7 @@ PROTOTYPES: dict[str, list] = {
     "az_calib_write_f32": [vp, i64, f32, c_stream],
     "az_calib_mfma_f32": [vp, i32, i32, f32, f32, c_stream],
     "az_calib_mfma_random_f32": [vp, i32, i32, f32, f32, c_stream],
+    "az_calib_mfma_random_bf16": [vp, i32, i32, f32, f32, c_stream],
 }
 
 _lock = threading.Lock()

@@ -222,8 +222,8 @@ KERNEL_OF = {  # C-ABI entry point -> the __global__ kernel it launches (names a
 }
 
 
-def sustained_mfma_tflops(device, random_operands=False):
-    r"""The fp32 MFMA rate the matrix pipe sustains ALONE (registers only, 2 waves per SIMD), median of 5 launches of ~1.5 ms:
+def sustained_mfma_tflops(device, random_operands=False, bf16=False):
+    r"""The fp32 (``bf16``: bf16, random operands) MFMA rate the matrix pipe sustains ALONE (registers only, 2 waves per SIMD), median of 5 launches of ~1.5 ms:
     `az_calib_mfma_f32` on constant operands (nothing toggles: ~690 W, the clock stays at 2.4 GHz) or `az_calib_mfma_random_f32`
     on per-lane pseudo-random operands (the bit activity of a real GEMM: the 1400 W cap then sets the clock).  Context for
     `roofline.frac`, which stays relative to the guide's nominal 157.3 TF/s."""
@@ -232,8 +232,11 @@ def sustained_mfma_tflops(device, random_operands=False):
     sink = torch.zeros(4, device=device)
     stream = torch.cuda.current_stream(device)
     wgs, iters = 256 * 2, 3000   # two workgroups per CU = 2 waves per SIMD, ~1.3 ms
-    flops = wgs * 4 * iters * 8 * 4096
-    entry = "az_calib_mfma_random_f32" if random_operands else "az_calib_mfma_f32"
+    flops = wgs * 4 * iters * 8 * (32768 if bf16 else 4096)  # (32 x 32 x 16 x 2 vs 32 x 32 x 2 x 2 per instruction)
+    if bf16:
+        iters, random_operands = iters * 2, True  # (a bf16 MFMA takes half the cycles of the fp32 one: same launch length)
+        flops *= 2
+    entry = "az_calib_mfma_random_bf16" if bf16 else "az_calib_mfma_random_f32" if random_operands else "az_calib_mfma_f32"
     times = []
     for rep in range(7):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -720,6 +723,16 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
                                   "multiplies constants (no bit activity, ~690 W: the pipe holds the nominal peak), "
                                   "az_calib_mfma_random_f32 per-lane random operands (the activity of real data: the 1400 W cap sets the "
                                   "clock -- tools/power_probe.py, profiles/r04_power_probe.txt); `frac` stays relative to the nominal peak")
+    if not args.half and "az_conv2d_x3_f32" in kernels:
+        # the bf16x3 family: what the 1400 W cap leaves v_mfma_f32_32x32x16_bf16 on random operands, registers only (az_calib_mfma_random_bf16,
+        # 2 waves per SIMD); the family's `frac` stays on the nominal 2516.8 TF/s
+        sus16 = sustained_mfma_tflops(device, bf16=True)
+        x3k = kernels["az_conv2d_x3_f32"]
+        x3k["sustained_bf16_mfma_tflops_random_operands"] = round(sus16, 1)
+        x3k["frac_of_sustained_random_operands"] = round(x3k["executed_mfma_tflops"] / sus16, 4)
+        if dom is x3k:
+            roof["sustained_bf16_mfma_tflops_random_operands"] = x3k["sustained_bf16_mfma_tflops_random_operands"]
+            roof["frac_of_sustained_random_operands"] = x3k["frac_of_sustained_random_operands"]
     mf = "bf16 v_mfma_f32_32x32x16_bf16, 6 partial products per fp32 product" if dom["entry"] == "az_conv2d_x3_f32" else "fp32 v_mfma_f32_32x32x2_f32"
     roof["kernel"] = f"{dom['kernel']} ({mf}), all {dom['launches']} launches of one denoise step"
     roof["note"] = ("achieved = ALGORITHMIC FLOP (2*pixels*Cout*Cin*k^2; attention 4*B*H*T^2*d) of the kernel's launches in one "

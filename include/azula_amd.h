@@ -499,6 +499,9 @@ int az_calib_mfma_f32(float* sink, int32_t workgroups, int32_t iters, float a, f
  * MI355X); on random bit patterns the matrix pipe alone draws what a real GEMM's does, and the 1400 W cap -- not the 2.4 GHz
  * clock -- sets the rate (tools/power_probe.py).  bench.py reports both as the context of `roofline.frac`. */
 int az_calib_mfma_random_f32(float* sink, int32_t workgroups, int32_t iters, float a, float b, az_stream_t stream);
+/* The bf16 pipe: 8 independent v_mfma_f32_32x32x16_bf16 per iteration (32768 FLOP each) on per-lane random bf16 operands:
+ * the rate the power cap leaves the instruction of the bf16x3 kernels (nominal 2516.8 TF/s). */
+int az_calib_mfma_random_bf16(float* sink, int32_t workgroups, int32_t iters, float a, float b, az_stream_t stream);
 
 #ifdef __cplusplus
 }

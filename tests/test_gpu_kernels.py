@@ -1077,4 +1077,11 @@ def test_calibration_kernels(az):
     tf = wgs * 4 * iters * 8 * 4096 / (e0.elapsed_time(e1) * 1e-3) / 1e12
     print(f"az_calib_mfma_random_f32: {tf:.1f} TF/s")
     assert 20.0 < tf < 170.0
+    e0.record()
+    az.call("az_calib_mfma_random_bf16", sink.data_ptr(), wgs, 2 * iters, 1.0, 0.5, az.stream_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    tf = wgs * 4 * 2 * iters * 8 * 32768 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    print(f"az_calib_mfma_random_bf16: {tf:.1f} TF/s")
+    assert 300.0 < tf < 2700.0  # (nominal 2516.8; ~1700 - 1800 under the 1400 W cap)
 

@@ -34,4 +34,17 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
+if len(bld.tape.ops) > 1:  # per-op times (e.g. the split pass of AZ_X3_PLANES=1, split-K combine is inside its entry)
+    import ctypes
+    from azula_amd import _lib
+    st = torch.cuda.current_stream().cuda_stream
+    per = []
+    for fn, args, name in bld.tape.ops:
+        e0.record()
+        for _ in range(reps):
+            fn(*args, st)
+        e1.record()
+        torch.cuda.synchronize()
+        per.append(f"{name} {e0.elapsed_time(e1) / reps * 1e3:.1f} us")
+    print("   ", "; ".join(per))
 print(f"conv[{desc._algo[10:-4]}] {B}x{H}x{W} {Cin}->{Cout} k{ks} s{stride} splitk={desc.splitk}: {ms * 1e3:.1f} us  {desc._flops / ms / 1e9:.1f} TF/s")

@@ -76,7 +76,20 @@ print(f"    -> {512 * 4 * 3000 * 8 * 4096 / ms / 1e9:.1f} TF/s")
 ms = sample_while(lambda: _lib.call("az_calib_mfma_random_f32", sink.data_ptr(), 512, 3000, 1.0, 0.5, st), "calib: fp32 MFMA, random operands")
 print(f"    -> {512 * 4 * 3000 * 8 * 4096 / ms / 1e9:.1f} TF/s")
 
+ms = sample_while(lambda: _lib.call("az_calib_mfma_random_bf16", sink.data_ptr(), 512, 6000, 1.0, 0.5, st), "calib: bf16 MFMA, random operands")
+print(f"    -> {512 * 4 * 6000 * 8 * 32768 / ms / 1e9:.1f} TF/s (nominal 2516.8)")
+
 torch.manual_seed(0)
+# the bf16x3 GEMM on a token-linear shape (DiT-B MLP: 16384 tokens, 768 -> 3072)
+for (T, Cin, Cout) in ((16384, 768, 3072), (16384, 3072, 768)):
+    bld = Builder(dev)
+    x = Act(torch.randn(T * Cin, device=dev), 1, T, 1, Cin, Cin, True)
+    w = torch.randn(Cout, Cin, device=dev) / Cin ** 0.5
+    y = bld.conv(x, bld.pack_conv(w, torch.randn(Cout, device=dev)), Cout, winograd="x3")
+    bld.finish()
+    ms = sample_while(bld.tape.run, f"bf16x3 GEMM {T} x {Cin} -> {Cout}")
+    fl = 2 * T * Cin * Cout
+    print(f"    -> {fl / ms / 1e9:.1f} TF/s algorithmic, {fl * 6 / ms / 1e9 / 2516.8:.3f} of the bf16 MFMA peak executed")
 for (B, H, W, Cin, Cout) in ((4, 256, 256, 256, 256), (4, 64, 64, 512, 512)):
     for zero in (False, True):
         bld = Builder(dev)
