@@ -556,6 +556,327 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
   }
 }
 
+// =================================================================================================
+// fp32 attention on the bf16 matrix pipe ("bf16x3", the default mode of fp32 modules -- engine.FP32_MFMA): q, k, v and the
+// probabilities are split EXACTLY into three bf16 pieces each (az_split3) and every product of the two contractions is the six
+// largest of the nine partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the dropped terms are at the level
+// of one fp32 rounding of the product -- at 6 x 32 cycles per 16 values against 8 x 64 for v_mfma_f32_32x32x2_f32.
+// Layout and fragment maps are attention_half_kernel's with three planes per operand: K [piece][key][D + 8], V^T
+// [piece][d][key position] (keys permuted to the order the S^T registers hold them), q pieces and probability pieces in
+// registers; norms, gains, RoPE, the online softmax (scores in log2 units, hardware exp2) stay fp32 as in attention_kernel.
+template <int D>
+__global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
+  constexpr int DP = (D + 31) / 32 * 32;
+  constexpr int DT = DP / 32;
+  constexpr int KS = D / 16;        // K-steps of the QK^T contraction
+  constexpr int KLS = D + 8;        // K tile row stride (2-byte elements)
+  constexpr int VLS = KT + 8;       // V^T tile row stride
+  constexpr int KPL = KT * KLS, VPL = DP * VLS;  // elements per piece plane
+  __shared__ __attribute__((aligned(16))) unsigned short xsm[3 * (KPL + VPL)];
+  unsigned short* Ks = xsm;
+  unsigned short* Vt = xsm + 3 * KPL;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int h2 = lane >> 5;
+  const int ql = lane & 31;
+  const int bh = blockIdx.y;
+  const int b = bh / a.heads;
+  const int hd = bh - b * a.heads;
+  const int T = a.tokens;
+  const int qi = blockIdx.x * QT + wave * 32 + ql;
+
+  const float* qp = a.q + (int64_t)b * a.q_bstride + (int64_t)hd * a.q_hstride;
+  const float* kp = a.k + (int64_t)b * a.k_bstride + (int64_t)hd * a.k_hstride;
+  const float* vp = a.v + (int64_t)b * a.v_bstride + (int64_t)hd * a.v_hstride;
+  const uint8_t* mrow = (a.mask != nullptr && qi < T)
+                            ? a.mask + (int64_t)b * a.mask_bstride + (int64_t)hd * a.mask_hstride + (int64_t)qi * T
+                            : nullptr;
+
+  // cooperative K/V tile loader (attention_kernel's): thread -> (row = tid / CH + pass * rows per pass, 16-byte chunk)
+  constexpr int CH = D / 4;
+  constexpr bool POW2 = (CH & (CH - 1)) == 0;
+  constexpr int RW = 64 / CH;
+  constexpr int RPP = POW2 ? 256 / CH : 4 * RW;
+  const int lc = POW2 ? tid % CH : lane % CH;
+  const int lr = POW2 ? tid / CH : wave * RW + lane / CH;
+  const bool lactive = POW2 || lane < RW * CH;
+  constexpr int NPS = (KT + RPP - 1) / RPP;
+  constexpr bool VT4 = POW2 && CH <= 16;  // a wave holds >= 4 consecutive rows of a chunk: V^T goes out in 8-byte stores
+  float4 pk[NPS], pv[NPS];  // raw rows of the NEXT tile, in flight under the current tile's MFMAs
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int row = ps * RPP + lr;
+      const int key = k0 + row;
+      pk[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pv[ps] = pk[ps];
+      if (row < KT && lactive && key < T) {
+        pk[ps] = *reinterpret_cast<const float4*>(kp + (int64_t)key * a.k_tstride + lc * 4);
+        pv[ps] = *reinterpret_cast<const float4*>(vp + (int64_t)key * a.v_tstride + lc * 4);
+      }
+    }
+  };
+  fetch(0);
+
+  // zero V^T once: rows d >= D (padding of the last 32-wide output tile) are never written again
+  if (D < DP)
+    for (int e = tid; e < 3 * VPL / 2; e += 256) reinterpret_cast<unsigned*>(Vt)[e] = 0u;
+
+  // ---- Q fragments: lane holds q[qi][16 ks + 8 h2 + (0..7)], scaled to log2 units (and RMS-normalised, gained, rotated) in
+  // fp32, then split: qf[piece][ks]
+  abf16x8 qf[3][KS];
+  {
+    float qv[KS][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qi < T) v = *reinterpret_cast<const float4*>(qp + (int64_t)qi * a.q_tstride + 16 * ks + 8 * h2 + 4 * hh);
+        qv[ks][4 * hh + 0] = v.x;
+        qv[ks][4 * hh + 1] = v.y;
+        qv[ks][4 * hh + 2] = v.z;
+        qv[ks][4 * hh + 3] = v.w;
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    }
+    float f = a.scale * 1.4426950408889634f;  // (scores in log2 units: one v_exp_f32 per score, see attention_kernel)
+    if (a.qk_rmsnorm) {
+      ss += __shfl_xor(ss, 32, 64);
+      f *= rsqrtf(ss / (float)D + a.eps);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = 16 * ks + 8 * h2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        qv[ks][j] *= f;
+        if (a.q_weight != nullptr) qv[ks][j] *= a.q_weight[d0 + j];
+      }
+      if (a.rope_cos != nullptr && qi < T) {
+        const int64_t rb = (int64_t)qi * a.heads * (D / 2) + (int64_t)hd * (D / 2) + d0 / 2;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          const float c = a.rope_cos[rb + pr], sn = a.rope_sin[rb + pr];
+          const float re = qv[ks][2 * pr], im = qv[ks][2 * pr + 1];
+          qv[ks][2 * pr] = re * c - im * sn;
+          qv[ks][2 * pr + 1] = re * sn + im * c;
+        }
+      }
+      unsigned q3[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) az_split3(qv[ks][2 * j], qv[ks][2 * j + 1], q3[0][j], q3[1][j], q3[2][j]);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) qf[pl][ks] = __builtin_bit_cast(abf16x8, make_uint4(q3[pl][0], q3[pl][1], q3[pl][2], q3[pl][3]));
+    }
+  }
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // (A piece, B piece) of the six partial products, smallest first
+  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+
+  for (int k0 = 0; k0 < T; k0 += KT) {
+    __syncthreads();  // previous tile fully consumed (and, first time, the V^T zero fill is complete)
+#pragma unroll
+    for (int rr = 0; rr < KT; rr += RPP) {
+      const int row = rr + lr;
+      if (row < KT && lactive) {
+        const int key = k0 + row;
+        float4 kv = pk[rr / RPP], vv = pv[rr / RPP];
+        if (a.qk_rmsnorm) {
+          float ss = (kv.x * kv.x + kv.y * kv.y) + (kv.z * kv.z + kv.w * kv.w);
+          if constexpr (POW2) {
+#pragma unroll
+            for (int o = 1; o < CH; o <<= 1) ss += __shfl_xor(ss, o, 64);
+          } else {
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            const int base = (lane / CH) * CH;
+            float tot = 0.f;
+#pragma unroll
+            for (int j = 0; j < CH / 4; ++j) tot += __shfl(ss, base + 4 * j, 64);
+            ss = tot;
+          }
+          const float f = rsqrtf(ss / (float)D + a.eps);
+          kv.x *= f;
+          kv.y *= f;
+          kv.z *= f;
+          kv.w *= f;
+        }
+        if (a.k_weight != nullptr) {
+          const float4 w = *reinterpret_cast<const float4*>(a.k_weight + lc * 4);
+          kv.x *= w.x;
+          kv.y *= w.y;
+          kv.z *= w.z;
+          kv.w *= w.w;
+        }
+        if (a.rope_cos != nullptr && key < T) {
+          const int64_t ro = (int64_t)key * a.heads * (D / 2) + (int64_t)hd * (D / 2) + 2 * lc;
+          const float2 c = *reinterpret_cast<const float2*>(a.rope_cos + ro);
+          const float2 sn = *reinterpret_cast<const float2*>(a.rope_sin + ro);
+          const float r0 = kv.x, i0 = kv.y, r1 = kv.z, i1 = kv.w;
+          kv.x = r0 * c.x - i0 * sn.x;
+          kv.y = r0 * sn.x + i0 * c.x;
+          kv.z = r1 * c.y - i1 * sn.y;
+          kv.w = r1 * sn.y + i1 * c.y;
+        }
+        unsigned k3[3][2], v3[3][2];
+        az_split3(kv.x, kv.y, k3[0][0], k3[1][0], k3[2][0]);
+        az_split3(kv.z, kv.w, k3[0][1], k3[1][1], k3[2][1]);
+        az_split3(vv.x, vv.y, v3[0][0], v3[1][0], v3[2][0]);
+        az_split3(vv.z, vv.w, v3[0][1], v3[1][1], v3[2][1]);
+        // V^T, keys permuted inside their 32-key tile to the order the S^T registers hold them
+        const int kk = row & 31;
+        const int r = (kk & 3) + 4 * (kk >> 3);
+        const int pos = (row & ~31) + 16 * (r >> 3) + 8 * ((kk >> 2) & 1) + (r & 7);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          *reinterpret_cast<uint2*>(Ks + pl * KPL + row * KLS + lc * 4) = make_uint2(k3[pl][0], k3[pl][1]);
+#ifndef AZ_AX_NOVT  // (timing ablations, WRONG results: AZ_AX_*)
+          if constexpr (VT4) {
+            // 4 x 4 transpose among the four lanes that hold rows 4m .. 4m+3 of this chunk (lane ^ CH, lane ^ 2 CH): the lane of
+            // row 4m + j ends with channel lc*4 + j of the four keys, whose positions are contiguous -- one 8-byte store
+            // instead of four scattered 2-byte ones (measured 112 -> 94 us without the scattered stores, 64 x 12 heads x 256 tokens)
+            const bool b0 = (lr & 1) != 0, b1 = (lr & 2) != 0;
+            const unsigned w0 = v3[pl][0], w1 = v3[pl][1];           // (d1:d0), (d3:d2) of this lane's key
+            const unsigned got1 = __shfl_xor(b1 ? w0 : w1, 2 * CH, 64);
+            const unsigned A = b1 ? got1 : w0, B = b1 ? w1 : got1;   // channel pair b1 of keys b0 and 2 + b0
+            const unsigned lo = __builtin_amdgcn_perm(B, A, 0x05040100u), hi = __builtin_amdgcn_perm(B, A, 0x07060302u);  // (B.e : A.e)
+            const unsigned mine = b0 ? hi : lo;                      // element b0 of the pair: channel 2 b1 + b0
+            const unsigned got2 = __shfl_xor(b0 ? lo : hi, CH, 64);  // the partner's keys 1 - b0 and 3 - b0, same channel
+            const unsigned ha = b0 ? mine : got2, la = b0 ? got2 : mine;
+            const unsigned o0 = __builtin_amdgcn_perm(ha, la, 0x05040100u);  // (key 1 : key 0)
+            const unsigned o1 = __builtin_amdgcn_perm(ha, la, 0x07060302u);  // (key 3 : key 2)
+            const int kk4 = row & 28, m = kk4 >> 2;
+            const int pos4 = (row & ~31) + 16 * (m >> 2) + 8 * (m & 1) + 4 * ((m >> 1) & 1);
+            *reinterpret_cast<uint2*>(Vt + pl * VPL + (lc * 4 + (lr & 3)) * VLS + pos4) = make_uint2(o0, o1);
+          } else {
+            unsigned short* vt = Vt + pl * VPL + (lc * 4) * VLS + pos;
+            vt[0] = (unsigned short)(v3[pl][0] & 0xFFFFu);
+            vt[VLS] = (unsigned short)(v3[pl][0] >> 16);
+            vt[2 * VLS] = (unsigned short)(v3[pl][1] & 0xFFFFu);
+            vt[3 * VLS] = (unsigned short)(v3[pl][1] >> 16);
+          }
+#endif
+        }
+      }
+    }
+    __syncthreads();
+    if (k0 + KT < T) fetch(k0 + KT);
+
+#pragma unroll
+    for (int sub = 0; sub < KT / 32; ++sub) {
+      if (k0 + sub * 32 >= T) break;
+      // ---- S^T tile (32 keys x 32 queries): A = K pieces from LDS, B = the lane's q pieces
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      const unsigned short* kr = Ks + (sub * 32 + ql) * KLS + 8 * h2;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        abf16x8 kf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const abf16x8*>(kr + pl * KPL + 16 * ks);
+#pragma unroll
+#ifdef AZ_AX_ONEPROD
+        for (int t = 5; t < 6; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qf[PB[t]][ks], sacc, 0, 0, 0);
+#else
+        for (int t = 0; t < 6; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qf[PB[t]][ks], sacc, 0, 0, 0);
+#endif
+      }
+      if (k0 + sub * 32 + 32 > T) {  // ragged last tile (wave-uniform): keys past T
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + sub * 32 + key_of(r, h2) >= T) sacc[r] = -INFINITY;
+      }
+      if (mrow != nullptr) {  // boolean attention mask: one byte per (query, key)
+        unsigned char mb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + sub * 32 + key_of(r, h2);
+          mb[r] = key < T ? mrow[key] : (unsigned char)1;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = mb[r] == 0 ? -INFINITY : sacc[r];
+      }
+      float mt = sacc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sacc[r]);
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt);
+      const float m_sub = m_new == -INFINITY ? 0.f : m_new;  // (-inf only while every key so far is masked: all terms 2^-inf = 0)
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_sub);
+      float ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+#ifdef AZ_AX_NOEXP
+        const float pe = sacc[r] - m_sub;
+#else
+        const float pe = __builtin_amdgcn_exp2f(sacc[r] - m_sub);
+#endif
+        sacc[r] = pe;
+        ls += pe;
+      }
+      ls += __shfl_xor(ls, 32, 64);
+      l_run = l_run * alpha + ls;
+      m_run = m_new;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+      // ---- O^T += V^T P^T: B = the pieces of the lane's probabilities (registers 8 s2 .. 8 s2 + 7 = one fragment), A = V^T pieces
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        unsigned p3[3][4];
+#pragma unroll
+#ifdef AZ_AX_NOSPLITP
+        for (int j = 0; j < 4; ++j) p3[0][j] = p3[1][j] = p3[2][j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sacc[8 * s2 + 2 * j + 1]), __builtin_bit_cast(unsigned, sacc[8 * s2 + 2 * j]), 0x07060302u);
+#else
+        for (int j = 0; j < 4; ++j) az_split3(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1], p3[0][j], p3[1][j], p3[2][j]);
+#endif
+        abf16x8 pb[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) pb[pl] = __builtin_bit_cast(abf16x8, make_uint4(p3[pl][0], p3[pl][1], p3[pl][2], p3[pl][3]));
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          abf16x8 va[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            va[pl] = *reinterpret_cast<const abf16x8*>(Vt + pl * VPL + (ql + 32 * t) * VLS + sub * 32 + 16 * s2 + 8 * h2);
+#pragma unroll
+#ifdef AZ_AX_ONEPROD
+          for (int u = 5; u < 6; ++u) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[u]], pb[PB[u]], oacc[t], 0, 0, 0);
+#else
+          for (int u = 0; u < 6; ++u) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[u]], pb[PB[u]], oacc[t], 0, 0, 0);
+#endif
+        }
+      }
+    }
+  }
+
+  if (qi < T) {
+    const float inv = 1.f / l_run;
+    float* op = a.out + (int64_t)b * a.o_bstride + (int64_t)hd * a.o_hstride + (int64_t)qi * a.o_tstride;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * t + 8 * g + 4 * h2;
+        if (d < D)
+          *reinterpret_cast<float4*>(op + d) = make_float4(oacc[t][4 * g] * inv, oacc[t][4 * g + 1] * inv,
+                                                            oacc[t][4 * g + 2] * inv, oacc[t][4 * g + 3] * inv);
+      }
+  }
+}
+
 // NCHW (B, Z, H, W) -> tokens (B, L = H/p * W/p, cs) with feature index z*p*p + a*p + b
 // ('... Z (A a) (B b) -> ... A B (Z a b)', azula/nn/layers.py:198-222); optional scale.
 // IDX = unsigned when the element count fits 32 bits (always on the sampling path): the index decomposition is a chain
@@ -681,6 +1002,29 @@ extern "C" {
 
 int az_attention_bf16_f32(const AzAttnArgs* a, az_stream_t stream) { return attention_half_launch<false>(a, stream); }
 int az_attention_f16_f32(const AzAttnArgs* a, az_stream_t stream) { return attention_half_launch<true>(a, stream); }
+
+/* az_attention_f32 with both contractions evaluated as 3 x bf16 operand pieces / 6 partial products on the bf16 MFMA (fp32
+ * accumulation, fp32 softmax): fp32-level accuracy at 0.375 x the matrix-pipe time.  head_dim 16, 32, 64, 80 or 128.       */
+int az_attention_x3_f32(const AzAttnArgs* a, az_stream_t stream) {
+  AZ_REQUIRE(a && a->q && a->k && a->v && a->out, AZ_E_NULL);
+  AZ_REQUIRE(a->batch > 0 && a->heads > 0 && a->tokens > 0, AZ_E_SHAPE);
+  AZ_REQUIRE(a->head_dim == 16 || a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 80 || a->head_dim == 128,
+             AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(AZ_ALIGNED16(a->q) && AZ_ALIGNED16(a->k) && AZ_ALIGNED16(a->v) && AZ_ALIGNED16(a->out), AZ_E_ALIGN);
+  const int64_t strides[] = {a->q_bstride, a->q_tstride, a->q_hstride, a->k_bstride, a->k_tstride, a->k_hstride,
+                             a->v_bstride, a->v_tstride, a->v_hstride, a->o_bstride, a->o_tstride, a->o_hstride};
+  for (int64_t s : strides) AZ_REQUIRE(s % 4 == 0, AZ_E_ALIGN);
+  dim3 grid((unsigned)((a->tokens + QT - 1) / QT), (unsigned)(a->batch * a->heads));
+  hipStream_t st = az_s(stream);
+  switch (a->head_dim) {
+    case 16: hipLaunchKernelGGL(attention_x3_kernel<16>, grid, dim3(256), 0, st, *a); break;
+    case 32: hipLaunchKernelGGL(attention_x3_kernel<32>, grid, dim3(256), 0, st, *a); break;
+    case 64: hipLaunchKernelGGL(attention_x3_kernel<64>, grid, dim3(256), 0, st, *a); break;
+    case 80: hipLaunchKernelGGL(attention_x3_kernel<80>, grid, dim3(256), 0, st, *a); break;
+    default: hipLaunchKernelGGL(attention_x3_kernel<128>, grid, dim3(256), 0, st, *a); break;
+  }
+  return az_launch_status();
+}
 
 int az_attention_f32(const AzAttnArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->q && a->k && a->v && a->out, AZ_E_NULL);

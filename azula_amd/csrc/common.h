@@ -52,6 +52,21 @@ __device__ __forceinline__ float az_wave_max(float v) {
   return v;
 }
 
+// x = x1 + x2 + x3 EXACTLY, each piece a bf16 (three 8-bit slices of the 24-bit significand, by truncation): the operand form of
+// the "bf16x3" kernels, which evaluate a product as the six largest of the nine partial products on v_mfma_f32_32x32x16_bf16
+// with fp32 accumulation (conv.hip, attention.hip).  Two values per call; p1 / p2 / p3 = the packed (x1, x0) pairs of the pieces.
+__device__ __forceinline__ void az_split3(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+  const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+  const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);  // exact: the low 16 significand bits
+  const float r1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+  const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+  const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u);
+  const float s1 = r1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
+  p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // high halves of (x1, x0) = truncated bf16 pair
+  p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  p3 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+}
+
 // Memory-bound launches: cap the grid at 256 CUs x 8 blocks and grid-stride the rest.
 static inline int az_stream_grid(int64_t work_items, int block) {
   int64_t g = (work_items + block - 1) / block;

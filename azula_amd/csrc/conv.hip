@@ -1029,15 +1029,7 @@ constexpr int X_LDS_BYTES = (BN * OSTR + BN) * 4;  // the epilogue's exchange bu
 static_assert(6 * XPLANE * 2 <= X_LDS_BYTES, "stage planes must fit under the epilogue buffer");
 
 __device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
-  const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
-  const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);  // exact: the low 16 significand bits
-  const float r1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
-  const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
-  const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u);
-  const float s1 = r1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
-  p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // high halves of (x1, x0) = truncated bf16 pair
-  p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-  p3 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+  az_split3(x0, x1, p1, p2, p3);  // (common.h: shared with the attention kernel)
 }
 
 __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {

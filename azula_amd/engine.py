@@ -137,6 +137,7 @@ WINOGRAD = os.environ.get("AZ_WINOGRAD", "1")
 # "native": v_mfma_f32_32x32x2_f32 everywhere.  The stride-1 3 x 3 convolutions stay on the fp32 Winograd kernel in both modes.
 FP32_MFMA = os.environ.get("AZ_FP32_MFMA", "bf16x3")
 assert FP32_MFMA in ("native", "bf16x3"), FP32_MFMA
+ATTN_X3 = os.environ.get("AZ_ATTN_X3", "1") != "0"  # bf16x3 mode: attention contractions on the bf16 pipe too (az_attention_x3_f32)
 X3_MIN_CHANNELS = 32  # bf16x3 only where both channel counts fill a K tile / an MFMA tile
 WINOGRAD4_MIN_TILES = int(os.environ.get("AZ_WINOGRAD4_MIN_TILES", "1024"))
 # q / k RMS norm, gains and RoPE of an attention layer in the epilogue of its qkv projection ("0": inside the attention kernel)
@@ -707,6 +708,10 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
         self.tape.keep.append(m8)
     a._flops = 4 * qkv.B * heads * L * L * dim
     name = "az_attention_f32"
+    if self.half is None and FP32_MFMA == "bf16x3" and ATTN_X3 and dim in (16, 32, 64, 80):
+        # the two contractions as 3 x bf16 pieces / 6 partial products: fp32 accuracy, 0.375 x the pipe time (64 x 12 heads x 256
+        # tokens x 64: 140 -> 111 us; head_dim 128 needs one wave per SIMD there and measured slower, 458 vs 516 us: fp32 kernel)
+        name = "az_attention_x3_f32"
     if self.half is not None:  # module cast to half precision: contractions on the bf16 / f16 MFMA
         name = "az_attention_f16_f32" if self.half == torch.float16 else "az_attention_bf16_f32"
     self.tape.add(name, C.byref(a), keep=[a])

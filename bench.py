@@ -130,7 +130,7 @@ def build_denoiser(cfg, device):
 
 CONV_OPS = ("az_conv2d_f32", "az_conv2d_winograd_f32", "az_conv2d_winograd4_f32", "az_conv2d_bf16_f32", "az_conv2d_f16_f32",
             "az_conv2d_x3_f32")
-ATTN_OPS = ("az_attention_f32", "az_attention_bf16_f32", "az_attention_f16_f32")
+ATTN_OPS = ("az_attention_f32", "az_attention_x3_f32", "az_attention_bf16_f32", "az_attention_f16_f32")
 
 
 def sampler_kwargs(cfg, device):
@@ -216,7 +216,7 @@ def tape_profile(sampler, device):
 
 
 KERNEL_OF = {  # C-ABI entry point -> the __global__ kernel it launches (names as rocprofv3 prints them)
-    "az_conv2d_winograd_f32": "conv_winograd_kernel", "az_conv2d_f32": "conv_igemm_kernel", "az_attention_f32": "attention_kernel",
+    "az_conv2d_winograd_f32": "conv_winograd_kernel", "az_conv2d_f32": "conv_igemm_kernel", "az_attention_f32": "attention_kernel", "az_attention_x3_f32": "attention_x3_kernel",
     "az_conv2d_stem_f32": "conv_stem_kernel", "az_conv2d_bf16_f32": "conv_igemm_half_kernel", "az_conv2d_f16_f32": "conv_igemm_half_kernel", "az_conv2d_x3_f32": "conv_igemm_x3_kernel",
     "az_conv2d_winograd4_f32": "conv_winograd4_kernel",
 }
@@ -664,7 +664,7 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
         if not f["flops"]:
             continue
         wino = fam == "az_conv2d_winograd_f32"
-        x3 = fam == "az_conv2d_x3_f32"
+        x3 = fam in ("az_conv2d_x3_f32", "az_attention_x3_f32")  # 3 x bf16 operand pieces, 6 partial products per fp32 product
         peak = PEAK_BF16_TFLOPS / X3_PRODUCTS if x3 else PEAK_FP32_TFLOPS * (WINOGRAD_GAIN if wino else 1.0)
         f = dict(f, ms_event_pairs=f["ms"], ms=b2b[fam])  # the family's launches back to back inside one event pair
         tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
@@ -712,7 +712,7 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
     dom["ms_per_denoise_step_from_graph_step"] = round(dom_ms_graph, 3)
     roof = dict(dom)
     roof["graph_ms_per_denoise_step"] = round(graph_step_ms, 3)
-    if not args.half and dom["kernel"] != "attention_kernel" and dom["entry"] != "az_conv2d_x3_f32":
+    if not args.half and dom["kernel"] not in ("attention_kernel", "attention_x3_kernel") and dom["entry"] != "az_conv2d_x3_f32":
         sus = sustained_mfma_tflops(device)
         sus_rnd = sustained_mfma_tflops(device, random_operands=True)
         roof["sustained_mfma_tflops"] = round(sus, 1)

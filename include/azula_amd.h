@@ -405,6 +405,11 @@ typedef struct AzAttnArgs {
 int az_attention_f32(const AzAttnArgs* args, az_stream_t stream);
 /* The same operation for backbones cast to half precision: q / k / v / out stay fp32 tensors, norms, gains, RoPE and the
  * online softmax stay fp32, both contractions run on v_mfma_f32_32x32x16_{bf16,f16} (fp32 accumulate); exp via exp2. */
+/* az_attention_f32's arithmetic on the bf16 matrix pipe at fp32 accuracy: q, k, v and the probabilities are split exactly into
+ * three bf16 pieces and each product is six partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (softmax, norms,
+ * RoPE in fp32); the attention of fp32 modules when AZ_FP32_MFMA = bf16x3 (the default).  head_dim 16, 32, 64, 80, 128.
+ * Replaces the same reference lines as az_attention_f32. */
+int az_attention_x3_f32(const AzAttnArgs* args, az_stream_t stream);
 int az_attention_bf16_f32(const AzAttnArgs* args, az_stream_t stream);
 int az_attention_f16_f32(const AzAttnArgs* args, az_stream_t stream);
 

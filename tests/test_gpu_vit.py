@@ -16,8 +16,15 @@ torch.set_grad_enabled(False)
 
 @pytest.mark.parametrize("B,H,T,D", [(2, 4, 16, 16), (1, 2, 64, 32), (2, 3, 256, 64), (1, 2, 100, 64), (1, 1, 1024, 64), (1, 2, 40, 128)])
 @pytest.mark.parametrize("order,rms", [("nHC", True), ("nHC", False), ("H3C", False), ("3HC", False)])
-def test_attention_kernel(B, H, T, D, order, rms):
+@pytest.mark.parametrize("x3", [True, False])
+def test_attention_kernel(monkeypatch, B, H, T, D, order, rms, x3):
+    """az_attention_x3_f32 (the contractions as 3 x bf16 pieces / 6 partial products on the bf16 MFMA: the default of fp32
+    modules) and az_attention_f32 (fp32 MFMA), both against torch's SDPA at the same bound."""
+    from azula_amd import engine
     from azula_amd.engine import Act, Builder
+
+    monkeypatch.setattr(engine, "ATTN_X3", x3)
+    monkeypatch.setattr(engine, "FP32_MFMA", "bf16x3")
 
     g = torch.Generator().manual_seed(B * T + D)
     q, k, v = (torch.randn(B, H, T, D, generator=g) for _ in range(3))
@@ -31,6 +38,12 @@ def test_attention_kernel(B, H, T, D, order, rms):
     bld = Builder(torch.device("cuda"))
     act = Act(qkv.cuda().contiguous().reshape(-1), B, T, 1, 3 * H * D, 3 * H * D, True)
     out = bld.attention(act, H, order, rms, 1.0 / math.sqrt(D))
+    assert [n for _, _, n in bld.tape.ops] == ["az_attention_x3_f32" if x3 and D <= 80 else "az_attention_f32"]
+    if x3 and D > 80:  # the engine keeps head_dim 128 on the fp32 kernel (faster there); the entry point itself takes it
+        from azula_amd import _lib
+
+        _, args, _ = bld.tape.ops[0]
+        bld.tape.ops[0] = (_lib.lib().az_attention_x3_f32, args, "az_attention_x3_f32")
     bld.tape.run()
     got = out.buf.reshape(B, T, H * D)
     assert max_err(got, ref) < 2e-5, max_err(got, ref)
