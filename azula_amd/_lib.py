@@ -255,6 +255,7 @@ PROTOTYPES: dict[str, list] = {
     "az_pack_conv_weight_half_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, c_stream],
     "az_pack_conv_weight_x3_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, c_stream],
     "az_conv2d_suggest_splitk": [i64, i32, i32, i32],
+    "az_conv2d_x3_suggest_splitk": [C.POINTER(AzConvArgs)],
     "az_conv2d_winograd_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_winograd_suggest_splitk": [i64, i32, i32, i32, i32],
     "az_winograd_pack_filter_f32": [vp, vp, i32, i32, i32, i32, i32, i32, c_stream],

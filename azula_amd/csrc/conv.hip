@@ -56,6 +56,7 @@ struct ConvP {
   int tiles_m;  // ceil(cout_s / BM)
   int tiles_n;  // ceil(npix / BN)
   int asm_loop; // fp32 K-32 kernel: one tap, whole K tiles -> the hand-scheduled K loop (igemm_kloop.inc)
+  int m_tile0;  // bf16x3 kernel: first output-channel tile of this launch (the 256 x 256 kernel took the tiles before it)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -1048,7 +1049,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
   const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
   const int tile_n = wg / p.tiles_m;
   const int tile_m = wg - tile_n * p.tiles_m;
-  const int m0 = tile_m * BM;
+  const int m0 = (p.m_tile0 + tile_m) * BM;
   const int n0 = tile_n * BN;
   const int kt_begin = blockIdx.y * p.kps;
   const int kt_end = min(p.nk, kt_begin + p.kps);
@@ -1232,6 +1233,183 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
     __syncthreads();
   }
   store_acc_tiles(p, acc, m0, n0, wc, wp, lane, xsmf);
+}
+
+// =================================================================================================
+// bf16x3 token GEMM / 1x1 convolution on a 256 x 256 tile (conv_gemm_x3_big_kernel).  The 128 x 128 kernel above is power-bound
+// with about half of its energy outside the matrix pipe (profiles/r04_x3_gemm_ablation.txt): per MFMA it moves 0.5 fragment
+// reads, and per 128 x 128 x 16 unit 20 KB of operand fill, 24 KB of LDS stores and one activation split.  Here 8 waves share
+// one 256-cout x 256-pixel tile (wave = 128 couts x 64 pixels = 4 x 2 accumulators): 0.375 fragment reads per MFMA, and per
+// unit 10 KB of fill, 12 KB of LDS stores, half a split; K step = 16 channels, two LDS stages of
+// [operand][piece][256 rows][32 B] (96 KB), ONE barrier per 48 MFMAs, the next step's operands split and stored into the other
+// stage under the MFMAs, the one after that in flight from L2.  Rows are 32 bytes; the two 16-byte chunks of a row are
+// swapped in rows with bit 3 set (ds_read_b128 lane groups {0-3, 12-15, 20-27}, ... then cover all 64 banks).
+// One workgroup of 512 threads per CU.  1 x 1, stride 1, one source, c0s % 16 == 0, NHWC destination.
+constexpr int GB = 256;                      // tile edge (couts and pixels)
+constexpr int GBK = 16;                      // K step
+constexpr int GPLANE = GB * GBK * 2;         // bytes per (operand, piece) plane of a stage: 8 KB
+constexpr int GSTAGE = 6 * GPLANE;           // 48 KB
+constexpr int GOSTR = 128 + 4;               // floats per pixel row of the epilogue's exchange buffer (one 128-cout pass)
+constexpr int G_LDS_BYTES = (GB * GOSTR + GB) * 4;  // 136,192 B >= 2 stages (98,304 B)
+static_assert(2 * GSTAGE <= G_LDS_BYTES, "stages must fit under the epilogue buffer");
+
+__global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
+  __shared__ __attribute__((aligned(16))) float gsmf[G_LDS_BYTES / 4];
+  char* const smem = reinterpret_cast<char*>(gsmf);
+  const AzConvArgs& a = p.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wc = wid >> 2;  // cout half (128)
+  const int wp = wid & 3;   // pixel quarter (64)
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  const int tile_n = wg / p.tiles_m;
+  const int tile_m = wg - tile_n * p.tiles_m;
+  const int m0 = tile_m * GB;
+  const int n0 = tile_n * GB;
+  const int kt_begin = blockIdx.y * p.kps;
+  const int kt_end = min(p.nk, kt_begin + p.kps);
+  const int nk = kt_end - kt_begin;
+
+  const int64_t wplane = (int64_t)a.cout_s * p.cin_s;  // elements per weight piece
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, (unsigned)(3 * wplane * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (unsigned)((int64_t)p.npix * a.c0s * 4), 0x00020000);
+
+  // loaders: thread -> row tid >> 1 of both operands; weights: chunk tid & 1 (8 k-values) of each piece, activations: the 8
+  // fp32 channels of that chunk (two adjacent lanes read one 64-byte unit)
+  const int lrow = tid >> 1, lch = tid & 1;
+  const int co_l = min(m0 + lrow, a.cout_s - 1);  // (rows past the edge: a valid duplicate, never stored)
+  const int px_l = min(n0 + lrow, p.npix - 1);
+  const unsigned voffW = (unsigned)(((int64_t)co_l * p.cin_s + lch * 8) * 2);
+  const unsigned voffX = (unsigned)(((int64_t)px_l * a.c0s + lch * 8) * 4);
+  const int lds_row = lrow * 32 + ((lch ^ ((lrow >> 3) & 1)) * 16);  // byte offset inside a plane
+
+  float4 rwt[3], rxa[2];
+  auto load_step = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) rwt[pl] = buf_ld4(rw, voffW, (unsigned)((pl * wplane + (int64_t)kt * GBK) * 2));
+    rxa[0] = buf_ld4(rx, voffX, (unsigned)(kt * GBK * 4));
+    rxa[1] = buf_ld4(rx, voffX + 16u, (unsigned)(kt * GBK * 4));
+  };
+  auto store_step = [&](int buf) __attribute__((always_inline)) {
+    char* st = smem + buf * GSTAGE + lds_row;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<float4*>(st + pl * GPLANE) = rwt[pl];
+    const float x[8] = {rxa[0].x, rxa[0].y, rxa[0].z, rxa[0].w, rxa[1].x, rxa[1].y, rxa[1].z, rxa[1].w};
+    unsigned q[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      *reinterpret_cast<uint4*>(st + (3 + pl) * GPLANE) = make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: row (lane & 31) of a 32-row MFMA tile, chunk lane >> 5 (swapped in rows with bit 3 set)
+  const int frow = lane & 31;
+  const int foff = frow * 32 + (((lane >> 5) ^ ((frow >> 3) & 1)) * 16);
+  const char* As = smem + (wc * 128) * 32 + foff;               // + buf * GSTAGE + piece * GPLANE + tile * 1024
+  const char* Bs = smem + 3 * GPLANE + (wp * 64) * 32 + foff;
+
+  if (nk > 0) {
+    load_step(kt_begin);
+    store_step(0);
+    load_step(min(kt_begin + 1, kt_end - 1));
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int i = 0; i < nk; ++i) {
+    const int buf = i & 1;
+    bf16x8 fa[3][4], fb[3][2];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fa[pl][t] = *reinterpret_cast<const bf16x8*>(As + buf * GSTAGE + pl * GPLANE + t * 1024);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fb[pl][t] = *reinterpret_cast<const bf16x8*>(Bs + buf * GSTAGE + pl * GPLANE + t * 1024);
+    }
+    // (unconditional, so that the iteration is ONE basic block the scheduler can interleave: the last two iterations restage
+    // the final step into a stage nobody reads)
+    store_step(buf ^ 1);                               // step i + 1 (in registers since the previous iteration) -> the other stage
+    load_step(min(kt_begin + i + 2, kt_end - 1));      // in flight under the MFMAs below and the next iteration's first ones
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest partial products first
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int pj = 0; pj < 2; ++pj)
+          acc[ci][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][ci], fb[PB[t]][pj], acc[ci][pj], 0, 0, 0);
+#ifndef AZ_X3_BIG_NOSCHED
+    // Issue order: the 18 fragment reads, then the staging of the next step (44 split instructions, 6 LDS stores, 5 loads) spread
+    // under the 48 MFMAs -- the matrix pipe takes 32 cycles per instruction, ~5 other issues fit in each gap -- instead of in
+    // front of them (the compiler's own order: the pipe idles while both waves of a SIMD stage).
+    __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);  // DS reads
+#pragma unroll
+    for (int k = 0; k < 48; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
+      if (k < 40) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two vector instructions
+      if (k >= 8 && k < 40 && (k & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS store
+      if (k >= 40 && k < 45) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                 // a buffer load
+    }
+    // (measured alternatives: the staging ten MFMAs later 388 vs 371 us, one vector instruction per gap all along 380, on 16384 x 768 -> 3072)
+#endif
+    __syncthreads();  // every wave has read stage `buf`; the other stage is complete
+  }
+
+  // ---- epilogue: two passes of 128 couts through the exchange buffer [pixel][128 + 4] (the layout of store_acc_tiles)
+  int* pimg = reinterpret_cast<int*>(gsmf + GB * GOSTR);  // image index of each pixel of the tile (-1: past the end)
+  if (tid < GB) {
+    const int n = n0 + tid;
+    pimg[tid] = n < p.npix ? n / (a.hout * a.wout) : -1;
+  }
+#pragma unroll 1
+  for (int cb = 0; cb < 2; ++cb) {
+    if (wc == cb) {
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        float* orow = gsmf + (wp * 64 + pt * 32 + (lane & 31)) * GOSTR + 4 * (lane >> 5);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(orow + ct * 32 + 8 * q) =
+                make_float4(acc[ct][pt][4 * q + 0], acc[ct][pt][4 * q + 1], acc[ct][pt][4 * q + 2], acc[ct][pt][4 * q + 3]);
+      }
+    }
+    __syncthreads();
+    const int cq = tid & 31;  // the same channel quad in every iteration
+    const int co = m0 + cb * 128 + cq * 4;
+    if (co < a.cout_s) {
+      constexpr int NIT = GB * 32 / 512, NB = 4;  // (8 per batch spills here: the other cout half's 64 accumulator registers are live)
+#pragma unroll 1
+      for (int it0 = 0; it0 < NIT; it0 += NB) {
+        int n[NB], b[NB];
+        float4 v[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int px = ((it0 + i) * 512 + tid) >> 5;
+          b[i] = pimg[px];
+          n[i] = b[i] >= 0 ? n0 + px : -1;
+          v[i] = *reinterpret_cast<const float4*>(gsmf + px * GOSTR + cq * 4);
+        }
+        epilogue_store_batch<NB>(a, n, b, co, v, (int64_t)blockIdx.y * p.npix);
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // =================================================================================================
@@ -2413,8 +2591,45 @@ __global__ __launch_bounds__(512, 2) void conv_winograd4_kernel(Wino4P p) {
 
 }  // namespace
 
+// bf16x3 token GEMMs / 1x1 convolutions: how many 256-cout tiles go to the 256 x 256 kernel (conv_gemm_x3_big_kernel; the rest of
+// the output channels, if any, to the 128 x 128 kernel in a second launch) and which split-K keeps its ONE workgroup per CU in
+// whole rounds.  Measured on 16384 tokens (tools/x3_probe.sh): 768 -> 3072 (768 big tiles = 3 rounds) 389 vs 455 us, 768 -> 768
+// (192 tiles, 0.75 of a round) 117 vs 125, 768 -> 2304 (576 tiles = 2.25 rounds) a tie -- hence 8 of its 9 cout tiles big: 311 vs 338;
+// 3072 -> 768 387 vs 444 (and no split-K combine).
+// AZ_X3_BIG = 0 / 1: never / every eligible launch whole (A/B measurements; read per call).
+static bool x3_big_eligible(const AzConvArgs* a, int64_t npix) {
+  return a->ksize == 1 && a->stride == 1 && a->pad == 0 && !a->src1 && a->up0 == 0 && !a->aniso && a->depth == 0 && !a->dst_nchw &&
+         a->h0 == a->hin && a->w0 == a->win && a->c0s % GBK == 0 && a->c0s >= 64 && npix * a->c0s * 4 < (1ll << 31);
+}
+static double x3_round_eff(int64_t wgs) { return (double)wgs / (double)(((wgs + 255) / 256) * 256); }
+// -> number of 256-cout tiles for the big kernel (0: none); *splitk = the split-K it wants (1 unless the K loop is deep)
+static int x3_big_plan(const AzConvArgs* a, int64_t npix, int* splitk) {
+  *splitk = 1;
+  if (!x3_big_eligible(a, npix)) return 0;
+  const char* force = getenv("AZ_X3_BIG");
+  const int all = (a->cout_s + GB - 1) / GB;
+  if (force && force[0]) return force[0] == '1' ? all : 0;
+  const int64_t tn = (npix + GB - 1) / GB;
+  if (all * tn < 176 || a->cout_s < 192) return 0;  // (128 tiles = half a round: 74 vs 62 us on 16384 x 512 -> 512; 192 tiles win)
+  if (x3_round_eff(all * tn) >= 0.85) return all;
+  // (no split-K, however deep the K loop: 16384 x 3072 -> 768 as 192 unsplit tiles 387 us, split 4 ways into whole rounds 444)
+  for (int nb = a->cout_s / GB; nb >= 2; --nb)  // whole rounds of big tiles, the remaining output channels on the 128 x 128 kernel
+    if (x3_round_eff(nb * tn) >= 0.95 && 2 * nb >= all) return nb;
+  return all;  // (a partial round still beats the small tile: 192 tiles 117 vs 125 us)
+}
+
 extern "C" {
 
+int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_t ksize);
+/* Split-K of az_conv2d_x3_f32 for a filled descriptor (everything but splitk / workspace): the 256 x 256 kernel's own choice where
+ * it takes the launch (x3_big_plan), az_conv2d_suggest_splitk's otherwise. */
+int az_conv2d_x3_suggest_splitk(const AzConvArgs* a) {
+  if (!a) return 1;
+  const int64_t npix = (int64_t)a->batch * a->hout * a->wout;
+  int sk = 1;
+  if (x3_big_plan(a, npix, &sk) > 0) return sk;
+  return az_conv2d_suggest_splitk(npix, a->cout_s, a->c0s + a->c1s, a->ksize);
+}
 int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_t ksize) {
   const int64_t tiles = ((npix + BN - 1) / BN) * ((cout_s + BM - 1) / BM);
   const int64_t nk = (int64_t)ksize * ksize * ((cin_s + BK - 1) / BK);  // (two-source convs: within +1 per tap)
@@ -2590,7 +2805,10 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   } else {
     p.asm_loop = 0;
   }
-  const int bk = half == 3 ? XBK : (half ? HBK : (k16 ? 16 : BK));
+  int big_sk = 1;
+  const int nbig = half == 3 ? x3_big_plan(a, npix64, &big_sk) : 0;  // 256-cout tiles of the 256 x 256 bf16x3 kernel
+  const bool big = nbig > 0;
+  const int bk = big ? GBK : half == 3 ? XBK : (half ? HBK : (k16 ? 16 : BK));
   p.nkc0 = (a->c0s + bk - 1) / bk;
   p.nkc1 = (a->c1s + bk - 1) / bk;
   p.nk = a->ksize * a->ksize * (p.nkc0 + p.nkc1);
@@ -2627,8 +2845,29 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   p.a.gn_quads = nullptr;
   p.tiles_m = (a->cout_s + BM - 1) / BM;
   p.tiles_n = (p.npix + BN - 1) / BN;
-  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  p.m_tile0 = 0;
+  if (big) {
+    p.tiles_m = nbig;
+    p.tiles_n = (p.npix + GB - 1) / GB;
+  }
+  int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   AZ_REQUIRE(nwg < (1ll << 31), AZ_E_SHAPE);
+  if (big) {
+    hipLaunchKernelGGL(conv_gemm_x3_big_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
+    if (nbig * GB < a->cout_s) {  // the remaining output channels: 128 x 128 tiles, K tiles of 32
+      ConvP q = p;
+      q.nkc0 = (a->c0s + XBK - 1) / XBK;
+      q.nkc1 = 0;
+      q.nk = q.nkc0;
+      q.kps = (q.nk + splitk - 1) / splitk;
+      AZ_REQUIRE((q.nk + q.kps - 1) / q.kps == splitk, AZ_E_SHAPE);  // (the same slabs as the big launch)
+      q.m_tile0 = nbig * (GB / BM);
+      q.tiles_m = (a->cout_s - nbig * GB + BM - 1) / BM;
+      q.tiles_n = (p.npix + BN - 1) / BN;
+      nwg = (int64_t)q.tiles_m * q.tiles_n;
+      hipLaunchKernelGGL(conv_igemm_x3_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, q);
+    }
+  } else
   if (half == 1)
     hipLaunchKernelGGL(conv_igemm_half_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
   else if (half == 2)

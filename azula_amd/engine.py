@@ -416,7 +416,7 @@ class Builder:
             name = "az_conv2d_winograd_f32"
         elif use_x3:
             a.weight = packed.direct_x3().data_ptr()
-            a.splitk = lib.az_conv2d_suggest_splitk(npix, a.cout_s, cin_s, ks)
+            a.splitk = lib.az_conv2d_x3_suggest_splitk(C.byref(a))  # (the 256 x 256-tile kernel has its own rule)
             name = "az_conv2d_x3_f32"
         elif self.half is not None:
             a.weight = packed.direct_half(self.half == torch.float16).data_ptr()

@@ -343,6 +343,10 @@ int az_conv2d_f16_f32(const AzConvArgs* args, az_stream_t stream);
  * level of the fp32 kernel and below the Winograd form's.  `weight` = az_pack_conv_weight_x3_f32 output; everything else
  * (fp32 src / res / dst, the fused epilogue) as az_conv2d_f32.  Same reference op: azula/nn/layers.py:48-55 ConvNd.  */
 int az_conv2d_x3_f32(const AzConvArgs* args, az_stream_t stream);
+/* The split-K az_conv2d_x3_f32 wants for a filled descriptor (splitk / workspace not read): its 256 x 256-tile kernel runs one
+ * workgroup per CU and splits a deep K (the 3072 -> 768 token projections) until its rounds are whole; az_conv2d_suggest_splitk's
+ * value wherever the 128 x 128 kernel takes the launch.  No reference counterpart. */
+int az_conv2d_x3_suggest_splitk(const AzConvArgs* args);
 /* Winograd F(2x2,3x3) form of the same operation for ksize = 3, stride = 1, pad = 1: 2.25x fewer
  * multiplies in exact fp32 (transforms only add/subtract; the input transform, the 16 frequency
  * GEMMs and the output transform + epilogue are ONE kernel).  `weight` must be the host-side

@@ -1085,3 +1085,42 @@ def test_calibration_kernels(az):
     print(f"az_calib_mfma_random_bf16: {tf:.1f} TF/s")
     assert 300.0 < tf < 2700.0  # (nominal 2516.8; ~1700 - 1800 under the 1400 W cap)
 
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 768, 768), (1, 300, 64, 260), (3, 130, 128, 388), (1, 4096, 3072, 768), (1, 1000, 256, 1024),
+                                   (64, 256, 128, 2304), (16, 1024, 3072, 768)])
+@pytest.mark.parametrize("act,res", [(0, False), (1, True)])
+def test_x3_gemm_big_tile(az, monkeypatch, shape, act, res):
+    """conv_gemm_x3_big_kernel (256 x 256 tile, 8 waves, two LDS stages) against the 128 x 128 bf16x3 kernel and fp64: same six
+    partial products per K step of 16 channels, so the two agree to a few ulps; ragged token / channel tiles, split-K, residual."""
+    from azula_amd.engine import Act, Builder
+
+    B, T, Cin, Cout = shape
+    g = torch.Generator().manual_seed(T + Cout)
+    x = torch.randn(B, Cin, T, 1, generator=g) * torch.logspace(-2, 2, Cin)[None, :, None, None]
+    w = torch.randn(Cout, Cin, generator=g) / Cin**0.5
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, Cout, T, 1, generator=g) if res else None
+    ref = F.conv2d(x.double(), w.double()[:, :, None, None], b.double())
+    if act:
+        ref = F.silu(ref)
+    if res:
+        ref = ref + r.double()
+    outs = {}
+    for big in ("0", "1", "plan"):  # 128 x 128 everywhere / 256 x 256 wherever eligible / the library's own plan (big tiles + remainder)
+        if big == "plan":
+            monkeypatch.delenv("AZ_X3_BIG")
+        else:
+            monkeypatch.setenv("AZ_X3_BIG", big)
+        bld = Builder(torch.device("cuda"))
+        xin = Act(to_nhwc(dev(x)).reshape(-1), B, T, 1, Cin, Cin, True)  # (kept alive: the tape holds raw addresses)
+        rin = Act(to_nhwc(dev(r)).reshape(-1), B, T, 1, Cout, (Cout + 3) // 4 * 4, True) if res else None
+        y = bld.conv(xin, bld.pack_conv(dev(w), dev(b)), Cout, act=act, res=rin, winograd="x3")
+        bld.finish()
+        bld.tape.run()
+        outs[big] = from_nhwc(y.buf.reshape(B, T, 1, -1), Cout).double().cpu()
+    scale = ref.abs().max().item()
+    e0, e1 = (outs["0"] - ref).abs().max().item() / scale, (outs["1"] - ref).abs().max().item() / scale
+    e2 = (outs["plan"] - ref).abs().max().item() / scale
+    print(shape, act, "128 tile", e0, "256 tile", e1, "plan", e2, "between", (outs["1"] - outs["0"]).abs().max().item() / scale)
+    assert e1 < 2e-6 and e0 < 2e-6 and e2 < 2e-6
