@@ -217,7 +217,7 @@ def tape_profile(sampler, device):
 
 KERNEL_OF = {  # C-ABI entry point -> the __global__ kernel it launches (names as rocprofv3 prints them)
     "az_conv2d_winograd_f32": "conv_winograd_kernel", "az_conv2d_f32": "conv_igemm_kernel", "az_attention_f32": "attention_kernel", "az_attention_x3_f32": "attention_x3_kernel",
-    "az_conv2d_stem_f32": "conv_stem_kernel", "az_conv2d_bf16_f32": "conv_igemm_half_kernel", "az_conv2d_f16_f32": "conv_igemm_half_kernel", "az_conv2d_x3_f32": "conv_igemm_x3_kernel",
+    "az_conv2d_stem_f32": "conv_stem_kernel", "az_conv2d_bf16_f32": "conv_igemm_half_kernel", "az_conv2d_f16_f32": "conv_igemm_half_kernel", "az_conv2d_x3_f32": "conv_gemm_x3_big_kernel / conv_igemm_x3_kernel",  # (256 x 256 tiles where they fill rounds / 128 x 128 tiles)
     "az_conv2d_winograd4_f32": "conv_winograd4_kernel",
 }
 
@@ -692,7 +692,7 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
                               "algorithmic (direct) count has 9; frac = executed MFMA FLOP/s / the fp32 MFMA peak")
         kn = KERNEL_OF.get(fam)
         if pmc and kn:
-            hit = [v for name, v in pmc.get("forward", {}).items() if re.search(r"(^|::|\s)" + kn + r"[(<]", name)]
+            hit = [v for name, v in pmc.get("forward", {}).items() if re.search(r"(^|::|\s)(?:" + kn.replace(" / ", "|") + r")[(<]", name)]
             if hit:
                 k["traffic"] = round(sum(h["traffic_bytes_per_forward"] for h in hit) / sum(h["launches_per_forward"] for h in hit))
                 k["traffic_per_denoise_step"] = round(sum(h["traffic_bytes_per_forward"] for h in hit))
