@@ -1278,6 +1278,10 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
   const int64_t wplane = (int64_t)a.cout_s * p.cin_s;  // elements per weight piece
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, (unsigned)(3 * wplane * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (unsigned)((int64_t)p.npix * a.c0s * 4), 0x00020000);
+  // (two sources -- a channel concatenation read in place, the 1x1 skip convolutions of ADM's decoder: K steps [0, nkc0) walk
+  //  source 0, the rest source 1; the packed weights hold source 1's channels from column c0s on)
+  const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? (unsigned)((int64_t)p.npix * a.c1s * 4) : 0u, 0x00020000);
 
   // loaders: thread -> row tid >> 1 of both operands; weights: chunk tid & 1 (8 k-values) of each piece, activations: the 8
   // fp32 channels of that chunk (two adjacent lanes read one 64-byte unit)
@@ -1286,14 +1290,18 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
   const int px_l = min(n0 + lrow, p.npix - 1);
   const unsigned voffW = (unsigned)(((int64_t)co_l * p.cin_s + lch * 8) * 2);
   const unsigned voffX = (unsigned)(((int64_t)px_l * a.c0s + lch * 8) * 4);
+  const unsigned voffX1 = (unsigned)(((int64_t)px_l * a.c1s + lch * 8) * 4);
   const int lds_row = lrow * 32 + ((lch ^ ((lrow >> 3) & 1)) * 16);  // byte offset inside a plane
 
   float4 rwt[3], rxa[2];
   auto load_step = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) rwt[pl] = buf_ld4(rw, voffW, (unsigned)((pl * wplane + (int64_t)kt * GBK) * 2));
-    rxa[0] = buf_ld4(rx, voffX, (unsigned)(kt * GBK * 4));
-    rxa[1] = buf_ld4(rx, voffX + 16u, (unsigned)(kt * GBK * 4));
+    const bool s1 = kt >= p.nkc0;  // (wave-uniform; selects, not a branch: the iteration stays one basic block)
+    const __amdgpu_buffer_rsrc_t r = s1 ? rx1 : rx;
+    const unsigned vo = s1 ? voffX1 : voffX, so = (unsigned)((s1 ? kt - p.nkc0 : kt) * GBK * 4);
+    rxa[0] = buf_ld4(r, vo, so);
+    rxa[1] = buf_ld4(r, vo + 16u, so);
   };
   auto store_step = [&](int buf) __attribute__((always_inline)) {
     char* st = smem + buf * GSTAGE + lds_row;
@@ -2598,8 +2606,9 @@ __global__ __launch_bounds__(512, 2) void conv_winograd4_kernel(Wino4P p) {
 // 3072 -> 768 387 vs 444 (and no split-K combine).
 // AZ_X3_BIG = 0 / 1: never / every eligible launch whole (A/B measurements; read per call).
 static bool x3_big_eligible(const AzConvArgs* a, int64_t npix) {
-  return a->ksize == 1 && a->stride == 1 && a->pad == 0 && !a->src1 && a->up0 == 0 && !a->aniso && a->depth == 0 && !a->dst_nchw &&
-         a->h0 == a->hin && a->w0 == a->win && a->c0s % GBK == 0 && a->c0s >= 64 && npix * a->c0s * 4 < (1ll << 31);
+  if (a->src1 && !(a->up1 == 0 && a->h1 == a->hin && a->w1 == a->win && a->c1s % GBK == 0 && npix * a->c1s * 4 < (1ll << 31))) return false;
+  return a->ksize == 1 && a->stride == 1 && a->pad == 0 && a->up0 == 0 && !a->aniso && a->depth == 0 && !a->dst_nchw &&
+         a->h0 == a->hin && a->w0 == a->win && a->c0s % GBK == 0 && a->c0s + a->c1s >= 64 && npix * a->c0s * 4 < (1ll << 31);
 }
 static double x3_round_eff(int64_t wgs) { return (double)wgs / (double)(((wgs + 255) / 256) * 256); }
 // -> number of 256-cout tiles for the big kernel (0: none); *splitk = the split-K it wants (1 unless the K loop is deep)
@@ -2857,8 +2866,8 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     if (nbig * GB < a->cout_s) {  // the remaining output channels: 128 x 128 tiles, K tiles of 32
       ConvP q = p;
       q.nkc0 = (a->c0s + XBK - 1) / XBK;
-      q.nkc1 = 0;
-      q.nk = q.nkc0;
+      q.nkc1 = (a->c1s + XBK - 1) / XBK;
+      q.nk = q.nkc0 + q.nkc1;
       q.kps = (q.nk + splitk - 1) / splitk;
       AZ_REQUIRE((q.nk + q.kps - 1) / q.kps == splitk, AZ_E_SHAPE);  // (the same slabs as the big launch)
       q.m_tile0 = nbig * (GB / BM);

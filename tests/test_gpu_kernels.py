@@ -1124,3 +1124,31 @@ def test_x3_gemm_big_tile(az, monkeypatch, shape, act, res):
     e2 = (outs["plan"] - ref).abs().max().item() / scale
     print(shape, act, "128 tile", e0, "256 tile", e1, "plan", e2, "between", (outs["1"] - outs["0"]).abs().max().item() / scale)
     assert e1 < 2e-6 and e0 < 2e-6 and e2 < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 64, 256, 256, 256), (1, 96, 100, 64, 128, 320), (2, 48, 48, 512, 256, 256)])
+def test_x3_gemm_big_tile_two_sources(az, monkeypatch, shape):
+    """The 256 x 256 bf16x3 kernel on a channel concatenation read in place (the 1x1 skip convolutions of ADM's decoder,
+    plugins/adm/_src/unet.py:215,631): K steps walk source 0, then source 1; against the 128 x 128 kernel and fp64."""
+    from azula_amd.engine import Act, Builder
+
+    B, H, W, C0, C1, Cout = shape
+    g = torch.Generator().manual_seed(H + Cout)
+    x0, x1 = torch.randn(B, C0, H, W, generator=g), torch.randn(B, C1, H, W, generator=g) * 3
+    w = torch.randn(Cout, C0 + C1, generator=g) / (C0 + C1) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(torch.cat([x0, x1], 1).double(), w.double()[:, :, None, None], b.double())
+    outs = {}
+    for big in ("0", "1"):
+        monkeypatch.setenv("AZ_X3_BIG", big)
+        bld = Builder(torch.device("cuda"))
+        a0 = Act(to_nhwc(dev(x0)).reshape(-1), B, H, W, C0, C0, True)
+        a1 = Act(to_nhwc(dev(x1)).reshape(-1), B, H, W, C1, C1, True)
+        y = bld.conv(a0, bld.pack_conv(dev(w), dev(b), cin0=C0), Cout, src1=a1, winograd="x3")
+        bld.finish()
+        bld.tape.run()
+        outs[big] = from_nhwc(y.buf.reshape(B, H, W, -1), Cout).double().cpu()
+    scale = ref.abs().max().item()
+    e0, e1 = (outs["0"] - ref).abs().max().item() / scale, (outs["1"] - ref).abs().max().item() / scale
+    print(shape, "128 tile", e0, "256 tile", e1, "between", (outs["1"] - outs["0"]).abs().max().item() / scale)
+    assert e1 < 2e-6 and e0 < 2e-6
