@@ -2617,9 +2617,21 @@ static int x3_big_plan(const AzConvArgs* a, int64_t npix, int* splitk) {
   if (!x3_big_eligible(a, npix)) return 0;
   const char* force = getenv("AZ_X3_BIG");
   const int all = (a->cout_s + GB - 1) / GB;
-  if (force && force[0]) return force[0] == '1' ? all : 0;
+  if (force && force[0]) {
+    if (force[0] == '1' && force[1] == ',') *splitk = atoi(force + 2);  // "1,S": every eligible launch on big tiles with split-K S (A/B)
+    return force[0] == '1' ? all : 0;
+  }
   const int64_t tn = (npix + GB - 1) / GB;
-  if (all * tn < 176 || a->cout_s < 192) return 0;  // (128 tiles = half a round: 74 vs 62 us on 16384 x 512 -> 512; 192 tiles win)
+  if (a->cout_s < 192) return 0;
+  if (all * tn < 176) {  // (128 tiles = half a round: 74 vs 62 us on 16384 x 512 -> 512; 192 tiles win)
+    // ... unless the K loop is deep enough to split in two: 9216 x 2048 -> 768 (108 tiles) 168 us as 216 half-K tiles against 182 on
+    // 128 x 128 tiles and 210 unsplit; 768-channel K loops lose that way (84 vs 79 us)
+    if (all * tn * 2 >= 176 && (a->c0s + a->c1s) / GBK >= 96) {
+      *splitk = 2;
+      return all;
+    }
+    return 0;
+  }
   if (x3_round_eff(all * tn) >= 0.85) return all;
   // (no split-K, however deep the K loop: 16384 x 3072 -> 768 as 192 unsplit tiles 387 us, split 4 ways into whole rounds 444)
   for (int nb = a->cout_s / GB; nb >= 2; --nb)  // whole rounds of big tiles, the remaining output channels on the 128 x 128 kernel
