@@ -2827,7 +2827,8 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     p.asm_loop = 0;
   }
   int big_sk = 1;
-  const int nbig = half == 3 ? x3_big_plan(a, npix64, &big_sk) : 0;  // 256-cout tiles of the 256 x 256 bf16x3 kernel
+  int nbig = half == 3 ? x3_big_plan(a, npix64, &big_sk) : 0;  // 256-cout tiles of the 256 x 256 bf16x3 kernel
+  if (nbig > 0 && nbig * GB < a->cout_s && a->splitk > 1) nbig = 0;  // (a remainder launch would need the same slabs: one kernel then)
   const bool big = nbig > 0;
   const int bk = big ? GBK : half == 3 ? XBK : (half ? HBK : (k16 ? 16 : BK));
   p.nkc0 = (a->c0s + bk - 1) / bk;
