@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
 
-@pytest.mark.parametrize("B,H,T,D", [(2, 4, 16, 16), (1, 2, 64, 32), (2, 3, 256, 64), (1, 2, 100, 64), (1, 1, 1024, 64), (1, 2, 40, 128)])
+@pytest.mark.parametrize("B,H,T,D", [(2, 4, 16, 16), (1, 2, 64, 32), (2, 3, 256, 64), (1, 2, 100, 64), (1, 1, 1024, 64), (1, 2, 40, 128), (2, 2, 72, 80)])
 @pytest.mark.parametrize("order,rms", [("nHC", True), ("nHC", False), ("H3C", False), ("3HC", False)])
 @pytest.mark.parametrize("x3", [True, False])
 def test_attention_kernel(monkeypatch, B, H, T, D, order, rms, x3):
