@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
   const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
   const int tile_n = wg / p.tiles_m;
   const int tile_m = wg - tile_n * p.tiles_m;
-  const int m0 = tile_m * BM;
+  const int m0 = (p.m_tile0 + tile_m) * BM;
   const int n0 = tile_n * BN;
   const int kt_begin = blockIdx.y * p.kps;
   const int kt_end = min(p.nk, kt_begin + p.kps);
@@ -1253,6 +1253,55 @@ constexpr int GOSTR = 128 + 4;               // floats per pixel row of the epil
 constexpr int G_LDS_BYTES = (GB * GOSTR + GB) * 4;  // 136,192 B >= 2 stages (98,304 B)
 static_assert(2 * GSTAGE <= G_LDS_BYTES, "stages must fit under the epilogue buffer");
 
+// Epilogue of a 256 x 256 tile held as 8 waves x (128 couts x 64 pixels): two passes of 128 couts through the exchange buffer
+// [pixel][128 + 4] (the layout of store_acc_tiles), all 512 threads storing (bias / activation / gate / residual / SwiGLU / q-k
+// preparation / split-K slabs: epilogue_store_batch).
+__device__ __forceinline__ void gemm_big_epilogue(const ConvP& p, const f32x16 (&acc)[4][2], int m0, int n0, int wc, int wp, int lane,
+                                                  int tid, float* gsmf) {
+  const AzConvArgs& a = p.a;
+  int* pimg = reinterpret_cast<int*>(gsmf + GB * GOSTR);  // image index of each pixel of the tile (-1: past the end)
+  if (tid < GB) {
+    const int n = n0 + tid;
+    pimg[tid] = n < p.npix ? n / (a.hout * a.wout) : -1;
+  }
+#pragma unroll 1
+  for (int cb = 0; cb < 2; ++cb) {
+    if (wc == cb) {
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        float* orow = gsmf + (wp * 64 + pt * 32 + (lane & 31)) * GOSTR + 4 * (lane >> 5);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(orow + ct * 32 + 8 * q) =
+                make_float4(acc[ct][pt][4 * q + 0], acc[ct][pt][4 * q + 1], acc[ct][pt][4 * q + 2], acc[ct][pt][4 * q + 3]);
+      }
+    }
+    __syncthreads();
+    const int cq = tid & 31;  // the same channel quad in every iteration
+    const int co = m0 + cb * 128 + cq * 4;
+    if (co < a.cout_s) {
+      constexpr int NIT = GB * 32 / 512, NB = 4;  // (8 per batch spills here: the other cout half's 64 accumulator registers are live)
+#pragma unroll 1
+      for (int it0 = 0; it0 < NIT; it0 += NB) {
+        int n[NB], b[NB];
+        float4 v[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int px = ((it0 + i) * 512 + tid) >> 5;
+          b[i] = pimg[px];
+          n[i] = b[i] >= 0 ? n0 + px : -1;
+          v[i] = *reinterpret_cast<const float4*>(gsmf + px * GOSTR + cq * 4);
+        }
+        epilogue_store_batch<NB>(a, n, b, co, v, (int64_t)blockIdx.y * p.npix);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+
 __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
   __shared__ __attribute__((aligned(16))) float gsmf[G_LDS_BYTES / 4];
   char* const smem = reinterpret_cast<char*>(gsmf);
@@ -1377,47 +1426,151 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
     __syncthreads();  // every wave has read stage `buf`; the other stage is complete
   }
 
-  // ---- epilogue: two passes of 128 couts through the exchange buffer [pixel][128 + 4] (the layout of store_acc_tiles)
-  int* pimg = reinterpret_cast<int*>(gsmf + GB * GOSTR);  // image index of each pixel of the tile (-1: past the end)
-  if (tid < GB) {
-    const int n = n0 + tid;
-    pimg[tid] = n < p.npix ? n / (a.hout * a.wout) : -1;
+  gemm_big_epilogue(p, acc, m0, n0, wc, wp, lane, tid, gsmf);
+}
+
+// =================================================================================================
+// The 256 x 256 tile for modules cast to half precision (az_conv2d_{bf16,f16}_f32 on token GEMMs / 1x1 convolutions): the same
+// 8 waves x (128 couts x 64 pixels), K steps of 64 channels (32 MFMAs per wave and barrier), two LDS stages of
+// [operand][256 rows][128 B] (128 KB); weights arrive in the operand type, activations fp32 and are rounded to it (nearest even,
+// as conv_igemm_half_kernel) on their way into LDS, under the MFMAs.  A row's eight 16-byte chunks are XOR-ed with bits 1..3 of
+// the row: the 16 lanes of a ds_read_b128 group then hit 16 different slots of the 256-byte bank line.
+constexpr int HGK = 64;                       // K step
+constexpr int HGPLANE = GB * HGK * 2;         // bytes per operand plane of a stage: 32 KB
+constexpr int HGSTAGE = 2 * HGPLANE;          // 64 KB
+static_assert(2 * HGSTAGE <= G_LDS_BYTES, "stages must fit under the epilogue buffer");
+
+template <bool F16>
+__global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
+  using H8 = typename std::conditional<F16, f16x8, bf16x8>::type;
+  using H4 = typename std::conditional<F16, f16x4, bf16x4>::type;
+  __shared__ __attribute__((aligned(16))) float gsmf[G_LDS_BYTES / 4];
+  char* const smem = reinterpret_cast<char*>(gsmf);
+  const AzConvArgs& a = p.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wc = wid >> 2;  // cout half (128)
+  const int wp = wid & 3;   // pixel quarter (64)
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  const int tile_n = wg / p.tiles_m;
+  const int tile_m = wg - tile_n * p.tiles_m;
+  const int m0 = tile_m * GB;
+  const int n0 = tile_n * GB;
+  const int kt_begin = blockIdx.y * p.kps;
+  const int kt_end = min(p.nk, kt_begin + p.kps);
+  const int nk = kt_end - kt_begin;
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, (unsigned)((int64_t)a.cout_s * p.cin_s * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (unsigned)((int64_t)p.npix * a.c0s * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? (unsigned)((int64_t)p.npix * a.c1s * 4) : 0u, 0x00020000);
+
+  // loaders: thread -> chunk tid & 7 (8 k-values) of rows (tid >> 3) + 64 i of both operands: the 8 lanes of a row read 128
+  // (weights) / 256 (activations) contiguous bytes
+  const int lch = tid & 7, lr0 = tid >> 3;
+  unsigned voffW[4], voffX[4], voffX1[4];
+  int lds_row[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = lr0 + 64 * i;
+    const int co = min(m0 + row, a.cout_s - 1);  // (rows past the edge: a valid duplicate, never stored)
+    const int px = min(n0 + row, p.npix - 1);
+    voffW[i] = (unsigned)(((int64_t)co * p.cin_s + lch * 8) * 2);
+    voffX[i] = (unsigned)(((int64_t)px * a.c0s + lch * 8) * 4);
+    voffX1[i] = (unsigned)(((int64_t)px * a.c1s + lch * 8) * 4);
+    lds_row[i] = row * 128 + ((lch ^ ((row >> 1) & 7)) * 16);
   }
-#pragma unroll 1
-  for (int cb = 0; cb < 2; ++cb) {
-    if (wc == cb) {
+  float4 rwt[4], rxa[4][2];
+  auto load_step = [&](int kt) __attribute__((always_inline)) {
+    const bool s1 = kt >= p.nkc0;  // (wave-uniform; selects, not a branch)
+    const __amdgpu_buffer_rsrc_t r = s1 ? rx1 : rx;
+    const unsigned so = (unsigned)((s1 ? kt - p.nkc0 : kt) * HGK * 4);
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
-        float* orow = gsmf + (wp * 64 + pt * 32 + (lane & 31)) * GOSTR + 4 * (lane >> 5);
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(orow + ct * 32 + 8 * q) =
-                make_float4(acc[ct][pt][4 * q + 0], acc[ct][pt][4 * q + 1], acc[ct][pt][4 * q + 2], acc[ct][pt][4 * q + 3]);
-      }
+    for (int i = 0; i < 4; ++i) {
+      rwt[i] = buf_ld4(rw, voffW[i], (unsigned)(kt * HGK * 2));
+      const unsigned vo = s1 ? voffX1[i] : voffX[i];
+      rxa[i][0] = buf_ld4(r, vo, so);
+      rxa[i][1] = buf_ld4(r, vo + 16u, so);
     }
-    __syncthreads();
-    const int cq = tid & 31;  // the same channel quad in every iteration
-    const int co = m0 + cb * 128 + cq * 4;
-    if (co < a.cout_s) {
-      constexpr int NIT = GB * 32 / 512, NB = 4;  // (8 per batch spills here: the other cout half's 64 accumulator registers are live)
-#pragma unroll 1
-      for (int it0 = 0; it0 < NIT; it0 += NB) {
-        int n[NB], b[NB];
-        float4 v[NB];
+  };
+  auto store_step = [&](int buf) __attribute__((always_inline)) {
+    char* st = smem + buf * HGSTAGE;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-          const int px = ((it0 + i) * 512 + tid) >> 5;
-          b[i] = pimg[px];
-          n[i] = b[i] >= 0 ? n0 + px : -1;
-          v[i] = *reinterpret_cast<const float4*>(gsmf + px * GOSTR + cq * 4);
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(st + lds_row[i]) = rwt[i];
+      const f32x4v lo = {rxa[i][0].x, rxa[i][0].y, rxa[i][0].z, rxa[i][0].w}, hi = {rxa[i][1].x, rxa[i][1].y, rxa[i][1].z, rxa[i][1].w};
+      const H4 l4 = __builtin_convertvector(lo, H4), h4 = __builtin_convertvector(hi, H4);
+      H8 v8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v8[j] = l4[j];
+        v8[4 + j] = h4[j];
+      }
+      *reinterpret_cast<H8*>(st + HGPLANE + lds_row[i]) = v8;
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: row (lane & 31) of a 32-row MFMA tile (tile bases are multiples of 32: the swizzle sees the row's own
+  // bits 1..3), chunk 2 ks + (lane >> 5)
+  const int frow = lane & 31;
+  const int fsw = (frow >> 1) & 7;
+  const char* As = smem + (wc * 128 + frow) * 128;             // + buf * HGSTAGE + tile * 4096 + swizzled chunk * 16
+  const char* Bs = smem + HGPLANE + (wp * 64 + frow) * 128;
+
+  if (nk > 0) {
+    load_step(kt_begin);
+    store_step(0);
+    load_step(min(kt_begin + 1, kt_end - 1));
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int i = 0; i < nk; ++i) {
+    const int buf = i & 1;
+    store_step(buf ^ 1);                               // step i + 1 (in registers since the previous iteration) -> the other stage
+    load_step(min(kt_begin + i + 2, kt_end - 1));      // in flight under the MFMAs below and the next iteration's first ones
+#pragma unroll
+    for (int ks = 0; ks < HGK / 16; ++ks) {
+      const int ch = ((2 * ks + (lane >> 5)) ^ fsw) * 16;
+      H8 fa[4], fb[2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const H8*>(As + buf * HGSTAGE + t * 4096 + ch);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fb[t] = *reinterpret_cast<const H8*>(Bs + buf * HGSTAGE + t * 4096 + ch);
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int pj = 0; pj < 2; ++pj) {
+          if constexpr (F16) acc[ci][pj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ci], fb[pj], acc[ci][pj], 0, 0, 0);
+          else acc[ci][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ci], fb[pj], acc[ci][pj], 0, 0, 0);
         }
-        epilogue_store_batch<NB>(a, n, b, co, v, (int64_t)blockIdx.y * p.npix);
-      }
     }
-    __syncthreads();
+    // issue order: the 24 fragment reads in four groups ahead of their MFMAs, the conversions and the 8 LDS stores of the next
+    // step under the 32 MFMAs, its 12 loads last
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if ((k & 7) == 1 && k < 24) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // the next k-step's fragments
+      if (k < 24) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                   // two vector instructions
+      if (k >= 4 && k < 20 && (k & 1) == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS store
+      if (k >= 20) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                  // a buffer load
+    }
+    __syncthreads();  // every wave has read stage `buf`; the other stage is complete
   }
+  gemm_big_epilogue(p, acc, m0, n0, wc, wp, lane, tid, gsmf);
 }
 
 // =================================================================================================
@@ -2605,16 +2758,16 @@ __global__ __launch_bounds__(512, 2) void conv_winograd4_kernel(Wino4P p) {
 // (192 tiles, 0.75 of a round) 117 vs 125, 768 -> 2304 (576 tiles = 2.25 rounds) a tie -- hence 8 of its 9 cout tiles big: 311 vs 338;
 // 3072 -> 768 387 vs 444 (and no split-K combine).
 // AZ_X3_BIG = 0 / 1: never / every eligible launch whole (A/B measurements; read per call).
-static bool x3_big_eligible(const AzConvArgs* a, int64_t npix) {
-  if (a->src1 && !(a->up1 == 0 && a->h1 == a->hin && a->w1 == a->win && a->c1s % GBK == 0 && npix * a->c1s * 4 < (1ll << 31))) return false;
+static bool x3_big_eligible(const AzConvArgs* a, int64_t npix, int kstep = GBK) {  // kstep: 16 (bf16x3) / 64 (half-precision operands)
+  if (a->src1 && !(a->up1 == 0 && a->h1 == a->hin && a->w1 == a->win && a->c1s % kstep == 0 && npix * a->c1s * 4 < (1ll << 31))) return false;
   return a->ksize == 1 && a->stride == 1 && a->pad == 0 && a->up0 == 0 && !a->aniso && a->depth == 0 && !a->dst_nchw &&
-         a->h0 == a->hin && a->w0 == a->win && a->c0s % GBK == 0 && a->c0s + a->c1s >= 64 && npix * a->c0s * 4 < (1ll << 31);
+         a->h0 == a->hin && a->w0 == a->win && a->c0s % kstep == 0 && a->c0s + a->c1s >= 64 && npix * a->c0s * 4 < (1ll << 31);
 }
 static double x3_round_eff(int64_t wgs) { return (double)wgs / (double)(((wgs + 255) / 256) * 256); }
 // -> number of 256-cout tiles for the big kernel (0: none); *splitk = the split-K it wants (1 unless the K loop is deep)
-static int x3_big_plan(const AzConvArgs* a, int64_t npix, int* splitk) {
+static int x3_big_plan(const AzConvArgs* a, int64_t npix, int* splitk, int kstep = GBK) {
   *splitk = 1;
-  if (!x3_big_eligible(a, npix)) return 0;
+  if (!x3_big_eligible(a, npix, kstep)) return 0;
   const char* force = getenv("AZ_X3_BIG");
   const int all = (a->cout_s + GB - 1) / GB;
   if (force && force[0]) {
@@ -2626,7 +2779,7 @@ static int x3_big_plan(const AzConvArgs* a, int64_t npix, int* splitk) {
   if (all * tn < 176) {  // (128 tiles = half a round: 74 vs 62 us on 16384 x 512 -> 512; 192 tiles win)
     // ... unless the K loop is deep enough to split in two: 9216 x 2048 -> 768 (108 tiles) 168 us as 216 half-K tiles against 182 on
     // 128 x 128 tiles and 210 unsplit; 768-channel K loops lose that way (84 vs 79 us)
-    if (all * tn * 2 >= 176 && (a->c0s + a->c1s) / GBK >= 96) {
+    if (all * tn * 2 >= 176 && a->c0s + a->c1s >= 1536) {
       *splitk = 2;
       return all;
     }
@@ -2827,10 +2980,11 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     p.asm_loop = 0;
   }
   int big_sk = 1;
-  int nbig = half == 3 ? x3_big_plan(a, npix64, &big_sk) : 0;  // 256-cout tiles of the 256 x 256 bf16x3 kernel
+  // 256-cout tiles of the 256 x 256 kernel (bf16x3: K steps of 16 channels; half-precision operands: 64)
+  int nbig = half == 3 ? x3_big_plan(a, npix64, &big_sk) : (half == 1 || half == 2) ? x3_big_plan(a, npix64, &big_sk, HGK) : 0;
   if (nbig > 0 && nbig * GB < a->cout_s && a->splitk > 1) nbig = 0;  // (a remainder launch would need the same slabs: one kernel then)
   const bool big = nbig > 0;
-  const int bk = big ? GBK : half == 3 ? XBK : (half ? HBK : (k16 ? 16 : BK));
+  const int bk = big ? (half == 3 ? GBK : HGK) : half == 3 ? XBK : (half ? HBK : (k16 ? 16 : BK));
   p.nkc0 = (a->c0s + bk - 1) / bk;
   p.nkc1 = (a->c1s + bk - 1) / bk;
   p.nk = a->ksize * a->ksize * (p.nkc0 + p.nkc1);
@@ -2875,11 +3029,14 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   AZ_REQUIRE(nwg < (1ll << 31), AZ_E_SHAPE);
   if (big) {
-    hipLaunchKernelGGL(conv_gemm_x3_big_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
+    if (half == 3) hipLaunchKernelGGL(conv_gemm_x3_big_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
+    else if (half == 2) hipLaunchKernelGGL(conv_gemm_half_big_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(conv_gemm_half_big_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     if (nbig * GB < a->cout_s) {  // the remaining output channels: 128 x 128 tiles, K tiles of 32
       ConvP q = p;
-      q.nkc0 = (a->c0s + XBK - 1) / XBK;
-      q.nkc1 = (a->c1s + XBK - 1) / XBK;
+      const int sbk = half == 3 ? XBK : HBK;
+      q.nkc0 = (a->c0s + sbk - 1) / sbk;
+      q.nkc1 = (a->c1s + sbk - 1) / sbk;
       q.nk = q.nkc0 + q.nkc1;
       q.kps = (q.nk + splitk - 1) / splitk;
       AZ_REQUIRE((q.nk + q.kps - 1) / q.kps == splitk, AZ_E_SHAPE);  // (the same slabs as the big launch)
@@ -2887,7 +3044,9 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
       q.tiles_m = (a->cout_s - nbig * GB + BM - 1) / BM;
       q.tiles_n = (p.npix + BN - 1) / BN;
       nwg = (int64_t)q.tiles_m * q.tiles_n;
-      hipLaunchKernelGGL(conv_igemm_x3_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, q);
+      if (half == 3) hipLaunchKernelGGL(conv_igemm_x3_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, q);
+      else if (half == 2) hipLaunchKernelGGL(conv_igemm_half_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, q);
+      else hipLaunchKernelGGL(conv_igemm_half_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, q);
     }
   } else
   if (half == 1)

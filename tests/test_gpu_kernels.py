@@ -1152,3 +1152,36 @@ def test_x3_gemm_big_tile_two_sources(az, monkeypatch, shape):
     e0, e1 = (outs["0"] - ref).abs().max().item() / scale, (outs["1"] - ref).abs().max().item() / scale
     print(shape, "128 tile", e0, "256 tile", e1, "between", (outs["1"] - outs["0"]).abs().max().item() / scale)
     assert e1 < 2e-6 and e0 < 2e-6
+
+
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 512, 768, 768), (1, 300, 64, 260), (3, 130, 128, 388), (1, 4096, 3072, 768), (64, 256, 128, 2304)])
+def test_half_gemm_big_tile(az, monkeypatch, shape, half):
+    """conv_gemm_half_big_kernel (256 x 256 tile for modules cast to half precision) against the 128 x 128 half kernel (same
+    rounding of the operands) and an fp64 product of the rounded operands."""
+    from azula_amd.engine import Act, Builder
+
+    B, T, Cin, Cout = shape
+    g = torch.Generator().manual_seed(T + Cout)
+    x = torch.randn(B, Cin, T, 1, generator=g)
+    w = torch.randn(Cout, Cin, generator=g) / Cin**0.5
+    b = torch.randn(Cout, generator=g)
+    exact = F.conv2d(x.to(half).double(), w.to(half).double()[:, :, None, None], b.double())
+    outs = {}
+    for big in ("0", "1", "plan"):
+        if big == "plan":
+            monkeypatch.delenv("AZ_X3_BIG")
+        else:
+            monkeypatch.setenv("AZ_X3_BIG", big)
+        bld = Builder(torch.device("cuda"), half=half)
+        xin = Act(to_nhwc(dev(x)).reshape(-1), B, T, 1, Cin, Cin, True)
+        y = bld.conv(xin, bld.pack_conv(dev(w), dev(b)), Cout, act=1)
+        bld.finish()
+        bld.tape.run()
+        outs[big] = from_nhwc(y.buf.reshape(B, T, 1, -1), Cout).double().cpu()
+    ref = F.silu(exact)
+    for k, o in outs.items():
+        assert (o - ref).abs().max().item() < conv_tol(Cin, 1), (k, (o - ref).abs().max().item())
+    print(shape, half, "128 vs 256 tile", (outs["1"] - outs["0"]).abs().max().item(), "plan", (outs["plan"] - outs["0"]).abs().max().item())
+    # (equal to the last bit where the 128 x 128 launch is not split along K; a split changes the summation order)
+    assert (outs["1"] - outs["0"]).abs().max().item() < 2e-5 and (outs["plan"] - outs["0"]).abs().max().item() < 2e-5

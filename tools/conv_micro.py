@@ -23,6 +23,12 @@ w = torch.randn(Cout, Cin, ks, ks, device=dev) / (Cin * ks * ks) ** 0.5 * scale
 b = torch.randn(Cout, device=dev)
 wino = {"1": True, "0": False, "4": 4, "x3": "x3"}.get(os.environ.get("AZ_WINO", ""), None)
 y = bld.conv(x, bld.pack_conv(w, b), Cout, stride=stride, act=int(os.environ.get("AZ_ACT", "1")), winograd=wino, gn_stats=bool(os.environ.get("AZ_GN")))
+if os.environ.get("AZ_SPLITK"):  # override the suggested split-K (A/B)
+    _d = [k for k in bld.tape.keep if hasattr(k, "_flops")][-1]
+    _d.splitk = int(os.environ["AZ_SPLITK"])
+    bld._ws_need = max(bld._ws_need, _d.splitk * B * ((H + stride - 1) // stride) * ((W + stride - 1) // stride) * _d.cout_s)
+    if _d not in bld._ws_users:
+        bld._ws_users.append(_d)
 bld.finish()
 desc = bld.tape.keep[-1] if hasattr(bld.tape.keep[-1], "_flops") else [k for k in bld.tape.keep if hasattr(k, "_flops")][-1]
 for _ in range(3):
