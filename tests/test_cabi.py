@@ -111,3 +111,31 @@ def test_committed_kloop_streams_are_the_generators_output(monkeypatch):
         assert res.returncode == 0, res.stdout + res.stderr
     tracked = subprocess.run(["git", "ls-files", "azula_amd/csrc/_obj", "azula_amd/csrc/_ab"], cwd=ROOT, capture_output=True, text=True)
     assert tracked.returncode != 0 or tracked.stdout.strip() == "", "build by-products are tracked: " + tracked.stdout
+
+
+def test_bf16x3_tile_plan_on_the_host(built_lib, monkeypatch):
+    """az_conv2d_x3_suggest_splitk is host arithmetic (no device): it pins the 256 x 256-tile plan of the bf16x3 token GEMMs --
+    one workgroup per CU, so whole rounds of the 256 CUs, never a split of a grid that already fills 0.75 of a round, a split
+    in two for a deep K under one round -- and falls back to az_conv2d_suggest_splitk wherever the 128 x 128 kernel runs."""
+    from azula_amd import _lib
+
+    lib = _lib.lib()
+    monkeypatch.delenv("AZ_X3_BIG", raising=False)
+
+    def gemm(tokens, cin, cout, **kw):
+        d = dict(src0=0x1000, weight=0x1000, dst=0x1000, c0s=cin, cout_s=cout, batch=1, hin=tokens, win=1, hout=tokens, wout=1,
+                 ksize=1, stride=1, pad=0, splitk=1, h0=tokens, w0=1)
+        d.update(kw)
+        return _lib.AzConvArgs(**d)
+
+    sk = lambda a: lib.az_conv2d_x3_suggest_splitk(ctypes.byref(a))  # noqa: E731
+    assert sk(gemm(16384, 768, 3072)) == 1   # 768 big tiles = 3 whole rounds
+    assert sk(gemm(16384, 3072, 768)) == 1   # 192 big tiles, deep K: unsplit (the 128 x 128 kernel would split in two)
+    assert lib.az_conv2d_suggest_splitk(16384, 768, 3072, 1) == 2
+    assert sk(gemm(9216, 2048, 768)) == 2    # 108 big tiles: the deep K loop in two halves -> 216 workgroups
+    assert sk(gemm(9216, 768, 768)) == lib.az_conv2d_suggest_splitk(9216, 768, 768, 1)      # shallow K, under a round: 128 x 128 tiles
+    assert sk(gemm(256, 1024, 1024)) == lib.az_conv2d_suggest_splitk(256, 1024, 1024, 1)    # a small map: 128 x 128 tiles, their split-K
+    conv3 = gemm(16384, 768, 3072, ksize=3, pad=1)
+    assert sk(conv3) == lib.az_conv2d_suggest_splitk(16384, 3072, 768, 3)                    # taps: not a big-tile launch
+    monkeypatch.setenv("AZ_X3_BIG", "0")
+    assert sk(gemm(16384, 3072, 768)) == 2
