@@ -1256,8 +1256,15 @@ static_assert(2 * GSTAGE <= G_LDS_BYTES, "stages must fit under the epilogue buf
 // Epilogue of a 256 x 256 tile held as 8 waves x (128 couts x 64 pixels): two passes of 128 couts through the exchange buffer
 // [pixel][128 + 4] (the layout of store_acc_tiles), all 512 threads storing (bias / activation / gate / residual / SwiGLU / q-k
 // preparation / split-K slabs: epilogue_store_batch).
-__device__ __forceinline__ void gemm_big_epilogue(const ConvP& p, const f32x16 (&acc)[4][2], int m0, int n0, int wc, int wp, int lane,
+// NCT = 32-cout MFMA tiles per wave: 4 (256-cout tile, passes of 128) or 3 (192-cout tile, passes of 96 couts = 24 quads per pixel
+// row, 21 rows per sweep of the 512 threads, 8 of them idle).
+template <int NCT>
+__device__ __forceinline__ void gemm_big_epilogue(const ConvP& p, const f32x16 (&acc)[NCT][2], int m0, int n0, int wc, int wp, int lane,
                                                   int tid, float* gsmf) {
+  constexpr int PW = 32 * NCT;         // couts per pass
+  constexpr int Q = PW / 4;            // channel quads per pixel row
+  constexpr int RPI = 512 / Q;         // pixel rows per sweep
+  constexpr int OST = PW + 4;          // floats per pixel row of the exchange buffer
   const AzConvArgs& a = p.a;
   int* pimg = reinterpret_cast<int*>(gsmf + GB * GOSTR);  // image index of each pixel of the tile (-1: past the end)
   if (tid < GB) {
@@ -1269,9 +1276,9 @@ __device__ __forceinline__ void gemm_big_epilogue(const ConvP& p, const f32x16 (
     if (wc == cb) {
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt) {
-        float* orow = gsmf + (wp * 64 + pt * 32 + (lane & 31)) * GOSTR + 4 * (lane >> 5);
+        float* orow = gsmf + (wp * 64 + pt * 32 + (lane & 31)) * OST + 4 * (lane >> 5);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(orow + ct * 32 + 8 * q) =
@@ -1279,20 +1286,22 @@ __device__ __forceinline__ void gemm_big_epilogue(const ConvP& p, const f32x16 (
       }
     }
     __syncthreads();
-    const int cq = tid & 31;  // the same channel quad in every iteration
-    const int co = m0 + cb * 128 + cq * 4;
-    if (co < a.cout_s) {
-      constexpr int NIT = GB * 32 / 512, NB = 4;  // (8 per batch spills here: the other cout half's 64 accumulator registers are live)
+    const int cq = tid % Q;  // the same channel quad in every iteration
+    const int pr = tid / Q;  // pixel row inside a sweep (>= RPI: an idle thread of the 24-quad form)
+    const int co = m0 + cb * PW + cq * 4;
+    if (co < a.cout_s && pr < RPI) {
+      constexpr int NIT = (GB + RPI - 1) / RPI, NB = 4;  // (8 per batch spills here: the other cout half's accumulator registers are live)
 #pragma unroll 1
       for (int it0 = 0; it0 < NIT; it0 += NB) {
         int n[NB], b[NB];
         float4 v[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-          const int px = ((it0 + i) * 512 + tid) >> 5;
-          b[i] = pimg[px];
+          const int px = (it0 + i) * RPI + pr;
+          const bool in = px < GB;
+          b[i] = in ? pimg[px] : -1;
           n[i] = b[i] >= 0 ? n0 + px : -1;
-          v[i] = *reinterpret_cast<const float4*>(gsmf + px * GOSTR + cq * 4);
+          v[i] = in ? *reinterpret_cast<const float4*>(gsmf + px * OST + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         epilogue_store_batch<NB>(a, n, b, co, v, (int64_t)blockIdx.y * p.npix);
       }
@@ -1302,7 +1311,9 @@ __device__ __forceinline__ void gemm_big_epilogue(const ConvP& p, const f32x16 (
 }
 
 
+template <int NCT>  // 32-cout MFMA tiles per wave: 4 = the 256-cout tile, 3 = a 192-cout tile (768 = 4 x 192: whole rounds where 3 x 256 leaves a quarter of the CUs idle)
 __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
+  constexpr int CT = 64 * NCT;  // couts per tile
   __shared__ __attribute__((aligned(16))) float gsmf[G_LDS_BYTES / 4];
   char* const smem = reinterpret_cast<char*>(gsmf);
   const AzConvArgs& a = p.a;
@@ -1318,7 +1329,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
   const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
   const int tile_n = wg / p.tiles_m;
   const int tile_m = wg - tile_n * p.tiles_m;
-  const int m0 = tile_m * GB;
+  const int m0 = tile_m * CT;
   const int n0 = tile_n * GB;
   const int kt_begin = blockIdx.y * p.kps;
   const int kt_end = min(p.nk, kt_begin + p.kps);
@@ -1337,7 +1348,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
   const int lrow = tid >> 1, lch = tid & 1;
   const int co_l = min(m0 + lrow, a.cout_s - 1);  // (rows past the edge: a valid duplicate, never stored)
   const int px_l = min(n0 + lrow, p.npix - 1);
-  const unsigned voffW = (unsigned)(((int64_t)co_l * p.cin_s + lch * 8) * 2);
+  const unsigned voffW = lrow < CT ? (unsigned)(((int64_t)co_l * p.cin_s + lch * 8) * 2) : OOB;  // (a 192-cout tile: rows 192 .. 255 stage zeros)
   const unsigned voffX = (unsigned)(((int64_t)px_l * a.c0s + lch * 8) * 4);
   const unsigned voffX1 = (unsigned)(((int64_t)px_l * a.c1s + lch * 8) * 4);
   const int lds_row = lrow * 32 + ((lch ^ ((lrow >> 3) & 1)) * 16);  // byte offset inside a plane
@@ -1365,9 +1376,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
       *reinterpret_cast<uint4*>(st + (3 + pl) * GPLANE) = make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[NCT][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NCT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1376,7 +1387,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
   // fragment addresses: row (lane & 31) of a 32-row MFMA tile, chunk lane >> 5 (swapped in rows with bit 3 set)
   const int frow = lane & 31;
   const int foff = frow * 32 + (((lane >> 5) ^ ((frow >> 3) & 1)) * 16);
-  const char* As = smem + (wc * 128) * 32 + foff;               // + buf * GSTAGE + piece * GPLANE + tile * 1024
+  const char* As = smem + (wc * (CT / 2)) * 32 + foff;               // + buf * GSTAGE + piece * GPLANE + tile * 1024
   const char* Bs = smem + 3 * GPLANE + (wp * 64) * 32 + foff;
 
   if (nk > 0) {
@@ -1388,11 +1399,11 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
 #pragma unroll 1
   for (int i = 0; i < nk; ++i) {
     const int buf = i & 1;
-    bf16x8 fa[3][4], fb[3][2];
+    bf16x8 fa[3][NCT], fb[3][2];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) fa[pl][t] = *reinterpret_cast<const bf16x8*>(As + buf * GSTAGE + pl * GPLANE + t * 1024);
+      for (int t = 0; t < NCT; ++t) fa[pl][t] = *reinterpret_cast<const bf16x8*>(As + buf * GSTAGE + pl * GPLANE + t * 1024);
 #pragma unroll
       for (int t = 0; t < 2; ++t) fb[pl][t] = *reinterpret_cast<const bf16x8*>(Bs + buf * GSTAGE + pl * GPLANE + t * 1024);
     }
@@ -1405,7 +1416,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
 #pragma unroll
     for (int t = 0; t < 6; ++t)
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
+      for (int ci = 0; ci < NCT; ++ci)
 #pragma unroll
         for (int pj = 0; pj < 2; ++pj)
           acc[ci][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][ci], fb[PB[t]][pj], acc[ci][pj], 0, 0, 0);
@@ -1413,20 +1424,21 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
     // Issue order: the 18 fragment reads, then the staging of the next step (44 split instructions, 6 LDS stores, 5 loads) spread
     // under the 48 MFMAs -- the matrix pipe takes 32 cycles per instruction, ~5 other issues fit in each gap -- instead of in
     // front of them (the compiler's own order: the pipe idles while both waves of a SIMD stage).
-    __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);  // DS reads
+    constexpr int NM = 12 * NCT;  // MFMAs of the step
+    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NCT + 2), 0);  // DS reads
 #pragma unroll
-    for (int k = 0; k < 48; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
-      if (k < 40) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two vector instructions
-      if (k >= 8 && k < 40 && (k & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS store
-      if (k >= 40 && k < 45) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                 // a buffer load
+    for (int k = 0; k < NM; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
+      if (k < NM - 8) __builtin_amdgcn_sched_group_barrier(0x002, NCT == 4 ? 2 : 3, 0);  // two (three) vector instructions
+      if (k >= 8 && k < NM - 8 && (k & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS store
+      if (k >= NM - 8 && k < NM - 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // a buffer load
     }
     // (measured alternatives: the staging ten MFMAs later 388 vs 371 us, one vector instruction per gap all along 380, on 16384 x 768 -> 3072)
 #endif
     __syncthreads();  // every wave has read stage `buf`; the other stage is complete
   }
 
-  gemm_big_epilogue(p, acc, m0, n0, wc, wp, lane, tid, gsmf);
+  gemm_big_epilogue<NCT>(p, acc, m0, n0, wc, wp, lane, tid, gsmf);
 }
 
 // =================================================================================================
@@ -1570,7 +1582,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
     }
     __syncthreads();  // every wave has read stage `buf`; the other stage is complete
   }
-  gemm_big_epilogue(p, acc, m0, n0, wc, wp, lane, tid, gsmf);
+  gemm_big_epilogue<4>(p, acc, m0, n0, wc, wp, lane, tid, gsmf);
 }
 
 // =================================================================================================
@@ -2765,17 +2777,38 @@ static bool x3_big_eligible(const AzConvArgs* a, int64_t npix, int kstep = GBK) 
 }
 static double x3_round_eff(int64_t wgs) { return (double)wgs / (double)(((wgs + 255) / 256) * 256); }
 // -> number of 256-cout tiles for the big kernel (0: none); *splitk = the split-K it wants (1 unless the K loop is deep)
-static int x3_big_plan(const AzConvArgs* a, int64_t npix, int* splitk, int kstep = GBK) {
+// *ct (bf16x3 kernel only) = the tile's couts: 256, or 192 where that makes whole rounds (768 = 4 x 192 and 2304 = 12 x 192 against
+// 3 and 9 x 256 on 64 pixel tiles: 256 and 768 workgroups instead of 192 and 576); not for the SwiGLU / q-k preparation epilogues,
+// whose lane maps assume 32 channel quads per pixel row.  AZ_X3_BIG = 3 forces it (A/B).
+static int x3_big_plan(const AzConvArgs* a, int64_t npix, int* splitk, int kstep = GBK, int* ct = nullptr) {
   *splitk = 1;
+  if (ct) *ct = GB;
   if (!x3_big_eligible(a, npix, kstep)) return 0;
   const char* force = getenv("AZ_X3_BIG");
   const int all = (a->cout_s + GB - 1) / GB;
+#ifdef AZ_X3_NO192  // (A/B: the plan without the 192-cout tile)
+  const bool ok192 = false;
+#else
+  const bool ok192 = ct != nullptr && kstep == GBK && a->act <= 3;
+#endif
+  const int all192 = (a->cout_s + 191) / 192;
   if (force && force[0]) {
     if (force[0] == '1' && force[1] == ',') *splitk = atoi(force + 2);  // "1,S": every eligible launch on big tiles with split-K S (A/B)
-    return force[0] == '1' ? all : 0;
+    if (force[0] == '3' && ok192) {
+      *ct = 192;
+      return all192;
+    }
+    return force[0] == '1' || force[0] == '3' ? all : 0;
   }
   const int64_t tn = (npix + GB - 1) / GB;
   if (a->cout_s < 192) return 0;
+  if (ok192 && all192 * tn >= 176) {
+    const double e192 = x3_round_eff(all192 * tn) * a->cout_s / (all192 * 192.0), e256 = x3_round_eff(all * tn) * a->cout_s / (all * 256.0);
+    if (e192 >= 0.9 && e192 > e256 + 0.08) {
+      *ct = 192;
+      return all192;
+    }
+  }
   if (all * tn < 176) {  // (128 tiles = half a round: 74 vs 62 us on 16384 x 512 -> 512; 192 tiles win)
     // ... unless the K loop is deep enough to split in two: 9216 x 2048 -> 768 (108 tiles) 168 us as 216 half-K tiles against 182 on
     // 128 x 128 tiles and 210 unsplit; 768-channel K loops lose that way (84 vs 79 us)
@@ -2981,8 +3014,9 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   }
   int big_sk = 1;
   // 256-cout tiles of the 256 x 256 kernel (bf16x3: K steps of 16 channels; half-precision operands: 64)
-  int nbig = half == 3 ? x3_big_plan(a, npix64, &big_sk) : (half == 1 || half == 2) ? x3_big_plan(a, npix64, &big_sk, HGK) : 0;
-  if (nbig > 0 && nbig * GB < a->cout_s && a->splitk > 1) nbig = 0;  // (a remainder launch would need the same slabs: one kernel then)
+  int big_ct = GB;
+  int nbig = half == 3 ? x3_big_plan(a, npix64, &big_sk, GBK, &big_ct) : (half == 1 || half == 2) ? x3_big_plan(a, npix64, &big_sk, HGK) : 0;
+  if (nbig > 0 && nbig * big_ct < a->cout_s && a->splitk > 1) nbig = 0;  // (a remainder launch would need the same slabs: one kernel then)
   const bool big = nbig > 0;
   const int bk = big ? (half == 3 ? GBK : HGK) : half == 3 ? XBK : (half ? HBK : (k16 ? 16 : BK));
   p.nkc0 = (a->c0s + bk - 1) / bk;
@@ -3029,10 +3063,11 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   AZ_REQUIRE(nwg < (1ll << 31), AZ_E_SHAPE);
   if (big) {
-    if (half == 3) hipLaunchKernelGGL(conv_gemm_x3_big_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
+    if (half == 3 && big_ct == 192) hipLaunchKernelGGL(conv_gemm_x3_big_kernel<3>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
+    else if (half == 3) hipLaunchKernelGGL(conv_gemm_x3_big_kernel<4>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else if (half == 2) hipLaunchKernelGGL(conv_gemm_half_big_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else hipLaunchKernelGGL(conv_gemm_half_big_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
-    if (nbig * GB < a->cout_s) {  // the remaining output channels: 128 x 128 tiles, K tiles of 32
+    if (nbig * big_ct < a->cout_s) {  // the remaining output channels (256-cout tiles only): 128 x 128 tiles, K tiles of 32
       ConvP q = p;
       const int sbk = half == 3 ? XBK : HBK;
       q.nkc0 = (a->c0s + sbk - 1) / sbk;

@@ -1107,7 +1107,7 @@ def test_x3_gemm_big_tile(az, monkeypatch, shape, act, res):
     if res:
         ref = ref + r.double()
     outs = {}
-    for big in ("0", "1", "plan"):  # 128 x 128 everywhere / 256 x 256 wherever eligible / the library's own plan (big tiles + remainder)
+    for big in ("0", "1", "3", "plan"):  # 128 x 128 everywhere / 256 x 256 wherever eligible / 192-cout tiles / the library's own plan
         if big == "plan":
             monkeypatch.delenv("AZ_X3_BIG")
         else:
@@ -1121,9 +1121,9 @@ def test_x3_gemm_big_tile(az, monkeypatch, shape, act, res):
         outs[big] = from_nhwc(y.buf.reshape(B, T, 1, -1), Cout).double().cpu()
     scale = ref.abs().max().item()
     e0, e1 = (outs["0"] - ref).abs().max().item() / scale, (outs["1"] - ref).abs().max().item() / scale
-    e2 = (outs["plan"] - ref).abs().max().item() / scale
-    print(shape, act, "128 tile", e0, "256 tile", e1, "plan", e2, "between", (outs["1"] - outs["0"]).abs().max().item() / scale)
-    assert e1 < 2e-6 and e0 < 2e-6 and e2 < 2e-6
+    e2, e3 = (outs["plan"] - ref).abs().max().item() / scale, (outs["3"] - ref).abs().max().item() / scale
+    print(shape, act, "128 tile", e0, "256 tile", e1, "192-cout tile", e3, "plan", e2, "between", (outs["1"] - outs["0"]).abs().max().item() / scale)
+    assert e1 < 2e-6 and e0 < 2e-6 and e2 < 2e-6 and e3 < 2e-6
 
 
 @pytest.mark.parametrize("shape", [(4, 64, 64, 256, 256, 256), (1, 96, 100, 64, 128, 320), (2, 48, 48, 512, 256, 256)])
