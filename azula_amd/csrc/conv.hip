@@ -1311,7 +1311,10 @@ __device__ __forceinline__ void gemm_big_epilogue(const ConvP& p, const f32x16 (
 }
 
 
-template <int NCT>  // 32-cout MFMA tiles per wave: 4 = the 256-cout tile, 3 = a 192-cout tile (768 = 4 x 192: whole rounds where 3 x 256 leaves a quarter of the CUs idle)
+// NCT = 32-cout MFMA tiles per wave: 4 = the 256-cout tile, 3 = a 192-cout tile (768 = 4 x 192: whole rounds where 3 x 256 leaves a
+// quarter of the CUs idle).  TAPS: k x k filters with a stride and zero padding (the strided 3x3 convolutions of a UNet's
+// descent): the K walk is tap-major, the loader thread's pixel row is fixed, so a tap is one offset and one bounds test per step.
+template <int NCT, bool TAPS = false>
 __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
   constexpr int CT = 64 * NCT;  // couts per tile
   __shared__ __attribute__((aligned(16))) float gsmf[G_LDS_BYTES / 4];
@@ -1335,17 +1338,26 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
   const int kt_end = min(p.nk, kt_begin + p.kps);
   const int nk = kt_end - kt_begin;
 
-  const int64_t wplane = (int64_t)a.cout_s * p.cin_s;  // elements per weight piece
+  const int64_t wtap = (int64_t)a.cout_s * p.cin_s;               // elements per (piece, tap)
+  const int64_t wplane = (int64_t)a.ksize * a.ksize * wtap;       // elements per weight piece
+  const int64_t spix = (int64_t)a.batch * a.h0 * a.w0;             // source pixels (= p.npix for a 1x1, stride-1 launch)
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, (unsigned)(3 * wplane * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (unsigned)((int64_t)p.npix * a.c0s * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (unsigned)(spix * a.c0s * 4), 0x00020000);
   // (two sources -- a channel concatenation read in place, the 1x1 skip convolutions of ADM's decoder: K steps [0, nkc0) walk
   //  source 0, the rest source 1; the packed weights hold source 1's channels from column c0s on)
   const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? (unsigned)((int64_t)p.npix * a.c1s * 4) : 0u, 0x00020000);
+      (void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? (unsigned)(spix * a.c1s * 4) : 0u, 0x00020000);
 
   // loaders: thread -> row tid >> 1 of both operands; weights: chunk tid & 1 (8 k-values) of each piece, activations: the 8
   // fp32 channels of that chunk (two adjacent lanes read one 64-byte unit)
   const int lrow = tid >> 1, lch = tid & 1;
+  // (TAPS) the output pixel of this thread's row: image plane base, top-left input coordinate of its window
+  const bool rowok = n0 + lrow < p.npix;
+  const int hw_out = a.hout * a.wout;
+  const int nn_l = rowok ? n0 + lrow : 0;
+  const int b_l = nn_l / hw_out, rem_l = nn_l - b_l * hw_out, oh_l = rem_l / a.wout;
+  const int ihb = oh_l * a.stride - a.pad, iwb = (rem_l - oh_l * a.wout) * a.stride - a.pad, pb_l = b_l * a.h0;
+  const int nk_tap = p.nkc0 + p.nkc1;
   const int co_l = min(m0 + lrow, a.cout_s - 1);  // (rows past the edge: a valid duplicate, never stored)
   const int px_l = min(n0 + lrow, p.npix - 1);
   const unsigned voffW = lrow < CT ? (unsigned)(((int64_t)co_l * p.cin_s + lch * 8) * 2) : OOB;  // (a 192-cout tile: rows 192 .. 255 stage zeros)
@@ -1355,13 +1367,29 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
 
   float4 rwt[3], rxa[2];
   auto load_step = [&](int kt) __attribute__((always_inline)) {
+    if constexpr (TAPS) {
+      const int tap = kt / nk_tap, kr = kt - tap * nk_tap;  // (wave-uniform)
+      const int ky = tap / a.ksize, kx = tap - ky * a.ksize;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) rwt[pl] = buf_ld4(rw, voffW, (unsigned)((pl * wplane + (int64_t)kt * GBK) * 2));
-    const bool s1 = kt >= p.nkc0;  // (wave-uniform; selects, not a branch: the iteration stays one basic block)
-    const __amdgpu_buffer_rsrc_t r = s1 ? rx1 : rx;
-    const unsigned vo = s1 ? voffX1 : voffX, so = (unsigned)((s1 ? kt - p.nkc0 : kt) * GBK * 4);
-    rxa[0] = buf_ld4(r, vo, so);
-    rxa[1] = buf_ld4(r, vo + 16u, so);
+      for (int pl = 0; pl < 3; ++pl) rwt[pl] = buf_ld4(rw, voffW, (unsigned)((pl * wplane + tap * wtap + (int64_t)kr * GBK) * 2));
+      const int ih = ihb + ky, iw = iwb + kx;
+      const bool ok = rowok && (unsigned)ih < (unsigned)a.h0 && (unsigned)iw < (unsigned)a.w0;  // (zero padding: reads zeros)
+      const int pix = (pb_l + ih) * a.w0 + iw;
+      const bool s1 = kr >= p.nkc0;
+      const __amdgpu_buffer_rsrc_t r = s1 ? rx1 : rx;
+      const unsigned vo = ok ? (unsigned)(((int64_t)pix * (s1 ? a.c1s : a.c0s) + lch * 8) * 4) : OOB;
+      const unsigned so = (unsigned)((s1 ? kr - p.nkc0 : kr) * GBK * 4);
+      rxa[0] = buf_ld4(r, vo, so);
+      rxa[1] = buf_ld4(r, ok ? vo + 16u : OOB, so);
+    } else {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) rwt[pl] = buf_ld4(rw, voffW, (unsigned)((pl * wplane + (int64_t)kt * GBK) * 2));
+      const bool s1 = kt >= p.nkc0;  // (wave-uniform; selects, not a branch: the iteration stays one basic block)
+      const __amdgpu_buffer_rsrc_t r = s1 ? rx1 : rx;
+      const unsigned vo = s1 ? voffX1 : voffX, so = (unsigned)((s1 ? kt - p.nkc0 : kt) * GBK * 4);
+      rxa[0] = buf_ld4(r, vo, so);
+      rxa[1] = buf_ld4(r, vo + 16u, so);
+    }
   };
   auto store_step = [&](int buf) __attribute__((always_inline)) {
     char* st = smem + buf * GSTAGE + lds_row;
@@ -2770,10 +2798,13 @@ __global__ __launch_bounds__(512, 2) void conv_winograd4_kernel(Wino4P p) {
 // (192 tiles, 0.75 of a round) 117 vs 125, 768 -> 2304 (576 tiles = 2.25 rounds) a tie -- hence 8 of its 9 cout tiles big: 311 vs 338;
 // 3072 -> 768 387 vs 444 (and no split-K combine).
 // AZ_X3_BIG = 0 / 1: never / every eligible launch whole (A/B measurements; read per call).
+static bool x3_big_taps(const AzConvArgs* a) { return !(a->ksize == 1 && a->stride == 1 && a->pad == 0); }
 static bool x3_big_eligible(const AzConvArgs* a, int64_t npix, int kstep = GBK) {  // kstep: 16 (bf16x3) / 64 (half-precision operands)
-  if (a->src1 && !(a->up1 == 0 && a->h1 == a->hin && a->w1 == a->win && a->c1s % kstep == 0 && npix * a->c1s * 4 < (1ll << 31))) return false;
-  return a->ksize == 1 && a->stride == 1 && a->pad == 0 && a->up0 == 0 && !a->aniso && a->depth == 0 && !a->dst_nchw &&
-         a->h0 == a->hin && a->w0 == a->win && a->c0s % kstep == 0 && a->c0s + a->c1s >= 64 && npix * a->c0s * 4 < (1ll << 31);
+  const int64_t spix = (int64_t)a->batch * a->h0 * a->w0;
+  if (a->src1 && !(a->up1 == 0 && a->h1 == a->hin && a->w1 == a->win && a->c1s % kstep == 0 && spix * a->c1s * 4 < (1ll << 31))) return false;
+  if (x3_big_taps(a) && (kstep != GBK || a->pad_mode != 0)) return false;  // (filters with taps: the bf16x3 kernel, zero padding)
+  return a->up0 == 0 && !a->aniso && a->depth == 0 && !a->dst_nchw && a->h0 == a->hin && a->w0 == a->win && a->c0s % kstep == 0 &&
+         a->c0s + a->c1s >= 64 && spix * a->c0s * 4 < (1ll << 31);
 }
 static double x3_round_eff(int64_t wgs) { return (double)wgs / (double)(((wgs + 255) / 256) * 256); }
 // -> number of 256-cout tiles for the big kernel (0: none); *splitk = the split-K it wants (1 unless the K loop is deep)
@@ -2789,7 +2820,7 @@ static int x3_big_plan(const AzConvArgs* a, int64_t npix, int* splitk, int kstep
 #ifdef AZ_X3_NO192  // (A/B: the plan without the 192-cout tile)
   const bool ok192 = false;
 #else
-  const bool ok192 = ct != nullptr && kstep == GBK && a->act <= 3;
+  const bool ok192 = ct != nullptr && kstep == GBK && a->act <= 3 && !x3_big_taps(a);
 #endif
   const int all192 = (a->cout_s + 191) / 192;
   if (force && force[0]) {
@@ -2812,7 +2843,7 @@ static int x3_big_plan(const AzConvArgs* a, int64_t npix, int* splitk, int kstep
   if (all * tn < 176) {  // (128 tiles = half a round: 74 vs 62 us on 16384 x 512 -> 512; 192 tiles win)
     // ... unless the K loop is deep enough to split in two: 9216 x 2048 -> 768 (108 tiles) 168 us as 216 half-K tiles against 182 on
     // 128 x 128 tiles and 210 unsplit; 768-channel K loops lose that way (84 vs 79 us)
-    if (all * tn * 2 >= 176 && a->c0s + a->c1s >= 1536) {
+    if (all * tn * 2 >= 176 && (int64_t)a->ksize * a->ksize * (a->c0s + a->c1s) >= 1536) {
       *splitk = 2;
       return all;
     }
@@ -3064,6 +3095,7 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   AZ_REQUIRE(nwg < (1ll << 31), AZ_E_SHAPE);
   if (big) {
     if (half == 3 && big_ct == 192) hipLaunchKernelGGL(conv_gemm_x3_big_kernel<3>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
+    else if (half == 3 && x3_big_taps(a)) hipLaunchKernelGGL((conv_gemm_x3_big_kernel<4, true>), dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else if (half == 3) hipLaunchKernelGGL(conv_gemm_x3_big_kernel<4>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else if (half == 2) hipLaunchKernelGGL(conv_gemm_half_big_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else hipLaunchKernelGGL(conv_gemm_half_big_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
@@ -3072,7 +3104,7 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
       const int sbk = half == 3 ? XBK : HBK;
       q.nkc0 = (a->c0s + sbk - 1) / sbk;
       q.nkc1 = (a->c1s + sbk - 1) / sbk;
-      q.nk = q.nkc0 + q.nkc1;
+      q.nk = a->ksize * a->ksize * (q.nkc0 + q.nkc1);
       q.kps = (q.nk + splitk - 1) / splitk;
       AZ_REQUIRE((q.nk + q.kps - 1) / q.kps == splitk, AZ_E_SHAPE);  // (the same slabs as the big launch)
       q.m_tile0 = nbig * (GB / BM);

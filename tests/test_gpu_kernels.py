@@ -1185,3 +1185,29 @@ def test_half_gemm_big_tile(az, monkeypatch, shape, half):
     print(shape, half, "128 vs 256 tile", (outs["1"] - outs["0"]).abs().max().item(), "plan", (outs["plan"] - outs["0"]).abs().max().item())
     # (equal to the last bit where the 128 x 128 launch is not split along K; a split changes the summation order)
     assert (outs["1"] - outs["0"]).abs().max().item() < 2e-5 and (outs["plan"] - outs["0"]).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks,stride", [(2, 64, 256, 40, 36, 3, 2), (1, 32, 320, 33, 47, 3, 1), (3, 48, 256, 17, 19, 5, 2),
+                                                      (2, 128, 256, 64, 64, 3, 2), (1, 64, 200, 30, 30, 1, 2), (2, 32, 256, 21, 21, 7, 3)])
+def test_x3_big_tile_with_taps(az, monkeypatch, B, Cin, Cout, H, W, ks, stride):
+    """conv_gemm_x3_big_kernel<4, TAPS>: k x k filters, strides, zero padding, tiles that span image borders and several images --
+    against the 128 x 128 bf16x3 kernel (same products; the K walk is tap-major in both) and an fp64 convolution."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(H * W + ks)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    b = torch.randn(Cout, generator=g)
+    ref = F.silu(F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=ks // 2))
+    outs = {}
+    for big in ("0", "1"):
+        monkeypatch.setenv("AZ_X3_BIG", big)
+        bld = Builder(torch.device("cuda"))
+        xin = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
+        y = bld.conv(xin, bld.pack_conv(dev(w), dev(b)), Cout, stride=stride, act=1, winograd="x3")
+        bld.finish()
+        bld.tape.run()
+        outs[big] = from_nhwc(y.buf.reshape(B, y.H, y.W, -1), Cout).double().cpu()
+    e0, e1 = (outs["0"] - ref).abs().max().item(), (outs["1"] - ref).abs().max().item()
+    print((B, Cin, Cout, H, W, ks, stride), "128 tile", e0, "256 tile", e1, "between", (outs["1"] - outs["0"]).abs().max().item())
+    assert e0 < conv_tol(Cin, ks, "x3") and e1 < conv_tol(Cin, ks, "x3")
