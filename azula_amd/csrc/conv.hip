@@ -1480,7 +1480,7 @@ constexpr int HGPLANE = GB * HGK * 2;         // bytes per operand plane of a st
 constexpr int HGSTAGE = 2 * HGPLANE;          // 64 KB
 static_assert(2 * HGSTAGE <= G_LDS_BYTES, "stages must fit under the epilogue buffer");
 
-template <bool F16>
+template <bool F16, bool TAPS = false>  // TAPS: k x k filters with a stride and zero padding, as in conv_gemm_x3_big_kernel
 __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
   using H8 = typename std::conditional<F16, f16x8, bf16x8>::type;
   using H4 = typename std::conditional<F16, f16x4, bf16x4>::type;
@@ -1505,21 +1505,31 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
   const int kt_end = min(p.nk, kt_begin + p.kps);
   const int nk = kt_end - kt_begin;
 
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, (unsigned)((int64_t)a.cout_s * p.cin_s * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (unsigned)((int64_t)p.npix * a.c0s * 4), 0x00020000);
+  const int64_t wtap = (int64_t)a.cout_s * p.cin_s;     // elements per tap
+  const int64_t spix = (int64_t)a.batch * a.h0 * a.w0;   // source pixels (= p.npix for a 1x1, stride-1 launch)
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, (unsigned)(a.ksize * a.ksize * wtap * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (unsigned)(spix * a.c0s * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? (unsigned)((int64_t)p.npix * a.c1s * 4) : 0u, 0x00020000);
+      (void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? (unsigned)(spix * a.c1s * 4) : 0u, 0x00020000);
 
   // loaders: thread -> chunk tid & 7 (8 k-values) of rows (tid >> 3) + 64 i of both operands: the 8 lanes of a row read 128
   // (weights) / 256 (activations) contiguous bytes
   const int lch = tid & 7, lr0 = tid >> 3;
   unsigned voffW[4], voffX[4], voffX1[4];
   int lds_row[4];
+  int ihb[4], iwb[4], pb[4];  // (TAPS) top-left input coordinate of each row's window, its image's first source row; pb < 0: no pixel
+  const int hw_out = a.hout * a.wout, nk_tap = p.nkc0 + p.nkc1;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = lr0 + 64 * i;
     const int co = min(m0 + row, a.cout_s - 1);  // (rows past the edge: a valid duplicate, never stored)
     const int px = min(n0 + row, p.npix - 1);
+    {
+      const int b_ = px / hw_out, rem = px - b_ * hw_out, oh = rem / a.wout;
+      ihb[i] = oh * a.stride - a.pad;
+      iwb[i] = (rem - oh * a.wout) * a.stride - a.pad;
+      pb[i] = n0 + row < p.npix ? b_ * a.h0 : -1;
+    }
     voffW[i] = (unsigned)(((int64_t)co * p.cin_s + lch * 8) * 2);
     voffX[i] = (unsigned)(((int64_t)px * a.c0s + lch * 8) * 4);
     voffX1[i] = (unsigned)(((int64_t)px * a.c1s + lch * 8) * 4);
@@ -1527,15 +1537,33 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
   }
   float4 rwt[4], rxa[4][2];
   auto load_step = [&](int kt) __attribute__((always_inline)) {
-    const bool s1 = kt >= p.nkc0;  // (wave-uniform; selects, not a branch)
-    const __amdgpu_buffer_rsrc_t r = s1 ? rx1 : rx;
-    const unsigned so = (unsigned)((s1 ? kt - p.nkc0 : kt) * HGK * 4);
+    if constexpr (TAPS) {
+      const int tap = kt / nk_tap, kr = kt - tap * nk_tap;  // (wave-uniform)
+      const int ky = tap / a.ksize, kx = tap - ky * a.ksize;
+      const bool s1 = kr >= p.nkc0;
+      const __amdgpu_buffer_rsrc_t r = s1 ? rx1 : rx;
+      const int cs = s1 ? a.c1s : a.c0s;
+      const unsigned so = (unsigned)((s1 ? kr - p.nkc0 : kr) * HGK * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      rwt[i] = buf_ld4(rw, voffW[i], (unsigned)(kt * HGK * 2));
-      const unsigned vo = s1 ? voffX1[i] : voffX[i];
-      rxa[i][0] = buf_ld4(r, vo, so);
-      rxa[i][1] = buf_ld4(r, vo + 16u, so);
+      for (int i = 0; i < 4; ++i) {
+        rwt[i] = buf_ld4(rw, voffW[i], (unsigned)((tap * wtap + (int64_t)kr * HGK) * 2));
+        const int ih = ihb[i] + ky, iw = iwb[i] + kx;
+        const bool ok = pb[i] >= 0 && (unsigned)ih < (unsigned)a.h0 && (unsigned)iw < (unsigned)a.w0;  // (zero padding: reads zeros)
+        const unsigned vo = ok ? (unsigned)((((int64_t)(pb[i] + ih) * a.w0 + iw) * cs + lch * 8) * 4) : OOB;
+        rxa[i][0] = buf_ld4(r, vo, so);
+        rxa[i][1] = buf_ld4(r, ok ? vo + 16u : OOB, so);
+      }
+    } else {
+      const bool s1 = kt >= p.nkc0;  // (wave-uniform; selects, not a branch)
+      const __amdgpu_buffer_rsrc_t r = s1 ? rx1 : rx;
+      const unsigned so = (unsigned)((s1 ? kt - p.nkc0 : kt) * HGK * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rwt[i] = buf_ld4(rw, voffW[i], (unsigned)(kt * HGK * 2));
+        const unsigned vo = s1 ? voffX1[i] : voffX[i];
+        rxa[i][0] = buf_ld4(r, vo, so);
+        rxa[i][1] = buf_ld4(r, vo + 16u, so);
+      }
     }
   };
   auto store_step = [&](int buf) __attribute__((always_inline)) {
@@ -2802,7 +2830,7 @@ static bool x3_big_taps(const AzConvArgs* a) { return !(a->ksize == 1 && a->stri
 static bool x3_big_eligible(const AzConvArgs* a, int64_t npix, int kstep = GBK) {  // kstep: 16 (bf16x3) / 64 (half-precision operands)
   const int64_t spix = (int64_t)a->batch * a->h0 * a->w0;
   if (a->src1 && !(a->up1 == 0 && a->h1 == a->hin && a->w1 == a->win && a->c1s % kstep == 0 && spix * a->c1s * 4 < (1ll << 31))) return false;
-  if (x3_big_taps(a) && (kstep != GBK || a->pad_mode != 0)) return false;  // (filters with taps: the bf16x3 kernel, zero padding)
+  if (x3_big_taps(a) && a->pad_mode != 0) return false;  // (filters with taps: zero padding only)
   return a->up0 == 0 && !a->aniso && a->depth == 0 && !a->dst_nchw && a->h0 == a->hin && a->w0 == a->win && a->c0s % kstep == 0 &&
          a->c0s + a->c1s >= 64 && spix * a->c0s * 4 < (1ll << 31);
 }
@@ -3097,7 +3125,9 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     if (half == 3 && big_ct == 192) hipLaunchKernelGGL(conv_gemm_x3_big_kernel<3>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else if (half == 3 && x3_big_taps(a)) hipLaunchKernelGGL((conv_gemm_x3_big_kernel<4, true>), dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else if (half == 3) hipLaunchKernelGGL(conv_gemm_x3_big_kernel<4>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
+    else if (half == 2 && x3_big_taps(a)) hipLaunchKernelGGL((conv_gemm_half_big_kernel<true, true>), dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else if (half == 2) hipLaunchKernelGGL(conv_gemm_half_big_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
+    else if (x3_big_taps(a)) hipLaunchKernelGGL((conv_gemm_half_big_kernel<false, true>), dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else hipLaunchKernelGGL(conv_gemm_half_big_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     if (nbig * big_ct < a->cout_s) {  // the remaining output channels (256-cout tiles only): 128 x 128 tiles, K tiles of 32
       ConvP q = p;

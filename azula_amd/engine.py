@@ -421,7 +421,7 @@ class Builder:
         elif self.half is not None:
             a.weight = packed.direct_half(self.half == torch.float16).data_ptr()
             a.splitk = lib.az_conv2d_suggest_splitk(npix, a.cout_s, cin_s, ks)
-            if ks == 1 and a.c0s % 64 == 0 and a.c1s % 64 == 0:  # (token GEMMs: the 256 x 256-tile kernel has its own rule)
+            if a.c0s % 64 == 0 and a.c1s % 64 == 0:  # (the 256 x 256-tile kernel has its own rule where it takes the launch)
                 a.splitk = lib.az_conv2d_x3_suggest_splitk(C.byref(a))
             name = "az_conv2d_f16_f32" if self.half == torch.float16 else "az_conv2d_bf16_f32"
         else:

@@ -1214,3 +1214,30 @@ def test_x3_big_tile_with_taps(az, monkeypatch, B, Cin, Cout, H, W, ks, stride):
     e0, e1 = (outs["0"] - ref).abs().max().item(), (outs["1"] - ref).abs().max().item()
     print((B, Cin, Cout, H, W, ks, stride), "128 tile", e0, "256 tile", e1, "between", (outs["1"] - outs["0"]).abs().max().item())
     assert e0 < conv_tol(Cin, ks, "x3") and e1 < conv_tol(Cin, ks, "x3")
+
+
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks,stride", [(2, 64, 256, 40, 36, 3, 2), (1, 128, 320, 33, 47, 3, 1), (2, 64, 256, 17, 19, 5, 2),
+                                                      (1, 64, 200, 30, 30, 1, 2)])
+def test_half_big_tile_with_taps(az, monkeypatch, B, Cin, Cout, H, W, ks, stride, half):
+    """conv_gemm_half_big_kernel<F16, TAPS>: k x k filters, strides, zero padding on the 256 x 256 tile of half-precision modules,
+    against the 128 x 128 half kernel and an fp64 convolution of the rounded operands."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(H * W + ks)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    b = torch.randn(Cout, generator=g)
+    exact = F.conv2d(x.to(half).double(), w.to(half).double(), b.double(), stride=stride, padding=ks // 2)
+    outs = {}
+    for big in ("0", "1"):
+        monkeypatch.setenv("AZ_X3_BIG", big)
+        bld = Builder(torch.device("cuda"), half=half)
+        xin = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
+        y = bld.conv(xin, bld.pack_conv(dev(w), dev(b)), Cout, stride=stride)
+        bld.finish()
+        bld.tape.run()
+        outs[big] = from_nhwc(y.buf.reshape(B, y.H, y.W, -1), Cout).double().cpu()
+    e0, e1 = (outs["0"] - exact).abs().max().item(), (outs["1"] - exact).abs().max().item()
+    print((B, Cin, Cout, H, W, ks, stride), half, "128 tile", e0, "256 tile", e1)
+    assert e0 < conv_tol(Cin, ks) and e1 < conv_tol(Cin, ks)
