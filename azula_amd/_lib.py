@@ -259,6 +259,8 @@ PROTOTYPES: dict[str, list] = {
     "az_conv2d_winograd_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_winograd_suggest_splitk": [i64, i32, i32, i32, i32],
     "az_winograd_pack_filter_f32": [vp, vp, i32, i32, i32, i32, i32, i32, c_stream],
+    "az_conv2d_winograd_x3_f32": [C.POINTER(AzConvArgs), c_stream],
+    "az_winograd_pack_filter_x3_f32": [vp, vp, i32, i32, i32, i32, i32, i32, c_stream],
     "az_conv2d_winograd4_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_winograd4_suggest_splitk": [i64, i32, i32, i32, i32],
     "az_winograd4_pack_filter_f32": [vp, vp, i32, i32, i32, i32, i32, i32, c_stream],

@@ -15,7 +15,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["transition.hip", "layout.hip", "linear.hip", "norm.hip", "conv.hip", "attention.hip", "graph.hip", "calib.hip"]
+SOURCES = ["transition.hip", "layout.hip", "linear.hip", "norm.hip", "conv.hip", "wino_x3.hip", "attention.hip", "graph.hip", "calib.hip"]
 LIB = os.path.join(HERE, "libazula_amd.so")
 OBJ_DIR = os.path.join(HERE, "_obj")
 FLAGS = [
@@ -71,7 +71,7 @@ def _stale(target: str, deps: list[str]) -> bool:
 
 def build(force: bool = False, verbose: bool = False, regen: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
-    headers = [os.path.join(HERE, "common.h"), os.path.join(ROOT, "include", "azula_amd.h"), os.path.join(HERE, "wino_kloop.inc")]
+    headers = [os.path.join(HERE, "common.h"), os.path.join(HERE, "conv_shared.h"), os.path.join(ROOT, "include", "azula_amd.h"), os.path.join(HERE, "wino_kloop.inc")]
     headers.append(os.path.join(HERE, "igemm_kloop.inc"))
     # The hand-scheduled K loops are COMMITTED sources.  A build never rewrites them (mtime order after a checkout is arbitrary
     # and an install may be read-only); it only writes one that is missing.  Developers regenerate with `--regen` (or by running

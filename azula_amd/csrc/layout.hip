@@ -164,6 +164,56 @@ __global__ __launch_bounds__(256) void winograd_filter_kernel(float* __restrict_
   }
 }
 
+// The same transform for az_conv2d_winograd_x3_f32 (wino_x3.hip): U rounded to fp32 exactly as above, then split into three bf16
+// pieces (u = u1 + u2 + u3 exactly, 8-bit slices of the significand by truncation) and stored in the order the kernel's waves load
+// it, as v_mfma_f32_32x32x16_bf16 A fragments: [16-cin step][64-cout block][wave w = 0..7][nu][piece][lane][8 bf16], where wave w
+// owns frequency row xi = w & 3 of couts 32 (w >> 2) .. + 31 and lane (l31 = lane & 31, h = lane >> 5) holds
+// U[xi, nu][cout l31][channels 8 h .. 8 h + 7] -- twelve contiguous 1 KB pieces per wave and step; the filter never passes through LDS.
+__global__ __launch_bounds__(256) void winograd_filter_x3_kernel(unsigned short* __restrict__ dst, const float* __restrict__ src,
+                                                                 int cout, int cin, int cin0, int nk0, int nk, int cblocks) {
+  const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+  const int64_t total = (int64_t)nk * cblocks * 8 * 4 * 64 * 8;  // values (three pieces each)
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int k8 = (int)(e & 7);
+    const int ln = (int)((e >> 3) & 63);
+    const int nu = (int)((e >> 9) & 3);
+    const int w = (int)((e >> 11) & 7);
+    const int64_t r = e >> 14;
+    const int cbk = (int)(r % cblocks);
+    const int kt = (int)(r / cblocks);
+    const int co = cbk * 64 + (w >> 2) * 32 + (ln & 31);
+    const int k = 8 * (ln >> 5) + k8;
+    int ci = -1;
+    if (kt < nk0) {
+      const int pc = kt * 16 + k;
+      if (pc < cin0) ci = pc;
+    } else {
+      const int pc = (kt - nk0) * 16 + k;
+      if (pc < cin - cin0) ci = cin0 + pc;
+    }
+    float v = 0.f;
+    if (co < cout && ci >= 0) {
+      const float* g = src + ((int64_t)co * cin + ci) * 9;
+      const int xi = w & 3;
+      double acc = 0.0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc += G[xi][a] * (double)g[a * 3 + b] * G[nu][b];
+      v = (float)acc;
+    }
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const float r1 = v - __builtin_bit_cast(float, u & 0xFFFF0000u);
+    const unsigned u1 = __builtin_bit_cast(unsigned, r1);
+    const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+    unsigned short* d = dst + ((((r * 8 + w) * 4 + nu) * 3) * 64 + ln) * 8 + k8;  // piece 0; pieces are 512 elements apart
+    d[0] = (unsigned short)(u >> 16);
+    d[512] = (unsigned short)(u1 >> 16);
+    d[1024] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+  }
+}
+
 // Winograd F(4x4,3x3) filter transform U = G g G^T (6x6 per filter, interpolation points 0, +-1, +-2, inf;
 // fp64 accumulate, rounded once) in the layout conv_winograd4_kernel streams:
 // [4-cin chunk][64-cout block][36][64][4].
@@ -309,6 +359,18 @@ int az_winograd_pack_filter_f32(float* dst, const float* src, int32_t cout, int3
   const int64_t total = (int64_t)nk * cblocks * 16 * 64 * 8;
   hipLaunchKernelGGL(winograd_filter_kernel, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream), dst, src,
                      cout, cin, cin0, nk0, nk, cblocks);
+  return az_launch_status();
+}
+
+int az_winograd_pack_filter_x3_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t cin0, int32_t nk0,
+                                   int32_t nk, int32_t cblocks, az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(cout > 0 && cin > 0 && cin0 >= 0 && cin0 <= cin && nk0 * 16 >= cin0 && (nk - nk0) * 16 >= cin - cin0 &&
+                 cblocks * 64 >= cout,
+             AZ_E_SHAPE);
+  const int64_t total = (int64_t)nk * cblocks * 8 * 4 * 64 * 8;
+  hipLaunchKernelGGL(winograd_filter_x3_kernel, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream),
+                     (unsigned short*)dst, src, cout, cin, cin0, nk0, nk, cblocks);
   return az_launch_status();
 }
 

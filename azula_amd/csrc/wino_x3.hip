@@ -1,0 +1,416 @@
+// Winograd F(2x2, 3x3) with the 16 frequency GEMMs on the bf16 matrix pipe at fp32 accuracy (az_conv2d_winograd_x3_f32).
+//
+//   out tile (2x2) = A^T [ sum_ci U[xi,nu][co][ci] * V[xi,nu][ci] ] A ,  U = G g G^T (offline),  V = B^T d B
+//
+// Same algorithm, same transforms and the same fused epilogue as conv_winograd_kernel (conv.hip); what changes is the
+// arithmetic of the frequency GEMMs: U (at pack time) and V (in the gather role, after B^T d B) are split EXACTLY into three
+// bf16 pieces (common.h: az_split3) and a product is the six largest of the nine partial products on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- 6 matrix instructions of 32 cycles per 16 channels where the fp32 form
+// issues 8 of 64 cycles (0.375 x the matrix-pipe time; more accurate against fp64 than v_mfma_f32_32x32x2_f32, see
+// tests/test_gpu_kernels.py::test_conv2d_x3_accuracy for the direct kernels).
+//
+// Block = 64 couts x 64 tiles (256 output pixels) x 16 frequencies, K step = 16 input channels, 8 waves = 2 per SIMD.
+//   * Wave w = (cout half w >> 2, frequency row xi = w & 3): all 64 tiles, nu = 0..3 -> 8 accumulators acc[2 nu + tile half].
+//   * U never passes through LDS: az_winograd_pack_filter_x3_f32 stores it in MFMA A-fragment order
+//     [step][cout block][wave][nu][piece][lane][8 bf16], so a wave reads its 12 fragments of a step as 12 contiguous 1 KB loads.
+//   * V lives in LDS as three planes of [frequency][tile][16 channels] bf16 rows (32 B; the two 16-byte halves of a row swapped
+//     in rows with bit 3 set: conflict-free ds_read_b128 fragments, as in the fp32 kernel).  A whole 16-channel stage would be
+//     96 KB, so the pipeline runs on HALF-stages of 8 frequencies (nu in {0, 1} | nu in {2, 3}; 48 KB each, two buffers):
+//         phase 0: MFMAs on (step s, nu 0..1) from buffer 0 | V(s, nu 2..3) -> buffer 1, raw patch of step s + 1 in flight
+//         phase 1: MFMAs on (step s, nu 2..3) from buffer 1 | B^T d of step s + 1, V(s + 1, nu 0..1) -> buffer 0
+//     one barrier per phase.  Every thread gathers: thread = (tile tid >> 3, channel pair tid & 7), 16 x 8-byte bounds-checked
+//     buffer loads per step (eight lanes read one 64-byte unit); the 16 patch offsets are parked in LDS behind the buffers.
+//   * Epilogue: the nu side of A^T M A in registers, the xi side on the way out of the LDS exchange buffer; bias / SiLU / gate /
+//     residual / split-K slabs / GroupNorm moments of the output as in the fp32 kernel.
+#include "conv_shared.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int XT = 64;                       // tiles per workgroup
+constexpr int XC = 64;                       // output channels per workgroup
+constexpr int XK = 16;                       // input channels per step
+constexpr int X_ROW = XK * 2;                // bytes of one (frequency, tile) row of a piece plane
+constexpr int X_FREQ = XT * X_ROW;           // 2 KB
+constexpr int X_PLANE = 8 * X_FREQ;          // one piece of a half-stage: 16 KB
+constexpr int X_HALF = 3 * X_PLANE;          // 48 KB
+constexpr int X_VOFF = 2 * X_HALF;           // the threads' 16 patch offsets per source: 2 x 512 x 64 B behind the two half-stage buffers
+constexpr int X_OT = 2 * XC + 4;             // epilogue: floats per tile row of one xi's [tile][px][cout] exchange buffer
+constexpr int X_EPI_BYTES = (4 * XT * X_OT + 3 * XT + 384) * 4;  // 137,472 B: four xi partials + tile table + GroupNorm partials
+constexpr int X_LDS_BYTES = X_VOFF + 2 * 512 * 64;  // 163,840 B = all of a CU's LDS (>= the epilogue's exchange buffer)
+static_assert(X_LDS_BYTES >= X_EPI_BYTES, "the epilogue reuses the K loop's LDS");
+constexpr int XU_STEP_BYTES = 16 * XC * XK * 3 * 2;  // one (step, cout block) filter chunk: 96 KB
+static_assert(X_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+
+// AFF: 0 = plain input, 1 = the input is x * scale + shift (in_affine: a GroupNorm apply pass folded into the gather), 2 = SiLU of that.
+// TAIL: a source's channel count is not a multiple of 16 -- the last step of that source masks the channel pairs past its end.
+template <int AFF, bool TAIL>
+__global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  char* const smem = reinterpret_cast<char*>(wsm);
+  const AzConvArgs& a = p.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;  // 8 waves = 2 per SIMD: wave w and w + 4 share a SIMD
+  const int wxi = wave & 3;   // the wave's frequency row xi (its 4 frequencies: xi, nu = 0..3)
+  const int wco = wave >> 2;  // which 32 of the 64 couts (all 64 tiles: two 32-tile accumulators per frequency)
+  const int l31 = lane & 31;
+  const int h = lane >> 5;
+
+  // workgroup order: see conv_winograd_kernel (contiguous ranges per XCD, rectangles of gt tile blocks x gc cout blocks)
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  const int rsz = p.gt * p.gc;
+  const int rect = wg / rsz, rin = wg - rect * rsz;
+  const int rcols = p.cblocks / p.gc;
+  const int rrow = rect / rcols;
+  const int rin_c = rin / p.gt;
+  const int tb = rrow * p.gt + (rin - rin_c * p.gt);
+  const int cb = (rect - rrow * rcols) * p.gc + rin_c;
+  const int t0 = tb * XT;
+  const int tiles_img = p.tiles_h * p.tiles_w;
+  const int b_first = t0 / tiles_img;
+
+  const int kt_begin = blockIdx.y * p.kps;
+  const int kt_end = min(p.nk, kt_begin + p.kps);
+
+  const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
+  const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
+  const int b_base = az_depth_base(a, b_first);
+  auto clamp_bytes = [](int64_t e) { return (unsigned)(e <= 0 ? 0 : (e * 4 > AZ_RSRC_CLAMP ? AZ_RSRC_CLAMP : e * 4)); };
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.weight, 0, (unsigned)((int64_t)p.nk * p.cblocks * XU_STEP_BYTES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src0 + b_base * s0_elems), 0, clamp_bytes((a.batch - b_base) * s0_elems), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src1 ? a.src1 + b_base * s1_elems : a.src0), 0, a.src1 ? clamp_bytes((a.batch - b_base) * s1_elems) : 0u, 0x00020000);
+
+  // ---- gather role (every thread): tile vj, channel pair vq of the step's 16
+  const int vj = tid >> 3;
+  const int vq = tid & 7;
+  int v_b = -1, v_bs = 0, v_ih0 = 0, v_iw0 = 0;  // v_bs: the tile's source plane relative to b_base
+  bool v_dok = true;
+  {
+    const int t = t0 + vj;
+    if (t < p.ntiles) {
+      const int b = t / tiles_img;
+      const int r = t - b * tiles_img;
+      const int th = r / p.tiles_w;
+      v_b = b - b_first;
+      v_ih0 = 2 * th - 1;
+      v_iw0 = 2 * (r - th * p.tiles_w) - 1;
+      v_bs = az_depth_plane(a, b, v_dok) - b_base;
+    }
+  }
+  uint4* const park = reinterpret_cast<uint4*>(smem + X_VOFF + tid * 64);  // source 1: + 32 KB
+  auto park_offsets = [&](int src) {  // the 16 patch offsets of source `src` (separable: 4 row parts + 4 column parts) -> LDS
+    const int cs = src ? a.c1s : a.c0s;
+    const int up = src ? a.up1 : a.up0;
+    const int hs = src ? a.h1 : a.h0;
+    const int ws = src ? a.w1 : a.w0;
+    int rpart[4], cpart[4];
+    bool rok[4], cok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ih = wrap_coord(v_ih0 + r, a.hin, a.pad_mode);
+      rok[r] = v_b >= 0 && v_dok && (unsigned)ih < (unsigned)a.hin;
+      rpart[r] = (v_bs * hs + (ih >> up)) * ws * cs * 4;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int iw = wrap_coord(v_iw0 + c, a.win, a.pad_mode);
+      cok[c] = (unsigned)iw < (unsigned)a.win;
+      cpart[c] = ((iw >> up) * cs + vq * 2) * 4;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      unsigned o[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] = rok[r] && cok[c] ? (unsigned)(rpart[r] + cpart[c]) : OOB;
+      park[src * 2048 + r] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  };
+  park_offsets(0);
+  if (a.src1) park_offsets(1);  // (a thread reads back only what it parked itself: no barrier)
+
+  f32x2 rv[16];  // raw 4x4 patch of the channel pair (index = patch row * 4 + column), then B^T d in place
+  int staged_kt = 0;
+  auto load_raw = [&](int kt) __attribute__((always_inline)) {  // kt is wave-uniform
+    const bool src1 = kt >= p.nkc0;
+    staged_kt = kt;
+    const int kc = src1 ? kt - p.nkc0 : kt;
+    const unsigned soff = (unsigned)(kc * XK * 4);
+    const __amdgpu_buffer_rsrc_t r = src1 ? rs1 : rs0;  // (selects, not a branch: the phase stays one basic block)
+    const uint4* pk = park + (src1 ? 2048 : 0);
+    unsigned o[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = pk[q];
+      o[4 * q] = v.x, o[4 * q + 1] = v.y, o[4 * q + 2] = v.z, o[4 * q + 3] = v.w;
+    }
+    if constexpr (TAIL) {
+      const bool kv = kc * XK + vq * 2 < (src1 ? a.c1s : a.c0s);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[i] = kv ? o[i] : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rv[i] = buf_ld2(r, o[i], soff);
+  };
+  // B^T d (rows of the patch), in place; with in_affine the input is act(x * scale + shift) first (padding positions stay zero)
+  auto row_transform = [&]() __attribute__((always_inline)) {
+    if constexpr (AFF != 0) {
+      const float* sp = a.in_affine + ((int64_t)(b_first + (v_b < 0 ? 0 : v_b)) * a.c0s + staged_kt * XK + vq * 2);
+      const bool kv = !TAIL || staged_kt * XK + vq * 2 < a.c0s;  // (masked pairs hold zeros and stay zero: their positions read OOB below)
+      const f32x2 sc = kv ? *reinterpret_cast<const f32x2*>(sp) : f32x2{0.f, 0.f};
+      const f32x2 sh = kv ? *reinterpret_cast<const f32x2*>(sp + (int64_t)a.batch * a.c0s) : f32x2{0.f, 0.f};
+      const uint4 o0 = park[0], o1 = park[1], o2 = park[2], o3 = park[3];
+      const unsigned o[16] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y, o2.z, o2.w, o3.x, o3.y, o3.z, o3.w};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        f32x2 v = rv[i] * sc + sh;
+        if constexpr (AFF == 2) v = f32x2{az_silu(v.x), az_silu(v.y)};
+        rv[i] = o[i] == OOB ? f32x2{0.f, 0.f} : v;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x2 d0 = rv[c], d1 = rv[4 + c], d2 = rv[8 + c], d3 = rv[12 + c];
+      rv[c] = d0 - d2;
+      rv[4 + c] = d1 + d2;
+      rv[8 + c] = d2 - d1;
+      rv[12 + c] = d1 - d3;
+    }
+  };
+  // columns side of B^T d B for one half of the frequencies (hs = 0: nu in {0, 1}; 1: nu in {2, 3}), split, -> buffer hs
+  const int vrow = vj * X_ROW + (((vq >> 2) ^ ((vj >> 3) & 1)) * 16) + (vq & 3) * 4;
+  auto produce = [&](int hs) __attribute__((always_inline)) {
+    char* dst = smem + hs * X_HALF + vrow;
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      const f32x2 u0 = rv[4 * xi], u1 = rv[4 * xi + 1], u2 = rv[4 * xi + 2], u3 = rv[4 * xi + 3];
+      const f32x2 va = hs == 0 ? u0 - u2 : u2 - u1;
+      const f32x2 vb = hs == 0 ? u1 + u2 : u1 - u3;
+      unsigned q[2][3];
+      az_split3(va.x, va.y, q[0][0], q[0][1], q[0][2]);
+      az_split3(vb.x, vb.y, q[1][0], q[1][1], q[1][2]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned*>(dst + pl * X_PLANE + (2 * xi + j) * X_FREQ) = q[j][pl];
+    }
+  };
+  // the wave's filter fragments of (step kt, half hs): A[j][piece] = U[xi, 2 hs + j] pieces, rows = couts wco * 32 + l31,
+  // k = 8 h .. 8 h + 7 of the step -- six contiguous 1 KB loads
+  const unsigned u_lane = (unsigned)(lane * 16);
+  auto load_u = [&](int kt, int hs, bf16x8 (&ua)[2][3]) __attribute__((always_inline)) {
+    const unsigned soff =  // (wave-uniform, but derived from threadIdx: readfirstlane makes it a scalar operand)
+        (unsigned)__builtin_amdgcn_readfirstlane((int)((((int64_t)kt * p.cblocks + cb) * 8 + wave) * (12 * 1024) + hs * (6 * 1024)));
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        ua[j][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((j * 3 + pl) * 1024), soff));
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+  // V fragment: frequency (xi, j) = row 2 xi + j of the half-stage, tile th * 32 + l31, half h (swapped in rows with bit 3 set)
+  const int fragB = (2 * wxi) * X_FREQ + l31 * X_ROW + ((h ^ ((l31 >> 3) & 1)) * 16);
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest partial products first (as the direct bf16x3 kernels)
+  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+  auto mma = [&](int hs, const bf16x8 (&ua)[2][3]) __attribute__((always_inline)) {
+    const char* vb = smem + hs * X_HALF + fragB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x8 fb[2][3];
+#pragma unroll
+      for (int th = 0; th < 2; ++th)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          fb[th][pl] = *reinterpret_cast<const bf16x8*>(vb + pl * X_PLANE + j * X_FREQ + th * (32 * X_ROW));
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int th = 0; th < 2; ++th) {
+          f32x16& c = acc[2 * (2 * hs + j) + th];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[j][PA[t]], fb[th][PB[t]], c, 0, 0, 0);
+        }
+    }
+  };
+
+  if (kt_begin < kt_end) {
+    bf16x8 ua[2][3], ub[2][3];
+    load_raw(kt_begin);
+    load_u(kt_begin, 0, ua);
+    row_transform();
+    produce(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int ktn = min(kt + 1, kt_end - 1);  // (the last step restages itself into a buffer nobody reads: no branch in the body)
+      // phase 0: nu in {0, 1} of step kt
+      load_u(kt, 1, ub);
+      mma(0, ua);
+      produce(1);
+      load_raw(ktn);
+      __syncthreads();
+      // phase 1: nu in {2, 3} of step kt
+      load_u(ktn, 0, ua);
+      mma(1, ub);
+      row_transform();
+      produce(0);
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+  }
+
+  // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  A wave holds one frequency row xi (nu = 0..3) of its
+  // 32 couts x 64 tiles: it applies the nu side in registers -- Z[xi][px] = M[xi][0] + M[xi][1] + M[xi][2] (px = 0),
+  // M[xi][1] - M[xi][2] - M[xi][3] (px = 1) -- and parks Z in LDS as [xi][tile][px][cout] (tile stride padded by 4 floats:
+  // conflict-free ds_write_b128).  Then ALL 8 waves read rows back, applying the xi side on the way
+  // (py = 0: Z[0] + Z[1] + Z[2]; py = 1: Z[1] - Z[2] - Z[3]), so that 16 consecutive lanes store the 256 contiguous bytes of
+  // one output pixel.  Lane: tile = th * 32 + l31; couts wco * 32 + 8 g + 4 h + (0..3) in registers 4 g .. 4 g + 3 of acc[2 nu + th].
+  {
+    float* zbuf = wsm + wxi * (XT * X_OT);
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+      float* zrow = zbuf + (th * 32 + l31) * X_OT + wco * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float z0[4], z1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float m0 = acc[0 + th][4 * g + r], m1 = acc[2 + th][4 * g + r], m2 = acc[4 + th][4 * g + r], m3 = acc[6 + th][4 * g + r];
+          z0[r] = (m0 + m1) + m2;
+          z1[r] = (m1 - m2) - m3;
+        }
+        *reinterpret_cast<float4*>(zrow + 8 * g) = make_float4(z0[0], z0[1], z0[2], z0[3]);
+        *reinterpret_cast<float4*>(zrow + XC + 8 * g) = make_float4(z1[0], z1[1], z1[2], z1[3]);
+      }
+    }
+  }
+  int* tinfo = reinterpret_cast<int*>(wsm + 4 * XT * X_OT);  // [64] first output pixel of the tile (-1: none), [64] flags, [64] image
+  if (wave < 2 && h == 0) {
+    const int tl = wave * 32 + l31;
+    const int t = t0 + tl;
+    int n00 = -1, fl = 0, b = 0;
+    if (t < p.ntiles) {
+      b = t / tiles_img;
+      const int rr = t - b * tiles_img;
+      const int th = rr / p.tiles_w;
+      const int tw = rr - th * p.tiles_w;
+      n00 = (b * a.hout + 2 * th) * a.wout + 2 * tw;
+      fl = (2 * th + 1 < a.hout ? 1 : 0) | (2 * tw + 1 < a.wout ? 2 : 0);
+    }
+    tinfo[tl] = n00;
+    tinfo[XT + tl] = fl;
+    tinfo[2 * XT + tl] = b;
+  }
+  __syncthreads();
+  const int cq = tid & 15;  // the same channel quad in every iteration
+  const int co = cb * XC + cq * 4;
+  if (co >= a.cout_s) return;
+  int on[8], ob[8];
+  float4 ov[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = (it * 512 + tid) >> 4;  // tile * 4 + pixel
+    const int tile = row >> 2, px = row & 3;
+    const int n00 = tinfo[tile], fl = tinfo[XT + tile];
+    ob[it] = tinfo[2 * XT + tile];
+    const bool skip = n00 < 0 || (((px >> 1) & ~fl) | ((px & 1) & ~(fl >> 1)));
+    on[it] = skip ? -1 : n00 + (px >> 1) * a.wout + (px & 1);
+    const float* zp = wsm + tile * X_OT + (px & 1) * XC + cq * 4;
+    // py = 0: (z1 + z2) + z0;  py = 1: (z1 - z2) - z3 -- one code path for both: the sign as an FMA factor (exact), the third
+    // term's buffer by address
+    const int py = px >> 1;
+    const float sg = py ? -1.f : 1.f;
+    const float4 z1 = *reinterpret_cast<const float4*>(zp + 1 * (XT * X_OT));
+    const float4 z2 = *reinterpret_cast<const float4*>(zp + 2 * (XT * X_OT));
+    const float4 za = *reinterpret_cast<const float4*>(zp + (py ? 3 : 0) * (XT * X_OT));
+    ov[it] = make_float4(fmaf(sg, za.x, fmaf(sg, z2.x, z1.x)), fmaf(sg, za.y, fmaf(sg, z2.y, z1.y)),
+                         fmaf(sg, za.z, fmaf(sg, z2.z, z1.z)), fmaf(sg, za.w, fmaf(sg, z2.w, z1.w)));
+  }
+  if (a.gn_quads == nullptr) {
+    epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix);
+    return;
+  }
+  // ---- GroupNorm statistics of the OUTPUT (see conv_winograd_kernel: one partial per (image, tile block, channel quad); the host
+  // enables this only when the 64 tiles of a workgroup lie in one image, whole 2 x 2 tiles, cout_s % 64 == 0)
+  float mom[3] = {0.f, 0.f, 0.f};
+  epilogue_store_batch<8, true>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix, mom);
+  float am = mom[0] + mom[1] * (1.f / 32.f);
+  float a2 = mom[2] - mom[1] * mom[1] * (1.f / 32.f);
+  auto chan = [](float& am, float& a2, float bm, float b2, float half_n) {  // both sides hold 2 * half_n values
+    const float d = bm - am;
+    am = am + 0.5f * d;
+    a2 = (a2 + b2) + d * d * half_n;
+  };
+  chan(am, a2, __shfl_xor(am, 16), __shfl_xor(a2, 16), 16.f);
+  chan(am, a2, __shfl_xor(am, 32), __shfl_xor(a2, 32), 32.f);
+  float* sh = reinterpret_cast<float*>(tinfo + 3 * XT);
+  if (lane < 16) {
+    sh[wave * 16 + lane] = am;
+    sh[128 + wave * 16 + lane] = a2;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float wm[8], w2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      wm[k] = sh[k * 16 + tid];
+      w2[k] = sh[128 + k * 16 + tid];
+    }
+    float hn = 64.f;  // each wave's partial: 128 values
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1, hn *= 2.f)
+#pragma unroll
+      for (int k = 0; k < 8; k += 2 * o) chan(wm[k], w2[k], wm[k + o], w2[k + o], hn);
+    const int chunk = (t0 - b_first * tiles_img) / XT;
+    float* out = a.gn_quads + ((((int64_t)b_first * a.gn_chunks + chunk) * (a.cout_s / 4)) + (cb * (XC / 4) + tid)) * 4;
+    out[0] = 1024.f;
+    out[1] = wm[0];
+    out[2] = w2[0];
+    out[3] = 0.f;
+  }
+}
+
+}  // namespace
+
+// Launch (host side of az_conv2d_winograd_x3_f32, conv.hip validates the descriptor and fills `p` in 16-channel steps).
+template <int AFF, bool TAIL>
+static int launch_x3(const WinoP& p, unsigned splitk, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_winograd_x3_kernel<AFF, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_winograd_x3_kernel<AFF, TAIL>), dim3((unsigned)((int64_t)p.cblocks * p.tblocks), splitk), dim3(512), X_LDS_BYTES,
+                     st, p);
+  return az_launch_status();
+}
+
+__attribute__((visibility("hidden"))) int azi_winograd_x3_launch(const WinoP& p, unsigned splitk, hipStream_t st) {
+  const bool tail = (p.a.c0s % XK) != 0 || (p.a.c1s % XK) != 0;
+  const int aff = !p.a.in_affine ? 0 : (p.a.in_act == 0 ? 1 : 2);
+  switch (aff * 2 + (tail ? 1 : 0)) {
+    case 0: return launch_x3<0, false>(p, splitk, st);
+    case 1: return launch_x3<0, true>(p, splitk, st);
+    case 2: return launch_x3<1, false>(p, splitk, st);
+    case 3: return launch_x3<1, true>(p, splitk, st);
+    case 4: return launch_x3<2, false>(p, splitk, st);
+    default: return launch_x3<2, true>(p, splitk, st);
+  }
+}

@@ -138,6 +138,7 @@ WINOGRAD = os.environ.get("AZ_WINOGRAD", "1")
 FP32_MFMA = os.environ.get("AZ_FP32_MFMA", "bf16x3")
 assert FP32_MFMA in ("native", "bf16x3"), FP32_MFMA
 ATTN_X3 = os.environ.get("AZ_ATTN_X3", "1") != "0"  # bf16x3 mode: attention contractions on the bf16 pipe too (az_attention_x3_f32)
+WINO_X3 = os.environ.get("AZ_WINO_X3", "0") != "0" and FP32_MFMA == "bf16x3"  # the Winograd frequency GEMMs on the bf16 pipe too
 X3_MIN_CHANNELS = 32  # bf16x3 only where both channel counts fill a K tile / an MFMA tile
 WINOGRAD4_MIN_TILES = int(os.environ.get("AZ_WINOGRAD4_MIN_TILES", "1024"))
 # q / k RMS norm, gains and RoPE of an attention layer in the epilogue of its qkv projection ("0": inside the attention kernel)
@@ -244,6 +245,20 @@ class ConvWeights:
             self._wino = packed
         return self._wino
 
+
+    def winograd_x3(self) -> torch.Tensor:
+        r"""The same filter transform as three bf16 pieces in MFMA fragment order, 16-channel steps
+        (az_winograd_pack_filter_x3_f32), for ``az_conv2d_winograd_x3_f32``; source 1 starts on a step boundary."""
+        if getattr(self, "_wino_x3", None) is None:
+            nk0, nk1 = (self.c0s + 15) // 16, (self.c1s + 15) // 16
+            cb = (self.cout_s + 63) // 64
+            packed = torch.empty((nk0 + nk1) * cb * 16 * 64 * 16 * 3, dtype=torch.int16, device=self.device)
+            _lib.call(
+                "az_winograd_pack_filter_x3_f32", packed.data_ptr(), self.w.data_ptr(), self.cout, self.cin, self.cin0,
+                nk0, nk0 + nk1, cb, _lib.stream_ptr(),
+            )
+            self._wino_x3 = packed
+        return self._wino_x3
 
     def winograd4(self) -> torch.Tensor:
         r"""F(4x4,3x3) filter transform (az_winograd4_pack_filter_f32) laid out
@@ -411,6 +426,10 @@ class Builder:
             a.weight = packed.winograd4().data_ptr()
             a.splitk = lib.az_conv2d_winograd4_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
             name = "az_conv2d_winograd4_f32"
+        elif use_wino and (winograd == "wx3" or (winograd is None and WINO_X3)):
+            # the frequency GEMMs on the bf16 pipe as exact 3 x bf16 splits (wino_x3.hip); same descriptor, 16-channel steps
+            a.weight = packed.winograd_x3().data_ptr()
+            name = "az_conv2d_winograd_x3_f32"
         elif use_wino:
             a.weight = packed.winograd().data_ptr()
             name = "az_conv2d_winograd_f32"
@@ -431,12 +450,12 @@ class Builder:
         tmp_src = None
         if src0.affine is not None:  # a normalisation whose apply pass has not run (group_norm(lazy=True))
             ST, in_act = src0.affine
-            if name == "az_conv2d_winograd_f32" and src1 is None and up0 == 0 and a.c0s % 8 == 0:
+            if name in ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32") and src1 is None and up0 == 0 and a.c0s % 8 == 0:
                 a.in_affine, a.in_act = ST.data_ptr(), in_act
             else:
                 tmp_src = self.materialize(src0)
                 a.src0 = tmp_src.ptr
-        if (gn_stats and GN_FUSED and name == "az_conv2d_winograd_f32" and a.splitk == 1 and out is not None and cout == a.cout_s
+        if (gn_stats and GN_FUSED and name in ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32") and a.splitk == 1 and out is not None and cout == a.cout_s
                 and cout % 64 == 0 and hout % 2 == 0 and wout % 2 == 0 and ((hout // 2) * (wout // 2)) % 64 == 0):
             # the output feeds a GroupNorm: its epilogue also writes per-(tile block, channel quad) moments
             chunks = ((hout // 2) * (wout // 2)) // 64

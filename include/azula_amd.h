@@ -354,6 +354,13 @@ int az_conv2d_x3_suggest_splitk(const AzConvArgs* args);
  * (azula_amd/engine.py: Builder.pack_winograd); all other fields as az_conv2d_f32.             */
 int az_conv2d_winograd_f32(const AzConvArgs* args, az_stream_t stream);
 int az_conv2d_winograd_suggest_splitk(int64_t batch, int32_t hout, int32_t wout, int32_t cout_s, int32_t cin_s);
+/* The same F(2x2,3x3) convolution with its 16 frequency GEMMs on the bf16 matrix pipe at fp32 accuracy (csrc/wino_x3.hip): U (at
+ * pack time) and V = B^T d B (in the kernel) are split EXACTLY into three bf16 pieces and a product is the six largest of the
+ * nine partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- 0.375 x the matrix-pipe time of the fp32 form.
+ * `weight` = az_winograd_pack_filter_x3_f32 output (16-channel steps; source 1 starts on a step boundary); every other field,
+ * the epilogue, split-K and gn_quads as az_conv2d_winograd_f32.  Inputs are assumed finite (an Inf operand splits into NaN
+ * pieces).                                                                                                                  */
+int az_conv2d_winograd_x3_f32(const AzConvArgs* args, az_stream_t stream);
 /* Winograd F(4x4,3x3) form (6x6 patches, 36 frequency GEMMs: 2.25 multiplies per output instead of 4 / 9).
  * NOT exact: the transforms multiply by 2, 4, 5, 8 and the filter transform by 1/4 .. 1/24, so the fp32
  * rounding error is ~20x that of the F(2x2) kernel (~1e-5 of the output scale per layer).  Opt-in
@@ -456,6 +463,13 @@ int az_pack_conv_weight_x3_f32(void* dst, const float* src, int32_t cout, int32_
  * channels [0, cin0) fill chunks [0, nk0), the rest start at chunk nk0 (two-source concat).      */
 int az_winograd_pack_filter_f32(float* dst, const float* src, int32_t cout, int32_t cin, int32_t cin0, int32_t nk0,
                                 int32_t nk, int32_t cblocks, az_stream_t stream);
+
+/* The same transform for az_conv2d_winograd_x3_f32: U (rounded to fp32 as above) split exactly into three bf16 pieces, in the
+ * order that kernel's waves load it as MFMA A fragments: [nk steps of 16 cin][cblocks of 64 cout][wave 0..7 = (32-cout half) * 4 +
+ * frequency row xi][nu][piece][lane][8 bf16] (96 KB per step and cout block; opaque to callers).  dst holds
+ * nk * cblocks * 49152 two-byte elements; channels [0, cin0) fill steps [0, nk0), the rest start at step nk0.      */
+int az_winograd_pack_filter_x3_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t cin0, int32_t nk0,
+                                   int32_t nk, int32_t cblocks, az_stream_t stream);
 
 /* Same for F(4x4,3x3) (points 0, +-1, +-2, inf): [nk chunks of 4 cin][cblocks of 64 cout][36][64][4]; packed
  * channel position pc maps to input channel pc (pc < cin0) or cin0 + pc - c0s (pc >= c0s).        */

@@ -392,17 +392,18 @@ CONV_CASES = [
 def conv_tol(cin, ks, wino=False):
     """Direct: exact fp32 fmaf chains.  F(2x2,3x3) only adds/subtracts (3x).  F(4x4,3x3) multiplies by up to 8
     and its filter transform by 1/24: ~20x the rounding error of F(2x2) (stated in include/azula_amd.h)."""
-    return (3e-6 * math.sqrt(cin * ks * ks) + 1e-5) * {False: 1, True: 3, 4: 40, "x3": 1}[wino]
+    return (3e-6 * math.sqrt(cin * ks * ks) + 1e-5) * {False: 1, True: 3, 4: 40, "x3": 1, "wx3": 3}[wino]
 
 
-WINO_NAME = {False: "az_conv2d_f32", True: "az_conv2d_winograd_f32", 4: "az_conv2d_winograd4_f32", "x3": "az_conv2d_x3_f32"}
+WINO_NAME = {False: "az_conv2d_f32", True: "az_conv2d_winograd_f32", 4: "az_conv2d_winograd4_f32", "x3": "az_conv2d_x3_f32",
+             "wx3": "az_conv2d_winograd_x3_f32"}  # "wx3": Winograd with its frequency GEMMs on the bf16 pipe (csrc/wino_x3.hip)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ks,stride", CONV_CASES)
 @pytest.mark.parametrize("splitk", [0, 3])
-@pytest.mark.parametrize("wino", [False, True, 4, "x3"])
+@pytest.mark.parametrize("wino", [False, True, 4, "x3", "wx3"])
 def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk, wino):
-    if wino in (True, 4) and (ks != 3 or stride != 1):
+    if wino in (True, 4, "wx3") and (ks != 3 or stride != 1):
         pytest.skip("Winograd is the stride-1 3x3 path")
     from azula_amd.engine import Act, Builder
 
@@ -428,7 +429,7 @@ def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk, wino):
     assert (y.buf.reshape(B, y.H, y.W, y.cs)[..., Cout:] == 0).all()
 
 
-@pytest.mark.parametrize("wino", [False, True, 4, "x3"])
+@pytest.mark.parametrize("wino", [False, True, 4, "x3", "wx3"])
 def test_conv2d_random_shapes(az, wino):
     """Seeded sweep over ragged shapes (odd sizes, channel counts off the 4 / 8 / 32 grids, batch 1-3, optional second
     source with nearest-x2 upsampling, SiLU / gate / residual) for the three 3x3 stride-1 algorithms."""
@@ -436,7 +437,7 @@ def test_conv2d_random_shapes(az, wino):
 
     from azula_amd.engine import Act, Builder
 
-    rnd = random.Random(1234 + {False: 0, True: 7, 4: 4, "x3": 3}[wino])
+    rnd = random.Random(1234 + {False: 0, True: 7, 4: 4, "x3": 3, "wx3": 7}[wino])
     g = torch.Generator().manual_seed(99)
     for case in range(10):
         B = rnd.randint(1, 3)
@@ -475,7 +476,7 @@ def test_conv2d_random_shapes(az, wino):
         assert err < conv_tol(C0 + C1, 3, wino) * max(1.0, ref.abs().max().item()), (case, B, H, W, C0, C1, Cout, act, err)
 
 
-@pytest.mark.parametrize("wino", [False, True])
+@pytest.mark.parametrize("wino", [False, True, "wx3"])
 @pytest.mark.parametrize("shift", [-2, -1, 1, 2])
 @pytest.mark.parametrize("Cin,H,W", [(32, 16, 16), (64, 12, 20), (20, 9, 7)])
 def test_conv2d_depth_tap_between_poisoned_neighbours(az, wino, shift, Cin, H, W):
@@ -511,7 +512,7 @@ def test_conv2d_depth_tap_between_poisoned_neighbours(az, wino, shift, Cin, H, W
     assert max_err(out, ref) < conv_tol(Cin, 3, wino), max_err(out, ref)
 
 
-@pytest.mark.parametrize("wino", [False, True])
+@pytest.mark.parametrize("wino", [False, True, "wx3"])
 @pytest.mark.parametrize("Cin,Cout,ks", [(32, 64, 1), (20, 24, 3), (64, 256, 1)])
 def test_conv2d_swiglu_epilogue(az, wino, Cin, Cout, ks):
     """AzConvArgs.act = 4: y[c] = x[2c] * silu(x[2c+1]) applied to the convolution's output in its epilogue (half the
@@ -537,7 +538,8 @@ def test_conv2d_swiglu_epilogue(az, wino, Cin, Cout, ks):
     assert max_err(out, ref) < 2 * conv_tol(Cin, ks, wino) * max(1.0, ref.abs().max().item())
 
 
-def test_winograd_stream_fuzz(az):
+@pytest.mark.parametrize("mode", [True, "wx3"])
+def test_winograd_stream_fuzz(az, mode):
     """The hand-scheduled K loop (wino_kloop.inc) over 40 seeded cases that move every event of the stream around: 1 .. 24
     eight-channel stages (first / steady / second-to-last / last iteration bodies), two sources whose switch falls on any
     stage, half chunks at the end of either source, split-K slices that start in either source, nearest-x2 upsampling of the
@@ -573,8 +575,8 @@ def test_winograd_stream_fuzz(az):
             a1 = Act(to_nhwc(dev(x1)).reshape(-1), B, h1, w1, C1, (C1 + 3) // 4 * 4, True)
             kw = dict(src1=a1, up1=1 if up else 0, hin=H, win=W)
         ref = F.conv2d(F.pad(src, (1, 1, 1, 1), mode="circular"), w, b) if periodic else F.conv2d(src, w, b, padding=1)
-        y = bld.conv(a0, bld.pack_conv(dev(w), dev(b), cin0=C0), Cout, winograd=True, periodic=periodic, **kw)
-        assert bld.tape.ops[-1][2] == "az_conv2d_winograd_f32"
+        y = bld.conv(a0, bld.pack_conv(dev(w), dev(b), cin0=C0), Cout, winograd=mode, periodic=periodic, **kw)
+        assert bld.tape.ops[-1][2] == WINO_NAME[mode]
         if splitk:
             a = bld.tape.keep[-1]
             a.splitk = splitk
@@ -656,7 +658,7 @@ def test_conv2d_stem(az, cin, B, H, W, cout, periodic):
     assert max_err(from_nhwc(n.buf.reshape(B, H, W, cout), cout), ref_n) < 2e-5
 
 
-@pytest.mark.parametrize("asm", ["1", "0"])
+@pytest.mark.parametrize("asm", ["1", "0", "wx3"])
 @pytest.mark.parametrize("in_act", [0, 1])
 def test_winograd_input_affine(az, asm, in_act, monkeypatch):
     """AzConvArgs.in_affine: conv(act(x * scale[b, c] + shift[b, c])) with the affine evaluated inside the Winograd gather
@@ -667,7 +669,9 @@ def test_winograd_input_affine(az, asm, in_act, monkeypatch):
 
     from azula_amd.engine import Act, Builder
 
-    monkeypatch.setenv("AZ_WINOGRAD_ASM", asm)
+    mode = "wx3" if asm == "wx3" else True  # ("wx3": the bf16-pipe kernel, csrc/wino_x3.hip)
+    if mode is True:
+        monkeypatch.setenv("AZ_WINOGRAD_ASM", asm)
     rnd = random.Random(77 + in_act)
     g = torch.Generator().manual_seed(77 + in_act)
     for case in range(24):
@@ -688,8 +692,8 @@ def test_winograd_input_affine(az, asm, in_act, monkeypatch):
         bld = Builder(torch.device("cuda"))
         a0 = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, C0, C0, True)
         a0.affine = (dev(torch.cat((sc.reshape(-1), sh.reshape(-1)))), in_act)
-        y = bld.conv(a0, bld.pack_conv(dev(w), dev(b)), Cout, winograd=True, periodic=periodic)
-        assert [nm for _, _, nm in bld.tape.ops] == ["az_conv2d_winograd_f32"]  # no apply pass
+        y = bld.conv(a0, bld.pack_conv(dev(w), dev(b)), Cout, winograd=mode, periodic=periodic)
+        assert [nm for _, _, nm in bld.tape.ops] == [WINO_NAME[mode]]  # no apply pass
         if splitk:
             a = bld.tape.keep[-1]
             a.splitk = splitk
@@ -706,7 +710,7 @@ def test_winograd_input_affine(az, asm, in_act, monkeypatch):
     assert az.lib().az_conv2d_f32(C.byref(a), az.stream_ptr()) == -4  # AZ_E_UNSUPPORTED
 
 
-@pytest.mark.parametrize("wino", [False, True, 4, "x3"])
+@pytest.mark.parametrize("wino", [False, True, 4, "x3", "wx3"])
 def test_conv2d_concat_upsample_narrow_gate_res(az, wino):
     """cat((y, upsample(x)[narrowed])) -> conv -> x0 + c * silu-free epilogue, as azula/nn/unet.py:253-257,93."""
     from azula_amd.engine import Act, Builder
@@ -732,7 +736,7 @@ def test_conv2d_concat_upsample_narrow_gate_res(az, wino):
     assert max_err(from_nhwc(out.buf.reshape(B, H, W, 12), Cout), ref) < conv_tol(Cy + Cx, 3, wino)
 
 
-@pytest.mark.parametrize("wino", [False, True, 4, "x3"])
+@pytest.mark.parametrize("wino", [False, True, 4, "x3", "wx3"])
 def test_conv2d_nchw_output_and_res_up(az, wino):
     from azula_amd.engine import Act, Builder
 
@@ -819,7 +823,7 @@ def test_conv2d_x3_accuracy(az, monkeypatch):
     assert errs["x3"][1] <= errs[True][1], errs
 
 
-@pytest.mark.parametrize("wino", [False, True, "x3"])
+@pytest.mark.parametrize("wino", [False, True, "x3", "wx3"])
 def test_conv2d_is_deterministic_across_launches(az, wino):
     """Race screen for the LDS-exchange epilogues and the split-K combine: 12 launches of the same convolution (gate,
     residual, SiLU; one with split-K) must give bit-identical outputs."""
@@ -895,7 +899,7 @@ def test_conv2d_half_operands(az, B, Cin, Cout, H, W, ks, stride, half):
     assert (y.buf.reshape(B, y.H, y.W, y.cs)[..., Cout:] == 0).all()
 
 
-@pytest.mark.parametrize("wino", [False, True])
+@pytest.mark.parametrize("wino", [False, True, "wx3"])
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
 @pytest.mark.parametrize("gated", [False, True])
 @pytest.mark.parametrize("res_kind", ["none", "same", "up", "nobias"])
@@ -939,6 +943,8 @@ def test_conv2d_epilogue_forms(az, wino, act, gated, res_kind):
         (2, 256, 128, 8, 8, 3, 1, False, "gate_res"),
         (4, 256, 256, 16, 16, 3, 1, True, "silu"),
         (4, 512, 256, 8, 8, 3, 1, True, "gate_res"),
+        (4, 256, 256, 16, 16, 3, 1, "wx3", "silu"),
+        (4, 512, 256, 8, 8, 3, 1, "wx3", "gate_res"),
         (1, 1024, 96, 6, 6, 1, 1, False, "plain"),       # 24 quads (not a divisor of 256), 36 pixels in 2 ragged chunks
         (2, 128, 1280, 8, 8, 3, 2, False, "plain"),      # 320 quads: a thread owns two quads in turn; stride 2
         (2, 256, 128, 8, 8, 3, 1, False, "concat"),
@@ -996,8 +1002,9 @@ def test_groupnorm_statistics_from_the_splitk_combine(az, case, monkeypatch):
     assert e_ab < 2.5e-5
 
 
+@pytest.mark.parametrize("mode", [True, "wx3"])
 @pytest.mark.parametrize("form", ["plain", "gate_res", "silu", "concat", "mixed"])
-def test_groupnorm_statistics_from_the_conv_epilogue(az, form, monkeypatch):
+def test_groupnorm_statistics_from_the_conv_epilogue(az, form, mode, monkeypatch):
     """AzConvArgs.gn_quads: the Winograd epilogue leaves (n, mean, M2) per (image, 64-tile block, channel quad) and the
     following GroupNorm skips its statistics pass.  Checked against torch's group_norm of the torch conv, with a large
     common offset (bias 30, residual mean 50: mean >> std, the case a naive sum-of-squares loses) and against the
@@ -1033,10 +1040,10 @@ def test_groupnorm_statistics_from_the_conv_epilogue(az, form, monkeypatch):
         xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
         ra = Act(to_nhwc(dev(res)).reshape(-1), B, H, W, Cout, Cout, True)
         kw = dict(gate=dev(gate), gate_bstride=Cout, res=ra) if form in ("gate_res", "concat", "mixed") else {}
-        y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, act=int(form == "silu"), winograd=True, gn_stats=True, **kw)
+        y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, act=int(form == "silu"), winograd=mode, gn_stats=True, **kw)
         y1 = None
         if two:  # "mixed": the second source carries no moments -> the whole norm falls back to the statistics pass
-            y1 = bld.conv(xa, bld.pack_conv(dev(w2), None), 128, winograd=True, gn_stats=form == "concat")
+            y1 = bld.conv(xa, bld.pack_conv(dev(w2), None), 128, winograd=mode, gn_stats=form == "concat")
         n = bld.group_norm(y, groups, weight=dev(gw), bias=dev(gb), act=1, x1=y1)
         bld.finish()
         names = [nm for _, _, nm in bld.tape.ops]
