@@ -141,29 +141,29 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
 
   f32x2 rv[16];  // raw 4x4 patch of the channel pair (index = patch row * 4 + column), then B^T d in place
   int staged_kt = 0;
-  auto load_raw = [&](int kt) __attribute__((always_inline)) {  // kt is wave-uniform
+  // the gather of step kt in pieces the issue schedule can place: the 16 parked offsets (4 LDS reads), then 4 x 4 loads
+  unsigned ro[16];
+  auto raw_offsets = [&](int kt, int q0, int q1) __attribute__((always_inline)) {
+    const uint4* pk = park + (kt >= p.nkc0 ? 2048 : 0);
+#pragma unroll
+    for (int q = q0; q < q1; ++q) {
+      const uint4 v = pk[q];
+      ro[4 * q] = v.x, ro[4 * q + 1] = v.y, ro[4 * q + 2] = v.z, ro[4 * q + 3] = v.w;
+    }
+  };
+  auto raw_loads = [&](int kt, int i0, int i1) __attribute__((always_inline)) {  // kt is wave-uniform
     const bool src1 = kt >= p.nkc0;
     staged_kt = kt;
     const int kc = src1 ? kt - p.nkc0 : kt;
     const unsigned soff = (unsigned)(kc * XK * 4);
     const __amdgpu_buffer_rsrc_t r = src1 ? rs1 : rs0;  // (selects, not a branch: the phase stays one basic block)
-    const uint4* pk = park + (src1 ? 2048 : 0);
-    unsigned o[16];
+    bool kv = true;
+    if constexpr (TAIL) kv = kc * XK + vq * 2 < (src1 ? a.c1s : a.c0s);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint4 v = pk[q];
-      o[4 * q] = v.x, o[4 * q + 1] = v.y, o[4 * q + 2] = v.z, o[4 * q + 3] = v.w;
-    }
-    if constexpr (TAIL) {
-      const bool kv = kc * XK + vq * 2 < (src1 ? a.c1s : a.c0s);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[i] = kv ? o[i] : OOB;
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) rv[i] = buf_ld2(r, o[i], soff);
+    for (int i = i0; i < i1; ++i) rv[i] = buf_ld2(r, TAIL && !kv ? OOB : ro[i], soff);
   };
-  // B^T d (rows of the patch), in place; with in_affine the input is act(x * scale + shift) first (padding positions stay zero)
-  auto row_transform = [&]() __attribute__((always_inline)) {
+  // with in_affine the input is act(x * scale + shift) (padding positions stay zero): applied to the raw patch in place
+  auto affine = [&]() __attribute__((always_inline)) {
     if constexpr (AFF != 0) {
       const float* sp = a.in_affine + ((int64_t)(b_first + (v_b < 0 ? 0 : v_b)) * a.c0s + staged_kt * XK + vq * 2);
       const bool kv = !TAIL || staged_kt * XK + vq * 2 < a.c0s;  // (masked pairs hold zeros and stay zero: their positions read OOB below)
@@ -178,44 +178,54 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
         rv[i] = o[i] == OOB ? f32x2{0.f, 0.f} : v;
       }
     }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const f32x2 d0 = rv[c], d1 = rv[4 + c], d2 = rv[8 + c], d3 = rv[12 + c];
-      rv[c] = d0 - d2;
-      rv[4 + c] = d1 + d2;
-      rv[8 + c] = d2 - d1;
-      rv[12 + c] = d1 - d3;
-    }
   };
-  // columns side of B^T d B for one half of the frequencies (hs = 0: nu in {0, 1}; 1: nu in {2, 3}), split, -> buffer hs
+  // B^T d (rows of the patch) of patch column c, in place
+  auto row_transform = [&](int c) __attribute__((always_inline)) {
+    const f32x2 d0 = rv[c], d1 = rv[4 + c], d2 = rv[8 + c], d3 = rv[12 + c];
+    rv[c] = d0 - d2;
+    rv[4 + c] = d1 + d2;
+    rv[8 + c] = d2 - d1;
+    rv[12 + c] = d1 - d3;
+  };
+  // columns side of B^T d B of frequency row xi for one half of the frequencies (hs = 0: nu in {0, 1}; 1: nu in {2, 3})
+  f32x2 vv[8];  // vv[2 xi + j] = V[xi][2 hs + j] of the channel pair
+  auto nu_side = [&](int hs, int xi) __attribute__((always_inline)) {
+    const f32x2 u0 = rv[4 * xi], u1 = rv[4 * xi + 1], u2 = rv[4 * xi + 2], u3 = rv[4 * xi + 3];
+    vv[2 * xi] = hs == 0 ? u0 - u2 : u2 - u1;
+    vv[2 * xi + 1] = hs == 0 ? u1 + u2 : u1 - u3;
+  };
+  // exact 3 x bf16 split of vv[c] (az_split3 in three stages the schedule can place) and the stores of a frequency row
   const int vrow = vj * X_ROW + (((vq >> 2) ^ ((vj >> 3) & 1)) * 16) + (vq & 3) * 4;
-  auto produce = [&](int hs) __attribute__((always_inline)) {
+  unsigned qq[8][3];
+  auto split_a = [&](int c) __attribute__((always_inline)) {  // piece 1, first remainder
+    const float x0 = vv[c].x, x1 = vv[c].y;  // (by value: __builtin_bit_cast of a vector ELEMENT expression read element 0 twice)
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    qq[c][0] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    vv[c] = f32x2{x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u), x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u)};
+  };
+  auto split_b = [&](int c) __attribute__((always_inline)) {  // piece 2, second remainder = piece 3
+    const float r0 = vv[c].x, r1 = vv[c].y;
+    const unsigned u0 = __builtin_bit_cast(unsigned, r0), u1 = __builtin_bit_cast(unsigned, r1);
+    qq[c][1] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float s0 = r0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
+    const float s1 = r1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+    qq[c][2] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+  };
+  auto store_row = [&](int hs, int xi) __attribute__((always_inline)) {  // both frequencies of row xi, three planes -> buffer hs
     char* dst = smem + hs * X_HALF + vrow;
 #pragma unroll
-    for (int xi = 0; xi < 4; ++xi) {
-      const f32x2 u0 = rv[4 * xi], u1 = rv[4 * xi + 1], u2 = rv[4 * xi + 2], u3 = rv[4 * xi + 3];
-      const f32x2 va = hs == 0 ? u0 - u2 : u2 - u1;
-      const f32x2 vb = hs == 0 ? u1 + u2 : u1 - u3;
-      unsigned q[2][3];
-      az_split3(va.x, va.y, q[0][0], q[0][1], q[0][2]);
-      az_split3(vb.x, vb.y, q[1][0], q[1][1], q[1][2]);
+    for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned*>(dst + pl * X_PLANE + (2 * xi + j) * X_FREQ) = q[j][pl];
-    }
+      for (int j = 0; j < 2; ++j) *reinterpret_cast<unsigned*>(dst + pl * X_PLANE + (2 * xi + j) * X_FREQ) = qq[2 * xi + j][pl];
   };
-  // the wave's filter fragments of (step kt, half hs): A[j][piece] = U[xi, 2 hs + j] pieces, rows = couts wco * 32 + l31,
-  // k = 8 h .. 8 h + 7 of the step -- six contiguous 1 KB loads
+  // the wave's filter fragments of (step kt, frequency nu): A[piece] = the pieces of U[xi, nu], rows = couts wco * 32 + l31,
+  // k = 8 h .. 8 h + 7 of the step -- three contiguous 1 KB loads
   const unsigned u_lane = (unsigned)(lane * 16);
-  auto load_u = [&](int kt, int hs, bf16x8 (&ua)[2][3]) __attribute__((always_inline)) {
+  auto load_u = [&](int kt, int nu, bf16x8 (&ua)[3]) __attribute__((always_inline)) {
     const unsigned soff =  // (wave-uniform, but derived from threadIdx: readfirstlane makes it a scalar operand)
-        (unsigned)__builtin_amdgcn_readfirstlane((int)((((int64_t)kt * p.cblocks + cb) * 8 + wave) * (12 * 1024) + hs * (6 * 1024)));
+        (unsigned)__builtin_amdgcn_readfirstlane((int)((((int64_t)kt * p.cblocks + cb) * 8 + wave) * (12 * 1024) + nu * (3 * 1024)));
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        ua[j][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((j * 3 + pl) * 1024), soff));
+    for (int pl = 0; pl < 3; ++pl) ua[pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)(pl * 1024), soff));
   };
 
   f32x16 acc[8];
@@ -226,54 +236,124 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
 
   // V fragment: frequency (xi, j) = row 2 xi + j of the half-stage, tile th * 32 + l31, half h (swapped in rows with bit 3 set)
   const int fragB = (2 * wxi) * X_FREQ + l31 * X_ROW + ((h ^ ((l31 >> 3) & 1)) * 16);
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest partial products first (as the direct bf16x3 kernels)
-  constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
-  auto mma = [&](int hs, const bf16x8 (&ua)[2][3]) __attribute__((always_inline)) {
-    const char* vb = smem + hs * X_HALF + fragB;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bf16x8 fb[2][3];
-#pragma unroll
-      for (int th = 0; th < 2; ++th)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          fb[th][pl] = *reinterpret_cast<const bf16x8*>(vb + pl * X_PLANE + j * X_FREQ + th * (32 * X_ROW));
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int th = 0; th < 2; ++th) {
-          f32x16& c = acc[2 * (2 * hs + j) + th];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[j][PA[t]], fb[th][PB[t]], c, 0, 0, 0);
-        }
+  // the six partial products of a frequency, smallest first; B piece 2 is needed by the first pair of MFMAs only and piece 1
+  // by the first eight, so the NEXT frequency's fragments can replace them early (one set of fragment registers)
+  constexpr int PA[6] = {0, 1, 2, 0, 1, 0};
+  constexpr int PB[6] = {2, 1, 0, 1, 0, 0};
+  bf16x8 ua[2][3], fb[2][3];
+  auto frag = [&](int hs, int j, int pl) __attribute__((always_inline)) {  // piece pl of both tile halves of frequency (xi, 2 hs + j)
+    const char* vb = smem + hs * X_HALF + fragB + j * X_FREQ + pl * X_PLANE;
+    fb[0][pl] = *reinterpret_cast<const bf16x8*>(vb);
+    fb[1][pl] = *reinterpret_cast<const bf16x8*>(vb + 32 * X_ROW);
+  };
+  auto mf = [&](int hs, int k) __attribute__((always_inline)) {  // MFMA k = 0..23 of a phase: frequency j = k / 12, product t, tile half th
+    const int j = k / 12, t = (k % 12) / 2, th = k & 1;
+    f32x16& c = acc[2 * (2 * hs + j) + th];
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[j][PA[t]], fb[th][PB[t]], c, 0, 0, 0);
+  };
+
+  // One phase = the 24 MFMAs of (step kt, half hs) + the production of the NEXT half-stage into the other buffer:
+  //   hs = 0: V(kt, nu 2..3) -> buffer 1 from the B^T d of step kt held in rv; then the raw patch of step ktn replaces rv;
+  //   hs = 1: B^T d of step ktn, V(ktn, nu 0..1) -> buffer 0.
+  // The matrix pipe takes 32 cycles per MFMA and both waves of a SIMD share it, so the rest of the phase -- 96 vector
+  // instructions of splits, 12 paired LDS stores, 16 + 6 loads, 16 fragment reads -- is issued in SLOTS of one MFMA plus a few
+  // other instructions, fenced by sched_barrier(0): the compiler's own order put all 24 MFMAs first and the vector work
+  // behind them with the pipe idle (1139 us at 4 x 256^2, 256 -> 256), and a sched_group_barrier pattern was not honoured.
+  // Fragment / filter registers are reloaded for their next use right behind their last MFMA (see PA / PB).
+#define XS_FENCE __builtin_amdgcn_sched_barrier(0)
+  auto phase = [&](auto HS, int kt, int ktn) __attribute__((always_inline)) {
+    constexpr int hs = decltype(HS)::value;
+    constexpr int ob = 1 - hs;  // the buffer (and half of the frequencies) this phase produces
+    const int ktu = hs == 0 ? kt : ktn;  // the step whose filter fragments are loaded next
+    // slots 0 .. 5: the head of the phase
+    if constexpr (hs == 0) {
+      mf(hs, 0); nu_side(ob, 0); nu_side(ob, 1); XS_FENCE;
+      mf(hs, 1); nu_side(ob, 2); nu_side(ob, 3); XS_FENCE;  // rv is free from here
+      mf(hs, 2); frag(hs, 1, 2); raw_offsets(ktn, 0, 2); split_a(0); XS_FENCE;
+      mf(hs, 3); raw_offsets(ktn, 2, 4); split_b(0); XS_FENCE;
+      mf(hs, 4); raw_loads(ktn, 0, 4); split_a(1); XS_FENCE;
+      mf(hs, 5); raw_loads(ktn, 4, 8); split_b(1); XS_FENCE;
+      mf(hs, 6); raw_loads(ktn, 8, 12); store_row(ob, 0); XS_FENCE;
+      mf(hs, 7); raw_loads(ktn, 12, 16); split_a(2); XS_FENCE;
+      mf(hs, 8); frag(hs, 1, 1); split_b(2); XS_FENCE;
+      mf(hs, 9); split_a(3); XS_FENCE;
+      mf(hs, 10); split_b(3); XS_FENCE;
+      mf(hs, 11); store_row(ob, 1); XS_FENCE;
+    } else {
+      affine();
+      mf(hs, 0); row_transform(0); XS_FENCE;
+      mf(hs, 1); row_transform(1); XS_FENCE;
+      mf(hs, 2); frag(hs, 1, 2); row_transform(2); XS_FENCE;
+      mf(hs, 3); row_transform(3); XS_FENCE;
+      mf(hs, 4); nu_side(ob, 0); nu_side(ob, 1); XS_FENCE;
+      mf(hs, 5); nu_side(ob, 2); nu_side(ob, 3); XS_FENCE;
+      mf(hs, 6); split_a(0); XS_FENCE;
+      mf(hs, 7); split_b(0); XS_FENCE;
+      mf(hs, 8); frag(hs, 1, 1); split_a(1); XS_FENCE;
+      mf(hs, 9); split_b(1); XS_FENCE;
+      mf(hs, 10); store_row(ob, 0); split_a(2); XS_FENCE;
+      mf(hs, 11); split_b(2); XS_FENCE;
     }
+    // second frequency: its B pieces 2 and 1 are in place; piece 0 and the first frequency's filter fragments behind MFMA 11
+    mf(hs, 12); frag(hs, 1, 0); load_u(ktu, hs == 0 ? 2 : 0, ua[0]); XS_FENCE;
+    if constexpr (hs == 0) {
+      mf(hs, 13); split_a(4); XS_FENCE;
+      mf(hs, 14); split_b(4); XS_FENCE;
+      mf(hs, 15); split_a(5); XS_FENCE;
+      mf(hs, 16); split_b(5); XS_FENCE;
+      mf(hs, 17); store_row(ob, 2); XS_FENCE;
+      mf(hs, 18); split_a(6); XS_FENCE;
+      mf(hs, 19); split_b(6); XS_FENCE;
+      mf(hs, 20); split_a(7); XS_FENCE;
+      mf(hs, 21); split_b(7); XS_FENCE;
+      mf(hs, 22); store_row(ob, 3); XS_FENCE;
+      mf(hs, 23);
+    } else {
+      mf(hs, 13); split_a(3); XS_FENCE;
+      mf(hs, 14); split_b(3); store_row(ob, 1); XS_FENCE;
+      mf(hs, 15); split_a(4); XS_FENCE;
+      mf(hs, 16); split_b(4); XS_FENCE;
+      mf(hs, 17); split_a(5); XS_FENCE;
+      mf(hs, 18); split_b(5); store_row(ob, 2); XS_FENCE;
+      mf(hs, 19); split_a(6); XS_FENCE;
+      mf(hs, 20); split_b(6); XS_FENCE;
+      mf(hs, 21); split_a(7); XS_FENCE;
+      mf(hs, 22); split_b(7); XS_FENCE;
+      mf(hs, 23); store_row(ob, 3);
+    }
+    load_u(ktu, hs == 0 ? 3 : 1, ua[1]);
+    // the NEXT phase's first frequency: its buffer is complete behind the barrier
+    __syncthreads();
+    frag(ob, 0, 2); frag(ob, 0, 1); frag(ob, 0, 0);
+    XS_FENCE;
   };
 
   if (kt_begin < kt_end) {
-    bf16x8 ua[2][3], ub[2][3];
-    load_raw(kt_begin);
-    load_u(kt_begin, 0, ua);
-    row_transform();
-    produce(0);
+    raw_offsets(kt_begin, 0, 4);
+    raw_loads(kt_begin, 0, 16);
+    load_u(kt_begin, 0, ua[0]);
+    load_u(kt_begin, 1, ua[1]);
+    affine();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) row_transform(c);
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      nu_side(0, xi);
+      split_a(2 * xi), split_b(2 * xi), split_a(2 * xi + 1), split_b(2 * xi + 1);
+      store_row(0, xi);
+    }
     __syncthreads();
+    frag(0, 0, 2); frag(0, 0, 1); frag(0, 0, 0);
 #pragma unroll 1
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int ktn = min(kt + 1, kt_end - 1);  // (the last step restages itself into a buffer nobody reads: no branch in the body)
-      // phase 0: nu in {0, 1} of step kt
-      load_u(kt, 1, ub);
-      mma(0, ua);
-      produce(1);
-      load_raw(ktn);
-      __syncthreads();
-      // phase 1: nu in {2, 3} of step kt
-      load_u(ktn, 0, ua);
-      mma(1, ub);
-      row_transform();
-      produce(0);
-      __syncthreads();
+      phase(std::integral_constant<int, 0>{}, kt, ktn);
+      phase(std::integral_constant<int, 1>{}, kt, ktn);
     }
   } else {
     __syncthreads();
   }
+#undef XS_FENCE
 
   // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  A wave holds one frequency row xi (nu = 0..3) of its
   // 32 couts x 64 tiles: it applies the nu side in registers -- Z[xi][px] = M[xi][0] + M[xi][1] + M[xi][2] (px = 0),
