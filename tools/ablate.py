@@ -1,0 +1,73 @@
+r"""Timing ablations WITHOUT ablation code in the product sources: builds a variant of libazula_amd.so from a patched COPY of
+azula_amd/csrc (textual substitutions listed below; results of such a library are WRONG, only its timing means something).
+
+    python tools/ablate.py NAME [NAME ...]     ->  azula_amd/csrc/_ab/libazula_amd_NAME.so   (select with AZULA_AMD_LIB=<path>)
+    python tools/ablate.py --list
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from azula_amd.csrc import build as B  # noqa: E402
+
+# name -> [(file, old, new), ...]; every `old` must occur exactly once
+VARIANTS = {
+    # ---- wino_x3.hip: what bounds the K loop of az_conv2d_winograd_x3_f32
+    "wx3_nogather": [("wino_x3.hip", "    for (int i = i0; i < i1; ++i) rv[i] = buf_ld2(r, TAIL && !kv ? OOB : ro[i], soff);",
+                      "    for (int i = i0; i < i1; ++i) asm volatile(\"\" : \"+v\"(rv[i]) : \"v\"(ro[i]), \"s\"(soff));")],
+    "wx3_nou": [("wino_x3.hip", "    for (int pl = 0; pl < 3; ++pl) ua[pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)(pl * 1024), soff));",
+                 "    for (int pl = 0; pl < 3; ++pl) asm volatile(\"\" : \"+v\"(ua[pl]) : \"s\"(soff));")],
+    "wx3_nomfma": [("wino_x3.hip", "    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[j][PA[t]], fb[th][PB[t]], c, 0, 0, 0);",
+                    "    asm volatile(\"\" : \"+v\"(c) : \"v\"(ua[j][PA[t]]), \"v\"(fb[th][PB[t]]));")],
+    "wx3_nostore": [("wino_x3.hip", "      for (int j = 0; j < 2; ++j) *reinterpret_cast<unsigned*>(dst + pl * X_PLANE + (2 * xi + j) * X_FREQ) = qq[2 * xi + j][pl];",
+                     "      for (int j = 0; j < 2; ++j) asm volatile(\"\" :: \"v\"(qq[2 * xi + j][pl]), \"v\"(dst));")],
+    "wx3_nofrag": [("wino_x3.hip", "    fb[0][pl] = *reinterpret_cast<const bf16x8*>(vb);\n    fb[1][pl] = *reinterpret_cast<const bf16x8*>(vb + 32 * X_ROW);",
+                    "    asm volatile(\"\" : \"+v\"(fb[0][pl]), \"+v\"(fb[1][pl]) : \"v\"(vb));")],
+}
+VARIANTS["wx3_noloads"] = VARIANTS["wx3_nogather"] + VARIANTS["wx3_nou"]
+VARIANTS["wx3_mfmaonly"] = VARIANTS["wx3_noloads"] + VARIANTS["wx3_nostore"] + VARIANTS["wx3_nofrag"]
+
+
+def build(name: str) -> str:
+    out_dir = os.path.join(B.HERE, "_ab")
+    src_dir = os.path.join(out_dir, "src_" + name, "azula_amd", "csrc")
+    shutil.rmtree(os.path.join(out_dir, "src_" + name), ignore_errors=True)
+    os.makedirs(src_dir)
+    os.makedirs(os.path.join(out_dir, "src_" + name, "include"))
+    shutil.copy(os.path.join(ROOT, "include", "azula_amd.h"), os.path.join(out_dir, "src_" + name, "include"))
+    for f in os.listdir(B.HERE):
+        if f.endswith((".hip", ".h", ".inc")):
+            shutil.copy(os.path.join(B.HERE, f), src_dir)
+    touched = set()
+    for f, old, new in VARIANTS[name]:
+        path = os.path.join(src_dir, f)
+        text = open(path).read()
+        assert text.count(old) == 1, f"{name}: pattern occurs {text.count(old)} times in {f}: {old[:60]!r}"
+        open(path, "w").write(text.replace(old, new))
+        touched.add(f)
+    objs = []
+    procs = []
+    for s in B.SOURCES:
+        if s in touched:
+            obj = os.path.join(src_dir, s.replace(".hip", ".o"))
+            procs.append(subprocess.Popen([B.hipcc(), *B.FLAGS, *B.EXTRA_FLAGS.get(s, []), "-x", "hip", "-c", os.path.join(src_dir, s), "-o", obj]))
+        else:  # untouched translation units: the tree's own objects
+            obj = os.path.join(B.OBJ_DIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+    assert all(p.wait() == 0 for p in procs)
+    lib = os.path.join(out_dir, f"libazula_amd_{name}.so")
+    subprocess.run([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib], check=True)
+    shutil.rmtree(os.path.join(out_dir, "src_" + name), ignore_errors=True)
+    return lib
+
+
+if __name__ == "__main__":
+    if sys.argv[1:] == ["--list"]:
+        print("\n".join(VARIANTS))
+    else:
+        B.build()
+        for n in sys.argv[1:]:
+            print(build(n))
