@@ -2869,6 +2869,7 @@ int az_conv2d_winograd_x3_f32(const AzConvArgs* a, az_stream_t stream) {
   int splitk = 1;
   const int prc = wino_prepare(a, 16, 16ll * WC * 16 * 3 * 2, p, splitk);
   if (prc != AZ_OK) return prc;
+  AZ_REQUIRE(p.tiles_w >= 2, AZ_E_UNSUPPORTED);  // (the kernel stages <= 32 tile-row segments per 64-tile block: maps >= 3 pixels wide)
   hipStream_t st = az_s(stream);
   int rc = azi_winograd_x3_launch(p, (unsigned)splitk, st);
   if (rc != AZ_OK) return rc;

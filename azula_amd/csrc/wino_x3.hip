@@ -18,8 +18,13 @@
 //     96 KB, so the pipeline runs on HALF-stages of 8 frequencies (nu in {0, 1} | nu in {2, 3}; 48 KB each, two buffers):
 //         phase 0: MFMAs on (step s, nu 0..1) from buffer 0 | V(s, nu 2..3) -> buffer 1, raw patch of step s + 1 in flight
 //         phase 1: MFMAs on (step s, nu 2..3) from buffer 1 | B^T d of step s + 1, V(s + 1, nu 0..1) -> buffer 0
-//     one barrier per phase.  Every thread gathers: thread = (tile tid >> 3, channel pair tid & 7), 16 x 8-byte bounds-checked
-//     buffer loads per step (eight lanes read one 64-byte unit); the 16 patch offsets are parked in LDS behind the buffers.
+//     one barrier per phase.
+//   * The raw input is STAGED in LDS once per step, each pixel once: the 64 tiles of a block are runs ("segments") of
+//     horizontally adjacent tiles whose 4x4 patches overlap by two columns, so a segment of n tiles needs 4 rows x (2 n + 2)
+//     pixels instead of 16 n (the gather was 28 % of the kernel, the vector memory path its bound: profiles/r05_wx3_ablation_v2.txt).
+//     The pixels' 16 channels of the step (64 B) go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no registers, bounds-
+//     checked, padding / ragged tiles land as zeros; upsampling, two sources, circular padding are offsets), into the 64 KB behind
+//     the V buffers; then thread (tile tid >> 3, channel pair tid & 7) reads its 4x4 patch with 16 ds_read_b64.
 //   * Epilogue: the nu side of A^T M A in registers, the xi side on the way out of the LDS exchange buffer; bias / SiLU / gate /
 //     residual / split-K slabs / GroupNorm moments of the output as in the fp32 kernel.
 #include "conv_shared.h"
@@ -38,10 +43,12 @@ constexpr int X_ROW = XK * 2;                // bytes of one (frequency, tile) r
 constexpr int X_FREQ = XT * X_ROW;           // 2 KB
 constexpr int X_PLANE = 8 * X_FREQ;          // one piece of a half-stage: 16 KB
 constexpr int X_HALF = 3 * X_PLANE;          // 48 KB
-constexpr int X_VOFF = 2 * X_HALF;           // the threads' 16 patch offsets per source: 2 x 512 x 64 B behind the two half-stage buffers
+constexpr int X_STAGE = 2 * X_HALF;          // raw staging behind the two half-stage buffers: <= 768 pixel slots x 64 B = 48 KB
+constexpr int X_SLOTS = 768;                 // (8 (64 + segments) slots: up to 32 segments, i.e. maps at least 3 pixels wide; the host checks)
+constexpr int X_DOFF1 = X_STAGE + X_SLOTS * 64;  // the second source's DMA offsets (8 per thread: 16 KB), read back at the switch
 constexpr int X_OT = 2 * XC + 4;             // epilogue: floats per tile row of one xi's [tile][px][cout] exchange buffer
 constexpr int X_EPI_BYTES = (4 * XT * X_OT + 3 * XT + 384) * 4;  // 137,472 B: four xi partials + tile table + GroupNorm partials
-constexpr int X_LDS_BYTES = X_VOFF + 2 * 512 * 64;  // 163,840 B = all of a CU's LDS (>= the epilogue's exchange buffer)
+constexpr int X_LDS_BYTES = X_DOFF1 + 512 * 32;  // 163,840 B = all of a CU's LDS (>= the epilogue's exchange buffer)
 static_assert(X_LDS_BYTES >= X_EPI_BYTES, "the epilogue reuses the K loop's LDS");
 constexpr int XU_STEP_BYTES = 16 * XC * XK * 3 * 2;  // one (step, cout block) filter chunk: 96 KB
 static_assert(X_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
@@ -108,74 +115,118 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
       v_bs = az_depth_plane(a, b, v_dok) - b_base;
     }
   }
-  uint4* const park = reinterpret_cast<uint4*>(smem + X_VOFF + tid * 64);  // source 1: + 32 KB
-  auto park_offsets = [&](int src) {  // the 16 patch offsets of source `src` (separable: 4 row parts + 4 column parts) -> LDS
+  // ---- staging geometry.  Tile j of the block sits in segment g = (j + tw0) / tiles_w (tw0 = tile column of tile 0; tile rows
+  // follow each other seamlessly across images); segment g = tiles [js, js + len) of one tile row, staged as 4 rows of
+  // RS = 2 len + 2 pixels from slot S = 8 (js + g) on: slot(j, r, c) = S + r RS + 2 (j - js) + c.  Slots of the block: 8 (64 + G).
+  const int tw0 = (t0 % tiles_img) % p.tiles_w;
+  const int nseg = (XT - 1 + tw0) / p.tiles_w + 1;
+  const int nslots = 8 * (XT + nseg);
+  const int ndma = (4 * nslots + 511) >> 9;  // LDS-DMA instructions per thread and step (one 16-byte lane slot each): 5 .. 8
+  auto seg_of = [&](int g, int& js, int& len) {
+    js = max(0, g * p.tiles_w - tw0);
+    len = min(XT, (g + 1) * p.tiles_w - tw0) - js;
+  };
+  auto fdiv = [](int x, int d) {  // floor(x / d) for 0 <= x < 2^23, d > 0, without the integer-division expansion
+    int q = (int)((float)x * __builtin_amdgcn_rcpf((float)d));
+    int r = x - q * d;
+    q += r >= d ? 1 : (r < 0 ? -1 : 0);
+    return q;
+  };
+  // byte offsets of this thread's lane slots L = m * 512 + tid (pixel slot L >> 2, channels 4 (L & 3) .. + 3 of the step) in source `src`
+  unsigned doff[8];
+  auto dma_offsets = [&](int src) {
     const int cs = src ? a.c1s : a.c0s;
     const int up = src ? a.up1 : a.up0;
     const int hs = src ? a.h1 : a.h0;
     const int ws = src ? a.w1 : a.w0;
-    int rpart[4], cpart[4];
-    bool rok[4], cok[4];
+    const int row0 = t0 / p.tiles_w;  // global tile row (image * tiles_h + tile row) of tile 0
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ih = wrap_coord(v_ih0 + r, a.hin, a.pad_mode);
-      rok[r] = v_b >= 0 && v_dok && (unsigned)ih < (unsigned)a.hin;
-      rpart[r] = (v_bs * hs + (ih >> up)) * ws * cs * 4;
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int iw = wrap_coord(v_iw0 + c, a.win, a.pad_mode);
-      cok[c] = (unsigned)iw < (unsigned)a.win;
-      cpart[c] = ((iw >> up) * cs + vq * 2) * 4;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      unsigned o[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) o[c] = rok[r] && cok[c] ? (unsigned)(rpart[r] + cpart[c]) : OOB;
-      park[src * 2048 + r] = make_uint4(o[0], o[1], o[2], o[3]);
+    for (int m = 0; m < 8; ++m) {
+      const int L = m * 512 + tid;
+      const int s = L >> 2;
+      const int g = fdiv((s >> 3) + tw0, p.tiles_w + 1);
+      int js, len;
+      seg_of(g, js, len);
+      const int RS = 2 * len + 2;
+      const int o = s - 8 * (js + g);
+      const int r = fdiv(o, RS);
+      const int x = o - r * RS;
+      const int grow = row0 + g;
+      const int b = fdiv(grow, p.tiles_h);
+      const int th = grow - b * p.tiles_h;
+      const int tws = g == 0 ? tw0 : 0;
+      bool dok = true;
+      const int bs = az_depth_plane(a, b, dok) - b_base;
+      const int ih = wrap_coord(2 * th - 1 + r, a.hin, a.pad_mode);
+      const int iw = wrap_coord(2 * tws - 1 + x, a.win, a.pad_mode);
+      const bool ok = s < nslots && b < a.batch && dok && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
+      doff[m] = ok ? (unsigned)((((bs * hs + (ih >> up)) * ws + (iw >> up)) * cs + (L & 3) * 4) * 4) : OOB;
     }
   };
-  park_offsets(0);
-  if (a.src1) park_offsets(1);  // (a thread reads back only what it parked itself: no barrier)
+  uint4* const park1 = reinterpret_cast<uint4*>(smem + X_DOFF1 + tid * 32);
+  int cur_src = 0;
+  auto switch_source = [&]() __attribute__((always_inline)) {  // (a thread reads back only what it parked itself: no barrier)
+    cur_src = 1;
+    const uint4 lo = park1[0], hi = park1[1];
+    doff[0] = lo.x, doff[1] = lo.y, doff[2] = lo.z, doff[3] = lo.w, doff[4] = hi.x, doff[5] = hi.y, doff[6] = hi.z, doff[7] = hi.w;
+  };
+  if (a.src1) {
+    dma_offsets(1);
+    park1[0] = make_uint4(doff[0], doff[1], doff[2], doff[3]);
+    park1[1] = make_uint4(doff[4], doff[5], doff[6], doff[7]);
+  }
+  dma_offsets(0);
+  if (kt_begin >= p.nkc0) switch_source();  // (a split-K slice inside the second source)
+  // the thread's own patch: LDS address of (row 0, column 0), row stride; validity of its 16 positions (in_affine keeps padding at zero)
+  int pj_s, pj_len;
+  seg_of(fdiv(vj + tw0, p.tiles_w), pj_s, pj_len);
+  const int prow = (2 * pj_len + 2) * 64;
+  const char* const patch = smem + X_STAGE + (8 * (pj_s + fdiv(vj + tw0, p.tiles_w)) + 2 * (vj - pj_s)) * 64 + vq * 8;
+  unsigned vmask = 0;
+  if constexpr (AFF != 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ih = wrap_coord(v_ih0 + r, a.hin, a.pad_mode), iw = wrap_coord(v_iw0 + c, a.win, a.pad_mode);
+        if (v_b >= 0 && v_dok && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win) vmask |= 1u << (r * 4 + c);
+      }
+  }
 
   f32x2 rv[16];  // raw 4x4 patch of the channel pair (index = patch row * 4 + column), then B^T d in place
   int staged_kt = 0;
-  // the gather of step kt in pieces the issue schedule can place: the 16 parked offsets (4 LDS reads), then 4 x 4 loads
-  unsigned ro[16];
-  auto raw_offsets = [&](int kt, int q0, int q1) __attribute__((always_inline)) {
-    const uint4* pk = park + (kt >= p.nkc0 ? 2048 : 0);
-#pragma unroll
-    for (int q = q0; q < q1; ++q) {
-      const uint4 v = pk[q];
-      ro[4 * q] = v.x, ro[4 * q + 1] = v.y, ro[4 * q + 2] = v.z, ro[4 * q + 3] = v.w;
+  typedef __attribute__((address_space(3))) void lds_void;
+  // LDS-DMA instruction m of step kt: 64 lane slots of 16 bytes -> 1 KB of the staging area (lane slot L at byte 16 L)
+  auto dma = [&](int kt, int m) __attribute__((always_inline)) {
+    if (m < 5 || m < ndma) {  // (uniform; a block always has at least 520 slots = 4.06 instructions per thread)
+      const bool src1 = kt >= p.nkc0;
+      const int kc = src1 ? kt - p.nkc0 : kt;
+      const __amdgpu_buffer_rsrc_t r = src1 ? rs1 : rs0;
+      unsigned off = doff[m];
+      if constexpr (TAIL) off = kc * XK + (tid & 3) * 4 < (src1 ? a.c1s : a.c0s) ? off : OOB;  // (channel quads past the source's end)
+      lds_void* dst = (lds_void*)(smem + X_STAGE + __builtin_amdgcn_readfirstlane((m * 512 + (tid & ~63)) * 16));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, (int)off, kc * XK * 4, 0, 0);
     }
   };
-  auto raw_loads = [&](int kt, int i0, int i1) __attribute__((always_inline)) {  // kt is wave-uniform
-    const bool src1 = kt >= p.nkc0;
+  auto patch_rows = [&](int kt, int r0, int r1) __attribute__((always_inline)) {  // rows [r0, r1) of the staged patch -> rv
     staged_kt = kt;
-    const int kc = src1 ? kt - p.nkc0 : kt;
-    const unsigned soff = (unsigned)(kc * XK * 4);
-    const __amdgpu_buffer_rsrc_t r = src1 ? rs1 : rs0;  // (selects, not a branch: the phase stays one basic block)
-    bool kv = true;
-    if constexpr (TAIL) kv = kc * XK + vq * 2 < (src1 ? a.c1s : a.c0s);
 #pragma unroll
-    for (int i = i0; i < i1; ++i) rv[i] = buf_ld2(r, TAIL && !kv ? OOB : ro[i], soff);
+    for (int r = r0; r < r1; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) rv[4 * r + c] = *reinterpret_cast<const f32x2*>(patch + r * prow + c * 64);
   };
   // with in_affine the input is act(x * scale + shift) (padding positions stay zero): applied to the raw patch in place
   auto affine = [&]() __attribute__((always_inline)) {
     if constexpr (AFF != 0) {
       const float* sp = a.in_affine + ((int64_t)(b_first + (v_b < 0 ? 0 : v_b)) * a.c0s + staged_kt * XK + vq * 2);
-      const bool kv = !TAIL || staged_kt * XK + vq * 2 < a.c0s;  // (masked pairs hold zeros and stay zero: their positions read OOB below)
+      const bool kv = !TAIL || staged_kt * XK + vq * 2 < a.c0s;  // (masked pairs hold zeros and stay zero)
       const f32x2 sc = kv ? *reinterpret_cast<const f32x2*>(sp) : f32x2{0.f, 0.f};
       const f32x2 sh = kv ? *reinterpret_cast<const f32x2*>(sp + (int64_t)a.batch * a.c0s) : f32x2{0.f, 0.f};
-      const uint4 o0 = park[0], o1 = park[1], o2 = park[2], o3 = park[3];
-      const unsigned o[16] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y, o2.z, o2.w, o3.x, o3.y, o3.z, o3.w};
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         f32x2 v = rv[i] * sc + sh;
         if constexpr (AFF == 2) v = f32x2{az_silu(v.x), az_silu(v.y)};
-        rv[i] = o[i] == OOB ? f32x2{0.f, 0.f} : v;
+        rv[i] = (vmask >> i) & 1u ? v : f32x2{0.f, 0.f};
       }
     }
   };
@@ -267,24 +318,26 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
     const int ktu = hs == 0 ? kt : ktn;  // the step whose filter fragments are loaded next
     // slots 0 .. 5: the head of the phase
     if constexpr (hs == 0) {
-      mf(hs, 0); nu_side(ob, 0); nu_side(ob, 1); XS_FENCE;
-      mf(hs, 1); nu_side(ob, 2); nu_side(ob, 3); XS_FENCE;  // rv is free from here
-      mf(hs, 2); frag(hs, 1, 2); raw_offsets(ktn, 0, 2); split_a(0); XS_FENCE;
-      mf(hs, 3); raw_offsets(ktn, 2, 4); split_b(0); XS_FENCE;
-      mf(hs, 4); raw_loads(ktn, 0, 4); split_a(1); XS_FENCE;
-      mf(hs, 5); raw_loads(ktn, 4, 8); split_b(1); XS_FENCE;
-      mf(hs, 6); raw_loads(ktn, 8, 12); store_row(ob, 0); XS_FENCE;
-      mf(hs, 7); raw_loads(ktn, 12, 16); split_a(2); XS_FENCE;
+      // (the staging area is free: every thread read its patch of step kt at the head of the previous phase 1)
+      mf(hs, 0); dma(ktn, 0); nu_side(ob, 0); nu_side(ob, 1); XS_FENCE;
+      mf(hs, 1); dma(ktn, 1); nu_side(ob, 2); nu_side(ob, 3); XS_FENCE;
+      mf(hs, 2); dma(ktn, 2); frag(hs, 1, 2); split_a(0); XS_FENCE;
+      mf(hs, 3); dma(ktn, 3); split_b(0); XS_FENCE;
+      mf(hs, 4); dma(ktn, 4); split_a(1); XS_FENCE;
+      mf(hs, 5); dma(ktn, 5); split_b(1); XS_FENCE;
+      mf(hs, 6); dma(ktn, 6); store_row(ob, 0); XS_FENCE;
+      mf(hs, 7); dma(ktn, 7); split_a(2); XS_FENCE;
       mf(hs, 8); frag(hs, 1, 1); split_b(2); XS_FENCE;
       mf(hs, 9); split_a(3); XS_FENCE;
       mf(hs, 10); split_b(3); XS_FENCE;
       mf(hs, 11); store_row(ob, 1); XS_FENCE;
     } else {
+      // (the raw pixels of step ktn are staged: behind the barrier that closed phase 0)
+      mf(hs, 0); patch_rows(ktn, 0, 2); XS_FENCE;
+      mf(hs, 1); patch_rows(ktn, 2, 4); XS_FENCE;
       affine();
-      mf(hs, 0); row_transform(0); XS_FENCE;
-      mf(hs, 1); row_transform(1); XS_FENCE;
-      mf(hs, 2); frag(hs, 1, 2); row_transform(2); XS_FENCE;
-      mf(hs, 3); row_transform(3); XS_FENCE;
+      mf(hs, 2); frag(hs, 1, 2); row_transform(0); row_transform(1); XS_FENCE;
+      mf(hs, 3); row_transform(2); row_transform(3); XS_FENCE;
       mf(hs, 4); nu_side(ob, 0); nu_side(ob, 1); XS_FENCE;
       mf(hs, 5); nu_side(ob, 2); nu_side(ob, 3); XS_FENCE;
       mf(hs, 6); split_a(0); XS_FENCE;
@@ -322,6 +375,11 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
       mf(hs, 23); store_row(ob, 3);
     }
     load_u(ktu, hs == 0 ? 3 : 1, ua[1]);
+    if constexpr (hs == 0) {
+      // this wave's LDS-DMA pieces must have landed before the barrier publishes the staging area: everything but the six
+      // filter loads issued behind them (vector memory operations complete in order)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
     // the NEXT phase's first frequency: its buffer is complete behind the barrier
     __syncthreads();
     frag(ob, 0, 2); frag(ob, 0, 1); frag(ob, 0, 0);
@@ -329,10 +387,13 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
   };
 
   if (kt_begin < kt_end) {
-    raw_offsets(kt_begin, 0, 4);
-    raw_loads(kt_begin, 0, 16);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) dma(kt_begin, m);
     load_u(kt_begin, 0, ua[0]);
     load_u(kt_begin, 1, ua[1]);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __syncthreads();
+    patch_rows(kt_begin, 0, 4);
     affine();
 #pragma unroll
     for (int c = 0; c < 4; ++c) row_transform(c);
@@ -347,6 +408,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
 #pragma unroll 1
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int ktn = min(kt + 1, kt_end - 1);  // (the last step restages itself into a buffer nobody reads: no branch in the body)
+      if (ktn >= p.nkc0 && cur_src == 0) switch_source();  // (uniform, once per K walk: this iteration gathers from the second source)
       phase(std::integral_constant<int, 0>{}, kt, ktn);
       phase(std::integral_constant<int, 1>{}, kt, ktn);
     }
