@@ -22,9 +22,9 @@
 //   * The raw input is STAGED in LDS once per step, each pixel once: the 64 tiles of a block are runs ("segments") of
 //     horizontally adjacent tiles whose 4x4 patches overlap by two columns, so a segment of n tiles needs 4 rows x (2 n + 2)
 //     pixels instead of 16 n (the gather was 28 % of the kernel, the vector memory path its bound: profiles/r05_wx3_ablation_v2.txt).
-//     The pixels' 16 channels of the step (64 B) go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no registers, bounds-
-//     checked, padding / ragged tiles land as zeros; upsampling, two sources, circular padding are offsets), into the 64 KB behind
-//     the V buffers; then thread (tile tid >> 3, channel pair tid & 7) reads its 4x4 patch with 16 ds_read_b64.
+//     The pixels' 16 channels of the step (64 B) go global -> registers -> LDS as 16-byte lane slots (bounds-checked buffer loads:
+//     padding / ragged tiles land as zeros; upsampling, two sources, circular padding are offsets), into the 48 KB behind the V
+//     buffers; then thread (tile tid >> 3, channel pair tid & 7) reads its 4x4 patch with 16 ds_read_b64.
 //   * Epilogue: the nu side of A^T M A in registers, the xi side on the way out of the LDS exchange buffer; bias / SiLU / gate /
 //     residual / split-K slabs / GroupNorm moments of the output as in the fp32 kernel.
 #include "conv_shared.h"
@@ -45,12 +45,13 @@ constexpr int X_PLANE = 8 * X_FREQ;          // one piece of a half-stage: 16 KB
 constexpr int X_HALF = 3 * X_PLANE;          // 48 KB
 constexpr int X_STAGE = 2 * X_HALF;          // raw staging behind the two half-stage buffers: <= 768 pixel slots x 64 B = 48 KB
 constexpr int X_SLOTS = 768;                 // (8 (64 + segments) slots: up to 32 segments, i.e. maps at least 3 pixels wide; the host checks)
-constexpr int X_DOFF1 = X_STAGE + X_SLOTS * 64;  // the second source's DMA offsets (8 per thread: 16 KB), read back at the switch
+constexpr int X_DOFF1 = X_STAGE + X_SLOTS * 64;  // the second source's staging offsets (6 per thread, 32 B apart: 16 KB), read back at the switch
 constexpr int X_OT = 2 * XC + 4;             // epilogue: floats per tile row of one xi's [tile][px][cout] exchange buffer
 constexpr int X_EPI_BYTES = (4 * XT * X_OT + 3 * XT + 384) * 4;  // 137,472 B: four xi partials + tile table + GroupNorm partials
 constexpr int X_LDS_BYTES = X_DOFF1 + 512 * 32;  // 163,840 B = all of a CU's LDS (>= the epilogue's exchange buffer)
 static_assert(X_LDS_BYTES >= X_EPI_BYTES, "the epilogue reuses the K loop's LDS");
 constexpr int XU_STEP_BYTES = 16 * XC * XK * 3 * 2;  // one (step, cout block) filter chunk: 96 KB
+static_assert(4 * X_SLOTS <= 6 * 512, "six staging pieces per thread");
 static_assert(X_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
 // AFF: 0 = plain input, 1 = the input is x * scale + shift (in_affine: a GroupNorm apply pass folded into the gather), 2 = SiLU of that.
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
   const int tw0 = (t0 % tiles_img) % p.tiles_w;
   const int nseg = (XT - 1 + tw0) / p.tiles_w + 1;
   const int nslots = 8 * (XT + nseg);
-  const int ndma = (4 * nslots + 511) >> 9;  // LDS-DMA instructions per thread and step (one 16-byte lane slot each): 5 .. 8
+  const int ndma = (4 * nslots + 511) >> 9;  // staging pieces per thread and step (one 16-byte lane slot each): 5 or 6 (nslots <= 768)
   auto seg_of = [&](int g, int& js, int& len) {
     js = max(0, g * p.tiles_w - tw0);
     len = min(XT, (g + 1) * p.tiles_w - tw0) - js;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
     return q;
   };
   // byte offsets of this thread's lane slots L = m * 512 + tid (pixel slot L >> 2, channels 4 (L & 3) .. + 3 of the step) in source `src`
-  unsigned doff[8];
+  unsigned doff[6];
   auto dma_offsets = [&](int src) {
     const int cs = src ? a.c1s : a.c0s;
     const int up = src ? a.up1 : a.up0;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
     const int ws = src ? a.w1 : a.w0;
     const int row0 = t0 / p.tiles_w;  // global tile row (image * tiles_h + tile row) of tile 0
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < 6; ++m) {
       const int L = m * 512 + tid;
       const int s = L >> 2;
       const int g = fdiv((s >> 3) + tw0, p.tiles_w + 1);
@@ -168,12 +169,12 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
   auto switch_source = [&]() __attribute__((always_inline)) {  // (a thread reads back only what it parked itself: no barrier)
     cur_src = 1;
     const uint4 lo = park1[0], hi = park1[1];
-    doff[0] = lo.x, doff[1] = lo.y, doff[2] = lo.z, doff[3] = lo.w, doff[4] = hi.x, doff[5] = hi.y, doff[6] = hi.z, doff[7] = hi.w;
+    doff[0] = lo.x, doff[1] = lo.y, doff[2] = lo.z, doff[3] = lo.w, doff[4] = hi.x, doff[5] = hi.y;
   };
   if (a.src1) {
     dma_offsets(1);
     park1[0] = make_uint4(doff[0], doff[1], doff[2], doff[3]);
-    park1[1] = make_uint4(doff[4], doff[5], doff[6], doff[7]);
+    park1[1] = make_uint4(doff[4], doff[5], 0u, 0u);
   }
   dma_offsets(0);
   if (kt_begin >= p.nkc0) switch_source();  // (a split-K slice inside the second source)
@@ -195,18 +196,22 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
 
   f32x2 rv[16];  // raw 4x4 patch of the channel pair (index = patch row * 4 + column), then B^T d in place
   int staged_kt = 0;
-  typedef __attribute__((address_space(3))) void lds_void;
-  // LDS-DMA instruction m of step kt: 64 lane slots of 16 bytes -> 1 KB of the staging area (lane slot L at byte 16 L)
-  auto dma = [&](int kt, int m) __attribute__((always_inline)) {
-    if (m < 5 || m < ndma) {  // (uniform; a block always has at least 520 slots = 4.06 instructions per thread)
+  // piece m of the staging of step kt: this thread's lane slot L = m * 512 + tid (16 bytes) global -> registers (gl), and on to
+  // the staging area at byte 16 L (gs) half a phase later.  (LDS-DMA moved the same bytes without registers, but one
+  // buffer_load ... lds costs the issuing wave 100 - 180 cycles beside MFMAs: profiles/r05_wx3_timeline_v3.txt.)
+  float4 gq[6];
+  auto gl = [&](int kt, int m) __attribute__((always_inline)) {
+    if (m < 5 || m < ndma) {  // (uniform; a block always has at least 520 slots = 4.06 pieces per thread)
       const bool src1 = kt >= p.nkc0;
       const int kc = src1 ? kt - p.nkc0 : kt;
       const __amdgpu_buffer_rsrc_t r = src1 ? rs1 : rs0;
       unsigned off = doff[m];
       if constexpr (TAIL) off = kc * XK + (tid & 3) * 4 < (src1 ? a.c1s : a.c0s) ? off : OOB;  // (channel quads past the source's end)
-      lds_void* dst = (lds_void*)(smem + X_STAGE + __builtin_amdgcn_readfirstlane((m * 512 + (tid & ~63)) * 16));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, (int)off, kc * XK * 4, 0, 0);
+      gq[m] = buf_ld4(r, off, (unsigned)(kc * XK * 4));
     }
+  };
+  auto gs = [&](int m) __attribute__((always_inline)) {
+    if (m < 5 || m < ndma) *reinterpret_cast<float4*>(smem + X_STAGE + (m * 512 + tid) * 16) = gq[m];
   };
   auto patch_rows = [&](int kt, int r0, int r1) __attribute__((always_inline)) {  // rows [r0, r1) of the staged patch -> rv
     staged_kt = kt;
@@ -316,70 +321,63 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
     constexpr int hs = decltype(HS)::value;
     constexpr int ob = 1 - hs;  // the buffer (and half of the frequencies) this phase produces
     const int ktu = hs == 0 ? kt : ktn;  // the step whose filter fragments are loaded next
-    // slots 0 .. 5: the head of the phase
     if constexpr (hs == 0) {
-      // (the staging area is free: every thread read its patch of step kt at the head of the previous phase 1)
-      mf(hs, 0); dma(ktn, 0); nu_side(ob, 0); nu_side(ob, 1); XS_FENCE;
-      mf(hs, 1); dma(ktn, 1); nu_side(ob, 2); nu_side(ob, 3); XS_FENCE;
-      mf(hs, 2); dma(ktn, 2); frag(hs, 1, 2); split_a(0); XS_FENCE;
-      mf(hs, 3); dma(ktn, 3); split_b(0); XS_FENCE;
-      mf(hs, 4); dma(ktn, 4); split_a(1); XS_FENCE;
-      mf(hs, 5); dma(ktn, 5); split_b(1); XS_FENCE;
-      mf(hs, 6); dma(ktn, 6); store_row(ob, 0); XS_FENCE;
-      mf(hs, 7); dma(ktn, 7); split_a(2); XS_FENCE;
+      // (rv holds B^T d of step kt until the nu side is done; the staging area is free: every thread read its patch of
+      //  step kt at the head of the previous phase 1)
+      mf(hs, 0); nu_side(ob, 0); nu_side(ob, 1); XS_FENCE;
+      mf(hs, 1); nu_side(ob, 2); nu_side(ob, 3); XS_FENCE;
+      mf(hs, 2); frag(hs, 1, 2); gl(ktn, 0); split_a(0); XS_FENCE;
+      mf(hs, 3); gl(ktn, 1); split_b(0); XS_FENCE;
+      mf(hs, 4); gl(ktn, 2); split_a(1); XS_FENCE;
+      mf(hs, 5); gl(ktn, 3); split_b(1); XS_FENCE;
+      mf(hs, 6); gl(ktn, 4); store_row(ob, 0); XS_FENCE;
+      mf(hs, 7); gl(ktn, 5); split_a(2); XS_FENCE;
       mf(hs, 8); frag(hs, 1, 1); split_b(2); XS_FENCE;
       mf(hs, 9); split_a(3); XS_FENCE;
       mf(hs, 10); split_b(3); XS_FENCE;
       mf(hs, 11); store_row(ob, 1); XS_FENCE;
-    } else {
-      // (the raw pixels of step ktn are staged: behind the barrier that closed phase 0)
-      mf(hs, 0); patch_rows(ktn, 0, 2); XS_FENCE;
-      mf(hs, 1); patch_rows(ktn, 2, 4); XS_FENCE;
-      affine();
-      mf(hs, 2); frag(hs, 1, 2); row_transform(0); row_transform(1); XS_FENCE;
-      mf(hs, 3); row_transform(2); row_transform(3); XS_FENCE;
-      mf(hs, 4); nu_side(ob, 0); nu_side(ob, 1); XS_FENCE;
-      mf(hs, 5); nu_side(ob, 2); nu_side(ob, 3); XS_FENCE;
-      mf(hs, 6); split_a(0); XS_FENCE;
-      mf(hs, 7); split_b(0); XS_FENCE;
-      mf(hs, 8); frag(hs, 1, 1); split_a(1); XS_FENCE;
-      mf(hs, 9); split_b(1); XS_FENCE;
-      mf(hs, 10); store_row(ob, 0); split_a(2); XS_FENCE;
-      mf(hs, 11); split_b(2); XS_FENCE;
-    }
-    // second frequency: its B pieces 2 and 1 are in place; piece 0 and the first frequency's filter fragments behind MFMA 11
-    mf(hs, 12); frag(hs, 1, 0); load_u(ktu, hs == 0 ? 2 : 0, ua[0]); XS_FENCE;
-    if constexpr (hs == 0) {
+      // second frequency: its B pieces 2 and 1 are in place; piece 0 and the first frequency's filter fragments behind MFMA 11
+      mf(hs, 12); frag(hs, 1, 0); load_u(ktu, 2, ua[0]); XS_FENCE;
       mf(hs, 13); split_a(4); XS_FENCE;
-      mf(hs, 14); split_b(4); XS_FENCE;
-      mf(hs, 15); split_a(5); XS_FENCE;
-      mf(hs, 16); split_b(5); XS_FENCE;
-      mf(hs, 17); store_row(ob, 2); XS_FENCE;
-      mf(hs, 18); split_a(6); XS_FENCE;
-      mf(hs, 19); split_b(6); XS_FENCE;
+      mf(hs, 14); split_b(4); gs(0); XS_FENCE;
+      mf(hs, 15); split_a(5); gs(1); XS_FENCE;
+      mf(hs, 16); split_b(5); gs(2); XS_FENCE;
+      mf(hs, 17); store_row(ob, 2); gs(3); XS_FENCE;
+      mf(hs, 18); split_a(6); gs(4); XS_FENCE;
+      mf(hs, 19); split_b(6); gs(5); XS_FENCE;
       mf(hs, 20); split_a(7); XS_FENCE;
       mf(hs, 21); split_b(7); XS_FENCE;
       mf(hs, 22); store_row(ob, 3); XS_FENCE;
       mf(hs, 23);
     } else {
-      mf(hs, 13); split_a(3); XS_FENCE;
-      mf(hs, 14); split_b(3); store_row(ob, 1); XS_FENCE;
-      mf(hs, 15); split_a(4); XS_FENCE;
-      mf(hs, 16); split_b(4); XS_FENCE;
-      mf(hs, 17); split_a(5); XS_FENCE;
-      mf(hs, 18); split_b(5); store_row(ob, 2); XS_FENCE;
-      mf(hs, 19); split_a(6); XS_FENCE;
-      mf(hs, 20); split_b(6); XS_FENCE;
-      mf(hs, 21); split_a(7); XS_FENCE;
-      mf(hs, 22); split_b(7); XS_FENCE;
-      mf(hs, 23); store_row(ob, 3);
+      // (the raw pixels of step ktn are staged: behind the barrier that closed phase 0; their readers sit four slots away)
+      mf(hs, 0); patch_rows(ktn, 0, 2); XS_FENCE;
+      mf(hs, 1); patch_rows(ktn, 2, 4); XS_FENCE;
+      mf(hs, 2); frag(hs, 1, 2); XS_FENCE;
+      mf(hs, 3); XS_FENCE;
+      affine();
+      mf(hs, 4); row_transform(0); row_transform(1); XS_FENCE;
+      mf(hs, 5); row_transform(2); row_transform(3); XS_FENCE;
+      mf(hs, 6); nu_side(ob, 0); nu_side(ob, 1); XS_FENCE;
+      mf(hs, 7); nu_side(ob, 2); nu_side(ob, 3); XS_FENCE;
+      mf(hs, 8); frag(hs, 1, 1); split_a(0); XS_FENCE;
+      mf(hs, 9); split_b(0); XS_FENCE;
+      mf(hs, 10); split_a(1); XS_FENCE;
+      mf(hs, 11); split_b(1); XS_FENCE;
+      mf(hs, 12); frag(hs, 1, 0); load_u(ktu, 0, ua[0]); store_row(ob, 0); XS_FENCE;
+      mf(hs, 13); split_a(2); XS_FENCE;
+      mf(hs, 14); split_b(2); XS_FENCE;
+      mf(hs, 15); split_a(3); XS_FENCE;
+      mf(hs, 16); split_b(3); store_row(ob, 1); XS_FENCE;
+      mf(hs, 17); split_a(4); XS_FENCE;
+      mf(hs, 18); split_b(4); XS_FENCE;
+      mf(hs, 19); split_a(5); XS_FENCE;
+      mf(hs, 20); split_b(5); store_row(ob, 2); XS_FENCE;
+      mf(hs, 21); split_a(6); split_b(6); XS_FENCE;
+      mf(hs, 22); split_a(7); XS_FENCE;
+      mf(hs, 23); split_b(7); store_row(ob, 3);
     }
     load_u(ktu, hs == 0 ? 3 : 1, ua[1]);
-    if constexpr (hs == 0) {
-      // this wave's LDS-DMA pieces must have landed before the barrier publishes the staging area: everything but the six
-      // filter loads issued behind them (vector memory operations complete in order)
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    }
     // the NEXT phase's first frequency: its buffer is complete behind the barrier
     __syncthreads();
     frag(ob, 0, 2); frag(ob, 0, 1); frag(ob, 0, 0);
@@ -388,10 +386,11 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
 
   if (kt_begin < kt_end) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) dma(kt_begin, m);
+    for (int m = 0; m < 6; ++m) gl(kt_begin, m);
     load_u(kt_begin, 0, ua[0]);
     load_u(kt_begin, 1, ua[1]);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < 6; ++m) gs(m);
     __syncthreads();
     patch_rows(kt_begin, 0, 4);
     affine();
@@ -405,6 +404,9 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
     }
     __syncthreads();
     frag(0, 0, 2); frag(0, 0, 1); frag(0, 0, 0);
+    // waves 4 .. 7 are the younger half of every SIMD pair and lose the vector-issue arbitration by age (they ran 1600 - 2000 cycles
+    // through the first 12 slots of a phase where waves 0 .. 3 took 1100 - 1250, which then waited at the barrier): static priority
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int ktn = min(kt + 1, kt_end - 1);  // (the last step restages itself into a buffer nobody reads: no branch in the body)
@@ -412,6 +414,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
       phase(std::integral_constant<int, 0>{}, kt, ktn);
       phase(std::integral_constant<int, 1>{}, kt, ktn);
     }
+    __builtin_amdgcn_s_setprio(0);
   } else {
     __syncthreads();
   }

@@ -134,11 +134,14 @@ WINOGRAD = os.environ.get("AZ_WINOGRAD", "1")
 # EXACTLY into three bf16 pieces, the six largest partial products accumulated in fp32 on v_mfma_f32_32x32x16_bf16
 # (az_conv2d_x3_f32) -- measured MORE accurate against fp64 than the fp32 MFMA (tests/test_gpu_kernels.py::
 # test_conv2d_x3_accuracy) at 0.375 x its matrix-pipe time: DiT-B/2 54.7 -> 70.1 images/s, JiT-B/16 43.6 -> 58.4.
-# "native": v_mfma_f32_32x32x2_f32 everywhere.  The stride-1 3 x 3 convolutions stay on the fp32 Winograd kernel in both modes.
+# "native": v_mfma_f32_32x32x2_f32 everywhere.  The stride-1 3 x 3 convolutions run the Winograd kernel in both modes (bf16x3: WINO_X3 below).
 FP32_MFMA = os.environ.get("AZ_FP32_MFMA", "bf16x3")
 assert FP32_MFMA in ("native", "bf16x3"), FP32_MFMA
 ATTN_X3 = os.environ.get("AZ_ATTN_X3", "1") != "0"  # bf16x3 mode: attention contractions on the bf16 pipe too (az_attention_x3_f32)
-WINO_X3 = os.environ.get("AZ_WINO_X3", "0") != "0" and FP32_MFMA == "bf16x3"  # the Winograd frequency GEMMs on the bf16 pipe too
+# The stride-1 3 x 3 layers in bf16x3 mode: "1" (default since round 5) = the Winograd kernel with its 16 frequency GEMMs on the bf16 pipe
+# as exact 3 x bf16 splits too (az_conv2d_winograd_x3_f32, csrc/wino_x3.hip: same transforms, same epilogue, 1.19 - 1.28 x the fp32
+# stream on the UNet / ADM layers, profiles/r05_wx3_*); "0" = the fp32-MFMA Winograd stream (always the one in "native" mode).
+WINO_X3 = os.environ.get("AZ_WINO_X3", "1") != "0"
 X3_MIN_CHANNELS = 32  # bf16x3 only where both channel counts fill a K tile / an MFMA tile
 WINOGRAD4_MIN_TILES = int(os.environ.get("AZ_WINOGRAD4_MIN_TILES", "1024"))
 # q / k RMS norm, gains and RoPE of an attention layer in the epilogue of its qkv projection ("0": inside the attention kernel)
@@ -426,7 +429,7 @@ class Builder:
             a.weight = packed.winograd4().data_ptr()
             a.splitk = lib.az_conv2d_winograd4_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
             name = "az_conv2d_winograd4_f32"
-        elif use_wino and (winograd == "wx3" or (winograd is None and WINO_X3)):
+        elif use_wino and wout >= 3 and (winograd == "wx3" or (winograd is None and WINO_X3 and FP32_MFMA == "bf16x3")):
             # the frequency GEMMs on the bf16 pipe as exact 3 x bf16 splits (wino_x3.hip); same descriptor, 16-channel steps
             a.weight = packed.winograd_x3().data_ptr()
             name = "az_conv2d_winograd_x3_f32"

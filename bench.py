@@ -128,8 +128,8 @@ def build_denoiser(cfg, device):
     return KarrasDenoiser(wrapped, VPSchedule()).to(device).eval()
 
 
-CONV_OPS = ("az_conv2d_f32", "az_conv2d_winograd_f32", "az_conv2d_winograd4_f32", "az_conv2d_bf16_f32", "az_conv2d_f16_f32",
-            "az_conv2d_x3_f32")
+CONV_OPS = ("az_conv2d_f32", "az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32", "az_conv2d_winograd4_f32", "az_conv2d_bf16_f32",
+            "az_conv2d_f16_f32", "az_conv2d_x3_f32")
 ATTN_OPS = ("az_attention_f32", "az_attention_x3_f32", "az_attention_bf16_f32", "az_attention_f16_f32")
 
 
@@ -218,7 +218,7 @@ def tape_profile(sampler, device):
 KERNEL_OF = {  # C-ABI entry point -> the __global__ kernel it launches (names as rocprofv3 prints them)
     "az_conv2d_winograd_f32": "conv_winograd_kernel", "az_conv2d_f32": "conv_igemm_kernel", "az_attention_f32": "attention_kernel", "az_attention_x3_f32": "attention_x3_kernel",
     "az_conv2d_stem_f32": "conv_stem_kernel", "az_conv2d_bf16_f32": "conv_igemm_half_kernel", "az_conv2d_f16_f32": "conv_igemm_half_kernel", "az_conv2d_x3_f32": "conv_gemm_x3_big_kernel / conv_igemm_x3_kernel",  # (256 x 256 tiles where they fill rounds / 128 x 128 tiles)
-    "az_conv2d_winograd4_f32": "conv_winograd4_kernel",
+    "az_conv2d_winograd4_f32": "conv_winograd4_kernel", "az_conv2d_winograd_x3_f32": "conv_winograd_x3_kernel",
 }
 
 
@@ -663,9 +663,9 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
     for fam, f in fams.items():
         if not f["flops"]:
             continue
-        wino = fam == "az_conv2d_winograd_f32"
-        x3 = fam in ("az_conv2d_x3_f32", "az_attention_x3_f32")  # 3 x bf16 operand pieces, 6 partial products per fp32 product
-        peak = PEAK_BF16_TFLOPS / X3_PRODUCTS if x3 else PEAK_FP32_TFLOPS * (WINOGRAD_GAIN if wino else 1.0)
+        wino = fam in ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32")
+        x3 = fam in ("az_conv2d_x3_f32", "az_attention_x3_f32", "az_conv2d_winograd_x3_f32")  # 3 x bf16 operand pieces, 6 partial products per fp32 product
+        peak = (PEAK_BF16_TFLOPS / X3_PRODUCTS if x3 else PEAK_FP32_TFLOPS) * (WINOGRAD_GAIN if wino else 1.0)
         f = dict(f, ms_event_pairs=f["ms"], ms=b2b[fam])  # the family's launches back to back inside one event pair
         tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
         k = {
@@ -680,14 +680,18 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
                       "frac_from_graph_step: the conservative figure, see there.  avg_us_with_event_pairs: one pair per launch (~10 us of idle each)",
             "algorithmic_over_nominal": round(tf / PEAK_FP32_TFLOPS, 4),  # (algorithmic FLOP/s over the fp32 MFMA peak, as SURVEY 8d is written)
             "algorithmic_flops_per_step": f["flops"],
-            "executed_mfma_tflops": round(tf * X3_PRODUCTS if x3 else tf / (WINOGRAD_GAIN if wino else 1.0), 2),
+            "executed_mfma_tflops": round(tf * (X3_PRODUCTS if x3 else 1.0) / (WINOGRAD_GAIN if wino else 1.0), 2),
             "mfma_peak": PEAK_BF16_TFLOPS if x3 else PEAK_FP32_TFLOPS,
             "traffic": None,
         }
         if x3:
             k["peak_note"] = (f"{PEAK_BF16_TFLOPS} TF/s dense bf16 MFMA / {X3_PRODUCTS}: every fp32 product is six v_mfma_f32_32x32x16_bf16 partial "
                               "products of exact 3 x bf16 operand splits (fp32 accumulate); frac = executed bf16 MFMA FLOP/s / the bf16 MFMA peak")
-        if wino:
+        if wino and x3:
+            k["peak_note"] = (f"{PEAK_BF16_TFLOPS} TF/s dense bf16 MFMA / {X3_PRODUCTS} x {WINOGRAD_GAIN}: F(2x2,3x3) executes 4 multiplies per output "
+                              "where the algorithmic (direct) count has 9, and every fp32 product of its 16 frequency GEMMs is six "
+                              "v_mfma_f32_32x32x16_bf16 partial products of exact 3 x bf16 splits; frac = executed bf16 MFMA FLOP/s / the bf16 MFMA peak")
+        elif wino:
             k["peak_note"] = (f"{PEAK_FP32_TFLOPS} TF/s fp32 MFMA x {WINOGRAD_GAIN}: F(2x2,3x3) executes 4 multiplies per output where the "
                               "algorithmic (direct) count has 9; frac = executed MFMA FLOP/s / the fp32 MFMA peak")
         kn = KERNEL_OF.get(fam)
@@ -712,7 +716,7 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
     dom["ms_per_denoise_step_from_graph_step"] = round(dom_ms_graph, 3)
     roof = dict(dom)
     roof["graph_ms_per_denoise_step"] = round(graph_step_ms, 3)
-    if not args.half and dom["kernel"] not in ("attention_kernel", "attention_x3_kernel") and dom["entry"] != "az_conv2d_x3_f32":
+    if not args.half and dom["kernel"] not in ("attention_kernel", "attention_x3_kernel") and dom["entry"] not in ("az_conv2d_x3_f32", "az_conv2d_winograd_x3_f32"):
         sus = sustained_mfma_tflops(device)
         sus_rnd = sustained_mfma_tflops(device, random_operands=True)
         roof["sustained_mfma_tflops"] = round(sus, 1)
@@ -723,17 +727,21 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
                                   "multiplies constants (no bit activity, ~690 W: the pipe holds the nominal peak), "
                                   "az_calib_mfma_random_f32 per-lane random operands (the activity of real data: the 1400 W cap sets the "
                                   "clock -- tools/power_probe.py, profiles/r04_power_probe.txt); `frac` stays relative to the nominal peak")
-    if not args.half and "az_conv2d_x3_f32" in kernels:
-        # the bf16x3 family: what the 1400 W cap leaves v_mfma_f32_32x32x16_bf16 on random operands, registers only (az_calib_mfma_random_bf16,
-        # 2 waves per SIMD); the family's `frac` stays on the nominal 2516.8 TF/s
+    if not args.half and any(e in kernels for e in ("az_conv2d_x3_f32", "az_conv2d_winograd_x3_f32")):
+        # the bf16x3 families: what the 1400 W cap leaves v_mfma_f32_32x32x16_bf16 on random operands, registers only (az_calib_mfma_random_bf16,
+        # 2 waves per SIMD); the families' `frac` stays on the nominal 2516.8 TF/s
         sus16 = sustained_mfma_tflops(device, bf16=True)
-        x3k = kernels["az_conv2d_x3_f32"]
-        x3k["sustained_bf16_mfma_tflops_random_operands"] = round(sus16, 1)
-        x3k["frac_of_sustained_random_operands"] = round(x3k["executed_mfma_tflops"] / sus16, 4)
-        if dom is x3k:
-            roof["sustained_bf16_mfma_tflops_random_operands"] = x3k["sustained_bf16_mfma_tflops_random_operands"]
-            roof["frac_of_sustained_random_operands"] = x3k["frac_of_sustained_random_operands"]
-    mf = "bf16 v_mfma_f32_32x32x16_bf16, 6 partial products per fp32 product" if dom["entry"] == "az_conv2d_x3_f32" else "fp32 v_mfma_f32_32x32x2_f32"
+        for e in ("az_conv2d_x3_f32", "az_conv2d_winograd_x3_f32"):
+            if e not in kernels:
+                continue
+            x3k = kernels[e]
+            x3k["sustained_bf16_mfma_tflops_random_operands"] = round(sus16, 1)
+            x3k["frac_of_sustained_random_operands"] = round(x3k["executed_mfma_tflops"] / sus16, 4)
+            if dom is x3k:
+                roof["sustained_bf16_mfma_tflops_random_operands"] = x3k["sustained_bf16_mfma_tflops_random_operands"]
+                roof["frac_of_sustained_random_operands"] = x3k["frac_of_sustained_random_operands"]
+    mf = ("bf16 v_mfma_f32_32x32x16_bf16, 6 partial products per fp32 product" if dom["entry"] in ("az_conv2d_x3_f32", "az_conv2d_winograd_x3_f32")
+          else "fp32 v_mfma_f32_32x32x2_f32")
     roof["kernel"] = f"{dom['kernel']} ({mf}), all {dom['launches']} launches of one denoise step"
     roof["note"] = ("achieved = ALGORITHMIC FLOP (2*pixels*Cout*Cin*k^2; attention 4*B*H*T^2*d) of the kernel's launches in one "
                     "denoise step / the sum of their HIP-event durations; traffic = HBM-side bytes per launch from rocprofv3 "

@@ -30,6 +30,38 @@ VARIANTS = {
 VARIANTS["wx3_noloads"] = VARIANTS["wx3_nogather"] + VARIANTS["wx3_nou"]
 VARIANTS["wx3_mfmaonly"] = VARIANTS["wx3_noloads"] + VARIANTS["wx3_nostore"] + VARIANTS["wx3_nofrag"]
 
+# ---- wino_x3.hip: per-wave phase timeline (s_memtime sums per workgroup, waves 0 and 4 of the first 512 workgroups):
+#      sections of a phase: [0] slots 0-11, [1] slots 12-23, [2] filter loads + wait for the LDS-DMA, [3] barrier + next fragments
+VARIANTS["wx3_tl"] = [
+    ("wino_x3.hip", "namespace {\n\ntypedef __bf16 bf16x8",
+     "__device__ unsigned az_wx3_tl[512 * 2 * 12];\n"
+     "extern \"C\" int az_debug_wx3_timeline(unsigned* host, int n_words) {\n"
+     "  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(az_wx3_tl), (size_t)n_words * 4, 0, hipMemcpyDeviceToHost);\n}\n"
+     "namespace {\n\ntypedef __bf16 bf16x8"),
+    ("wino_x3.hip", "  bf16x8 ua[2][3], fb[2][3];\n",
+     "  bf16x8 ua[2][3], fb[2][3];\n  unsigned tlacc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};\n  const unsigned long long tl_entry = __builtin_readcyclecounter();\n"),
+    ("wino_x3.hip", "    constexpr int ob = 1 - hs;  // the buffer (and half of the frequencies) this phase produces\n",
+     "    constexpr int ob = 1 - hs;\n    const unsigned long long tl0 = __builtin_readcyclecounter();\n"),
+    ("wino_x3.hip", "    // second frequency: its B pieces 2 and 1 are in place; piece 0 and the first frequency's filter fragments behind MFMA 11\n",
+     "    const unsigned long long tl1 = __builtin_readcyclecounter();\n"),
+    ("wino_x3.hip", "    load_u(ktu, hs == 0 ? 3 : 1, ua[1]);\n    if constexpr (hs == 0) {\n",
+     "    const unsigned long long tl2 = __builtin_readcyclecounter();\n    load_u(ktu, hs == 0 ? 3 : 1, ua[1]);\n    if constexpr (hs == 0) {\n"),
+    ("wino_x3.hip", "    // the NEXT phase's first frequency: its buffer is complete behind the barrier\n    __syncthreads();\n    frag(ob, 0, 2); frag(ob, 0, 1); frag(ob, 0, 0);\n    XS_FENCE;\n",
+     "    const unsigned long long tl3 = __builtin_readcyclecounter();\n    __syncthreads();\n    frag(ob, 0, 2); frag(ob, 0, 1); frag(ob, 0, 0);\n    XS_FENCE;\n"
+     "    const unsigned long long tl4 = __builtin_readcyclecounter();\n"
+     "    tlacc[hs][0] += (unsigned)(tl1 - tl0); tlacc[hs][1] += (unsigned)(tl2 - tl1); tlacc[hs][2] += (unsigned)(tl3 - tl2); tlacc[hs][3] += (unsigned)(tl4 - tl3);\n"),
+    ("wino_x3.hip", "#undef XS_FENCE\n",
+     "#undef XS_FENCE\n  const unsigned long long tl_loop = __builtin_readcyclecounter();\n"),
+    ("wino_x3.hip", "  if (a.gn_quads == nullptr) {\n    epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix);\n",
+     "  if (a.gn_quads == nullptr) {\n    epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix);\n"
+     "    if ((tid & 255) == 0 && blockIdx.x < 512 && blockIdx.y == 0) {\n"
+     "      __builtin_amdgcn_s_waitcnt(0);\n"
+     "      unsigned* o = az_wx3_tl + (blockIdx.x * 2 + (tid >> 8)) * 12;\n"
+     "      for (int i = 0; i < 8; ++i) o[i] = tlacc[i >> 2][i & 3];\n"
+     "      o[8] = (unsigned)(tl_loop - tl_entry); o[9] = (unsigned)(__builtin_readcyclecounter() - tl_loop); o[10] = (unsigned)tl_entry; o[11] = __builtin_amdgcn_s_getreg(63492);\n"
+     "    }\n"),
+]
+
 
 def build(name: str) -> str:
     out_dir = os.path.join(B.HERE, "_ab")
