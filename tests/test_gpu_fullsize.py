@@ -18,6 +18,9 @@ torch.set_grad_enabled(False)
 STEPS = 3
 
 
+WINO = ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32")  # the Winograd entries (fp32 stream / frequency GEMMs on the bf16 pipe)
+
+
 @pytest.fixture(scope="module")
 def c2():
     import bench
@@ -39,12 +42,12 @@ def test_winograd_equals_direct_on_the_real_shapes(c2, monkeypatch):
     net = den.backbone.net
     fast = den(x1, t).mean
     plan = next(iter(net._plans.values()))
-    assert sum(n == "az_conv2d_winograd_f32" for _, _, n in plan.tape.ops) >= 40
+    assert sum(n in WINO for _, _, n in plan.tape.ops) >= 40
     monkeypatch.setattr(engine, "WINOGRAD", "0")
     net._plans.clear()
     direct = den(x1, t).mean
     plan = next(iter(net._plans.values()))
-    assert not any(n == "az_conv2d_winograd_f32" for _, _, n in plan.tape.ops)
+    assert not any(n in WINO for _, _, n in plan.tape.ops)
     net._plans.clear()
     scale = direct.abs().max().item()
     print("full-size mean: Winograd vs direct max|d|", max_err(fast, direct), "scale", scale)
@@ -218,7 +221,7 @@ def test_odd_image_size_through_both_conv_paths(monkeypatch):
     x = torch.randn(2, 3, 250, 190, device="cuda")
     mod = torch.randn(64, device="cuda")
     fast = net(x, mod)
-    assert any(n == "az_conv2d_winograd_f32" for _, _, n in next(iter(net._plans.values())).tape.ops)
+    assert any(n in WINO for _, _, n in next(iter(net._plans.values())).tape.ops)
     monkeypatch.setattr(engine, "WINOGRAD", "0")
     net._plans.clear()
     direct = net(x, mod)

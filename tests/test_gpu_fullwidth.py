@@ -49,7 +49,7 @@ def test_c2_channel_plan_against_the_oracle(c2_net, policy, monkeypatch):
     net._plans.clear()
     mean = den(x1.cuda(), torch.tensor(0.6, device="cuda")).mean
     ops = [n for _, _, n in next(iter(net._plans.values())).tape.ops]
-    nw, nd = ops.count("az_conv2d_winograd_f32"), ops.count("az_conv2d_f32") + ops.count("az_conv2d_x3_f32")  # (direct family: native or bf16x3)
+    nw, nd = ops.count("az_conv2d_winograd_f32") + ops.count("az_conv2d_winograd_x3_f32"), ops.count("az_conv2d_f32") + ops.count("az_conv2d_x3_f32")  # (direct family: native or bf16x3)
     if policy == "2":
         assert nw >= 50 and nd <= 8, (nw, nd)  # only the stride-2 convolutions and the stem / head stay direct
     elif policy == "0":

@@ -25,7 +25,7 @@ def _bar(y32, y16, half):
 def _uses_half_kernel(plan, half):
     want = "az_conv2d_f16_f32" if half == torch.float16 else "az_conv2d_bf16_f32"
     names = {n for _, _, n in plan.tape.ops}
-    return want in names and "az_conv2d_f32" not in names and "az_conv2d_winograd_f32" not in names
+    return want in names and "az_conv2d_f32" not in names and "az_conv2d_winograd_f32" not in names and "az_conv2d_winograd_x3_f32" not in names
 
 
 @pytest.mark.parametrize("half", HALVES)
