@@ -2480,7 +2480,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd4_kernel(Wino4P p) {
 // whole rounds.  Measured on 16384 tokens (tools/x3_probe.sh): 768 -> 3072 (768 big tiles = 3 rounds) 389 vs 455 us, 768 -> 768
 // (192 tiles, 0.75 of a round) 117 vs 125, 768 -> 2304 (576 tiles = 2.25 rounds) a tie -- hence 8 of its 9 cout tiles big: 311 vs 338;
 // 3072 -> 768 387 vs 444 (and no split-K combine).
-// AZ_X3_BIG = 0 / 1: never / every eligible launch whole (A/B measurements; read per call).
+// AZ_X3_BIG = 0 / 1: never / every eligible launch whole (A/B measurements; read per call, honoured only with AZ_DEBUG_AB set).
 static bool x3_big_taps(const AzConvArgs* a) { return !(a->ksize == 1 && a->stride == 1 && a->pad == 0); }
 static bool x3_big_eligible(const AzConvArgs* a, int64_t npix, int kstep = GBK) {  // kstep: 16 (bf16x3) / 64 (half-precision operands)
   const int64_t spix = (int64_t)a->batch * a->h0 * a->w0;
@@ -2498,7 +2498,7 @@ static int x3_big_plan(const AzConvArgs* a, int64_t npix, int* splitk, int kstep
   *splitk = 1;
   if (ct) *ct = GB;
   if (!x3_big_eligible(a, npix, kstep)) return 0;
-  const char* force = getenv("AZ_X3_BIG");
+  const char* force = getenv("AZ_DEBUG_AB") ? getenv("AZ_X3_BIG") : nullptr;  // (A/B override: only under the explicit debug switch AZ_DEBUG_AB)
   const int all = (a->cout_s + GB - 1) / GB;
 #ifdef AZ_X3_NO192  // (A/B: the plan without the 192-cout tile)
   const bool ok192 = false;
@@ -2549,8 +2549,8 @@ int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_
 int az_conv2d_x3_suggest_splitk(const AzConvArgs* a) {
   if (!a) return 1;
   const int64_t npix = (int64_t)a->batch * a->hout * a->wout;
-  int sk = 1;
-  if (x3_big_plan(a, npix, &sk) > 0) return sk;
+  int sk = 1, ct = GB;
+  if (x3_big_plan(a, npix, &sk, GBK, &ct) > 0) return sk;  // (the same call as the launch: fill act / the q-k fields before asking)
   return az_conv2d_suggest_splitk(npix, a->cout_s, a->c0s + a->c1s, a->ksize);
 }
 int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_t ksize) {
@@ -2646,12 +2646,12 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     AZ_REQUIRE(a->depth > 0 && a->batch % a->depth == 0 && a->depth_shift > -a->depth && a->depth_shift < a->depth &&
                    a->cout_s != 4 && (!a->gate || a->gate_bstride == 0) && (a->depth_wrap == 0 || a->depth_wrap == 1),
                AZ_E_UNSUPPORTED);
-  if (a && a->depth > 0) {  // 32-bit offsets from the descriptor's first plane: a tile's images + the planes a tap may reach back
-    const int64_t span = (int64_t)BN / ((int64_t)a->hout * a->wout) + 2 + a->depth;
-    AZ_REQUIRE(span * a->h0 * a->w0 * a->c0s * 4 < (1ll << 31) && span * a->h1 * a->w1 * a->c1s * 4 < (1ll << 31), AZ_E_SHAPE);
-  }
   AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout > 0 && a->wout > 0, AZ_E_SHAPE);
+  if (a->depth > 0) {  // 32-bit offsets from the descriptor's first plane: a tile's images + the planes a tap may reach back
+    const int64_t span = (int64_t)BN / ((int64_t)a->hout * a->wout) + 2 + a->depth;  // (behind the shape checks: hout * wout > 0)
+    AZ_REQUIRE(span * a->h0 * a->w0 * a->c0s * 4 < (1ll << 31) && span * a->h1 * a->w1 * a->c1s * 4 < (1ll << 31), AZ_E_SHAPE);
+  }
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
   AZ_REQUIRE(a->act >= 0 && a->act <= 5, AZ_E_UNSUPPORTED);

@@ -486,6 +486,9 @@ class Builder:
             # the fused q | k | v projection of an attention layer: q / k RMS norm, gains and RoPE in THIS epilogue, once per
             # layer, instead of in every workgroup of the attention kernel (three per head at 288 tokens: 123 -> 163 us)
             a.act = 5
+            if name != "az_conv2d_f32" and lib.az_conv2d_x3_suggest_splitk(C.byref(a)) != 1:
+                a.act = 0  # (the tile plan of THIS epilogue wants a split K walk, which the epilogue cannot take: plain projection)
+        if a.act == 5:
             a.qk_head_dim, a.qk_heads, a.qk_tokens = qk_prep["head_dim"], qk_prep["heads"], hout * wout
             a.qk_rmsnorm, a.qk_eps = int(qk_prep["rmsnorm"]), qk_prep["eps"]
             keep = []

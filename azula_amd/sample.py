@@ -101,6 +101,14 @@ class Sampler(abc.ABC):
     def timesteps(self) -> Tensor:
         return torch.linspace(self.start, self.stop, self.steps + 1, dtype=self.dtype, device=self.device)
 
+    def invalidate(self) -> None:
+        r"""Forget the captured plan and every cached hyper-parameter value: the next call re-reads weights, schedule,
+        guidance / eta / temperature tensors and rebuilds the coefficient table, as after construction.  Needed only after
+        writes the plan key cannot see -- ``tensor.data.copy_()``, custom kernels or other raw writes through ``data_ptr()``,
+        which do not bump a tensor's version counter (ordinary in-place ops, ``load_state_dict``, ``.to()`` are tracked)."""
+        self._fused_cache = {}
+        _SMALL_VALUES.clear()
+
     @torch.no_grad()
     def init(self, shape: Sequence[int], mean: float | Tensor = 0.0, var: float | Tensor = 1.0, **kwargs) -> Tensor:
         r"""x_T ~ N(alpha_T E[X], alpha_T^2 V[X] + sigma_T^2 I) (reference ``azula/sample.py:96-128``).

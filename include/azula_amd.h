@@ -337,11 +337,13 @@ int az_conv2d_stem_f32(const AzConvArgs* args, az_stream_t stream);
  * output; src / res / dst stay fp32 tensors -- activations are rounded to the operand type while they are staged.   */
 int az_conv2d_bf16_f32(const AzConvArgs* args, az_stream_t stream);
 int az_conv2d_f16_f32(const AzConvArgs* args, az_stream_t stream);
-/* fp32 operands on the bf16 matrix pipe ("bf16x3", opt-in: AZ_FP32_MFMA=bf16x3): each fp32 value is split exactly into
+/* fp32 operands on the bf16 matrix pipe ("bf16x3", the default of the direct contractions since round 4; AZ_FP32_MFMA=native opts out): each fp32 value is split exactly into
  * three bf16 pieces and a product is the six largest of the nine partial products, accumulated in fp32
  * (6 x v_mfma_f32_32x32x16_bf16 per 16 channels = 0.375 x the time of 8 x v_mfma_f32_32x32x2_f32).  Error vs fp64 at the
  * level of the fp32 kernel and below the Winograd form's.  `weight` = az_pack_conv_weight_x3_f32 output; everything else
- * (fp32 src / res / dst, the fused epilogue) as az_conv2d_f32.  Same reference op: azula/nn/layers.py:48-55 ConvNd.  */
+ * (fp32 src / res / dst, the fused epilogue) as az_conv2d_f32.  Same reference op: azula/nn/layers.py:48-55 ConvNd.
+ * Domain: finite operands (an Inf operand splits into NaN pieces: Inf in -> NaN out, where the fp32 MFMA gives Inf); operands
+ * below ~2^-110 keep ~16 significant bits (their low pieces are subnormal bf16 values).                                  */
 int az_conv2d_x3_f32(const AzConvArgs* args, az_stream_t stream);
 /* The split-K az_conv2d_x3_f32 wants for a filled descriptor (splitk / workspace not read): its 256 x 256-tile kernel runs one
  * workgroup per CU and splits a deep K (the 3072 -> 768 token projections) until its rounds are whole; az_conv2d_suggest_splitk's

@@ -135,7 +135,9 @@ def test_bf16x3_tile_plan_on_the_host(built_lib, monkeypatch):
     assert sk(gemm(9216, 2048, 768)) == 2    # 108 big tiles: the deep K loop in two halves -> 216 workgroups
     assert sk(gemm(9216, 768, 768)) == lib.az_conv2d_suggest_splitk(9216, 768, 768, 1)      # shallow K, under a round: 128 x 128 tiles
     assert sk(gemm(256, 1024, 1024)) == lib.az_conv2d_suggest_splitk(256, 1024, 1024, 1)    # a small map: 128 x 128 tiles, their split-K
+    assert sk(gemm(58 * 256, 1536, 768)) == 1  # 4 x 192-cout tiles x 58 = 232 workgroups (what the launch picks), not 174 256-cout tiles split in two
     conv3 = gemm(16384, 768, 3072, ksize=3, pad=1)
     assert sk(conv3) == lib.az_conv2d_suggest_splitk(16384, 3072, 768, 3)                    # taps: not a big-tile launch
     monkeypatch.setenv("AZ_X3_BIG", "0")
+    monkeypatch.setenv("AZ_DEBUG_AB", "1")  # (A/B overrides are honoured only under the debug switch)
     assert sk(gemm(16384, 3072, 768)) == 2

@@ -823,6 +823,44 @@ def test_conv2d_x3_accuracy(az, monkeypatch):
     assert errs["x3"][1] <= errs[True][1], errs
 
 
+@pytest.mark.parametrize("mode", ["x3", "wx3"])
+def test_x3_split_domain(az, mode):
+    """The stated domain of the exact 3 x bf16 split (csrc/common.h, include/azula_amd.h): tiny operands (|x| ~ 1e-30, products
+    ~ 1e-60 * K: far below fp32's range -> exact zeros or denormal noise, never garbage), operands around 2^-100 (low pieces
+    subnormal in bf16: >= 16 significant bits) and a single Inf activation (non-finite out wherever the fp32 path gives a
+    non-finite value, finite everywhere else)."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cout, H, W = 1, 64, 64, 16, 16
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    for scale, rel in ((1.0, 3e-6), (2.0 ** -50, 3e-6), (2.0 ** -100, 2e-4)):
+        x = torch.randn(B, Cin, H, W, generator=g) * scale
+        ref = F.conv2d(x.double(), w.double(), None, padding=1)
+        bld = Builder(torch.device("cuda"))
+        xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
+        y = bld.conv(xa, bld.pack_conv(dev(w), None), Cout, winograd=mode)
+        bld.finish()
+        bld.tape.run()
+        out = from_nhwc(y.buf.reshape(B, H, W, Cout), Cout).double().cpu()
+        err = (out - ref).abs().max().item()
+        assert err < rel * ref.abs().max().item(), (scale, err, ref.abs().max().item())
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x[0, 3, 8, 8] = float("inf")
+    ref = F.conv2d(x, w, None, padding=1)
+    bld = Builder(torch.device("cuda"))
+    xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
+    y = bld.conv(xa, bld.pack_conv(dev(w), None), Cout, winograd=mode)
+    bld.finish()
+    bld.tape.run()
+    out = from_nhwc(y.buf.reshape(B, H, W, Cout), Cout).cpu()
+    bad_ref = ~torch.isfinite(ref)
+    assert bad_ref.any() and (~torch.isfinite(out))[bad_ref].all()  # Inf / NaN where the reference is non-finite ...
+    far = torch.ones_like(bad_ref)
+    far[:, :, 5:12, 5:12] = False  # (the Winograd tiles touching the Inf pixel may turn NaN as a whole: transforms subtract Inf)
+    assert torch.isfinite(out[far]).all() and max_err(out[far], ref[far]) < conv_tol(Cin, 3, True)
+
+
 @pytest.mark.parametrize("wino", [False, True, "x3", "wx3"])
 def test_conv2d_is_deterministic_across_launches(az, wino):
     """Race screen for the LDS-exchange epilogues and the split-K combine: 12 launches of the same convolution (gate,
@@ -1122,6 +1160,7 @@ def test_x3_gemm_big_tile(az, monkeypatch, shape, act, res):
             monkeypatch.delenv("AZ_X3_BIG")
         else:
             monkeypatch.setenv("AZ_X3_BIG", big)
+            monkeypatch.setenv("AZ_DEBUG_AB", "1")  # (A/B overrides are honoured only under the debug switch)
         bld = Builder(torch.device("cuda"))
         xin = Act(to_nhwc(dev(x)).reshape(-1), B, T, 1, Cin, Cin, True)  # (kept alive: the tape holds raw addresses)
         rin = Act(to_nhwc(dev(r)).reshape(-1), B, T, 1, Cout, (Cout + 3) // 4 * 4, True) if res else None
@@ -1151,6 +1190,7 @@ def test_x3_gemm_big_tile_two_sources(az, monkeypatch, shape):
     outs = {}
     for big in ("0", "1"):
         monkeypatch.setenv("AZ_X3_BIG", big)
+        monkeypatch.setenv("AZ_DEBUG_AB", "1")  # (A/B overrides are honoured only under the debug switch)
         bld = Builder(torch.device("cuda"))
         a0 = Act(to_nhwc(dev(x0)).reshape(-1), B, H, W, C0, C0, True)
         a1 = Act(to_nhwc(dev(x1)).reshape(-1), B, H, W, C1, C1, True)
@@ -1183,6 +1223,7 @@ def test_half_gemm_big_tile(az, monkeypatch, shape, half):
             monkeypatch.delenv("AZ_X3_BIG")
         else:
             monkeypatch.setenv("AZ_X3_BIG", big)
+            monkeypatch.setenv("AZ_DEBUG_AB", "1")  # (A/B overrides are honoured only under the debug switch)
         bld = Builder(torch.device("cuda"), half=half)
         xin = Act(to_nhwc(dev(x)).reshape(-1), B, T, 1, Cin, Cin, True)
         y = bld.conv(xin, bld.pack_conv(dev(w), dev(b)), Cout, act=1)
@@ -1212,6 +1253,7 @@ def test_x3_big_tile_with_taps(az, monkeypatch, B, Cin, Cout, H, W, ks, stride):
     outs = {}
     for big in ("0", "1"):
         monkeypatch.setenv("AZ_X3_BIG", big)
+        monkeypatch.setenv("AZ_DEBUG_AB", "1")  # (A/B overrides are honoured only under the debug switch)
         bld = Builder(torch.device("cuda"))
         xin = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
         y = bld.conv(xin, bld.pack_conv(dev(w), dev(b)), Cout, stride=stride, act=1, winograd="x3")
@@ -1239,6 +1281,7 @@ def test_half_big_tile_with_taps(az, monkeypatch, B, Cin, Cout, H, W, ks, stride
     outs = {}
     for big in ("0", "1"):
         monkeypatch.setenv("AZ_X3_BIG", big)
+        monkeypatch.setenv("AZ_DEBUG_AB", "1")  # (A/B overrides are honoured only under the debug switch)
         bld = Builder(torch.device("cuda"), half=half)
         xin = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
         y = bld.conv(xin, bld.pack_conv(dev(w), dev(b)), Cout, stride=stride)

@@ -128,6 +128,27 @@ def test_fused_loop_sees_sampler_hyperparameters(golden):
     assert torch.equal(smp(x1), DDIMSampler(den_f, steps=5, start=0.8, eta=0.0, silent=True)(x1))
 
 
+def test_invalidate_after_a_raw_write(golden):
+    """Writes that do not bump a tensor's version counter (`.data.copy_`) are invisible to the plan key -- documented in
+    INTEGRATION.md; `Sampler.invalidate()` is the explicit way to make the next call re-read everything."""
+    from azula_amd.sample import DDIMSampler
+
+    g = golden("g6_unet_loop")
+    x1 = g["x1"].cuda()
+    den, _ = _unet_denoiser(g)
+    eta = torch.tensor(0.5, device="cuda")
+    smp = DDIMSampler(den, steps=8, eta=eta, silent=True)
+    torch.manual_seed(5)
+    a = smp(x1)
+    eta.data.copy_(torch.tensor(1.0))  # (no version bump: the cached value 0.5 stays in use ...)
+    smp.invalidate()                   # (... until the caller says so)
+    torch.manual_seed(5)
+    b = smp(x1)
+    torch.manual_seed(5)
+    fresh = DDIMSampler(den, steps=8, eta=1.0, silent=True)(x1)
+    assert torch.equal(b, fresh) and not torch.equal(a, b)
+
+
 def _small_cond_adm():
     from azula_amd.guidance import CFGDenoiser
     from azula_amd.plugins import adm

@@ -62,6 +62,26 @@ VARIANTS["wx3_tl"] = [
      "    }\n"),
 ]
 
+# energy probes on RANDOM data (the kernel sits at the 1400 W cap: time = energy / cap, so a variant's time change is the energy share
+# of what it removes -- as long as the data stay random; the no-load variants above freeze operands and overstate)
+VARIANTS["wx3_nosplit"] = [
+    ("wino_x3.hip", "    qq[c][0] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);\n    vv[c] = f32x2{x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u), x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u)};",
+     "    qq[c][0] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);"),
+    ("wino_x3.hip", "    qq[c][1] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);\n    const float s0 = r0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);\n    const float s1 = r1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);\n    qq[c][2] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);",
+     "    qq[c][1] = __builtin_amdgcn_perm(u0, u1, 0x05040100u);\n    qq[c][2] = qq[c][1] ^ u0;"),
+]
+VARIANTS["wx3_halffrag"] = [
+    ("wino_x3.hip", "    fb[1][pl] = *reinterpret_cast<const bf16x8*>(vb + 32 * X_ROW);", "    fb[1][pl] = fb[0][pl];"),
+]
+VARIANTS["wx3_halfstore"] = [
+    ("wino_x3.hip", "      for (int j = 0; j < 2; ++j) *reinterpret_cast<unsigned*>(dst + pl * X_PLANE + (2 * xi + j) * X_FREQ) = qq[2 * xi + j][pl];",
+     "      for (int j = 0; j < 1; ++j) *reinterpret_cast<unsigned*>(dst + pl * X_PLANE + (2 * xi + j) * X_FREQ) = qq[2 * xi + j][pl] ^ qq[2 * xi + 1][pl];"),
+]
+VARIANTS["wx3_halfmfma"] = [
+    ("wino_x3.hip", "    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[j][PA[t]], fb[th][PB[t]], c, 0, 0, 0);",
+     "    if (t < 3) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[j][PA[t]], fb[th][PB[t]], c, 0, 0, 0);"),
+]
+
 
 def build(name: str) -> str:
     out_dir = os.path.join(B.HERE, "_ab")
