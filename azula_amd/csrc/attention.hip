@@ -740,7 +740,6 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
           *reinterpret_cast<uint2*>(Ks + pl * KPL + row * KLS + lc * 4) = make_uint2(k3[pl][0], k3[pl][1]);
-#ifndef AZ_AX_NOVT  // (timing ablations, WRONG results: AZ_AX_*)
           if constexpr (VT4) {
             // 4 x 4 transpose among the four lanes that hold rows 4m .. 4m+3 of this chunk (lane ^ CH, lane ^ 2 CH): the lane of
             // row 4m + j ends with channel lc*4 + j of the four keys, whose positions are contiguous -- one 8-byte store
@@ -765,7 +764,6 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
             vt[2 * VLS] = (unsigned short)(v3[pl][1] & 0xFFFFu);
             vt[3 * VLS] = (unsigned short)(v3[pl][1] >> 16);
           }
-#endif
         }
       }
     }
@@ -786,11 +784,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const abf16x8*>(kr + pl * KPL + 16 * ks);
 #pragma unroll
-#ifdef AZ_AX_ONEPROD
-        for (int t = 5; t < 6; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qf[PB[t]][ks], sacc, 0, 0, 0);
-#else
         for (int t = 0; t < 6; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qf[PB[t]][ks], sacc, 0, 0, 0);
-#endif
       }
       if (k0 + sub * 32 + 32 > T) {  // ragged last tile (wave-uniform): keys past T
 #pragma unroll
@@ -817,11 +811,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
       float ls = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-#ifdef AZ_AX_NOEXP
-        const float pe = sacc[r] - m_sub;
-#else
         const float pe = __builtin_amdgcn_exp2f(sacc[r] - m_sub);
-#endif
         sacc[r] = pe;
         ls += pe;
       }
@@ -837,11 +827,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
       for (int s2 = 0; s2 < 2; ++s2) {
         unsigned p3[3][4];
 #pragma unroll
-#ifdef AZ_AX_NOSPLITP
-        for (int j = 0; j < 4; ++j) p3[0][j] = p3[1][j] = p3[2][j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sacc[8 * s2 + 2 * j + 1]), __builtin_bit_cast(unsigned, sacc[8 * s2 + 2 * j]), 0x07060302u);
-#else
         for (int j = 0; j < 4; ++j) az_split3(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1], p3[0][j], p3[1][j], p3[2][j]);
-#endif
         abf16x8 pb[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) pb[pl] = __builtin_bit_cast(abf16x8, make_uint4(p3[pl][0], p3[pl][1], p3[pl][2], p3[pl][3]));
@@ -852,11 +838,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
           for (int pl = 0; pl < 3; ++pl)
             va[pl] = *reinterpret_cast<const abf16x8*>(Vt + pl * VPL + (ql + 32 * t) * VLS + sub * 32 + 16 * s2 + 8 * h2);
 #pragma unroll
-#ifdef AZ_AX_ONEPROD
-          for (int u = 5; u < 6; ++u) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[u]], pb[PB[u]], oacc[t], 0, 0, 0);
-#else
           for (int u = 0; u < 6; ++u) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[u]], pb[PB[u]], oacc[t], 0, 0, 0);
-#endif
         }
       }
     }

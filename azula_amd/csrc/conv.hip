@@ -38,11 +38,7 @@ constexpr int BK = 32;    // k tile (input channels of one tap)
 constexpr int LDSS = 36;  // padded LDS row stride in floats (144 B, 16-B aligned)
 constexpr int TILE_F = (BM + BN) * LDSS;
 
-#ifdef AZ_IGEMM_KLOOP_INC  // A/B builds (tools/kloop_variant.py): a variant stream generated outside the source tree
-#include AZ_IGEMM_KLOOP_INC
-#else
-#include "igemm_kloop.inc"
-#endif
+#include "igemm_kloop.inc"  // (A/B variants of the stream: tools/kloop_variant.py builds from a patched COPY of this directory)
 struct ConvP {
   AzConvArgs a;
   int npix;     // batch * hout * wout
@@ -426,9 +422,7 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
     const bool more = kt + 1 < kt_end;
     if (more) {
       advance();
-#ifndef AZ_ABL_IGEMM_NOLOAD  // (timing ablations of this loop, tools/ab_build.py -DAZ_ABL_IGEMM_*: wrong results)
       load_tile();  // global loads in flight under the MFMAs below
-#endif
     }
 
     const float* As = smem + buf * TF + (wc * 64) * LS + frag_off;
@@ -451,10 +445,8 @@ __global__ __launch_bounds__(256, KT == 32 ? 2 : 3) void conv_igemm_kernel(ConvP
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
       }
     }
-#ifndef AZ_ABL_IGEMM_NOSTORE
     if (more) store_tile(buf ^ 1);
     __syncthreads();
-#endif
   }
   }
 
@@ -834,11 +826,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
       const float x[8] = {rb[i][0].x, rb[i][0].y, rb[i][0].z, rb[i][0].w, rb[i][1].x, rb[i][1].y, rb[i][1].z, rb[i][1].w};
       unsigned q[3][4];
 #pragma unroll
-#ifdef AZ_X3_NOSPLIT  // timing ablation (WRONG results): what would activations that arrive pre-split cost?
-      for (int j = 0; j < 4; ++j) q[0][j] = q[1][j] = q[2][j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x[2 * j + 1]), __builtin_bit_cast(unsigned, x[2 * j]), 0x07060302u);
-#else
       for (int j = 0; j < 4; ++j) split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);
-#endif
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
         *reinterpret_cast<uint4*>(xsm + (3 + pl) * XPLANE + (r0 + 64 * i) * XLDS + wsw) =
@@ -1113,7 +1101,6 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
 #pragma unroll
         for (int pj = 0; pj < 2; ++pj)
           acc[ci][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][ci], fb[PB[t]][pj], acc[ci][pj], 0, 0, 0);
-#ifndef AZ_X3_BIG_NOSCHED
     // Issue order: the 18 fragment reads, then the staging of the next step (44 split instructions, 6 LDS stores, 5 loads) spread
     // under the 48 MFMAs -- the matrix pipe takes 32 cycles per instruction, ~5 other issues fit in each gap -- instead of in
     // front of them (the compiler's own order: the pipe idles while both waves of a SIMD stage).
@@ -1126,8 +1113,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
       if (k >= 8 && k < NM - 8 && (k & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS store
       if (k >= NM - 8 && k < NM - 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // a buffer load
     }
-    // (measured alternatives: the staging ten MFMAs later 388 vs 371 us, one vector instruction per gap all along 380, on 16384 x 768 -> 3072)
-#endif
+    // (measured alternatives: the staging ten MFMAs later 388 vs 371 us, one vector instruction per gap all along 380, on 16384 x 768 -> 3072;
+    //  the compiler's own order, tools/ablate.py x3big_nosched: 411)
     __syncthreads();  // every wave has read stage `buf`; the other stage is complete
   }
 
@@ -1656,26 +1643,7 @@ constexpr int W_LDS_BYTES = (2 * WT * W_OT + 3 * WT + 384) * 4;  // 135,424 B >=
 // ds_write_b128 of the loaders are bank-conflict-free without padding.
 __device__ __forceinline__ int wswz(int row, int half) { return row * WK + 4 * (half ^ ((row >> 3) & 1)); }
 
-#ifdef AZ_WINO_KLOOP_INC
-#include AZ_WINO_KLOOP_INC
-#else
 #include "wino_kloop.inc"
-#endif
-#ifdef AZ_WINO_TL
-// Experiment builds only (tools/ab_build.py tl -DAZ_WINO_TL; tools/wino_timeline.py): s_memtime stamps of waves 0 and 4 of
-// every workgroup + the hardware id of its CU, to see what a workgroup spends outside its K loop and between workgroups.
-__device__ unsigned long long az_wino_tl[8192 * 2 * 8];
-extern "C" int az_debug_wino_timeline(unsigned long long* host, int n_words) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(az_wino_tl), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
-}
-#define TL_STAMP(k)                                                                                           \
-  do {                                                                                                        \
-    if ((threadIdx.x & 255) == 0 && blockIdx.x < 8192 && blockIdx.y == 0)                                      \
-      az_wino_tl[(blockIdx.x * 2 + (threadIdx.x >> 8)) * 8 + (k)] = __builtin_readcyclecounter();              \
-  } while (0)
-#else
-#define TL_STAMP(k)
-#endif
 constexpr int W_VOFF_BYTES = 256 * 64;  // ASM form: the second source's 16 patch offsets of the 256 gather threads
 
 // ASM = true: the K loop is the hand-scheduled instruction stream of wino_kloop.inc (gen_wino_kloop.py), software
@@ -1684,12 +1652,6 @@ constexpr int W_VOFF_BYTES = 256 * 64;  // ASM form: the second source's 16 patc
 template <bool ASM>
 __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];  // 2 * W_STAGE floats
-  TL_STAMP(0);
-#ifdef AZ_WINO_TL
-  if ((threadIdx.x & 255) == 0 && blockIdx.x < 8192 && blockIdx.y == 0)
-    az_wino_tl[(blockIdx.x * 2 + (threadIdx.x >> 8)) * 8 + 7] =
-        ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
-#endif
   const AzConvArgs& a = p.a;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1876,7 +1838,6 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
   // fragment addresses: row (within a frequency) = wave's 32-row block + l31; half = h (swizzled)
   const int fragA = (fh * 8) * WC * WK + wswz(wco * 32 + l31, h);  // + f * WC * WK
   const int fragB = (fh * 8) * WT * WK + wswz(wti * 32 + l31, h);  // + f * WT * WK
-  TL_STAMP(1);
   if constexpr (ASM) {
     if (kt_begin < kt_end) {
       typedef __attribute__((address_space(3))) float lds_float;
@@ -1936,23 +1897,13 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
         const unsigned ww0 = (unsigned)bw, ww1 = (unsigned)(bw >> 32) & 0xffffu;
         const unsigned ww2 = clamp_bytes((int64_t)p.nk * p.cblocks * WU_STAGE), ww3 = 0x00020000u;
         const int e0 = tid - 256;
-#ifdef WINO_KLOOP_UDMA
-        // LDS-DMA: lane L of a wave fills slot (wave's first slot + L); slot q holds float4 (q & ~1) | ((q & 1) ^ ((q >> 4) & 1))
-        const unsigned uvoff = (unsigned)((e0 & ~1) | ((e0 & 1) ^ ((e0 >> 4) & 1))) * 16u;
-        const unsigned ust = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wave - 4) * 1024u);
-#else
         const unsigned uvoff = (unsigned)(tid - 256) * 16u;
         const unsigned ust = lds0 + (unsigned)wswz(e0 >> 1, e0 & 1) * 4u;
-#endif
         const unsigned usoff0 = (unsigned)(((int64_t)kt_begin * p.cblocks + cb) * (WU_STAGE * 4));
         const unsigned ustep = (unsigned)(p.cblocks * (WU_STAGE * 4));
         asm volatile(WINO_KLOOP_U_ASM
                      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
-#ifdef WINO_KLOOP_UDMA
-                     : "v"(fragA_b), "v"(fragB_b), "s"(ust), "v"(uvoff), "s"(ww0), "s"(ww1), "s"(ww2), "s"(ww3), "s"(kt_begin), "s"(kt_end),
-#else
                      : "v"(fragA_b), "v"(fragB_b), "v"(ust), "v"(uvoff), "s"(ww0), "s"(ww1), "s"(ww2), "s"(ww3), "s"(kt_begin), "s"(kt_end),
-#endif
                        "s"(usoff0), "s"(ustep)
                      : WINO_KLOOP_CLOBBERS);
       }
@@ -1997,8 +1948,6 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
     __syncthreads();
   }
   }
-
-  TL_STAMP(2);
   // ---- output transform.  Y = A^T M A is linear in M, so each wave transforms the 8 frequencies
   // (two xi rows) it owns into a partial 2x2 output; the xi in {2,3} waves hand theirs to their
   // xi in {0,1} partners through LDS (once per workgroup), which add and run the fused epilogue.
@@ -2072,7 +2021,6 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
     tinfo[2 * WT + wti * 32 + l31] = b;
   }
   __syncthreads();
-  TL_STAMP(3);
   const int cq = tid & 15;  // the same channel quad in every iteration
   const int co = cb * WC + cq * 4;
   if (co >= a.cout_s) return;
@@ -2091,13 +2039,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_kernel(WinoP p) {
     ov[it] = make_float4(v0.x + v1.x, v0.y + v1.y, v0.z + v1.z, v0.w + v1.w);
   }
   if (a.gn_quads == nullptr) {
-    TL_STAMP(4);
     epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix);
-    TL_STAMP(5);
-#ifdef AZ_WINO_TL
-    __builtin_amdgcn_s_waitcnt(0);
-    TL_STAMP(6);
-#endif
     return;
   }
   // ---- GroupNorm statistics of the OUTPUT, for the normalisation that consumes it (the separate statistics pass read
@@ -2500,11 +2442,7 @@ static int x3_big_plan(const AzConvArgs* a, int64_t npix, int* splitk, int kstep
   if (!x3_big_eligible(a, npix, kstep)) return 0;
   const char* force = getenv("AZ_DEBUG_AB") ? getenv("AZ_X3_BIG") : nullptr;  // (A/B override: only under the explicit debug switch AZ_DEBUG_AB)
   const int all = (a->cout_s + GB - 1) / GB;
-#ifdef AZ_X3_NO192  // (A/B: the plan without the 192-cout tile)
-  const bool ok192 = false;
-#else
   const bool ok192 = ct != nullptr && kstep == GBK && a->act <= 3 && !x3_big_taps(a);
-#endif
   const int all192 = (a->cout_s + 191) / 192;
   if (force && force[0]) {
     if (force[0] == '1' && force[1] == ',') *splitk = atoi(force + 2);  // "1,S": every eligible launch on big tiles with split-K S (A/B)

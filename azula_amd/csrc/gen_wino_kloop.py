@@ -264,7 +264,7 @@ def v_extras(S: bool, L: bool, tag: str):
 U_OPS = dict(fragA=8, fragB=9, st=10, voff=11, rw=12, kt_begin=16, kt_end=17, soff0=18, soff_step=19)
 
 
-UDMA = _AB.get("KL_UDMA", "0") == "1"  # filter chunk by LDS-DMA (buffer_load ... lds): no staging registers, no ds_write
+UDMA = False  # (round-3 experiment: filter chunk by LDS-DMA; its operand set left conv.hip in round 5 -- measured a tie, DESIGN_HISTORY)
 S_UST = S_KT  # (the filter role has no stage counter: its SGPR holds the wave's LDS slot in the buffer to fill next)
 
 

@@ -297,10 +297,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(float* __restrict__ y, 
   const float4 t = *reinterpret_cast<const float4*>(T + (int64_t)b * cs + c4 * 4);
   const int64_t pix0 = (int64_t)b * HW;
   float4* yb = reinterpret_cast<float4*>(y) + pix0 * q + c4;
-#ifndef AZ_AFFINE_UN
-#define AZ_AFFINE_UN 4
-#endif
-  constexpr int UN = AZ_AFFINE_UN;  // loads in flight per thread (2: 0.65 of the HBM roofline at batch 32)
+  constexpr int UN = 4;  // loads in flight per thread (2: 0.65 of the HBM roofline at batch 32)
   auto apply = [&](float4 v) {
     float4 o;
     o.x = fmaf(v.x, sc.x, t.x);

@@ -262,10 +262,7 @@ __global__ __launch_bounds__(256) void transition_image_kernel(AzTransitionArgs 
 // lines) -- the scaled outputs are transposed through 16 KB of LDS ([channel][pixel], conflict-free ds_write_b128 /
 // ds_read_b32) so that every wave store writes 1 KB of consecutive pixels.  Measured at 96 Mi elements (DDIM eta=0,
 // 16 B/element algorithmic): 3.97 TB/s with per-lane NHWC stores -> see DESIGN.md section 4 for the current number.
-#ifndef AZ_TI_UN
-#define AZ_TI_UN 4
-#endif
-constexpr int TI_UN = AZ_TI_UN;  // pixel quads per thread and pass in the image4 kernel (all their loads before the first store)
+constexpr int TI_UN = 4;  // pixel quads per thread and pass in the image4 kernel (all their loads before the first store)
 
 template <bool CFG, bool EPS, bool MEAN>
 __global__ __launch_bounds__(256) void transition_image4_kernel(AzTransitionArgs a, int64_t quads_per_sample,

@@ -82,8 +82,34 @@ VARIANTS["wx3_halfmfma"] = [
      "    if (t < 3) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[j][PA[t]], fb[th][PB[t]], c, 0, 0, 0);"),
 ]
 
+# ---- the ablations / A-B switches that lived in the product sources as -D macros until round 4 (conv.hip, attention.hip)
+VARIANTS["igemm_noload"] = [("conv.hip", "      load_tile();  // global loads in flight under the MFMAs below\n", "")]
+VARIANTS["igemm_nostore"] = [("conv.hip", "    if (more) store_tile(buf ^ 1);\n    __syncthreads();\n  }\n  }\n", "  }\n  }\n")]
+VARIANTS["x3_nosplit"] = [  # what would activations that arrive pre-split cost the 128 x 128 bf16x3 kernel?
+    ("conv.hip", "      for (int j = 0; j < 4; ++j) split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);\n#pragma unroll\n      for (int pl = 0; pl < 3; ++pl)",
+     "      for (int j = 0; j < 4; ++j) q[0][j] = q[1][j] = q[2][j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x[2 * j + 1]), __builtin_bit_cast(unsigned, x[2 * j]), 0x07060302u);\n#pragma unroll\n      for (int pl = 0; pl < 3; ++pl)"),
+]
+VARIANTS["x3big_nosched"] = [("conv.hip", "    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NCT + 2), 0);  // DS reads\n", "    if (false)\n    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NCT + 2), 0);\n"),
+                             ("conv.hip", "    for (int k = 0; k < NM; ++k) {\n      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);", "    for (int k = 0; k < 0; ++k) {\n      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);")]
+VARIANTS["x3_no192"] = [("conv.hip", "  const bool ok192 = ct != nullptr && kstep == GBK && a->act <= 3 && !x3_big_taps(a);", "  const bool ok192 = false;")]
+VARIANTS["ax_oneprod"] = [
+    ("attention.hip", "        for (int t = 0; t < 6; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qf[PB[t]][ks], sacc, 0, 0, 0);",
+     "        for (int t = 5; t < 6; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qf[PB[t]][ks], sacc, 0, 0, 0);"),
+    ("attention.hip", "          for (int u = 0; u < 6; ++u) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[u]], pb[PB[u]], oacc[t], 0, 0, 0);",
+     "          for (int u = 5; u < 6; ++u) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[u]], pb[PB[u]], oacc[t], 0, 0, 0);"),
+]
+VARIANTS["ax_noexp"] = [("attention.hip", "        const float pe = __builtin_amdgcn_exp2f(sacc[r] - m_sub);", "        const float pe = sacc[r] - m_sub;")]
+VARIANTS["ax_nosplitp"] = [
+    ("attention.hip", "        for (int j = 0; j < 4; ++j) az_split3(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1], p3[0][j], p3[1][j], p3[2][j]);",
+     "        for (int j = 0; j < 4; ++j) p3[0][j] = p3[1][j] = p3[2][j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sacc[8 * s2 + 2 * j + 1]), __builtin_bit_cast(unsigned, sacc[8 * s2 + 2 * j]), 0x07060302u);"),
+]
+VARIANTS["ax_novt"] = [("attention.hip", "          if constexpr (VT4) {\n            // 4 x 4 transpose among the four lanes", "          if constexpr (false) {\n          } else if constexpr (VT4 && false) {\n            // 4 x 4 transpose among the four lanes"),
+                       ("attention.hip", "            unsigned short* vt = Vt + pl * VPL + (lc * 4) * VLS + pos;\n            vt[0] = (unsigned short)(v3[pl][0] & 0xFFFFu);", "            unsigned short* vt = Vt + pl * VPL + (lc * 4) * VLS + pos;\n            if (false) vt[0] = (unsigned short)(v3[pl][0] & 0xFFFFu);")]
 
-def build(name: str) -> str:
+
+def build(name: str, patches=None, regen_env=None) -> str:
+    r"""`patches`: a substitution list instead of VARIANTS[name]; `regen_env`: generator overrides (KL_* / KG_*) -- the copy's
+    wino_kloop.inc / igemm_kloop.inc are regenerated with them (tools/kloop_variant.py)."""
     out_dir = os.path.join(B.HERE, "_ab")
     src_dir = os.path.join(out_dir, "src_" + name, "azula_amd", "csrc")
     shutil.rmtree(os.path.join(out_dir, "src_" + name), ignore_errors=True)
@@ -94,7 +120,12 @@ def build(name: str) -> str:
         if f.endswith((".hip", ".h", ".inc")):
             shutil.copy(os.path.join(B.HERE, f), src_dir)
     touched = set()
-    for f, old, new in VARIANTS[name]:
+    if regen_env is not None:
+        env = dict(os.environ, AZ_KLOOP_AB="1", **regen_env)
+        for gen, inc in (("gen_wino_kloop.py", "wino_kloop.inc"), ("gen_igemm_kloop.py", "igemm_kloop.inc")):
+            subprocess.run([sys.executable, os.path.join(B.HERE, gen), "--out", os.path.join(src_dir, inc)], check=True, env=env, stdout=subprocess.DEVNULL)
+        touched.add("conv.hip")
+    for f, old, new in (VARIANTS[name] if patches is None else patches):
         path = os.path.join(src_dir, f)
         text = open(path).read()
         assert text.count(old) == 1, f"{name}: pattern occurs {text.count(old)} times in {f}: {old[:60]!r}"
