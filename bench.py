@@ -353,8 +353,8 @@ def pmc_traffic(config: str, live: bool = True, timeout: int = 420):
     with "source", or the committed profile of the same tool when the live run is unavailable / disabled."""
     import subprocess
 
-    committed = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_traffic_{config}.json") for r in ("r03", "r02")) if os.path.exists(p)),
-                     os.path.join(ROOT, "profiles", f"r03_traffic_{config}.json"))
+    committed = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_traffic_{config}.json") for r in ("r05", "r04", "r03", "r02")) if os.path.exists(p)),
+                     os.path.join(ROOT, "profiles", f"r05_traffic_{config}.json"))
     if live and os.environ.get("AZ_BENCH_PMC", "1") != "0":
         try:
             res = subprocess.run(
@@ -397,32 +397,65 @@ def physical_cores() -> int:
 
 def cpu_baseline(denoiser, cfg, budget_s=60.0):
     r"""The oracle (CPU restatement of azula's op sequence, bit-checked against the reference in the build container) timed
-    on this host: full DDIM steps of the same network at the GPU leg's batch, >= 2 timed steps after one warm-up, at two
-    thread counts -- the host's physical cores (SURVEY 8d asks for every core; SMT siblings only oversubscribe the FMA
-    units) and the fastest count of a probe on the dominant op.  `value` is the faster of the two; both are reported."""
+    on this host: full denoise steps of the same network -- at the GPU leg's batch, or at 4 images where a step of the full
+    batch would not fit the budget (ADM at batch 32: stated in `sample`) --, >= 2 timed steps after one warm-up, at two thread
+    counts: the host's physical cores (SURVEY 8d asks for every core; SMT siblings only oversubscribe the FMA units) and the
+    fastest count of a probe on the dominant op.  `value` is the faster of the two; both are reported."""
     from oracle import nets, sampling
 
-    sd = {k: v.detach().cpu() for k, v in denoiser.backbone.state_dict().items()}
-    ncfg = dict(cfg["net"])
-    B = cfg["batch"]
+    inner = denoiser.denoiser if hasattr(denoiser, "denoiser") else denoiser  # (CFGDenoiser wraps the conditional model)
+    sd = {k: v.detach().cpu().float() for k, v in inner.backbone.state_dict().items()}
+    kind = cfg["kind"]
+    B = cfg["batch"] if kind in ("unet", "vit") else min(cfg["batch"], 4)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     phys = min(physical_cores(), avail)
-    probe_x, probe_w = torch.randn(B, 256, 128, 128), torch.randn(256, 256, 3, 3)
+    if kind in ("vit", "jit"):  # dominant op: a token GEMM (tokens x 768 -> 3072)
+        probe_x, probe_w = torch.randn(B * 256, 768), torch.randn(3072, 768)
+        probe_op, probe_name = (lambda: torch.nn.functional.linear(probe_x, probe_w)), f"a {B * 256} x 768 -> 3072 token GEMM"
+    else:
+        probe_x, probe_w = torch.randn(B, 256, 128, 128), torch.randn(256, 256, 3, 3)
+        probe_op, probe_name = (lambda: torch.nn.functional.conv2d(probe_x, probe_w, padding=1)), f"a 256->256 3x3 conv at batch {B}"
     probe = {}
     for nt in sorted({min(avail, c) for c in (16, 32, 64, 128, phys)}):
         torch.set_num_threads(nt)
-        torch.nn.functional.conv2d(probe_x, probe_w, padding=1)
+        probe_op()
         t0 = time.perf_counter()
         for _ in range(2):
-            torch.nn.functional.conv2d(probe_x, probe_w, padding=1)
+            probe_op()
         probe[nt] = (time.perf_counter() - t0) / 2
     best = min(probe, key=probe.get)
-    mean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, ncfg, a, c), x, t)  # noqa: E731
+    evals = 1  # backbone evaluations per denoise step
+    schedule = sampling.vp_schedule
+    if kind == "unet":
+        ncfg = dict(cfg["net"])
+        mean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, ncfg, a, c), x, t)  # noqa: E731
+    elif kind == "vit":
+        ncfg = dict(cfg["net"])
+        mean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_vit(sd, ncfg, a, c), x, t)  # noqa: E731
+    elif kind == "adm":
+        from azula_amd.plugins import adm
+
+        acfg = dict(adm.load_cards(adm)[cfg["card"]].config)
+        sig = sampling.adm_sigmas(acfg.get("discrete_schedule", "linear"), acfg.get("discrete_steps", 1000))
+        bb = lambda a, i, y=None: nets.adm_unet_forward(sd, acfg, a, i, y)  # noqa: E731
+        schedule = lambda t: sampling.vp_schedule(t, 1e-2, 1e-2)  # noqa: E731
+        post = lambda x, t, label=None: sampling.adm_posterior(bb, x, t, sig, label=label, learn_var=acfg.get("learn_var", True))[0]  # noqa: E731
+        if cfg.get("cfg"):
+            lab = torch.arange(B) % 1000
+            evals = 2
+            mean = lambda x, t: sampling.cfg_mean(post, x, t, {"label": lab}, {"label": torch.zeros_like(lab)}, cfg["cfg"])  # noqa: E731
+        else:
+            mean = lambda x, t: post(x, t)  # noqa: E731
+    else:  # jit
+        jcfg = {"model": cfg["model"], "input_size": cfg["shape"][-1]}
+        lab = torch.arange(B) % 1000
+        schedule = sampling.rectified_schedule
+        mean = lambda x, t: sampling.jit_mean(lambda a, c, y: nets.jit_forward(sd, jcfg, a, c, y), x, t, label=lab)  # noqa: E731
     torch.manual_seed(1)
     x = torch.randn(B, *cfg["shape"])
     pairs = sampling.time_pairs(steps=cfg["steps"])
-    a_t, s_t = sampling.vp_schedule(pairs[0, 0])
-    a_s, s_s = sampling.vp_schedule(pairs[0, 1])
+    a_t, s_t = schedule(pairs[0, 0])
+    a_s, s_s = schedule(pairs[0, 1])
 
     def one_step(x):
         m = mean(x, pairs[0, 0])
@@ -442,18 +475,19 @@ def cpu_baseline(denoiser, cfg, budget_s=60.0):
             el = time.perf_counter() - t0
             if n >= 2 and (el + warm > budget_s / len(settings) or n >= 6):
                 break
-        runs.append(dict(threads=nt, which="physical cores" if nt == phys else "fastest of the conv probe", timed_steps=n,
+        runs.append(dict(threads=nt, which="physical cores" if nt == phys else "fastest of the probe", timed_steps=n,
                          s_per_step=round(el / n, 3), images_per_s=round(B / (cfg["steps"] * el / n), 6)))
     top = max(runs, key=lambda r: r["images_per_s"])
     hi = host_info()
     return dict(
         value=top["images_per_s"], unit="images/s", cores=top["threads"], kind="port", batch=B,
         host_cores=hi["host_cores"], usable_cores=hi["usable_cores"], physical_cores=phys, cpu_model=hi["cpu_model"],
-        runs=runs, probe_s_per_conv={str(k): round(v, 4) for k, v in probe.items()},
+        runs=runs, probe_s_per_op={str(k): round(v, 4) for k, v in probe.items()},
         threads_note=f"torch intra-op threads: {phys} = the physical cores of this host ({hi['host_cores']} logical) and {best} = the fastest of a "
-                     f"probe over {sorted(probe)} threads on the dominant op (a 256->256 3x3 conv at batch {B}); value = the faster run",
-        sample=f"{top['timed_steps']} full DDIM steps of the same UNet at batch {B} ({top['s_per_step']:.2f} s/step on {top['threads']} threads, "
-               f"1 warm-up step), extrapolated x{cfg['steps']} steps",
+                     f"probe over {sorted(probe)} threads on the dominant op ({probe_name}); value = the faster run",
+        sample=f"{top['timed_steps']} full denoise steps ({evals} backbone evaluation{'s' if evals > 1 else ''} each) of the same {kind} network at batch {B}"
+               f"{'' if B == cfg['batch'] else ' (the GPU leg runs ' + str(cfg['batch']) + ' per GPU: per-image cost, CPU batch bounded by the time budget)'}"
+               f" ({top['s_per_step']:.2f} s/step on {top['threads']} threads, 1 warm-up step), extrapolated x{cfg['steps']} steps",
         caveat="a reported baseline, not a target -- the roofline fraction says what the kernels are worth",
     )
 
@@ -535,7 +569,8 @@ def main() -> None:
     if _engine.FP32_MFMA != "native" and not args.half:
         cfg["name"] += (" [fp32 arithmetic; the direct-kernel contractions (1x1 / stride-2 / small-map convs, token GEMMs) as exact "
                         "3 x bf16 splits, 6 partial products on the bf16 MFMA, fp32 accumulate (default mode, AZ_FP32_MFMA=native "
-                        "for v_mfma_f32_32x32x2_f32 everywhere); stride-1 3x3 convs on the fp32 MFMA Winograd kernel]")
+                        "for v_mfma_f32_32x32x2_f32 everywhere); stride-1 3x3 convs on the Winograd F(2x2,3x3) kernel, "
+                        + ("its 16 frequency GEMMs as the same exact 3 x bf16 splits on the bf16 MFMA]" if _engine.WINO_X3 else "fp32 MFMA]"))
     Smp = DDPMSampler if cfg.get("sampler") == "ddpm" else DDIMSampler
     sampler = Smp(den, steps=cfg["steps"], silent=True)
     B = cfg["batch"]
@@ -556,9 +591,18 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
+    # the first sampling call = weight repack (direct / bf16x3 / Winograd-domain filters) + plan + graph capture + one sampling
+    # (it is the first of the W warm-up passes; with --warmup 0 it falls into the timed region and is not reported)
+    mem0 = torch.cuda.memory_allocated(device)
+    first_call_s = None
+    for i in range(args.warmup):
+        t0 = time.perf_counter()
         one_pass()
+        if i == 0:
+            fence()
+            first_call_s = time.perf_counter() - t0
     fence()
+    hbm_resident = torch.cuda.memory_allocated(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         x0 = one_pass()
@@ -608,6 +652,9 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "ms_per_denoise_step": round(ms_per_step / cfg["steps"], 3),
+            "first_call_s": None if first_call_s is None else round(first_call_s, 3),  # repack + plan + capture + the first sampling (untimed; minus one ms_per_step = the set-up)
+            "hbm_bytes_resident": int(hbm_resident),  # torch allocator, this rank, after warm-up: module + packed weights + the plan's pool + x1
+            "hbm_bytes_plan": int(hbm_resident - mem0),  # ... of which allocated by the first call (packed weights, activation pool, tables)
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -644,7 +691,7 @@ def main() -> None:
                 del den_n, smp_n, x1n, x0n
             finally:
                 _engine.FP32_MFMA = "bf16x3"
-        if world == 1 and not args.no_cpu_baseline and cfg["kind"] == "unet":
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(den, cfg)
             out["speedup_vs_cpu"] = round(images_per_s / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
