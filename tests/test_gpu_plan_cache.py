@@ -145,7 +145,7 @@ def test_invalidate_after_a_raw_write(golden):
     torch.manual_seed(5)
     b = smp(x1)
     torch.manual_seed(5)
-    fresh = DDIMSampler(den, steps=8, eta=1.0, silent=True)(x1)
+    fresh = DDIMSampler(den, steps=8, eta=torch.tensor(1.0, device="cuda"), silent=True)(x1)
     assert torch.equal(b, fresh) and not torch.equal(a, b)
 
 

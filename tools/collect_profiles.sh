@@ -1,20 +1,23 @@
 #!/bin/bash
 # End-of-round evidence, on the GPU box:  bash tools/collect_profiles.sh r04   ->  gpurun_out/<tag>_*  (copy into profiles/)
 #   bench lines of every configuration, rocprofv3 --kernel-trace --stats tables of C2 / C3 / C5 / C6 (same command as the
-#   bench line, fewer steps), the PMC traffic collection of C2 (tools/pmc_traffic.py, also run live by the default bench.py).
-TAG=${1:-r04}
+#   bench line, fewer steps, ONE mode per table: --no-native-line), the PMC traffic collections (tools/pmc_traffic.py, also run live by
+#   the default bench.py for its own configuration).
+TAG=${1:-r05}
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 python bench.py > gpurun_out/${TAG}_bench_c2.json 2> gpurun_out/${TAG}_bench_c2.err
 for c in c2 c3 c5 c6; do
   extra=""; [ $c = c5 ] && extra="--denoise-steps 16"   # (rocprofv3 segfaults on the full C5 trace: 16 of the 64 denoise steps)
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$c -o run -- python $R/bench.py --config $c --steps 2 --warmup 1 --no-pmc --no-cpu-baseline $extra > $R/gpurun_out/prof_$c.json 2> $R/gpurun_out/prof_$c.err)
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$c -o run -- python $R/bench.py --config $c --steps 2 --warmup 1 --no-pmc --no-cpu-baseline --no-native-line $extra > $R/gpurun_out/prof_$c.json 2> $R/gpurun_out/prof_$c.err)
   db=$(find gpurun_out/prof_$c -name "*.db" | head -1)
   python profiles/summarize.py $db 40 > gpurun_out/${TAG}_${c}_kernel_stats.txt
   rm -rf gpurun_out/prof_$c
 done
-python tools/pmc_traffic.py collect --config c2 > gpurun_out/${TAG}_traffic_c2.json 2> gpurun_out/${TAG}_traffic_c2.err
+for c in c2 c3 c5 c6; do  # live PMC traffic of every configuration's dominant family (separate --pmc passes, --kernel-trace only)
+  python tools/pmc_traffic.py collect --config $c > gpurun_out/${TAG}_traffic_$c.json 2> gpurun_out/${TAG}_traffic_$c.err
+done
 python bench.py --config c3 --steps 3 --warmup 1 --no-pmc > gpurun_out/${TAG}_bench_c3.json 2> gpurun_out/b_c3.err
 python bench.py --config c5 --steps 2 --warmup 1 --no-pmc > gpurun_out/${TAG}_bench_c5.json 2> gpurun_out/b_c5.err
 python bench.py --config c5cfg32 --steps 1 --warmup 1 --no-pmc > gpurun_out/${TAG}_bench_c5cfg32.json 2> gpurun_out/b_c5cfg32.err
