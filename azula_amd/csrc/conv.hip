@@ -2839,8 +2839,9 @@ static int wino_prepare(const AzConvArgs* a, int wk, int64_t ustage_bytes, WinoP
     const int64_t span = (WT + tiles_img - 1) / tiles_img + 2 + a->depth;
     AZ_REQUIRE(span * a->h0 * a->w0 * a->c0s * 4 < (1ll << 31) && span * a->h1 * a->w1 * a->c1s * 4 < (1ll << 31), AZ_E_SHAPE);
   }
-  if (a->in_affine)  // the normalisation apply pass inside the gather
-    AZ_REQUIRE(!a->src1 && a->c0s % 8 == 0 && a->up0 == 0 && (a->in_act == 0 || a->in_act == 1) && AZ_ALIGNED16(a->in_affine) &&
+  if (a->in_affine)  // the normalisation apply pass inside the gather (the x3 kernel's patch masks live in output coordinates: it
+                     // also takes a nearest-upsampled source)
+    AZ_REQUIRE(!a->src1 && a->c0s % 8 == 0 && (a->up0 == 0 || wk == 16) && (a->in_act == 0 || a->in_act == 1) && AZ_ALIGNED16(a->in_affine) &&
                    (int64_t)a->batch * a->c0s * 8 < (1ll << 31),
                AZ_E_UNSUPPORTED);
   AZ_REQUIRE(!a->aniso || (a->up0_w >= 0 && a->up0_w <= 4 && a->up1_w >= 0 && a->up1_w <= 4), AZ_E_SHAPE);  // (shift amounts)

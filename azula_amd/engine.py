@@ -453,7 +453,10 @@ class Builder:
         tmp_src = None
         if src0.affine is not None:  # a normalisation whose apply pass has not run (group_norm(lazy=True))
             ST, in_act = src0.affine
-            if name in ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32") and src1 is None and up0 == 0 and a.c0s % 8 == 0:
+            # the apply pass inside the gather (the fp32 kernel on a source of the output's size only; the x3 kernel's patch masks
+            # live in output coordinates, so it also reads a nearest-upsampled source)
+            if src1 is None and a.c0s % 8 == 0 and not aniso and (
+                    name == "az_conv2d_winograd_x3_f32" or (name == "az_conv2d_winograd_f32" and up0 == 0)):
                 a.in_affine, a.in_act = ST.data_ptr(), in_act
             else:
                 tmp_src = self.materialize(src0)
