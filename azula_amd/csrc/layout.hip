@@ -166,9 +166,10 @@ __global__ __launch_bounds__(256) void winograd_filter_kernel(float* __restrict_
 
 // The same transform for az_conv2d_winograd_x3_f32 (wino_x3.hip): U rounded to fp32 exactly as above, then split into three bf16
 // pieces (u = u1 + u2 + u3 exactly, 8-bit slices of the significand by truncation) and stored in the order the kernel's waves load
-// it, as v_mfma_f32_32x32x16_bf16 A fragments: [16-cin step][64-cout block][wave w = 0..7][nu][piece][lane][8 bf16], where wave w
-// owns frequency row xi = w & 3 of couts 32 (w >> 2) .. + 31 and lane (l31 = lane & 31, h = lane >> 5) holds
-// U[xi, nu][cout l31][channels 8 h .. 8 h + 7] -- twelve contiguous 1 KB pieces per wave and step; the filter never passes through LDS.
+// it, as v_mfma_f32_32x32x16_bf16 A fragments: [16-cin step][64-cout block][wave w = 0..7][f][cout half][piece][lane][8 bf16], where
+// wave w owns the frequencies (xi = w & 3, nu = (w >> 2) + 2 f) of all 64 couts and lane (l31 = lane & 31, h = lane >> 5) holds
+// U[xi, nu][cout 32 half + l31][channels 8 h .. 8 h + 7] -- twelve contiguous 1 KB pieces per wave and step; the filter never
+// passes through LDS.
 __global__ __launch_bounds__(256) void winograd_filter_x3_kernel(unsigned short* __restrict__ dst, const float* __restrict__ src,
                                                                  int cout, int cin, int cin0, int nk0, int nk, int cblocks) {
   const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
@@ -177,12 +178,13 @@ __global__ __launch_bounds__(256) void winograd_filter_x3_kernel(unsigned short*
        e += (int64_t)gridDim.x * blockDim.x) {
     const int k8 = (int)(e & 7);
     const int ln = (int)((e >> 3) & 63);
-    const int nu = (int)((e >> 9) & 3);
+    const int ch = (int)((e >> 9) & 1);
+    const int f = (int)((e >> 10) & 1);
     const int w = (int)((e >> 11) & 7);
     const int64_t r = e >> 14;
     const int cbk = (int)(r % cblocks);
     const int kt = (int)(r / cblocks);
-    const int co = cbk * 64 + (w >> 2) * 32 + (ln & 31);
+    const int co = cbk * 64 + ch * 32 + (ln & 31);
     const int k = 8 * (ln >> 5) + k8;
     int ci = -1;
     if (kt < nk0) {
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void winograd_filter_x3_kernel(unsigned short*
     float v = 0.f;
     if (co < cout && ci >= 0) {
       const float* g = src + ((int64_t)co * cin + ci) * 9;
-      const int xi = w & 3;
+      const int xi = w & 3, nu = (w >> 2) + 2 * f;
       double acc = 0.0;
 #pragma unroll
       for (int a = 0; a < 3; ++a)
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void winograd_filter_x3_kernel(unsigned short*
     const float r1 = v - __builtin_bit_cast(float, u & 0xFFFF0000u);
     const unsigned u1 = __builtin_bit_cast(unsigned, r1);
     const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
-    unsigned short* d = dst + ((((r * 8 + w) * 4 + nu) * 3) * 64 + ln) * 8 + k8;  // piece 0; pieces are 512 elements apart
+    unsigned short* d = dst + (((((r * 8 + w) * 2 + f) * 2 + ch) * 3) * 64 + ln) * 8 + k8;  // piece 0; pieces are 512 elements apart
     d[0] = (unsigned short)(u >> 16);
     d[512] = (unsigned short)(u1 >> 16);
     d[1024] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);

@@ -10,23 +10,28 @@
 // tests/test_gpu_kernels.py::test_conv2d_x3_accuracy for the direct kernels).
 //
 // Block = 64 couts x 64 tiles (256 output pixels) x 16 frequencies, K step = 16 input channels, 8 waves = 2 per SIMD.
-//   * Wave w = (cout half w >> 2, frequency row xi = w & 3): all 64 tiles, nu = 0..3 -> 8 accumulators acc[2 nu + tile half].
-//   * U never passes through LDS: az_winograd_pack_filter_x3_f32 stores it in MFMA A-fragment order
-//     [step][cout block][wave][nu][piece][lane][8 bf16], so a wave reads its 12 fragments of a step as 12 contiguous 1 KB loads.
-//   * V lives in LDS as three planes of [frequency][tile][16 channels] bf16 rows (32 B; the two 16-byte halves of a row swapped
-//     in rows with bit 3 set: conflict-free ds_read_b128 fragments, as in the fp32 kernel).  A whole 16-channel stage would be
-//     96 KB, so the pipeline runs on HALF-stages of 8 frequencies (nu in {0, 1} | nu in {2, 3}; 48 KB each, two buffers):
-//         phase 0: MFMAs on (step s, nu 0..1) from buffer 0 | V(s, nu 2..3) -> buffer 1, raw patch of step s + 1 in flight
-//         phase 1: MFMAs on (step s, nu 2..3) from buffer 1 | B^T d of step s + 1, V(s + 1, nu 0..1) -> buffer 0
+//   * Wave w = (frequency row xi = w & 3, k = w >> 2) owns the two frequencies (xi, k) and (xi, k + 2) of ALL 64 couts x 64 tiles:
+//     8 accumulators acc[4 f + 2 (cout half) + (tile half)].  Every filter fragment and every V fragment of the block is then
+//     read by exactly one wave (round 5's first form, wave = 32 couts x 64 tiles x 4 frequencies, read every V fragment twice).
+//   * U never passes through LDS: az_winograd_pack_filter_x3_f32 stores it pre-split in MFMA A-fragment order
+//     [step][cout block][wave][f][cout half][piece][lane][8 bf16], twelve contiguous 1 KB loads per wave and step.
+//   * V = B^T d B lives in LDS as fp32, [frequency][tile][16 channels] rows of 64 B (the 16-byte chunks of a row permuted by
+//     (tile >> 2) & 3: conflict-free ds_read_b128 / ds_write_b64), and is split into its three bf16 pieces by the ONE wave
+//     that consumes it, in registers, on the way into the MFMAs: 4 B instead of 6 B per value through LDS, no second read.
+//     The pipeline runs on HALF-stages of 8 frequencies (nu in {0, 1} | nu in {2, 3}; 32 KB each, two buffers):
+//         phase 0: MFMAs on (step s, nu = k) from buffer 0     | V(s, nu 2..3) -> buffer 1, raw pixels of step s + 1 staged
+//         phase 1: MFMAs on (step s, nu = k + 2) from buffer 1 | B^T d of step s + 1, V(s + 1, nu 0..1) -> buffer 0
 //     one barrier per phase.
 //   * The raw input is STAGED in LDS once per step, each pixel once: the 64 tiles of a block are runs ("segments") of
 //     horizontally adjacent tiles whose 4x4 patches overlap by two columns, so a segment of n tiles needs 4 rows x (2 n + 2)
-//     pixels instead of 16 n (the gather was 28 % of the kernel, the vector memory path its bound: profiles/r05_wx3_ablation_v2.txt).
-//     The pixels' 16 channels of the step (64 B) go global -> registers -> LDS as 16-byte lane slots (bounds-checked buffer loads:
-//     padding / ragged tiles land as zeros; upsampling, two sources, circular padding are offsets), into the 48 KB behind the V
-//     buffers; then thread (tile tid >> 3, channel pair tid & 7) reads its 4x4 patch with 16 ds_read_b64.
-//   * Epilogue: the nu side of A^T M A in registers, the xi side on the way out of the LDS exchange buffer; bias / SiLU / gate /
-//     residual / split-K slabs / GroupNorm moments of the output as in the fp32 kernel.
+//     pixels instead of 16 n.  The pixels' 16 channels of the step (64 B) go global -> registers -> LDS as 16-byte lane slots
+//     (bounds-checked buffer loads: padding / ragged tiles land as zeros; upsampling, two sources, circular padding are
+//     offsets); then thread (tile tid >> 3, channel pair tid & 7) reads its 4x4 patch with 16 ds_read_b64.
+//   * Epilogue: every wave applies the nu side of A^T M A to its two frequencies in registers, the k = 1 waves hand their partial
+//     to the k = 0 waves through LDS, which park Z[xi][px] as [xi][tile][px][cout]; all 8 waves read rows back applying the xi
+//     side; bias / SiLU / gate / residual / split-K slabs / GroupNorm moments of the output as in the fp32 kernel.
+//   The kernel sits at the 1400 W cap (profiles/r05_wino_x3_gate.txt): its time is its energy, so what counts is bytes moved
+//   and instructions issued, not cycles.
 #include "conv_shared.h"
 
 #include <cstdlib>
@@ -39,17 +44,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int XT = 64;                       // tiles per workgroup
 constexpr int XC = 64;                       // output channels per workgroup
 constexpr int XK = 16;                       // input channels per step
-constexpr int X_ROW = XK * 2;                // bytes of one (frequency, tile) row of a piece plane
-constexpr int X_FREQ = XT * X_ROW;           // 2 KB
-constexpr int X_PLANE = 8 * X_FREQ;          // one piece of a half-stage: 16 KB
-constexpr int X_HALF = 3 * X_PLANE;          // 48 KB
+constexpr int X_ROW = XK * 4;                // bytes of one (frequency, tile) row of V: 16 channels fp32
+constexpr int X_FREQ = XT * X_ROW;           // 4 KB
+constexpr int X_HALF = 8 * X_FREQ;           // one half-stage (8 frequencies): 32 KB
 constexpr int X_STAGE = 2 * X_HALF;          // raw staging behind the two half-stage buffers: <= 768 pixel slots x 64 B = 48 KB
 constexpr int X_SLOTS = 768;                 // (8 (64 + segments) slots: up to 32 segments, i.e. maps at least 3 pixels wide; the host checks)
 constexpr int X_DOFF1 = X_STAGE + X_SLOTS * 64;  // the second source's staging offsets (6 per thread, 32 B apart: 16 KB), read back at the switch
 constexpr int X_OT = 2 * XC + 4;             // epilogue: floats per tile row of one xi's [tile][px][cout] exchange buffer
 constexpr int X_EPI_BYTES = (4 * XT * X_OT + 3 * XT + 384) * 4;  // 137,472 B: four xi partials + tile table + GroupNorm partials
-constexpr int X_LDS_BYTES = X_DOFF1 + 512 * 32;  // 163,840 B = all of a CU's LDS (>= the epilogue's exchange buffer)
-static_assert(X_LDS_BYTES >= X_EPI_BYTES, "the epilogue reuses the K loop's LDS");
+constexpr int X_LDS_BYTES = X_EPI_BYTES;     // (>= the K loop's 64 + 48 + 16 KB and the 128 KB hand-off of the k = 1 waves' partials)
+static_assert(X_LDS_BYTES >= X_DOFF1 + 512 * 32 && X_LDS_BYTES >= 4 * 128 * 64 * 4, "the epilogue reuses the K loop's LDS");
 constexpr int XU_STEP_BYTES = 16 * XC * XK * 3 * 2;  // one (step, cout block) filter chunk: 96 KB
 static_assert(4 * X_SLOTS <= 6 * 512, "six staging pieces per thread");
 static_assert(X_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
@@ -64,8 +68,8 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;  // 8 waves = 2 per SIMD: wave w and w + 4 share a SIMD
-  const int wxi = wave & 3;   // the wave's frequency row xi (its 4 frequencies: xi, nu = 0..3)
-  const int wco = wave >> 2;  // which 32 of the 64 couts (all 64 tiles: two 32-tile accumulators per frequency)
+  const int wxi = wave & 3;   // the wave's frequency row xi
+  const int wk = wave >> 2;   // its two frequencies: (xi, nu = k) in phase 0, (xi, nu = k + 2) in phase 1
   const int l31 = lane & 31;
   const int h = lane >> 5;
 
@@ -243,152 +247,149 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
     rv[8 + c] = d2 - d1;
     rv[12 + c] = d1 - d3;
   };
-  // columns side of B^T d B of frequency row xi for one half of the frequencies (hs = 0: nu in {0, 1}; 1: nu in {2, 3})
-  f32x2 vv[8];  // vv[2 xi + j] = V[xi][2 hs + j] of the channel pair
-  auto nu_side = [&](int hs, int xi) __attribute__((always_inline)) {
+  // columns side of B^T d B of frequency row xi for one half of the frequencies (hs = 0: nu in {0, 1}; 1: nu in {2, 3}), stored
+  // as fp32 pairs: row (2 xi + j) of buffer hs, tile vj, channels 2 vq, 2 vq + 1
+  const int vrow = vj * X_ROW + (((vq >> 1) ^ ((vj >> 2) & 3)) * 16) + (vq & 1) * 8;
+  auto nu_store = [&](int hs, int xi) __attribute__((always_inline)) {
     const f32x2 u0 = rv[4 * xi], u1 = rv[4 * xi + 1], u2 = rv[4 * xi + 2], u3 = rv[4 * xi + 3];
-    vv[2 * xi] = hs == 0 ? u0 - u2 : u2 - u1;
-    vv[2 * xi + 1] = hs == 0 ? u1 + u2 : u1 - u3;
+    char* dst = smem + hs * X_HALF + vrow + (2 * xi) * X_FREQ;
+    *reinterpret_cast<f32x2*>(dst) = hs == 0 ? u0 - u2 : u2 - u1;
+    *reinterpret_cast<f32x2*>(dst + X_FREQ) = hs == 0 ? u1 + u2 : u1 - u3;
   };
-  // exact 3 x bf16 split of vv[c] (az_split3 in three stages the schedule can place) and the stores of a frequency row
-  const int vrow = vj * X_ROW + (((vq >> 2) ^ ((vj >> 3) & 1)) * 16) + (vq & 3) * 4;
-  unsigned qq[8][3];
-  auto split_a = [&](int c) __attribute__((always_inline)) {  // piece 1, first remainder
-    const float x0 = vv[c].x, x1 = vv[c].y;  // (by value: __builtin_bit_cast of a vector ELEMENT expression read element 0 twice)
-    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
-    qq[c][0] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    vv[c] = f32x2{x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u), x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u)};
-  };
-  auto split_b = [&](int c) __attribute__((always_inline)) {  // piece 2, second remainder = piece 3
-    const float r0 = vv[c].x, r1 = vv[c].y;
-    const unsigned u0 = __builtin_bit_cast(unsigned, r0), u1 = __builtin_bit_cast(unsigned, r1);
-    qq[c][1] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    const float s0 = r0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
-    const float s1 = r1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
-    qq[c][2] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
-  };
-  auto store_row = [&](int hs, int xi) __attribute__((always_inline)) {  // both frequencies of row xi, three planes -> buffer hs
-    char* dst = smem + hs * X_HALF + vrow;
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) *reinterpret_cast<unsigned*>(dst + pl * X_PLANE + (2 * xi + j) * X_FREQ) = qq[2 * xi + j][pl];
-  };
-  // the wave's filter fragments of (step kt, frequency nu): A[piece] = the pieces of U[xi, nu], rows = couts wco * 32 + l31,
-  // k = 8 h .. 8 h + 7 of the step -- three contiguous 1 KB loads
+  // the wave's filter fragments of (step kt, its frequency f, piece pl): both cout halves, rows = couts ch * 32 + l31,
+  // k = 8 h .. 8 h + 7 of the step -- two contiguous 1 KB loads
   const unsigned u_lane = (unsigned)(lane * 16);
-  auto load_u = [&](int kt, int nu, bf16x8 (&ua)[3]) __attribute__((always_inline)) {
+  bf16x8 ua[2][3];  // [cout half][piece]
+  auto load_u = [&](int kt, int f, int pl) __attribute__((always_inline)) {
     const unsigned soff =  // (wave-uniform, but derived from threadIdx: readfirstlane makes it a scalar operand)
-        (unsigned)__builtin_amdgcn_readfirstlane((int)((((int64_t)kt * p.cblocks + cb) * 8 + wave) * (12 * 1024) + nu * (3 * 1024)));
+        (unsigned)__builtin_amdgcn_readfirstlane((int)((((int64_t)kt * p.cblocks + cb) * 8 + wave) * (12 * 1024) + f * (6 * 1024)));
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) ua[pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)(pl * 1024), soff));
+    for (int ch = 0; ch < 2; ++ch) ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));
   };
 
-  f32x16 acc[8];
+  f32x16 acc[8];  // [4 f + 2 ch + th]
 #pragma unroll
   for (int f = 0; f < 8; ++f)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
-  // V fragment: frequency (xi, j) = row 2 xi + j of the half-stage, tile th * 32 + l31, half h (swapped in rows with bit 3 set)
-  const int fragB = (2 * wxi) * X_FREQ + l31 * X_ROW + ((h ^ ((l31 >> 3) & 1)) * 16);
-  // the six partial products of a frequency, smallest first; B piece 2 is needed by the first pair of MFMAs only and piece 1
-  // by the first eight, so the NEXT frequency's fragments can replace them early (one set of fragment registers)
-  constexpr int PA[6] = {0, 1, 2, 0, 1, 0};
-  constexpr int PB[6] = {2, 1, 0, 1, 0, 0};
-  bf16x8 ua[2][3], fb[2][3];
-  auto frag = [&](int hs, int j, int pl) __attribute__((always_inline)) {  // piece pl of both tile halves of frequency (xi, 2 hs + j)
-    const char* vb = smem + hs * X_HALF + fragB + j * X_FREQ + pl * X_PLANE;
-    fb[0][pl] = *reinterpret_cast<const bf16x8*>(vb);
-    fb[1][pl] = *reinterpret_cast<const bf16x8*>(vb + 32 * X_ROW);
+  // V fragment of the wave's frequency in a half-stage (row 2 xi + k): tile th * 32 + l31, channels 8 h .. 8 h + 7 = chunks 2 h,
+  // 2 h + 1 of the row (chunk c sits at c ^ ((tile >> 2) & 3)), fp32 -> split here into the three bf16 fragments fw[th][piece]
+  const int fragB = (2 * wxi + wk) * X_FREQ + l31 * X_ROW;
+  const int fsw = (l31 >> 2) & 3;
+  float xf[2][8];      // the raw values, then their remainders
+  unsigned fw[2][3][4];
+  auto frag_read = [&](int hs, int th) __attribute__((always_inline)) {
+    const char* vb = smem + hs * X_HALF + fragB + th * (32 * X_ROW);
+    const float4 lo = *reinterpret_cast<const float4*>(vb + (((2 * h) ^ fsw) * 16));
+    const float4 hi = *reinterpret_cast<const float4*>(vb + (((2 * h + 1) ^ fsw) * 16));
+    xf[th][0] = lo.x, xf[th][1] = lo.y, xf[th][2] = lo.z, xf[th][3] = lo.w;
+    xf[th][4] = hi.x, xf[th][5] = hi.y, xf[th][6] = hi.z, xf[th][7] = hi.w;
   };
-  auto mf = [&](int hs, int k) __attribute__((always_inline)) {  // MFMA k = 0..23 of a phase: frequency j = k / 12, product t, tile half th
-    const int j = k / 12, t = (k % 12) / 2, th = k & 1;
-    f32x16& c = acc[2 * (2 * hs + j) + th];
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[j][PA[t]], fb[th][PB[t]], c, 0, 0, 0);
+  auto piece = [&](int th, int pl) __attribute__((always_inline)) {  // piece pl = the high halves of the current remainders
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      fw[th][pl][j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, xf[th][2 * j + 1]), __builtin_bit_cast(unsigned, xf[th][2 * j]), 0x07060302u);
+  };
+  auto remainder = [&](int th, int j0, int j1) __attribute__((always_inline)) {  // x -= its high 16 bits (exact), values 2 j0 .. 2 j1 - 1
+#pragma unroll
+    for (int i = 2 * j0; i < 2 * j1; ++i) {
+      const float x = xf[th][i];
+      xf[th][i] = x - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u);
+    }
+  };
+  // the six partial products of a frequency in the order the B pieces become available: b0 (3 products), b1 (2), b2 (1); the A
+  // pieces free up in the order a2 (after 4 MFMAs), a1 (after 16), a0 -- their registers take the next phase's fragments
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+  constexpr int PB[6] = {0, 0, 0, 1, 1, 2};
+  auto mf = [&](int f, int k) __attribute__((always_inline)) {  // MFMA k = 0..23 of a phase: product t = k / 4, tile half, cout half
+    const int t = k >> 2, th = (k >> 1) & 1, ch = k & 1;
+    f32x16& c = acc[4 * f + 2 * ch + th];
+    uint4 bw = make_uint4(fw[th][PB[t]][0], fw[th][PB[t]][1], fw[th][PB[t]][2], fw[th][PB[t]][3]);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[ch][PA[t]], __builtin_bit_cast(bf16x8, bw), c, 0, 0, 0);
   };
 
-  // One phase = the 24 MFMAs of (step kt, half hs) + the production of the NEXT half-stage into the other buffer:
-  //   hs = 0: V(kt, nu 2..3) -> buffer 1 from the B^T d of step kt held in rv; then the raw patch of step ktn replaces rv;
-  //   hs = 1: B^T d of step ktn, V(ktn, nu 0..1) -> buffer 0.
-  // The matrix pipe takes 32 cycles per MFMA and both waves of a SIMD share it, so the rest of the phase -- 96 vector
-  // instructions of splits, 12 paired LDS stores, 16 + 6 loads, 16 fragment reads -- is issued in SLOTS of one MFMA plus a few
-  // other instructions, fenced by sched_barrier(0): the compiler's own order put all 24 MFMAs first and the vector work
-  // behind them with the pipe idle (1139 us at 4 x 256^2, 256 -> 256), and a sched_group_barrier pattern was not honoured.
-  // Fragment / filter registers are reloaded for their next use right behind their last MFMA (see PA / PB).
+  // One phase = the 24 MFMAs of (step kt, the wave's frequency f = hs) + the production of the NEXT half-stage into the other buffer:
+  //   hs = 0: V(kt, nu 2..3) -> buffer 1 from the B^T d of step kt held in rv; the raw pixels of step ktn are staged;
+  //   hs = 1: the thread's patch of step ktn, its B^T d, V(ktn, nu 0..1) -> buffer 0.
+  // Issued in SLOTS of one MFMA plus a few other instructions, fenced by sched_barrier(0) (the compiler's own order puts all 24
+  // MFMAs first and everything else behind them; a sched_group_barrier pattern was not honoured).  The consumer side of a
+  // slot splits the phase's own V fragments just ahead of the products that need them; the producer side follows.
 #define XS_FENCE __builtin_amdgcn_sched_barrier(0)
   auto phase = [&](auto HS, int kt, int ktn) __attribute__((always_inline)) {
     constexpr int hs = decltype(HS)::value;
     constexpr int ob = 1 - hs;  // the buffer (and half of the frequencies) this phase produces
-    const int ktu = hs == 0 ? kt : ktn;  // the step whose filter fragments are loaded next
+    const int ktu = hs == 0 ? kt : ktn;  // the step whose filter fragments are loaded next (frequency f = ob of it)
+    // (entry: xf[0], xf[1] hold the phase's raw fragments, read behind the barrier)
+    piece(0, 0); XS_FENCE;
     if constexpr (hs == 0) {
-      // (rv holds B^T d of step kt until the nu side is done; the staging area is free: every thread read its patch of
-      //  step kt at the head of the previous phase 1)
-      mf(hs, 0); nu_side(ob, 0); nu_side(ob, 1); XS_FENCE;
-      mf(hs, 1); nu_side(ob, 2); nu_side(ob, 3); XS_FENCE;
-      mf(hs, 2); frag(hs, 1, 2); gl(ktn, 0); split_a(0); XS_FENCE;
-      mf(hs, 3); gl(ktn, 1); split_b(0); XS_FENCE;
-      mf(hs, 4); gl(ktn, 2); split_a(1); XS_FENCE;
-      mf(hs, 5); gl(ktn, 3); split_b(1); XS_FENCE;
-      mf(hs, 6); gl(ktn, 4); store_row(ob, 0); XS_FENCE;
-      mf(hs, 7); gl(ktn, 5); split_a(2); XS_FENCE;
-      mf(hs, 8); frag(hs, 1, 1); split_b(2); XS_FENCE;
-      mf(hs, 9); split_a(3); XS_FENCE;
-      mf(hs, 10); split_b(3); XS_FENCE;
-      mf(hs, 11); store_row(ob, 1); XS_FENCE;
-      // second frequency: its B pieces 2 and 1 are in place; piece 0 and the first frequency's filter fragments behind MFMA 11
-      mf(hs, 12); frag(hs, 1, 0); load_u(ktu, 2, ua[0]); XS_FENCE;
-      mf(hs, 13); split_a(4); XS_FENCE;
-      mf(hs, 14); split_b(4); gs(0); XS_FENCE;
-      mf(hs, 15); split_a(5); gs(1); XS_FENCE;
-      mf(hs, 16); split_b(5); gs(2); XS_FENCE;
-      mf(hs, 17); store_row(ob, 2); gs(3); XS_FENCE;
-      mf(hs, 18); split_a(6); gs(4); XS_FENCE;
-      mf(hs, 19); split_b(6); gs(5); XS_FENCE;
-      mf(hs, 20); split_a(7); XS_FENCE;
-      mf(hs, 21); split_b(7); XS_FENCE;
-      mf(hs, 22); store_row(ob, 3); XS_FENCE;
+      // (rv holds B^T d of step kt: consumed first, its registers then take the staging loads; the staging area is free: every
+      //  thread read its patch in the previous phase 1)
+      mf(hs, 0); piece(1, 0); XS_FENCE;
+      mf(hs, 1); nu_store(ob, 0); XS_FENCE;
+      mf(hs, 2); nu_store(ob, 1); XS_FENCE;
+      mf(hs, 3); nu_store(ob, 2); XS_FENCE;
+      mf(hs, 4); nu_store(ob, 3); load_u(ktu, ob, 2); XS_FENCE;  // (rv is free from here; a2 is free: the next phase's a2)
+      mf(hs, 5); remainder(0, 0, 2); XS_FENCE;
+      mf(hs, 6); remainder(0, 2, 4); XS_FENCE;
+      mf(hs, 7); remainder(1, 0, 2); XS_FENCE;
+      mf(hs, 8); remainder(1, 2, 4); XS_FENCE;
+      mf(hs, 9); piece(0, 1); XS_FENCE;
+      mf(hs, 10); piece(1, 1); XS_FENCE;
+      mf(hs, 11); gl(ktn, 0); gl(ktn, 1); remainder(0, 0, 2); XS_FENCE;
+      mf(hs, 12); gl(ktn, 2); gl(ktn, 3); remainder(0, 2, 4); XS_FENCE;
+      mf(hs, 13); gl(ktn, 4); gl(ktn, 5); remainder(1, 0, 2); XS_FENCE;
+      mf(hs, 14); remainder(1, 2, 4); XS_FENCE;
+      mf(hs, 15); piece(0, 2); piece(1, 2); XS_FENCE;
+      mf(hs, 16); load_u(ktu, ob, 1); XS_FENCE;  // (a1 is free)
+      mf(hs, 17); gs(0); XS_FENCE;
+      mf(hs, 18); gs(1); XS_FENCE;
+      mf(hs, 19); gs(2); XS_FENCE;
+      mf(hs, 20); gs(3); XS_FENCE;
+      mf(hs, 21); gs(4); XS_FENCE;
+      mf(hs, 22); gs(5); XS_FENCE;
       mf(hs, 23);
     } else {
-      // (the raw pixels of step ktn are staged: behind the barrier that closed phase 0; their readers sit four slots away)
-      mf(hs, 0); patch_rows(ktn, 0, 2); XS_FENCE;
-      mf(hs, 1); patch_rows(ktn, 2, 4); XS_FENCE;
-      mf(hs, 2); frag(hs, 1, 2); XS_FENCE;
-      mf(hs, 3); XS_FENCE;
+      // (the raw pixels of step ktn are staged: behind the barrier that closed phase 0; the patch is read late, when the
+      //  fragment registers of this phase are mostly done)
+      mf(hs, 0); piece(1, 0); XS_FENCE;
+      mf(hs, 1); remainder(0, 0, 2); XS_FENCE;
+      mf(hs, 2); remainder(0, 2, 4); XS_FENCE;
+      mf(hs, 3); remainder(1, 0, 2); XS_FENCE;
+      mf(hs, 4); remainder(1, 2, 4); load_u(ktu, ob, 2); XS_FENCE;  // (a2 is free: the next phase's a2)
+      mf(hs, 5); piece(0, 1); XS_FENCE;
+      mf(hs, 6); piece(1, 1); XS_FENCE;
+      mf(hs, 7); remainder(0, 0, 2); XS_FENCE;
+      mf(hs, 8); remainder(0, 2, 4); XS_FENCE;
+      mf(hs, 9); remainder(1, 0, 2); XS_FENCE;
+      mf(hs, 10); remainder(1, 2, 4); XS_FENCE;
+      mf(hs, 11); piece(0, 2); piece(1, 2); XS_FENCE;
+      mf(hs, 12); patch_rows(ktn, 0, 2); XS_FENCE;
+      mf(hs, 13); patch_rows(ktn, 2, 4); XS_FENCE;
+      mf(hs, 14); XS_FENCE;
+      mf(hs, 15); XS_FENCE;
+      mf(hs, 16); load_u(ktu, ob, 1); XS_FENCE;  // (a1 is free)
       affine();
-      mf(hs, 4); row_transform(0); row_transform(1); XS_FENCE;
-      mf(hs, 5); row_transform(2); row_transform(3); XS_FENCE;
-      mf(hs, 6); nu_side(ob, 0); nu_side(ob, 1); XS_FENCE;
-      mf(hs, 7); nu_side(ob, 2); nu_side(ob, 3); XS_FENCE;
-      mf(hs, 8); frag(hs, 1, 1); split_a(0); XS_FENCE;
-      mf(hs, 9); split_b(0); XS_FENCE;
-      mf(hs, 10); split_a(1); XS_FENCE;
-      mf(hs, 11); split_b(1); XS_FENCE;
-      mf(hs, 12); frag(hs, 1, 0); load_u(ktu, 0, ua[0]); store_row(ob, 0); XS_FENCE;
-      mf(hs, 13); split_a(2); XS_FENCE;
-      mf(hs, 14); split_b(2); XS_FENCE;
-      mf(hs, 15); split_a(3); XS_FENCE;
-      mf(hs, 16); split_b(3); store_row(ob, 1); XS_FENCE;
-      mf(hs, 17); split_a(4); XS_FENCE;
-      mf(hs, 18); split_b(4); XS_FENCE;
-      mf(hs, 19); split_a(5); XS_FENCE;
-      mf(hs, 20); split_b(5); store_row(ob, 2); XS_FENCE;
-      mf(hs, 21); split_a(6); split_b(6); XS_FENCE;
-      mf(hs, 22); split_a(7); XS_FENCE;
-      mf(hs, 23); split_b(7); store_row(ob, 3);
+      mf(hs, 17); row_transform(0); row_transform(1); XS_FENCE;
+      mf(hs, 18); row_transform(2); row_transform(3); XS_FENCE;
+      mf(hs, 19); nu_store(ob, 0); XS_FENCE;
+      mf(hs, 20); nu_store(ob, 1); XS_FENCE;
+      mf(hs, 21); nu_store(ob, 2); XS_FENCE;
+      mf(hs, 22); nu_store(ob, 3); XS_FENCE;
+      mf(hs, 23);
     }
-    load_u(ktu, hs == 0 ? 3 : 1, ua[1]);
-    // the NEXT phase's first frequency: its buffer is complete behind the barrier
+    load_u(ktu, ob, 0);
+    // the NEXT phase's fragments: its buffer is complete behind the barrier
     __syncthreads();
-    frag(ob, 0, 2); frag(ob, 0, 1); frag(ob, 0, 0);
+    frag_read(ob, 0); frag_read(ob, 1);
     XS_FENCE;
   };
 
   if (kt_begin < kt_end) {
 #pragma unroll
     for (int m = 0; m < 6; ++m) gl(kt_begin, m);
-    load_u(kt_begin, 0, ua[0]);
-    load_u(kt_begin, 1, ua[1]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) load_u(kt_begin, 0, pl);
 #pragma unroll
     for (int m = 0; m < 6; ++m) gs(m);
     __syncthreads();
@@ -397,15 +398,10 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) row_transform(c);
 #pragma unroll
-    for (int xi = 0; xi < 4; ++xi) {
-      nu_side(0, xi);
-      split_a(2 * xi), split_b(2 * xi), split_a(2 * xi + 1), split_b(2 * xi + 1);
-      store_row(0, xi);
-    }
+    for (int xi = 0; xi < 4; ++xi) nu_store(0, xi);
     __syncthreads();
-    frag(0, 0, 2); frag(0, 0, 1); frag(0, 0, 0);
-    // waves 4 .. 7 are the younger half of every SIMD pair and lose the vector-issue arbitration by age (they ran 1600 - 2000 cycles
-    // through the first 12 slots of a phase where waves 0 .. 3 took 1100 - 1250, which then waited at the barrier): static priority
+    frag_read(0, 0); frag_read(0, 1);
+    // waves 4 .. 7 are the younger half of every SIMD pair and lose the vector-issue arbitration by age: static priority
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -415,34 +411,65 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
       phase(std::integral_constant<int, 1>{}, kt, ktn);
     }
     __builtin_amdgcn_s_setprio(0);
-  } else {
-    __syncthreads();
   }
+  __syncthreads();
 #undef XS_FENCE
 
-  // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  A wave holds one frequency row xi (nu = 0..3) of its
-  // 32 couts x 64 tiles: it applies the nu side in registers -- Z[xi][px] = M[xi][0] + M[xi][1] + M[xi][2] (px = 0),
-  // M[xi][1] - M[xi][2] - M[xi][3] (px = 1) -- and parks Z in LDS as [xi][tile][px][cout] (tile stride padded by 4 floats:
-  // conflict-free ds_write_b128).  Then ALL 8 waves read rows back, applying the xi side on the way
-  // (py = 0: Z[0] + Z[1] + Z[2]; py = 1: Z[1] - Z[2] - Z[3]), so that 16 consecutive lanes store the 256 contiguous bytes of
-  // one output pixel.  Lane: tile = th * 32 + l31; couts wco * 32 + 8 g + 4 h + (0..3) in registers 4 g .. 4 g + 3 of acc[2 nu + th].
+  // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  Z[xi][px] = sum_nu M[xi][nu] A[nu][px]: px = 0: M0 + M1 + M2,
+  // px = 1: M1 - M2 - M3.  A wave holds M[xi][k] (f = 0) and M[xi][k + 2] (f = 1) of all 64 couts x 64 tiles:
+  //   k = 0: P0 = M0 + M2, P1 = -M2;   k = 1: P0 = M1, P1 = M1 - M3;   Z[px] = P_px(k = 0) + P_px(k = 1).
+  // The k = 1 waves hand (P0, P1) to the k = 0 wave of their xi through LDS (same lane, same register: 32 float4 per lane, lane-
+  // contiguous), which adds and parks Z in LDS as [xi][tile][px][cout] (tile stride padded by 4 floats: conflict-free
+  // ds_write_b128).  Then ALL 8 waves read rows back, applying the xi side on the way (py = 0: Z[0] + Z[1] + Z[2]; py = 1:
+  // Z[1] - Z[2] - Z[3]), so that 16 consecutive lanes store the 256 contiguous bytes of one output pixel.
+  // Lane: tile = th * 32 + l31; couts ch * 32 + 8 g + 4 h + (0..3) in registers 4 g .. 4 g + 3 of acc[4 f + 2 ch + th].
+  // (two code versions behind a scalar branch on the wave-uniform k: as selects the compiler computes both and spills)
+  if (wk == 0) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[q] = acc[q] + acc[4 + q];  // P0 = M0 + M2
+      acc[4 + q] = -acc[4 + q];      // P1 = -M2
+    }
+  } else {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[4 + q] = acc[q] - acc[4 + q];  // P0 = M1 (in place), P1 = M1 - M3
+  }
   {
-    float* zbuf = wsm + wxi * (XT * X_OT);
+    float4* hand = reinterpret_cast<float4*>(wsm) + wxi * (32 * 64) + lane;  // [xi][32 float4][lane]
+    if (wk == 1) {
 #pragma unroll
-    for (int th = 0; th < 2; ++th) {
-      float* zrow = zbuf + (th * 32 + l31) * X_OT + wco * 32 + 4 * h;
+      for (int q = 0; q < 8; ++q)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float z0[4], z1[4];
+        for (int g = 0; g < 4; ++g) hand[(q * 4 + g) * 64] = make_float4(acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]);
+    }
+    __syncthreads();
+    if (wk == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float m0 = acc[0 + th][4 * g + r], m1 = acc[2 + th][4 * g + r], m2 = acc[4 + th][4 * g + r], m3 = acc[6 + th][4 * g + r];
-          z0[r] = (m0 + m1) + m2;
-          z1[r] = (m1 - m2) - m3;
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 o = hand[(q * 4 + g) * 64];
+          acc[q][4 * g] += o.x, acc[q][4 * g + 1] += o.y, acc[q][4 * g + 2] += o.z, acc[q][4 * g + 3] += o.w;
         }
-        *reinterpret_cast<float4*>(zrow + 8 * g) = make_float4(z0[0], z0[1], z0[2], z0[3]);
-        *reinterpret_cast<float4*>(zrow + XC + 8 * g) = make_float4(z1[0], z1[1], z1[2], z1[3]);
-      }
+    }
+    __syncthreads();  // (the hand-off area is dead: Z goes on top of it)
+    if (wk == 0) {
+      float* zbuf = wsm + wxi * (XT * X_OT);
+#pragma unroll
+      for (int th = 0; th < 2; ++th)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          float* zrow = zbuf + (th * 32 + l31) * X_OT + ch * 32 + 4 * h;
+          const f32x16& z0 = acc[2 * ch + th];
+          const f32x16& z1 = acc[4 + 2 * ch + th];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<float4*>(zrow + 8 * g) = make_float4(z0[4 * g], z0[4 * g + 1], z0[4 * g + 2], z0[4 * g + 3]);
+            *reinterpret_cast<float4*>(zrow + XC + 8 * g) = make_float4(z1[4 * g], z1[4 * g + 1], z1[4 * g + 2], z1[4 * g + 3]);
+          }
+        }
     }
   }
   int* tinfo = reinterpret_cast<int*>(wsm + 4 * XT * X_OT);  // [64] first output pixel of the tile (-1: none), [64] flags, [64] image

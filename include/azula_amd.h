@@ -467,8 +467,8 @@ int az_winograd_pack_filter_f32(float* dst, const float* src, int32_t cout, int3
                                 int32_t nk, int32_t cblocks, az_stream_t stream);
 
 /* The same transform for az_conv2d_winograd_x3_f32: U (rounded to fp32 as above) split exactly into three bf16 pieces, in the
- * order that kernel's waves load it as MFMA A fragments: [nk steps of 16 cin][cblocks of 64 cout][wave 0..7 = (32-cout half) * 4 +
- * frequency row xi][nu][piece][lane][8 bf16] (96 KB per step and cout block; opaque to callers).  dst holds
+ * order that kernel's waves load it as MFMA A fragments: [nk steps of 16 cin][cblocks of 64 cout][wave 0..7 = k * 4 + frequency
+ * row xi][f: nu = k + 2 f][32-cout half][piece][lane][8 bf16] (96 KB per step and cout block; opaque to callers).  dst holds
  * nk * cblocks * 49152 two-byte elements; channels [0, cin0) fill steps [0, nk0), the rest start at step nk0.      */
 int az_winograd_pack_filter_x3_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t cin0, int32_t nk0,
                                    int32_t nk, int32_t cblocks, az_stream_t stream);
