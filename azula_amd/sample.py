@@ -456,8 +456,16 @@ class _FusedLoop:
     loop replays the captured graph of ``period`` consecutive steps (1 except for the multistep family, whose history
     ring makes the buffer addresses cycle with period ``order``)."""
 
+    @property
+    def sampler(self) -> "Sampler":
+        return self._sampler()
+
     def __init__(self, sampler: Sampler, fused: FusedDenoiser, x: Tensor, cur: Tensor) -> None:
-        self.sampler, self.fused, self.cur = sampler, fused, cur
+        # (a weak reference: the loop lives in sampler._fused_cache -- a strong one would make a cycle, and a dropped plan's pool,
+        #  tens of GB of HBM at ADM sizes, would wait for the cycle collector instead of going with the last reference)
+        import weakref
+
+        self._sampler, self.fused, self.cur = weakref.ref(sampler), fused, cur
         dev = x.device
         self.x = torch.empty_like(x, memory_format=torch.contiguous_format)
         # noise[k]: the k-th randn_like of a step that a kernel reads.  With DDIM eta = 0 nothing reads it, but the

@@ -28,6 +28,18 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _release_device_memory():
+    r"""Plans hold tens of GB of HBM at the full-size configurations; reference cycles (modules, closures) would keep a finished
+    test's plans alive until the cycle collector runs, and the suite's peak would be the sum of its tests."""
+    yield
+    if torch.cuda.is_available():
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 class Golden:
     def __init__(self, name: str) -> None:
         z = np.load(os.path.join(GOLDEN, name + ".npz"))
