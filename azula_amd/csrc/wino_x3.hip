@@ -199,7 +199,6 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
   }
 
   f32x2 rv[16];  // raw 4x4 patch of the channel pair (index = patch row * 4 + column), then B^T d in place
-  int staged_kt = 0;
   // piece m of the staging of step kt: this thread's lane slot L = m * 512 + tid (16 bytes) global -> registers (gl), and on to
   // the staging area at byte 16 L (gs) half a phase later.  (LDS-DMA moved the same bytes without registers, but one
   // buffer_load ... lds costs the issuing wave 100 - 180 cycles beside MFMAs: profiles/r05_wx3_timeline_v3.txt.)
@@ -218,22 +217,33 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
     if (m < 5 || m < ndma) *reinterpret_cast<float4*>(smem + X_STAGE + (m * 512 + tid) * 16) = gq[m];
   };
   auto patch_rows = [&](int kt, int r0, int r1) __attribute__((always_inline)) {  // rows [r0, r1) of the staged patch -> rv
-    staged_kt = kt;
 #pragma unroll
     for (int r = r0; r < r1; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) rv[4 * r + c] = *reinterpret_cast<const f32x2*>(patch + r * prow + c * 64);
   };
   // with in_affine the input is act(x * scale + shift) (padding positions stay zero): applied to the raw patch in place
+  // the scale / shift pair of the thread's channel pair for step kt: two bounds-checked 8-byte loads issued well ahead of their
+  // use (as a pointer dereference in front of the multiply they put a global round trip on every step: - 2 % on the affine layers).
+  // (Measured and not kept: the plain affine in the transformed domain, B^T (s d + t m) B = s B^T d B + t (B^T r)(B^T c)^T for the
+  //  validity pattern m = r c^T -- 36 instead of 80 vector instructions per step, the same time.)
+  const __amdgpu_buffer_rsrc_t raf = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(AFF != 0 ? a.in_affine : nullptr), 0, AFF != 0 ? (unsigned)(2 * a.batch * a.c0s * 4) : 0u, 0x00020000);
+  const unsigned af_voff = (unsigned)(((b_first + (v_b < 0 ? 0 : v_b)) * a.c0s + vq * 2) * 4);
+  const unsigned af_shift = (unsigned)(a.batch * a.c0s * 4);  // the shift table sits behind the scale table
+  f32x2 af_sc = {0.f, 0.f}, af_sh = {0.f, 0.f};
+  auto affine_load = [&](int kt) __attribute__((always_inline)) {
+    if constexpr (AFF != 0) {
+      const bool kv = !TAIL || kt * XK + vq * 2 < a.c0s;  // (masked pairs hold zeros and stay zero)
+      af_sc = buf_ld2(raf, kv ? af_voff : OOB, (unsigned)(kt * XK * 4));
+      af_sh = buf_ld2(raf, kv ? af_voff : OOB, (unsigned)(kt * XK * 4) + af_shift);
+    }
+  };
   auto affine = [&]() __attribute__((always_inline)) {
     if constexpr (AFF != 0) {
-      const float* sp = a.in_affine + ((int64_t)(b_first + (v_b < 0 ? 0 : v_b)) * a.c0s + staged_kt * XK + vq * 2);
-      const bool kv = !TAIL || staged_kt * XK + vq * 2 < a.c0s;  // (masked pairs hold zeros and stay zero)
-      const f32x2 sc = kv ? *reinterpret_cast<const f32x2*>(sp) : f32x2{0.f, 0.f};
-      const f32x2 sh = kv ? *reinterpret_cast<const f32x2*>(sp + (int64_t)a.batch * a.c0s) : f32x2{0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        f32x2 v = rv[i] * sc + sh;
+        f32x2 v = rv[i] * af_sc + af_sh;
         if constexpr (AFF == 2) v = f32x2{az_silu(v.x), az_silu(v.y)};
         rv[i] = (vmask >> i) & 1u ? v : f32x2{0.f, 0.f};
       }
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
       // (the raw pixels of step ktn are staged: behind the barrier that closed phase 0; the patch is read late, when the
       //  fragment registers of this phase are mostly done)
       mf(hs, 0); piece(1, 0); XS_FENCE;
-      mf(hs, 1); remainder(0, 0, 2); XS_FENCE;
+      mf(hs, 1); affine_load(ktn); remainder(0, 0, 2); XS_FENCE;
       mf(hs, 2); remainder(0, 2, 4); XS_FENCE;
       mf(hs, 3); remainder(1, 0, 2); XS_FENCE;
       mf(hs, 4); remainder(1, 2, 4); load_u(ktu, ob, 2); XS_FENCE;  // (a2 is free: the next phase's a2)
@@ -393,6 +403,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
 #pragma unroll
     for (int m = 0; m < 6; ++m) gs(m);
     __syncthreads();
+    affine_load(kt_begin);
     patch_rows(kt_begin, 0, 4);
     affine();
 #pragma unroll
