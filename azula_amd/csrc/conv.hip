@@ -2897,7 +2897,9 @@ static int wino_prepare(const AzConvArgs* a, int wk, int64_t ustage_bytes, WinoP
     // otherwise (gt = 1, gc = cblocks).  AZ_WINO_RECT="gt,gc" overrides (A/B runs); "1,0" = cout fastest everywhere.
     int env_gt = 0, env_gc = 0;  // (read per call like the other A/B switches: no unsynchronised static)
     if (const char* e = getenv("AZ_WINO_RECT")) sscanf(e, "%d,%d", &env_gt, &env_gc);
-    int gt = env_gt > 0 ? env_gt : 8, gc = env_gt > 0 ? (env_gc > 0 ? env_gc : p.cblocks) : 4;
+    // (the x3 kernel's filter chunks are 1.5 x the fp32 stream's -- 6 B per value: two cout blocks per XCD keep a layer's chunks in its
+    //  4 MB L2 where four thrash it: 16 x 2 measured 1 - 2 % ahead of 8 x 4 on the 256- and 512-channel layers, tools/wx3_rect_ab.sh)
+    int gt = env_gt > 0 ? env_gt : 8, gc = env_gt > 0 ? (env_gc > 0 ? env_gc : p.cblocks) : (wk == 16 ? 2 : 4);
     while (gc > 1 && p.cblocks % gc) gc >>= 1;
     if (env_gt <= 0) gt = 32 / gc;
     while (gt > 1 && p.tblocks % gt) gt >>= 1;
