@@ -15,43 +15,49 @@ from azula_amd.csrc import build as B  # noqa: E402
 
 # name -> [(file, old, new), ...]; every `old` must occur exactly once
 VARIANTS = {
-    # ---- wino_x3.hip: what bounds the K loop of az_conv2d_winograd_x3_f32
-    "wx3_nogather": [("wino_x3.hip", "    for (int i = i0; i < i1; ++i) rv[i] = buf_ld2(r, TAIL && !kv ? OOB : ro[i], soff);",
-                      "    for (int i = i0; i < i1; ++i) asm volatile(\"\" : \"+v\"(rv[i]) : \"v\"(ro[i]), \"s\"(soff));")],
-    "wx3_nou": [("wino_x3.hip", "    for (int pl = 0; pl < 3; ++pl) ua[pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)(pl * 1024), soff));",
-                 "    for (int pl = 0; pl < 3; ++pl) asm volatile(\"\" : \"+v\"(ua[pl]) : \"s\"(soff));")],
-    "wx3_nomfma": [("wino_x3.hip", "    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[j][PA[t]], fb[th][PB[t]], c, 0, 0, 0);",
-                    "    asm volatile(\"\" : \"+v\"(c) : \"v\"(ua[j][PA[t]]), \"v\"(fb[th][PB[t]]));")],
-    "wx3_nostore": [("wino_x3.hip", "      for (int j = 0; j < 2; ++j) *reinterpret_cast<unsigned*>(dst + pl * X_PLANE + (2 * xi + j) * X_FREQ) = qq[2 * xi + j][pl];",
-                     "      for (int j = 0; j < 2; ++j) asm volatile(\"\" :: \"v\"(qq[2 * xi + j][pl]), \"v\"(dst));")],
-    "wx3_nofrag": [("wino_x3.hip", "    fb[0][pl] = *reinterpret_cast<const bf16x8*>(vb);\n    fb[1][pl] = *reinterpret_cast<const bf16x8*>(vb + 32 * X_ROW);",
-                    "    asm volatile(\"\" : \"+v\"(fb[0][pl]), \"+v\"(fb[1][pl]) : \"v\"(vb));")],
+    # ---- wino_x3.hip (the second form of its K loop; profiles/r05_wx3_ablation_v2.txt and r05_wx3_energy_probes.txt were measured
+    #      with the corresponding patches of the first form: git history of this file)
+    # no-load variants FREEZE operands (constant data toggles nothing in the matrix pipe): they overstate under the power cap
+    "wx3_nogather": [("wino_x3.hip", "      gq[m] = buf_ld4(r, off, (unsigned)(kc * XK * 4));",
+                      "      asm volatile(\"\" : \"+v\"(gq[m].x), \"+v\"(gq[m].y), \"+v\"(gq[m].z), \"+v\"(gq[m].w) : \"v\"(off));")],
+    "wx3_nou": [("wino_x3.hip", "    for (int ch = 0; ch < 2; ++ch) ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
+                 "    for (int ch = 0; ch < 2; ++ch) asm volatile(\"\" : \"+v\"(ua[ch][pl]) : \"s\"(soff));")],
+    "wx3_nomfma": [("wino_x3.hip", "    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[ch][PA[t]], __builtin_bit_cast(bf16x8, bw), c, 0, 0, 0);",
+                    "    asm volatile(\"\" : \"+v\"(c) : \"v\"(bw.x), \"v\"(bw.y), \"v\"(bw.z), \"v\"(bw.w));")],
+    # energy probes on RANDOM data (the kernel sits at the 1400 W cap: time = energy / cap, so a variant's time change is the
+    # energy share of what it removes, as long as the data stay random)
+    "wx3_halfmfma": [("wino_x3.hip", "    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[ch][PA[t]], __builtin_bit_cast(bf16x8, bw), c, 0, 0, 0);",
+                      "    if (t < 3) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[ch][PA[t]], __builtin_bit_cast(bf16x8, bw), c, 0, 0, 0);")],
+    "wx3_nosplit": [("wino_x3.hip", "      xf[th][i] = x - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u);",
+                     "      xf[th][i] = x;")],
+    "wx3_halfstore": [("wino_x3.hip", "    *reinterpret_cast<f32x2*>(dst + X_FREQ) = hs == 0 ? u1 + u2 : u1 - u3;",
+                       "    asm volatile(\"\" :: \"v\"(hs == 0 ? u1 + u2 : u1 - u3));")],
 }
 VARIANTS["wx3_noloads"] = VARIANTS["wx3_nogather"] + VARIANTS["wx3_nou"]
-VARIANTS["wx3_mfmaonly"] = VARIANTS["wx3_noloads"] + VARIANTS["wx3_nostore"] + VARIANTS["wx3_nofrag"]
 
 # ---- wino_x3.hip: per-wave phase timeline (s_memtime sums per workgroup, waves 0 and 4 of the first 512 workgroups):
-#      sections of a phase: [0] slots 0-11, [1] slots 12-23, [2] filter loads + wait for the LDS-DMA, [3] barrier + next fragments
+#      sections of a phase: [0] slots 0-11, [1] slots 12-23, [2] last filter loads, [3] barrier + next fragment reads
 VARIANTS["wx3_tl"] = [
     ("wino_x3.hip", "namespace {\n\ntypedef __bf16 bf16x8",
      "__device__ unsigned az_wx3_tl[512 * 2 * 12];\n"
      "extern \"C\" int az_debug_wx3_timeline(unsigned* host, int n_words) {\n"
      "  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(az_wx3_tl), (size_t)n_words * 4, 0, hipMemcpyDeviceToHost);\n}\n"
      "namespace {\n\ntypedef __bf16 bf16x8"),
-    ("wino_x3.hip", "  bf16x8 ua[2][3], fb[2][3];\n",
-     "  bf16x8 ua[2][3], fb[2][3];\n  unsigned tlacc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};\n  const unsigned long long tl_entry = __builtin_readcyclecounter();\n"),
+    ("wino_x3.hip", "  bf16x8 ua[2][3];  // [cout half][piece]\n",
+     "  bf16x8 ua[2][3];\n  unsigned tlacc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};\n  const unsigned long long tl_entry = __builtin_readcyclecounter();\n"),
     ("wino_x3.hip", "    constexpr int ob = 1 - hs;  // the buffer (and half of the frequencies) this phase produces\n",
-     "    constexpr int ob = 1 - hs;\n    const unsigned long long tl0 = __builtin_readcyclecounter();\n"),
-    ("wino_x3.hip", "    // second frequency: its B pieces 2 and 1 are in place; piece 0 and the first frequency's filter fragments behind MFMA 11\n",
-     "    const unsigned long long tl1 = __builtin_readcyclecounter();\n"),
-    ("wino_x3.hip", "    load_u(ktu, hs == 0 ? 3 : 1, ua[1]);\n    if constexpr (hs == 0) {\n",
-     "    const unsigned long long tl2 = __builtin_readcyclecounter();\n    load_u(ktu, hs == 0 ? 3 : 1, ua[1]);\n    if constexpr (hs == 0) {\n"),
-    ("wino_x3.hip", "    // the NEXT phase's first frequency: its buffer is complete behind the barrier\n    __syncthreads();\n    frag(ob, 0, 2); frag(ob, 0, 1); frag(ob, 0, 0);\n    XS_FENCE;\n",
-     "    const unsigned long long tl3 = __builtin_readcyclecounter();\n    __syncthreads();\n    frag(ob, 0, 2); frag(ob, 0, 1); frag(ob, 0, 0);\n    XS_FENCE;\n"
+     "    constexpr int ob = 1 - hs;\n    const unsigned long long tl0 = __builtin_readcyclecounter();\n    unsigned long long tl1 = tl0;\n"),
+    ("wino_x3.hip", "      mf(hs, 12); gl(ktn, 2); gl(ktn, 3); remainder(0, 2, 4); XS_FENCE;\n",
+     "      tl1 = __builtin_readcyclecounter();\n      mf(hs, 12); gl(ktn, 2); gl(ktn, 3); remainder(0, 2, 4); XS_FENCE;\n"),
+    ("wino_x3.hip", "      mf(hs, 12); patch_rows(ktn, 0, 2); XS_FENCE;\n",
+     "      tl1 = __builtin_readcyclecounter();\n      mf(hs, 12); patch_rows(ktn, 0, 2); XS_FENCE;\n"),
+    ("wino_x3.hip", "    load_u(ktu, ob, 0);\n    // the NEXT phase's fragments: its buffer is complete behind the barrier\n    __syncthreads();\n    frag_read(ob, 0); frag_read(ob, 1);\n    XS_FENCE;\n",
+     "    const unsigned long long tl2 = __builtin_readcyclecounter();\n    load_u(ktu, ob, 0);\n    const unsigned long long tl3 = __builtin_readcyclecounter();\n"
+     "    __syncthreads();\n    frag_read(ob, 0); frag_read(ob, 1);\n    XS_FENCE;\n"
      "    const unsigned long long tl4 = __builtin_readcyclecounter();\n"
      "    tlacc[hs][0] += (unsigned)(tl1 - tl0); tlacc[hs][1] += (unsigned)(tl2 - tl1); tlacc[hs][2] += (unsigned)(tl3 - tl2); tlacc[hs][3] += (unsigned)(tl4 - tl3);\n"),
-    ("wino_x3.hip", "#undef XS_FENCE\n",
-     "#undef XS_FENCE\n  const unsigned long long tl_loop = __builtin_readcyclecounter();\n"),
+    ("wino_x3.hip", "  __syncthreads();\n#undef XS_FENCE\n",
+     "  __syncthreads();\n#undef XS_FENCE\n  const unsigned long long tl_loop = __builtin_readcyclecounter();\n"),
     ("wino_x3.hip", "  if (a.gn_quads == nullptr) {\n    epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix);\n",
      "  if (a.gn_quads == nullptr) {\n    epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix);\n"
      "    if ((tid & 255) == 0 && blockIdx.x < 512 && blockIdx.y == 0) {\n"
@@ -60,26 +66,6 @@ VARIANTS["wx3_tl"] = [
      "      for (int i = 0; i < 8; ++i) o[i] = tlacc[i >> 2][i & 3];\n"
      "      o[8] = (unsigned)(tl_loop - tl_entry); o[9] = (unsigned)(__builtin_readcyclecounter() - tl_loop); o[10] = (unsigned)tl_entry; o[11] = __builtin_amdgcn_s_getreg(63492);\n"
      "    }\n"),
-]
-
-# energy probes on RANDOM data (the kernel sits at the 1400 W cap: time = energy / cap, so a variant's time change is the energy share
-# of what it removes -- as long as the data stay random; the no-load variants above freeze operands and overstate)
-VARIANTS["wx3_nosplit"] = [
-    ("wino_x3.hip", "    qq[c][0] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);\n    vv[c] = f32x2{x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u), x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u)};",
-     "    qq[c][0] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);"),
-    ("wino_x3.hip", "    qq[c][1] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);\n    const float s0 = r0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);\n    const float s1 = r1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);\n    qq[c][2] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);",
-     "    qq[c][1] = __builtin_amdgcn_perm(u0, u1, 0x05040100u);\n    qq[c][2] = qq[c][1] ^ u0;"),
-]
-VARIANTS["wx3_halffrag"] = [
-    ("wino_x3.hip", "    fb[1][pl] = *reinterpret_cast<const bf16x8*>(vb + 32 * X_ROW);", "    fb[1][pl] = fb[0][pl];"),
-]
-VARIANTS["wx3_halfstore"] = [
-    ("wino_x3.hip", "      for (int j = 0; j < 2; ++j) *reinterpret_cast<unsigned*>(dst + pl * X_PLANE + (2 * xi + j) * X_FREQ) = qq[2 * xi + j][pl];",
-     "      for (int j = 0; j < 1; ++j) *reinterpret_cast<unsigned*>(dst + pl * X_PLANE + (2 * xi + j) * X_FREQ) = qq[2 * xi + j][pl] ^ qq[2 * xi + 1][pl];"),
-]
-VARIANTS["wx3_halfmfma"] = [
-    ("wino_x3.hip", "    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[j][PA[t]], fb[th][PB[t]], c, 0, 0, 0);",
-     "    if (t < 3) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[j][PA[t]], fb[th][PB[t]], c, 0, 0, 0);"),
 ]
 
 # ---- the ablations / A-B switches that lived in the product sources as -D macros until round 4 (conv.hip, attention.hip)
