@@ -343,18 +343,22 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
       mf(hs, 5); remainder(0, 0, 2); XS_FENCE;
       mf(hs, 6); remainder(0, 2, 4); XS_FENCE;
       mf(hs, 7); remainder(1, 0, 2); XS_FENCE;
-      mf(hs, 8); gl(ktn, 0); gl(ktn, 1); remainder(1, 2, 4); XS_FENCE;
-      mf(hs, 9); gl(ktn, 2); gl(ktn, 3); piece(0, 1); XS_FENCE;
-      mf(hs, 10); gl(ktn, 4); gl(ktn, 5); piece(1, 1); XS_FENCE;
-      mf(hs, 11); remainder(0, 0, 2); XS_FENCE;
-      mf(hs, 12); remainder(0, 2, 4); XS_FENCE;
-      mf(hs, 13); remainder(1, 0, 2); XS_FENCE;
-      mf(hs, 14); remainder(1, 2, 4); gs(0); XS_FENCE;
-      mf(hs, 15); piece(0, 2); piece(1, 2); gs(1); XS_FENCE;
-      mf(hs, 16); load_u(ktu, ob, 1); gs(2); XS_FENCE;  // (a1 is free)
-      mf(hs, 17); gs(3); XS_FENCE;
-      mf(hs, 18); gs(4); XS_FENCE;
-      mf(hs, 19); gs(5); XS_FENCE;
+      mf(hs, 8); remainder(1, 2, 4); XS_FENCE;
+      mf(hs, 9); piece(0, 1); XS_FENCE;
+      mf(hs, 10); piece(1, 1); XS_FENCE;
+      mf(hs, 11); gl(ktn, 0); gl(ktn, 1); remainder(0, 0, 2); XS_FENCE;
+      mf(hs, 12); gl(ktn, 2); gl(ktn, 3); remainder(0, 2, 4); XS_FENCE;
+      mf(hs, 13); gl(ktn, 4); gl(ktn, 5); remainder(1, 0, 2); XS_FENCE;
+      mf(hs, 14); remainder(1, 2, 4); XS_FENCE;
+      mf(hs, 15); piece(0, 2); piece(1, 2); XS_FENCE;
+      mf(hs, 16); load_u(ktu, ob, 1); XS_FENCE;  // (a1 is free)
+      mf(hs, 17); gs(0); XS_FENCE;
+      mf(hs, 18); gs(1); XS_FENCE;
+      mf(hs, 19); gs(2); XS_FENCE;
+      mf(hs, 20); gs(3); XS_FENCE;
+      mf(hs, 21); gs(4); XS_FENCE;
+      mf(hs, 22); gs(5); XS_FENCE;
+      mf(hs, 23);
     } else {
       // (the raw pixels of step ktn are staged: behind the barrier that closed phase 0; the patch is read late, when the
       //  fragment registers of this phase are mostly done)
@@ -372,31 +376,33 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
       mf(hs, 11); piece(0, 2); piece(1, 2); XS_FENCE;
       mf(hs, 12); patch_rows(ktn, 0, 2); XS_FENCE;
       mf(hs, 13); patch_rows(ktn, 2, 4); XS_FENCE;
+      mf(hs, 14); XS_FENCE;
+      mf(hs, 15); XS_FENCE;
+      mf(hs, 16); load_u(ktu, ob, 1); XS_FENCE;  // (a1 is free)
       affine();
-      mf(hs, 14); row_transform(0); row_transform(1); XS_FENCE;
-      mf(hs, 15); row_transform(2); row_transform(3); XS_FENCE;
-      mf(hs, 16); load_u(ktu, ob, 1); nu_store(ob, 0); XS_FENCE;  // (a1 is free)
-      mf(hs, 17); nu_store(ob, 1); XS_FENCE;
-      mf(hs, 18); nu_store(ob, 2); XS_FENCE;
-      mf(hs, 19); nu_store(ob, 3); XS_FENCE;
+      mf(hs, 17); row_transform(0); row_transform(1); XS_FENCE;
+      mf(hs, 18); row_transform(2); row_transform(3); XS_FENCE;
+      mf(hs, 19); nu_store(ob, 0); XS_FENCE;
+      mf(hs, 20); nu_store(ob, 1); XS_FENCE;
+      mf(hs, 21); nu_store(ob, 2); XS_FENCE;
+      mf(hs, 22); nu_store(ob, 3); XS_FENCE;
+      mf(hs, 23);
     }
-    // the NEXT phase's fragments: its buffer is complete behind the barrier; the phase's last four products (pieces in registers)
-    // are issued behind it, so that the LDS round trip of the fragment reads is not exposed at the head of the next phase
+    load_u(ktu, ob, 0);
+    // the NEXT phase's fragments: its buffer is complete behind the barrier.  (Measured and not kept -- profiles/r05_wx3_sched_ab.txt:
+    // the barrier AHEAD of the last four products, to cover the LDS round trip of these reads with matrix work, and the producer
+    // side three slots earlier: + 3.5 % cycles, a wave then waits with products unissued.)
     __syncthreads();
-    frag_read(ob, 0); frag_read(ob, 1); XS_FENCE;
-    mf(hs, 20); XS_FENCE;
-    mf(hs, 21); XS_FENCE;
-    mf(hs, 22); XS_FENCE;
-    mf(hs, 23); load_u(ktu, ob, 0);
+    frag_read(ob, 0); frag_read(ob, 1);
     XS_FENCE;
   };
 
   if (kt_begin < kt_end) {
 #pragma unroll
     for (int m = 0; m < 6; ++m) gl(kt_begin, m);
-    // (piece 2 first: the order in which the loop keeps its filter loads in flight -- the wait counts the compiler derives at the
-    //  loop header are the stricter of the entry's and the back edge's, and with the pieces in ascending order the entry made the
-    //  first products of every step wait for ALL outstanding filter loads)
+    // (piece 2 first, fenced: the order in which the loop keeps its filter loads in flight.  The wait counts the compiler derives
+    //  at the loop header are the stricter of the entry's and the back edge's; with the pieces in ascending order the entry made
+    //  the first two products of EVERY step wait for all outstanding filter loads -- vmcnt(2) / vmcnt(0) instead of 5 / 4)
     XS_FENCE; load_u(kt_begin, 0, 2); XS_FENCE; load_u(kt_begin, 0, 1); XS_FENCE; load_u(kt_begin, 0, 0); XS_FENCE;
 #pragma unroll
     for (int m = 0; m < 6; ++m) gs(m);
