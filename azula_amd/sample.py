@@ -222,15 +222,17 @@ class Sampler(abc.ABC):
     def _device_kernel_wide(self, x_t: Tensor, mean: Tensor, alpha_t, alpha_s, k_x, k_eps, draw: bool) -> Tensor:
         r"""The same update in fp64 (``az_transition_f64``): fp64 latents, or an fp64 posterior mean -- what a
         ``Sampler(dtype=float64)`` produces from its first step on (the reference's promotion, ``azula/sample.py:257-259``).
-        The noise is drawn in ``x_t``'s own dtype, like the reference's ``randn_like(x_t)``."""
+        The noise is drawn in ``x_t``'s own dtype, like the reference's ``randn_like(x_t)`` (``_noise_like_update``: in the
+        updated state's, fp64)."""
         dev = x_t.device
         row = torch.zeros(12, dtype=torch.float64, device=dev)
         names = ["c_in", "c_skip", "c_out", "c_time", "alpha_t", "alpha_s", "k_x", "k_eps", "c_in_next", "clip_lo", "clip_hi", "guidance"]
         vals = {"c_out": 1.0, "alpha_t": alpha_t, "alpha_s": alpha_s, "k_x": k_x, "k_eps": k_eps, "clip_lo": -math.inf, "clip_hi": math.inf}
         for name, v in vals.items():
             row[names.index(name)] = v.to(device=dev, dtype=torch.float64) if torch.is_tensor(v) else v
-        eps = self._draw_noise(x_t.contiguous()).to(torch.float64) if draw else None
         x64, m64 = x_t.to(torch.float64).contiguous(), mean.to(torch.float64).contiguous()
+        # (the Ito step draws randn_like(x_s), which the fp64 scalars have promoted already: azula/sample.py:427-429)
+        eps = self._draw_noise(x64 if self._noise_like_update else x_t.contiguous()).to(torch.float64) if draw else None
         x_s = torch.empty_like(x64)
         a = transition_args(x_t=x64.data_ptr(), F=m64.data_ptr(), eps=eps.data_ptr() if draw else 0, x_s=x_s.data_ptr(), batch=1,
                             channels=1, inner=x64.numel(), f_channels=1, coef=row.data_ptr())
@@ -249,30 +251,39 @@ class Sampler(abc.ABC):
         # samplers whose step is one evaluation + one transition
         return self._wide_fusable(x)
 
+    # True: the step's randn_like takes the UPDATED state (already fp64 under an fp64 clock) as its model, not x_t (ItoSampler)
+    _noise_like_update = False
+
     def _wide_fusable(self, x: Tensor) -> bool:
-        return (self.dtype == torch.float64 and x.dtype in (torch.float32, torch.float64) and type(self).__name__ in ("DDPMSampler", "DDIMSampler")
-                and type(self)._fused_step_tapes is Sampler._fused_step_tapes and WIDE_FUSED)
+        r"""The one-evaluation samplers (DDPM, DDIM, Euler, Ito) and the two whose tapes are built from the loop's own blocks
+        (Heun, PC); the multistep family keeps its per-statement fp64 loop (``_MultistepSampler._call_wide``)."""
+        tapes = (Sampler._fused_step_tapes, HeunSampler._fused_step_tapes, PCSampler._fused_step_tapes)
+        return (self.dtype == torch.float64 and x.dtype in (torch.float32, torch.float64) and WIDE_FUSED
+                and type(self)._fused_step_tapes in tapes)
 
     def _host_table_wide(self, fused: "FusedDenoiser") -> Tensor:
-        r"""(steps, 24) fp64: per step the denoiser's row [c_in, c_skip, c_out, c_time, ...] and the transition's row
+        r"""(steps * evaluations per step, 24) fp64: per evaluation the denoiser's row [c_in, c_skip, c_out, c_time, ...] and the transition's row
         [.., c_skip = 0, c_out = 1, alpha_t, alpha_s, k_x, k_eps, .., clip_lo = -inf, clip_hi = inf, ..] in the field order of
         ``az_transition_f64``'s coefficient row -- the 0-d host scalars of the fp64 time grid, in the reference's op order."""
         names = ["c_in", "c_skip", "c_out", "c_time", "alpha_t", "alpha_s", "k_x", "k_eps", "c_in_next", "clip_lo", "clip_hi", "guidance"]
         ts = torch.linspace(self.start, self.stop, self.steps + 1, dtype=self.dtype)
         out = []
+        f64 = lambda v: v.to(torch.float64) if torch.is_tensor(v) else float(v)  # noqa: E731
         for t, s in ts.unfold(0, 2, 1).unbind():
-            (spec,) = self._fused_rows(t, s, fused)
-            row = torch.zeros(24, dtype=torch.float64)
-            co = fused.coefficients(spec["alpha"], spec["sigma"])
-            for n in ("c_in", "c_skip", "c_out", "c_time"):
-                row[names.index(n)] = co[n].to(torch.float64)
-            row[names.index("clip_lo")], row[names.index("clip_hi")] = -math.inf, math.inf
-            b = 12
-            row[b + names.index("c_out")] = 1.0
-            row[b + names.index("alpha_t")], row[b + names.index("alpha_s")] = spec["a_t"].to(torch.float64), spec["a_s"].to(torch.float64)
-            row[b + names.index("k_x")], row[b + names.index("k_eps")] = spec["k_x"].to(torch.float64), spec["k_eps"].to(torch.float64)
-            row[b + names.index("clip_lo")], row[b + names.index("clip_hi")] = -math.inf, math.inf
-            out.append(row)
+            for spec in self._fused_rows(t, s, fused):  # one row per denoiser evaluation, like _host_table
+                row = torch.zeros(24, dtype=torch.float64)
+                co = fused.coefficients(spec["alpha"], spec["sigma"])
+                for n in ("c_in", "c_skip", "c_out", "c_time"):
+                    row[names.index(n)] = co[n].to(torch.float64)
+                # (words 4, 5 of the denoiser half are free: the two spare coefficients of a row, HeunSampler's p and q)
+                row[4], row[5] = f64(spec.get("pad0", 0.0)), f64(spec.get("pad1", 0.0))
+                row[names.index("clip_lo")], row[names.index("clip_hi")] = -math.inf, math.inf
+                b = 12
+                row[b + names.index("c_out")] = 1.0
+                row[b + names.index("alpha_t")], row[b + names.index("alpha_s")] = f64(spec["a_t"]), f64(spec["a_s"])
+                row[b + names.index("k_x")], row[b + names.index("k_eps")] = f64(spec["k_x"]), f64(spec["k_eps"])
+                row[b + names.index("clip_lo")], row[b + names.index("clip_hi")] = -math.inf, math.inf
+                out.append(row)
         return torch.stack(out)
 
     # -- what a step looks like inside the captured graph ----------------------------------------------------------
@@ -519,6 +530,10 @@ class _FusedLoop:
         else:
             tape.add(*args)
 
+    def add_spare_axpby(self, tape: Tape, y: Tensor, x: Tensor, z: Tensor) -> None:
+        r"""y = p x + q z with the current row's two spare coefficients (``pad0``, ``pad1`` of ``Sampler._fused_rows``)."""
+        tape.add("az_axpby_f32", y.data_ptr(), self.coef_ptr(14), x.data_ptr(), self.coef_ptr(15), z.data_ptr(), 1, x.numel(), 0)
+
     def coef_ptr(self, name_or_word) -> int:
         r"""Device address of one float of the current row (``cur``): kernels that take coefficient POINTERS read the
         step's value through it, so the captured graph needs no per-step update."""
@@ -599,7 +614,7 @@ class _FusedLoopWide(_FusedLoop):
         self.table64 = torch.zeros(n_rows, self.WORDS, dtype=torch.float64, device=dev)
         self.mean64 = torch.empty(x.shape, dtype=torch.float64, device=dev)
         super().__init__(sampler, fused, torch.empty(x.shape, dtype=torch.float64, device=dev), cur)
-        n32 = len(self.noise) if x.dtype == torch.float32 else 0
+        n32 = min(1, len(self.noise)) if x.dtype == torch.float32 else 0
         self.noise32 = [torch.empty(x.shape, dtype=torch.float32, device=dev) for _ in range(n32)]
         self.dummy32 = torch.empty(x.shape, dtype=torch.float32, device=dev) if (self.dummy is not None and x.dtype == torch.float32) else None
 
@@ -608,20 +623,30 @@ class _FusedLoopWide(_FusedLoop):
         return self.cur64.data_ptr() + 8 * (names.index(name) + (12 if second else 0))
 
     def add_evaluation(self, tape: Tape) -> None:
+        r"""The evaluation reads the state the previous transition of the tape wrote (``x`` at the head of a step): the fp32
+        loop's transition kernel leaves the pre-scaled backbone input behind, here it is a pass of its own."""
         p0 = self.fused.programs[0]
+        src = getattr(self, "_src", None)
+        src = self.x if src is None else src
         tape.add("az_step_begin", self.cur.data_ptr(), self.table.data_ptr(), self.counter.data_ptr(), self.n_rows)
         tape.add("az_step_row_f64", self.cur64.data_ptr(), self.table64.data_ptr(), self.counter.data_ptr(), self.n_rows, self.WORDS)
-        tape.add("az_scale_f64_to_f32", p0.x_in.data_ptr(), self.x.data_ptr(), self._c64("c_in"), 1, self.x.numel(), 0)
+        tape.add("az_scale_f64_to_f32", p0.x_in.data_ptr(), src.data_ptr(), self._c64("c_in"), 1, src.numel(), 0)
         tape.extend(p0.tape)
 
     def add_transition(self, tape: Tape, *, x_t: Tensor, x_s: Tensor, eps: Tensor | None = None, mean_out: Tensor | None = None,
                        write_xin: bool = True) -> None:
         p0 = self.fused.programs[0]
         n = x_t.numel()
-        tape.add("az_axpby_f64", self.mean64.data_ptr(), self._c64("c_skip"), x_t.data_ptr(), self._c64("c_out"), p0.out.data_ptr(), 1, 1, n, 0)
-        a = transition_args(x_t=x_t.data_ptr(), F=self.mean64.data_ptr(), eps=eps.data_ptr() if eps is not None else None,
+        mean = self.mean64 if mean_out is None else mean_out  # (Heun keeps the first evaluation's posterior mean)
+        tape.add("az_axpby_f64", mean.data_ptr(), self._c64("c_skip"), x_t.data_ptr(), self._c64("c_out"), p0.out.data_ptr(), 1, 1, n, 0)
+        a = transition_args(x_t=x_t.data_ptr(), F=mean.data_ptr(), eps=eps.data_ptr() if eps is not None else None,
                             x_s=x_s.data_ptr(), batch=1, channels=1, inner=n, f_channels=1, coef=self.cur64.data_ptr() + 8 * 12)
         tape.add("az_transition_f64", C.byref(a), keep=[a])
+        self._src = x_s
+
+    def add_spare_axpby(self, tape: Tape, y: Tensor, x: Tensor, z: Tensor) -> None:
+        tape.add("az_axpby_f64", y.data_ptr(), self.cur64.data_ptr() + 8 * 4, x.data_ptr(), self.cur64.data_ptr() + 8 * 5, z.data_ptr(), 0, 1,
+                 x.numel(), 0)
 
     def _upload_table(self, kwargs: dict) -> None:
         before = self.table_key
@@ -636,9 +661,11 @@ class _FusedLoopWide(_FusedLoop):
         self.counter.zero_()
         stream = _lib.stream_ptr()
         for g in s.progress_bar(range(s.steps)):
-            first32 = g == 0 and self.in_dtype == torch.float32
+            # (randn_like(x_t): fp32 only for the FIRST draw of an fp32 input -- the update it feeds promotes the state; a
+            #  sampler whose draw is modelled on the updated state never draws fp32)
+            first32 = g == 0 and self.in_dtype == torch.float32 and not s._noise_like_update
             for k, buf in enumerate(self.noise):
-                if first32:
+                if first32 and k == 0:
                     s._draw_noise(self.noise32[k], out=self.noise32[k])
                     buf.copy_(self.noise32[k])
                 else:
@@ -783,8 +810,7 @@ class HeunSampler(EulerSampler):
         loop.add_evaluation(tape)
         loop.add_transition(tape, x_t=loop.x, x_s=xp, mean_out=m)  # x_p (+ the backbone input c_in(s) x_p), m_t
         loop.add_evaluation(tape)
-        tape.add("az_axpby_f32", e.data_ptr(), loop.coef_ptr(14), loop.x.data_ptr(), loop.coef_ptr(15), m.data_ptr(), 1,
-                 loop.x.numel(), 0)
+        loop.add_spare_axpby(tape, e, loop.x, m)
         loop.add_transition(tape, x_t=xp, x_s=loop.x, eps=e)
         return [tape]
 
@@ -819,6 +845,8 @@ class ItoSampler(Sampler):
         self.denoiser = denoiser
         self.eta = eta
         self.temperature = temperature
+
+    _noise_like_update = True  # randn_like(x_s), reference azula/sample.py:427-429
 
     def _ito(self, alpha_t, sigma_t, alpha_s, sigma_s):
         k = (1 + self.eta**2) / self.temperature * (sigma_s / sigma_t - alpha_s / alpha_t)

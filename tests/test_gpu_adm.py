@@ -33,7 +33,7 @@ def test_adm_backbone_matches_reference(golden, name):
     out = den.backbone(g["x"].cuda(), g["idx"].cuda(), y=y)
     err, sc = max_err(out, g["out"]), g["out"].abs().max().item()
     print(name, "backbone max|d|", err, "scale", sc)
-    assert err < 2e-5 * max(1.0, sc)  # measured 3.8e-6 / 2.7e-6 on scale 2.9 / 2.1 (MI355X, round 2)
+    assert err < 7e-6 * max(1.0, sc)  # measured 3.6e-6 / 2.7e-6 on scale 2.9 / 2.1 (MI355X, round 5): bound = 5.6 x
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -81,7 +81,7 @@ def test_adm_ddpm8_device_rng_matches_oracle(golden):
     ref = sampling.sample(omean, g["x1"], schedule=lambda t: sampling.vp_schedule(t, 1e-2, 1e-2), steps=8, eta=None, eps_list=eps)
     err = max_err(x0, ref)
     print("ADM DDPM-8 max|d| vs oracle", err)
-    assert err < 1e-4
+    assert err < 6e-5  # measured 1.2e-5: bound = 5 x
 
 
 def _adm_oracle(g, sd, cfg):
@@ -158,7 +158,7 @@ def test_cfg_ddim16_fused_and_generic(golden):
     # t = 1 the ADM preconditioning has c_out = -100, so last-ulp scalar differences are amplified
     print("CFG generic vs fused", max_err(x0g, x0), "generic vs reference", max_err(x0g, g["cfg_ddim16"]))
     # measured 5.5e-5 .. 3.5e-4 (with AZ_STEM_PLANAR=0) / 1.1e-4 .. 2.0e-4: two roundings of the same chaotic amplification
-    assert max_err(x0g, x0) < 6e-4 and max_err(x0g, g["cfg_ddim16"]) < 1e-3
+    assert max_err(x0g, x0) < 6e-4 and max_err(x0g, g["cfg_ddim16"]) < 4e-4  # (generic vs reference: measured 7.7e-5)
     # schedule passes through the wrapper (reference cfg.py:31-33)
     assert cfgden.schedule is den.schedule
 
@@ -180,7 +180,7 @@ def test_adm_options_outside_the_cards(golden, name):
     assert next(iter(smp._fused_cache.values())).graph is not None
     e2 = max_err(x0, g["ddim8"])
     print(name, "backbone max|d|", err, "scale", sc, "DDIM-8", e2, "scale", g["ddim8"].abs().max().item())
-    assert err < 2e-5 * max(1.0, sc)  # measured 2.3e-6 .. 2.6e-6 on scale 2.2 .. 2.7
+    assert err < 5e-6 * max(1.0, sc)  # measured 2.1e-6 .. 2.5e-6 on scale 2.2 .. 2.7: bound = 5 x
     assert e2 < 2.5e-4  # measured 2.8e-5 .. 5.0e-5 (means clipped to +-1, c_out = -100 at t = 1)
 
 
@@ -204,8 +204,8 @@ def test_adm_on_one_dimensional_signals(golden, name):
     assert next(iter(smp._fused_cache.values())).graph is not None  # the captured loop, not the generic one
     e2 = max_err(x0, g["ddim8"])
     print(name, "backbone max|d|", err, "scale", sc, "DDIM-8", e2, "scale", g["ddim8"].abs().max().item())
-    assert err < 2e-5 * max(1.0, sc)
-    assert e2 < 2.5e-4
+    assert err < 7e-6 * max(1.0, sc)  # measured 2.0e-6 .. 2.8e-6 on scale 1.6 .. 2.0
+    assert e2 < 1.4e-4  # measured 2.8e-6 .. 2.7e-5
     # the posterior (generic call path) on the same signal
     post = den(g["x1"].cuda(), torch.tensor(0.5, device="cuda"), **kw)
     assert post.mean.shape == g["x1"].shape and torch.isfinite(post.mean).all()
@@ -232,7 +232,7 @@ def test_adm_fractional_timesteps(golden, name):
     out1 = net(g[name + "_x"].cuda(), torch.tensor([417.75], device="cuda"), y=y)
     e1 = max_err(out1, g[name + "_out_shared"])
     print(name, "fractional timesteps max|d|", e, e1, "scale", sc)
-    assert e < 2e-5 * sc and e1 < 2e-5 * sc
+    assert e < 7e-6 * sc and e1 < 7e-6 * sc  # measured 3.2e-6 .. 3.8e-6 on scale 2.4 .. 2.8: bound = 5 x
     # the integer path still takes the table
     ops = [n for _, _, n in net.plan(2, g[name + "_x"].shape[2], g[name + "_x"].shape[3], 2, torch.device("cuda", 0)).tape.ops]
     assert "az_timestep_embedding_f32" not in ops

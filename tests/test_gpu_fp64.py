@@ -93,6 +93,78 @@ def test_fp64_clock_runs_as_a_captured_loop(golden, in_dtype, monkeypatch):
         assert e < 2e-5 * sc
 
 
+@pytest.mark.parametrize("in_dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("which", ["euler", "heun", "ito", "pc"])
+def test_fp64_clock_captured_loop_of_the_other_samplers(golden, which, in_dtype, monkeypatch):
+    """Euler / Ito (one evaluation per step), Heun (two evaluations, the first posterior mean kept, the spare-coefficient axpby in
+    fp64) and PC (corrections + 1 evaluations, one noise buffer per corrector move) with ``dtype=float64``: the captured fp64 loop
+    against the per-statement fp64 loop -- the same integrator with the same generator draws (the first randn_like(x_t) of an
+    fp32 input is fp32, every later one fp64; Ito's randn_like(x_s) is fp64 from the start, azula/sample.py:427-429).  Euler /
+    Heun fold their coefficients in the captured form, so equality is to fp64 round-off, not to the bit."""
+    from azula_amd import sample as S
+
+    g = golden("g11_sampler_dtype")
+    den = unet_denoiser(g)
+    x1 = g["unet_x1"].cuda().to(in_dtype)
+    make = {
+        "euler": lambda: S.EulerSampler(den, steps=6, silent=True, dtype=torch.float64),
+        "heun": lambda: S.HeunSampler(den, steps=4, silent=True, dtype=torch.float64),
+        "ito": lambda: S.ItoSampler(den, steps=5, eta=0.7, silent=True, dtype=torch.float64),
+        "pc": lambda: S.PCSampler(den, steps=3, corrections=2, silent=True, dtype=torch.float64),
+    }[which]
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(S, "WIDE_FUSED", fused)
+        smp = make()
+        torch.manual_seed(31)
+        outs[fused] = smp(x1)
+        if fused:
+            loop = next(iter(smp._fused_cache.values()))
+            assert isinstance(loop, S._FusedLoopWide) and loop.graphs[1].num_nodes >= len(loop.tape)
+            torch.manual_seed(31)
+            assert torch.equal(smp(x1), outs[True])  # replay of the captured graph
+        else:
+            assert not smp._fused_cache
+    sc = max(1.0, outs[False].abs().max().item())
+    e = max_err(outs[True], outs[False])
+    print(which, in_dtype, "captured vs per-statement fp64 loop: max|d|", e, "scale", sc)
+    assert outs[True].dtype == torch.float64 and e < 1e-10 * sc
+    if in_dtype == torch.float32 and which == "heun":
+        assert max_err(outs[True], g["unet_heun4"]) < 2e-5 * max(1.0, g["unet_heun4"].abs().max().item())
+    if in_dtype == torch.float64 and which == "euler":
+        assert max_err(outs[True], g["unet_euler6_x64"]) < 2e-5 * max(1.0, g["unet_euler6_x64"].abs().max().item())
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_ito_with_an_fp64_clock_draws_its_noise_in_fp64(golden, fused, monkeypatch):
+    """ItoSampler's noise is randn_like(x_s) (azula/sample.py:427-429): with fp64 schedule scalars x_s is fp64 before the draw, also
+    in the first step of an fp32 input -- one step against the update written out with an fp64 draw from the same seed."""
+    from azula_amd import sample as S
+
+    monkeypatch.setattr(S, "WIDE_FUSED", fused)
+    g = golden("g11_sampler_dtype")
+    den = unet_denoiser(g)
+    x1 = g["unet_x1"].cuda()
+    smp = S.ItoSampler(den, steps=1, start=0.9, stop=0.5, eta=1.0, silent=True, dtype=torch.float64)
+    torch.manual_seed(5)
+    out = smp(x1)
+    torch.manual_seed(5)
+    eps = torch.randn(x1.shape, dtype=torch.float64, device="cuda")
+    t, s = torch.tensor(0.9, dtype=torch.float64), torch.tensor(0.5, dtype=torch.float64)
+    a_t, s_t = den.schedule(t)
+    a_s, s_s = den.schedule(s)
+    mean = den(x1, t).mean
+    r, k, k_eps = smp._ito(a_t, s_t, a_s, s_s)
+    ref = r.item() * x1.double() + k.item() * (x1.double() - a_t.item() * mean.double()) + k_eps.item() * eps
+    sc = max(1.0, ref.abs().max().item())
+    print("Ito, one fp64 step from an fp32 state (fused =", fused, "): max|d|", max_err(out, ref))
+    assert out.dtype == torch.float64 and max_err(out, ref) < 1e-5 * sc  # (two evaluations of the fp32 backbone agree to its round-off)
+    wrong = r.item() * x1.double() + k.item() * (x1.double() - a_t.item() * mean.double())
+    torch.manual_seed(5)
+    wrong = wrong + k_eps.item() * torch.randn_like(x1).double()
+    assert max_err(out, wrong) > 1e-2  # an fp32 draw from the same seed is a different sample
+
+
 def test_fp64_elementwise_kernels_bit_exact():
     """az_axpby_f64 / az_scale_f64_to_f32 / az_transition_f64 against torch's fp64 CPU ops, op for op."""
     import ctypes as C

@@ -51,7 +51,7 @@ def test_winograd_equals_direct_on_the_real_shapes(c2, monkeypatch):
     net._plans.clear()
     scale = direct.abs().max().item()
     print("full-size mean: Winograd vs direct max|d|", max_err(fast, direct), "scale", scale)
-    assert max_err(fast, direct) < 2e-5 * max(1.0, scale)
+    assert max_err(fast, direct) < 5e-6 * max(1.0, scale)  # measured 1.0e-6 on scale 1.25 (MI355X, round 5): bound = 5 x
 
 
 def test_batch_of_4_equals_two_batches_of_2(c2):
@@ -64,7 +64,7 @@ def test_batch_of_4_equals_two_batches_of_2(c2):
     halves = torch.cat([DDIMSampler(den, steps=STEPS, silent=True)(x1[i : i + 2]) for i in (0, 2)])
     scale = full.abs().max().item()
     print("batch 4 vs 2 + 2 max|d|", max_err(full, halves), "scale", scale)
-    assert max_err(full, halves) < 5e-5 * max(1.0, scale)
+    assert max_err(full, halves) < 1e-6 * max(1.0, scale)  # measured 4.2e-7 on scale 2.5 (other split-K choices at batch 2): bound = 6 x
 
 
 def test_ddim_eta1_equals_ddpm_and_fused_equals_generic(c2):
@@ -85,7 +85,7 @@ def test_ddim_eta1_equals_ddpm_and_fused_equals_generic(c2):
     fused = DDIMSampler(den, steps=STEPS, silent=True)(x1)
     generic = Generic(den, steps=STEPS, silent=True)(x1)
     print("fused vs generic max|d|", max_err(fused, generic), "scale", fused.abs().max().item())
-    assert max_err(fused, generic) < 5e-5 * max(1.0, fused.abs().max().item())
+    assert max_err(fused, generic) < 1e-6 * max(1.0, fused.abs().max().item())  # measured 4.8e-7 on scale 2.5: bound = 5 x
 
 
 def test_dit_b2_full_size_properties():
@@ -104,7 +104,7 @@ def test_dit_b2_full_size_properties():
     halves = torch.cat([DDIMSampler(den, steps=STEPS, silent=True)(x1[i : i + 32]) for i in (0, 32)])
     scale = max(1.0, full.abs().max().item())
     print("DiT-B/2 batch 64 vs 32 + 32 max|d|", max_err(full, halves), "scale", scale)
-    assert max_err(full, halves) < 5e-5 * scale
+    assert max_err(full, halves) < 1.5e-6 * scale  # measured 7.2e-7 on scale 2.7: bound = 5.6 x
 
 
 def test_adm_256_cfg_full_size_properties():
@@ -127,12 +127,12 @@ def test_adm_256_cfg_full_size_properties():
     print("ADM-256 CFG(g=0) vs conditional max|d|", max_err(g0, ref), "scale", scale)
     # the guided run evaluates both label sets as ONE 2B batch (other tile / split-K choices than the batch-B plan);
     # ADM's c_out = -100 at t = 1 amplifies those fp32 round-off differences: the ADM trajectory bound applies
-    assert max_err(g0, ref) < 1e-3 * scale
+    assert max_err(g0, ref) < 9e-4 * scale  # measured 1.8e-4: bound = 5 x
     one = DDIMSampler(plain, steps=STEPS, silent=True)(x1[1:], label=lab[1:])
     # a batch of 1 takes other split-K / tile choices; ADM's c_out = -sigma/alpha = -100 at t = 1 amplifies the fp32
     # round-off differences of the backbone (the same 1e-3 bound as the ADM trajectory tests)
     print("ADM-256 batch 2 vs 1 max|d|", max_err(ref[1:], one))
-    assert max_err(ref[1:], one) < 1e-3 * scale
+    assert max_err(ref[1:], one) < 7.5e-4 * scale  # measured 1.5e-4: bound = 5 x
 
 
 def test_adm_256_cfg_at_baseline_batch_32():
@@ -158,14 +158,14 @@ def test_adm_256_cfg_at_baseline_batch_32():
     assert ent.graph is not None and len(ent.fused.programs) == 2
     scale = max(1.0, ref.abs().max().item())
     print("ADM-256 batch 32: CFG(g=0) vs conditional max|d|", max_err(g0, ref), "scale", scale)
-    assert max_err(g0, ref) < 1e-3 * scale
+    assert max_err(g0, ref) < 1e-3 * scale  # measured 2.1e-4: bound = 4.7 x
     g2 = smp(x1, guidance=2.0, **kw)
     assert torch.equal(g2, smp(x1, guidance=2.0, **kw)) and not torch.equal(g2, g0)
     del smp, ent
     torch.cuda.empty_cache()
     halves = torch.cat([DDIMSampler(plain, steps=steps, silent=True)(x1[i : i + 16], label=lab[i : i + 16]) for i in (0, 16)])
     print("ADM-256 batch 32 vs 16 + 16 max|d|", max_err(ref, halves))
-    assert max_err(ref, halves) < 1e-3 * scale
+    assert max_err(ref, halves) < 1e-3 * scale  # measured 2.0e-4: bound = 4.9 x
 
 
 def test_adm_256_ddpm_at_the_c4_shard_of_32():
@@ -191,7 +191,7 @@ def test_adm_256_ddpm_at_the_c4_shard_of_32():
     b = DDIMSampler(den, eta=1.0, steps=steps, silent=True)(x1)
     scale = max(1.0, a.abs().max().item())
     print("ADM-256 DDPM vs DDIM(eta=1), batch 32: max|d|", max_err(a, b), "scale", scale)
-    assert max_err(a, b) < 1e-4 * scale
+    assert max_err(a, b) < 1e-6 * scale  # measured 0.0: the same kernels on the same table values
     # rank 1 of a world of 2 over a global batch of 64: draws 64 x noise per step, keeps rows 32..63
     torch.manual_seed(3)
     big = DDPMSampler(den, steps=steps, silent=True)
@@ -204,7 +204,7 @@ def test_adm_256_ddpm_at_the_c4_shard_of_32():
     mine = smp(x64[32:])
     smp.shard = None
     print("ADM-256 shard (rank 1 of 2) vs rows 32..63 of the batch-64 run: max|d|", max_err(mine, full[32:]))
-    assert max_err(mine, full[32:]) < 1e-3 * scale
+    assert max_err(mine, full[32:]) < 1e-3 * scale  # measured 2.2e-4 (batch 32 vs batch 64 plans): bound = 4.5 x
 
 
 def test_odd_image_size_through_both_conv_paths(monkeypatch):
@@ -228,7 +228,7 @@ def test_odd_image_size_through_both_conv_paths(monkeypatch):
     net._plans.clear()
     scale = max(1.0, direct.abs().max().item())
     print("odd-size UNet: Winograd vs direct max|d|", max_err(fast, direct), "scale", scale)
-    assert fast.shape == (2, 3, 250, 190) and max_err(fast, direct) < 2e-5 * scale
+    assert fast.shape == (2, 3, 250, 190) and max_err(fast, direct) < 2.5e-6 * scale  # measured 5.2e-7: bound = 5 x
 
 
 @pytest.mark.parametrize("H,Cin,Cout", [(256, 256, 256), (64, 512, 512), (16, 1024, 1024)])
@@ -254,7 +254,7 @@ def test_real_layer_shapes_against_torch_cpu(H, Cin, Cout, algo):
     out = y.buf[: Cout * H * H].view(H, H, Cout).permute(2, 0, 1)[None]
     err = max_err(out, ref)
     print(algo, H, Cin, "max|d|", err, "scale", ref.abs().max().item())
-    assert err < 1e-5 * max(1.0, ref.abs().max().item())
+    assert err < 1e-5 * max(1.0, ref.abs().max().item())  # measured: Winograd 4.5e-6, direct 1.24e-5 on scale 6.9 (bound 6.9e-5 = 5.6 x the direct kernel's)
 
 
 @pytest.mark.parametrize("algo", ["winograd", "direct"])

@@ -130,7 +130,7 @@ def test_adm_256_widths_against_the_oracle(adm_net):
           f"(|x0| <= {ref_x0.abs().max().item():.2f}, c_out = -100 at t = 1)")
     assert e0 < 1.5e-5  # measured 3.0e-6 on scale 2.3
     assert e1 < 4e-5  # measured 7.9e-6
-    assert e2 < 1e-3  # measured 1.9e-4
+    assert e2 < 7.5e-4  # measured 1.5e-4 .. 1.9e-4
 
 
 def test_adm_256_widths_ddpm_against_the_oracle(adm_net):
@@ -195,8 +195,8 @@ def test_dit_b2_full_width_against_the_oracle(dit_b2, k16, monkeypatch):
     print(f"DiT-B/2 full width, K16={k16}: mean max|d| {e1:.3e} (scale {sc:.2f}); DDIM-3 max|d| {e2:.3e} "
           f"(scale {ref_x0.abs().max().item():.2f})")
     net._plans.clear()
-    assert e1 < 1e-5 * sc
-    assert e2 < 1e-5 * max(1.0, ref_x0.abs().max().item())
+    assert e1 < 2e-6 * sc  # measured 7.2e-7 on scale 1.88: bound = 5 x
+    assert e2 < 1.5e-6 * max(1.0, ref_x0.abs().max().item())  # measured 8.0e-7 on scale 2.65: bound = 5 x
 
 
 @pytest.mark.parametrize("k16", k16_modes())
@@ -219,10 +219,10 @@ def test_jit_b16_full_width_against_the_oracle(k16, monkeypatch):
     sc = max(1.0, ref.abs().max().item())
     e = max_err(out, ref)
     print(f"JiT-B/16 full width, K16={k16}: backbone max|d| {e:.3e} (scale {sc:.2f})")
-    assert e < 2e-5 * sc
+    assert e < 3.3e-6 * sc  # measured 3.0e-6 on scale 4.57 = 6.5e-7 relative: bound = 5 x
     bb = lambda a, c, lab: nets.jit_forward(sd, {"model": cfg["model"], "input_size": 256}, a, c, lab)  # noqa: E731
     ref_mean = sampling.jit_mean(bb, x, torch.tensor(0.4), y)
     mean = den(x.cuda(), torch.tensor(0.4, device="cuda"), label=y.cuda()).mean
     e = max_err(mean, ref_mean)
     print(f"JiT-B/16 full width, K16={k16}: posterior mean max|d| {e:.3e} (scale {ref_mean.abs().max().item():.2f})")
-    assert e < 2e-5 * max(1.0, ref_mean.abs().max().item())
+    assert e < 3.3e-6 * max(1.0, ref_mean.abs().max().item())  # measured 2.9e-6 on scale 4.56: bound = 5 x
