@@ -564,14 +564,20 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
 // Layout and fragment maps are attention_half_kernel's with three planes per operand: K [piece][key][D + 8], V^T
 // [piece][d][key position] (keys permuted to the order the S^T registers hold them), q pieces and probability pieces in
 // registers; norms, gains, RoPE, the online softmax (scores in log2 units, hardware exp2) stay fp32 as in attention_kernel.
-template <int D>
-__global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 as3_s4;
+template <int D, int NW>  // NW = waves (32 queries each) per workgroup: 4, or 8 where the grid still fills the chip (the K / V tile is split and staged once per workgroup)
+__global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {
+  constexpr int NT = 64 * NW;
   constexpr int DP = (D + 31) / 32 * 32;
   constexpr int DT = DP / 32;
   constexpr int KS = D / 16;        // K-steps of the QK^T contraction
   constexpr int KLS = D + 8;        // K tile row stride (2-byte elements)
-  constexpr int VLS = KT + 8;       // V^T tile row stride
-  constexpr int KPL = KT * KLS, VPL = DP * VLS;  // elements per piece plane
+  // V tile: ROW-major [key][VLS] like K, consumed through ds_read_b64_tr_b16 (the hardware's 4 x 4 transpose of 16-bit elements
+  // inside a 16-lane group: lane i supplies the address of 4 channels of key i / 4 and receives channel i of 4 keys).  Row stride
+  // = +-16 dwords (mod 64): the 4 keys x 2 channel blocks that a 32-lane half reads in one access fall on eight distinct bank octets
+  constexpr int VLS = DP == 32 ? 32 : DP == 128 ? 160 : 96;
+  constexpr int KPL = KT * KLS, VPL = KT * VLS;  // elements per piece plane
   __shared__ __attribute__((aligned(16))) unsigned short xsm[3 * (KPL + VPL)];
   unsigned short* Ks = xsm;
   unsigned short* Vt = xsm + 3 * KPL;
@@ -585,7 +591,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
   const int b = bh / a.heads;
   const int hd = bh - b * a.heads;
   const int T = a.tokens;
-  const int qi = blockIdx.x * QT + wave * 32 + ql;
+  const int qi = blockIdx.x * (32 * NW) + wave * 32 + ql;
 
   const float* qp = a.q + (int64_t)b * a.q_bstride + (int64_t)hd * a.q_hstride;
   const float* kp = a.k + (int64_t)b * a.k_bstride + (int64_t)hd * a.k_hstride;
@@ -598,12 +604,11 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
   constexpr int CH = D / 4;
   constexpr bool POW2 = (CH & (CH - 1)) == 0;
   constexpr int RW = 64 / CH;
-  constexpr int RPP = POW2 ? 256 / CH : 4 * RW;
+  constexpr int RPP = POW2 ? NT / CH : NW * RW;
   const int lc = POW2 ? tid % CH : lane % CH;
   const int lr = POW2 ? tid / CH : wave * RW + lane / CH;
   const bool lactive = POW2 || lane < RW * CH;
   constexpr int NPS = (KT + RPP - 1) / RPP;
-  constexpr bool VT4 = POW2 && CH <= 16;  // a wave holds >= 4 consecutive rows of a chunk: V^T goes out in 8-byte stores
   float4 pk[NPS], pv[NPS];  // raw rows of the NEXT tile, in flight under the current tile's MFMAs
   auto fetch = [&](int k0) {
 #pragma unroll
@@ -620,9 +625,9 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
   };
   fetch(0);
 
-  // zero V^T once: rows d >= D (padding of the last 32-wide output tile) are never written again
+  // zero V once: channels d >= D (padding of the last 32-wide output tile) are never written again
   if (D < DP)
-    for (int e = tid; e < 3 * VPL / 2; e += 256) reinterpret_cast<unsigned*>(Vt)[e] = 0u;
+    for (int e = tid; e < 3 * VPL / 2; e += NT) reinterpret_cast<unsigned*>(Vt)[e] = 0u;
 
   // ---- Q fragments: lane holds q[qi][16 ks + 8 h2 + (0..7)], scaled to log2 units (and RMS-normalised, gained, rotated) in
   // fp32, then split: qf[piece][ks]
@@ -733,37 +738,10 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
         az_split3(kv.z, kv.w, k3[0][1], k3[1][1], k3[2][1]);
         az_split3(vv.x, vv.y, v3[0][0], v3[1][0], v3[2][0]);
         az_split3(vv.z, vv.w, v3[0][1], v3[1][1], v3[2][1]);
-        // V^T, keys permuted inside their 32-key tile to the order the S^T registers hold them
-        const int kk = row & 31;
-        const int r = (kk & 3) + 4 * (kk >> 3);
-        const int pos = (row & ~31) + 16 * (r >> 3) + 8 * ((kk >> 2) & 1) + (r & 7);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
           *reinterpret_cast<uint2*>(Ks + pl * KPL + row * KLS + lc * 4) = make_uint2(k3[pl][0], k3[pl][1]);
-          if constexpr (VT4) {
-            // 4 x 4 transpose among the four lanes that hold rows 4m .. 4m+3 of this chunk (lane ^ CH, lane ^ 2 CH): the lane of
-            // row 4m + j ends with channel lc*4 + j of the four keys, whose positions are contiguous -- one 8-byte store
-            // instead of four scattered 2-byte ones (measured 112 -> 94 us without the scattered stores, 64 x 12 heads x 256 tokens)
-            const bool b0 = (lr & 1) != 0, b1 = (lr & 2) != 0;
-            const unsigned w0 = v3[pl][0], w1 = v3[pl][1];           // (d1:d0), (d3:d2) of this lane's key
-            const unsigned got1 = __shfl_xor(b1 ? w0 : w1, 2 * CH, 64);
-            const unsigned A = b1 ? got1 : w0, B = b1 ? w1 : got1;   // channel pair b1 of keys b0 and 2 + b0
-            const unsigned lo = __builtin_amdgcn_perm(B, A, 0x05040100u), hi = __builtin_amdgcn_perm(B, A, 0x07060302u);  // (B.e : A.e)
-            const unsigned mine = b0 ? hi : lo;                      // element b0 of the pair: channel 2 b1 + b0
-            const unsigned got2 = __shfl_xor(b0 ? lo : hi, CH, 64);  // the partner's keys 1 - b0 and 3 - b0, same channel
-            const unsigned ha = b0 ? mine : got2, la = b0 ? got2 : mine;
-            const unsigned o0 = __builtin_amdgcn_perm(ha, la, 0x05040100u);  // (key 1 : key 0)
-            const unsigned o1 = __builtin_amdgcn_perm(ha, la, 0x07060302u);  // (key 3 : key 2)
-            const int kk4 = row & 28, m = kk4 >> 2;
-            const int pos4 = (row & ~31) + 16 * (m >> 2) + 8 * (m & 1) + 4 * ((m >> 1) & 1);
-            *reinterpret_cast<uint2*>(Vt + pl * VPL + (lc * 4 + (lr & 3)) * VLS + pos4) = make_uint2(o0, o1);
-          } else {
-            unsigned short* vt = Vt + pl * VPL + (lc * 4) * VLS + pos;
-            vt[0] = (unsigned short)(v3[pl][0] & 0xFFFFu);
-            vt[VLS] = (unsigned short)(v3[pl][0] >> 16);
-            vt[2 * VLS] = (unsigned short)(v3[pl][1] & 0xFFFFu);
-            vt[3 * VLS] = (unsigned short)(v3[pl][1] >> 16);
-          }
+          *reinterpret_cast<uint2*>(Vt + pl * VPL + row * VLS + lc * 4) = make_uint2(v3[pl][0], v3[pl][1]);
         }
       }
     }
@@ -805,9 +783,24 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
 #pragma unroll
       for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sacc[r]);
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float m_new = fmaxf(m_run, mt);
-      const float m_sub = m_new == -INFINITY ? 0.f : m_new;  // (-inf only while every key so far is masked: all terms 2^-inf = 0)
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_sub);
+      // LAZY running maximum: the reference point m_run of a query moves only when the tile's maximum exceeds it by more than
+      // 2^8 (scores are in log2 units), so the probabilities are at most 256 instead of at most 1 -- the same relative accuracy
+      // in fp32, exact splits either way, the final O / l unchanged -- and the rescale of the 32 output accumulators (vector
+      // instructions that do not overlap with the matrix pipe) runs in the first tile and after a genuine jump only:
+      // wave-uniform branch, the lanes that stay put rescale by exactly 1
+      const bool jump = mt > m_run + 8.f;  // (first tile: m_run = -inf; a fully masked tile: mt = -inf, no jump)
+      if (__builtin_amdgcn_ballot_w64(jump) != 0ull) {
+        const float m_new = jump ? mt : m_run;
+        const float m_sub_new = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_sub_new);  // (-inf - finite -> 0; equal -> 1)
+        l_run *= alpha;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+      }
+      const float m_sub = m_run == -INFINITY ? 0.f : m_run;  // (-inf only while every key so far is masked: all terms 2^-inf = 0)
       float ls = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -816,12 +809,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
         ls += pe;
       }
       ls += __shfl_xor(ls, 32, 64);
-      l_run = l_run * alpha + ls;
-      m_run = m_new;
-#pragma unroll
-      for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+      l_run += ls;
       // ---- O^T += V^T P^T: B = the pieces of the lane's probabilities (registers 8 s2 .. 8 s2 + 7 = one fragment), A = V^T pieces
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -833,10 +821,17 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(AzAttnArgs a) {
         for (int pl = 0; pl < 3; ++pl) pb[pl] = __builtin_bit_cast(abf16x8, make_uint4(p3[pl][0], p3[pl][1], p3[pl][2], p3[pl][3]));
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
+          // A = V^T: k slots 0 .. 3 = keys 16 s2 + 4 h2 + (0 .. 3), slots 4 .. 7 = the same + 8 (the order the S^T registers 8 s2 ..
+          // 8 s2 + 7 hold them): two transpose reads of 4 keys x 16 channels per 16-lane group
           abf16x8 va[3];
+          const unsigned short* vr = Vt + (sub * 32 + 16 * s2 + 4 * h2 + ((lane & 15) >> 2)) * VLS + 32 * t + (lane & 16) + 4 * (lane & 3);
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            va[pl] = *reinterpret_cast<const abf16x8*>(Vt + pl * VPL + (ql + 32 * t) * VLS + sub * 32 + 16 * s2 + 8 * h2);
+          for (int pl = 0; pl < 3; ++pl) {
+            const as3_s4* pa = (const as3_s4*)(vr + pl * VPL);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<as3_s4*>(pa));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<as3_s4*>(pa) + 2 * VLS);  // (+ 8 keys: 8 VLS elements = 2 VLS vectors of 4)
+            va[pl] = __builtin_bit_cast(abf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
 #pragma unroll
           for (int u = 0; u < 6; ++u) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[u]], pb[PB[u]], oacc[t], 0, 0, 0);
         }
@@ -996,15 +991,25 @@ int az_attention_x3_f32(const AzAttnArgs* a, az_stream_t stream) {
   const int64_t strides[] = {a->q_bstride, a->q_tstride, a->q_hstride, a->k_bstride, a->k_tstride, a->k_hstride,
                              a->v_bstride, a->v_tstride, a->v_hstride, a->o_bstride, a->o_tstride, a->o_hstride};
   for (int64_t s : strides) AZ_REQUIRE(s % 4 == 0, AZ_E_ALIGN);
-  dim3 grid((unsigned)((a->tokens + QT - 1) / QT), (unsigned)(a->batch * a->heads));
   hipStream_t st = az_s(stream);
+  // 256 queries per workgroup (8 waves) halve the splitting / staging of K and V per query; taken where whole 256-query blocks
+  // still make two rounds of the 256 CUs (one 8-wave workgroup is resident per CU).  Measured (us, 4 / 8 waves): 64 x 12 heads x
+  // 256 tokens 111 / 104; smaller grids lose: 4 x 8 x 1024 82 / 90, 4 x 16 x 256 22 / 26; 288 tokens (not whole blocks) 95 / 104
+  const int64_t bh = (int64_t)a->batch * a->heads;
+  const bool wide = a->head_dim <= 80 && a->tokens % 256 == 0 && bh * (a->tokens / 256) >= 512;
+  const int qt = wide ? 256 : QT;
+  dim3 grid((unsigned)((a->tokens + qt - 1) / qt), (unsigned)bh);
+#define AZ_ATT_X3(DD)                                                                                         \
+  if (wide) hipLaunchKernelGGL((attention_x3_kernel<DD, 8>), grid, dim3(512), 0, st, *a);                     \
+  else hipLaunchKernelGGL((attention_x3_kernel<DD, 4>), grid, dim3(256), 0, st, *a)
   switch (a->head_dim) {
-    case 16: hipLaunchKernelGGL(attention_x3_kernel<16>, grid, dim3(256), 0, st, *a); break;
-    case 32: hipLaunchKernelGGL(attention_x3_kernel<32>, grid, dim3(256), 0, st, *a); break;
-    case 64: hipLaunchKernelGGL(attention_x3_kernel<64>, grid, dim3(256), 0, st, *a); break;
-    case 80: hipLaunchKernelGGL(attention_x3_kernel<80>, grid, dim3(256), 0, st, *a); break;
-    default: hipLaunchKernelGGL(attention_x3_kernel<128>, grid, dim3(256), 0, st, *a); break;
+    case 16: AZ_ATT_X3(16); break;
+    case 32: AZ_ATT_X3(32); break;
+    case 64: AZ_ATT_X3(64); break;
+    case 80: AZ_ATT_X3(80); break;
+    default: hipLaunchKernelGGL((attention_x3_kernel<128, 4>), grid, dim3(256), 0, st, *a); break;
   }
+#undef AZ_ATT_X3
   return az_launch_status();
 }
 

@@ -3,6 +3,8 @@ azula_amd/csrc (textual substitutions listed below; results of such a library ar
 
     python tools/ablate.py NAME [NAME ...]     ->  azula_amd/csrc/_ab/libazula_amd_NAME.so   (select with AZULA_AMD_LIB=<path>)
     python tools/ablate.py --list
+    python tools/ablate.py --head FILE [FILE ...]   ->  .../_ab/libazula_amd_head.so: the named sources as committed at HEAD, the
+                                                        rest from the working tree (A/B of an uncommitted kernel change)
 """
 import os
 import shutil
@@ -33,6 +35,8 @@ VARIANTS = {
     "wx3_halfstore": [("wino_x3.hip", "    *reinterpret_cast<f32x2*>(dst + X_FREQ) = hs == 0 ? u1 + u2 : u1 - u3;",
                        "    asm volatile(\"\" :: \"v\"(hs == 0 ? u1 + u2 : u1 - u3));")],
 }
+# attention_x3_kernel: the running maximum updated (and the accumulators rescaled) in every tile, as before the lazy form
+VARIANTS["att_eager"] = [("attention.hip", "      const bool jump = mt > m_run + 8.f;", "      const bool jump = mt > m_run;")]
 VARIANTS["wx3_noloads"] = VARIANTS["wx3_nogather"] + VARIANTS["wx3_nou"]
 
 # ---- wino_x3.hip: per-wave phase timeline (s_memtime sums per workgroup, waves 0 and 4 of the first 512 workgroups):
@@ -93,7 +97,7 @@ VARIANTS["ax_novt"] = [("attention.hip", "          if constexpr (VT4) {\n      
                        ("attention.hip", "            unsigned short* vt = Vt + pl * VPL + (lc * 4) * VLS + pos;\n            vt[0] = (unsigned short)(v3[pl][0] & 0xFFFFu);", "            unsigned short* vt = Vt + pl * VPL + (lc * 4) * VLS + pos;\n            if (false) vt[0] = (unsigned short)(v3[pl][0] & 0xFFFFu);")]
 
 
-def build(name: str, patches=None, regen_env=None) -> str:
+def build(name: str, patches=None, regen_env=None, head_files=None) -> str:
     r"""`patches`: a substitution list instead of VARIANTS[name]; `regen_env`: generator overrides (KL_* / KG_*) -- the copy's
     wino_kloop.inc / igemm_kloop.inc are regenerated with them (tools/kloop_variant.py)."""
     out_dir = os.path.join(B.HERE, "_ab")
@@ -111,7 +115,10 @@ def build(name: str, patches=None, regen_env=None) -> str:
         for gen, inc in (("gen_wino_kloop.py", "wino_kloop.inc"), ("gen_igemm_kloop.py", "igemm_kloop.inc")):
             subprocess.run([sys.executable, os.path.join(B.HERE, gen), "--out", os.path.join(src_dir, inc)], check=True, env=env, stdout=subprocess.DEVNULL)
         touched.add("conv.hip")
-    for f, old, new in (VARIANTS[name] if patches is None else patches):
+    for f in (head_files or ()):
+        open(os.path.join(src_dir, f), "w").write(subprocess.run(["git", "show", "HEAD:azula_amd/csrc/" + f], check=True, capture_output=True, text=True, cwd=ROOT).stdout)
+        touched.add(f)
+    for f, old, new in (() if head_files else VARIANTS[name] if patches is None else patches):
         path = os.path.join(src_dir, f)
         text = open(path).read()
         assert text.count(old) == 1, f"{name}: pattern occurs {text.count(old)} times in {f}: {old[:60]!r}"
@@ -136,6 +143,9 @@ def build(name: str, patches=None, regen_env=None) -> str:
 if __name__ == "__main__":
     if sys.argv[1:] == ["--list"]:
         print("\n".join(VARIANTS))
+    elif sys.argv[1:2] == ["--head"]:
+        B.build()
+        print(build("head", head_files=sys.argv[2:]))
     else:
         B.build()
         for n in sys.argv[1:]:
