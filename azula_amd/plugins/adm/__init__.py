@@ -155,6 +155,7 @@ class AblatedDenoiser(Denoiser):
         if not isinstance(bb, unet.UNetModel) or x.ndim != bb.dims + 2 or get_module_dtype(bb) not in (torch.float32, torch.float16, torch.bfloat16):
             return None
         B, (H, W) = x.shape[0], _map_size(x)
+        D = x.shape[2] if x.ndim == 5 else 1
         if len(kwargs_list) == 2 and bb.num_classes is not None and os.environ.get("AZ_CFG_BATCHED", "1") != "0":
             batched = self._az_cfg_batched(x, kwargs_list, cur_coef)
             if batched is not None:
@@ -167,7 +168,7 @@ class AblatedDenoiser(Denoiser):
             if (label is not None) != (bb.num_classes is not None):
                 return None
             rows = B if bb.num_classes is not None else 1
-            plan = bb.plan(B, H, W, rows, x.device, x_in=x_in, coef_ptr=cur_coef.data_ptr(), tag=i)
+            plan = bb.plan(B, H, W, rows, x.device, x_in=x_in, coef_ptr=cur_coef.data_ptr(), tag=i, D=D)
             x_in = plan.x_in
 
             def prepare(call_kwargs: dict, plan=plan, key=i) -> None:
@@ -196,8 +197,9 @@ class AblatedDenoiser(Denoiser):
         if any(set(kw) - {"label"} or kw.get("label") is None for kw in kwargs_list):
             return None
         B, (H, W) = x.shape[0], _map_size(x)
-        plan = bb.plan(2 * B, H, W, 2 * B, x.device, coef_ptr=cur_coef.data_ptr(), tag="cfg2b")
-        half_in = B * H * W * (plan.x_in.cs if plan.x_in.cs > 0 else plan.x_in.C)  # (channel stride 0: the planar latent layout)
+        D = x.shape[2] if x.ndim == 5 else 1
+        plan = bb.plan(2 * B, H, W, 2 * B, x.device, coef_ptr=cur_coef.data_ptr(), tag="cfg2b", D=D)
+        half_in = B * D * H * W * (plan.x_in.cs if plan.x_in.cs > 0 else plan.x_in.C)  # (channel stride 0: the planar latent layout)
         one = torch.ones(1, dtype=torch.float32, device=x.device)
         tape = Tape()
         tape.add("az_scale_f32", plan.x_in.ptr + 4 * half_in, plan.x_in.ptr, one.data_ptr(), half_in, keep=[one, plan])
@@ -224,7 +226,7 @@ class AblatedDenoiser(Denoiser):
 
 def _map_size(x: Tensor) -> tuple[int, int]:
     r"""(H, W) of the feature map a latent is run as: a (B, C, L) signal (``dims=1``) is a one-row image."""
-    return (1, x.shape[2]) if x.ndim == 3 else (x.shape[2], x.shape[3])
+    return (1, x.shape[2]) if x.ndim == 3 else (x.shape[-2], x.shape[-1])
 
 
 def load_model(name: str, **kwargs) -> Denoiser:

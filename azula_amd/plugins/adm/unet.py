@@ -35,7 +35,7 @@ from ...engine import Act, Builder, pad4
 __all__ = ["UNetModel"]
 
 
-_CONV = {1: nn.Conv1d, 2: nn.Conv2d}  # conv_nd, reference _src/nn.py:50-61 (3-D signals are not built)
+_CONV = {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}  # conv_nd, reference _src/nn.py:50-61
 
 
 def _zero(m: nn.Module) -> nn.Module:
@@ -71,10 +71,10 @@ class Downsample(nn.Module):
         super().__init__()
         self.channels, self.out_channels, self.use_conv = channels, out_channels or channels, use_conv
         if use_conv:
-            self.op = _CONV[dims](channels, self.out_channels, 3, stride=2, padding=1)
+            self.op = _CONV[dims](channels, self.out_channels, 3, stride=2 if dims != 3 else (1, 2, 2), padding=1)
         else:
             assert self.channels == self.out_channels
-            self.op = nn.AvgPool1d(2, 2) if dims == 1 else nn.AvgPool2d(2, 2)
+            self.op = nn.AvgPool1d(2, 2) if dims == 1 else nn.AvgPool2d(2, 2) if dims == 2 else nn.AvgPool3d((1, 2, 2), (1, 2, 2))
 
 
 class Upsample(nn.Module):
@@ -123,7 +123,7 @@ class ADMPlan:
     share the timestep and there are no labels, else the batch size."""
 
     def __init__(self, net: "UNetModel", B: int, H: int, W: int, emb_rows: int, device, x_in: Act | None = None,
-                 coef_ptr: int | None = None, frac: bool = False) -> None:
+                 coef_ptr: int | None = None, frac: bool = False, D: int = 1) -> None:
         bld = self.bld = Builder(device, half=next(net.parameters()).dtype)
         mc, E = net.model_channels, 4 * net.model_channels
         self.versions = net._param_versions()
@@ -131,6 +131,14 @@ class ADMPlan:
         cin = net.in_channels
         one_d = net.dims == 1  # (B, C, L) signals: H = 1, every resampling acts along the width alone
         assert not one_d or H == 1
+        # dims = 3: a (B, C, D, H, W) volume is B * D channel-padded NHWC planes -- every `Act` below has batch PB = B * D.  The
+        # depth axis is never resampled (_src/unet.py:103-104,128: Upsample / Downsample act on the inner two axes), so a
+        # Conv3d is the sum over its depth taps of 2-D convolutions of depth-shifted planes (AzConvArgs.depth, one launch per
+        # tap accumulating through the residual operand, as nn/unet3d.py), the norms and elementwise passes see a sample as
+        # one (D H) x W image (`vol`), the attention blocks as D H W tokens.
+        three_d = net.dims == 3
+        assert three_d or D == 1
+        PB = B * D
         up2 = (0, 1) if one_d else 1  # log2 of the nearest upsampling per axis
         down2 = (1, 2) if one_d else 2  # stride per axis
         pool2 = 2 if one_d else 1  # az_affine_act_f32's pooling mode: 1x2 or 2x2
@@ -148,17 +156,54 @@ class ADMPlan:
         def halved(a: Act) -> tuple[int, int]:
             return (a.H, a.W // 2) if one_d else (a.H // 2, a.W // 2)
 
+        def vol(a: Act | None) -> Act | None:
+            r"""The B samples of a plane stack as (D H) x W images (same memory); the producing convolution's GroupNorm
+            partials, one set per plane, are D sets per sample."""
+            if a is None or not three_d:
+                return a
+            v = Act(a.buf, B, D * a.H, a.W, a.C, a.cs, True)
+            if a.gn_quads is not None:
+                v.gn_quads = (a.gn_quads[0], D * a.gn_quads[1])
+            return v
+
+        def planes(a: Act) -> Act:
+            r"""Inverse of `vol` for a pass's result (pooled or not): B (D H') x W' images -> B D planes of H' x W'."""
+            if not three_d:
+                return a
+            return Act(a.buf, PB, a.H // D, a.W, a.C, a.cs, a.pinned)
+
+        def group_norm(x: Act, *args, x1: Act | None = None, **kw) -> Act:
+            return planes(bld.group_norm(vol(x), *args, x1=vol(x1), **kw))
+
+        def conv(src: Act, layer, cout: int, *, cin0=None, **kw) -> Act | None:
+            r"""conv_nd layer on `src` (| kw["src1"] concatenated).  Conv3d with three depth taps: the centre tap first (it exists for
+            every plane; bias, residual), the others accumulate in place; the moments for a following GroupNorm come from the last."""
+            w = layer.weight
+            if not (three_d and w.ndim == 5 and w.shape[2] > 1):
+                if w.ndim == 5:  # 1 x 1 x 1
+                    return bld.conv(src, bld.pack_conv(w[:, :, 0], layer.bias, cin0=cin0), cout, **kw)
+                return bld.conv(src, packed(layer, cin0=cin0), cout, **kw)
+            assert w.shape[2] == 3
+            gn_stats, dst = kw.pop("gn_stats", False), kw.pop("dst_nchw", None)
+            assert dst is None
+            res, res_up = kw.pop("res", None), kw.pop("res_up", 0)
+            out = bld.conv(src, bld.pack_conv(w[:, :, 1], layer.bias, cin0=cin0), cout, res=res, res_up=res_up, depth=(D, 0), **kw)
+            for n_, j in enumerate((0, 2)):
+                bld.conv(src, bld.pack_conv(w[:, :, j], None, cin0=cin0), cout, res=out, out=out, depth=(D, j - 1),
+                         gn_stats=gn_stats and n_ == 1, **kw)
+            return out
+
         c_first = net.input_blocks[0][0]
         # the first convolution reads the latent PLANAR (x_in = the loop's own (B, C, H, W) layout, channel stride 0): Builder.conv_stem
-        self.planar = (engine.STEM_PLANAR and cin <= 4 and isinstance(c_first, (nn.Conv1d, nn.Conv2d)) and c_first.weight.shape[-1] == 3
+        self.planar = (engine.STEM_PLANAR and cin <= 4 and not three_d and isinstance(c_first, (nn.Conv1d, nn.Conv2d)) and c_first.weight.shape[-1] == 3
                        and c_first.out_channels % 4 == 0 and bld.half is None and (x_in is None or x_in.cs == 0))
         if x_in is not None:
             self.x_in = x_in
         elif self.planar:
             self.x_in = Act(torch.empty(B * cin * H * W, dtype=torch.float32, device=device), B, H, W, cin, 0, True)
         else:
-            self.x_in = Act(torch.empty(B * H * W * pad4(cin), dtype=torch.float32, device=device), B, H, W, cin, pad4(cin), True)
-        self.out = torch.empty(B, net.out_channels, H, W, dtype=torch.float32, device=device)
+            self.x_in = Act(torch.empty(PB * H * W * pad4(cin), dtype=torch.float32, device=device), PB, H, W, cin, pad4(cin), True)
+        self.out = torch.empty((B, net.out_channels) + ((D,) if three_d else ()) + (H, W), dtype=torch.float32, device=device)
         self.table = bld.const(timestep_embedding_table(net.table_steps, mc))
         self.t_idx = torch.zeros(emb_rows, dtype=torch.int64, device=device)
         self.labels = torch.zeros(B, dtype=torch.int64, device=device) if net.num_classes is not None else None
@@ -216,79 +261,79 @@ class ADMPlan:
             film_jobs.append((film, bld.const(w), bld.const(b_), nf * ocs))
             fbs = nf * ocs if emb_rows > 1 else 0
             # h = conv(updown(SiLU(GN(x))))
-            n1 = bld.group_norm(x, 32, weight=bld.const(gi.weight), bias=bld.const(gi.bias), act=1, pool=pool2 if rb.down else 0, x1=x1)
-            h = bld.conv(n1, packed(ci), oc, up0=up2 if rb.up else 0, winograd=wino,
-                         gn_stats=rb.use_scale_shift_norm)  # -> out_layers' GroupNorm
+            n1 = group_norm(x, 32, weight=bld.const(gi.weight), bias=bld.const(gi.bias), act=1, pool=pool2 if rb.down else 0, x1=x1)
+            h = conv(n1, ci, oc, up0=up2 if rb.up else 0, winograd=wino,
+                     gn_stats=rb.use_scale_shift_norm)  # -> out_layers' GroupNorm
             bld.free(n1)
             if rb.use_scale_shift_norm:  # h = SiLU(GN(h) * (1 + scale) + shift)
-                n2 = bld.group_norm(h, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), scale=film, shift=film,
-                                    scale_off=0, shift_off=ocs, bstride=fbs, act=1)
+                n2 = group_norm(h, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), scale=film, shift=film,
+                                scale_off=0, shift_off=ocs, bstride=fbs, act=1)
             else:  # h = SiLU(GN(h + emb_out)), _src/unet.py:244-246: the statistics are those of the SUM -> one more pass
                 eb = film
                 if emb_rows == 1 and B > 1:  # the pass wants one row per sample
                     eb = bld.empty(B, ocs)
                     bld.tape.add("az_gather_rows_f32", eb.data_ptr(), film.data_ptr(),
                                  row0.data_ptr(), B, ocs, 1)
-                he = bld.new_act(B, h.H, h.W, oc)
+                he = bld.new_act(PB, h.H, h.W, oc)
                 bld.tape.add("az_affine_act_f32", he.ptr, h.ptr, None, 0, bld.const(torch.ones(B * ocs)).data_ptr(),
-                             eb.data_ptr(), B, h.H, h.W, ocs, 0, 0)
-                n2 = bld.group_norm(he, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), act=1)
+                             eb.data_ptr(), B, D * h.H, h.W, ocs, 0, 0)
+                n2 = group_norm(he, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), act=1)
                 bld.free(he)
             bld.free(h)
             # skip path
             if rb.down:
                 assert x1 is None
                 ones, zeros = bld.const(torch.ones(B * x.cs)), bld.const(torch.zeros(B * x.cs))
-                xs = bld.new_act(B, *halved(x), x.C)
-                bld.tape.add("az_affine_act_f32", xs.ptr, x.ptr, None, 0, ones.data_ptr(), zeros.data_ptr(), B, x.H, x.W, x.cs, 0, pool2)
-                out = bld.conv(n2, packed(co), oc, res=xs, gn_stats=True, winograd=wino)
+                xs = bld.new_act(PB, *halved(x), x.C)
+                bld.tape.add("az_affine_act_f32", xs.ptr, x.ptr, None, 0, ones.data_ptr(), zeros.data_ptr(), B, D * x.H, x.W, x.cs, 0, pool2)
+                out = conv(n2, co, oc, res=xs, gn_stats=True, winograd=wino)
                 bld.free(xs)
             elif rb.up:
                 assert x1 is None
-                out = bld.conv(n2, packed(co), oc, res=x, res_up=1, gn_stats=True, winograd=wino)  # (one row: oh >> 1 = 0)
+                out = conv(n2, co, oc, res=x, res_up=1, gn_stats=True, winograd=wino)  # (one row: oh >> 1 = 0)
             elif isinstance(rb.skip_connection, nn.Identity):
                 assert x1 is None
-                out = bld.conv(n2, packed(co), oc, res=x, gn_stats=True, winograd=wino)
+                out = conv(n2, co, oc, res=x, gn_stats=True, winograd=wino)
             else:
                 sc = rb.skip_connection
-                skip = bld.conv(x, packed(sc, cin0=x.C if x1 is not None else None), oc, src1=x1)
-                out = bld.conv(n2, packed(co), oc, res=skip, gn_stats=True, winograd=wino)
+                skip = conv(x, sc, oc, cin0=x.C if x1 is not None else None, src1=x1)
+                out = conv(n2, co, oc, res=skip, gn_stats=True, winograd=wino)
                 bld.free(skip)
             bld.free(n2)
             return out
 
         def attention(ab: AttentionBlock, x: Act) -> Act:
             Cc = ab.channels
-            n_ = bld.group_norm(x, 32, weight=bld.const(ab.norm.weight), bias=bld.const(ab.norm.bias))
-            tok = Act(n_.buf, B, n_.H * n_.W, 1, Cc, n_.cs, True)
+            n_ = group_norm(x, 32, weight=bld.const(ab.norm.weight), bias=bld.const(ab.norm.bias))
+            tok = Act(n_.buf, B, D * n_.H * n_.W, 1, Cc, n_.cs, True)
             qkv = bld.conv(tok, bld.pack_conv(ab.qkv.weight, ab.qkv.bias), 3 * Cc)
             ch = Cc // ab.num_heads
             att = bld.attention(qkv, ab.num_heads, "3HC" if ab.new_order else "H3C", False, 1.0 / math.sqrt(ch))
             bld.free(qkv)
-            xt = Act(x.buf, B, x.H * x.W, 1, Cc, x.cs, True)
+            xt = Act(x.buf, B, D * x.H * x.W, 1, Cc, x.cs, True)
             o = bld.conv(att, bld.pack_conv(ab.proj_out.weight, ab.proj_out.bias), Cc, res=xt)
             bld.free(att)
             bld.free(n_)
-            return Act(o.buf, B, x.H, x.W, Cc, o.cs)
+            return Act(o.buf, PB, x.H, x.W, Cc, o.cs)
 
         def run(block: nn.Sequential, h: Act, h1: Act | None = None) -> Act:
             for layer in block:
                 if isinstance(layer, (nn.Conv1d, nn.Conv2d)) and h is self.x_in and self.planar:
                     nh = bld.conv_stem(h.buf, B, cin, H, W, packed(layer), layer.out_channels, gn_stats=True)
-                elif isinstance(layer, (nn.Conv1d, nn.Conv2d)):
-                    nh = bld.conv(h, packed(layer), layer.out_channels, gn_stats=True, winograd=wino)
+                elif isinstance(layer, (nn.Conv1d, nn.Conv2d, nn.Conv3d)):
+                    nh = conv(h, layer, layer.out_channels, gn_stats=True, winograd=wino)
                 elif isinstance(layer, ResBlock):
                     nh = resblock(layer, h, h1)
                 elif isinstance(layer, Downsample):
                     if layer.use_conv:
-                        nh = bld.conv(h, packed(layer.op), layer.out_channels, stride=down2)
+                        nh = conv(h, layer.op, layer.out_channels, stride=down2)
                     else:  # AvgPoolNd(2, 2): the pooling form of the elementwise pass with S = 1, T = 0
-                        nh = bld.new_act(B, *halved(h), h.C)
+                        nh = bld.new_act(PB, *halved(h), h.C)
                         bld.tape.add("az_affine_act_f32", nh.ptr, h.ptr, None, 0, bld.const(torch.ones(B * h.cs)).data_ptr(),
-                                     bld.const(torch.zeros(B * h.cs)).data_ptr(), B, h.H, h.W, h.cs, 0, pool2)
+                                     bld.const(torch.zeros(B * h.cs)).data_ptr(), B, D * h.H, h.W, h.cs, 0, pool2)
                 elif isinstance(layer, Upsample):
                     if layer.use_conv:  # nearest x2 is a read-side shift of the conv gather
-                        nh = bld.conv(h, packed(layer.conv), layer.out_channels, up0=up2, winograd=wino)
+                        nh = conv(h, layer.conv, layer.out_channels, up0=up2, winograd=wino)
                     else:  # nearest x2 alone: the same gather under an identity 1x1 filter (exact: one product per output)
                         eye = torch.eye(h.C, dtype=torch.float32, device=device)
                         nh = bld.conv(h, bld.pack_conv(eye, None), h.C, up0=up2)
@@ -314,8 +359,12 @@ class ADMPlan:
             bld.free(skip)
             h = nh
         go, co = net.out[0], net.out[2]
-        n_ = bld.group_norm(h, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), act=1)
-        bld.conv(n_, packed(co), net.out_channels, dst_nchw=self.out, winograd=wino)
+        n_ = group_norm(h, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), act=1)
+        if three_d:  # (the NCHW epilogue writes per-plane images: a volume's (C, D, H, W) order takes a pass of its own)
+            head = conv(n_, co, net.out_channels, winograd=wino)
+            bld.tape.add("az_nhwc_to_nchw_f32", self.out.data_ptr(), head.ptr, B, net.out_channels, D * H * W, head.cs)
+        else:
+            bld.conv(n_, packed(co), net.out_channels, dst_nchw=self.out, winograd=wino)
         bld.finish()
         if film_jobs:
             from ..._lib import AzLinearGroup, lib
@@ -338,8 +387,8 @@ class ADMPlan:
 class UNetModel(nn.Module):
     r"""guided-diffusion ``UNetModel`` (reference ``_src/unet.py:387-634``), gfx950-native forward.
 
-    ``dims=2`` (all of the plugin's cards) and ``dims=1`` ((B, C, L) signals, run as one-row images); ``dims=3`` raises
-    ``NotImplementedError``.  The cards use
+    ``dims=2`` (all of the plugin's cards), ``dims=1`` ((B, C, L) signals, run as one-row images) and ``dims=3`` ((B, C, D, H, W)
+    volumes as B D planes: a Conv3d is three depth-tap launches of the 2-D kernels, G23).  The cards use
     ``resblock_updown=True, use_scale_shift_norm=True``; guided-diffusion's defaults (``h + emb`` instead of FiLM,
     ``Downsample`` / ``Upsample`` layers with or without ``conv_resample``) are built too (G14).
     """
@@ -366,8 +415,8 @@ class UNetModel(nn.Module):
         use_new_attention_order=False,
     ) -> None:
         super().__init__()
-        if dims not in (1, 2):
-            raise NotImplementedError("the HIP path implements dims=2 (all ADM cards) and dims=1; 3-D signals are not built")
+        if dims not in (1, 2, 3):
+            raise ValueError(f"unsupported dimensions: {dims}")
         self.dims = dims
         conv = _CONV[dims]
         if num_heads_upsample == -1:
@@ -422,18 +471,19 @@ class UNetModel(nn.Module):
     def _param_versions(self) -> tuple:
         return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
 
-    def plan(self, B, H, W, emb_rows, device, x_in: Act | None = None, coef_ptr: int | None = None, tag=None, frac=False) -> ADMPlan:
-        key = (B, H, W, emb_rows, str(device), x_in.ptr if x_in is not None else None, coef_ptr, tag, frac)
+    def plan(self, B, H, W, emb_rows, device, x_in: Act | None = None, coef_ptr: int | None = None, tag=None, frac=False,
+             D: int = 1) -> ADMPlan:
+        key = (B, D, H, W, emb_rows, str(device), x_in.ptr if x_in is not None else None, coef_ptr, tag, frac)
         p = self._plans.get(key)
         if p is None or p.versions != self._param_versions():
-            p = ADMPlan(self, B, H, W, emb_rows, device, x_in=x_in, coef_ptr=coef_ptr, frac=frac)
+            p = ADMPlan(self, B, H, W, emb_rows, device, x_in=x_in, coef_ptr=coef_ptr, frac=frac, D=D)
             self._plans[key] = p
         return p
 
     @torch.no_grad()
     @_lib.on_device
     def forward(self, x: Tensor, timesteps: Tensor, y: Tensor | None = None) -> Tensor:
-        r"""x: (N, C, H, W) [dims = 1: (N, C, L)]; timesteps: (N,) or (1,) integer indices or fractional values; y: (N,) labels
+        r"""x: (N, C, H, W) [dims = 1: (N, C, L); dims = 3: (N, C, D, H, W)]; timesteps: (N,) or (1,) integer indices or fractional values; y: (N,) labels
         iff class-conditional."""
         assert (y is not None) == (self.num_classes is not None), (
             "must specify y if and only if the model is class-conditional"
@@ -446,16 +496,17 @@ class UNetModel(nn.Module):
         shape = x.shape
         if self.dims == 1:
             x = x[:, :, None, :]
-        B, Cin, H, W = x.shape
+        D = x.shape[2] if self.dims == 3 else 1
+        B, Cin, H, W = x.shape[0], x.shape[1], x.shape[-2], x.shape[-1]
         timesteps = timesteps.reshape(-1)
         frac = torch.is_floating_point(timesteps)  # (azula itself passes integer indices; guided-diffusion allows fractions)
         rows = B if (timesteps.numel() > 1 or self.num_classes is not None) else 1
-        p = self.plan(B, H, W, rows, x.device, frac=frac)
+        p = self.plan(B, H, W, rows, x.device, frac=frac, D=D)
         s = _lib.stream_ptr()
         if p.planar:
             p.x_in.buf.copy_(x.reshape(-1))
         else:
-            _lib.call("az_nchw_to_nhwc_f32", p.x_in.ptr, x.data_ptr(), None, B, Cin, H * W, p.x_in.cs, s)
+            _lib.call("az_nchw_to_nhwc_f32", p.x_in.ptr, x.data_ptr(), None, B, Cin, D * H * W, p.x_in.cs, s)
         if frac:
             p.t_frac.copy_(timesteps.to(torch.float32).expand(rows) if timesteps.numel() == 1 else timesteps.to(torch.float32))
         else:

@@ -274,17 +274,33 @@ def _gn32(sd, key: str, x: Tensor) -> Tensor:
     return F.group_norm(x, 32, sd[key + ".weight"], sd[key + ".bias"], eps=1e-5)  # _src/nn.py:80-87
 
 
+def adm_upsample(x: Tensor) -> Tensor:
+    r"""Upsample.forward without its convolution -- _src/unet.py:101-106: nearest x2; volumes keep their depth."""
+    if x.ndim == 5:
+        return F.interpolate(x, (x.shape[2], x.shape[3] * 2, x.shape[4] * 2), mode="nearest")
+    return F.interpolate(x, scale_factor=2, mode="nearest")
+
+
+def adm_down_stride(x: Tensor):
+    r"""``stride = 2 if dims != 3 else (1, 2, 2)`` -- _src/unet.py:128."""
+    return (1, 2, 2) if x.ndim == 5 else 2
+
+
+def adm_avg_pool(x: Tensor) -> Tensor:
+    r"""avg_pool_nd(dims, kernel_size=stride, stride=stride) -- _src/nn.py:64-77, _src/unet.py:133."""
+    st = adm_down_stride(x)
+    return {3: F.avg_pool1d, 4: F.avg_pool2d, 5: F.avg_pool3d}[x.ndim](x, st, st)
+
+
 def adm_resblock(sd, key: str, x: Tensor, emb: Tensor, up: bool, down: bool, scale_shift: bool) -> Tensor:
-    r"""ResBlock._forward -- azula/plugins/adm/_src/unet.py:227-247 (dims = 1: (B, C, L) signals, dims = 2: images)."""
+    r"""ResBlock._forward -- azula/plugins/adm/_src/unet.py:227-247 (dims = 1: (B, C, L) signals, dims = 2: images, dims = 3:
+    volumes, whose depth axis is never resampled: ``Upsample`` / ``Downsample`` act on the inner two axes, :103-104,128)."""
     n = x.ndim - 2
-    pool = F.avg_pool1d if n == 1 else F.avg_pool2d  # avg_pool_nd, _src/nn.py:64-77
     h = F.silu(_gn32(sd, key + ".in_layers.0", x))
     if up:  # :104-106 nearest x2 on both branches
-        h = F.interpolate(h, scale_factor=2, mode="nearest")
-        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        h, x = adm_upsample(h), adm_upsample(x)
     elif down:  # :133 AvgPoolNd(2, 2)
-        h = pool(h, 2, 2)
-        x = pool(x, 2, 2)
+        h, x = adm_avg_pool(h), adm_avg_pool(x)
     h = _conv(sd, key + ".in_layers.2", h)
     emb_out = _linear(sd, key + ".emb_layers.1", F.silu(emb))[(...,) + (None,) * n]  # :236-237
     if scale_shift:
@@ -387,9 +403,9 @@ def adm_unet_forward(sd, cfg: dict, x: Tensor, timesteps: Tensor, y: Tensor | No
             elif layer[0] == "res":
                 h = adm_resblock(sd, key, h, emb, layer[1], layer[2], ss)
             elif layer[0] == "down":  # Downsample.forward, _src/unet.py:128-137: stride-2 3-tap conv or AvgPoolNd(2, 2)
-                h = _conv(sd, key + ".op", h, stride=2) if layer[1] else (F.avg_pool1d if h.ndim == 3 else F.avg_pool2d)(h, 2, 2)
+                h = _conv(sd, key + ".op", h, stride=adm_down_stride(h)) if layer[1] else adm_avg_pool(h)
             elif layer[0] == "up":  # Upsample.forward, _src/unet.py:101-109: nearest x2, then the optional 3x3 conv
-                h = F.interpolate(h, scale_factor=2, mode="nearest")
+                h = adm_upsample(h)
                 if layer[1]:
                     h = _conv(sd, key + ".conv", h)
             else:

@@ -227,12 +227,13 @@ def test_g13_other_spatial_dimensions(golden):
 
 ADM_FIXTURES = [("g14_" + n) for n in ("adm_plain_conv", "adm_plain_pool", "adm_film_noupdown")] + [
     ("g22_" + n) for n in ("adm_1d_film_updown", "adm_1d_plain_conv", "adm_1d_plain_pool")
-]
+] + [("g23_" + n) for n in ("adm_3d_film_updown", "adm_3d_plain_conv", "adm_3d_plain_pool")]
 
 
-def test_g14_g22_adm_offcard_and_1d(golden):
-    """guided-diffusion's default wiring (h + emb, Downsample / Upsample layers with and without conv_resample; G14) and
-    ``dims=1`` signals (G22): the oracle against the reference's outputs (oracle/make_golden.py --only-g14 / --only-g22)."""
+def test_g14_g22_g23_adm_offcard_1d_and_3d(golden):
+    """guided-diffusion's default wiring (h + emb, Downsample / Upsample layers with and without conv_resample; G14),
+    ``dims=1`` signals (G22) and ``dims=3`` volumes (G23): the oracle against the reference's outputs
+    (oracle/make_golden.py --only-g14 / --only-g22 / --only-g23)."""
     for fixture in ADM_FIXTURES:
         g = golden(fixture)
         cfg = g.meta["cfg"]
