@@ -294,8 +294,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
 //   S^T = K Q^T : A = K rows from LDS (bf16 [key][D+8]), B = the lane's query (D/16 fragments of 8 values, registers)
 //   O^T += V^T P^T : B = the lane's own probabilities -- registers 8s .. 8s+7 of the S^T tile are 8 keys of one
 //       query, i.e. exactly one B fragment if the MFMA's k index is mapped to keys as the C layout orders them;
-//       A = V^T from LDS, stored TRANSPOSED [d][key position] with the keys of every 32-key tile permuted by that
-//       same map (position 16 (r>>3) + 8 h + (r&7) holds key (r&3) + 8 (r>>2) + 4 h), so a fragment is one 16-byte read.
+//       A = V^T: V sits in LDS ROW-major [key][d] (one 8-byte store per staged chunk) and a fragment is two
+//       ds_read_b64_tr_b16 -- the hardware's 4 x 4 transpose of 16-bit elements inside a 16-lane group delivers channel d of 4
+//       keys per read, and the two groups of 4 keys are exactly those of registers 8 s .. 8 s + 7 (keys (r&3) + 8 (r>>2) + 4 h).
 // With the matrix work 16x cheaper the exponentials bound the kernel: the half mode uses the hardware exp2.
 typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 abf16x4 __attribute__((ext_vector_type(4)));
@@ -323,6 +324,8 @@ __device__ __forceinline__ f32x16 mfma_half(typename HalfT<F16>::x8 a, typename 
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 as3_s4;
 template <int D, bool F16>
 __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
   using H8 = typename HalfT<F16>::x8;
@@ -332,8 +335,9 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
   constexpr int DT = DP / 32;
   constexpr int KS = D / 16;        // K-steps of the QK^T contraction
   constexpr int KLS = D + 8;        // K tile row stride (2-byte elements)
-  constexpr int VLS = KT + 8;       // V^T tile row stride
-  __shared__ __attribute__((aligned(16))) unsigned short hsm[KT * KLS + DP * VLS];
+  // V tile ROW-major [key][VLS], consumed through ds_read_b64_tr_b16 (see attention_x3_kernel): row stride = +-16 dwords (mod 64)
+  constexpr int VLS = DP == 32 ? 32 : DP == 128 ? 160 : 96;
+  __shared__ __attribute__((aligned(16))) unsigned short hsm[KT * KLS + KT * VLS];
   H1* Ks = reinterpret_cast<H1*>(hsm);
   H1* Vt = Ks + KT * KLS;
 
@@ -355,8 +359,9 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
                             ? a.mask + (int64_t)b * a.mask_bstride + (int64_t)hd * a.mask_hstride + (int64_t)qi * T
                             : nullptr;
 
-  // zero V^T once: rows d >= D (padding of the last 32-wide output tile) are never written again
-  for (int e = tid; e < DP * VLS / 2; e += 256) reinterpret_cast<unsigned*>(Vt)[e] = 0u;
+  // zero V once: channels d >= D (padding of the last 32-wide output tile) are never written again
+  if (D < DP)
+    for (int e = tid; e < KT * VLS / 2; e += 256) reinterpret_cast<unsigned*>(Vt)[e] = 0u;
 
   // ---- Q fragments: lane holds q[qi][16 ks + 8 h2 + (0..7)], scaled (and RMS-normalised, gained, rotated) in fp32
   H8 qf[KS];
@@ -471,14 +476,8 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
         }
         const af32x4 k4 = {kv.x, kv.y, kv.z, kv.w};
         *reinterpret_cast<H4*>(Ks + row * KLS + lc * 4) = __builtin_convertvector(k4, H4);
-        // V^T, keys permuted inside their 32-key tile to the order the S^T registers hold them
-        const int kk = row & 31;
-        const int r = (kk & 3) + 4 * (kk >> 3);
-        const int pos = (row & ~31) + 16 * (r >> 3) + 8 * ((kk >> 2) & 1) + (r & 7);
         const af32x4 v4 = {vv.x, vv.y, vv.z, vv.w};
-        const H4 vh = __builtin_convertvector(v4, H4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Vt[(lc * 4 + j) * VLS + pos] = vh[j];
+        *reinterpret_cast<H4*>(Vt + row * VLS + lc * 4) = __builtin_convertvector(v4, H4);
       }
     }
     __syncthreads();
@@ -534,7 +533,12 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
         const H8 pb = __builtin_convertvector(p8, H8);
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
-          const H8 va = *reinterpret_cast<const H8*>(Vt + (ql + 32 * t) * VLS + sub * 32 + 16 * s2 + 8 * h2);
+          // A = V^T: k slots 0 .. 3 = keys 16 s2 + 4 h2 + (0 .. 3), slots 4 .. 7 = the same + 8 -- the order the S^T registers
+          // 8 s2 .. 8 s2 + 7 hold them: two transpose reads of 4 keys x 16 channels per 16-lane group
+          as3_s4* pa = (as3_s4*)(Vt + (sub * 32 + 16 * s2 + 4 * h2 + ((lane & 15) >> 2)) * VLS + 32 * t + (lane & 16) + 4 * (lane & 3));
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pa);
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pa + 2 * VLS);
+          const H8 va = __builtin_bit_cast(H8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
           oacc[t] = mfma_half<F16>(va, pb, oacc[t]);
         }
       }
@@ -561,11 +565,8 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
 // probabilities are split EXACTLY into three bf16 pieces each (az_split3) and every product of the two contractions is the six
 // largest of the nine partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the dropped terms are at the level
 // of one fp32 rounding of the product -- at 6 x 32 cycles per 16 values against 8 x 64 for v_mfma_f32_32x32x2_f32.
-// Layout and fragment maps are attention_half_kernel's with three planes per operand: K [piece][key][D + 8], V^T
-// [piece][d][key position] (keys permuted to the order the S^T registers hold them), q pieces and probability pieces in
-// registers; norms, gains, RoPE, the online softmax (scores in log2 units, hardware exp2) stay fp32 as in attention_kernel.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) s16x4 as3_s4;
+// Layout and fragment maps are attention_half_kernel's with three planes per operand: K [piece][key][D + 8], V [piece][key][row
+// stride] read transposed by ds_read_b64_tr_b16, q pieces and probability pieces in registers; norms, gains, RoPE, the online softmax (scores in log2 units, hardware exp2) stay fp32 as in attention_kernel.
 template <int D, int NW>  // NW = waves (32 queries each) per workgroup: 4, or 8 where the grid still fills the chip (the K / V tile is split and staged once per workgroup)
 __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {
   constexpr int NT = 64 * NW;

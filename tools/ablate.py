@@ -37,6 +37,22 @@ VARIANTS = {
 }
 # attention_x3_kernel: the running maximum updated (and the accumulators rescaled) in every tile, as before the lazy form
 VARIANTS["att_eager"] = [("attention.hip", "      const bool jump = mt > m_run + 8.f;", "      const bool jump = mt > m_run;")]
+# attention_x3_kernel timing ablations (64 x 12 heads x 256 tokens x 64: profiles/r05_attention_x3_ablation.txt)
+_ATT_CHEAP = "{{ {0} = __builtin_bit_cast(unsigned, {3}); {1} = {0}; {2} = {0}; }}"
+VARIANTS["att_nopsplit"] = [("attention.hip", "for (int j = 0; j < 4; ++j) az_split3(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1], p3[0][j], p3[1][j], p3[2][j]);",
+                             "for (int j = 0; j < 4; ++j) " + _ATT_CHEAP.format("p3[0][j]", "p3[1][j]", "p3[2][j]", "sacc[8 * s2 + 2 * j]"))]
+VARIANTS["att_nokvsplit"] = [
+    ("attention.hip", "        az_split3(kv.x, kv.y, k3[0][0], k3[1][0], k3[2][0]);\n        az_split3(kv.z, kv.w, k3[0][1], k3[1][1], k3[2][1]);\n"
+                      "        az_split3(vv.x, vv.y, v3[0][0], v3[1][0], v3[2][0]);\n        az_split3(vv.z, vv.w, v3[0][1], v3[1][1], v3[2][1]);\n",
+     "        " + _ATT_CHEAP.format("k3[0][0]", "k3[1][0]", "k3[2][0]", "kv.x") + _ATT_CHEAP.format("k3[0][1]", "k3[1][1]", "k3[2][1]", "kv.z")
+     + _ATT_CHEAP.format("v3[0][0]", "v3[1][0]", "v3[2][0]", "vv.x") + _ATT_CHEAP.format("v3[0][1]", "v3[1][1]", "v3[2][1]", "vv.z") + "\n")]
+VARIANTS["att_1mfma"] = [("attention.hip", "for (int t = 0; t < 6; ++t) sacc", "for (int t = 0; t < 1; ++t) sacc"),
+                         ("attention.hip", "for (int u = 0; u < 6; ++u) oacc", "for (int u = 0; u < 1; ++u) oacc")]
+VARIANTS["att_noexp"] = [("attention.hip", "const float pe = __builtin_amdgcn_exp2f(sacc[r] - m_sub);", "const float pe = sacc[r] - m_sub;")]
+VARIANTS["att_nosoftmax"] = VARIANTS["att_noexp"] + VARIANTS["att_nopsplit"]
+VARIANTS["att_novalu"] = VARIANTS["att_nosoftmax"] + VARIANTS["att_nokvsplit"]
+VARIANTS["att_mfmaonly"] = VARIANTS["att_novalu"]  # (alias)
+VARIANTS["att_all"] = VARIANTS["att_novalu"] + VARIANTS["att_1mfma"]
 VARIANTS["wx3_noloads"] = VARIANTS["wx3_nogather"] + VARIANTS["wx3_nou"]
 
 # ---- wino_x3.hip: per-wave phase timeline (s_memtime sums per workgroup, waves 0 and 4 of the first 512 workgroups):

@@ -13,7 +13,8 @@ reps = int(sys.argv[5]) if len(sys.argv) > 5 else 50
 dev = torch.device("cuda")
 torch.manual_seed(0)
 qkv = torch.randn(B * T * 3 * H * D, device=dev)
-bld = Builder(dev)
+half = {"bf16": torch.bfloat16, "f16": torch.float16}.get(os.environ.get("AZ_ATTN_HALF", ""))  # the half-precision-operand kernel
+bld = Builder(dev, half=half)
 # AZ_ATTN_OPTS: comma list of  norms (q/k RMS norm, default on), gains (learned q/k gains), rope (rotary tables), order=3HC
 opts = set(os.environ.get("AZ_ATTN_OPTS", "norms").split(","))
 rope = (torch.randn(T, H * D // 2, device=dev), torch.randn(T, H * D // 2, device=dev)) if "rope" in opts else None
