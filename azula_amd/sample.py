@@ -255,26 +255,28 @@ class Sampler(abc.ABC):
     _noise_like_update = False
 
     def _wide_fusable(self, x: Tensor) -> bool:
-        r"""The one-evaluation samplers (DDPM, DDIM, Euler, Ito) and the two whose tapes are built from the loop's own blocks
-        (Heun, PC); the multistep family keeps its per-statement fp64 loop (``_MultistepSampler._call_wide``)."""
-        tapes = (Sampler._fused_step_tapes, HeunSampler._fused_step_tapes, PCSampler._fused_step_tapes)
+        r"""The one-evaluation samplers (DDPM, DDIM, Euler, Ito), the two whose tapes are built from the loop's own blocks
+        (Heun, PC) and the multistep family (its fp64 weights in words 36 .. 47 of the row)."""
+        tapes = (Sampler._fused_step_tapes, HeunSampler._fused_step_tapes, PCSampler._fused_step_tapes, _MultistepSampler._fused_step_tapes)
         return (self.dtype == torch.float64 and x.dtype in (torch.float32, torch.float64) and WIDE_FUSED
                 and type(self)._fused_step_tapes in tapes)
 
     def _host_table_wide(self, fused: "FusedDenoiser") -> Tensor:
         r"""(steps * evaluations per step, 24) fp64: per evaluation the denoiser's row [c_in, c_skip, c_out, c_time, ...] and the transition's row
         [.., c_skip = 0, c_out = 1, alpha_t, alpha_s, k_x, k_eps, .., clip_lo = -inf, clip_hi = inf, ..] in the field order of
-        ``az_transition_f64``'s coefficient row -- the 0-d host scalars of the fp64 time grid, in the reference's op order."""
+        ``az_transition_f64``'s coefficient row -- the 0-d host scalars of the fp64 time grid, in the reference's op order;
+        words 24 .. 35 the clamp / CFG row, words 36 .. 47 free for the sampler (the multistep family's weights)."""
         names = ["c_in", "c_skip", "c_out", "c_time", "alpha_t", "alpha_s", "k_x", "k_eps", "c_in_next", "clip_lo", "clip_hi", "guidance"]
         ts = torch.linspace(self.start, self.stop, self.steps + 1, dtype=self.dtype)
         out = []
         f64 = lambda v: v.to(torch.float64) if torch.is_tensor(v) else float(v)  # noqa: E731
         for t, s in ts.unfold(0, 2, 1).unbind():
             for spec in self._fused_rows(t, s, fused):  # one row per denoiser evaluation, like _host_table
-                row = torch.zeros(24, dtype=torch.float64)
+                row = torch.zeros(_FusedLoopWide.WORDS, dtype=torch.float64)
                 co = fused.coefficients(spec["alpha"], spec["sigma"])
                 for n in ("c_in", "c_skip", "c_out", "c_time"):
-                    row[names.index(n)] = co[n].to(torch.float64)
+                    if n in co:  # (ADM reads an integer time index from the fp32 row instead of c_time)
+                        row[names.index(n)] = co[n].to(torch.float64)
                 # (words 4, 5 of the denoiser half are free: the two spare coefficients of a row, HeunSampler's p and q)
                 row[4], row[5] = f64(spec.get("pad0", 0.0)), f64(spec.get("pad1", 0.0))
                 row[names.index("clip_lo")], row[names.index("clip_hi")] = -math.inf, math.inf
@@ -283,6 +285,13 @@ class Sampler(abc.ABC):
                 row[b + names.index("alpha_t")], row[b + names.index("alpha_s")] = f64(spec["a_t"]), f64(spec["a_s"])
                 row[b + names.index("k_x")], row[b + names.index("k_eps")] = f64(spec["k_x"]), f64(spec["k_eps"])
                 row[b + names.index("clip_lo")], row[b + names.index("clip_hi")] = -math.inf, math.inf
+                # words 24 .. 35: the CLAMP row of the posterior mean (a transition row that only clips: c_out = 1, alpha_s = 1)
+                # with the constants -1 / +1 and the guidance of the CFG combination in its unused slots
+                b = 24
+                row[b + names.index("c_out")], row[b + names.index("alpha_s")] = 1.0, 1.0
+                row[b + names.index("clip_lo")], row[b + names.index("clip_hi")] = fused.clip
+                row[b + names.index("c_time")], row[b + names.index("c_in_next")] = -1.0, 1.0
+                row[b + names.index("guidance")] = fused.guidance
                 out.append(row)
         return torch.stack(out)
 
@@ -379,9 +388,8 @@ class Sampler(abc.ABC):
             if wide:
                 p0 = fused.programs[0]
                 Cc = x.shape[1] if x.ndim > 2 else 1
-                if (len(fused.programs) != 1 or p0.x_in_cs != 0 or p0.f_nhwc or p0.f_channels != Cc or p0.prepare is not None
-                        or fused.clip != (-math.inf, math.inf)):
-                    return None  # (CFG, ADM's clipped 6-channel output, NHWC hand-over: the generic fp64 loop)
+                if p0.f_nhwc or p0.f_channels < Cc or len(fused.programs) > 2:
+                    return None  # (a backbone that hands F over channels-last: the generic fp64 loop)
                 ent = _FusedLoopWide(self, fused, x, cur)
             else:
                 ent = _FusedLoop(self, fused, x, cur)
@@ -604,7 +612,7 @@ class _FusedLoopWide(_FusedLoop):
     the device-resident current row, as ONE hipGraph per step.  Noise is drawn in the dtype of x_t like the reference's
     ``randn_like(x_t)``: fp32 in the first step of an fp32 input (x_t is promoted by that step), fp64 afterwards."""
 
-    WORDS = 24
+    WORDS = 48  # [0, 12) the denoiser's row, [12, 24) the transition's, [24, 36) clamp / CFG constants, [36, 48) the sampler's own
 
     def __init__(self, sampler: "Sampler", fused: FusedDenoiser, x: Tensor, cur: Tensor) -> None:
         dev = x.device
@@ -613,14 +621,19 @@ class _FusedLoopWide(_FusedLoop):
         n_rows = len(sampler._host_table(fused))
         self.table64 = torch.zeros(n_rows, self.WORDS, dtype=torch.float64, device=dev)
         self.mean64 = torch.empty(x.shape, dtype=torch.float64, device=dev)
+        p0 = fused.programs[0]
+        # (a backbone that reads its input channels-last: fp64 -> fp32 flat, then the layout pass of the fp32 loop)
+        self.xin32 = torch.empty(x.shape, dtype=torch.float32, device=dev) if p0.x_in_cs > 0 else None
+        # (CFG: the negative program's posterior mean and the difference of the two)
+        self.cfg64 = [torch.empty(x.shape, dtype=torch.float64, device=dev) for _ in range(2)] if len(fused.programs) == 2 else None
         super().__init__(sampler, fused, torch.empty(x.shape, dtype=torch.float64, device=dev), cur)
         n32 = min(1, len(self.noise)) if x.dtype == torch.float32 else 0
         self.noise32 = [torch.empty(x.shape, dtype=torch.float32, device=dev) for _ in range(n32)]
         self.dummy32 = torch.empty(x.shape, dtype=torch.float32, device=dev) if (self.dummy is not None and x.dtype == torch.float32) else None
 
-    def _c64(self, name: str, second: bool = False) -> int:
+    def _c64(self, name: str, block: int = 0) -> int:
         names = ["c_in", "c_skip", "c_out", "c_time", "alpha_t", "alpha_s", "k_x", "k_eps", "c_in_next", "clip_lo", "clip_hi", "guidance"]
-        return self.cur64.data_ptr() + 8 * (names.index(name) + (12 if second else 0))
+        return self.cur64.data_ptr() + 8 * (names.index(name) + 12 * int(block))
 
     def add_evaluation(self, tape: Tape) -> None:
         r"""The evaluation reads the state the previous transition of the tape wrote (``x`` at the head of a step): the fp32
@@ -630,15 +643,52 @@ class _FusedLoopWide(_FusedLoop):
         src = self.x if src is None else src
         tape.add("az_step_begin", self.cur.data_ptr(), self.table.data_ptr(), self.counter.data_ptr(), self.n_rows)
         tape.add("az_step_row_f64", self.cur64.data_ptr(), self.table64.data_ptr(), self.counter.data_ptr(), self.n_rows, self.WORDS)
-        tape.add("az_scale_f64_to_f32", p0.x_in.data_ptr(), src.data_ptr(), self._c64("c_in"), 1, src.numel(), 0)
-        tape.extend(p0.tape)
+        if self.xin32 is not None:
+            tape.add("az_scale_f64_to_f32", self.xin32.data_ptr(), src.data_ptr(), self._c64("c_in"), 1, src.numel(), 0)
+            tape.add("az_nchw_to_nhwc_f32", p0.x_in.data_ptr(), self.xin32.data_ptr(), None, self.B, self.C, self.inner, p0.x_in_cs)
+        else:
+            tape.add("az_scale_f64_to_f32", p0.x_in.data_ptr(), src.data_ptr(), self._c64("c_in"), 1, src.numel(), 0)
+        for p in self.fused.programs:
+            tape.extend(p.tape)
+
+    def add_mean(self, tape: Tape, x_t: Tensor, mean: Tensor) -> None:
+        r"""``mean`` <- the denoiser's posterior mean in fp64: c_skip x_t + c_out F (the first channels of a wider F: one launch
+        per sample), clipped where the denoiser clips (``az_transition_f64`` under the clamp row, in place), and for CFG
+        pos + g (pos - neg) of the two clipped means -- the statements of the per-statement fp64 loop
+        (``denoise.py`` / ``plugins/adm/__init__.py`` / ``guidance/cfg.py``, ``is_wide`` branches), reading their scalars
+        through pointers into the current fp64 row."""
+        n = x_t.numel()
+        clip = self.fused.clip != (-math.inf, math.inf)
+
+        def raw(dst: Tensor, p: BackboneProgram) -> None:
+            if p.f_channels == self.C:
+                tape.add("az_axpby_f64", dst.data_ptr(), self._c64("c_skip"), x_t.data_ptr(), self._c64("c_out"), p.out.data_ptr(), 1, 1, n, 0)
+            else:
+                per = self.C * self.inner
+                for b in range(self.B):
+                    tape.add("az_axpby_f64", dst.data_ptr() + 8 * b * per, self._c64("c_skip"), x_t.data_ptr() + 8 * b * per, self._c64("c_out"),
+                             p.out.data_ptr() + 4 * b * p.f_channels * self.inner, 1, 1, per, 0)
+            if clip:
+                a = transition_args(x_t=dst.data_ptr(), F=dst.data_ptr(), x_s=dst.data_ptr(), batch=1, channels=1, inner=n, f_channels=1,
+                                    coef=self.cur64.data_ptr() + 8 * 24)
+                tape.add("az_transition_f64", C.byref(a), keep=[a])
+
+        progs = self.fused.programs
+        if len(progs) == 1:
+            raw(mean, progs[0])
+            return
+        neg, diff = self.cfg64
+        raw(mean, progs[0])
+        raw(neg, progs[1])
+        one, minus, g = self._c64("c_in_next", 2), self._c64("c_time", 2), self._c64("guidance", 2)
+        tape.add("az_axpby_f64", diff.data_ptr(), one, mean.data_ptr(), minus, neg.data_ptr(), 0, 1, n, 0)
+        tape.add("az_axpby_f64", mean.data_ptr(), one, mean.data_ptr(), g, diff.data_ptr(), 0, 1, n, 0)
 
     def add_transition(self, tape: Tape, *, x_t: Tensor, x_s: Tensor, eps: Tensor | None = None, mean_out: Tensor | None = None,
                        write_xin: bool = True) -> None:
-        p0 = self.fused.programs[0]
         n = x_t.numel()
         mean = self.mean64 if mean_out is None else mean_out  # (Heun keeps the first evaluation's posterior mean)
-        tape.add("az_axpby_f64", mean.data_ptr(), self._c64("c_skip"), x_t.data_ptr(), self._c64("c_out"), p0.out.data_ptr(), 1, 1, n, 0)
+        self.add_mean(tape, x_t, mean)
         a = transition_args(x_t=x_t.data_ptr(), F=mean.data_ptr(), eps=eps.data_ptr() if eps is not None else None,
                             x_s=x_s.data_ptr(), batch=1, channels=1, inner=n, f_channels=1, coef=self.cur64.data_ptr() + 8 * 12)
         tape.add("az_transition_f64", C.byref(a), keep=[a])
@@ -657,9 +707,27 @@ class _FusedLoopWide(_FusedLoop):
     def run(self, x: Tensor, kwargs: dict) -> Tensor:
         s = self.sampler
         self._upload_table(kwargs)
+        for p in self.fused.programs:
+            if p.prepare is not None:
+                p.prepare(kwargs)
         self.x.copy_(x)  # (fp32 -> fp64 is exact: what the first fp64 multiplication of the reference's step does)
         self.counter.zero_()
+        s._fused_reset(self)
         stream = _lib.stream_ptr()
+        if self.period > 1:  # (the multistep family: `period` consecutive steps per graph, no noise)
+            assert not self.noise and self.dummy is None
+            for g in s.progress_bar(range(0, s.steps, self.period)):
+                n = min(self.period, s.steps - g)
+                graph = self.graphs.get(n)
+                if graph is None:
+                    cat = Tape()
+                    for t in self.step_tapes[:n]:
+                        t.run(stream)
+                        cat.extend(t)
+                    self.graphs[n] = StepGraph(cat, x.device)
+                else:
+                    graph.launch()
+            return self.x.clone()
         for g in s.progress_bar(range(s.steps)):
             # (randn_like(x_t): fp32 only for the FIRST draw of an fp32 input -- the update it feeds promotes the state; a
             #  sampler whose draw is modelled on the updated state never draws fp32)
@@ -997,6 +1065,29 @@ class _MultistepSampler(Sampler):
         dev, nh = loop.x.device, self.order - 1
         ncols = 4 + _lib.MULTISTEP_MAX_HIST
         loop.ring = [torch.zeros_like(loop.x) for _ in range(self.order)]
+        if isinstance(loop, _FusedLoopWide):
+            # fp64 clock: the statements of `_call_wide` (pred = a x_t + b mean; acc = p x_t + w_new pred; acc += w_j pred_j, oldest
+            # first) as az_axpby_f64 launches reading words 36 .. 47 of the current fp64 row: [a, b, p, w_new, w_hist x 7, 1]
+            mean, scratch = torch.empty_like(loop.x), torch.empty_like(loop.x)
+            loop.keep += [mean, scratch]
+            w = lambda k: loop.cur64.data_ptr() + 8 * (36 + k)  # noqa: E731
+            n = loop.x.numel()
+            tapes = []
+            for j in range(self.order):
+                tape = Tape()
+                loop._src = loop.x
+                loop.add_evaluation(tape)
+                loop.add_mean(tape, loop.x, mean)
+                pred = loop.ring[j]
+                tape.add("az_axpby_f64", pred.data_ptr(), w(0), loop.x.data_ptr(), w(1), mean.data_ptr(), 0, 1, n, 0)
+                acc = scratch if nh else loop.x
+                tape.add("az_axpby_f64", acc.data_ptr(), w(2), loop.x.data_ptr(), w(3), pred.data_ptr(), 0, 1, n, 0)
+                for k in range(nh):  # slot k <-> step i - nh + k (right-aligned weights: zero while that step does not exist)
+                    dst = loop.x if k == nh - 1 else scratch
+                    tape.add("az_axpby_f64", dst.data_ptr(), w(11), scratch.data_ptr(), w(4 + k),
+                             loop.ring[(j - nh + k) % self.order].data_ptr(), 0, 1, n, 0)
+                tapes.append(tape)
+            return tapes
         loop.mtable = torch.zeros(self.steps, ncols, dtype=torch.float32, device=dev)
         mrow = torch.zeros(ncols, dtype=torch.float32, device=dev)
         mean, scratch = torch.empty_like(loop.x), torch.empty_like(loop.x)
@@ -1041,7 +1132,20 @@ class _MultistepSampler(Sampler):
         return x_t
 
     def _fused_upload_extra(self, loop) -> None:
-        loop.mtable.copy_(self._ring_table())
+        if not isinstance(loop, _FusedLoopWide):
+            loop.mtable.copy_(self._ring_table())
+
+    def _host_table_wide(self, fused: "FusedDenoiser") -> Tensor:
+        rows = super()._host_table_wide(fused)
+        alpha, sigma = self.denoiser.schedule(torch.linspace(self.start, self.stop, self.steps + 1, dtype=self.dtype))
+        tab = self._device_table(alpha, sigma, dtype=torch.float64)
+        nh = self.order - 1
+        rows[:, 36:40] = tab[:, :4]
+        for i in range(self.steps):
+            n = min(self.order, i + 1) - 1
+            rows[i, 40 + nh - n : 40 + nh] = tab[i, 4 : 4 + n]
+        rows[:, 47] = 1.0
+        return rows
 
     def _fused_reset(self, loop) -> None:
         for r in loop.ring:
@@ -1055,8 +1159,8 @@ class _MultistepSampler(Sampler):
         time = self.timesteps.to(device=x.device)
         if not x.is_cuda:
             return self._call_host(x, time, kwargs)
-        if type(self).__call__ is _MultistepSampler.__call__ and x.dtype == torch.float32 and x.ndim >= 2 \
-                and self.dtype in (None, torch.float32):
+        if type(self).__call__ is _MultistepSampler.__call__ and x.ndim >= 2 and (
+                (x.dtype == torch.float32 and self.dtype in (None, torch.float32)) or self._wide_fusable(x)):
             out = self._call_fused(x, kwargs)
             if out is not None:
                 return out

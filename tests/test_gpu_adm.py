@@ -260,3 +260,54 @@ def test_adm_fractional_timesteps(golden, name):
     # the integer path still takes the table
     ops = [n for _, _, n in net.plan(2, g[name + "_x"].shape[2], g[name + "_x"].shape[3], 2, torch.device("cuda", 0)).tape.ops]
     assert "az_timestep_embedding_f32" not in ops
+
+
+@pytest.mark.parametrize("case", ["ddim", "ddpm", "cfg", "volume", "zab"])
+def test_adm_with_an_fp64_clock_runs_as_a_captured_loop(golden, case, monkeypatch):
+    """``Sampler(dtype=float64)`` around an ADM denoiser (azula/sample.py:69-94 applies to every denoiser): the captured fp64 loop
+    with the posterior mean from the first 3 of the backbone's 6 channels (one az_axpby_f64 per sample), clipped to +-1 by
+    az_transition_f64 under the clamp row, CFG as pos + g (pos - neg) of the two clipped means, a channels-last backbone input
+    (dims = 3) through an fp32 staging tensor -- against the per-statement fp64 loop (same kernels, same generator draws)."""
+    from azula_amd import sample as S
+    from azula_amd.guidance.cfg import CFGDenoiser
+
+    name = {"cfg": "g5_adm_cond_neworder", "volume": "g23_adm_3d_plain_conv"}.get(case, "g5_adm_uncond")
+    g = golden(name)
+    den, _, cfg = build(g)
+    x1 = g["x1"].cuda()
+    kw = {}
+    if case == "cfg":
+        # (two sequential programs: the 2B-batch form of the captured CFG step runs its small maps under other tile plans than
+        #  two B-batch calls, 1e-4 after c_out = -100 and the guidance -- the fp32 test above measures the same)
+        monkeypatch.setenv("AZ_CFG_BATCHED", "0")
+        y = g["y"].cuda()
+        den, kw = CFGDenoiser(den), dict(positive={"label": y}, negative={"label": torch.zeros_like(y)}, guidance=2.0)
+    make = {
+        "ddpm": lambda: S.DDPMSampler(den, steps=6, silent=True, dtype=torch.float64),
+        "zab": lambda: S.zABSampler(den, order=2, steps=5, silent=True, dtype=torch.float64),
+    }.get(case, lambda: S.DDIMSampler(den, steps=6, silent=True, dtype=torch.float64))
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(S, "WIDE_FUSED", fused)
+        smp = make()
+        torch.manual_seed(5)
+        outs[fused] = smp(x1, **kw)
+        if fused:
+            loop = next(iter(smp._fused_cache.values()))
+            assert isinstance(loop, S._FusedLoopWide) and loop.graphs
+            torch.manual_seed(5)
+            assert torch.equal(smp(x1, **kw), outs[True])
+        else:
+            assert not smp._fused_cache
+    sc = max(1.0, outs[False].abs().max().item())
+    e = max_err(outs[True], outs[False])
+    print(case, "ADM, captured vs per-statement fp64 loop: max|d|", e, "scale", sc)
+    # measured 1.6e-15 .. 4.0e-15 (the fp32 backbone sees bit-identical inputs; the host table vs the device's fp64 libm)
+    assert outs[True].dtype == torch.float64 and e < 1e-10 * sc
+    if case == "cfg":  # the default, batched form of the captured step: equal up to the backbone's round-off
+        monkeypatch.setenv("AZ_CFG_BATCHED", "1")
+        monkeypatch.setattr(S, "WIDE_FUSED", True)
+        torch.manual_seed(5)
+        xb = make()(x1, **kw)
+        print("cfg, 2B-batch captured fp64 loop vs per-statement:", max_err(xb, outs[False]))
+        assert max_err(xb, outs[False]) < 1e-3

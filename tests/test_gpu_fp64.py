@@ -135,6 +135,35 @@ def test_fp64_clock_captured_loop_of_the_other_samplers(golden, which, in_dtype,
         assert max_err(outs[True], g["unet_euler6_x64"]) < 2e-5 * max(1.0, g["unet_euler6_x64"].abs().max().item())
 
 
+@pytest.mark.parametrize("in_dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("which", ["zab2", "xeab3", "vab1", "reab4"])
+def test_fp64_clock_captured_loop_of_the_multistep_family(golden, which, in_dtype, monkeypatch):
+    """The Adams-Bashforth family with ``dtype=float64``: `order` consecutive steps per captured graph (the history ring's
+    addresses cycle), every statement an az_axpby_f64 reading its weight from words 36 .. 47 of the current fp64 row -- against
+    the per-statement fp64 loop (``_MultistepSampler._call_wide``), 7 steps (a remainder graph for orders 2 - 4)."""
+    from azula_amd import sample as S
+
+    g = golden("g11_sampler_dtype")
+    den = unet_denoiser(g)
+    x1 = g["unet_x1"].cuda().to(in_dtype)
+    cls, order = {"zab2": (S.zABSampler, 2), "xeab3": (S.xEABSampler, 3), "vab1": (S.vABSampler, 1), "reab4": (S.REABSampler, 4)}[which]
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(S, "WIDE_FUSED", fused)
+        smp = cls(den, order=order, steps=7, silent=True, dtype=torch.float64)
+        outs[fused] = smp(x1)
+        if fused:
+            loop = next(iter(smp._fused_cache.values()))
+            assert isinstance(loop, S._FusedLoopWide) and loop.period == order and loop.graphs
+            assert torch.equal(smp(x1), outs[True])  # replay of the captured graphs (ring zeroed per call)
+        else:
+            assert not smp._fused_cache
+    sc = max(1.0, outs[False].abs().max().item())
+    e = max_err(outs[True], outs[False])
+    print(which, in_dtype, "captured vs per-statement fp64 loop: max|d|", e, "scale", sc)
+    assert outs[True].dtype == torch.float64 and e < 1e-10 * sc
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_ito_with_an_fp64_clock_draws_its_noise_in_fp64(golden, fused, monkeypatch):
     """ItoSampler's noise is randn_like(x_s) (azula/sample.py:427-429): with fp64 schedule scalars x_s is fp64 before the draw, also
