@@ -280,6 +280,7 @@ PROTOTYPES: dict[str, list] = {
     "az_transition_f64": [C.POINTER(AzTransitionArgs), c_stream],
     "az_step_row_f64": [vp, vp, vp, i32, i32, c_stream],
     "az_axpby_f64": [vp, vp, vp, vp, vp, i32, i64, i64, i32, c_stream],
+    "az_randn_slice_f32": [vp, C.c_uint64, C.c_uint64, i64, i64, i64, c_stream],
     "az_scale_f64_to_f32": [vp, vp, vp, i64, i64, i32, c_stream],
     "az_calib_read_f32": [vp, vp, i64, i32, i32, i64, c_stream],
     "az_calib_write_f32": [vp, i64, f32, c_stream],

@@ -15,7 +15,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["transition.hip", "layout.hip", "linear.hip", "norm.hip", "conv.hip", "wino_x3.hip", "attention.hip", "graph.hip", "calib.hip"]
+SOURCES = ["transition.hip", "layout.hip", "linear.hip", "norm.hip", "conv.hip", "wino_x3.hip", "attention.hip", "graph.hip", "rng.hip", "calib.hip"]
 LIB = os.path.join(HERE, "libazula_amd.so")
 OBJ_DIR = os.path.join(HERE, "_obj")
 FLAGS = [

@@ -6,9 +6,12 @@ collective inside the loop; the only exchange is ONE all-gather of the final ``x
 xGMI with the ``nccl`` backend; ``gloo`` on CPU for the tests).  The reference has no
 distributed code at all -- this module is new.
 
-Determinism: every rank seeds its generator identically and draws full-batch noise, keeping its
-slice (``Sampler._draw_noise``), so ``world`` GPUs reproduce the single-device result sample for
-sample (``init_sharded`` does the same for ``x_T``).
+Determinism: every rank seeds its generator identically and takes ITS slice of the full-batch noise
+(``Sampler._draw_noise``): on the GPU ``az_randn_slice_f32`` evaluates exactly the rank's elements of
+the draw ``torch.randn`` would make for the whole batch (same Philox subsequences, calls and
+components: bit-identical, 1 / world of the work, no full-batch tensor) and advances the generator
+as the full draw would; host tensors draw the full batch and slice.  So ``world`` GPUs reproduce the
+single-device result sample for sample (``init_sharded`` does the same for ``x_T``).
 """
 
 from __future__ import annotations

@@ -33,6 +33,7 @@ from ._lib import COEF_FIELDS, COEF_WORDS
 from .denoise import Denoiser, axpby_wide, is_wide, require_f32_cuda
 from .engine import StepGraph, Tape, transition_args
 
+SLICED_NOISE = os.environ.get("AZ_SLICED_NOISE", "1") != "0"  # sharded batches: draw only the rank's slice of the full-batch noise
 WIDE_FUSED = os.environ.get("AZ_WIDE_FUSED", "1") != "0"  # captured loop for Sampler(dtype=float64) ("0": the generic fp64 loop)
 
 __all__ = [
@@ -151,10 +152,14 @@ class Sampler(abc.ABC):
         r"""One ``randn_like`` per step, as the reference (``azula/sample.py:214,259``).  When the batch
         is sharded (``self.shard = (rank, world)``) every rank draws the FULL batch from its
         identically seeded generator and keeps its slice, so an N-GPU run reproduces the
-        single-device random stream sample for sample."""
+        single-device random stream sample for sample.  fp32 device tensors: ``az_randn_slice_f32`` produces exactly this
+        rank's elements of that draw (1 / world of the generator work and no full-batch tensor) and advances the generator's
+        Philox offset as the full draw would; ``AZ_SLICED_NOISE=0``: the full draw."""
         if self.shard is None:
             return torch.randn_like(like) if out is None else out.normal_()
         rank, world = self.shard
+        if like.is_cuda and like.dtype == torch.float32 and SLICED_NOISE and world * like.numel() < 2**31:
+            return _randn_slice(like, rank, world, out)  # this rank's elements of the full-batch draw only (bit-identical)
         full = torch.randn((world * like.shape[0], *like.shape[1:]), dtype=like.dtype, device=like.device)
         mine = full[rank * like.shape[0] : (rank + 1) * like.shape[0]]
         return mine.contiguous() if out is None else out.copy_(mine)
@@ -465,6 +470,28 @@ def _kwargs_signature(kw) -> tuple:
     if torch.is_tensor(kw):
         return ("tensor", tuple(kw.shape))
     return ("value",)
+
+
+def _randn_slice(like: Tensor, rank: int, world: int, out: Tensor | None = None) -> Tensor:
+    r"""Elements [rank n, (rank + 1) n) of ``torch.randn(world * n)`` on ``like``'s device, without drawing the rest: ATen's
+    launch policy for the FULL tensor (``ATen/native/cuda/DistributionTemplates.h: calc_execution_policy``) fixes which Philox
+    subsequence / call / component produces every element; the kernel evaluates exactly those."""
+    dev = like.device
+    gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+    n = like.numel()
+    total = world * n
+    props = torch.cuda.get_device_properties(dev)
+    grid = min(props.multi_processor_count * (props.max_threads_per_multi_processor // 256), (total + 255) // 256)
+    threads = 256 * grid
+    seed, offset = gen.initial_seed(), gen.get_offset()
+    dst = out if (out is not None and out.is_contiguous()) else torch.empty_like(like, memory_format=torch.contiguous_format)
+    with torch.cuda.device(dev):
+        _lib.call("az_randn_slice_f32", dst.data_ptr(), seed, offset, threads, rank * n, n, _lib.stream_ptr())
+    gen.set_offset(offset + ((total - 1) // (threads * 4) + 1) * 4)  # (the full draw's counter_offset)
+    if out is not None and dst is not out:
+        out.copy_(dst)
+        return out
+    return dst
 
 
 class _FusedLoop:

@@ -506,6 +506,15 @@ int az_axpby_f64(double* y, const double* a_dev, const double* x, const double* 
 int az_scale_f64_to_f32(float* y, const double* x, const double* s_dev, int64_t rows, int64_t inner, int32_t s_stride,
                         az_stream_t stream);
 
+/* ------------------------------------------------------------------ multi-GPU sampling (no reference counterpart:
+ * the reference draws `torch.randn_like(x_t)` of the whole batch on one device, azula/sample.py:214,259)
+ * dst[e] = element start + e of the standard-normal tensor that torch.randn / Tensor.normal_ (float32) would draw with the
+ * Philox state (seed, offset) in a launch of `threads_total` threads (ATen's policy: 256 x min(ceil(numel / 256),
+ * CUs x max resident threads / 256)) -- bit for bit, so that a rank of a batch-sharded run draws only ITS samples of the
+ * single-device random stream.  The caller advances the generator's offset as the full draw would.                        */
+int az_randn_slice_f32(float* dst, uint64_t seed, uint64_t offset, int64_t threads_total, int64_t start, int64_t count,
+                       az_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement support (not on the sampling path)
  * Known-traffic kernels that calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters on gfx950 (MI355X_MICROARCH.md,
  * section HBM: "calibrate on a known byte count in your own access pattern").  `az_calib_read_f32` reads every byte of
