@@ -2592,7 +2592,8 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   }
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
-  AZ_REQUIRE(a->act >= 0 && a->act <= 5, AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(a->act >= 0 && a->act <= 6, AZ_E_UNSUPPORTED);
+  if (a->act == 6) AZ_REQUIRE(a->res && !a->gate && !a->dst_nchw && !a->gn_quads, AZ_E_UNSUPPORTED);  // SiLU of the sum with the residual
   if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
   if (a->act == 5) {  // q / k preparation of a fused qkv projection (epilogue_batch_qk)
     AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->splitk <= 1 && a->depth == 0, AZ_E_UNSUPPORTED);
@@ -2828,7 +2829,8 @@ static int wino_prepare(const AzConvArgs* a, int wk, int64_t ustage_bytes, WinoP
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
-  AZ_REQUIRE(a->act >= 0 && a->act <= 4, AZ_E_UNSUPPORTED);
+  AZ_REQUIRE((a->act >= 0 && a->act <= 4) || a->act == 6, AZ_E_UNSUPPORTED);
+  if (a->act == 6) AZ_REQUIRE(a->res && !a->gate && !a->dst_nchw && !a->gn_quads, AZ_E_UNSUPPORTED);  // SiLU of the sum with the residual
   if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
   if (a->depth != 0) {  // one depth tap of a 3-D convolution
     AZ_REQUIRE(a->depth > 0 && a->batch % a->depth == 0 && a->depth_shift > -a->depth && a->depth_shift < a->depth &&
@@ -2932,7 +2934,8 @@ int az_conv2d_winograd4_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
-  AZ_REQUIRE(a->act >= 0 && a->act <= 4, AZ_E_UNSUPPORTED);
+  AZ_REQUIRE((a->act >= 0 && a->act <= 4) || a->act == 6, AZ_E_UNSUPPORTED);
+  if (a->act == 6) AZ_REQUIRE(a->res && !a->gate && !a->dst_nchw && !a->gn_quads, AZ_E_UNSUPPORTED);  // SiLU of the sum with the residual
   if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
   AZ_REQUIRE(!a->in_affine && a->depth == 0, AZ_E_UNSUPPORTED);
   AZ_REQUIRE(!a->aniso || (a->up0_w >= 0 && a->up0_w <= 4 && a->up1_w >= 0 && a->up1_w <= 4), AZ_E_SHAPE);  // (shift amounts)

@@ -73,7 +73,7 @@ static inline int az_upw(const AzConvArgs* a, int up, int up_w) { return a->anis
 // Epilogue for 4 consecutive output channels [co, co+4) of output pixel n.
 // The fused epilogue in two halves so that callers can issue the loads of several outputs before the first store (the
 // compiler cannot move a load above a store that might alias it): fetch = the gate / residual reads, apply = bias,
-// activation, gate, residual, store.  The arithmetic order is fixed: ((v + bias) -> act) * gate + res.
+// activation, gate, residual, store.  The arithmetic order is fixed: ((v + bias) -> act) * gate + res (act 6: silu(v + bias + res)).
 __device__ __forceinline__ int64_t epilogue_res_index(const AzConvArgs& a, int n, int b) {
   const int rem = n - b * (a.hout * a.wout);
   if (a.res_up) {
@@ -101,6 +101,13 @@ __device__ __forceinline__ float4 epilogue_apply_store(const AzConvArgs& a, int 
     // its w12 rows interleaved at build time): the output has HALF the channels (row stride cout_s / 2; the host admits no
     // gate / residual / planar destination here) -- the separate az_swiglu_f32 pass and its 12 B per pair are gone
     *reinterpret_cast<float2*>(a.dst + (int64_t)n * (a.cout_s / 2) + co / 2) = make_float2(v.x * az_silu(v.y), v.z * az_silu(v.w));
+    return v;
+  }
+  if (a.act == 6) {
+    // SiLU of the SUM with the residual operand (no gate, NHWC destination): the last depth tap of a 3-D convolution that is
+    // followed by an activation accumulates into the other taps' sum and activates it in the same store (nn/unet3d.py)
+    v = make_float4(az_silu(v.x + r.x), az_silu(v.y + r.y), az_silu(v.z + r.z), az_silu(v.w + r.w));
+    *reinterpret_cast<float4*>(a.dst + (int64_t)n * a.cout_s + co) = v;
     return v;
   }
   if (a.act == 1) {
@@ -194,6 +201,11 @@ __device__ __forceinline__ void epilogue_batch_nhwc(const AzConvArgs& a, const i
       f.y = az_silu(f.y);
       f.z = az_silu(f.z);
       f.w = az_silu(f.w);
+    }
+    if constexpr (ACT == 6) {  // SiLU of the sum with the residual (RES = 1, no gate)
+      f = make_float4(az_silu(f.x + r[i].x), az_silu(f.y + r[i].y), az_silu(f.z + r[i].z), az_silu(f.w + r[i].w));
+      if (n[i] >= 0) *reinterpret_cast<float4*>(a.dst + (int64_t)n[i] * a.cout_s + co) = f;
+      continue;
     }
     if constexpr (ACT == 4) {  // SwiGLU over interleaved pairs: half the channels (see epilogue_apply_store)
       if (n[i] >= 0)
@@ -305,6 +317,7 @@ __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const 
   }
   if (a.act == 4) return epilogue_batch_nhwc<NB, false, 4, false, 0>(a, n, b, co, v, mom);
   if (a.act == 5) return epilogue_batch_qk<NB>(a, n, b, co, v);
+  if (a.act == 6 && !a.res_up && !a.res_bcast) return epilogue_batch_nhwc<NB, false, 6, false, 1>(a, n, b, co, v, mom);
   if (!a.dst_nchw && a.act <= 1) {
     const int rk = a.res == nullptr ? 0 : (a.res_up || a.res_bcast) ? 2 : 1;
     switch ((a.act * 2 + (a.gate != nullptr ? 1 : 0)) * 3 + rk) {

@@ -106,9 +106,11 @@ def conv3d(bld: Builder, x: Vol, conv, *, stride=1, periodic: bool = False, x1: 
         full = out if sd_ == 1 else new_vol(bld, x.B, Din, Ho, Wo, cout)  # (a strided depth axis: every plane, then every sd-th kept)
         allo = planes(full)
         allr = planes(res) if res is not None else None
+        # (the activation of the sum rides on the last tap's store: act 6 = silu(tap + what the earlier taps left; no pass of its own)
+        fold = silu and len(taps) > 1 and sd_ == 1 and gate is None
         for j in taps:
             bld.conv(planes(x), packs[j], cout, stride=(sh_, sw_), out=allo, res=allr if j == p else allo, depth=(Din, j - p, periodic),
-                     periodic=periodic, **g, **kw_)
+                     periodic=periodic, act=6 if (fold and j == taps[-1]) else 0, **g, **kw_)
         if sd_ > 1:  # out[d] = full[sd d]
             n = Ho * Wo * out.cs
             if Din % sd_ == 0:
@@ -125,7 +127,7 @@ def conv3d(bld: Builder, x: Vol, conv, *, stride=1, periodic: bool = False, x1: 
             free_vol(bld, full)
         if x1u is not None:
             free_vol(bld, x1u)
-        if silu:
+        if silu and not fold:
             bld.tape.add("az_silu_f32", out.buf.data_ptr(), out.buf.data_ptr(), out.buf.numel())
         return out
     for b in range(x.B):

@@ -263,7 +263,9 @@ typedef struct AzConvArgs {
   int32_t hout, wout;
   int32_t act;             /* 0 none, 1 SiLU, 2 ReLU, 3 ReLU^2, 4 SwiGLU over interleaved pairs: dst gets cout_s / 2 channels per
                               pixel, y[c] = x[2c] * silu(x[2c+1]) (no gate / res / dst_nchw; cout_s % 8 == 0), 5 q / k preparation
-                              of a fused qkv projection (the qk_* fields at the end of this struct) */
+                              of a fused qkv projection (the qk_* fields at the end of this struct; az_conv2d_f32 family only),
+                              6 SiLU of the sum with the residual: y = silu(conv + bias + res) (res required; no gate /
+                              dst_nchw / gn_quads) -- the last depth tap of a Conv3d -> SiLU pair */
   const float* gate;       /* optional (…, cout_s) */
   int64_t gate_bstride;    /* 0 = shared across the batch */
   const float* res;        /* optional residual, NHWC (B, hres, wres, cout_s) */

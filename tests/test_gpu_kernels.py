@@ -538,6 +538,38 @@ def test_conv2d_swiglu_epilogue(az, wino, Cin, Cout, ks):
     assert max_err(out, ref) < 2 * conv_tol(Cin, ks, wino) * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("wino", [False, True, "x3", "wx3"])
+@pytest.mark.parametrize("Cin,Cout,ks,splitk", [(32, 64, 1, 0), (20, 24, 3, 0), (64, 128, 3, 2)])
+def test_conv2d_silu_of_the_sum_with_the_residual(az, wino, Cin, Cout, ks, splitk):
+    """AzConvArgs.act = 6: y = silu(conv + bias + res), in place on the residual operand -- the last depth tap of a Conv3d -> SiLU
+    pair (nn/unet3d.py: no activation pass of its own)."""
+    if wino in (True, "wx3") and ks != 3:
+        pytest.skip("Winograd is the stride-1 3x3 path")
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(Cin + Cout + ks)
+    B, H, W = 2, 10, 6
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, Cout, H, W, generator=g)
+    ref = F.silu(F.conv2d(x, w, b, padding=ks // 2) + r)
+    bld = Builder(torch.device("cuda"))
+    xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, (Cin + 3) // 4 * 4, True)
+    acc = Act(to_nhwc(dev(r)).reshape(-1).clone(), B, H, W, Cout, Cout, True)
+    y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, act=6, res=acc, out=acc, winograd=wino)
+    if splitk:
+        d = [k for k in bld.tape.keep if hasattr(k, "_flops")][-1]
+        d.splitk = splitk
+        bld._ws_need = max(bld._ws_need, splitk * B * H * W * Cout)
+        if d not in bld._ws_users:
+            bld._ws_users.append(d)
+    bld.finish()
+    bld.tape.run()
+    out = from_nhwc(y.buf.reshape(B, H, W, y.cs), Cout)
+    assert max_err(out, ref) < 2 * conv_tol(Cin, ks, bool(wino) and wino != "x3") * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("mode", [True, "wx3"])
 def test_winograd_stream_fuzz(az, mode):
     """The hand-scheduled K loop (wino_kloop.inc) over 40 seeded cases that move every event of the stream around: 1 .. 24
