@@ -71,6 +71,22 @@ __device__ __forceinline__ void az_split3(float x0, float x1, unsigned& p1, unsi
   p3 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
 }
 
+// Streaming accesses of the pure HBM streams (the transition kernels: every byte read once and written once per launch):
+// non-temporal 16-byte loads / stores (global_load_dwordx4 ... nt).  Measured on the 96 Mi-element transition
+// (profiles/r05_stream_nt_ab.txt): 12 B/element form 5.71 -> 6.14 TB/s, the 16 B form 5.46 -> 5.78, the 20 B form 5.40 -> 5.89;
+// loads only or stores only give a third of it each.  The lines of an nt store still stay in the XCD's L2, so the consumer of
+// a small latent (the stem convolution right behind the step) loses nothing.  NOT used by az_affine_act_f32: there the
+// consumer re-reads a tensor that partly survives in the Infinity Cache, and the hint measured a loss inside an ADM step.
+typedef float az_f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 az_ld_stream(const float* p) {
+  const az_f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const az_f32x4_t*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void az_st_stream(float* p, float4 o) {
+  const az_f32x4_t v = {o.x, o.y, o.z, o.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<az_f32x4_t*>(p));
+}
+
 // Memory-bound launches: cap the grid at 256 CUs x 8 blocks and grid-stride the rest.
 static inline int az_stream_grid(int64_t work_items, int block) {
   int64_t g = (work_items + block - 1) / block;

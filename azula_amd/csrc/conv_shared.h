@@ -224,7 +224,8 @@ __device__ __forceinline__ void epilogue_batch_nhwc(const AzConvArgs& a, const i
       f.z += r[i].z;
       f.w += r[i].w;
     }
-    if (n[i] >= 0) *reinterpret_cast<float4*>(a.dst + (int64_t)n[i] * a.cout_s + co) = f;
+    // (non-temporal store: the output is not re-read by this launch; measured - 0.3 % of a C2 step, - 0.55 % of C5: profiles/r05_stream_nt_ab.txt)
+    if (n[i] >= 0) az_st_stream(a.dst + (int64_t)n[i] * a.cout_s + co, f);
     if constexpr (MOM) {  // GroupNorm statistics of the output come from here (gn_quads; the host admits no skipped pixel)
       if (i == 0) mom[0] = f.x;
       const float d0 = f.x - mom[0], d1 = f.y - mom[0], d2 = f.z - mom[0], d3 = f.w - mom[0];

@@ -87,15 +87,15 @@ __global__ __launch_bounds__(256) void transition_flat_kernel(const float* __res
     o.y = step_x<EPS>(k, xv.y, m.y, ev.y);
     o.z = step_x<EPS>(k, xv.z, m.z, ev.z);
     o.w = step_x<EPS>(k, xv.w, m.w, ev.w);
-    reinterpret_cast<float4*>(x_s)[i] = o;
-    if (MEAN) reinterpret_cast<float4*>(mean_out)[i] = m;
+    az_st_stream(x_s + 4 * i, o);
+    if (MEAN) az_st_stream(mean_out + 4 * i, m);
     if (XIN) {
       float4 q;
       q.x = az_mul(k.c_in_next, o.x);
       q.y = az_mul(k.c_in_next, o.y);
       q.z = az_mul(k.c_in_next, o.z);
       q.w = az_mul(k.c_in_next, o.w);
-      reinterpret_cast<float4*>(xin)[i] = q;
+      az_st_stream(xin + 4 * i, q);
     }
   };
   // x_s may alias x_t (in-place step), so the compiler cannot hoist the next element's loads above this element's
@@ -111,10 +111,11 @@ __global__ __launch_bounds__(256) void transition_flat_kernel(const float* __res
     float4 xv[UN], fv[UN], nv[UN], ev[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      xv[u] = reinterpret_cast<const float4*>(x_t)[i + u * blockDim.x];
-      fv[u] = reinterpret_cast<const float4*>(F)[i + u * blockDim.x];
-      nv[u] = CFG ? reinterpret_cast<const float4*>(Fn)[i + u * blockDim.x] : z4;
-      ev[u] = EPS ? reinterpret_cast<const float4*>(eps)[i + u * blockDim.x] : z4;
+      const int64_t e = 4 * (i + u * blockDim.x);  // (streams read once: non-temporal, see common.h)
+      xv[u] = az_ld_stream(x_t + e);
+      fv[u] = az_ld_stream(F + e);
+      nv[u] = CFG ? az_ld_stream(Fn + e) : z4;
+      ev[u] = EPS ? az_ld_stream(eps + e) : z4;
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) one(i + u * blockDim.x, xv[u], fv[u], nv[u], ev[u]);
@@ -291,10 +292,10 @@ __global__ __launch_bounds__(256) void transition_image4_kernel(AzTransitionArgs
         xo[u][c] = (b * C + c) * inner + i0;
         if (valid[u] && c < C) {
           const int64_t fo = (b * fC + c) * inner + i0;
-          xv[u][c] = *reinterpret_cast<const float4*>(a.x_t + xo[u][c]);
-          fv[u][c] = *reinterpret_cast<const float4*>(a.F + fo);
-          if (CFG) nv[u][c] = *reinterpret_cast<const float4*>(a.F_neg + fo);
-          if (EPS) ev[u][c] = *reinterpret_cast<const float4*>(a.eps + xo[u][c]);
+          xv[u][c] = az_ld_stream(a.x_t + xo[u][c]);
+          fv[u][c] = az_ld_stream(a.F + fo);
+          if (CFG) nv[u][c] = az_ld_stream(a.F_neg + fo);
+          if (EPS) ev[u][c] = az_ld_stream(a.eps + xo[u][c]);
         }
       }
     }
@@ -313,8 +314,8 @@ __global__ __launch_bounds__(256) void transition_image4_kernel(AzTransitionArgs
           o.y = step_x<EPS>(k, xv[u][c].y, m.y, ev[u][c].y);
           o.z = step_x<EPS>(k, xv[u][c].z, m.z, ev[u][c].z);
           o.w = step_x<EPS>(k, xv[u][c].w, m.w, ev[u][c].w);
-          *reinterpret_cast<float4*>(a.x_s + xo[u][c]) = o;
-          if (MEAN) *reinterpret_cast<float4*>(a.mean_out + xo[u][c]) = m;
+          az_st_stream(a.x_s + xo[u][c], o);
+          if (MEAN) az_st_stream(a.mean_out + xo[u][c], m);
           sc = make_float4(az_mul(k.c_in_next, o.x), az_mul(k.c_in_next, o.y), az_mul(k.c_in_next, o.z),
                            az_mul(k.c_in_next, o.w));
         }
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void transition_image4_kernel(AzTransitionArgs
 #pragma unroll
     for (int i = 0; i < 4 * UN; ++i) {
       const int p = 256 * i + tid;
-      if (p < npx) *reinterpret_cast<float4*>(dst + 4 * (int64_t)p) = make_float4(sm[0][p], sm[1][p], sm[2][p], sm[3][p]);
+      if (p < npx) az_st_stream(dst + 4 * (int64_t)p, make_float4(sm[0][p], sm[1][p], sm[2][p], sm[3][p]));
     }
     __syncthreads();
   }

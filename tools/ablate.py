@@ -112,6 +112,31 @@ VARIANTS["ax_nosplitp"] = [
 VARIANTS["ax_novt"] = [("attention.hip", "          if constexpr (VT4) {\n            // 4 x 4 transpose among the four lanes", "          if constexpr (false) {\n          } else if constexpr (VT4 && false) {\n            // 4 x 4 transpose among the four lanes"),
                        ("attention.hip", "            unsigned short* vt = Vt + pl * VPL + (lc * 4) * VLS + pos;\n            vt[0] = (unsigned short)(v3[pl][0] & 0xFFFFu);", "            unsigned short* vt = Vt + pl * VPL + (lc * 4) * VLS + pos;\n            if (false) vt[0] = (unsigned short)(v3[pl][0] & 0xFFFFu);")]
 
+# ---- streaming (HBM-bound) kernels and non-temporal accesses (RESULTS STAY CORRECT: only the cache policy changes); measured by
+#      tools/stream_ab.py -> profiles/r05_stream_nt_ab.txt.  The transition kernels ship with nt loads and stores (common.h:
+#      az_ld_stream / az_st_stream); az_affine_act_f32 ships plain.
+VARIANTS["tr_plain"] = [  # the transition kernels as before: plain loads and stores
+    ("common.h", "  const az_f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const az_f32x4_t*>(p));", "  const az_f32x4_t v = *reinterpret_cast<const az_f32x4_t*>(p);"),
+    ("common.h", "  __builtin_nontemporal_store(v, reinterpret_cast<az_f32x4_t*>(p));", "  *reinterpret_cast<az_f32x4_t*>(p) = v;")]
+VARIANTS["tr_ntld"] = VARIANTS["tr_plain"][1:]  # nt loads, plain stores
+VARIANTS["tr_ntst"] = VARIANTS["tr_plain"][:1]  # plain loads, nt stores
+VARIANTS["tr_un8"] = [("transition.hip", "constexpr int TF_UN = 4;", "constexpr int TF_UN = 8;")]  # 8 float4 per thread and stream in flight
+VARIANTS["tr_un2"] = [("transition.hip", "constexpr int TF_UN = 4;", "constexpr int TF_UN = 2;")]
+VARIANTS["tr_grid2k"] = [("transition.hip", "  const int64_t gcap = 16384 / gy < 1 ? 1 : 16384 / gy;", "  const int64_t gcap = 2048 / gy < 1 ? 1 : 2048 / gy;")]  # 8 resident workgroups per CU, grid-stride
+# the matrix kernels' output stores (epilogue_batch_nhwc: every Winograd / GEMM launch without a special epilogue) ship as non-temporal
+# stores; this variant restores plain stores
+VARIANTS["epi_plainst"] = [("conv_shared.h", "    if (n[i] >= 0) az_st_stream(a.dst + (int64_t)n[i] * a.cout_s + co, f);\n    if constexpr (MOM) {",
+                            "    if (n[i] >= 0) *reinterpret_cast<float4*>(a.dst + (int64_t)n[i] * a.cout_s + co) = f;\n    if constexpr (MOM) {")]
+# the x3 Winograd kernel's filter stream with the non-temporal hint (aux = 2): the small-map layers read every filter byte once or twice
+VARIANTS["wx3_unt"] = [("wino_x3.hip", "ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
+                        "ua[ch][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(u_lane + (unsigned)((ch * 3 + pl) * 1024)), (int)soff, 2));")]
+_AF_LD = [("norm.hip", "  if (x1 == nullptr) return *reinterpret_cast<const float4*>(x + pix * cs + c);", "  if (x1 == nullptr) return az_ld_stream(x + pix * cs + c);")]
+_AF_ST = [("norm.hip", "    for (int u = 0; u < UN; ++u) yb[(int64_t)(p + u * pstride) * q] = apply(v[u]);",
+           "    for (int u = 0; u < UN; ++u) az_st_stream(reinterpret_cast<float*>(yb + (int64_t)(p + u * pstride) * q), apply(v[u]));")]
+VARIANTS["aff_ntld"] = _AF_LD
+VARIANTS["aff_ntst"] = _AF_ST
+VARIANTS["aff_nt"] = _AF_LD + _AF_ST
+
 
 def build(name: str, patches=None, regen_env=None, head_files=None) -> str:
     r"""`patches`: a substitution list instead of VARIANTS[name]; `regen_env`: generator overrides (KL_* / KG_*) -- the copy's
@@ -140,6 +165,8 @@ def build(name: str, patches=None, regen_env=None, head_files=None) -> str:
         assert text.count(old) == 1, f"{name}: pattern occurs {text.count(old)} times in {f}: {old[:60]!r}"
         open(path, "w").write(text.replace(old, new))
         touched.add(f)
+    if any(f.endswith((".h", ".inc")) for f in touched):  # a patched header: every translation unit is rebuilt from the copy
+        touched |= set(B.SOURCES)
     objs = []
     procs = []
     for s in B.SOURCES:
