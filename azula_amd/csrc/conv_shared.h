@@ -176,6 +176,12 @@ __device__ __forceinline__ void epilogue_batch_nhwc(const AzConvArgs& a, const i
   // unconditional load (from the filter when there is no bias; the value is then unused): a load inside a branch is
   // waited for at the end of that branch, one more round trip in front of the gate / residual reads
   const float4 bv = ld4(has_bias ? a.bias + co : reinterpret_cast<const float*>(a.weight));
+  // Outputs that cannot fit the 256 MiB Infinity Cache (the 256^2 levels of the UNets at batch 4, every large map at batch 32)
+  // leave with non-temporal stores: the consumer has to fetch them from HBM anyway, and the hint keeps them from evicting what
+  // can stay (same box, plain -> hinted: C2 17.07 / 17.10 -> 17.01 / 17.03 ms per denoise step, C5 32.25 / 32.28 -> 32.20 / 32.17).
+  // Smaller outputs -- the token GEMMs of the transformers, whose consumer follows at once -- keep the default policy (with
+  // the hint on everything DiT-B/2 lost 0.1 - 0.3 %: profiles/r05_stream_nt_ab.txt).
+  const bool stream_out = (int64_t)a.batch * a.hout * a.wout * a.cout_s >= ((int64_t)64 << 20);
   float4 g[NB], r[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
@@ -224,8 +230,11 @@ __device__ __forceinline__ void epilogue_batch_nhwc(const AzConvArgs& a, const i
       f.z += r[i].z;
       f.w += r[i].w;
     }
-    // (non-temporal store: the output is not re-read by this launch; measured - 0.3 % of a C2 step, - 0.55 % of C5: profiles/r05_stream_nt_ab.txt)
-    if (n[i] >= 0) az_st_stream(a.dst + (int64_t)n[i] * a.cout_s + co, f);
+    if (n[i] >= 0) {
+      float* d = a.dst + (int64_t)n[i] * a.cout_s + co;
+      if (stream_out) az_st_stream(d, f);
+      else *reinterpret_cast<float4*>(d) = f;
+    }
     if constexpr (MOM) {  // GroupNorm statistics of the output come from here (gn_quads; the host admits no skipped pixel)
       if (i == 0) mom[0] = f.x;
       const float d0 = f.x - mom[0], d1 = f.y - mom[0], d2 = f.z - mom[0], d3 = f.w - mom[0];
