@@ -112,6 +112,30 @@ VARIANTS["ax_nosplitp"] = [
 VARIANTS["ax_novt"] = [("attention.hip", "          if constexpr (VT4) {\n            // 4 x 4 transpose among the four lanes", "          if constexpr (false) {\n          } else if constexpr (VT4 && false) {\n            // 4 x 4 transpose among the four lanes"),
                        ("attention.hip", "            unsigned short* vt = Vt + pl * VPL + (lc * 4) * VLS + pos;\n            vt[0] = (unsigned short)(v3[pl][0] & 0xFFFFu);", "            unsigned short* vt = Vt + pl * VPL + (lc * 4) * VLS + pos;\n            if (false) vt[0] = (unsigned short)(v3[pl][0] & 0xFFFFu);")]
 
+# ---- gate for a 128-cout x 32-tile block of the x3 Winograd kernel: timing only, WRONG results.  The producer side
+#      (gather, staging, B^T d B, V stores) runs in the EVEN cout blocks only (= once per two cout blocks, what a 128-cout block would
+#      do); the consumer side reads and splits ONE tile half and feeds it to both (= a V fragment serving four cout quarters).  Not in
+#      the gate: the filter fragment loads per MFMA double in that form (tools/ablate.py wx3_nou prices them).
+_G_PROD = [
+    ("wino_x3.hip", "  const int cb = (rect - rrow * rcols) * p.gc + rin_c;\n", "  const int cb = (rect - rrow * rcols) * p.gc + rin_c;\n  const bool prod = !(cb & 1);\n"),
+    ("wino_x3.hip", "    if (m < 5 || m < ndma) {  // (uniform; a block always has at least 520 slots = 4.06 pieces per thread)", "    if (prod && (m < 5 || m < ndma)) {"),
+    ("wino_x3.hip", "    if (m < 5 || m < ndma) *reinterpret_cast<float4*>(smem + X_STAGE + (m * 512 + tid) * 16) = gq[m];", "    if (prod && (m < 5 || m < ndma)) *reinterpret_cast<float4*>(smem + X_STAGE + (m * 512 + tid) * 16) = gq[m];"),
+    ("wino_x3.hip", "  auto patch_rows = [&](int kt, int r0, int r1) __attribute__((always_inline)) {  // rows [r0, r1) of the staged patch -> rv\n", "  auto patch_rows = [&](int kt, int r0, int r1) __attribute__((always_inline)) {\n    if (!prod) return;\n"),
+    ("wino_x3.hip", "    const f32x2 d0 = rv[c], d1 = rv[4 + c], d2 = rv[8 + c], d3 = rv[12 + c];\n", "    if (!prod) return;\n    const f32x2 d0 = rv[c], d1 = rv[4 + c], d2 = rv[8 + c], d3 = rv[12 + c];\n"),
+    ("wino_x3.hip", "    const f32x2 u0 = rv[4 * xi], u1 = rv[4 * xi + 1], u2 = rv[4 * xi + 2], u3 = rv[4 * xi + 3];\n", "    if (!prod) return;\n    const f32x2 u0 = rv[4 * xi], u1 = rv[4 * xi + 1], u2 = rv[4 * xi + 2], u3 = rv[4 * xi + 3];\n"),
+    ("wino_x3.hip", "    if constexpr (AFF != 0) {\n#pragma unroll\n      for (int i = 0; i < 16; ++i) {\n        f32x2 v = rv[i] * af_sc + af_sh;", "    if constexpr (AFF != 0) {\n      if (!prod) return;\n#pragma unroll\n      for (int i = 0; i < 16; ++i) {\n        f32x2 v = rv[i] * af_sc + af_sh;"),
+]
+_G_CONS = [
+    ("wino_x3.hip", "    const char* vb = smem + hs * X_HALF + fragB + th * (32 * X_ROW);\n", "    if (th == 1) return;\n    const char* vb = smem + hs * X_HALF + fragB + th * (32 * X_ROW);\n"),
+    ("wino_x3.hip", "  auto piece = [&](int th, int pl) __attribute__((always_inline)) {  // piece pl = the high halves of the current remainders\n",
+     "  auto piece = [&](int th, int pl) __attribute__((always_inline)) {\n    if (th == 1) { for (int j = 0; j < 4; ++j) fw[1][pl][j] = fw[0][pl][j]; return; }\n"),
+    ("wino_x3.hip", "  auto remainder = [&](int th, int j0, int j1) __attribute__((always_inline)) {  // x -= its high 16 bits (exact), values 2 j0 .. 2 j1 - 1\n",
+     "  auto remainder = [&](int th, int j0, int j1) __attribute__((always_inline)) {\n    if (th == 1) return;\n"),
+]
+VARIANTS["wx3_g_halfprod"] = _G_PROD
+VARIANTS["wx3_g_halfcons"] = _G_CONS
+VARIANTS["wx3_g_128x32"] = _G_PROD + _G_CONS
+
 # ---- streaming (HBM-bound) kernels and non-temporal accesses (RESULTS STAY CORRECT: only the cache policy changes); measured by
 #      tools/stream_ab.py -> profiles/r05_stream_nt_ab.txt.  The transition kernels ship with nt loads and stores (common.h:
 #      az_ld_stream / az_st_stream); az_affine_act_f32 ships plain.
