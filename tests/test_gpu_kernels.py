@@ -429,6 +429,30 @@ def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk, wino):
     assert (y.buf.reshape(B, y.H, y.W, y.cs)[..., Cout:] == 0).all()
 
 
+@pytest.mark.parametrize("wino", [False, True, "x3", "wx3"])
+def test_conv2d_output_beyond_the_infinity_cache(az, wino):
+    """An output of 256 MiB (1 x 512 x 512 x 256 fp32): from this size on the plain epilogue stores with the non-temporal hint
+    (conv_shared.h: stream_out -- the output cannot stay in the Infinity Cache for its consumer).  Same bound as every other
+    3 x 3 case; the store policy must not change a value."""
+    from azula_amd.engine import Act, Builder
+
+    B, Cin, Cout, H, W = 1, 32, 256, 512, 512
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, padding=1)
+    bld = Builder(torch.device("cuda"))
+    xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
+    y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, winograd=wino)
+    assert bld.tape.ops[-1][2] == WINO_NAME[wino]
+    assert B * y.H * y.W * y.cs * 4 >= 256 << 20
+    bld.finish()
+    bld.tape.run()
+    out = from_nhwc(y.buf.reshape(B, y.H, y.W, y.cs), Cout)
+    assert max_err(out, ref) < conv_tol(Cin, 3, wino), max_err(out, ref)
+
+
 @pytest.mark.parametrize("wino", [False, True, 4, "x3", "wx3"])
 def test_conv2d_random_shapes(az, wino):
     """Seeded sweep over ragged shapes (odd sizes, channel counts off the 4 / 8 / 32 grids, batch 1-3, optional second
