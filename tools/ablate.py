@@ -132,6 +132,10 @@ _G_CONS = [
     ("wino_x3.hip", "  auto remainder = [&](int th, int j0, int j1) __attribute__((always_inline)) {  // x -= its high 16 bits (exact), values 2 j0 .. 2 j1 - 1\n",
      "  auto remainder = [&](int th, int j0, int j1) __attribute__((always_inline)) {\n    if (th == 1) return;\n"),
 ]
+# half of the filter-fragment loads (cout half 1 reuses cout half 0's fragments: operands stay random, unlike wx3_nou): its time
+# change x 2 = what the filter stream costs the kernel
+VARIANTS["wx3_halfu"] = [("wino_x3.hip", "    for (int ch = 0; ch < 2; ++ch) ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
+                          "    for (int ch = 0; ch < 1; ++ch) ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));\n    ua[1][pl] = ua[0][pl];")]
 VARIANTS["wx3_g_halfprod"] = _G_PROD
 VARIANTS["wx3_g_halfcons"] = _G_CONS
 VARIANTS["wx3_g_128x32"] = _G_PROD + _G_CONS
