@@ -15,7 +15,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# AZULA_AMD_LIB: an alternative build of the same C ABI (kernel A/B experiments: tools/ab_build.py)
+# AZULA_AMD_LIB: an alternative build of the same C ABI (kernel A/B experiments: tools/ablate.py)
 LIB_PATH = os.environ.get("AZULA_AMD_LIB") or os.path.join(_HERE, "csrc", "libazula_amd.so")
 
 c_f32p = C.c_void_p  # device pointers travel as integers

@@ -22,6 +22,26 @@ static inline int az_launch_status() {
 
 static inline hipStream_t az_s(az_stream_t s) { return (hipStream_t)s; }
 
+// A/B switches of the launchers (kernel-selection overrides used by tools/ and a few tests) are honoured ONLY under the explicit
+// debug switch AZ_DEBUG_AB: a stray variable in a production environment never steers kernel selection.
+#include <stdlib.h>
+static inline const char* az_ab_env(const char* name) { return getenv("AZ_DEBUG_AB") ? getenv(name) : nullptr; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set once per (kernel, device), lock-free and
+// safe from several host threads (the launchers keep no other mutable state).  `mask` = one static std::atomic per kernel, bit d =
+// device d done (devices >= 64 simply set the attribute on every launch: it is idempotent).
+#include <atomic>
+static inline hipError_t az_max_dynamic_lds(const void* fn, int bytes, std::atomic<uint64_t>& mask) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = (unsigned)dev < 64u ? (1ull << dev) : 0ull;
+  if (bit && (mask.load(std::memory_order_acquire) & bit)) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && bit) mask.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+
 // Separately rounded fp32 ops: the compiler may not contract these into FMAs, so a chain
 // written with them reproduces torch's eager op-by-op rounding bit for bit.
 __device__ __forceinline__ float az_mul(float a, float b) { return __fmul_rn(a, b); }

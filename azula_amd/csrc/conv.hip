@@ -2440,7 +2440,7 @@ static int x3_big_plan(const AzConvArgs* a, int64_t npix, int* splitk, int kstep
   *splitk = 1;
   if (ct) *ct = GB;
   if (!x3_big_eligible(a, npix, kstep)) return 0;
-  const char* force = getenv("AZ_DEBUG_AB") ? getenv("AZ_X3_BIG") : nullptr;  // (A/B override: only under the explicit debug switch AZ_DEBUG_AB)
+  const char* force = az_ab_env("AZ_X3_BIG");  // (A/B override: only under the explicit debug switch AZ_DEBUG_AB)
   const int all = (a->cout_s + GB - 1) / GB;
   const bool ok192 = ct != nullptr && kstep == GBK && a->act <= 3 && !x3_big_taps(a);
   const int all192 = (a->cout_s + 191) / 192;
@@ -2635,7 +2635,7 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   // (see conv_igemm_kernel); AZ_IGEMM_K16 = 0 / 1 forces the choice (A/B measurements)
   bool k16 = false;
   if (!half) {
-    const char* force = getenv("AZ_IGEMM_K16");  // read per call: tests flip it between plans
+    const char* force = az_ab_env("AZ_IGEMM_K16");  // read per call: tests flip it between plans (only under AZ_DEBUG_AB)
     int sk = a->splitk;
     const int64_t nk32 = (int64_t)a->ksize * a->ksize * ((a->c0s + BK - 1) / BK + (a->c1s + BK - 1) / BK);
     if (sk > nk32) sk = (int)nk32;
@@ -2652,7 +2652,7 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     // one tap, whole 32-channel K tiles: the K-32 kernel runs its hand-scheduled K loop (igemm_kloop.inc), which keeps the
     // matrix pipe busy from ONE workgroup per CU as well -- it beats the K-16 instantiation on the badly quantised shapes too
     // (768 -> 768: 178 vs 184 us, 768 -> 2304: 492 vs 519 us).  AZ_IGEMM_ASM=0: the C++ K loop everywhere (A/B measurements)
-    const char* asm_env = getenv("AZ_IGEMM_ASM");
+    const char* asm_env = az_ab_env("AZ_IGEMM_ASM");
     const bool asm_ok = a->ksize == 1 && a->c0s % BK == 0 && a->c1s % BK == 0 && !(asm_env && asm_env[0] == '0');
     // several taps: the stream's taps variant (pixel-row offsets linear in the tap + a validity mask per row); it needs ONE
     // source, no upsampling, zero padding, isotropic strides, at most 32 taps, and pays from 16 stages per split-K slice on
@@ -2773,18 +2773,15 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
   if (prc != AZ_OK) return prc;
   hipStream_t st = az_s(stream);
   const int64_t nwg = (int64_t)p.cblocks * p.tblocks;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_winograd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       W_LDS_BYTES);
+  {
+    static std::atomic<uint64_t> lds_c{0}, lds_s{0};  // (per kernel, one bit per device: common.h)
+    hipError_t e = az_max_dynamic_lds((const void*)conv_winograd_kernel<false>, W_LDS_BYTES, lds_c);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)conv_winograd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            W_LDS_BYTES + W_VOFF_BYTES);
+    e = az_max_dynamic_lds((const void*)conv_winograd_kernel<true>, W_LDS_BYTES + W_VOFF_BYTES, lds_s);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   // AZ_WINOGRAD_ASM=0: the C++ K loop (A/B measurements); default: the hand-scheduled stream
-  const char* asm_env = getenv("AZ_WINOGRAD_ASM");
+  const char* asm_env = az_ab_env("AZ_WINOGRAD_ASM");
   if ((asm_env && asm_env[0] == '0') || (a->in_affine && a->in_act != 0))  // (the stream has the plain affine only)
     hipLaunchKernelGGL(conv_winograd_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), W_LDS_BYTES, st, p);
   else
@@ -2898,7 +2895,7 @@ static int wino_prepare(const AzConvArgs* a, int wk, int64_t ustage_bytes, WinoP
     // workgroup order (see the kernel): rectangles of gt x gc = 32 workgroups when both grid sides divide, cout blocks fastest
     // otherwise (gt = 1, gc = cblocks).  AZ_WINO_RECT="gt,gc" overrides (A/B runs); "1,0" = cout fastest everywhere.
     int env_gt = 0, env_gc = 0;  // (read per call like the other A/B switches: no unsynchronised static)
-    if (const char* e = getenv("AZ_WINO_RECT")) sscanf(e, "%d,%d", &env_gt, &env_gc);
+    if (const char* e = az_ab_env("AZ_WINO_RECT")) sscanf(e, "%d,%d", &env_gt, &env_gc);
     // (the x3 kernel's filter chunks are 1.5 x the fp32 stream's -- 6 B per value: two cout blocks per XCD keep a layer's chunks in its
     //  4 MB L2 where four thrash it: 16 x 2 measured 1 - 2 % ahead of 8 x 4 on the 256- and 512-channel layers, tools/wx3_rect_ab.sh)
     int gt = env_gt > 0 ? env_gt : 8, gc = env_gt > 0 ? (env_gc > 0 ? env_gc : p.cblocks) : (wk == 16 ? 2 : 4);
@@ -2983,12 +2980,10 @@ int az_conv2d_winograd4_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE((int64_t)p.nk * p.cblocks * W4U_STAGE * 4 <= (1ll << 31), AZ_E_SHAPE);
   const int64_t nwg = (int64_t)p.cblocks * p.tblocks;
   hipStream_t st = az_s(stream);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_winograd4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       W4_LDS * 4);
+  {
+    static std::atomic<uint64_t> lds4{0};
+    hipError_t e = az_max_dynamic_lds((const void*)conv_winograd4_kernel, W4_LDS * 4, lds4);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(conv_winograd4_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), W4_LDS * 4, st, p);
   int rc = az_launch_status();

@@ -578,12 +578,9 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
 // Launch (host side of az_conv2d_winograd_x3_f32, conv.hip validates the descriptor and fills `p` in 16-channel steps).
 template <int AFF, bool TAIL>
 static int launch_x3(const WinoP& p, unsigned splitk, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_winograd_x3_kernel<AFF, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_set{0};  // (one per instantiation, one bit per device: common.h)
+  hipError_t e = az_max_dynamic_lds((const void*)conv_winograd_x3_kernel<AFF, TAIL>, X_LDS_BYTES, lds_set);
+  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL((conv_winograd_x3_kernel<AFF, TAIL>), dim3((unsigned)((int64_t)p.cblocks * p.tblocks), splitk), dim3(512), X_LDS_BYTES,
                      st, p);
   return az_launch_status();

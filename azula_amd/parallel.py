@@ -44,12 +44,36 @@ def shard_range(batch: int, rank: int, world: int) -> range:
 
 @torch.no_grad()
 def init_sharded(sampler: Sampler, shape: Sequence[int], *, group=None, **kwargs) -> Tensor:
-    r"""This rank's slice of ``sampler.init(shape, **kwargs)``: the full batch is drawn on every
-    rank (same seed => same tensor) and sliced, matching the single-device draw."""
+    r"""This rank's slice of ``sampler.init(shape, **kwargs)``, matching the single-device draw sample for sample.  With the
+    reference's default ``mean`` / ``var`` (scalars, or tensors that broadcast over the batch axis) only the rank's own rows are
+    formed: ``Sampler.init`` is evaluated on the local shape with the noise drawn through ``Sampler._draw_noise`` -- on the GPU
+    the rank's elements of the full-batch Philox draw (``az_randn_slice_f32``; 1 / world of the work, no full-batch ``x_T``: 201 MB
+    for configs[3]), on the host the full draw sliced.  Per-sample ``mean`` / ``var`` tensors take the draw-everything-and-slice path."""
     rank, world = _world(group)
-    full = sampler.init(shape, **kwargs)
     r = shard_range(shape[0], rank, world)
-    return full[r.start : r.stop].contiguous()
+    mean, var = kwargs.get("mean", 0.0), kwargs.get("var", 1.0)
+    per_sample = any(torch.is_tensor(v) and v.ndim == len(shape) and v.shape[0] == shape[0] and shape[0] > 1 for v in (mean, var))
+    if world == 1 or per_sample:
+        full = sampler.init(shape, **kwargs)
+        return full[r.start : r.stop].contiguous()
+    to_kw = {k: v for k, v in kwargs.items() if k not in ("mean", "var")}
+    t_T = sampler.timesteps[0]
+    alpha_T, sigma_T = sampler.denoiser.schedule(t_T)
+    alpha_T, sigma_T = alpha_T.to(**to_kw), sigma_T.to(**to_kw)
+    if torch.is_tensor(mean):
+        mean = mean.to(**to_kw)
+    if torch.is_tensor(var):
+        var = var.to(**to_kw)
+    local = (len(r), *shape[1:])
+    mean_T, std_T = alpha_T * mean, torch.sqrt(alpha_T**2 * var + sigma_T**2)  # (reference azula/sample.py:121-128, same op order)
+    mean_T, std_T = mean_T.expand(local), std_T.expand(local)
+    prev = sampler.shard
+    sampler.shard = (rank, world)
+    try:
+        eps = sampler._draw_noise(torch.empty(local, dtype=mean_T.dtype, device=mean_T.device))
+    finally:
+        sampler.shard = prev
+    return mean_T + std_T * eps
 
 
 @torch.no_grad()

@@ -187,10 +187,14 @@ class ADMPlan:
             gn_stats, dst = kw.pop("gn_stats", False), kw.pop("dst_nchw", None)
             assert dst is None
             res, res_up = kw.pop("res", None), kw.pop("res_up", 0)
-            out = bld.conv(src, bld.pack_conv(w[:, :, 1], layer.bias, cin0=cin0), cout, res=res, res_up=res_up, depth=(D, 0), **kw)
-            for n_, j in enumerate((0, 2)):
+            # a depth tap that reads only padding (|j - 1| >= D: a single-plane volume) contributes zero and is not launched; the
+            # moments ride on the LAST tap that is
+            taps = [j for j in (0, 2) if abs(j - 1) < D]
+            out = bld.conv(src, bld.pack_conv(w[:, :, 1], layer.bias, cin0=cin0), cout, res=res, res_up=res_up, depth=(D, 0),
+                           gn_stats=gn_stats and not taps, **kw)
+            for j in taps:
                 bld.conv(src, bld.pack_conv(w[:, :, j], None, cin0=cin0), cout, res=out, out=out, depth=(D, j - 1),
-                         gn_stats=gn_stats and n_ == 1, **kw)
+                         gn_stats=gn_stats and j == taps[-1], **kw)
             return out
 
         c_first = net.input_blocks[0][0]

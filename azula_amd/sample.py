@@ -109,6 +109,14 @@ class Sampler(abc.ABC):
         which do not bump a tensor's version counter (ordinary in-place ops, ``load_state_dict``, ``.to()`` are tracked)."""
         self._fused_cache = {}
         _SMALL_VALUES.clear()
+        # the backbones keep their own plan caches -- packed (direct / bf16x3 / Winograd-domain) copies of the weights keyed on
+        # (shape, version, address), none of which a raw write changes: dropped too, so that the rebuilt loop repacks
+        den = getattr(self, "denoiser", None)
+        if isinstance(den, torch.nn.Module):
+            for m in den.modules():
+                plans = getattr(m, "_plans", None)
+                if isinstance(plans, dict):
+                    plans.clear()
 
     @torch.no_grad()
     def init(self, shape: Sequence[int], mean: float | Tensor = 0.0, var: float | Tensor = 1.0, **kwargs) -> Tensor:
@@ -158,7 +166,8 @@ class Sampler(abc.ABC):
         if self.shard is None:
             return torch.randn_like(like) if out is None else out.normal_()
         rank, world = self.shard
-        if like.is_cuda and like.dtype == torch.float32 and SLICED_NOISE and world * like.numel() < 2**31:
+        if (like.is_cuda and like.dtype == torch.float32 and SLICED_NOISE and world * like.numel() < 2**31
+                and _randn_slice_verified(like.device)):
             return _randn_slice(like, rank, world, out)  # this rank's elements of the full-batch draw only (bit-identical)
         full = torch.randn((world * like.shape[0], *like.shape[1:]), dtype=like.dtype, device=like.device)
         mine = full[rank * like.shape[0] : (rank + 1) * like.shape[0]]
@@ -470,6 +479,49 @@ def _kwargs_signature(kw) -> tuple:
     if torch.is_tensor(kw):
         return ("tensor", tuple(kw.shape))
     return ("value",)
+
+
+_SLICE_VERIFIED: dict = {}  # (device index, torch version) -> bool
+
+
+def _randn_slice_verified(dev: torch.device) -> bool:
+    r"""One-time self-check per (device, torch version): :func:`_randn_slice` re-derives ATen's launch policy (grid rule, unroll 4,
+    offset arithmetic) from the torch it was written against.  A torch whose policy differs would still hand out valid noise,
+    but the 1-GPU == N-GPU bit-reproducibility of ``parallel.py`` would break silently.  So the first sharded draw on a device
+    compares two slices -- a tensor under one grid's worth of elements and one that spans several grid iterations -- and the
+    generator's offset afterwards against ``torch.randn`` of the full shape, under a saved / restored generator state; on any
+    mismatch it warns once and every later sharded draw takes the draw-and-slice path."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, torch.__version__)
+    ok = _SLICE_VERIFIED.get(key)
+    if ok is None:
+        gen = torch.cuda.default_generators[idx]
+        saved = gen.get_state()
+        ok = True
+        try:
+            for total, world, rank in ((3 * 1000, 3, 1), (3 * (1 << 20) + 3 * 4096, 3, 2), (2 * 65536, 2, 0)):
+                gen.manual_seed(1234567)
+                gen.set_offset(8)
+                full = torch.randn(total, device=dev)
+                off_full = gen.get_offset()
+                gen.manual_seed(1234567)
+                gen.set_offset(8)
+                n = total // world
+                mine = _randn_slice(torch.empty(n, device=dev), rank, world)
+                ok = ok and gen.get_offset() == off_full and bool(torch.equal(mine, full[rank * n : (rank + 1) * n]))
+        except Exception:  # noqa: BLE001  (a generator API that moved: same verdict)
+            ok = False
+        finally:
+            gen.set_state(saved)
+        _SLICE_VERIFIED[key] = ok
+        if not ok:
+            import warnings
+
+            warnings.warn(
+                f"azula_amd: the sliced Philox draw does not reproduce torch.randn on torch {torch.__version__} (device {idx}); "
+                "sharded sampling falls back to drawing the full batch on every rank and slicing (same result, more work)",
+                RuntimeWarning, stacklevel=3)
+    return ok
 
 
 def _randn_slice(like: Tensor, rank: int, world: int, out: Tensor | None = None) -> Tensor:

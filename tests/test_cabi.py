@@ -113,6 +113,42 @@ def test_committed_kloop_streams_are_the_generators_output(monkeypatch):
     assert tracked.returncode != 0 or tracked.stdout.strip() == "", "build by-products are tracked: " + tracked.stdout
 
 
+def test_ablation_variants_apply_to_the_committed_sources():
+    r"""tools/ablate.py builds timing variants from textual substitutions on a COPY of csrc: every pattern of every variant must occur
+    exactly once in the committed sources (two variants had gone stale behind kernel edits, so profiles cited in
+    DESIGN could not be reproduced).  No compilation here -- only that the patches still apply."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("az_ablate", os.path.join(ROOT, "tools", "ablate.py"))
+    ab = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ab)
+    csrc = os.path.join(ROOT, "azula_amd", "csrc")
+    assert len(ab.VARIANTS) >= 40
+    for name, patches in ab.VARIANTS.items():
+        texts: dict = {}
+        for f, old, new in patches:
+            t = texts[f] if f in texts else open(os.path.join(csrc, f)).read()
+            assert t.count(old) == 1, f"variant {name}: pattern occurs {t.count(old)} times in {f}: {old[:70]!r}"
+            texts[f] = t.replace(old, new)
+
+
+def test_no_ungated_environment_switch_in_the_launchers():
+    r"""kernel selection reads the environment only through az_ab_env (honoured under AZ_DEBUG_AB), and the
+    launchers keep no unsynchronised static flag (the LDS attribute is set per (kernel, device) through an atomic mask)."""
+    import re
+
+    csrc = os.path.join(ROOT, "azula_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h", ".inc")):
+            continue
+        text = open(os.path.join(csrc, f)).read()
+        code = re.sub(r"//[^\n]*", "", text)
+        n_env = len(re.findall(r"\bgetenv\s*\(", code))
+        assert n_env == (2 if f == "common.h" else 0), (f, n_env)  # (common.h: az_ab_env itself)
+        assert not re.search(r"static\s+bool\s+\w+\s*=\s*false", code), f
+        assert "hipFuncSetAttribute" not in code or f == "common.h", f
+
+
 def test_bf16x3_tile_plan_on_the_host(built_lib, monkeypatch):
     """az_conv2d_x3_suggest_splitk is host arithmetic (no device): it pins the 256 x 256-tile plan of the bf16x3 token GEMMs --
     one workgroup per CU, so whole rounds of the 256 CUs, never a split of a grid that already fills 0.75 of a round, a split

@@ -239,6 +239,24 @@ def test_adm_on_volumes(golden, name):
     assert post.mean.shape == g["x1"].shape and torch.isfinite(post.mean).all()
 
 
+@pytest.mark.parametrize("name", ["adm_3d_plain_conv", "adm_3d_film_updown"])
+def test_adm_on_a_single_plane_volume(golden, name):
+    """a (B, C, 1, H, W) volume -- the outer depth taps of every Conv3d(padding=1) read only padding (reference:
+    torch.nn.Conv3d accepts it, plugins/adm/_src/nn.py:9-39).  The build launches the centre tap only (an out-of-volume tap is
+    rejected by the C ABI); checked against the oracle on the same weights."""
+    g = golden("g23_" + name)
+    den, sd, cfg = build(g)
+    x = g["x"][:, :, :1].contiguous()
+    assert x.ndim == 5 and x.shape[2] == 1
+    y = g["y"] if "y" in g else None
+    ref = nets.adm_unet_forward(sd, cfg, x, g["idx"], y)
+    out = den.backbone(x.cuda(), g["idx"].cuda(), y=None if y is None else y.cuda())
+    assert out.shape == ref.shape
+    err, sc = max_err(out, ref), ref.abs().max().item()
+    print(name, "depth 1: backbone max|d|", err, "scale", sc)
+    assert err < 1e-5 * max(1.0, sc)
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_adm_fractional_timesteps(golden, name):
     """UNetModel.forward with FRACTIONAL timesteps (plugins/adm/_src/nn.py:90-108): the sinusoid is evaluated on the device

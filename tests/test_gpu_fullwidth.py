@@ -180,6 +180,7 @@ def test_dit_b2_full_width_against_the_oracle(dit_b2, k16, monkeypatch):
     if k16 is None:
         monkeypatch.delenv("AZ_IGEMM_K16", raising=False)
     else:
+        monkeypatch.setenv("AZ_DEBUG_AB", "1")  # (A/B overrides are honoured only under the debug switch)
         monkeypatch.setenv("AZ_IGEMM_K16", k16)
     net = den.backbone.net
     net._plans.clear()
@@ -206,6 +207,7 @@ def test_jit_b16_full_width_against_the_oracle(k16, monkeypatch):
     if k16 is None:
         monkeypatch.delenv("AZ_IGEMM_K16", raising=False)
     else:
+        monkeypatch.setenv("AZ_DEBUG_AB", "1")  # (A/B overrides are honoured only under the debug switch)
         monkeypatch.setenv("AZ_IGEMM_K16", k16)
     cfg = dict(bench.CONFIGS["c6"])
     den = bench.build_denoiser(cfg, torch.device("cuda"))

@@ -727,6 +727,7 @@ def test_winograd_input_affine(az, asm, in_act, monkeypatch):
 
     mode = "wx3" if asm == "wx3" else True  # ("wx3": the bf16-pipe kernel, csrc/wino_x3.hip)
     if mode is True:
+        monkeypatch.setenv("AZ_DEBUG_AB", "1")  # (A/B overrides are honoured only under the debug switch)
         monkeypatch.setenv("AZ_WINOGRAD_ASM", asm)
     rnd = random.Random(77 + in_act)
     g = torch.Generator().manual_seed(77 + in_act)

@@ -149,6 +149,50 @@ def test_invalidate_after_a_raw_write(golden):
     assert torch.equal(b, fresh) and not torch.equal(a, b)
 
 
+def test_invalidate_after_a_raw_weight_write(golden):
+    """`.data.copy_()` on a convolution weight changes neither `_version` nor `data_ptr()`, so the backbone's
+    own plan cache (packed direct / bf16x3 / Winograd-domain filters) would survive a rebuilt sampler loop: `invalidate()` drops
+    those caches too, and the next call equals a freshly built denoiser with the new weights."""
+    from azula_amd.sample import DDIMSampler
+
+    g = golden("g6_unet_loop")
+    x1 = g["x1"].cuda()
+    den, _ = _unet_denoiser(g)
+    smp = DDIMSampler(den, steps=8, silent=True)
+    a = smp(x1)
+    convs = [m for m in den.modules() if isinstance(getattr(m, "weight", None), torch.nn.Parameter) and m.weight.ndim == 4 and m.weight.shape[-1] == 3]
+    w = convs[len(convs) // 2].weight
+    v0, p0 = w._version, w.data_ptr()
+    w.data.copy_(w.data * 1.5 + 0.01)
+    assert (w._version, w.data_ptr()) == (v0, p0)  # (invisible to every plan key)
+    assert torch.equal(smp(x1), a)  # documented: the stale plan is still in use ...
+    smp.invalidate()                # ... until the caller says so
+    b = smp(x1)
+    den2, _ = _unet_denoiser(g)
+    den2.load_state_dict(den.state_dict())
+    fresh = DDIMSampler(den2, steps=8, silent=True)(x1)
+    assert torch.equal(b, fresh) and not torch.equal(a, b)
+
+
+def test_invalidate_after_a_raw_weight_write_adm():
+    from azula_amd.sample import DDIMSampler
+
+    den, _ = _small_cond_adm()
+    torch.manual_seed(1)
+    x1 = torch.randn(2, 3, 16, 16, device="cuda")
+    lab = torch.tensor([1, 2], device="cuda")
+    smp = DDIMSampler(den, steps=4, silent=True)
+    a = smp(x1, label=lab)
+    w = den.backbone.input_blocks[1][0].in_layers[2].weight
+    w.data.copy_(w.data * 1.5 + 0.01)
+    smp.invalidate()
+    b = smp(x1, label=lab)
+    den2, _ = _small_cond_adm()
+    den2.load_state_dict(den.state_dict())
+    fresh = DDIMSampler(den2, steps=4, silent=True)(x1, label=lab)
+    assert torch.equal(b, fresh) and not torch.equal(a, b)
+
+
 def _small_cond_adm():
     from azula_amd.guidance import CFGDenoiser
     from azula_amd.plugins import adm

@@ -71,11 +71,12 @@ VARIANTS["wx3_tl"] = [
      "      tl1 = __builtin_readcyclecounter();\n      mf(hs, 12); gl(ktn, 2); gl(ktn, 3); remainder(0, 2, 4); XS_FENCE;\n"),
     ("wino_x3.hip", "      mf(hs, 12); patch_rows(ktn, 0, 2); XS_FENCE;\n",
      "      tl1 = __builtin_readcyclecounter();\n      mf(hs, 12); patch_rows(ktn, 0, 2); XS_FENCE;\n"),
-    ("wino_x3.hip", "    load_u(ktu, ob, 0);\n    // the NEXT phase's fragments: its buffer is complete behind the barrier\n    __syncthreads();\n    frag_read(ob, 0); frag_read(ob, 1);\n    XS_FENCE;\n",
-     "    const unsigned long long tl2 = __builtin_readcyclecounter();\n    load_u(ktu, ob, 0);\n    const unsigned long long tl3 = __builtin_readcyclecounter();\n"
+    ("wino_x3.hip", "    load_u(ktu, ob, 0);\n    // the NEXT phase's fragments",
+     "    const unsigned long long tl2 = __builtin_readcyclecounter();\n    load_u(ktu, ob, 0);\n    const unsigned long long tl3 = __builtin_readcyclecounter();\n    // the NEXT phase's fragments"),
+    ("wino_x3.hip", "    __syncthreads();\n    frag_read(ob, 0); frag_read(ob, 1);\n    XS_FENCE;\n  };\n",
      "    __syncthreads();\n    frag_read(ob, 0); frag_read(ob, 1);\n    XS_FENCE;\n"
      "    const unsigned long long tl4 = __builtin_readcyclecounter();\n"
-     "    tlacc[hs][0] += (unsigned)(tl1 - tl0); tlacc[hs][1] += (unsigned)(tl2 - tl1); tlacc[hs][2] += (unsigned)(tl3 - tl2); tlacc[hs][3] += (unsigned)(tl4 - tl3);\n"),
+     "    tlacc[hs][0] += (unsigned)(tl1 - tl0); tlacc[hs][1] += (unsigned)(tl2 - tl1); tlacc[hs][2] += (unsigned)(tl3 - tl2); tlacc[hs][3] += (unsigned)(tl4 - tl3);\n  };\n"),
     ("wino_x3.hip", "  __syncthreads();\n#undef XS_FENCE\n",
      "  __syncthreads();\n#undef XS_FENCE\n  const unsigned long long tl_loop = __builtin_readcyclecounter();\n"),
     ("wino_x3.hip", "  if (a.gn_quads == nullptr) {\n    epilogue_store_batch<8>(a, on, ob, co, ov, (int64_t)blockIdx.y * p.npix);\n",
@@ -109,8 +110,7 @@ VARIANTS["ax_nosplitp"] = [
     ("attention.hip", "        for (int j = 0; j < 4; ++j) az_split3(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1], p3[0][j], p3[1][j], p3[2][j]);",
      "        for (int j = 0; j < 4; ++j) p3[0][j] = p3[1][j] = p3[2][j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sacc[8 * s2 + 2 * j + 1]), __builtin_bit_cast(unsigned, sacc[8 * s2 + 2 * j]), 0x07060302u);"),
 ]
-VARIANTS["ax_novt"] = [("attention.hip", "          if constexpr (VT4) {\n            // 4 x 4 transpose among the four lanes", "          if constexpr (false) {\n          } else if constexpr (VT4 && false) {\n            // 4 x 4 transpose among the four lanes"),
-                       ("attention.hip", "            unsigned short* vt = Vt + pl * VPL + (lc * 4) * VLS + pos;\n            vt[0] = (unsigned short)(v3[pl][0] & 0xFFFFu);", "            unsigned short* vt = Vt + pl * VPL + (lc * 4) * VLS + pos;\n            if (false) vt[0] = (unsigned short)(v3[pl][0] & 0xFFFFu);")]
+# (ax_novt -- the scattered V^T store of round 4 -- went with that code: V is staged row-major and consumed through ds_read_b64_tr_b16)
 
 # ---- gate for a 128-cout x 32-tile block of the x3 Winograd kernel: timing only, WRONG results.  The producer side
 #      (gather, staging, B^T d B, V stores) runs in the EVEN cout blocks only (= once per two cout blocks, what a 128-cout block would
@@ -136,6 +136,28 @@ _G_CONS = [
 # change x 2 = what the filter stream costs the kernel
 VARIANTS["wx3_halfu"] = [("wino_x3.hip", "    for (int ch = 0; ch < 2; ++ch) ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
                           "    for (int ch = 0; ch < 1; ++ch) ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));\n    ua[1][pl] = ua[0][pl];")]
+# ---- gate for F(4x4,3x3) on the split operands (tools/f4_gate.py): timing only, WRONG results.  Launched on a map of
+#      0.75 x 0.75 the size, the shipped F(2x2) stream executes exactly the (tile x frequency) work of F(4x4) on the full map: 36 / 16
+#      frequencies x 1 / 4 of the tiles = 0.5625 of the matrix instructions, V values (patch reads, transforms, V stores, fragment reads,
+#      splits).  What F(4x4) pays on top PER V VALUE is in this variant: the 6 x 6 transform's 4.0 packed operations per value instead
+#      of 2.0 (one more packed add behind every add of B^T d and of the nu side), and TWICE the filter fragment bytes per matrix
+#      instruction (a 64-cout x 32-tile block: the 295 KB of accumulators of 36 frequencies allow no more; second load 48 KB further
+#      on, merged through an opaque zero so that it cannot be dropped).
+VARIANTS["wx3_f4proxy"] = [
+    ("wino_x3.hip", "  f32x2 rv[16];  // raw 4x4 patch of the channel pair (index = patch row * 4 + column), then B^T d in place\n",
+     "  f32x2 rv[16];\n  float zq;\n  asm volatile(\"v_mov_b32 %0, 0\" : \"=v\"(zq));\n  const f32x2 z2 = {zq, zq};\n  const unsigned zu = __builtin_bit_cast(unsigned, zq);\n"),
+    ("wino_x3.hip", "    rv[c] = d0 - d2;\n    rv[4 + c] = d1 + d2;\n    rv[8 + c] = d2 - d1;\n    rv[12 + c] = d1 - d3;\n",
+     "    rv[c] = (d0 - d2) + z2;\n    rv[4 + c] = (d1 + d2) + z2;\n    rv[8 + c] = (d2 - d1) + z2;\n    rv[12 + c] = (d1 - d3) + z2;\n"),
+    ("wino_x3.hip", "    *reinterpret_cast<f32x2*>(dst) = hs == 0 ? u0 - u2 : u2 - u1;\n    *reinterpret_cast<f32x2*>(dst + X_FREQ) = hs == 0 ? u1 + u2 : u1 - u3;\n",
+     "    *reinterpret_cast<f32x2*>(dst) = (hs == 0 ? u0 - u2 : u2 - u1) + z2;\n    *reinterpret_cast<f32x2*>(dst + X_FREQ) = (hs == 0 ? u1 + u2 : u1 - u3) + z2;\n"),
+    ("wino_x3.hip", "    for (int ch = 0; ch < 2; ++ch) ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
+     "    for (int ch = 0; ch < 2; ++ch) {\n      uint4 r0 = __builtin_bit_cast(uint4, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));\n"
+     "      const uint4 r1 = __builtin_bit_cast(uint4, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff + 49152u));\n"
+     "      r0.x |= r1.x & zu; r0.y |= r1.y & zu; r0.z |= r1.z & zu; r0.w |= r1.w & zu;\n      ua[ch][pl] = __builtin_bit_cast(bf16x8, r0);\n    }"),
+]
+# the same with only one of the two surcharges (which one costs what)
+VARIANTS["wx3_f4proxy_adds"] = VARIANTS["wx3_f4proxy"][:3]
+VARIANTS["wx3_f4proxy_u"] = [VARIANTS["wx3_f4proxy"][0], VARIANTS["wx3_f4proxy"][3]]
 VARIANTS["wx3_g_halfprod"] = _G_PROD
 VARIANTS["wx3_g_halfcons"] = _G_CONS
 VARIANTS["wx3_g_128x32"] = _G_PROD + _G_CONS
