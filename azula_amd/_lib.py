@@ -209,6 +209,7 @@ class AzAttnArgs(C.Structure):
         ("scale", C.c_float),
         ("qk_rmsnorm", C.c_int32),
         ("eps", C.c_float),
+        ("norm_dim", C.c_int32),
         ("rope_cos", c_f32p),
         ("rope_sin", c_f32p),
         ("q_weight", c_f32p),

@@ -30,6 +30,11 @@ struct AttnP {
 // key index inside a 32-key tile held by accumulator register r of a lane in half h
 __device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// channels the q / k RMS norm averages over: the head size, or the REAL head size of a head that the host zero-padded to an
+// instantiated one (AzAttnArgs.norm_dim; the same division, so an unpadded head rounds as before)
+template <int D>
+__device__ __forceinline__ float az_norm_dim(const AzAttnArgs& a) { return a.norm_dim > 0 ? (float)a.norm_dim : (float)D; }
+
 template <int D>
 __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
   constexpr int DP = (D + 31) / 32 * 32;  // padded head dim (whole 32-wide O^T tiles)
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
     float f = a.scale * 1.4426950408889634f;
     if (a.qk_rmsnorm) {
       ss += __shfl_xor(ss, 32, 64);
-      f *= rsqrtf(ss / (float)D + a.eps);
+      f *= rsqrtf(ss / az_norm_dim<D>(a) + a.eps);
     }
 #pragma unroll
     for (int jj = 0; jj < KJ; ++jj)
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AzAttnArgs a) {
             for (int j = 0; j < CH / 4; ++j) tot += __shfl(ss, base + 4 * j, 64);
             ss = tot;
           }
-          const float f = rsqrtf(ss / (float)D + a.eps);
+          const float f = rsqrtf(ss / az_norm_dim<D>(a) + a.eps);
           kv.x *= f;
           kv.y *= f;
           kv.z *= f;
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
     float f = a.scale;
     if (a.qk_rmsnorm) {
       ss += __shfl_xor(ss, 32, 64);
-      f *= rsqrtf(ss / (float)D + a.eps);
+      f *= rsqrtf(ss / az_norm_dim<D>(a) + a.eps);
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
             for (int j = 0; j < CH / 4; ++j) tot += __shfl(ss, base + 4 * j, 64);
             ss = tot;
           }
-          const float f = rsqrtf(ss / (float)D + a.eps);
+          const float f = rsqrtf(ss / az_norm_dim<D>(a) + a.eps);
           kv.x *= f;
           kv.y *= f;
           kv.z *= f;
@@ -652,7 +657,7 @@ __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {
     float f = a.scale * 1.4426950408889634f;  // (scores in log2 units: one v_exp_f32 per score, see attention_kernel)
     if (a.qk_rmsnorm) {
       ss += __shfl_xor(ss, 32, 64);
-      f *= rsqrtf(ss / (float)D + a.eps);
+      f *= rsqrtf(ss / az_norm_dim<D>(a) + a.eps);
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {
             for (int j = 0; j < CH / 4; ++j) tot += __shfl(ss, base + 4 * j, 64);
             ss = tot;
           }
-          const float f = rsqrtf(ss / (float)D + a.eps);
+          const float f = rsqrtf(ss / az_norm_dim<D>(a) + a.eps);
           kv.x *= f;
           kv.y *= f;
           kv.z *= f;
@@ -960,6 +965,7 @@ static int attention_half_launch(const AzAttnArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->batch > 0 && a->heads > 0 && a->tokens > 0, AZ_E_SHAPE);
   AZ_REQUIRE(a->head_dim == 16 || a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 80 || a->head_dim == 128,
              AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(a->norm_dim >= 0 && a->norm_dim <= a->head_dim, AZ_E_SHAPE);
   AZ_REQUIRE(AZ_ALIGNED16(a->q) && AZ_ALIGNED16(a->k) && AZ_ALIGNED16(a->v) && AZ_ALIGNED16(a->out), AZ_E_ALIGN);
   const int64_t strides[] = {a->q_bstride, a->q_tstride, a->q_hstride, a->k_bstride, a->k_tstride, a->k_hstride,
                              a->v_bstride, a->v_tstride, a->v_hstride, a->o_bstride, a->o_tstride, a->o_hstride};
@@ -988,6 +994,7 @@ int az_attention_x3_f32(const AzAttnArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->batch > 0 && a->heads > 0 && a->tokens > 0, AZ_E_SHAPE);
   AZ_REQUIRE(a->head_dim == 16 || a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 80 || a->head_dim == 128,
              AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(a->norm_dim >= 0 && a->norm_dim <= a->head_dim, AZ_E_SHAPE);
   AZ_REQUIRE(AZ_ALIGNED16(a->q) && AZ_ALIGNED16(a->k) && AZ_ALIGNED16(a->v) && AZ_ALIGNED16(a->out), AZ_E_ALIGN);
   const int64_t strides[] = {a->q_bstride, a->q_tstride, a->q_hstride, a->k_bstride, a->k_tstride, a->k_hstride,
                              a->v_bstride, a->v_tstride, a->v_hstride, a->o_bstride, a->o_tstride, a->o_hstride};
@@ -1020,6 +1027,7 @@ int az_attention_f32(const AzAttnArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a->head_dim == 8 || a->head_dim == 16 || a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 80 ||
                  a->head_dim == 128,
              AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(a->norm_dim >= 0 && a->norm_dim <= a->head_dim, AZ_E_SHAPE);
   AZ_REQUIRE(AZ_ALIGNED16(a->q) && AZ_ALIGNED16(a->k) && AZ_ALIGNED16(a->v) && AZ_ALIGNED16(a->out), AZ_E_ALIGN);
   const int64_t strides[] = {a->q_bstride, a->q_tstride, a->q_hstride, a->k_bstride, a->k_tstride, a->k_hstride,
                              a->v_bstride, a->v_tstride, a->v_hstride, a->o_bstride, a->o_tstride, a->o_hstride};

@@ -687,12 +687,63 @@ def transition_args(**kw) -> AzTransitionArgs:
 
 
 # ------------------------------------------------------------------------------- token-path helpers
+# Head sizes.  The reference accepts any channels // attention_heads (azula/nn/attention.py:35-51; guided-diffusion any
+# num_head_channels); the gfx950 attention kernels are instantiated for 16 / 32 / 64 / 80 / 128 (the fp32 kernel also for 8).  Any
+# other size d <= 128 runs ZERO-PADDED to the next instantiated size d': the q | k | v projection is packed with d' - d zero rows
+# (and zero bias) per head, so the padded channels of q, k and v are exact zeros -- they change neither q.k nor p.v --, the output
+# projection with d' - d zero input columns per head; the scale stays 1 / sqrt(d), the q / k RMS norm averages over d
+# (AzAttnArgs.norm_dim), padded RoPE pairs do not turn (theta = 0) and padded gains are 1.  (G24: 24, 48, 96.)
+ATTN_HEAD_DIMS = (16, 32, 64, 80, 128)
+
+
+def attn_padded_dim(d: int, half=None) -> int:
+    if d == 8 and half is None:
+        return 8
+    for v in ATTN_HEAD_DIMS:
+        if d <= v:
+            return v
+    raise NotImplementedError(f"attention head size {d}: the gfx950 attention kernels go up to 128 channels per head")
+
+
+def pad_qkv_heads(w: torch.Tensor, b: torch.Tensor | None, heads: int, d: int, dp: int, order: str):
+    r"""(3 heads d, Cin[, 1]) q | k | v projection weights (and bias) -> (3 heads dp, Cin): dp - d zero rows behind every head's d.
+    ``order`` as in Builder.attention: "nHC" / "3HC" = rows (n, head, c), "H3C" = rows (head, n, c)."""
+    w = w.detach().float().reshape(3 * heads * d, -1)
+    lead = (3, heads) if order in ("nHC", "3HC") else (heads, 3)
+    wp = w.new_zeros(*lead, dp, w.shape[1])
+    wp[:, :, :d] = w.reshape(*lead, d, w.shape[1])
+    bp = None
+    if b is not None:
+        bp = w.new_zeros(*lead, dp)
+        bp[:, :, :d] = b.detach().float().reshape(*lead, d)
+        bp = bp.reshape(-1)
+    return wp.reshape(3 * heads * dp, w.shape[1]), bp
+
+
+def pad_proj_heads(w: torch.Tensor, heads: int, d: int, dp: int) -> torch.Tensor:
+    r"""(Cout, heads d[, 1]) output projection -> (Cout, heads dp): zero columns for the padded channels of every head."""
+    w = w.detach().float().reshape(w.shape[0], heads, d)
+    wp = w.new_zeros(w.shape[0], heads, dp)
+    wp[:, :, :d] = w
+    return wp.reshape(w.shape[0], heads * dp)
+
+
+def pad_head_table(t: torch.Tensor, heads: int, n: int, n_pad: int, fill: float = 0.0) -> torch.Tensor:
+    r"""(..., heads n) per-head table (RoPE angles with n = d / 2) -> (..., heads n_pad), padded with ``fill``."""
+    lead = t.shape[:-1]
+    tp = t.new_full((*lead, heads, n_pad), fill)
+    tp[..., :n] = t.reshape(*lead, heads, n)
+    return tp.reshape(*lead, heads * n_pad)
+
+
 def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool, scale: float, eps: float = 1e-5,
-                       rope: tuple | None = None, qk_weight: tuple | None = None, mask: torch.Tensor | None = None) -> Act:
+                       rope: tuple | None = None, qk_weight: tuple | None = None, mask: torch.Tensor | None = None,
+                       norm_dim: int = 0) -> Act:
     r"""softmax(q k^T * scale) v over a fused-QKV token tensor (B, L, 1, 3*heads*dim).
 
     order: "nHC" = azula '(n H C)' (attention.py:90), "H3C" = ADM legacy (unet.py:338),
-    "3HC" = ADM new order (unet.py:371).  Output (B, L, 1, heads*dim) laid out '(H C)'."""
+    "3HC" = ADM new order (unet.py:371).  Output (B, L, 1, heads*dim) laid out '(H C)'.
+    ``norm_dim``: the real head size of zero-padded heads (see ATTN_HEAD_DIMS)."""
     from ._lib import AzAttnArgs
 
     Cq = qkv.C // 3
@@ -715,7 +766,7 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
         setattr(a, n + "_tstride", qkv.cs)
         setattr(a, n + "_hstride", hs)
     a.o_bstride, a.o_tstride, a.o_hstride = L * out.cs, out.cs, dim
-    a.scale, a.qk_rmsnorm, a.eps = scale, int(qk_rmsnorm), eps
+    a.scale, a.qk_rmsnorm, a.eps, a.norm_dim = scale, int(qk_rmsnorm), eps, norm_dim
     if qkv.qk_prepared:  # the projection's epilogue has normalised / gained / rotated q and k already (Builder.conv(qk_prep=...))
         assert order in ("nHC", "3HC")
         a.qk_rmsnorm, rope, qk_weight = 0, None, None

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from .. import _lib
+from .. import _lib, engine
 from ..engine import Act, Builder, Tape, ada_zero_triple, mod_front_tape, pad4
 
 __all__ = ["DiT", "DiTBlock", "MultiheadSelfAttention", "ViT"]
@@ -73,9 +73,22 @@ class MultiheadSelfAttention(nn.Module):
         # with RoPE: q / k RMS norm and the rotation in the projection's epilogue, once per layer (C6-like: attention 0.38 -> 0.49 of
         # the MFMA peak).  The RMS norm alone stays in the attention kernel: measured on DiT-B/2 (C3) the kernel gains 7 % but the
         # captured step loses 0.4 % (23.77 vs 23.67 ms, two rounds each) -- a norm of the staged K rows is nearly free there.
-        prep = dict(heads=self.heads, head_dim=C_ // self.heads, rmsnorm=self.qk_norm, eps=1e-5, rope=rope) if rope else None
+        d = C_ // self.heads
+        dp = engine.attn_padded_dim(d, bld.half)
+        if dp != d:  # a head size the kernels are not instantiated for: zero-padded heads (engine.ATTN_HEAD_DIMS; G24)
+            if rope is not None:
+                theta_p = engine.pad_head_table(theta, self.heads, d // 2, dp // 2)
+                rope = (bld.const(torch.cos(theta_p)), bld.const(torch.sin(theta_p)))
+            wq, bq = engine.pad_qkv_heads(self.qkv_proj.weight, self.qkv_proj.bias, self.heads, d, dp, "nHC")
+            qkv = bld.conv(y, bld.pack_conv(wq, bq), 3 * self.heads * dp)
+            att = bld.attention(qkv, self.heads, "nHC", self.qk_norm, 1.0 / math.sqrt(d), rope=rope, mask=mask, norm_dim=d)
+            bld.free(qkv)
+            out = bld.conv(att, bld.pack_conv(engine.pad_proj_heads(self.y_proj.weight, self.heads, d, dp), None), C_, res=res)
+            bld.free(att)
+            return out
+        prep = dict(heads=self.heads, head_dim=d, rmsnorm=self.qk_norm, eps=1e-5, rope=rope) if rope else None
         qkv = bld.conv(y, bld.pack_conv(self.qkv_proj.weight, self.qkv_proj.bias), 3 * C_, qk_prep=prep)
-        att = bld.attention(qkv, self.heads, "nHC", self.qk_norm, 1.0 / math.sqrt(C_ // self.heads), rope=rope, mask=mask)
+        att = bld.attention(qkv, self.heads, "nHC", self.qk_norm, 1.0 / math.sqrt(d), rope=rope, mask=mask)
         bld.free(qkv)
         out = bld.conv(att, bld.pack_conv(self.y_proj.weight, None), C_, res=res)
         bld.free(att)

@@ -310,12 +310,21 @@ class ADMPlan:
             Cc = ab.channels
             n_ = group_norm(x, 32, weight=bld.const(ab.norm.weight), bias=bld.const(ab.norm.bias))
             tok = Act(n_.buf, B, D * n_.H * n_.W, 1, Cc, n_.cs, True)
-            qkv = bld.conv(tok, bld.pack_conv(ab.qkv.weight, ab.qkv.bias), 3 * Cc)
             ch = Cc // ab.num_heads
-            att = bld.attention(qkv, ab.num_heads, "3HC" if ab.new_order else "H3C", False, 1.0 / math.sqrt(ch))
-            bld.free(qkv)
+            chp = engine.attn_padded_dim(ch, bld.half)
+            order = "3HC" if ab.new_order else "H3C"
             xt = Act(x.buf, B, D * x.H * x.W, 1, Cc, x.cs, True)
-            o = bld.conv(att, bld.pack_conv(ab.proj_out.weight, ab.proj_out.bias), Cc, res=xt)
+            if chp != ch:  # a head size the kernels are not instantiated for: zero-padded heads (engine.ATTN_HEAD_DIMS; G24)
+                wq, bq = engine.pad_qkv_heads(ab.qkv.weight, ab.qkv.bias, ab.num_heads, ch, chp, order)
+                qkv = bld.conv(tok, bld.pack_conv(wq, bq), 3 * ab.num_heads * chp)
+                att = bld.attention(qkv, ab.num_heads, order, False, 1.0 / math.sqrt(ch), norm_dim=ch)
+                bld.free(qkv)
+                o = bld.conv(att, bld.pack_conv(engine.pad_proj_heads(ab.proj_out.weight, ab.num_heads, ch, chp), ab.proj_out.bias), Cc, res=xt)
+            else:
+                qkv = bld.conv(tok, bld.pack_conv(ab.qkv.weight, ab.qkv.bias), 3 * Cc)
+                att = bld.attention(qkv, ab.num_heads, order, False, 1.0 / math.sqrt(ch))
+                bld.free(qkv)
+                o = bld.conv(att, bld.pack_conv(ab.proj_out.weight, ab.proj_out.bias), Cc, res=xt)
             bld.free(att)
             bld.free(n_)
             return Act(o.buf, PB, x.H, x.W, Cc, o.cs)

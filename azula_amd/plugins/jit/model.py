@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from ... import _lib
+from ... import _lib, engine
 from ...engine import Act, Builder
 
 __all__ = ["JiT", "JiT_models"]
@@ -165,8 +165,17 @@ class JiTPlan:
         x = bld.conv(low, bld.pack_conv(e.proj2.weight.detach().reshape(Hd, -1), e.proj2.bias), Hd, res=_Shared(pos))
         bld.free(low)
 
-        rope_img = tuple(bld.const(t) for t in rotary_tables(hd, heads, grid, 0))
-        rope_ctx = tuple(bld.const(t) for t in rotary_tables(hd, heads, grid, Lc)) if Lc else rope_img
+        hdp = engine.attn_padded_dim(hd, bld.half)
+
+        def rope_tables(ctx: int) -> tuple:
+            cos, sin = rotary_tables(hd, heads, grid, ctx)  # (tokens, heads, hd / 2)
+            if hdp != hd:  # padded pairs do not turn
+                cos = torch.cat([cos, cos.new_ones(*cos.shape[:-1], (hdp - hd) // 2)], dim=-1).contiguous()
+                sin = torch.cat([sin, sin.new_zeros(*sin.shape[:-1], (hdp - hd) // 2)], dim=-1).contiguous()
+            return bld.const(cos), bld.const(sin)
+
+        rope_img = rope_tables(0)
+        rope_ctx = rope_tables(Lc) if Lc else rope_img
         for i, blk in enumerate(net.blocks):
             if Lc and i == net.in_context_start:  # prepend the class tokens (_src/model.py:364-367)
                 wide = bld.new_act(B, L + Lc, 1, Hd)
@@ -182,12 +191,23 @@ class JiTPlan:
             rope_i = rope_img if i < net.in_context_start else rope_ctx
             gains = (bld.const(at.q_norm.weight), bld.const(at.k_norm.weight))
             # q / k RMS norm, gains and RoPE in the projection's epilogue, once per layer (head_dim 80 of JiT-H: in the attention kernel)
-            qkv = bld.conv(n1, bld.pack_conv(at.qkv.weight, at.qkv.bias), 3 * Hd,
-                           qk_prep=dict(heads=heads, head_dim=hd, rmsnorm=True, eps=1e-6, rope=rope_i, weight=gains))
-            bld.free(n1)
-            att = bld.attention(qkv, heads, "3HC", True, 1.0 / math.sqrt(hd), eps=1e-6, rope=rope_i, qk_weight=gains)
-            bld.free(qkv)
-            x2 = bld.conv(att, bld.pack_conv(at.proj.weight, at.proj.bias), Hd, gate=mod, gate_off=m0_ + 2 * Hd, gate_bstride=MS, res=x)
+            if hdp != hd:  # a head size the kernels are not instantiated for: zero-padded heads (engine.ATTN_HEAD_DIMS)
+                ones = torch.ones(hdp - hd)
+                gains = tuple(bld.const(torch.cat([w_.detach().float().cpu(), ones])) for w_ in (at.q_norm.weight, at.k_norm.weight))
+                wq, bq = engine.pad_qkv_heads(at.qkv.weight, at.qkv.bias, heads, hd, hdp, "3HC")
+                qkv = bld.conv(n1, bld.pack_conv(wq, bq), 3 * heads * hdp)
+                bld.free(n1)
+                att = bld.attention(qkv, heads, "3HC", True, 1.0 / math.sqrt(hd), eps=1e-6, rope=rope_i, qk_weight=gains, norm_dim=hd)
+                bld.free(qkv)
+                x2 = bld.conv(att, bld.pack_conv(engine.pad_proj_heads(at.proj.weight, heads, hd, hdp), at.proj.bias), Hd,
+                              gate=mod, gate_off=m0_ + 2 * Hd, gate_bstride=MS, res=x)
+            else:
+                qkv = bld.conv(n1, bld.pack_conv(at.qkv.weight, at.qkv.bias), 3 * Hd,
+                               qk_prep=dict(heads=heads, head_dim=hd, rmsnorm=True, eps=1e-6, rope=rope_i, weight=gains))
+                bld.free(n1)
+                att = bld.attention(qkv, heads, "3HC", True, 1.0 / math.sqrt(hd), eps=1e-6, rope=rope_i, qk_weight=gains)
+                bld.free(qkv)
+                x2 = bld.conv(att, bld.pack_conv(at.proj.weight, at.proj.bias), Hd, gate=mod, gate_off=m0_ + 2 * Hd, gate_bstride=MS, res=x)
             bld.free(att)
             bld.free(x)
             n2 = bld.row_norm(x2, 1, weight=bld.const(blk.norm2.weight), scale=mod, shift=mod, scale_off=m0_ + 4 * Hd,
@@ -288,9 +308,10 @@ class JiT(nn.Module):
         in_context_start: int = 8,
     ) -> None:
         super().__init__()
-        if hidden_size % num_heads or hidden_size // num_heads not in (16, 32, 64, 80, 128):
-            raise NotImplementedError(
-                f"head_dim {hidden_size / num_heads:g}: the gfx950 attention kernel is instantiated for 16/32/64/80/128"
+        if hidden_size % num_heads or hidden_size // num_heads > 128 or (hidden_size // num_heads) % 4:
+            raise NotImplementedError(  # (the rotary layout splits a head into quarters: reference _src/util.py:100-143)
+                f"head_dim {hidden_size / num_heads:g}: the gfx950 attention kernels take heads of up to 128 channels "
+                "(16/32/64/80/128 natively, other multiples of 4 zero-padded to the next of those)"
             )
         if input_size % patch_size or hidden_size % 8:
             raise ValueError("input_size must be a multiple of patch_size and hidden_size of 8")

@@ -401,6 +401,11 @@ typedef struct AzAttnArgs {
   float scale;
   int32_t qk_rmsnorm; /* 1: q and k rows are RMS-normalised (eps) before the dot product */
   float eps;
+  /* channels the RMS norm averages over; 0 = head_dim.  The kernels exist for head_dim 16 / 32 / 64 / 80 / 128 (fp32: also 8):
+   * the host runs any other head size d (azula/nn/attention.py:35-51 accepts every channels // attention_heads) by zero-padding
+   * each head of q, k, v to the next instantiated size when it packs the projections -- zero channels change neither q.k nor
+   * p.v -- and passes norm_dim = d here (scale is explicit: 1 / sqrt(d) of the REAL size).                                  */
+  int32_t norm_dim;
   /* optional rotary embedding (azula/nn/attention.py:93-96,112-156): cos/sin of theta, laid out
    * (tokens, heads, head_dim / 2), shared by the batch; adjacent channel pairs (2i, 2i+1) of q and k are
    * rotated after the RMS norm.  NULL = no RoPE.                                                */

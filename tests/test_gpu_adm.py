@@ -163,13 +163,14 @@ def test_cfg_ddim16_fused_and_generic(golden):
     assert cfgden.schedule is den.schedule
 
 
-@pytest.mark.parametrize("name", ["adm_plain_conv", "adm_plain_pool", "adm_film_noupdown"])
+@pytest.mark.parametrize("name", ["adm_plain_conv", "adm_plain_pool", "adm_film_noupdown", "g24_adm_hd24_legacy", "g24_adm_hd48_hd96_neworder"])
 def test_adm_options_outside_the_cards(golden, name):
     """guided-diffusion's default wiring -- ``use_scale_shift_norm=False`` (h + emb), ``resblock_updown=False``
-    (Downsample / Upsample layers, with and without ``conv_resample``) -- against the reference's outputs (G14)."""
+    (Downsample / Upsample layers, with and without ``conv_resample``) -- against the reference's outputs (G14); G24: attention
+    heads of 24 (legacy q | k | v order) and of 48 / 96 channels (new order), run zero-padded to 32 / 64 / 128."""
     from azula_amd.sample import DDIMSampler
 
-    g = golden("g14_" + name)
+    g = golden(name if name.startswith("g24_") else "g14_" + name)
     den, _, cfg = build(g)
     y = g["y"].cuda() if "y" in g else None
     out = den.backbone(g["x"].cuda(), g["idx"].cuda(), y=y)

@@ -90,6 +90,41 @@ def test_c2_channel_plan_ddim64_full_length(c2_net):
     assert e < 3.4e-6 * sc  # measured 2.6e-6 on scale 3.88 = 6.8e-7 relative (MI355X, round 4): bound = 5 x
 
 
+def test_c2_channel_plan_under_the_f4_policy(c2_net, monkeypatch):
+    """The opt-in inexact F(4x4,3x3) policy (AZ_WINOGRAD=4: the fp32 kernel of round 1 on every layer with >= 16 tiles) on
+    configs[1]'s channel plan: what the 6 x 6 transforms cost in accuracy END TO END (posterior mean, DDIM-3, DDIM-64) -- the
+    accuracy half of the round-6 gate for F(4x4) on the split operands (profiles/r06_wx3_f4_gate.txt)."""
+    from azula_amd import engine
+    from azula_amd.sample import DDIMSampler
+
+    den, x1, ref_mean, ref_x0 = c2_net
+    monkeypatch.setattr(engine, "WINOGRAD", "4")
+    monkeypatch.setattr(engine, "WINOGRAD4_MIN_TILES", 16)
+    net = den.backbone.net
+    net._plans.clear()
+    mean = den(x1.cuda(), torch.tensor(0.6, device="cuda")).mean
+    ops = [n for _, _, n in next(iter(net._plans.values())).tape.ops]
+    n4 = ops.count("az_conv2d_winograd4_f32")
+    assert n4 >= 25, n4  # the 64^2, 32^2 and 16^2 levels
+    e1 = max_err(mean, ref_mean)
+    x0 = DDIMSampler(den, steps=3, silent=True)(x1.cuda())
+    e2 = max_err(x0, ref_x0)
+    sd = {k: v.detach().cpu() for k, v in den.backbone.state_dict().items()}
+    import bench
+
+    ncfg = dict(bench.CONFIGS["c2"]["net"])
+    oracle_mean = lambda x, t: sampling.karras_mean(lambda a, c: nets.time_wrapped_unet(sd, ncfg, a, c), x, t)  # noqa: E731
+    x64 = DDIMSampler(den, steps=64, silent=True)(x1.cuda())
+    ref64 = sampling.sample(oracle_mean, x1, steps=64, eta=0.0)
+    e3 = max_err(x64, ref64)
+    print(f"C2 widths @{RES}^2 policy 4 (F(4x4) fp32 on {n4} layers): mean max|d| {e1:.3e} (scale {ref_mean.abs().max().item():.2f}); "
+          f"DDIM-3 {e2:.3e} (scale {ref_x0.abs().max().item():.2f}); DDIM-64 {e3:.3e} (scale {ref64.abs().max().item():.2f})")
+    net._plans.clear()
+    # measured (MI355X, round 6): mean 3.8e-6 (F(2x2): 3.3e-7), DDIM-3 3.6e-6 (3.6e-7), DDIM-64 2.6e-6 on scale 3.88 (2.6e-6: the long
+    # trajectory's error is not the convolutions').  Bounds = 5 x.
+    assert e1 < 2e-5 and e2 < 2e-5 * max(1.0, ref_x0.abs().max().item()) and e3 < 3.4e-6 * max(1.0, ref64.abs().max().item())
+
+
 @pytest.fixture(scope="module")
 def adm_net():
     import bench

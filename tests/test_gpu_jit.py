@@ -12,7 +12,7 @@ from oracle import nets, synth
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
-CONFIGS = ("jit_ctx", "jit_noctx_hd32", "jit_hd80")
+CONFIGS = ("jit_ctx", "jit_noctx_hd32", "jit_hd80", "g24_jit_hd48")  # (G24: heads of 48 channels, zero-padded to 64)
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +34,7 @@ def build(g):
 
 @pytest.mark.parametrize("name", CONFIGS)
 def test_jit_backbone_matches_reference(golden, name):
-    g = golden("g10_" + name)
+    g = golden(name if name.startswith("g24_") else "g10_" + name)
     den = build(g)
     x, t, y = g["x"].cuda(), g["t"].cuda(), g["y"].long().cuda()
     sc = g["out"].abs().max().item()
@@ -51,7 +51,7 @@ def test_jit_denoiser_and_fused_loops(golden, name):
     from azula_amd.guidance.cfg import CFGDenoiser
     from azula_amd.sample import DDIMSampler
 
-    g = golden("g10_" + name)
+    g = golden(name if name.startswith("g24_") else "g10_" + name)
     den = build(g)
     x, y = g["x"].cuda(), g["y"].long().cuda()
     sc = g["mean_t04"].abs().max().item()

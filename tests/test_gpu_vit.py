@@ -218,12 +218,13 @@ def test_vit_ddim50_fused_matches_reference(golden):
     assert err < 5e-4 * max(1.0, sc)
 
 
-@pytest.mark.parametrize("name", ["vit_rope_swiglu", "vit_relu2_noqknorm", "vit_relu"])
+@pytest.mark.parametrize("name", ["vit_rope_swiglu", "vit_relu2_noqknorm", "vit_relu", "g24_vit_hd48_rope", "g24_vit_hd96_noqknorm", "g24_vit_hd24"])
 def test_vit_variants_match_reference(golden, name):
-    """RoPE (attention.py:112-156), SwiGLU / ReLU^2 / ReLU FFNs (layers.py:71-110), qk_norm=False."""
+    """RoPE (attention.py:112-156), SwiGLU / ReLU^2 / ReLU FFNs (layers.py:71-110), qk_norm=False; G24: head sizes 48 (RoPE +
+    q/k norm), 96 and 24 -- run zero-padded to 64 / 128 / 32 (engine.ATTN_HEAD_DIMS; azula/nn/attention.py:35-51 takes any)."""
     from azula_amd.nn import ViT
 
-    g = golden("g5_" + name)
+    g = golden(name if name.startswith("g24_") else "g5_" + name)
     cfg = g.meta["cfg"]
     extra = {k: cfg[k] for k in ("rope", "ffn_activation", "qk_norm") if k in cfg}
     net = ViT(cfg["in_channels"], cfg["out_channels"], hid_channels=cfg["hid_channels"], hid_blocks=cfg["hid_blocks"],
@@ -235,3 +236,7 @@ def test_vit_variants_match_reference(golden, name):
     err, sc = max_err(y, g["y_modB"]), g["y_modB"].abs().max().item()
     print(name, "max|d|", err, "scale", sc)
     assert err < 1e-4 * max(1.0, sc)
+    if name.startswith("g24_"):
+        ops = [a for _, a, n in next(iter(net._plans.values())).tape.ops if n.startswith("az_attention")]
+        hd = cfg["hid_channels"] // cfg["attention_heads"]
+        assert ops and all(a[0]._obj.norm_dim == hd and a[0]._obj.head_dim > hd for a in ops)  # (padded heads, norm over the real size)

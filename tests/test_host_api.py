@@ -315,8 +315,9 @@ def test_jit_plugin_host_side(golden):
     assert cards["jit_0.5b_32"].config == {"model": "JiT-L/32"}
     with pytest.raises(FileNotFoundError, match="does not download"):
         jit.load_model("jit_0.1b_16")
+    jit.JiT(input_size=32, patch_size=4, hidden_size=96, depth=1, num_heads=2)  # head_dim 48: zero-padded to 64 (round 6)
     with pytest.raises(NotImplementedError, match="head_dim"):
-        jit.JiT(input_size=32, patch_size=4, hidden_size=96, depth=1, num_heads=2)  # head_dim 48: no kernel
+        jit.JiT(input_size=32, patch_size=4, hidden_size=288, depth=1, num_heads=2)  # head_dim 144 > 128: no kernel
 
     g = golden("g10_jit_ctx")
     net = jit.JiT(**g.meta["cfg"])

@@ -168,8 +168,8 @@ def test_g9_toy_multistep_loops(golden):
 
 def test_g10_jit(golden):
     """JiT backbone, JITDenoiser (label / null class), DDIM and CFG loops on the rectified schedule."""
-    for name in ("jit_ctx", "jit_noctx_hd32", "jit_hd80"):
-        g = golden("g10_" + name)
+    for name in ("g10_jit_ctx", "g10_jit_noctx_hd32", "g10_jit_hd80", "g24_jit_hd48"):
+        g = golden(name)
         cfg = g.meta["cfg"]
         sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"])
         bb = lambda a, c, l: nets.jit_forward(sd, cfg, a, c, l)  # noqa: E731
@@ -227,7 +227,9 @@ def test_g13_other_spatial_dimensions(golden):
 
 ADM_FIXTURES = [("g14_" + n) for n in ("adm_plain_conv", "adm_plain_pool", "adm_film_noupdown")] + [
     ("g22_" + n) for n in ("adm_1d_film_updown", "adm_1d_plain_conv", "adm_1d_plain_pool")
-] + [("g23_" + n) for n in ("adm_3d_film_updown", "adm_3d_plain_conv", "adm_3d_plain_pool")]
+] + [("g23_" + n) for n in ("adm_3d_film_updown", "adm_3d_plain_conv", "adm_3d_plain_pool")] + [
+    ("g24_" + n) for n in ("adm_hd24_legacy", "adm_hd48_hd96_neworder")  # head sizes 24 / 48 / 96 (--only-g24)
+]
 
 
 def test_g14_g22_g23_adm_offcard_1d_and_3d(golden):
@@ -247,6 +249,15 @@ def test_g14_g22_g23_adm_offcard_1d_and_3d(golden):
         kw = {"label": y} if y is not None else {}
         x0 = sampling.sample(omean, g["x1"], schedule=lambda t: sampling.vp_schedule(t, 1e-2, 1e-2), steps=8, eta=0.0, **kw)
         torch.testing.assert_close(x0, g["ddim8"], **TIGHT)
+
+
+def test_g24_vit_head_sizes(golden):
+    """ViT with head sizes the gfx950 attention kernels are not instantiated for (48 with RoPE + q/k norm, 96, 24): the oracle
+    against the reference's outputs (oracle/make_golden.py --only-g24)."""
+    for name in ("vit_hd48_rope", "vit_hd96_noqknorm", "vit_hd24"):
+        g = golden("g24_" + name)
+        sd = synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"])
+        assert max_err(nets.vit_forward(sd, g.meta["cfg"], g["x"], g["modB"]), g["y_modB"]) < 1e-5, name
 
 
 def test_g15_strides(golden):
