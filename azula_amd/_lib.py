@@ -166,7 +166,7 @@ class AzConvArgs(C.Structure):
         ("up1_w", C.c_int32),
         ("in_affine", c_f32p),
         ("in_act", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("src_dtype", C.c_int32),
         ("depth", C.c_int32),
         ("depth_shift", C.c_int32),
         ("qk_head_dim", C.c_int32),
@@ -180,7 +180,7 @@ class AzConvArgs(C.Structure):
         ("qk_rope_cos", c_f32p),
         ("qk_rope_sin", c_f32p),
         ("depth_wrap", C.c_int32),
-        ("depth_reserved", C.c_int32),
+        ("dst_dtype", C.c_int32),
     ]
 
 
@@ -217,6 +217,8 @@ class AzAttnArgs(C.Structure):
         ("mask", c_f32p),
         ("mask_bstride", C.c_int64),
         ("mask_hstride", C.c_int64),
+        ("io_dtype", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -244,6 +246,7 @@ PROTOTYPES: dict[str, list] = {
     "az_groupnorm_finalize_f32": [C.POINTER(AzNormFinalizeArgs), c_stream],
     "az_affine_act_f32": [vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, i32, i32, c_stream],
     "az_rownorm_mod_f32": [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, c_stream],
+    "az_rownorm_mod_h16": [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, i32, c_stream],
     "az_token_copy_f32": [vp, i64, i64, vp, i64, i64, i64, i64, i64, c_stream],
     "az_token_fill_f32": [vp, i64, i64, i64, vp, i64, vp, i64, i64, c_stream],
     "az_timestep_embedding_f32": [vp, i64, vp, i64, i64, i32, f32, c_stream],

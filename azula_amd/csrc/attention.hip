@@ -357,9 +357,14 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
   const int T = a.tokens;
   const int qi = blockIdx.x * QT + wave * 32 + ql;
 
-  const float* qp = a.q + (int64_t)b * a.q_bstride + (int64_t)hd * a.q_hstride;
-  const float* kp = a.k + (int64_t)b * a.k_bstride + (int64_t)hd * a.k_hstride;
-  const float* vp = a.v + (int64_t)b * a.v_bstride + (int64_t)hd * a.v_hstride;
+  // q / k / v / out: fp32 tensors, or (io_dtype = 1: a module cast to half precision keeps its activations in HBM in its own type)
+  // tensors of the kernel's 2-byte type -- same element strides, 8-byte accesses of 4 values
+  constexpr int HIO = F16 ? 2 : 1;
+  const bool hio = a.io_dtype != 0;
+  auto ld = [&](const float* base, int64_t idx) __attribute__((always_inline)) { return hio ? ld4_io<HIO>(base, idx) : ld4_io<0>(base, idx); };
+  const int64_t qo = (int64_t)b * a.q_bstride + (int64_t)hd * a.q_hstride;
+  const int64_t ko = (int64_t)b * a.k_bstride + (int64_t)hd * a.k_hstride;
+  const int64_t vo = (int64_t)b * a.v_bstride + (int64_t)hd * a.v_hstride;
   const uint8_t* mrow = (a.mask != nullptr && qi < T)
                             ? a.mask + (int64_t)b * a.mask_bstride + (int64_t)hd * a.mask_hstride + (int64_t)qi * T
                             : nullptr;
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (qi < T) v = *reinterpret_cast<const float4*>(qp + (int64_t)qi * a.q_tstride + 16 * ks + 8 * h2 + 4 * hh);
+        if (qi < T) v = ld(a.q, qo + (int64_t)qi * a.q_tstride + 16 * ks + 8 * h2 + 4 * hh);
         qv[ks][4 * hh + 0] = v.x;
         qv[ks][4 * hh + 1] = v.y;
         qv[ks][4 * hh + 2] = v.z;
@@ -439,8 +444,8 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
         const int key = k0 + row;
         float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
         if (key < T) {
-          kv = *reinterpret_cast<const float4*>(kp + (int64_t)key * a.k_tstride + lc * 4);
-          vv = *reinterpret_cast<const float4*>(vp + (int64_t)key * a.v_tstride + lc * 4);
+          kv = ld(a.k, ko + (int64_t)key * a.k_tstride + lc * 4);
+          vv = ld(a.v, vo + (int64_t)key * a.v_tstride + lc * 4);
         }
         if (a.qk_rmsnorm) {
           float ss = (kv.x * kv.x + kv.y * kv.y) + (kv.z * kv.z + kv.w * kv.w);
@@ -552,15 +557,17 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
 
   if (qi < T) {
     const float inv = 1.f / l_run;
-    float* op = a.out + (int64_t)b * a.o_bstride + (int64_t)hd * a.o_hstride + (int64_t)qi * a.o_tstride;
+    const int64_t oo = (int64_t)b * a.o_bstride + (int64_t)hd * a.o_hstride + (int64_t)qi * a.o_tstride;
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = 32 * t + 8 * g + 4 * h2;
-        if (d < D)
-          *reinterpret_cast<float4*>(op + d) = make_float4(oacc[t][4 * g] * inv, oacc[t][4 * g + 1] * inv,
-                                                            oacc[t][4 * g + 2] * inv, oacc[t][4 * g + 3] * inv);
+        if (d < D) {
+          const float4 o = make_float4(oacc[t][4 * g] * inv, oacc[t][4 * g + 1] * inv, oacc[t][4 * g + 2] * inv, oacc[t][4 * g + 3] * inv);
+          if (hio) st4_io<HIO>(a.out, oo + d, o);
+          else st4_io<0>(a.out, oo + d, o);
+        }
       }
   }
 }
@@ -962,11 +969,13 @@ __global__ __launch_bounds__(256) void swiglu_kernel(float* __restrict__ y, cons
 template <bool F16>
 static int attention_half_launch(const AzAttnArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->q && a->k && a->v && a->out, AZ_E_NULL);
+  AZ_REQUIRE(a->io_dtype == 0 || a->io_dtype == 1, AZ_E_SHAPE);
   AZ_REQUIRE(a->batch > 0 && a->heads > 0 && a->tokens > 0, AZ_E_SHAPE);
   AZ_REQUIRE(a->head_dim == 16 || a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 80 || a->head_dim == 128,
              AZ_E_UNSUPPORTED);
   AZ_REQUIRE(a->norm_dim >= 0 && a->norm_dim <= a->head_dim, AZ_E_SHAPE);
-  AZ_REQUIRE(AZ_ALIGNED16(a->q) && AZ_ALIGNED16(a->k) && AZ_ALIGNED16(a->v) && AZ_ALIGNED16(a->out), AZ_E_ALIGN);
+  if (a->io_dtype) AZ_REQUIRE((((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out) & 7u) == 0, AZ_E_ALIGN);
+  else AZ_REQUIRE(AZ_ALIGNED16(a->q) && AZ_ALIGNED16(a->k) && AZ_ALIGNED16(a->v) && AZ_ALIGNED16(a->out), AZ_E_ALIGN);
   const int64_t strides[] = {a->q_bstride, a->q_tstride, a->q_hstride, a->k_bstride, a->k_tstride, a->k_hstride,
                              a->v_bstride, a->v_tstride, a->v_hstride, a->o_bstride, a->o_tstride, a->o_hstride};
   for (int64_t s : strides) AZ_REQUIRE(s % 4 == 0, AZ_E_ALIGN);
@@ -991,6 +1000,7 @@ int az_attention_f16_f32(const AzAttnArgs* a, az_stream_t stream) { return atten
  * accumulation, fp32 softmax): fp32-level accuracy at 0.375 x the matrix-pipe time.  head_dim 16, 32, 64, 80 or 128.       */
 int az_attention_x3_f32(const AzAttnArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->q && a->k && a->v && a->out, AZ_E_NULL);
+  AZ_REQUIRE(a->io_dtype == 0, AZ_E_UNSUPPORTED);  // (half-precision tensors: the bf16 / f16 entries)
   AZ_REQUIRE(a->batch > 0 && a->heads > 0 && a->tokens > 0, AZ_E_SHAPE);
   AZ_REQUIRE(a->head_dim == 16 || a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 80 || a->head_dim == 128,
              AZ_E_UNSUPPORTED);
@@ -1023,6 +1033,7 @@ int az_attention_x3_f32(const AzAttnArgs* a, az_stream_t stream) {
 
 int az_attention_f32(const AzAttnArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->q && a->k && a->v && a->out, AZ_E_NULL);
+  AZ_REQUIRE(a->io_dtype == 0, AZ_E_UNSUPPORTED);  // (half-precision tensors: the bf16 / f16 entries)
   AZ_REQUIRE(a->batch > 0 && a->heads > 0 && a->tokens > 0, AZ_E_SHAPE);
   AZ_REQUIRE(a->head_dim == 8 || a->head_dim == 16 || a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 80 ||
                  a->head_dim == 128,

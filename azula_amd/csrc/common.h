@@ -107,6 +107,67 @@ __device__ __forceinline__ void az_st_stream(float* p, float4 o) {
   __builtin_nontemporal_store(v, reinterpret_cast<az_f32x4_t*>(p));
 }
 
+// Element type of a launch's DESTINATION and RESIDUAL tensors (AzConvArgs.dst_dtype; modules cast to half precision keep their
+// activations in HBM in the module's type, azula/denoise.py:314-320): IO = 0 fp32, 1 bfloat16, 2 IEEE half.  `base` is the
+// tensor's address whatever the type, `idx` an ELEMENT index (a multiple of 4: 8-byte accesses for the 2-byte types); values are
+// rounded to nearest even on the way out (what torch's cast does), arithmetic stays fp32.  IO is a compile-time parameter: the
+// fp32 kernels instantiate IO = 0 only and compile to exactly the code they had.
+typedef __bf16 az_bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 az_f16x4 __attribute__((ext_vector_type(4)));
+typedef float az_f32x4v __attribute__((ext_vector_type(4)));
+template <int IO>
+__device__ __forceinline__ float4 ld4_io(const float* base, int64_t idx) {
+  if constexpr (IO == 0) {
+    return *reinterpret_cast<const float4*>(base + idx);
+  } else if constexpr (IO == 1) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(base) + idx * 2);
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xFFFF0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xFFFF0000u));
+  } else {
+    const az_f16x4 h = *reinterpret_cast<const az_f16x4*>(reinterpret_cast<const char*>(base) + idx * 2);
+    const az_f32x4v f = __builtin_convertvector(h, az_f32x4v);
+    return make_float4(f.x, f.y, f.z, f.w);
+  }
+}
+template <int IO>
+__device__ __forceinline__ float4 round_io(float4 v) {  // the value the destination will hold (GroupNorm moments are taken of THAT)
+  if constexpr (IO == 0) return v;
+  const az_f32x4v f = {v.x, v.y, v.z, v.w};
+  az_f32x4v r;
+  if constexpr (IO == 1) r = __builtin_convertvector(__builtin_convertvector(f, az_bf16x4), az_f32x4v);
+  else r = __builtin_convertvector(__builtin_convertvector(f, az_f16x4), az_f32x4v);
+  return make_float4(r.x, r.y, r.z, r.w);
+}
+template <int IO>
+__device__ __forceinline__ void st4_io(float* base, int64_t idx, float4 v, bool stream = false) {
+  if constexpr (IO == 0) {
+    if (stream) az_st_stream(base + idx, v);
+    else *reinterpret_cast<float4*>(base + idx) = v;
+  } else {
+    const az_f32x4v f = {v.x, v.y, v.z, v.w};
+    char* d = reinterpret_cast<char*>(base) + idx * 2;
+    if constexpr (IO == 1) *reinterpret_cast<az_bf16x4*>(d) = __builtin_convertvector(f, az_bf16x4);
+    else *reinterpret_cast<az_f16x4*>(d) = __builtin_convertvector(f, az_f16x4);
+  }
+}
+template <int IO>
+__device__ __forceinline__ void st2_io(float* base, int64_t idx, float2 v) {  // (the SwiGLU epilogue's half-width rows)
+  if constexpr (IO == 0) {
+    *reinterpret_cast<float2*>(base + idx) = v;
+  } else {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const f2v f = {v.x, v.y};
+    char* d = reinterpret_cast<char*>(base) + idx * 2;
+    if constexpr (IO == 1) {
+      typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<b2*>(d) = __builtin_convertvector(f, b2);
+    } else {
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<h2*>(d) = __builtin_convertvector(f, h2);
+    }
+  }
+}
+
 // Memory-bound launches: cap the grid at 256 CUs x 8 blocks and grid-stride the rest.
 static inline int az_stream_grid(int64_t work_items, int block) {
   int64_t g = (work_items + block - 1) / block;

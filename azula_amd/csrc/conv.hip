@@ -64,6 +64,7 @@ struct ConvP {
 constexpr int OSTR = BM + 4;  // floats per pixel row of the exchange buffer
 static_assert((BN * OSTR + BN) * 4 <= 2 * TILE_F * 4, "epilogue exchange buffer must fit in the operand stages");
 
+template <int IO = 0>  // element type of dst / res (conv_shared.h: ld4_io / st4_io); the planar destination is always fp32
 __device__ __forceinline__ void store_acc_tiles(const ConvP& p, const f32x16 (&acc)[2][2], int m0, int n0, int wc, int wp,
                                                 int lane, float* obuf) {
   const AzConvArgs& a = p.a;
@@ -117,7 +118,7 @@ __device__ __forceinline__ void store_acc_tiles(const ConvP& p, const f32x16 (&a
       n[i] = b[i] >= 0 ? n0 + px : -1;
       v[i] = *reinterpret_cast<const float4*>(obuf + px * OSTR + cq * 4);
     }
-    epilogue_store_batch<NB>(a, n, b, co, v, (int64_t)blockIdx.y * p.npix);
+    epilogue_store_batch<NB, false, IO>(a, n, b, co, v, (int64_t)blockIdx.y * p.npix);
   }
 }
 
@@ -477,8 +478,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <bool F16>
+// SRCH: the sources hold the operand type already (AzConvArgs.src_dtype = 1: half-precision activations in HBM) -- a row's 64
+// k-values are 128 bytes, thread -> (16-byte chunk = 8 values, rows (tid >> 3) + 32 i): half the loads, no conversion.
+template <bool F16, bool SRCH = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
+  constexpr int ES = SRCH ? 2 : 4;         // bytes per source element
+  constexpr int NA = SRCH ? 4 : 8;         // activation loads per thread and stage
+  constexpr int ACH = SRCH ? 8 : 4;        // k-values per 16-byte activation chunk
   __shared__ __attribute__((aligned(16))) unsigned short hsm[2 * HTILE];
   const AzConvArgs& a = p.a;
   const int tid = threadIdx.x;
@@ -507,25 +513,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.weight, 0, clamp_bytes((int64_t)a.ksize * a.ksize * a.cout_s * p.cin_s * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src0 + b_base * s0_elems), 0, clamp_bytes((a.batch - b_base) * s0_elems * 4), 0x00020000);
+      (void*)(reinterpret_cast<const char*>(a.src0) + b_base * s0_elems * ES), 0, clamp_bytes((a.batch - b_base) * s0_elems * ES), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src1 ? a.src1 + b_base * s1_elems : a.src0), 0,
-      a.src1 ? clamp_bytes((a.batch - b_base) * s1_elems * 4) : 0u, 0x00020000);
+      (void*)(a.src1 ? reinterpret_cast<const char*>(a.src1) + b_base * s1_elems * ES : reinterpret_cast<const char*>(a.src0)), 0,
+      a.src1 ? clamp_bytes((a.batch - b_base) * s1_elems * ES) : 0u, 0x00020000);
 
-  // loaders.  Weights: thread -> (16-byte chunk wcc = 8 k-values, rows wr0 + 32 i).  Activations (fp32 in memory):
-  // thread -> (16-byte chunk acc4 = 4 k-values, rows ar0 + 16 i).
+  // loaders.  Weights: thread -> (16-byte chunk wcc = 8 k-values, rows wr0 + 32 i).  Activations: fp32 in memory: thread ->
+  // (16-byte chunk acc4 = 4 k-values, rows ar0 + 16 i); operand type in memory (SRCH): (chunk = 8 k-values, rows ar0 + 32 i).
   const int wcc = tid & 7, wr0 = tid >> 3;
-  const int acc4 = tid & 15, ar0 = tid >> 4;
+  const int acc4 = SRCH ? (tid & 7) : (tid & 15), ar0 = SRCH ? (tid >> 3) : (tid >> 4);
+  constexpr int ARS = SRCH ? 32 : 16;      // row step between a thread's activation loads
   unsigned voffW[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int co = m0 + wr0 + 32 * i;
     voffW[i] = co < a.cout_s ? (unsigned)((co * p.cin_s + wcc * 8) * 2) : OOB;
   }
-  int prel[8], ihb[8], iwb[8];
+  int prel[NA], ihb[NA], iwb[NA];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int n = n0 + ar0 + 16 * i;
+  for (int i = 0; i < NA; ++i) {
+    const int n = n0 + ar0 + ARS * i;
     const bool pv = n < p.npix;
     const int nn = pv ? n : 0;
     const int b = nn / hw_out;
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
   int it_r = kt_begin - it_tap * nk_tap;
   int it_src = it_r >= p.nkc0 ? 1 : 0;
   int it_kc = it_src ? it_r - p.nkc0 : it_r;
-  unsigned voffA[8];
+  unsigned voffA[NA];
   auto set_tap_src = [&]() __attribute__((always_inline)) {
     const int ky = it_tap / a.ksize;
     const int kx = it_tap - ky * a.ksize;
@@ -553,32 +560,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
     const int hs = it_src ? a.h1 : a.h0;
     const int ws = it_src ? a.w1 : a.w0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int ih = wrap_coord(ihb[i] + ky, a.hin, a.pad_mode);
       const int iw = wrap_coord(iwb[i] + kx, a.win, a.pad_mode);
       const bool ok = prel[i] >= 0 && (unsigned)ih < (unsigned)a.hin && (unsigned)iw < (unsigned)a.win;
       const int pix = (prel[i] * hs + (ih >> up)) * ws + (iw >> upw);
-      voffA[i] = ok ? (unsigned)((pix * cs + acc4 * 4) * 4) : OOB;
+      voffA[i] = ok ? (unsigned)((pix * cs + acc4 * ACH) * ES) : OOB;
     }
   };
 
-  float4 ra[4];  // 8 two-byte weights each
-  float4 rb[8];  // 4 fp32 activations each
+  float4 ra[4];   // 8 two-byte weights each
+  float4 rb[NA];  // 4 fp32 activations each (SRCH: 8 two-byte ones)
   auto load_tile = [&]() __attribute__((always_inline)) {
     const int cs = it_src ? a.c1s : a.c0s;
     const int kbase = it_kc * HBK;
     const int kglob = (it_src ? a.c0s : 0) + kbase;
     const unsigned soffW = (unsigned)(((int64_t)it_tap * a.cout_s * p.cin_s + kglob) * 2);
-    const unsigned soffA = (unsigned)(kbase * 4);
-    const bool kv = kbase + acc4 * 4 < cs;
+    const unsigned soffA = (unsigned)(kbase * ES);
+    const bool kv = kbase + acc4 * ACH < cs;
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = buf_ld4(rw, voffW[i], soffW);
     if (it_src) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) rb[i] = buf_ld4(rs1, kv ? voffA[i] : OOB, soffA);
+      for (int i = 0; i < NA; ++i) rb[i] = buf_ld4(rs1, kv ? voffA[i] : OOB, soffA);
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) rb[i] = buf_ld4(rs0, kv ? voffA[i] : OOB, soffA);
+      for (int i = 0; i < NA; ++i) rb[i] = buf_ld4(rs0, kv ? voffA[i] : OOB, soffA);
     }
   };
   auto advance = [&]() __attribute__((always_inline)) {
@@ -599,14 +606,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(As + (wr0 + 32 * i) * HLDS + wcc * 8) = ra[i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NA; ++i) {
+      if constexpr (SRCH) {
+        *reinterpret_cast<float4*>(Bs + (ar0 + ARS * i) * HLDS + acc4 * 8) = rb[i];
+        continue;
+      }
       const f32x4v v = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
       if constexpr (F16) {
         const f16x4 hv = __builtin_convertvector(v, f16x4);
-        *reinterpret_cast<f16x4*>(Bs + (ar0 + 16 * i) * HLDS + acc4 * 4) = hv;
+        *reinterpret_cast<f16x4*>(Bs + (ar0 + ARS * i) * HLDS + acc4 * 4) = hv;
       } else {
         const bf16x4 hv = __builtin_convertvector(v, bf16x4);
-        *reinterpret_cast<bf16x4*>(Bs + (ar0 + 16 * i) * HLDS + acc4 * 4) = hv;
+        *reinterpret_cast<bf16x4*>(Bs + (ar0 + ARS * i) * HLDS + acc4 * 4) = hv;
       }
     }
   };
@@ -662,7 +673,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_half_kernel(ConvP p) {
     if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
-  store_acc_tiles(p, acc, m0, n0, wc, wp, lane, reinterpret_cast<float*>(hsm));
+  if (a.dst_dtype) store_acc_tiles<F16 ? 2 : 1>(p, acc, m0, n0, wc, wp, lane, reinterpret_cast<float*>(hsm));
+  else store_acc_tiles(p, acc, m0, n0, wc, wp, lane, reinterpret_cast<float*>(hsm));
 }
 
 // =================================================================================================
@@ -911,7 +923,7 @@ static_assert(2 * GSTAGE <= G_LDS_BYTES, "stages must fit under the epilogue buf
 // preparation / split-K slabs: epilogue_store_batch).
 // NCT = 32-cout MFMA tiles per wave: 4 (256-cout tile, passes of 128) or 3 (192-cout tile, passes of 96 couts = 24 quads per pixel
 // row, 21 rows per sweep of the 512 threads, 8 of them idle).
-template <int NCT>
+template <int NCT, int IO = 0>
 __device__ __forceinline__ void gemm_big_epilogue(const ConvP& p, const f32x16 (&acc)[NCT][2], int m0, int n0, int wc, int wp, int lane,
                                                   int tid, float* gsmf) {
   constexpr int PW = 32 * NCT;         // couts per pass
@@ -956,7 +968,7 @@ __device__ __forceinline__ void gemm_big_epilogue(const ConvP& p, const f32x16 (
           n[i] = b[i] >= 0 ? n0 + px : -1;
           v[i] = in ? *reinterpret_cast<const float4*>(gsmf + px * OST + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        epilogue_store_batch<NB>(a, n, b, co, v, (int64_t)blockIdx.y * p.npix);
+        epilogue_store_batch<NB, false, IO>(a, n, b, co, v, (int64_t)blockIdx.y * p.npix);
       }
     }
     __syncthreads();
@@ -1132,8 +1144,11 @@ constexpr int HGPLANE = GB * HGK * 2;         // bytes per operand plane of a st
 constexpr int HGSTAGE = 2 * HGPLANE;          // 64 KB
 static_assert(2 * HGSTAGE <= G_LDS_BYTES, "stages must fit under the epilogue buffer");
 
-template <bool F16, bool TAPS = false>  // TAPS: k x k filters with a stride and zero padding, as in conv_gemm_x3_big_kernel
+// SRCH: the sources hold the operand type already (AzConvArgs.src_dtype = 1): a row's 64 k-values are 128 contiguous bytes, one
+// 16-byte load per row and thread instead of two, stored to LDS as loaded.
+template <bool F16, bool TAPS = false, bool SRCH = false>  // TAPS: k x k filters with a stride and zero padding, as in conv_gemm_x3_big_kernel
 __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
+  constexpr int ES = SRCH ? 2 : 4;  // bytes per source element
   using H8 = typename std::conditional<F16, f16x8, bf16x8>::type;
   using H4 = typename std::conditional<F16, f16x4, bf16x4>::type;
   __shared__ __attribute__((aligned(16))) float gsmf[G_LDS_BYTES / 4];
@@ -1160,12 +1175,12 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
   const int64_t wtap = (int64_t)a.cout_s * p.cin_s;     // elements per tap
   const int64_t spix = (int64_t)a.batch * a.h0 * a.w0;   // source pixels (= p.npix for a 1x1, stride-1 launch)
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.weight, 0, (unsigned)(a.ksize * a.ksize * wtap * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (unsigned)(spix * a.c0s * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (unsigned)(spix * a.c0s * ES), 0x00020000);
   const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? (unsigned)(spix * a.c1s * 4) : 0u, 0x00020000);
+      (void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? (unsigned)(spix * a.c1s * ES) : 0u, 0x00020000);
 
   // loaders: thread -> chunk tid & 7 (8 k-values) of rows (tid >> 3) + 64 i of both operands: the 8 lanes of a row read 128
-  // (weights) / 256 (activations) contiguous bytes
+  // (weights, half-precision activations) / 256 (fp32 activations) contiguous bytes
   const int lch = tid & 7, lr0 = tid >> 3;
   unsigned voffW[4], voffX[4], voffX1[4];
   int lds_row[4];
@@ -1183,8 +1198,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
       pb[i] = n0 + row < p.npix ? b_ * a.h0 : -1;
     }
     voffW[i] = (unsigned)(((int64_t)co * p.cin_s + lch * 8) * 2);
-    voffX[i] = (unsigned)(((int64_t)px * a.c0s + lch * 8) * 4);
-    voffX1[i] = (unsigned)(((int64_t)px * a.c1s + lch * 8) * 4);
+    voffX[i] = (unsigned)(((int64_t)px * a.c0s + lch * 8) * ES);
+    voffX1[i] = (unsigned)(((int64_t)px * a.c1s + lch * 8) * ES);
     lds_row[i] = row * 128 + ((lch ^ ((row >> 1) & 7)) * 16);
   }
   float4 rwt[4], rxa[4][2];
@@ -1195,26 +1210,26 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
       const bool s1 = kr >= p.nkc0;
       const __amdgpu_buffer_rsrc_t r = s1 ? rx1 : rx;
       const int cs = s1 ? a.c1s : a.c0s;
-      const unsigned so = (unsigned)((s1 ? kr - p.nkc0 : kr) * HGK * 4);
+      const unsigned so = (unsigned)((s1 ? kr - p.nkc0 : kr) * HGK * ES);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         rwt[i] = buf_ld4(rw, voffW[i], (unsigned)((tap * wtap + (int64_t)kr * HGK) * 2));
         const int ih = ihb[i] + ky, iw = iwb[i] + kx;
         const bool ok = pb[i] >= 0 && (unsigned)ih < (unsigned)a.h0 && (unsigned)iw < (unsigned)a.w0;  // (zero padding: reads zeros)
-        const unsigned vo = ok ? (unsigned)((((int64_t)(pb[i] + ih) * a.w0 + iw) * cs + lch * 8) * 4) : OOB;
+        const unsigned vo = ok ? (unsigned)((((int64_t)(pb[i] + ih) * a.w0 + iw) * cs + lch * 8) * ES) : OOB;
         rxa[i][0] = buf_ld4(r, vo, so);
-        rxa[i][1] = buf_ld4(r, ok ? vo + 16u : OOB, so);
+        if constexpr (!SRCH) rxa[i][1] = buf_ld4(r, ok ? vo + 16u : OOB, so);
       }
     } else {
       const bool s1 = kt >= p.nkc0;  // (wave-uniform; selects, not a branch)
       const __amdgpu_buffer_rsrc_t r = s1 ? rx1 : rx;
-      const unsigned so = (unsigned)((s1 ? kt - p.nkc0 : kt) * HGK * 4);
+      const unsigned so = (unsigned)((s1 ? kt - p.nkc0 : kt) * HGK * ES);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         rwt[i] = buf_ld4(rw, voffW[i], (unsigned)(kt * HGK * 2));
         const unsigned vo = s1 ? voffX1[i] : voffX[i];
         rxa[i][0] = buf_ld4(r, vo, so);
-        rxa[i][1] = buf_ld4(r, vo + 16u, so);
+        if constexpr (!SRCH) rxa[i][1] = buf_ld4(r, vo + 16u, so);
       }
     }
   };
@@ -1223,6 +1238,10 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       *reinterpret_cast<float4*>(st + lds_row[i]) = rwt[i];
+      if constexpr (SRCH) {
+        *reinterpret_cast<float4*>(st + HGPLANE + lds_row[i]) = rxa[i][0];
+        continue;
+      }
       const f32x4v lo = {rxa[i][0].x, rxa[i][0].y, rxa[i][0].z, rxa[i][0].w}, hi = {rxa[i][1].x, rxa[i][1].y, rxa[i][1].z, rxa[i][1].w};
       const H4 l4 = __builtin_convertvector(lo, H4), h4 = __builtin_convertvector(hi, H4);
       H8 v8;
@@ -1290,7 +1309,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
     }
     __syncthreads();  // every wave has read stage `buf`; the other stage is complete
   }
-  gemm_big_epilogue<4>(p, acc, m0, n0, wc, wp, lane, tid, gsmf);
+  if (a.dst_dtype) gemm_big_epilogue<4, F16 ? 2 : 1>(p, acc, m0, n0, wc, wp, lane, tid, gsmf);
+  else gemm_big_epilogue<4>(p, acc, m0, n0, wc, wp, lane, tid, gsmf);
 }
 
 // =================================================================================================
@@ -1512,7 +1532,8 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvP p, int tiles_w, in
   }
 }
 
-// Split-K combine + epilogue: one thread per (pixel, 4 channels).
+// Split-K combine + epilogue: one thread per (pixel, 4 channels).  IO: element type of dst / res (AzConvArgs.dst_dtype x the entry's type).
+template <int IO = 0>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvP p) {
   const AzConvArgs& a = p.a;
   const int q = a.cout_s / 4;
@@ -1529,7 +1550,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvP p) {
       v.z += w.z;
       v.w += w.w;
     }
-    epilogue_store(a, n, co, v);
+    epilogue_store<IO>(a, n, co, v);
   }
 }
 
@@ -1539,6 +1560,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvP p) {
 // visits, so its pivoted sums need no cross-thread traffic until the end, where the (at most 256 / Q) slots of a quad are
 // folded with Chan's combination in a fixed order through LDS (deterministic).  Layout of the partials: az_conv2d_winograd_f32's
 // ([image][chunk][quad] x (n, mean, M2, 0)), n = the number of values behind a partial (az_groupnorm_finalize_f32 takes any n).
+template <int IO = 0>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(ConvP p, int cpix) {
   __shared__ float sh[3 * 256];
   const AzConvArgs& a = p.a;
@@ -1566,8 +1588,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(ConvP p, 
         }
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f), r = g, bv = g;
         if (a.bias) bv = ld4(a.bias + q * 4);
-        epilogue_fetch(a, n, b, q * 4, g, r);
-        const float4 f = epilogue_apply_store(a, n, b, q * 4, v, bv, g, r);
+        epilogue_fetch<IO>(a, n, b, q * 4, g, r);
+        const float4 f = epilogue_apply_store<IO>(a, n, b, q * 4, v, bv, g, r);
         if (cnt == 0.f) pivot = f.x;
         const float d0 = f.x - pivot, d1 = f.y - pivot, d2 = f.z - pivot, d3 = f.w - pivot;
         s1 += (d0 + d1) + (d2 + d3);
@@ -2520,17 +2542,22 @@ int az_conv2d_suggest_splitk(int64_t npix, int32_t cout_s, int32_t cin_s, int32_
 
 // Split-K combine + fused epilogue; with AzConvArgs.gn_quads also the GroupNorm moments of the output, one partial per
 // (image, chunk of ceil(hw / gn_chunks) pixels, channel quad).
-static int launch_splitk_reduce(const ConvP& cp, hipStream_t st) {
+static int launch_splitk_reduce(const ConvP& cp, hipStream_t st, int io = 0) {  // io: 0 fp32, 1 bf16, 2 f16 destination / residual
   const AzConvArgs& a = cp.a;
   if (a.gn_quads != nullptr) {
     AZ_REQUIRE(a.gn_chunks >= 1 && !a.dst_nchw && a.act != 4, AZ_E_UNSUPPORTED);
     const int hw = a.hout * a.wout;
     const int cpix = (hw + a.gn_chunks - 1) / a.gn_chunks;
     AZ_REQUIRE((int64_t)cpix * (a.gn_chunks - 1) < hw, AZ_E_SHAPE);  // no empty chunk
-    hipLaunchKernelGGL(conv_splitk_reduce_stats_kernel, dim3((unsigned)a.gn_chunks, (unsigned)a.batch), dim3(256), 0, st, cp, cpix);
+    const dim3 grid((unsigned)a.gn_chunks, (unsigned)a.batch);
+    if (io == 1) hipLaunchKernelGGL(conv_splitk_reduce_stats_kernel<1>, grid, dim3(256), 0, st, cp, cpix);
+    else if (io == 2) hipLaunchKernelGGL(conv_splitk_reduce_stats_kernel<2>, grid, dim3(256), 0, st, cp, cpix);
+    else hipLaunchKernelGGL(conv_splitk_reduce_stats_kernel<0>, grid, dim3(256), 0, st, cp, cpix);
   } else {
     const int grid = az_stream_grid((int64_t)cp.npix * (a.cout_s / 4), 256);
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, cp);
+    if (io == 1) hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, cp);
+    else if (io == 2) hipLaunchKernelGGL(conv_splitk_reduce_kernel<2>, dim3(grid), dim3(256), 0, st, cp);
+    else hipLaunchKernelGGL(conv_splitk_reduce_kernel<0>, dim3(grid), dim3(256), 0, st, cp);
   }
   return az_launch_status();
 }
@@ -2578,6 +2605,13 @@ int az_conv2d_f16_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_d
  * of az_pack_conv_weight_x3_f32; fp32-level accuracy at 0.375 x the matrix-pipe time of the fp32 MFMA.              */
 int az_conv2d_x3_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 3); }
 
+static void launch_igemm_half(const ConvP& p, bool f16, bool srch, dim3 grid, hipStream_t st) {
+  if (f16 && srch) hipLaunchKernelGGL((conv_igemm_half_kernel<true, true>), grid, dim3(256), 0, st, p);
+  else if (f16) hipLaunchKernelGGL((conv_igemm_half_kernel<true, false>), grid, dim3(256), 0, st, p);
+  else if (srch) hipLaunchKernelGGL((conv_igemm_half_kernel<false, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((conv_igemm_half_kernel<false, false>), grid, dim3(256), 0, st, p);
+}
+
 static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   AZ_REQUIRE(!a || !a->in_affine, AZ_E_UNSUPPORTED);  // (the Winograd kernel's gather only)
   if (a && a->depth != 0)  // one depth tap of a 3-D convolution (both sources hold `batch` planes)
@@ -2592,6 +2626,11 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   }
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
+  // half-precision activations in HBM (sources / destination + residual in the entry's 2-byte type): the bf16 / f16 entries only
+  AZ_REQUIRE((a->src_dtype == 0 || a->src_dtype == 1) && (a->dst_dtype == 0 || a->dst_dtype == 1), AZ_E_SHAPE);
+  AZ_REQUIRE((a->src_dtype == 0 && a->dst_dtype == 0) || half == 1 || half == 2, AZ_E_UNSUPPORTED);
+  if (a->src_dtype) AZ_REQUIRE(a->c0s % 8 == 0 && a->c1s % 8 == 0, AZ_E_SHAPE);  // (16-byte loads of 8 values)
+  if (a->dst_dtype) AZ_REQUIRE(!a->dst_nchw, AZ_E_UNSUPPORTED);                   // (the planar destination is the network's fp32 output)
   AZ_REQUIRE(a->act >= 0 && a->act <= 6, AZ_E_UNSUPPORTED);
   if (a->act == 6) AZ_REQUIRE(a->res && !a->gate && !a->dst_nchw && !a->gn_quads, AZ_E_UNSUPPORTED);  // SiLU of the sum with the residual
   if (a->act == 4) AZ_REQUIRE(!a->gate && !a->res && !a->dst_nchw && !a->gn_quads && a->cout_s % 8 == 0, AZ_E_UNSUPPORTED);  // SwiGLU epilogue
@@ -2721,10 +2760,21 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     if (half == 3 && big_ct == 192) hipLaunchKernelGGL(conv_gemm_x3_big_kernel<3>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else if (half == 3 && x3_big_taps(a)) hipLaunchKernelGGL((conv_gemm_x3_big_kernel<4, true>), dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else if (half == 3) hipLaunchKernelGGL(conv_gemm_x3_big_kernel<4>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
-    else if (half == 2 && x3_big_taps(a)) hipLaunchKernelGGL((conv_gemm_half_big_kernel<true, true>), dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
-    else if (half == 2) hipLaunchKernelGGL(conv_gemm_half_big_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
-    else if (x3_big_taps(a)) hipLaunchKernelGGL((conv_gemm_half_big_kernel<false, true>), dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL(conv_gemm_half_big_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
+    else {
+      const dim3 g((unsigned)nwg, (unsigned)splitk);
+#define AZ_HBIG(F16, TAPS, SRCH) hipLaunchKernelGGL((conv_gemm_half_big_kernel<F16, TAPS, SRCH>), g, dim3(512), 0, st, p)
+      switch ((half == 2 ? 4 : 0) + (x3_big_taps(a) ? 2 : 0) + (a->src_dtype ? 1 : 0)) {
+        case 0: AZ_HBIG(false, false, false); break;
+        case 1: AZ_HBIG(false, false, true); break;
+        case 2: AZ_HBIG(false, true, false); break;
+        case 3: AZ_HBIG(false, true, true); break;
+        case 4: AZ_HBIG(true, false, false); break;
+        case 5: AZ_HBIG(true, false, true); break;
+        case 6: AZ_HBIG(true, true, false); break;
+        default: AZ_HBIG(true, true, true); break;
+      }
+#undef AZ_HBIG
+    }
     if (nbig * big_ct < a->cout_s) {  // the remaining output channels (256-cout tiles only): 128 x 128 tiles, K tiles of 32
       ConvP q = p;
       const int sbk = half == 3 ? XBK : HBK;
@@ -2738,14 +2788,11 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
       q.tiles_n = (p.npix + BN - 1) / BN;
       nwg = (int64_t)q.tiles_m * q.tiles_n;
       if (half == 3) hipLaunchKernelGGL(conv_igemm_x3_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, q);
-      else if (half == 2) hipLaunchKernelGGL(conv_igemm_half_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, q);
-      else hipLaunchKernelGGL(conv_igemm_half_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, q);
+      else launch_igemm_half(q, half == 2, a->src_dtype != 0, dim3((unsigned)nwg, (unsigned)splitk), st);
     }
   } else
-  if (half == 1)
-    hipLaunchKernelGGL(conv_igemm_half_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
-  else if (half == 2)
-    hipLaunchKernelGGL(conv_igemm_half_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
+  if (half == 1 || half == 2)
+    launch_igemm_half(p, half == 2, a->src_dtype != 0, dim3((unsigned)nwg, (unsigned)splitk), st);
   else if (half == 3)
     hipLaunchKernelGGL(conv_igemm_x3_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
   else if (k16)
@@ -2756,7 +2803,7 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   if (rc != AZ_OK) return rc;
   if (splitk > 1) {
     p.a.gn_quads = a->gn_quads;
-    rc = launch_splitk_reduce(p, st);
+    rc = launch_splitk_reduce(p, st, a->dst_dtype ? half : 0);
   }
   return rc;
 }
@@ -2822,7 +2869,7 @@ int az_conv2d_winograd_x3_f32(const AzConvArgs* a, az_stream_t stream) {
 /* Validation and launch geometry shared by the two Winograd entries; wk = input channels per K step (8 / 16). */
 static int wino_prepare(const AzConvArgs* a, int wk, int64_t ustage_bytes, WinoP& p, int& splitk) {
   AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
-  AZ_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->aniso, AZ_E_UNSUPPORTED);  // anisotropic: direct kernel
+  AZ_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->aniso && a->src_dtype == 0 && a->dst_dtype == 0, AZ_E_UNSUPPORTED);  // anisotropic, half-precision tensors: direct kernel
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);
@@ -2927,7 +2974,7 @@ int az_conv2d_winograd_suggest_splitk(int64_t batch, int32_t hout, int32_t wout,
  * az_winograd4_pack_filter_f32.  Only ksize = 3, stride = 1, pad = 1. */
 int az_conv2d_winograd4_f32(const AzConvArgs* a, az_stream_t stream) {
   AZ_REQUIRE(a && a->src0 && a->weight && a->dst, AZ_E_NULL);
-  AZ_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->aniso, AZ_E_UNSUPPORTED);  // anisotropic: direct kernel
+  AZ_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->aniso && a->src_dtype == 0 && a->dst_dtype == 0, AZ_E_UNSUPPORTED);  // anisotropic, half-precision tensors: direct kernel
   AZ_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->hout == a->hin && a->wout == a->win, AZ_E_SHAPE);
   AZ_REQUIRE(a->c0s > 0 && a->c0s % 4 == 0 && a->c1s % 4 == 0 && a->cout_s > 0 && a->cout_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE((a->c1s == 0) == (a->src1 == nullptr), AZ_E_SHAPE);

@@ -10,6 +10,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// (ld4_io / st4_io / st2_io / round_io -- typed 4-element accesses of half-precision activation tensors -- live in common.h)
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // 16-byte buffer load: per-lane byte offset `voff` (bounds-checked: >= num_records returns 0,
@@ -83,11 +85,13 @@ __device__ __forceinline__ int64_t epilogue_res_index(const AzConvArgs& a, int n
   return a.res_bcast ? rem : n;
 }
 
+template <int IO = 0>
 __device__ __forceinline__ void epilogue_fetch(const AzConvArgs& a, int n, int b, int co, float4& gate, float4& res) {
   if (a.gate) gate = ld4(a.gate + (int64_t)b * a.gate_bstride + co);
-  if (a.res) res = ld4(a.res + epilogue_res_index(a, n, b) * a.cout_s + co);
+  if (a.res) res = ld4_io<IO>(a.res, epilogue_res_index(a, n, b) * a.cout_s + co);
 }
 
+template <int IO = 0>  // (the planar destination -- the network's output -- is always fp32)
 __device__ __forceinline__ float4 epilogue_apply_store(const AzConvArgs& a, int n, int b, int co, float4 v, float4 bv,
                                                        float4 g, float4 r) {  // bv: bias (zeros if none); returns what it stored
   if (a.bias) {
@@ -100,14 +104,14 @@ __device__ __forceinline__ float4 epilogue_apply_store(const AzConvArgs& a, int 
     // SwiGLU over interleaved channel pairs, y[c] = x[2c] * silu(x[2c+1]) (azula/nn/layers.py:107-110; JiT's SwiGLUFFN with
     // its w12 rows interleaved at build time): the output has HALF the channels (row stride cout_s / 2; the host admits no
     // gate / residual / planar destination here) -- the separate az_swiglu_f32 pass and its 12 B per pair are gone
-    *reinterpret_cast<float2*>(a.dst + (int64_t)n * (a.cout_s / 2) + co / 2) = make_float2(v.x * az_silu(v.y), v.z * az_silu(v.w));
+    st2_io<IO>(a.dst, (int64_t)n * (a.cout_s / 2) + co / 2, make_float2(v.x * az_silu(v.y), v.z * az_silu(v.w)));
     return v;
   }
   if (a.act == 6) {
     // SiLU of the SUM with the residual operand (no gate, NHWC destination): the last depth tap of a 3-D convolution that is
     // followed by an activation accumulates into the other taps' sum and activates it in the same store (nn/unet3d.py)
-    v = make_float4(az_silu(v.x + r.x), az_silu(v.y + r.y), az_silu(v.z + r.z), az_silu(v.w + r.w));
-    *reinterpret_cast<float4*>(a.dst + (int64_t)n * a.cout_s + co) = v;
+    v = round_io<IO>(make_float4(az_silu(v.x + r.x), az_silu(v.y + r.y), az_silu(v.z + r.z), az_silu(v.w + r.w)));
+    st4_io<IO>(a.dst, (int64_t)n * a.cout_s + co, v);
     return v;
   }
   if (a.act == 1) {
@@ -147,16 +151,18 @@ __device__ __forceinline__ float4 epilogue_apply_store(const AzConvArgs& a, int 
     for (int j = 0; j < 4; ++j)
       if (co + j < a.dst_c) a.dst[((int64_t)b * a.dst_c + co + j) * hw + rem] = vv[j];
   } else {
-    *reinterpret_cast<float4*>(a.dst + (int64_t)n * a.cout_s + co) = v;
+    v = round_io<IO>(v);
+    st4_io<IO>(a.dst, (int64_t)n * a.cout_s + co, v);
   }
   return v;
 }
 
+template <int IO = 0>
 __device__ __forceinline__ void epilogue_store_b(const AzConvArgs& a, int n, int b, int co, float4 v) {  // b = image of pixel n
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f), r = g, bv = g;
   if (a.bias) bv = ld4(a.bias + co);
-  epilogue_fetch(a, n, b, co, g, r);
-  epilogue_apply_store(a, n, b, co, v, bv, g, r);
+  epilogue_fetch<IO>(a, n, b, co, g, r);
+  epilogue_apply_store<IO>(a, n, b, co, v, bv, g, r);
 }
 
 // A batch of NB outputs of one thread (same channel quad `co`, pixels n[i] of images b[i]; n[i] < 0: skip): all gate /
@@ -168,7 +174,7 @@ __device__ __forceinline__ void epilogue_store_b(const AzConvArgs& a, int n, int
 // phase of a workgroup was 8 serialised L2 round trips.  RES: 0 none, 1 same pixel, 2 upsampled / broadcast index.
 // MOM: also accumulate the moments of the STORED values about the first one (mom = {pivot, sum d, sum d^2}) on the fly
 // (nothing but three registers outlives the stores).
-template <int NB, bool MOM, int ACT, bool GATE, int RES>
+template <int NB, bool MOM, int ACT, bool GATE, int RES, int IO = 0>
 __device__ __forceinline__ void epilogue_batch_nhwc(const AzConvArgs& a, const int (&n)[NB], const int (&b)[NB], int co,
                                                     const float4 (&v)[NB], float* mom) {
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -189,8 +195,8 @@ __device__ __forceinline__ void epilogue_batch_nhwc(const AzConvArgs& a, const i
     r[i] = z;
     if (n[i] >= 0) {
       if constexpr (GATE) g[i] = ld4(a.gate + (int64_t)b[i] * a.gate_bstride + co);
-      if constexpr (RES == 1) r[i] = ld4(a.res + (int64_t)n[i] * a.cout_s + co);
-      if constexpr (RES == 2) r[i] = ld4(a.res + epilogue_res_index(a, n[i], b[i]) * a.cout_s + co);
+      if constexpr (RES == 1) r[i] = ld4_io<IO>(a.res, (int64_t)n[i] * a.cout_s + co);
+      if constexpr (RES == 2) r[i] = ld4_io<IO>(a.res, epilogue_res_index(a, n[i], b[i]) * a.cout_s + co);
     }
   }
 #pragma unroll
@@ -210,12 +216,11 @@ __device__ __forceinline__ void epilogue_batch_nhwc(const AzConvArgs& a, const i
     }
     if constexpr (ACT == 6) {  // SiLU of the sum with the residual (RES = 1, no gate)
       f = make_float4(az_silu(f.x + r[i].x), az_silu(f.y + r[i].y), az_silu(f.z + r[i].z), az_silu(f.w + r[i].w));
-      if (n[i] >= 0) *reinterpret_cast<float4*>(a.dst + (int64_t)n[i] * a.cout_s + co) = f;
+      if (n[i] >= 0) st4_io<IO>(a.dst, (int64_t)n[i] * a.cout_s + co, f);
       continue;
     }
     if constexpr (ACT == 4) {  // SwiGLU over interleaved pairs: half the channels (see epilogue_apply_store)
-      if (n[i] >= 0)
-        *reinterpret_cast<float2*>(a.dst + (int64_t)n[i] * (a.cout_s / 2) + co / 2) = make_float2(f.x * az_silu(f.y), f.z * az_silu(f.w));
+      if (n[i] >= 0) st2_io<IO>(a.dst, (int64_t)n[i] * (a.cout_s / 2) + co / 2, make_float2(f.x * az_silu(f.y), f.z * az_silu(f.w)));
       continue;
     }
     if constexpr (GATE) {
@@ -230,10 +235,15 @@ __device__ __forceinline__ void epilogue_batch_nhwc(const AzConvArgs& a, const i
       f.z += r[i].z;
       f.w += r[i].w;
     }
-    if (n[i] >= 0) {
-      float* d = a.dst + (int64_t)n[i] * a.cout_s + co;
-      if (stream_out) az_st_stream(d, f);
-      else *reinterpret_cast<float4*>(d) = f;
+    if constexpr (IO == 0) {
+      if (n[i] >= 0) {
+        float* d = a.dst + (int64_t)n[i] * a.cout_s + co;
+        if (stream_out) az_st_stream(d, f);
+        else *reinterpret_cast<float4*>(d) = f;
+      }
+    } else {
+      f = round_io<IO>(f);  // (the moments below are those of the stored values)
+      if (n[i] >= 0) st4_io<IO>(a.dst, (int64_t)n[i] * a.cout_s + co, f);
     }
     if constexpr (MOM) {  // GroupNorm statistics of the output come from here (gn_quads; the host admits no skipped pixel)
       if (i == 0) mom[0] = f.x;
@@ -249,7 +259,7 @@ __device__ __forceinline__ void epilogue_batch_nhwc(const AzConvArgs& a, const i
 // quad `co` of pixels (tokens) n[i]; the D / 4 quads of a (token, head) sit on D / 4 adjacent lanes (the exchange buffer is read
 // back with a pixel's 32 quads on 32 consecutive lanes and tiles start at multiples of 128 channels), so the sum of squares is a
 // butterfly over 8 / 16 / 32 lanes.  Every lane takes part in the shuffles (v lanes and skipped pixels compute values they drop).
-template <int NB>
+template <int NB, int IO = 0>
 __device__ __forceinline__ void epilogue_batch_qk(const AzConvArgs& a, const int (&n)[NB], const int (&b)[NB], int co,
                                                   const float4 (&v)[NB]) {
   const int D = a.qk_head_dim, HC = a.qk_heads * D;
@@ -310,13 +320,13 @@ __device__ __forceinline__ void epilogue_batch_qk(const AzConvArgs& a, const int
       f.z = r1 * rc[i].y - i1 * rs[i].y;
       f.w = r1 * rs[i].y + i1 * rc[i].y;
     }
-    if (n[i] >= 0) *reinterpret_cast<float4*>(a.dst + (int64_t)n[i] * a.cout_s + co) = f;
+    if (n[i] >= 0) st4_io<IO>(a.dst, (int64_t)n[i] * a.cout_s + co, f);
   }
 }
 
 // A batch of NB outputs of one thread (same channel quad `co`, pixels n[i] of images b[i]; n[i] < 0: skip): all gate /
 // residual reads are issued first, then the NB stores.
-template <int NB, bool MOM = false>
+template <int NB, bool MOM = false, int IO = 0>
 __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const int (&n)[NB], const int (&b)[NB], int co,
                                                      const float4 (&v)[NB], int64_t ws_slab, float* mom = nullptr) {
   if (a.splitk > 1) {
@@ -325,15 +335,15 @@ __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const 
       if (n[i] >= 0) *reinterpret_cast<float4*>(a.workspace + (ws_slab + n[i]) * a.cout_s + co) = v[i];
     return;
   }
-  if (a.act == 4) return epilogue_batch_nhwc<NB, false, 4, false, 0>(a, n, b, co, v, mom);
-  if (a.act == 5) return epilogue_batch_qk<NB>(a, n, b, co, v);
-  if (a.act == 6 && !a.res_up && !a.res_bcast) return epilogue_batch_nhwc<NB, false, 6, false, 1>(a, n, b, co, v, mom);
+  if (a.act == 4) return epilogue_batch_nhwc<NB, false, 4, false, 0, IO>(a, n, b, co, v, mom);
+  if (a.act == 5) return epilogue_batch_qk<NB, IO>(a, n, b, co, v);
+  if (a.act == 6 && !a.res_up && !a.res_bcast) return epilogue_batch_nhwc<NB, false, 6, false, 1, IO>(a, n, b, co, v, mom);
   if (!a.dst_nchw && a.act <= 1) {
     const int rk = a.res == nullptr ? 0 : (a.res_up || a.res_bcast) ? 2 : 1;
     switch ((a.act * 2 + (a.gate != nullptr ? 1 : 0)) * 3 + rk) {
 #define AZ_EPI_CASE(ACT, GATE, RES) \
   case (ACT * 2 + GATE) * 3 + RES:  \
-    return epilogue_batch_nhwc<NB, MOM, ACT, GATE != 0, RES>(a, n, b, co, v, mom);
+    return epilogue_batch_nhwc<NB, MOM, ACT, GATE != 0, RES, IO>(a, n, b, co, v, mom);
       AZ_EPI_CASE(0, 0, 0) AZ_EPI_CASE(0, 0, 1) AZ_EPI_CASE(0, 0, 2) AZ_EPI_CASE(0, 1, 0) AZ_EPI_CASE(0, 1, 1) AZ_EPI_CASE(0, 1, 2)
       AZ_EPI_CASE(1, 0, 0) AZ_EPI_CASE(1, 0, 1) AZ_EPI_CASE(1, 0, 2) AZ_EPI_CASE(1, 1, 0) AZ_EPI_CASE(1, 1, 1) AZ_EPI_CASE(1, 1, 2)
 #undef AZ_EPI_CASE
@@ -346,12 +356,12 @@ __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const 
   for (int i = 0; i < NB; ++i) {
     g[i] = z;
     r[i] = z;
-    if (n[i] >= 0) epilogue_fetch(a, n[i], b[i], co, g[i], r[i]);
+    if (n[i] >= 0) epilogue_fetch<IO>(a, n[i], b[i], co, g[i], r[i]);
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i)
     if (n[i] >= 0) {
-      const float4 f = epilogue_apply_store(a, n[i], b[i], co, v[i], bv, g[i], r[i]);
+      const float4 f = epilogue_apply_store<IO>(a, n[i], b[i], co, v[i], bv, g[i], r[i]);
       if constexpr (MOM) {
         if (i == 0) mom[0] = f.x;
         const float d0 = f.x - mom[0], d1 = f.y - mom[0], d2 = f.z - mom[0], d3 = f.w - mom[0];
@@ -361,8 +371,9 @@ __device__ __forceinline__ void epilogue_store_batch(const AzConvArgs& a, const 
     }
 }
 
+template <int IO = 0>
 __device__ __forceinline__ void epilogue_store(const AzConvArgs& a, int n, int co, float4 v) {
-  epilogue_store_b(a, n, n / (a.hout * a.wout), co, v);
+  epilogue_store_b<IO>(a, n, n / (a.hout * a.wout), co, v);
 }
 
 

@@ -374,6 +374,84 @@ __global__ __launch_bounds__(256) void affine_act_pool_kernel(float* __restrict_
   }
 }
 
+// rownorm_mod_kernel's fast path on 2-byte rows (IO 1: bfloat16, 2: IEEE half): one wave per row, lane -> 8 consecutive values per
+// 16-byte load (c = 8 lane + 512 k), fp32 statistics in the fast path's order of operations, output rounded to nearest even.
+template <int IO>
+__global__ __launch_bounds__(256) void rownorm_mod_h16_kernel(unsigned short* __restrict__ y, const unsigned short* __restrict__ x,
+                                                              const float* __restrict__ weight, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int64_t scale_bstride, int64_t rows,
+                                                              int64_t rows_per_batch, int C, int kind, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  constexpr int NV = 8;
+  const int c0 = lane * 8;
+  for (int64_t row = wave; row < rows; row += nwaves) {
+    const float* xr = reinterpret_cast<const float*>(x + row * C);  // (typed accesses through ld4_io: element indices)
+    float* yr = reinterpret_cast<float*>(y + row * C);
+    const int64_t b = row / rows_per_batch;
+    float4 v[NV][2];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = c0 + 512 * k;
+      if (c < C) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          v[k][hh] = ld4_io<IO>(xr, c + 4 * hh);
+          const float4 t = v[k][hh];
+          if (kind == 0) s += (t.x + t.y) + (t.z + t.w);
+          else s += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+        }
+      }
+    }
+    s = az_wave_sum(s);
+    float mean = 0.f, rstd;
+    if (kind == 0) {
+      mean = s / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+        if (c0 + 512 * k < C) {
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const float a0 = v[k][hh].x - mean, a1 = v[k][hh].y - mean, a2 = v[k][hh].z - mean, a3 = v[k][hh].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+          }
+        }
+      q = az_wave_sum(q);
+      rstd = rsqrtf(q / (float)(C - 1) + eps);
+    } else {
+      rstd = rsqrtf(s / (float)C + eps);
+    }
+    const float* sc = scale ? scale + b * scale_bstride : nullptr;
+    const float* sh = shift ? shift + b * scale_bstride : nullptr;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int cb = c0 + 512 * k;
+      if (cb < C) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int c = cb + 4 * hh;
+          const float in[4] = {v[k][hh].x, v[k][hh].y, v[k][hh].z, v[k][hh].w};
+          float w4[4] = {1.f, 1.f, 1.f, 1.f}, sc4[4] = {0.f, 0.f, 0.f, 0.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (weight) { const float4 t = *reinterpret_cast<const float4*>(weight + c); w4[0] = t.x; w4[1] = t.y; w4[2] = t.z; w4[3] = t.w; }
+          if (sc) { const float4 t = *reinterpret_cast<const float4*>(sc + c); sc4[0] = t.x; sc4[1] = t.y; sc4[2] = t.z; sc4[3] = t.w; }
+          if (sh) { const float4 t = *reinterpret_cast<const float4*>(sh + c); sh4[0] = t.x; sh4[1] = t.y; sh4[2] = t.z; sh4[3] = t.w; }
+          float o4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float o = (in[j] - mean) * rstd;
+            if (weight) o *= w4[j];
+            o4[j] = o * (1.f + sc4[j]) + sh4[j];
+          }
+          st4_io<IO>(yr, c, make_float4(o4[0], o4[1], o4[2], o4[3]));
+        }
+      }
+    }
+  }
+}
+
 // One wave per row.  kind 0: layer norm (unbiased variance), kind 1: RMS norm.
 __global__ __launch_bounds__(256) void rownorm_mod_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                           const float* __restrict__ weight,
@@ -589,6 +667,27 @@ int az_affine_act_f32(float* y, const float* x, const float* x1, int64_t c0s, co
     else
       hipLaunchKernelGGL(affine_act_kernel<0>, grid, dim3(256), 0, st, y, x, x1, (int)c0s, S, T, (int)(H * W), (int)cs);
   }
+  return az_launch_status();
+}
+
+/* az_rownorm_mod_f32 on rows held in a 2-byte type (dtype 1: bfloat16, 2: IEEE half; x and y alike): the activations of a module
+ * cast to half precision.  Statistics, the gain and the modulation are fp32 (the reference's RMSNorm / LayerNorm upcast
+ * internally); the row is read once into registers (C % 8 == 0, C == cs, C <= 4096).                                          */
+int az_rownorm_mod_h16(void* y, const void* x, const float* weight, const float* scale, const float* shift,
+                       int64_t scale_bstride, int64_t rows, int64_t rows_per_batch, int64_t C, int64_t cs, int32_t kind,
+                       float eps, int32_t dtype, az_stream_t stream) {
+  AZ_REQUIRE(y && x, AZ_E_NULL);
+  AZ_REQUIRE(rows > 0 && rows_per_batch > 0 && C > 0 && (kind == 0 || kind == 1) && (dtype == 1 || dtype == 2), AZ_E_SHAPE);
+  AZ_REQUIRE(C % 8 == 0 && C == cs && C <= 4096 && scale_bstride % 4 == 0, AZ_E_UNSUPPORTED);
+  AZ_REQUIRE(AZ_ALIGNED16(y) && AZ_ALIGNED16(x) && AZ_ALIGNED16(weight) && AZ_ALIGNED16(scale) && AZ_ALIGNED16(shift), AZ_E_ALIGN);
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == 1)
+    hipLaunchKernelGGL(rownorm_mod_h16_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, az_s(stream), (unsigned short*)y, (const unsigned short*)x,
+                       weight, scale, shift, scale_bstride, rows, rows_per_batch, (int)C, (int)kind, eps);
+  else
+    hipLaunchKernelGGL(rownorm_mod_h16_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, az_s(stream), (unsigned short*)y, (const unsigned short*)x,
+                       weight, scale, shift, scale_bstride, rows, rows_per_batch, (int)C, (int)kind, eps);
   return az_launch_status();
 }
 

@@ -22,6 +22,17 @@ def pad4(c: int) -> int:
     return (c + 3) // 4 * 4
 
 
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+# Modules cast to half precision (.bfloat16() / .half()): "1" (default since round 6) = their activations live in HBM in the module's
+# own type between the layers, as in the reference (azula/denoise.py:314-320 casts the backbone input to the module's dtype, so every
+# tensor of the forward is a half tensor); statistics, softmax, gates and residual ADDS are evaluated in fp32 registers.  "0" = fp32
+# activations in HBM, converted per tile (rounds 2 - 5).  Only plans whose every kernel has the typed form take it (ViT / DiT).
+HALF_ACT = os.environ.get("AZ_HALF_ACT", "1") != "0"
+
+
 class Tape:
     r"""A recorded sequence of C-ABI kernel launches with static arguments."""
 
@@ -92,26 +103,31 @@ class Pool:
         self.free: dict[int, list[torch.Tensor]] = {}
         self.all: list[torch.Tensor] = []
 
-    def alloc(self, numel: int) -> torch.Tensor:
-        lst = self.free.get(numel)
+    def alloc(self, numel: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        lst = self.free.get((numel, dtype))
         if lst:
             return lst.pop()
-        t = torch.empty(numel, dtype=torch.float32, device=self.device)
+        t = torch.empty(numel, dtype=dtype, device=self.device)
         self.all.append(t)
         return t
 
     def release(self, t: torch.Tensor) -> None:
-        self.free.setdefault(t.numel(), []).append(t)
+        self.free.setdefault((t.numel(), t.dtype), []).append(t)
 
     @property
     def bytes(self) -> int:
-        return sum(t.numel() * 4 for t in self.all)
+        return sum(t.numel() * t.element_size() for t in self.all)
 
 
 class Act:
     r"""An NHWC activation: ``buf`` holds (B, H, W, cs) floats, ``C`` real channels."""
 
     __slots__ = ("buf", "B", "H", "W", "C", "cs", "pinned", "gn_quads", "affine", "qk_prepared")
+
+    @property
+    def half(self) -> bool:
+        r"""The buffer holds a 2-byte type (the activations of a module cast to half precision, engine.HALF_ACT)."""
+        return self.buf.dtype != torch.float32
 
     def __init__(self, buf: torch.Tensor, B: int, H: int, W: int, C_: int, cs: int, pinned: bool = False) -> None:
         self.buf, self.B, self.H, self.W, self.C, self.cs, self.pinned = buf, B, H, W, C_, cs, pinned
@@ -180,8 +196,8 @@ class ConvWeights:
         self.cout, self.cin, self.ks, kw = self.w.shape
         assert self.ks == kw
         self.cin0 = self.cin if cin0 is None else cin0
-        self.c0s, self.c1s = pad4(self.cin0), pad4(self.cin - self.cin0)
-        self.cout_s = pad4(self.cout)
+        self.c0s, self.c1s = bld.pad(self.cin0), bld.pad(self.cin - self.cin0)
+        self.cout_s = bld.pad(self.cout)
         self.device = bld.device
         self.bias = None
         if bias is not None:
@@ -281,11 +297,13 @@ class ConvWeights:
 class Builder:
     r"""Emits kernels onto a tape; owns the pool, packed weights and the split-K workspace."""
 
-    def __init__(self, device: torch.device, half: torch.dtype | None = None) -> None:
+    def __init__(self, device: torch.device, half: torch.dtype | None = None, half_act: bool = False) -> None:
         r"""``half``: torch.bfloat16 / torch.float16 routes every conv / token GEMM through the half-operand MFMA
-        kernel (fp32 accumulate, fp32 activations) -- set by the plans of modules cast to half precision."""
+        kernel (fp32 accumulate) -- set by the plans of modules cast to half precision.  ``half_act``: the plan also keeps its
+        activations in HBM in that type (HALF_ACT; channel strides are then multiples of 8)."""
         self.device = device
         self.half = half if half in (torch.bfloat16, torch.float16) else None
+        self.half_act = bool(half_act) and self.half is not None and HALF_ACT
         self.tape = Tape()
         self.pool = Pool(device)
         self._ws_need = 0
@@ -293,9 +311,15 @@ class Builder:
         self.workspace: torch.Tensor | None = None
 
     # -- buffers ---------------------------------------------------------------------------
-    def new_act(self, B: int, H: int, W: int, C_: int, pinned: bool = False) -> Act:
-        cs = pad4(C_)
-        return Act(self.pool.alloc(B * H * W * cs), B, H, W, C_, cs, pinned)
+    def pad(self, c: int) -> int:
+        r"""Channel stride of this plan's activations: multiples of 4 floats, or of 8 two-byte values (16-byte vectors either way)."""
+        return pad8(c) if self.half_act else pad4(c)
+
+    def new_act(self, B: int, H: int, W: int, C_: int, pinned: bool = False, f32: bool = False) -> Act:
+        r"""``f32``: an fp32 tensor also in a half-activation plan (the plan's input / output tensors)."""
+        cs = self.pad(C_)
+        dtype = self.half if (self.half_act and not f32) else torch.float32
+        return Act(self.pool.alloc(B * H * W * cs, dtype), B, H, W, C_, cs, pinned)
 
     def free(self, a: Act) -> None:
         if not a.pinned:
@@ -345,6 +369,7 @@ class Builder:
         out: Act | None = None,
         depth: tuple | None = None,
         qk_prep: dict | None = None,
+        out_f32: bool = False,
     ) -> Act | None:
         ks, bias = packed.ks, packed.bias
         pad = ks // 2
@@ -371,7 +396,10 @@ class Builder:
             a.depth, a.depth_shift = depth[0], depth[1]
             a.depth_wrap = int(bool(depth[2])) if len(depth) > 2 else 0
         a.bias = bias.data_ptr() if bias is not None else None
-        a.cout_s = pad4(cout)
+        a.cout_s = self.pad(cout)
+        if self.half_act:  # typed tensors (AzConvArgs.src_dtype / dst_dtype): sources as they are, the destination in the module's type
+            assert src1 is None or src1.half == src0.half, "both sources in one element type"
+            a.src_dtype = int(src0.half)
         a.ksize, a.stride, a.pad = ks, stride, pad
         a.pad_mode = 1 if (periodic and pad > 0) else 0
         a.hout, a.wout = hout, wout
@@ -392,12 +420,16 @@ class Builder:
             if out is None:
                 if act == 4:  # SwiGLU epilogue: half the channels come out (y[c] = x[2c] * silu(x[2c+1]))
                     assert cout % 8 == 0 and gate is None and res is None, "SwiGLU epilogue: cout % 8 == 0, no gate / residual"
-                    out = self.new_act(B, hout, wout, cout // 2)
+                    assert not self.half_act or cout % 16 == 0
+                    out = self.new_act(B, hout, wout, cout // 2, f32=out_f32)
                 else:
-                    out = self.new_act(B, hout, wout, cout)
+                    out = self.new_act(B, hout, wout, cout, f32=out_f32)
             else:  # caller-owned destination (a plane range of a volume; may alias `res`: in-place accumulation)
-                assert (out.B, out.H, out.W, out.C, out.cs) == (B, hout, wout, cout, pad4(cout)), "destination shape"
+                assert (out.B, out.H, out.W, out.C, out.cs) == (B, hout, wout, cout, self.pad(cout)), "destination shape"
             a.dst = out.ptr
+            a.dst_dtype = int(out.half)
+            if res is not None:
+                assert res.half == out.half, "the residual has the destination's element type"
         npix = B * hout * wout
         cin_s = a.c0s + a.c1s
         lib = _lib.lib()
@@ -624,14 +656,16 @@ class Builder:
 
     def row_norm(self, x: Act, kind: int, *, weight=None, scale=None, shift=None, scale_off=0, shift_off=0, bstride=0,
                  eps=1e-5):
-        y = self.new_act(x.B, x.H, x.W, x.C)
+        y = self.new_act(x.B, x.H, x.W, x.C, f32=not x.half)
         rows = x.B * x.H * x.W
-        self.tape.add(
-            "az_rownorm_mod_f32", y.ptr, x.ptr, weight.data_ptr() if weight is not None else None,
-            scale.data_ptr() + 4 * scale_off if scale is not None else None,
-            shift.data_ptr() + 4 * shift_off if shift is not None else None,
-            bstride, rows, x.H * x.W, x.C, x.cs, kind, eps, keep=[weight, scale, shift],
-        )
+        args = (y.ptr, x.ptr, weight.data_ptr() if weight is not None else None,
+                scale.data_ptr() + 4 * scale_off if scale is not None else None,
+                shift.data_ptr() + 4 * shift_off if shift is not None else None,
+                bstride, rows, x.H * x.W, x.C, x.cs, kind, eps)
+        if x.half:  # rows in the module's 2-byte type (fp32 statistics / modulation)
+            self.tape.add("az_rownorm_mod_h16", *args, 2 if x.buf.dtype == torch.float16 else 1, keep=[weight, scale, shift])
+        else:
+            self.tape.add("az_rownorm_mod_f32", *args, keep=[weight, scale, shift])
         return y
 
 
@@ -750,8 +784,10 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
     dim = Cq // heads
     assert qkv.cs == qkv.C and dim * heads == Cq
     L = qkv.H * qkv.W
-    out = self.new_act(qkv.B, qkv.H, qkv.W, Cq)
+    out = self.new_act(qkv.B, qkv.H, qkv.W, Cq, f32=not qkv.half)
     a = AzAttnArgs()
+    a.io_dtype = int(qkv.half)  # (q, k, v, out in the module's 2-byte type: the bf16 / f16 entries only)
+    es = 2 if qkv.half else 4
     base = qkv.ptr
     if order in ("nHC", "3HC"):
         offs, hs = (0, Cq, 2 * Cq), dim
@@ -759,7 +795,7 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
         offs, hs = (0, dim, 2 * dim), 3 * dim
     else:
         raise ValueError(order)
-    a.q, a.k, a.v, a.out = base + 4 * offs[0], base + 4 * offs[1], base + 4 * offs[2], out.ptr
+    a.q, a.k, a.v, a.out = base + es * offs[0], base + es * offs[1], base + es * offs[2], out.ptr
     a.batch, a.heads, a.tokens, a.head_dim = qkv.B, heads, L, dim
     for n in ("q", "k", "v"):
         setattr(a, n + "_bstride", L * qkv.cs)

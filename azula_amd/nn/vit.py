@@ -106,11 +106,28 @@ class MultiheadSelfAttention(nn.Module):
         return plan.run(x, None).to(out_dtype)
 
 
+def _half_act_ok(module: nn.Module) -> bool:
+    r"""A token module cast to half precision can keep its activations in HBM in its own type (engine.HALF_ACT) when every
+    kernel on its tape has the typed form: token widths that are multiples of 8 and at most 4096 (az_rownorm_mod_h16, 16-byte
+    vectors of 8 values), SwiGLU only through the GEMM's epilogue."""
+    for m in module.modules():
+        if isinstance(m, MultiheadSelfAttention):
+            c = m.qkv_proj.in_features
+            if c % 8 or c > 4096 or (c // m.heads) % 4:
+                return False
+        if isinstance(m, DiTBlock):
+            if m.channels % 8 or m.channels > 4096 or m.ffn[3].in_features % 8:
+                return False
+            if m.ffn_activation == "swiglu" and m.ffn[0].out_features % 16:
+                return False
+    return True
+
+
 class _TokenPlan:
     r"""One-module plan on a (B, L, C) token tensor: input Act, optional modulation front, output Act."""
 
     def __init__(self, module: nn.Module, B: int, L: int, Cin: int, pos_h, mod_rows: int, D: int, emit, device) -> None:
-        bld = self.bld = Builder(device, half=next(module.parameters()).dtype)
+        bld = self.bld = Builder(device, half=next(module.parameters()).dtype, half_act=_half_act_ok(module) and Cin % 8 == 0)
         self.versions = _versions(module)
         self.x_in = bld.new_act(B, L, 1, Cin, pinned=True)
         self.mod = torch.empty(max(mod_rows, 1), max(D, 1), dtype=torch.float32, device=device)
@@ -270,7 +287,7 @@ class DiTPlan:
     r"""Compiled forward for (batch, tokens[, patch geometry], modulation rows)."""
 
     def __init__(self, net: "DiT", B: int, L: int, pos: Tensor, mod_rows: int, device, patch=None) -> None:
-        bld = self.bld = Builder(device, half=next(net.parameters()).dtype)
+        bld = self.bld = Builder(device, half=next(net.parameters()).dtype, half_act=_half_act_ok(net) and net.hid_channels % 8 == 0)
         D, C_ = net.mod_features, net.hid_channels
         self.mod = torch.empty(max(mod_rows, 1), max(D, 1), dtype=torch.float32, device=device)
         self.mod_rows = mod_rows
@@ -280,11 +297,11 @@ class DiTPlan:
         if patch is not None:
             Z, H, W, p, pu = patch
             self.x_nchw = torch.empty(B, Z, H, W, dtype=torch.float32, device=device)
-            tokens = bld.new_act(B, L, 1, cin, pinned=True)
+            tokens = bld.new_act(B, L, 1, cin, pinned=True, f32=True)  # (the plan's input stays fp32: the first GEMM rounds it per tile)
             bld.tape.add("az_patchify_f32", tokens.ptr, self.x_nchw.data_ptr(), None, B, Z, H, W, p, tokens.cs)
             self.x_in_buf, self.x_in_cs = self.x_nchw, 0
         else:
-            tokens = bld.new_act(B, L, 1, cin, pinned=True)
+            tokens = bld.new_act(B, L, 1, cin, pinned=True, f32=True)
             self.x_in_buf, self.x_in_cs = tokens.buf, tokens.cs
         self.tokens = tokens
 
@@ -295,6 +312,10 @@ class DiTPlan:
         ptab = pb.conv(enc_act, pb.pack_conv(net.pos_embedding[2].weight, None), C_)
         pb.finish()
         pb.tape.run()
+        if bld.half_act:  # the residual operand of the first GEMM has the destination's element type
+            pt = torch.zeros(L, bld.pad(C_), dtype=bld.half, device=device)
+            pt[:, :C_] = ptab.buf.view(L, ptab.cs)[:, :C_]
+            ptab = Act(pt.reshape(-1), 1, L, 1, C_, bld.pad(C_), True)
         self.pos_table = ptab
         bld.tape.keep.extend([pb, enc_act])
         ptab.pinned = True
@@ -303,7 +324,7 @@ class DiTPlan:
         mod_jobs: list[tuple] = []  # queued modulation MLPs of the blocks, emitted together at the tape front
         for blk in net.blocks:
             x = blk._emit(bld, x, pos, None, D, mod_rows, mod_jobs)
-        o = bld.conv(x, bld.pack_conv(net.out_proj.weight, net.out_proj.bias), cout)
+        o = bld.conv(x, bld.pack_conv(net.out_proj.weight, net.out_proj.bias), cout, out_f32=True)  # (the plan's output: fp32)
         bld.free(x)
         if patch is not None:  # '... A B (Z a b) -> ... Z (A a) (B b)' with the UNPATCH size (reference vit.py:63-74,104-106)
             Z, H, W, p, pu = patch

@@ -236,6 +236,12 @@ int az_rownorm_mod_f32(float* y, const float* x, const float* weight, const floa
                        int64_t scale_bstride,
                        int64_t rows, int64_t rows_per_batch, int64_t C, int64_t cs, int32_t kind, float eps,
                        az_stream_t stream);
+/* The same on rows held in a 2-byte type -- dtype 1: bfloat16, 2: IEEE half; x and y alike: the activations of a module cast to
+ * half precision (azula/denoise.py:314-320; torch's RMSNorm / the reference's layer_norm on a half tensor).  Statistics, gain and
+ * modulation in fp32, output rounded to nearest even.  C % 8 == 0, C == cs, C <= 4096 (else AZ_E_UNSUPPORTED).                 */
+int az_rownorm_mod_h16(void* y, const void* x, const float* weight, const float* scale, const float* shift,
+                       int64_t scale_bstride, int64_t rows, int64_t rows_per_batch, int64_t C, int64_t cs, int32_t kind,
+                       float eps, int32_t dtype, az_stream_t stream);
 
 /* ------------------------------------------------------------------ K3/K5: implicit-GEMM convolution
  * out[b, oh, ow, co] = epilogue( bias[co] + sum_{ky,kx,ci} in[b, oh*s+ky-p, ow*s+kx-p, ci] * W[co, ci, ky, kx] )
@@ -296,7 +302,10 @@ typedef struct AzConvArgs {
                             * Padding stays ZERO (the reference pads the normalised tensor: azula/nn/unet.py:85-92,
                             * plugins/adm/_src/unet.py:196-203).  Needs a single source, c0s % 8 == 0, up0 == 0 */
   int32_t in_act;          /* with in_affine: 0 none, 1 SiLU */
-  int32_t reserved1;
+  int32_t src_dtype;       /* az_conv2d_bf16_f32 / az_conv2d_f16_f32 only (0 elsewhere): 0 = the sources hold fp32 (rounded to the operand type
+                            * per tile), 1 = they hold the launch's 2-byte operand type already -- the activations of a module cast to
+                            * half precision live in HBM in the module's type (azula/denoise.py:314-320); channel strides are then
+                            * multiples of 8, `src0` / `src1` are the tensors' addresses and the strides stay in ELEMENTS */
   int32_t depth;           /* > 0 (az_conv2d_f32, az_conv2d_winograd_f32; every source holds `batch` planes): the `batch` images are the planes of
                             * batch / depth volumes, and this launch is ONE DEPTH TAP of a 3-D convolution (azula/nn/layers.py:25-68
                             * with spatial = 3): image b reads source plane b + depth_shift, taken as zeros where
@@ -322,7 +331,10 @@ typedef struct AzConvArgs {
   const float* qk_rope_sin;
   int32_t depth_wrap;      /* with depth: 1 = circular padding along the depth axis (azula/nn/layers.py:25-68 with
                             * padding_mode "circular": a tap that leaves the volume reads the plane at its other end) */
-  int32_t depth_reserved;
+  int32_t dst_dtype;       /* az_conv2d_bf16_f32 / az_conv2d_f16_f32 only (0 elsewhere): 1 = `dst` AND `res` hold the launch's 2-byte operand type
+                            * (rounded to nearest even on the way out; bias, activation, gate, residual arithmetic stays fp32; GroupNorm
+                            * moments are those of the rounded values); the planar destination (dst_nchw) and the split-K workspace are
+                            * always fp32 */
 } AzConvArgs;
 /* Narrow outputs (cout_s == 4, 3x3 stride 1 pad 1, one un-upsampled source with c0s % 16 == 0: the image head of
  * azula/nn/unet.py) run a VALU kernel instead of the 128-cout MFMA tile; splitk is ignored there.              */
@@ -421,6 +433,11 @@ typedef struct AzAttnArgs {
    * in the reference.  NULL = no mask.                                                                            */
   const uint8_t* mask;
   int64_t mask_bstride, mask_hstride;
+  /* az_attention_bf16_f32 / az_attention_f16_f32 only (0 elsewhere): 1 = q, k, v and out hold the entry's 2-byte type (the
+   * activations of a module cast to half precision live in HBM in the module's type); strides stay in ELEMENTS, addresses and
+   * strides need 8-byte granularity.  Norms, gains, RoPE and the softmax stay fp32.                                      */
+  int32_t io_dtype;
+  int32_t reserved;
 } AzAttnArgs;
 int az_attention_f32(const AzAttnArgs* args, az_stream_t stream);
 /* The same operation for backbones cast to half precision: q / k / v / out stay fp32 tensors, norms, gains, RoPE and the

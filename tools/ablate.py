@@ -175,15 +175,15 @@ VARIANTS["tr_un2"] = [("transition.hip", "constexpr int TF_UN = 4;", "constexpr 
 VARIANTS["tr_grid2k"] = [("transition.hip", "  const int64_t gcap = 16384 / gy < 1 ? 1 : 16384 / gy;", "  const int64_t gcap = 2048 / gy < 1 ? 1 : 2048 / gy;")]  # 8 resident workgroups per CU, grid-stride
 # the matrix kernels' output stores (epilogue_batch_nhwc) ship as non-temporal stores for outputs of 128 MiB and more:
 # never / always the hint
-VARIANTS["epi_plainst"] = [("conv_shared.h", "      if (stream_out) az_st_stream(d, f);\n      else *reinterpret_cast<float4*>(d) = f;", "      *reinterpret_cast<float4*>(d) = f;")]
-VARIANTS["epi_ntall"] = [("conv_shared.h", "      if (stream_out) az_st_stream(d, f);\n      else *reinterpret_cast<float4*>(d) = f;", "      az_st_stream(d, f);")]
+VARIANTS["epi_plainst"] = [("conv_shared.h", "        if (stream_out) az_st_stream(d, f);\n        else *reinterpret_cast<float4*>(d) = f;", "        *reinterpret_cast<float4*>(d) = f;")]
+VARIANTS["epi_ntall"] = [("conv_shared.h", "        if (stream_out) az_st_stream(d, f);\n        else *reinterpret_cast<float4*>(d) = f;", "        az_st_stream(d, f);")]
 # the x3 Winograd kernel's filter stream with the non-temporal hint (aux = 2): the small-map layers read every filter byte once or twice
 VARIANTS["wx3_unt"] = [("wino_x3.hip", "ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
                         "ua[ch][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(u_lane + (unsigned)((ch * 3 + pl) * 1024)), (int)soff, 2));")]
 # further candidates for the hint (one line each): the row norms' output, the stem's output, the epilogue's residual reads
 VARIANTS["rn_ntst"] = [("norm.hip", "          *reinterpret_cast<float4*>(yr + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);", "          az_st_stream(yr + c, make_float4(o4[0], o4[1], o4[2], o4[3]));")]
 VARIANTS["stem_ntst"] = [("conv.hip", "        *reinterpret_cast<float4*>(a.dst + (((int64_t)b * H + oh) * W + ow) * a.cout_s + q * 4) = o;", "        az_st_stream(a.dst + (((int64_t)b * H + oh) * W + ow) * a.cout_s + q * 4, o);")]
-VARIANTS["res_ntld"] = [("conv_shared.h", "      if constexpr (RES == 1) r[i] = ld4(a.res + (int64_t)n[i] * a.cout_s + co);", "      if constexpr (RES == 1) r[i] = az_ld_stream(a.res + (int64_t)n[i] * a.cout_s + co);")]
+VARIANTS["res_ntld"] = [("conv_shared.h", "      if constexpr (RES == 1) r[i] = ld4_io<IO>(a.res, (int64_t)n[i] * a.cout_s + co);", "      if constexpr (RES == 1) r[i] = az_ld_stream(a.res + (int64_t)n[i] * a.cout_s + co);")]
 _AF_LD = [("norm.hip", "  if (x1 == nullptr) return *reinterpret_cast<const float4*>(x + pix * cs + c);", "  if (x1 == nullptr) return az_ld_stream(x + pix * cs + c);")]
 _AF_ST = [("norm.hip", "    for (int u = 0; u < UN; ++u) yb[(int64_t)(p + u * pstride) * q] = apply(v[u]);",
            "    for (int u = 0; u < UN; ++u) az_st_stream(reinterpret_cast<float*>(yb + (int64_t)(p + u * pstride) * q), apply(v[u]));")]
