@@ -247,6 +247,8 @@ PROTOTYPES: dict[str, list] = {
     "az_affine_act_f32": [vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, i32, i32, c_stream],
     "az_rownorm_mod_f32": [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, c_stream],
     "az_rownorm_mod_h16": [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, f32, i32, c_stream],
+    "az_groupnorm_stats_h16": [vp, vp, vp, i64, i64, i64, i64, i64, i32, i32, i32, c_stream],
+    "az_affine_act_h16": [vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, i32, i32, i32, c_stream],
     "az_token_copy_f32": [vp, i64, i64, vp, i64, i64, i64, i64, i64, c_stream],
     "az_token_fill_f32": [vp, i64, i64, i64, vp, i64, vp, i64, i64, c_stream],
     "az_timestep_embedding_f32": [vp, i64, vp, i64, i64, i32, f32, c_stream],

@@ -34,6 +34,7 @@ __device__ __forceinline__ Moments combine(Moments a, Moments b) {
 // grid = (nchunks, B, slices); slice z covers float4 chunks [z*qs, (z+1)*qs).
 // Two-source form: logical channels [0, c0s) live in x (stride c0s), [c0s, cs) in x1 (stride cs - c0s):
 // the skip concatenation of the ADM decoder (plugins/adm/_src/unet.py:631) is never materialised.
+template <int IO = 0>  // element type of x / x1 (common.h: ld4_io; strides and offsets stay in elements)
 __global__ __launch_bounds__(256) void gn_stats_vec_kernel(float* __restrict__ partials,
                                                            const float* __restrict__ x,
                                                            const float* __restrict__ x1, int c0s, int64_t HW, int C,
@@ -54,14 +55,15 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(float* __restrict__ p
   if (live) {
     const bool second = x1 != nullptr && c >= c0s;
     const int scs = x1 == nullptr ? cs : (second ? cs - c0s : c0s);
-    const float* base = (second ? x1 : x) + ((int64_t)b * HW) * scs + (second ? c - c0s : c);
+    const float* src = second ? x1 : x;
+    const int64_t base = ((int64_t)b * HW) * scs + (second ? c - c0s : c);  // (element index)
     int64_t p = p0 + pl;
-    if (p < p1) shift = base[p * scs];  // shift = first element: sums of (x - shift) cannot cancel badly
+    if (p < p1) shift = ld4_io<IO>(src, base + p * scs).x;  // shift = first element: sums of (x - shift) cannot cancel badly
     // 4 independent 16-byte loads in flight per lane (a streaming reduction is latency-bound otherwise)
     for (; p + 3 * ppi < p1; p += 4 * ppi) {
       float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(base + (p + u * ppi) * scs);
+      for (int u = 0; u < 4; ++u) v[u] = ld4_io<IO>(src, base + (p + u * ppi) * scs);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float a0 = v[u].x - shift, a1 = v[u].y - shift, a2 = v[u].z - shift, a3 = v[u].w - shift;
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void gn_stats_vec_kernel(float* __restrict__ p
       cnt += 16.f;
     }
     for (; p < p1; p += ppi) {
-      const float4 v = *reinterpret_cast<const float4*>(base + p * scs);
+      const float4 v = ld4_io<IO>(src, base + p * scs);
       const float a0 = v.x - shift, a1 = v.y - shift, a2 = v.z - shift, a3 = v.w - shift;
       s1 += (a0 + a1) + (a2 + a3);
       s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
@@ -272,18 +274,19 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(AzNormFinalizeArgs a) {
   }
 }
 
+template <int IO = 0>
 __device__ __forceinline__ float4 ld_cat(const float* __restrict__ x, const float* __restrict__ x1, int c0s, int cs,
                                          int64_t pix, int c) {
-  if (x1 == nullptr) return *reinterpret_cast<const float4*>(x + pix * cs + c);
-  if (c < c0s) return *reinterpret_cast<const float4*>(x + pix * c0s + c);
-  return *reinterpret_cast<const float4*>(x1 + pix * (cs - c0s) + (c - c0s));
+  if (x1 == nullptr) return ld4_io<IO>(x, pix * cs + c);
+  if (c < c0s) return ld4_io<IO>(x, pix * c0s + c);
+  return ld4_io<IO>(x1, pix * (cs - c0s) + (c - c0s));
 }
 
 // y = act(x * S[b, c] + T[b, c]).  HBM-bound (8 B per element) only if the per-element ALU work stays small: a
 // thread owns ONE channel quad for its whole run (the launch makes the thread count a multiple of the quads per pixel,
 // blockIdx.y is the sample), so S / T are loaded once and the loop body has no division -- the first version spent
 // three 64-bit divisions per float4 and ran at 2.5 TB/s.
-template <int ACT>
+template <int ACT, int IO = 0>  // IO: element type of x / x1 / y
 __global__ __launch_bounds__(256) void affine_act_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                          const float* __restrict__ x1, int c0s,
                                                          const float* __restrict__ S, const float* __restrict__ T,
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(float* __restrict__ y, 
   const float4 sc = *reinterpret_cast<const float4*>(S + (int64_t)b * cs + c4 * 4);
   const float4 t = *reinterpret_cast<const float4*>(T + (int64_t)b * cs + c4 * 4);
   const int64_t pix0 = (int64_t)b * HW;
-  float4* yb = reinterpret_cast<float4*>(y) + pix0 * q + c4;
+  const int64_t yo = (pix0 * q + c4) * 4;  // (element index of the thread's first output quad)
   constexpr int UN = 4;  // loads in flight per thread (2: 0.65 of the HBM roofline at batch 32)
   auto apply = [&](float4 v) {
     float4 o;
@@ -316,14 +319,14 @@ __global__ __launch_bounds__(256) void affine_act_kernel(float* __restrict__ y, 
   for (; p + (UN - 1) * pstride < HW; p += UN * pstride) {
     float4 v[UN];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) v[u] = ld_cat(x, x1, c0s, cs, pix0 + p + u * pstride, c4 * 4);
+    for (int u = 0; u < UN; ++u) v[u] = ld_cat<IO>(x, x1, c0s, cs, pix0 + p + u * pstride, c4 * 4);
 #pragma unroll
-    for (int u = 0; u < UN; ++u) yb[(int64_t)(p + u * pstride) * q] = apply(v[u]);
+    for (int u = 0; u < UN; ++u) st4_io<IO>(y, yo + (int64_t)(p + u * pstride) * cs, apply(v[u]));
   }
-  for (; p < HW; p += pstride) yb[(int64_t)p * q] = apply(ld_cat(x, x1, c0s, cs, pix0 + p, c4 * 4));
+  for (; p < HW; p += pstride) st4_io<IO>(y, yo + (int64_t)p * cs, apply(ld_cat<IO>(x, x1, c0s, cs, pix0 + p, c4 * 4)));
 }
 
-template <int ACT, int PH>  // PH = rows of the pooling window: 2 (AvgPool2d(2, 2)) or 1 (AvgPool1d(2) on a one-row image)
+template <int ACT, int PH, int IO = 0>  // PH = rows of the pooling window: 2 (AvgPool2d(2, 2)) or 1 (AvgPool1d(2) on a one-row image)
 __global__ __launch_bounds__(256) void affine_act_pool_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                               const float* __restrict__ x1, int c0s,
                                                               const float* __restrict__ S,
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256) void affine_act_pool_kernel(float* __restrict_
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
         const int64_t pix = (b * H + (PH * oh + dy)) * W + (2 * ow + dx);
-        const float4 v = ld_cat(x, x1, c0s, cs, pix, c4 * 4);
+        const float4 v = ld_cat<IO>(x, x1, c0s, cs, pix, c4 * 4);
         float4 o;
         o.x = fmaf(v.x, s.x, t.x);
         o.y = fmaf(v.y, s.y, t.y);
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256) void affine_act_pool_kernel(float* __restrict_
     acc.y *= inv;
     acc.z *= inv;
     acc.w *= inv;
-    reinterpret_cast<float4*>(y)[e] = acc;
+    st4_io<IO>(y, e * 4, acc);
   }
 }
 
@@ -579,6 +582,37 @@ __global__ __launch_bounds__(256) void rownorm_mod_kernel(float* __restrict__ y,
 
 }  // namespace
 
+template <int IO>
+static int affine_act_h16_launch(float* y, const float* x, const float* x1, int64_t c0s, const float* S, const float* T, int64_t B,
+                                 int64_t H, int64_t W, int64_t cs, int32_t act, int32_t pool, hipStream_t st) {
+  if (pool == 2) {
+    AZ_REQUIRE(W % 2 == 0, AZ_E_SHAPE);
+    const int grid = az_stream_grid(B * H * (W / 2) * (cs / 4), 256);
+    if (act == 1) hipLaunchKernelGGL((affine_act_pool_kernel<1, 1, IO>), dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, (int)H, (int)W, (int)cs);
+    else hipLaunchKernelGGL((affine_act_pool_kernel<0, 1, IO>), dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, (int)H, (int)W, (int)cs);
+  } else if (pool) {
+    AZ_REQUIRE(H % 2 == 0 && W % 2 == 0, AZ_E_SHAPE);
+    const int grid = az_stream_grid(B * (H / 2) * (W / 2) * (cs / 4), 256);
+    if (act == 1) hipLaunchKernelGGL((affine_act_pool_kernel<1, 2, IO>), dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, (int)H, (int)W, (int)cs);
+    else hipLaunchKernelGGL((affine_act_pool_kernel<0, 2, IO>), dim3(grid), dim3(256), 0, st, y, x, x1, (int)c0s, S, T, B, (int)H, (int)W, (int)cs);
+  } else {
+    AZ_REQUIRE(H * W < (1ll << 31) && B < 65536, AZ_E_SHAPE);
+    const int q = (int)(cs / 4);
+    int qq = q, r256 = 256;
+    while (r256) { const int tmp = qq % r256; qq = r256; r256 = tmp; }  // qq = gcd(q, 256)
+    const int unit = q / qq;
+    int64_t want = (H * W * q + 256 * 8 - 1) / (256 * 8);
+    const int64_t cap = (2048 + B - 1) / B;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    const int gx = (int)((want + unit - 1) / unit * unit);
+    dim3 grid((unsigned)gx, (unsigned)B);
+    if (act == 1) hipLaunchKernelGGL((affine_act_kernel<1, IO>), grid, dim3(256), 0, st, y, x, x1, (int)c0s, S, T, (int)(H * W), (int)cs);
+    else hipLaunchKernelGGL((affine_act_kernel<0, IO>), grid, dim3(256), 0, st, y, x, x1, (int)c0s, S, T, (int)(H * W), (int)cs);
+  }
+  return az_launch_status();
+}
+
 extern "C" {
 
 int az_groupnorm_stats_f32(float* partials, const float* x, const float* x1, int64_t c0s, int64_t B, int64_t HW,
@@ -600,7 +634,7 @@ int az_groupnorm_stats_f32(float* partials, const float* x, const float* x1, int
   const bool fast = qs >= 32 || (qs > 0 && qs == q);  // (narrow slices of a wide tensor: the generic kernel)
   if (fast) {
     dim3 grid((unsigned)nchunks, (unsigned)B, (unsigned)(q / qs));
-    hipLaunchKernelGGL(gn_stats_vec_kernel, grid, dim3(256), 0, az_s(stream), partials, x, x1, (int)c0s, HW, (int)C,
+    hipLaunchKernelGGL(gn_stats_vec_kernel<0>, grid, dim3(256), 0, az_s(stream), partials, x, x1, (int)c0s, HW, (int)C,
                        (int)cs, (int)groups, (int)nchunks, qs);
   } else {
     dim3 grid((unsigned)nchunks, (unsigned)B, (unsigned)groups);
@@ -663,11 +697,55 @@ int az_affine_act_f32(float* y, const float* x, const float* x1, int64_t c0s, co
     const int gx = (int)((want + unit - 1) / unit * unit);
     dim3 grid((unsigned)gx, (unsigned)B);
     if (act == 1)
-      hipLaunchKernelGGL(affine_act_kernel<1>, grid, dim3(256), 0, st, y, x, x1, (int)c0s, S, T, (int)(H * W), (int)cs);
+      hipLaunchKernelGGL((affine_act_kernel<1, 0>), grid, dim3(256), 0, st, y, x, x1, (int)c0s, S, T, (int)(H * W), (int)cs);
     else
-      hipLaunchKernelGGL(affine_act_kernel<0>, grid, dim3(256), 0, st, y, x, x1, (int)c0s, S, T, (int)(H * W), (int)cs);
+      hipLaunchKernelGGL((affine_act_kernel<0, 0>), grid, dim3(256), 0, st, y, x, x1, (int)c0s, S, T, (int)(H * W), (int)cs);
   }
   return az_launch_status();
+}
+
+/* az_groupnorm_stats_f32 / az_affine_act_f32 on tensors held in a 2-byte type (dtype 1: bfloat16, 2: IEEE half; x, x1 and y alike):
+ * the activations of a module cast to half precision.  Statistics and the apply arithmetic are fp32; y is rounded to nearest even.
+ * Channel strides are multiples of 8; the statistics need whole groups in 4-channel chunks (else AZ_E_UNSUPPORTED).            */
+int az_groupnorm_stats_h16(float* partials, const void* x, const void* x1, int64_t c0s, int64_t B, int64_t HW, int64_t C,
+                           int64_t cs, int32_t groups, int32_t nchunks, int32_t dtype, az_stream_t stream) {
+  AZ_REQUIRE(partials && x, AZ_E_NULL);
+  AZ_REQUIRE(dtype == 1 || dtype == 2, AZ_E_SHAPE);
+  if (x1) AZ_REQUIRE(c0s > 0 && c0s < cs && c0s % 8 == 0 && C == cs && AZ_ALIGNED16(x1), AZ_E_SHAPE);
+  AZ_REQUIRE(B > 0 && HW > 0 && C > 0 && cs >= C && cs % 8 == 0 && groups > 0 && C % groups == 0 && nchunks > 0, AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(x), AZ_E_ALIGN);
+  const int Cg = (int)(C / groups);
+  const int q = (int)(cs / 4);
+  int qs = 0;
+  if (Cg % 4 == 0 && C == cs) {
+    for (int d = q < 256 ? q : 256; d >= Cg / 4 && qs == 0; --d)
+      if (q % d == 0 && (4 * d) % Cg == 0) qs = d;
+  } else if (Cg % 4 == 0 && q <= 256) {
+    qs = q;
+  }
+  AZ_REQUIRE(qs > 0, AZ_E_UNSUPPORTED);  // (the scalar generic kernel has no typed form)
+  dim3 grid((unsigned)nchunks, (unsigned)B, (unsigned)(q / qs));
+  const float* xf = reinterpret_cast<const float*>(x);
+  const float* x1f = reinterpret_cast<const float*>(x1);
+  if (dtype == 1)
+    hipLaunchKernelGGL(gn_stats_vec_kernel<1>, grid, dim3(256), 0, az_s(stream), partials, xf, x1f, (int)c0s, HW, (int)C, (int)cs, (int)groups, (int)nchunks, qs);
+  else
+    hipLaunchKernelGGL(gn_stats_vec_kernel<2>, grid, dim3(256), 0, az_s(stream), partials, xf, x1f, (int)c0s, HW, (int)C, (int)cs, (int)groups, (int)nchunks, qs);
+  return az_launch_status();
+}
+
+int az_affine_act_h16(void* y, const void* x, const void* x1, int64_t c0s, const float* S, const float* T, int64_t B, int64_t H,
+                      int64_t W, int64_t cs, int32_t act, int32_t pool, int32_t dtype, az_stream_t stream) {
+  AZ_REQUIRE(y && x && S && T, AZ_E_NULL);
+  AZ_REQUIRE(dtype == 1 || dtype == 2, AZ_E_SHAPE);
+  if (x1) AZ_REQUIRE(c0s > 0 && c0s < cs && c0s % 8 == 0 && AZ_ALIGNED16(x1), AZ_E_SHAPE);
+  AZ_REQUIRE(B > 0 && H > 0 && W > 0 && cs > 0 && cs % 8 == 0, AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(y) && AZ_ALIGNED16(x) && AZ_ALIGNED16(S) && AZ_ALIGNED16(T), AZ_E_ALIGN);
+  float* yf = reinterpret_cast<float*>(y);
+  const float* xf = reinterpret_cast<const float*>(x);
+  const float* x1f = reinterpret_cast<const float*>(x1);
+  if (dtype == 1) return affine_act_h16_launch<1>(yf, xf, x1f, c0s, S, T, B, H, W, cs, act, pool, az_s(stream));
+  return affine_act_h16_launch<2>(yf, xf, x1f, c0s, S, T, B, H, W, cs, act, pool, az_s(stream));
 }
 
 /* az_rownorm_mod_f32 on rows held in a 2-byte type (dtype 1: bfloat16, 2: IEEE half; x and y alike): the activations of a module

@@ -595,9 +595,17 @@ class Builder:
         r"""The apply pass of a lazy normalisation (``Act.affine``) as a tensor of its own."""
         ST, act = x.affine
         n = x.B * x.cs
-        y = self.new_act(x.B, x.H, x.W, x.C)
-        self.tape.add("az_affine_act_f32", y.ptr, x.ptr, None, 0, ST.data_ptr(), ST.data_ptr() + 4 * n, x.B, x.H, x.W, x.cs, act, 0)
+        y = self.new_act(x.B, x.H, x.W, x.C, f32=not x.half)
+        self._affine_act(y, x, None, 0, ST.data_ptr(), ST.data_ptr() + 4 * n, x.B, x.H, x.W, x.cs, act, 0)
         return y
+
+    def _affine_act(self, y: Act, x: Act, x1p, c0s: int, S: int, T: int, B: int, H: int, W: int, cs: int, act: int, pool: int) -> None:
+        r"""y = act(x * S + T) (optionally pooled) on fp32 tensors or on tensors in the module's 2-byte type (x, x1, y alike)."""
+        if x.half:
+            assert y.half
+            self.tape.add("az_affine_act_h16", y.ptr, x.ptr, x1p, c0s, S, T, B, H, W, cs, act, pool, 2 if x.buf.dtype == torch.float16 else 1)
+        else:
+            self.tape.add("az_affine_act_f32", y.ptr, x.ptr, x1p, c0s, S, T, B, H, W, cs, act, pool)
 
     def group_norm(
         self, x: Act, groups: int, *, weight=None, bias=None, scale=None, shift=None, scale_off=0, shift_off=0,
@@ -610,7 +618,7 @@ class Builder:
         src_quads = [x.gn_quads] + ([x1.gn_quads] if x1 is not None else [])
         src_channels = [x.C] + ([x1.C] if x1 is not None else [])
         if x1 is not None:
-            assert x.C == x.cs and x1.C == x1.cs and (x1.H, x1.W) == (x.H, x.W)
+            assert x.C == x.cs and x1.C == x1.cs and (x1.H, x1.W) == (x.H, x.W) and x1.half == x.half
             x1p, c0s = x1.ptr, x.cs
             x = Act(x.buf, x.B, x.H, x.W, x.C + x1.C, x.cs + x1.cs, True)
         ST = self.empty(2 * B * x.cs)  # [scale | shift]: one buffer (AzConvArgs.in_affine reads both through one descriptor)
@@ -628,7 +636,11 @@ class Builder:
         else:
             nchunks = int(min(512, max(1, (HW * x.cs * 4) // 65536)))  # ~64 KB of x per workgroup
             partials = self.empty(B * nchunks * groups * 4)
-            self.tape.add("az_groupnorm_stats_f32", partials.data_ptr(), x.ptr, x1p, c0s, B, HW, x.C, x.cs, groups, nchunks)
+            if x.half:
+                self.tape.add("az_groupnorm_stats_h16", partials.data_ptr(), x.ptr, x1p, c0s, B, HW, x.C, x.cs, groups, nchunks,
+                              2 if x.buf.dtype == torch.float16 else 1)
+            else:
+                self.tape.add("az_groupnorm_stats_f32", partials.data_ptr(), x.ptr, x1p, c0s, B, HW, x.C, x.cs, groups, nchunks)
             f.partials = partials.data_ptr()
         f.S, f.T = S.data_ptr(), T.data_ptr()
         f.weight = weight.data_ptr() if weight is not None else None
@@ -646,12 +658,10 @@ class Builder:
             y.affine = (ST, act)
             return y
         if pool:  # 1: 2x2, 2: along the width only (a 1-D signal held as a one-row image)
-            y = self.new_act(B, x.H // 2 if pool == 1 else x.H, x.W // 2, x.C)
+            y = self.new_act(B, x.H // 2 if pool == 1 else x.H, x.W // 2, x.C, f32=not x.half)
         else:
-            y = self.new_act(B, x.H, x.W, x.C)
-        self.tape.add(
-            "az_affine_act_f32", y.ptr, x.ptr, x1p, c0s, S.data_ptr(), T.data_ptr(), B, x.H, x.W, x.cs, act, pool
-        )
+            y = self.new_act(B, x.H, x.W, x.C, f32=not x.half)
+        self._affine_act(y, x, x1p, c0s, S.data_ptr(), T.data_ptr(), B, x.H, x.W, x.cs, act, pool)
         return y
 
     def row_norm(self, x: Act, kind: int, *, weight=None, scale=None, shift=None, scale_off=0, shift_off=0, bstride=0,

@@ -221,7 +221,14 @@ class UNetPlan:
 
     def __init__(self, net: "UNet", B: int, H: int, W: int, mod_rows: int, device: torch.device) -> None:
         self.B, self.H, self.W = B, H, W
-        bld = self.bld = Builder(device, half=next(net.parameters()).dtype)
+        # a network cast to half precision keeps its activations in HBM in its own type (engine.HALF_ACT) when every kernel on its
+        # tape has the typed form: channel counts in multiples of 8, whole GroupNorm groups in 4-channel chunks, power-of-two strides
+        sv0 = (net.stride, net.stride) if isinstance(net.stride, int) else tuple(net.stride)
+        blocks = [m for m in net.modules() if isinstance(m, UNetBlock)]
+        half_act = (net.spatial == 2 and all(c % 8 == 0 for c in net.hid_channels) and all(v in (1, 2, 4, 8, 16) for v in sv0)
+                    and all(b.norm_kind != "group" or (b.channels // b.groups) % 4 == 0 for b in blocks)
+                    and all(b.ffn[0].out_channels % 8 == 0 and b.channels <= 4096 for b in blocks))
+        bld = self.bld = Builder(device, half=next(net.parameters()).dtype, half_act=half_act)
         cin = net.in_channels + net.cond_channels
         D = net.mod_features
         first = net.descent[0][0]
@@ -232,7 +239,7 @@ class UNetPlan:
         if self.planar:
             self.x_in = Act(torch.empty(B * cin * H * W, dtype=torch.float32, device=device), B, H, W, cin, 0, True)
         else:
-            self.x_in = Act(torch.empty(B * H * W * pad4(cin), dtype=torch.float32, device=device), B, H, W, cin, pad4(cin), True)
+            self.x_in = Act(torch.zeros(B * H * W * bld.pad(cin), dtype=torch.float32, device=device), B, H, W, cin, bld.pad(cin), True)
         self.mod = torch.empty(max(mod_rows, 1), max(D, 1), dtype=torch.float32, device=device)
         self.mod_rows = mod_rows
         self.out = torch.empty(B, net.out_channels, H, W, dtype=torch.float32, device=device)

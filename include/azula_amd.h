@@ -236,6 +236,13 @@ int az_rownorm_mod_f32(float* y, const float* x, const float* weight, const floa
                        int64_t scale_bstride,
                        int64_t rows, int64_t rows_per_batch, int64_t C, int64_t cs, int32_t kind, float eps,
                        az_stream_t stream);
+/* az_groupnorm_stats_f32 and az_affine_act_f32 on tensors held in a 2-byte type -- dtype 1: bfloat16, 2: IEEE half; x, x1 and y
+ * alike: the activations of a module cast to half precision (azula/denoise.py:314-320; torch.nn.GroupNorm on a half tensor
+ * computes its statistics in fp32 as well).  Strides in elements, multiples of 8; y rounded to nearest even.                  */
+int az_groupnorm_stats_h16(float* partials, const void* x, const void* x1, int64_t c0s, int64_t B, int64_t HW, int64_t C,
+                           int64_t cs, int32_t groups, int32_t nchunks, int32_t dtype, az_stream_t stream);
+int az_affine_act_h16(void* y, const void* x, const void* x1, int64_t c0s, const float* S, const float* T, int64_t B, int64_t H,
+                      int64_t W, int64_t cs, int32_t act, int32_t pool, int32_t dtype, az_stream_t stream);
 /* The same on rows held in a 2-byte type -- dtype 1: bfloat16, 2: IEEE half; x and y alike: the activations of a module cast to
  * half precision (azula/denoise.py:314-320; torch's RMSNorm / the reference's layer_norm on a half tensor).  Statistics, gain and
  * modulation in fp32, output rounded to nearest even.  C % 8 == 0, C == cs, C <= 4096 (else AZ_E_UNSUPPORTED).                 */

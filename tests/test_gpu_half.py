@@ -258,3 +258,79 @@ def test_vit_half_activations_in_hbm(golden, half, monkeypatch):
     q99b, mxb, _, _ = _bar(g["y_modB"].cuda(), y32, half)
     print("vit, fp32 activations ", half, "q99/scale", q99b, "max/scale", mxb)
     assert q99b < bq and mxb < bm
+
+
+@pytest.mark.parametrize("half", HALVES)
+@pytest.mark.parametrize("pool,act,two", [(0, 1, False), (0, 0, True), (1, 1, False), (2, 0, True)])
+def test_typed_groupnorm_passes(half, pool, act, two):
+    """az_groupnorm_stats_h16 produces the SAME partials as az_groupnorm_stats_f32 on the same (half-representable) values, and
+    az_affine_act_h16 the rounded output of az_affine_act_f32 (two sources = channel concatenation; 2x2 / 1x2 pooling; SiLU)."""
+    from azula_amd.engine import Builder
+
+    g = torch.Generator().manual_seed(17 * pool + act)
+    B, H, W, C0, C1, groups = 2, 12, 16, 64, 32 if two else 0, 8
+    x = _rt(torch.randn(B, H, W, C0, generator=g) * 2 + 0.3, half)
+    x1 = _rt(torch.randn(B, H, W, C1, generator=g), half) if two else None
+    wt, bs = 1 + 0.1 * torch.randn(C0 + C1, generator=g), 0.1 * torch.randn(C0 + C1, generator=g)
+    outs, parts = [], []
+    for typed in (False, True):
+        bld = Builder(torch.device("cuda"), half=half, half_act=typed)
+        a = bld.new_act(B, H, W, C0, pinned=True)
+        a.buf.copy_(x.reshape(-1).cuda())
+        a1 = None
+        if two:
+            a1 = bld.new_act(B, H, W, C1, pinned=True)
+            a1.buf.copy_(x1.reshape(-1).cuda())
+        y = bld.group_norm(a, groups, weight=bld.const(wt), bias=bld.const(bs), act=act, pool=pool, x1=a1)
+        bld.tape.run()
+        names = [n for _, _, n in bld.tape.ops]
+        assert names == (["az_groupnorm_stats_h16", "az_groupnorm_finalize_f32", "az_affine_act_h16"] if typed else
+                         ["az_groupnorm_stats_f32", "az_groupnorm_finalize_f32", "az_affine_act_f32"])
+        outs.append(y.buf.float().clone())
+        parts.append(bld.tape.keep)
+    assert torch.equal(outs[1], _rt(outs[0], half)), (outs[1] - _rt(outs[0], half)).abs().max().item()
+
+
+@pytest.mark.parametrize("half", HALVES)
+@pytest.mark.parametrize("norm", ["group", "layer"])
+def test_unet_half_activations_in_hbm(half, norm):
+    """An azula UNet whose channel plan admits the typed kernels (multiples of 8, GroupNorm groups of >= 4 channels), cast to half:
+    every activation between its layers is a 2-byte tensor (typed convolutions incl. the strided, the two-source + upsampling merge
+    and the split-K layers, typed GroupNorm / row-norm passes), and the forward meets the reference's bar against the fp32 module
+    (tests/test_nn_unet.py:78-91); so does the fp32-activation form (AZ_HALF_ACT=0 semantics)."""
+    from azula_amd import engine
+    from azula_amd.nn import UNet
+
+    torch.manual_seed(3)
+    net = UNet(3, 3, hid_channels=(32, 64, 128), hid_blocks=(1, 1, 1), norm=norm, groups=8, mod_features=16)
+    sd = synth.synth_state_dict(synth.shapes_of(net.state_dict()), seed=77)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    x, mod = torch.randn(2, 3, 32, 32, device="cuda"), torch.randn(2, 16, device="cuda")
+    y32 = net(x, mod)
+    net.to(half)
+    y16 = net(x.to(half), mod.to(half))
+    plan = next(iter(net._plans.values()))
+    assert plan.bld.half_act
+    names = [n for _, _, n in plan.tape.ops]
+    assert not any(n in names for n in ("az_affine_act_f32", "az_groupnorm_stats_f32", "az_rownorm_mod_f32", "az_conv2d_f32", "az_conv2d_x3_f32"))
+    convs = [a[0]._obj for _, a, n in plan.tape.ops if n.startswith("az_conv2d")]
+    assert convs[0].src_dtype == 0 and convs[0].dst_dtype == 1 and convs[-1].src_dtype == 1 and convs[-1].dst_nchw == 1
+    assert all(c.src_dtype == 1 and c.dst_dtype == 1 for c in convs[1:-1])
+    q99, mx, bq, bm = _bar(y32, y16, half)
+    print("unet", norm, "half activations", half, "q99/scale", q99, "max/scale", mx)
+    assert q99 < bq and mx < bm
+    import pytest as _p
+
+    mp = _p.MonkeyPatch()
+    try:
+        mp.setattr(engine, "HALF_ACT", False)
+        net._plans.clear()
+        y16b = net(x.to(half), mod.to(half))
+        assert not next(iter(net._plans.values())).bld.half_act
+    finally:
+        mp.undo()
+        net._plans.clear()
+    q99b, mxb, _, _ = _bar(y32, y16b, half)
+    print("unet", norm, "fp32 activations ", half, "q99/scale", q99b, "max/scale", mxb)
+    assert q99b < bq and mxb < bm

@@ -184,9 +184,9 @@ VARIANTS["wx3_unt"] = [("wino_x3.hip", "ua[ch][pl] = __builtin_bit_cast(bf16x8, 
 VARIANTS["rn_ntst"] = [("norm.hip", "          *reinterpret_cast<float4*>(yr + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);", "          az_st_stream(yr + c, make_float4(o4[0], o4[1], o4[2], o4[3]));")]
 VARIANTS["stem_ntst"] = [("conv.hip", "        *reinterpret_cast<float4*>(a.dst + (((int64_t)b * H + oh) * W + ow) * a.cout_s + q * 4) = o;", "        az_st_stream(a.dst + (((int64_t)b * H + oh) * W + ow) * a.cout_s + q * 4, o);")]
 VARIANTS["res_ntld"] = [("conv_shared.h", "      if constexpr (RES == 1) r[i] = ld4_io<IO>(a.res, (int64_t)n[i] * a.cout_s + co);", "      if constexpr (RES == 1) r[i] = az_ld_stream(a.res + (int64_t)n[i] * a.cout_s + co);")]
-_AF_LD = [("norm.hip", "  if (x1 == nullptr) return *reinterpret_cast<const float4*>(x + pix * cs + c);", "  if (x1 == nullptr) return az_ld_stream(x + pix * cs + c);")]
-_AF_ST = [("norm.hip", "    for (int u = 0; u < UN; ++u) yb[(int64_t)(p + u * pstride) * q] = apply(v[u]);",
-           "    for (int u = 0; u < UN; ++u) az_st_stream(reinterpret_cast<float*>(yb + (int64_t)(p + u * pstride) * q), apply(v[u]));")]
+_AF_LD = [("norm.hip", "  if (x1 == nullptr) return ld4_io<IO>(x, pix * cs + c);", "  if (x1 == nullptr) return az_ld_stream(x + pix * cs + c);")]
+_AF_ST = [("norm.hip", "    for (int u = 0; u < UN; ++u) st4_io<IO>(y, yo + (int64_t)(p + u * pstride) * cs, apply(v[u]));",
+           "    for (int u = 0; u < UN; ++u) az_st_stream(y + yo + (int64_t)(p + u * pstride) * cs, apply(v[u]));")]
 VARIANTS["aff_ntld"] = _AF_LD
 VARIANTS["aff_ntst"] = _AF_ST
 VARIANTS["aff_nt"] = _AF_LD + _AF_ST
