@@ -1146,10 +1146,15 @@ static_assert(2 * HGSTAGE <= G_LDS_BYTES, "stages must fit under the epilogue bu
 
 // SRCH: the sources hold the operand type already (AzConvArgs.src_dtype = 1): a row's 64 k-values are 128 contiguous bytes, one
 // 16-byte load per row and thread instead of two, stored to LDS as loaded.
-// (Measured and not kept, round 6: the same tile as FOUR waves of 128 couts x 128 pixels -- 8 KB of fragment reads per 16 matrix
-//  instructions instead of 6 KB per 8, i.e. 1536 instead of 2048 cycles of the LDS port per 64-channel step: parity-green, 256 + 256
-//  registers, no scratch, and 10 - 27 % SLOWER on every shape of profiles/r06_half_gemm.txt: one wave per SIMD has nobody to cover
-//  its barrier and LDS round trips, the same finding as for the Winograd kernel.)
+// Measured and not kept in round 6 (profiles/r06_half_gemm.txt; all parity-green):
+//  * the same tile as FOUR waves of 128 couts x 128 pixels (8 KB of fragment reads per 16 matrix instructions instead of 6 KB per 8):
+//    10 - 27 % slower on every shape -- one wave per SIMD has nobody to cover its barrier and LDS round trips;
+//  * two register sets for the typed operand loads (step i + 3 loaded during iteration i) and the compiler's own issue order instead
+//    of the sched_group_barrier pattern: each looked 3 - 9 % ahead in isolated launches on one box, and same-box A/B of the
+//    captured C3 step (234 - 235 against 237 - 239 images/s for this form) says they are not.
+// Where its time is (timing ablations, same file): the load / stage / fragment-read / barrier skeleton alone is 60 - 66 % of a launch,
+// the matrix instructions overlap it only partly (matrix pipe busy 0.42 on the active CUs), and with 768-channel K loops the
+// epilogue -- a round's 32 MB of stores leaving in one burst -- is another 30 %.
 template <bool F16, bool TAPS = false, bool SRCH = false>  // TAPS: k x k filters with a stride and zero padding, as in conv_gemm_x3_big_kernel
 __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
   constexpr int ES = SRCH ? 2 : 4;  // bytes per source element
@@ -1206,16 +1211,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
     voffX1[i] = (unsigned)(((int64_t)px * a.c1s + lch * 8) * ES);
     lds_row[i] = row * 128 + ((lch ^ ((row >> 1) & 7)) * 16);
   }
-  // Register sets of the operand loads.  fp32 activations: one set -- step i + 2 is loaded during iteration i and stored to LDS at the
-  // top of iteration i + 1.  Operand-type activations (SRCH): TWO sets, step i + 3 loaded during iteration i into the set that
-  // iteration's store just freed and stored at the top of iteration i + 2 -- a full iteration more for the loads to land.  Measured
-  // on 16384 x 3072 -> 768 (profiles/r06_half_gemm.txt): with one set the waves spent 37 % of their cycles in s_waitcnt and a K step
-  // took ~3.5 k cycles for 2048 of matrix issue: the loads were issued under the LAST matrix instructions of an iteration and needed
-  // right behind its barrier, an HBM round trip (the activation stream does not fit any cache) exposed in every step.
-  constexpr int NSET = SRCH ? 2 : 1;
-  float4 rwt[NSET][4], rxa[NSET][4][2];
-  auto load_step = [&](int kt, auto SET) __attribute__((always_inline)) {
-    constexpr int set = decltype(SET)::value;
+  float4 rwt[4], rxa[4][2];
+  auto load_step = [&](int kt) __attribute__((always_inline)) {
     if constexpr (TAPS) {
       const int tap = kt / nk_tap, kr = kt - tap * nk_tap;  // (wave-uniform)
       const int ky = tap / a.ksize, kx = tap - ky * a.ksize;
@@ -1225,12 +1222,12 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
       const unsigned so = (unsigned)((s1 ? kr - p.nkc0 : kr) * HGK * ES);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        rwt[set][i] = buf_ld4(rw, voffW[i], (unsigned)((tap * wtap + (int64_t)kr * HGK) * 2));
+        rwt[i] = buf_ld4(rw, voffW[i], (unsigned)((tap * wtap + (int64_t)kr * HGK) * 2));
         const int ih = ihb[i] + ky, iw = iwb[i] + kx;
         const bool ok = pb[i] >= 0 && (unsigned)ih < (unsigned)a.h0 && (unsigned)iw < (unsigned)a.w0;  // (zero padding: reads zeros)
         const unsigned vo = ok ? (unsigned)((((int64_t)(pb[i] + ih) * a.w0 + iw) * cs + lch * 8) * ES) : OOB;
-        rxa[set][i][0] = buf_ld4(r, vo, so);
-        if constexpr (!SRCH) rxa[set][i][1] = buf_ld4(r, ok ? vo + 16u : OOB, so);
+        rxa[i][0] = buf_ld4(r, vo, so);
+        if constexpr (!SRCH) rxa[i][1] = buf_ld4(r, ok ? vo + 16u : OOB, so);
       }
     } else {
       const bool s1 = kt >= p.nkc0;  // (wave-uniform; selects, not a branch)
@@ -1238,24 +1235,23 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
       const unsigned so = (unsigned)((s1 ? kt - p.nkc0 : kt) * HGK * ES);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        rwt[set][i] = buf_ld4(rw, voffW[i], (unsigned)(kt * HGK * 2));
+        rwt[i] = buf_ld4(rw, voffW[i], (unsigned)(kt * HGK * 2));
         const unsigned vo = s1 ? voffX1[i] : voffX[i];
-        rxa[set][i][0] = buf_ld4(r, vo, so);
-        if constexpr (!SRCH) rxa[set][i][1] = buf_ld4(r, vo + 16u, so);
+        rxa[i][0] = buf_ld4(r, vo, so);
+        if constexpr (!SRCH) rxa[i][1] = buf_ld4(r, vo + 16u, so);
       }
     }
   };
-  auto store_step = [&](int buf, auto SET) __attribute__((always_inline)) {
-    constexpr int set = decltype(SET)::value;
+  auto store_step = [&](int buf) __attribute__((always_inline)) {
     char* st = smem + buf * HGSTAGE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<float4*>(st + lds_row[i]) = rwt[set][i];
+      *reinterpret_cast<float4*>(st + lds_row[i]) = rwt[i];
       if constexpr (SRCH) {
-        *reinterpret_cast<float4*>(st + HGPLANE + lds_row[i]) = rxa[set][i][0];
+        *reinterpret_cast<float4*>(st + HGPLANE + lds_row[i]) = rxa[i][0];
         continue;
       }
-      const f32x4v lo = {rxa[set][i][0].x, rxa[set][i][0].y, rxa[set][i][0].z, rxa[set][i][0].w}, hi = {rxa[set][i][1].x, rxa[set][i][1].y, rxa[set][i][1].z, rxa[set][i][1].w};
+      const f32x4v lo = {rxa[i][0].x, rxa[i][0].y, rxa[i][0].z, rxa[i][0].w}, hi = {rxa[i][1].x, rxa[i][1].y, rxa[i][1].z, rxa[i][1].w};
       const H4 l4 = __builtin_convertvector(lo, H4), h4 = __builtin_convertvector(hi, H4);
       H8 v8;
 #pragma unroll
@@ -1282,21 +1278,17 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
   const char* As = smem + (wc * 128 + frow) * 128;             // + buf * HGSTAGE + tile * 4096 + swizzled chunk * 16
   const char* Bs = smem + HGPLANE + (wp * 64 + frow) * 128;
 
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, NSET - 1>;  // (one set: S1 == S0)
-  const int klast = kt_end - 1;
   if (nk > 0) {
-    load_step(kt_begin, S0{});
-    store_step(0, S0{});
-    load_step(min(kt_begin + 1, klast), S1{});
-    if constexpr (NSET == 2) load_step(min(kt_begin + 2, klast), S0{});
+    load_step(kt_begin);
+    store_step(0);
+    load_step(min(kt_begin + 1, kt_end - 1));
   }
   __syncthreads();
-  // one iteration: stage `buf` holds step i.  The set that holds step i + 1 goes to the other stage, then takes step i + 1 + NSET.
-  auto iteration = [&](int i, auto SET) __attribute__((always_inline)) {
+#pragma unroll 1
+  for (int i = 0; i < nk; ++i) {
     const int buf = i & 1;
-    store_step(buf ^ 1, SET);
-    load_step(min(kt_begin + i + 1 + NSET, klast), SET);
+    store_step(buf ^ 1);                               // step i + 1 (in registers since the previous iteration) -> the other stage
+    load_step(min(kt_begin + i + 2, kt_end - 1));      // in flight under the MFMAs below and the next iteration's first ones
 #pragma unroll
     for (int ks = 0; ks < HGK / 16; ++ks) {
       const int ch = ((2 * ks + (lane >> 5)) ^ fsw) * 16;
@@ -1325,11 +1317,6 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_half_big_kernel(ConvP p) {
       if (k >= 20) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                  // a buffer load
     }
     __syncthreads();  // every wave has read stage `buf`; the other stage is complete
-  };
-#pragma unroll 1
-  for (int i = 0; i < nk; i += 2) {  // (step i + 1 sits in set (i + 1) & 1: odd for even i)
-    iteration(i, S1{});
-    if (i + 1 < nk) iteration(i + 1, S0{});
   }
   if (a.dst_dtype) gemm_big_epilogue<4, F16 ? 2 : 1>(p, acc, m0, n0, wc, wp, lane, tid, gsmf);
   else gemm_big_epilogue<4>(p, acc, m0, n0, wc, wp, lane, tid, gsmf);

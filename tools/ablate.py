@@ -96,6 +96,20 @@ VARIANTS["x3_nosplit"] = [  # what would activations that arrive pre-split cost 
     ("conv.hip", "      for (int j = 0; j < 4; ++j) split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);\n#pragma unroll\n      for (int pl = 0; pl < 3; ++pl)",
      "      for (int j = 0; j < 4; ++j) q[0][j] = q[1][j] = q[2][j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x[2 * j + 1]), __builtin_bit_cast(unsigned, x[2 * j]), 0x07060302u);\n#pragma unroll\n      for (int pl = 0; pl < 3; ++pl)"),
 ]
+# ---- conv_gemm_half_big_kernel (half-precision operands, 256 x 256 tile; typed launches): where does a K step's time go?  (timing only;
+#      profiles/r06_half_gemm.txt (5) was measured with these on the two-register-set form that was then dropped)
+_HB_KS = "#pragma unroll\n    for (int ks = 0; ks < HGK / 16; ++ks) {\n"
+_HB_IT = "    store_step(buf ^ 1);                               // step i + 1 (in registers since the previous iteration) -> the other stage\n    load_step(min(kt_begin + i + 2, kt_end - 1));      // in flight under the MFMAs below and the next iteration's first ones\n" + _HB_KS
+VARIANTS["hbig_noload"] = [("conv.hip", _HB_IT, "    store_step(buf ^ 1);\n" + _HB_KS)]
+VARIANTS["hbig_nostage"] = [("conv.hip", _HB_IT, _HB_KS)]  # neither the stage stores nor the loads: fragment reads + matrix instructions + barrier
+VARIANTS["hbig_nomfma"] = [
+    ("conv.hip", "          if constexpr (F16) acc[ci][pj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ci], fb[pj], acc[ci][pj], 0, 0, 0);\n"
+                 "          else acc[ci][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ci], fb[pj], acc[ci][pj], 0, 0, 0);\n        }\n    }\n    // issue order: the 24 fragment reads in four groups",
+     "          asm volatile(\"\" : \"+v\"(acc[ci][pj]) : \"v\"(fa[ci]), \"v\"(fb[pj]));\n        }\n    }\n    // issue order: the 24 fragment reads in four groups")]
+VARIANTS["hbig_noepi"] = [("conv.hip", "  if (a.dst_dtype) gemm_big_epilogue<4, F16 ? 2 : 1>(p, acc, m0, n0, wc, wp, lane, tid, gsmf);\n  else gemm_big_epilogue<4>(p, acc, m0, n0, wc, wp, lane, tid, gsmf);\n",
+                           "  if (acc[0][0][0] == 12345.678f) gemm_big_epilogue<4>(p, acc, m0, n0, wc, wp, lane, tid, gsmf);\n")]
+VARIANTS["hbig_nosched"] = [("conv.hip", "    for (int k = 0; k < 32; ++k) {\n      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);\n      if ((k & 7) == 1 && k < 24) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // the next k-step's fragments",
+                             "    for (int k = 0; k < 0; ++k) {\n      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);\n      if ((k & 7) == 1 && k < 24) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // the next k-step's fragments")]
 VARIANTS["x3big_nosched"] = [("conv.hip", "    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NCT + 2), 0);  // DS reads\n", "    if (false)\n    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NCT + 2), 0);\n"),
                              ("conv.hip", "    for (int k = 0; k < NM; ++k) {\n      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);", "    for (int k = 0; k < 0; ++k) {\n      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);")]
 VARIANTS["x3_no192"] = [("conv.hip", "  const bool ok192 = ct != nullptr && kstep == GBK && a->act <= 3 && !x3_big_taps(a);", "  const bool ok192 = false;")]
