@@ -30,7 +30,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from ... import _lib, engine
-from ...engine import Act, Builder, pad4
+from ...engine import Act, Builder, pad8
 
 __all__ = ["UNetModel"]
 
@@ -124,7 +124,13 @@ class ADMPlan:
 
     def __init__(self, net: "UNetModel", B: int, H: int, W: int, emb_rows: int, device, x_in: Act | None = None,
                  coef_ptr: int | None = None, frac: bool = False, D: int = 1) -> None:
-        bld = self.bld = Builder(device, half=next(net.parameters()).dtype)
+        # a network cast to half precision keeps its activations in HBM in its own type (engine.HALF_ACT) when every kernel on its tape
+        # has the typed form: 2-D / 1-D data, channel counts whose GroupNorm(32) groups are whole 4-channel chunks (C % 128 == 0: every
+        # card of the plugin), a shared fp32 input (the second program of classifier-free guidance) with the typed plans' channel stride
+        chans = sorted({m.num_channels for m in net.modules() if isinstance(m, nn.GroupNorm)})
+        half_act = (net.dims != 3 and all(c % 128 == 0 for c in chans) and net.model_channels % 8 == 0
+                    and (x_in is None or x_in.cs == pad8(net.in_channels)))  # (a shared input: the first program's, same stride)
+        bld = self.bld = Builder(device, half=next(net.parameters()).dtype, half_act=half_act)
         mc, E = net.model_channels, 4 * net.model_channels
         self.versions = net._param_versions()
         self.emb_rows = emb_rows
@@ -206,7 +212,7 @@ class ADMPlan:
         elif self.planar:
             self.x_in = Act(torch.empty(B * cin * H * W, dtype=torch.float32, device=device), B, H, W, cin, 0, True)
         else:
-            self.x_in = Act(torch.empty(PB * H * W * pad4(cin), dtype=torch.float32, device=device), PB, H, W, cin, pad4(cin), True)
+            self.x_in = Act(torch.zeros(PB * H * W * bld.pad(cin), dtype=torch.float32, device=device), PB, H, W, cin, bld.pad(cin), True)
         self.out = torch.empty((B, net.out_channels) + ((D,) if three_d else ()) + (H, W), dtype=torch.float32, device=device)
         self.table = bld.const(timestep_embedding_table(net.table_steps, mc))
         self.t_idx = torch.zeros(emb_rows, dtype=torch.int64, device=device)
@@ -250,7 +256,7 @@ class ADMPlan:
 
         def resblock(rb: ResBlock, x: Act, x1: Act | None = None) -> Act:
             r"""x (| x1 concatenated) -> block output.  Does not free its inputs."""
-            oc, ocs = rb.out_channels, pad4(rb.out_channels)
+            oc, ocs = rb.out_channels, bld.pad(rb.out_channels)
             gi, ci = rb.in_layers[0], rb.in_layers[2]
             go, co = rb.out_layers[0], rb.out_layers[3]
             # FiLM table: emb_layers = SiLU -> Linear(E, 2*oc); (scale | shift) padded to ocs each
@@ -279,8 +285,7 @@ class ADMPlan:
                     bld.tape.add("az_gather_rows_f32", eb.data_ptr(), film.data_ptr(),
                                  row0.data_ptr(), B, ocs, 1)
                 he = bld.new_act(PB, h.H, h.W, oc)
-                bld.tape.add("az_affine_act_f32", he.ptr, h.ptr, None, 0, bld.const(torch.ones(B * ocs)).data_ptr(),
-                             eb.data_ptr(), B, D * h.H, h.W, ocs, 0, 0)
+                bld._affine_act(he, h, None, 0, bld.const(torch.ones(B * ocs)).data_ptr(), eb.data_ptr(), B, D * h.H, h.W, ocs, 0, 0)
                 n2 = group_norm(he, 32, weight=bld.const(go.weight), bias=bld.const(go.bias), act=1)
                 bld.free(he)
             bld.free(h)
@@ -289,7 +294,7 @@ class ADMPlan:
                 assert x1 is None
                 ones, zeros = bld.const(torch.ones(B * x.cs)), bld.const(torch.zeros(B * x.cs))
                 xs = bld.new_act(PB, *halved(x), x.C)
-                bld.tape.add("az_affine_act_f32", xs.ptr, x.ptr, None, 0, ones.data_ptr(), zeros.data_ptr(), B, D * x.H, x.W, x.cs, 0, pool2)
+                bld._affine_act(xs, x, None, 0, ones.data_ptr(), zeros.data_ptr(), B, D * x.H, x.W, x.cs, 0, pool2)
                 out = conv(n2, co, oc, res=xs, gn_stats=True, winograd=wino)
                 bld.free(xs)
             elif rb.up:
@@ -342,8 +347,8 @@ class ADMPlan:
                         nh = conv(h, layer.op, layer.out_channels, stride=down2)
                     else:  # AvgPoolNd(2, 2): the pooling form of the elementwise pass with S = 1, T = 0
                         nh = bld.new_act(PB, *halved(h), h.C)
-                        bld.tape.add("az_affine_act_f32", nh.ptr, h.ptr, None, 0, bld.const(torch.ones(B * h.cs)).data_ptr(),
-                                     bld.const(torch.zeros(B * h.cs)).data_ptr(), B, D * h.H, h.W, h.cs, 0, pool2)
+                        bld._affine_act(nh, h, None, 0, bld.const(torch.ones(B * h.cs)).data_ptr(),
+                                        bld.const(torch.zeros(B * h.cs)).data_ptr(), B, D * h.H, h.W, h.cs, 0, pool2)
                 elif isinstance(layer, Upsample):
                     if layer.use_conv:  # nearest x2 is a read-side shift of the conv gather
                         nh = conv(h, layer.conv, layer.out_channels, up0=up2, winograd=wino)

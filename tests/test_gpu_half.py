@@ -334,3 +334,35 @@ def test_unet_half_activations_in_hbm(half, norm):
     q99b, mxb, _, _ = _bar(y32, y16b, half)
     print("unet", norm, "fp32 activations ", half, "q99/scale", q99b, "max/scale", mxb)
     assert q99b < bq and mxb < bm
+
+
+@pytest.mark.parametrize("half", HALVES)
+def test_adm_half_activations_in_hbm(half):
+    """guided-diffusion UNetModel with channel counts whose GroupNorm(32) groups are whole 4-channel chunks (every card of the
+    plugin: 256 / 512 / 1024), cast to half: typed GroupNorm passes incl. the concatenated decoder inputs and the pooled skip path,
+    typed attention, typed convolutions; the reference's bar x 2 against the fp32 module (as test_adm_half), CFG through the shared input."""
+    from azula_amd.guidance import CFGDenoiser
+    from azula_amd.plugins import adm
+    from azula_amd.sample import DDIMSampler
+
+    torch.manual_seed(0)
+    den = adm.make_model(image_size=16, num_channels=128, channel_mult=(1, 2), attention_resolutions=(8,), num_classes=10,
+                         num_res_blocks=1, num_head_channels=64, resblock_updown=True, use_scale_shift_norm=True)
+    sd = synth.synth_state_dict(synth.shapes_of(den.backbone.state_dict()), seed=91)
+    den.backbone.load_state_dict(sd)
+    den = den.cuda().eval()
+    x = torch.randn(2, 3, 16, 16, device="cuda")
+    idx, y = torch.tensor([700, 80], device="cuda"), torch.tensor([3, 7], device="cuda")
+    o32 = den.backbone(x, idx, y=y)
+    den.backbone.to(half)
+    o16 = den.backbone(x.to(half), idx, y=y)
+    plan = next(iter(den.backbone._plans.values()))
+    assert plan.bld.half_act and o16.dtype == half
+    names = [n for _, _, n in plan.tape.ops]
+    assert "az_affine_act_h16" in names and not any(n in names for n in ("az_affine_act_f32", "az_groupnorm_stats_f32", "az_conv2d_f32", "az_conv2d_x3_f32"))
+    q99, mx, bq, bm = _bar(o32, o16, half)
+    print("adm, half activations", half, "q99/scale", q99, "max/scale", mx)
+    assert q99 < 2 * bq and mx < 2 * bm
+    smp = DDIMSampler(CFGDenoiser(den), steps=4, silent=True)
+    x0 = smp(x, positive={"label": y}, negative={"label": torch.zeros_like(y)}, guidance=1.5)
+    assert x0.dtype == torch.float32 and torch.isfinite(x0).all() and next(iter(smp._fused_cache.values())).graph is not None
