@@ -251,6 +251,7 @@ PROTOTYPES: dict[str, list] = {
     "az_affine_act_h16": [vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, i32, i32, i32, c_stream],
     "az_token_copy_f32": [vp, i64, i64, vp, i64, i64, i64, i64, i64, c_stream],
     "az_token_fill_f32": [vp, i64, i64, i64, vp, i64, vp, i64, i64, c_stream],
+    "az_token_fill_h16": [vp, i64, i64, i64, vp, i64, vp, i64, i64, i32, c_stream],
     "az_timestep_embedding_f32": [vp, i64, vp, i64, i64, i32, f32, c_stream],
     "az_linear_small_grouped_f32": [vp, i32, i32, i64, i32, i32, c_stream],
     "az_conv2d_f32": [C.POINTER(AzConvArgs), c_stream],

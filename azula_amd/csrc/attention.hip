@@ -932,6 +932,20 @@ __global__ __launch_bounds__(256) void token_fill_kernel(float4* __restrict__ ds
   }
 }
 
+// The same with the destination in a 2-byte type (IO 1: bfloat16, 2: IEEE half; row / pos stay fp32): the in-context class tokens of
+// a JiT cast to half precision.
+template <int IO>
+__global__ __launch_bounds__(256) void token_fill_h16_kernel(float* __restrict__ dst, const float4* __restrict__ row,
+                                                             const float4* __restrict__ pos, int64_t dst_tokens, int64_t dst_off,
+                                                             int64_t n, int64_t B, int64_t cs4, int64_t row_bstride4) {
+  const int64_t total = B * n * cs4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = e % cs4, j = (e / cs4) % n, b = e / (cs4 * n);
+    const float4 r = row[b * row_bstride4 + c], q = pos[j * cs4 + c];
+    st4_io<IO>(dst, (((b * dst_tokens + dst_off + j) * cs4) + c) * 4, make_float4(az_add(r.x, q.x), az_add(r.y, q.y), az_add(r.z, q.z), az_add(r.w, q.w)));
+  }
+}
+
 // Sinusoidal timestep embedding, cos block then sin block (plugins/jit/_src/model.py:59-81):
 // dst[r, j] = cos(t_r f_j), dst[r, half + j] = sin(t_r f_j), f_j = exp(-ln(max_period) j / half).
 __global__ __launch_bounds__(256) void timestep_embedding_kernel(float* __restrict__ dst, int64_t ldd,
@@ -1115,6 +1129,23 @@ int az_token_fill_f32(float* dst, int64_t dst_tokens, int64_t dst_off, int64_t n
   hipLaunchKernelGGL(token_fill_kernel, dim3(az_stream_grid(B * n * (cs / 4), 256)), dim3(256), 0, az_s(stream),
                      reinterpret_cast<float4*>(dst), reinterpret_cast<const float4*>(row),
                      reinterpret_cast<const float4*>(pos), dst_tokens, dst_off, n, B, cs / 4, row_bstride / 4);
+  return az_launch_status();
+}
+
+int az_token_fill_h16(void* dst, int64_t dst_tokens, int64_t dst_off, int64_t n, const float* row, int64_t row_bstride,
+                      const float* pos, int64_t B, int64_t cs, int32_t dtype, az_stream_t stream) {
+  AZ_REQUIRE(dst && row && pos, AZ_E_NULL);
+  AZ_REQUIRE(B > 0 && n > 0 && cs > 0 && cs % 8 == 0 && row_bstride % 4 == 0 && dst_off >= 0 && dst_off + n <= dst_tokens &&
+                 (dtype == 1 || dtype == 2),
+             AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(dst) && AZ_ALIGNED16(row) && AZ_ALIGNED16(pos), AZ_E_ALIGN);
+  const dim3 grid(az_stream_grid(B * n * (cs / 4), 256));
+  if (dtype == 1)
+    hipLaunchKernelGGL(token_fill_h16_kernel<1>, grid, dim3(256), 0, az_s(stream), reinterpret_cast<float*>(dst), reinterpret_cast<const float4*>(row),
+                       reinterpret_cast<const float4*>(pos), dst_tokens, dst_off, n, B, cs / 4, row_bstride / 4);
+  else
+    hipLaunchKernelGGL(token_fill_h16_kernel<2>, grid, dim3(256), 0, az_s(stream), reinterpret_cast<float*>(dst), reinterpret_cast<const float4*>(row),
+                       reinterpret_cast<const float4*>(pos), dst_tokens, dst_off, n, B, cs / 4, row_bstride / 4);
   return az_launch_status();
 }
 

@@ -120,7 +120,10 @@ class JiTPlan:
     r"""Compiled forward for one (batch, shared/per-sample time) signature."""
 
     def __init__(self, net: "JiT", B: int, t_shared: bool, device) -> None:
-        bld = self.bld = Builder(device, half=net.pos_embed.dtype)
+        # a network cast to half precision keeps its activations in HBM in its own type (engine.HALF_ACT): widths in multiples of 8,
+        # SwiGLU through the GEMM's epilogue
+        half_act = net.hidden_size % 8 == 0 and all((blk.mlp.w12.weight.shape[0] // 2) % 8 == 0 for blk in net.blocks) and net.hidden_size <= 4096
+        bld = self.bld = Builder(device, half=net.pos_embed.dtype, half_act=half_act)
         Hd, heads, p, Z = net.hidden_size, net.num_heads, net.patch_size, net.in_channels
         S = net.input_size
         grid = S // p
@@ -152,16 +155,20 @@ class JiTPlan:
         b_all = torch.cat([m.bias.detach() for m in heads_]).to(device)
         c_act = Act(bld.empty(B * Hd), 1, B, 1, Hd, Hd, True)
         tape.add("az_silu_f32", c_act.ptr, c.data_ptr(), B * Hd)
-        mods = bld.conv(c_act, bld.pack_conv(w_all, b_all), w_all.shape[0])
+        mods = bld.conv(c_act, bld.pack_conv(w_all, b_all), w_all.shape[0], out_f32=True)  # (the modulation table stays fp32)
         mods.pinned = True
         mod, MS = mods.buf, mods.cs  # row stride of the modulation table
 
         # ---- bottleneck patch embedding + fixed positional table  (_src/model.py:16-43,358-359)
         e = net.x_embedder
-        tokens = bld.new_act(B, L, 1, Z * p * p, pinned=True)
+        tokens = bld.new_act(B, L, 1, Z * p * p, pinned=True, f32=True)  # (the plan's input stays fp32)
         tape.add("az_patchify_f32", tokens.ptr, self.x_nchw.data_ptr(), None, B, Z, S, S, p, tokens.cs)
         low = bld.conv(tokens, bld.pack_conv(e.proj1.weight.detach().reshape(e.proj1.out_channels, -1), None), e.proj1.out_channels)
-        pos = Act(bld.const(net.pos_embed.detach().reshape(-1)), 1, L, 1, Hd, Hd, True)
+        pos_t = bld.const(net.pos_embed.detach().reshape(-1))
+        if bld.half_act:  # (the residual operand has the destination's element type)
+            pos_t = pos_t.to(bld.half)
+            tape.keep.append(pos_t)
+        pos = Act(pos_t, 1, L, 1, Hd, Hd, True)
         x = bld.conv(low, bld.pack_conv(e.proj2.weight.detach().reshape(Hd, -1), e.proj2.bias), Hd, res=_Shared(pos))
         bld.free(low)
 
@@ -180,8 +187,12 @@ class JiTPlan:
             if Lc and i == net.in_context_start:  # prepend the class tokens (_src/model.py:364-367)
                 wide = bld.new_act(B, L + Lc, 1, Hd)
                 ctx_pos = bld.const(net.in_context_posemb.detach().reshape(-1))
-                tape.add("az_token_fill_f32", wide.ptr, L + Lc, 0, Lc, y_emb.data_ptr(), Hd, ctx_pos.data_ptr(), B, Hd)
-                tape.add("az_token_copy_f32", wide.ptr, L + Lc, Lc, x.ptr, L, 0, L, B, Hd)
+                if wide.half:  # 2-byte tokens: typed fill; the copy moves Hd / 2 floats per token
+                    tape.add("az_token_fill_h16", wide.ptr, L + Lc, 0, Lc, y_emb.data_ptr(), Hd, ctx_pos.data_ptr(), B, Hd, 2 if bld.half == torch.float16 else 1)
+                    tape.add("az_token_copy_f32", wide.ptr, L + Lc, Lc, x.ptr, L, 0, L, B, Hd // 2)
+                else:
+                    tape.add("az_token_fill_f32", wide.ptr, L + Lc, 0, Lc, y_emb.data_ptr(), Hd, ctx_pos.data_ptr(), B, Hd)
+                    tape.add("az_token_copy_f32", wide.ptr, L + Lc, Lc, x.ptr, L, 0, L, B, Hd)
                 bld.free(x)
                 x = wide
             m0_ = 6 * Hd * i  # this block's columns: shift_a | scale_a | gate_a | shift_m | scale_m | gate_m
@@ -232,7 +243,7 @@ class JiTPlan:
             bld.free(x2)
         if Lc and net.in_context_start < len(net.blocks):  # x[:, in_context_len:]
             body = bld.new_act(B, L, 1, Hd)
-            tape.add("az_token_copy_f32", body.ptr, L, 0, x.ptr, L + Lc, Lc, L, B, Hd)
+            tape.add("az_token_copy_f32", body.ptr, L, 0, x.ptr, L + Lc, Lc, L, B, Hd // 2 if body.half else Hd)
             bld.free(x)
             x = body
 
@@ -244,7 +255,7 @@ class JiTPlan:
         bld.free(x)
         wl = fl.linear.weight.detach().reshape(p * p, Z, Hd).transpose(0, 1).reshape(Z * p * p, Hd).contiguous()
         bl = fl.linear.bias.detach().reshape(p * p, Z).t().reshape(-1).contiguous()
-        o = bld.conv(n, bld.pack_conv(wl, bl), Z * p * p)
+        o = bld.conv(n, bld.pack_conv(wl, bl), Z * p * p, out_f32=True)  # (the plan's output: fp32 tokens for the unpatchify pass)
         bld.free(n)
         tape.add("az_unpatchify_f32", self.out.data_ptr(), o.ptr, B, Z, S, S, p, o.cs)
         bld.finish()

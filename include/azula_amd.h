@@ -469,6 +469,11 @@ int az_token_copy_f32(float* dst, int64_t dst_tokens, int64_t dst_off, const flo
                       int64_t src_off, int64_t n, int64_t B, int64_t cs, az_stream_t stream);
 int az_token_fill_f32(float* dst, int64_t dst_tokens, int64_t dst_off, int64_t n, const float* row,
                       int64_t row_bstride, const float* pos, int64_t B, int64_t cs, az_stream_t stream);
+/* fill with the DESTINATION in a 2-byte type (dtype 1: bfloat16, 2: IEEE half; row / pos fp32; cs % 8 == 0): the class tokens of a
+ * module cast to half precision whose activations live in HBM in its own type.  (A copy between two such tensors is
+ * az_token_copy_f32 with cs / 2: two 2-byte values per float.)                                                              */
+int az_token_fill_h16(void* dst, int64_t dst_tokens, int64_t dst_off, int64_t n, const float* row, int64_t row_bstride,
+                      const float* pos, int64_t B, int64_t cs, int32_t dtype, az_stream_t stream);
 
 /* Sinusoidal timestep embedding (plugins/jit/_src/model.py:59-81): dst[r, 0:half] = cos(t_r f),
  * dst[r, half:2 half] = sin(t_r f), f_j = exp(-ln(max_period) j / half); t_r = t_dev[r * t_stride]

@@ -366,3 +366,34 @@ def test_adm_half_activations_in_hbm(half):
     smp = DDIMSampler(CFGDenoiser(den), steps=4, silent=True)
     x0 = smp(x, positive={"label": y}, negative={"label": torch.zeros_like(y)}, guidance=1.5)
     assert x0.dtype == torch.float32 and torch.isfinite(x0).all() and next(iter(smp._fused_cache.values())).graph is not None
+
+
+@pytest.mark.parametrize("half", HALVES)
+def test_jit_half_activations_in_hbm(half):
+    """A JiT whose widths admit the typed kernels (hidden 192, SwiGLU width 512), cast to half: typed row norms, GEMMs (q-k preparation
+    and SwiGLU epilogues), attention, the in-context class tokens filled into a 2-byte sequence (az_token_fill_h16) and copied as pairs."""
+    from azula_amd.plugins import jit
+    from azula_amd.sample import DDIMSampler
+
+    torch.manual_seed(0)
+    net = jit.JiT(input_size=32, patch_size=4, hidden_size=192, depth=3, num_heads=3, bottleneck_dim=16, in_context_len=4,
+                  in_context_start=1, num_classes=7)
+    net.load_state_dict(synth.synth_state_dict(synth.shapes_of(net.state_dict()), seed=55))
+    den = jit.JITDenoiser(net, num_classes=7).cuda().eval()
+    x1, y = torch.randn(3, 3, 32, 32, device="cuda"), torch.tensor([1, 7, 4], device="cuda")
+    ref = DDIMSampler(den, steps=8, silent=True)(x1, label=y)
+    o32 = den.backbone(x1, torch.tensor([0.3], device="cuda"), y)
+    den.backbone.to(half)
+    o16 = den.backbone(x1.to(half), torch.tensor([0.3], device="cuda"), y)
+    plan = next(iter(den.backbone._plans.values()))
+    names = {n for _, _, n in plan.tape.ops}
+    assert plan.bld.half_act and "az_rownorm_mod_h16" in names and "az_token_fill_h16" in names and "az_rownorm_mod_f32" not in names
+    q99, mx, bq, bm = _bar(o32, o16, half)
+    print("jit, half activations", half, "q99/scale", q99, "max/scale", mx)
+    assert q99 < 2 * bq and mx < 2 * bm
+    smp = DDIMSampler(den, steps=8, silent=True)
+    x0 = smp(x1, label=y)
+    assert next(iter(smp._fused_cache.values())).graph is not None and x0.dtype == torch.float32
+    rel = (x0 - ref).abs().max().item() / ref.abs().max().item()
+    print("jit DDIM-8, half activations", half, "rel to fp32 weights", rel)
+    assert rel < (2e-2 if half == torch.float16 else 1e-1)
