@@ -91,6 +91,22 @@ def test_argument_errors_are_returned_not_raised(built_lib):
     assert lib.az_conv2d_winograd_f32(ctypes.byref(conv), None) == -4  # Winograd is stride 1 only
     ms = _lib.AzMultistepArgs(x_s=0x1000, pred=0x1000, x_t=0x1000, mean=0x1000, coef=0x1000, count=16, n_hist=9)
     assert lib.az_multistep_f32(ctypes.byref(ms), None) == -2
+    # round 6: typed (half-precision) tensors are a property of the bf16 / f16 entries only; the typed passes say what they do not take
+    conv.stride, conv.src0 = 1, 0x1000
+    conv.dst_dtype = 1
+    assert lib.az_conv2d_f32(ctypes.byref(conv), None) == -4 and lib.az_conv2d_x3_f32(ctypes.byref(conv), None) == -4
+    assert lib.az_conv2d_winograd_x3_f32(ctypes.byref(conv), None) == -4
+    conv.dst_dtype, conv.src_dtype, conv.c0s = 0, 1, 12
+    assert lib.az_conv2d_bf16_f32(ctypes.byref(conv), None) == -2  # 2-byte sources: channel strides in multiples of 8
+    att = _lib.AzAttnArgs(q=0x1000, k=0x1000, v=0x1000, out=0x1000, batch=1, heads=1, tokens=8, head_dim=64, io_dtype=1)
+    assert lib.az_attention_f32(ctypes.byref(att), None) == -4 and lib.az_attention_x3_f32(ctypes.byref(att), None) == -4
+    att.io_dtype, att.norm_dim = 0, 65
+    assert lib.az_attention_f32(ctypes.byref(att), None) == -2  # norm_dim <= head_dim
+    assert lib.az_rownorm_mod_h16(0x1000, 0x1000, None, None, None, 0, 4, 4, 20, 20, 1, 1e-5, 1, None) == -4  # C % 8
+    assert lib.az_rownorm_mod_h16(0x1000, 0x1000, None, None, None, 0, 4, 4, 64, 64, 1, 1e-5, 3, None) == -2  # dtype 1 | 2
+    assert lib.az_groupnorm_stats_h16(0x1000, 0x1000, None, 0, 1, 16, 24, 24, 8, 1, 1, None) == -4  # groups of 3 channels: no typed form
+    assert lib.az_affine_act_h16(0x1000, 0x1000, None, 0, 0x1000, 0x1000, 1, 4, 4, 12, 0, 0, 1, None) == -2  # cs % 8
+    assert lib.az_token_fill_h16(0x1000, 8, 0, 4, 0x1000, 64, 0x1000, 1, 60, 1, None) == -2
     for code, word in ((-1, b"NULL"), (-2, b"shape"), (-3, b"align"), (-4, b"unsupported")):
         assert word.lower() in lib.az_error_string(code).lower()
     with pytest.raises(_lib.AzulaAmdError, match="az_scale_f32"):

@@ -508,3 +508,39 @@ def test_sampler_dtype_float64_promotes_the_latents_like_the_reference(golden):
     torch.manual_seed(g.meta["loop_seed"])
     x0 = DDPMSampler(den, steps=16, silent=True, dtype=torch.float64)(g["toy_x1"])
     torch.testing.assert_close(x0, g["toy_ddpm16"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("order", ["nHC", "H3C", "3HC"])
+@pytest.mark.parametrize("d,dp", [(24, 32), (48, 64), (96, 128), (20, 32)])
+def test_zero_padded_heads_leave_attention_unchanged(order, d, dp):
+    """engine.pad_qkv_heads / pad_proj_heads (host arithmetic, round 6): a head of d channels zero-padded to the next instantiated
+    size d' -- projections packed with zero rows / columns per head, scale 1 / sqrt(d) -- computes the same attention (here in torch
+    on the CPU, in the three q | k | v channel orders of azula/nn/attention.py:90 and plugins/adm/_src/unet.py:338,371)."""
+    import torch.nn.functional as F
+
+    from azula_amd import engine
+
+    assert engine.attn_padded_dim(d) == dp and engine.attn_padded_dim(64) == 64 and engine.attn_padded_dim(8) == 8
+    with pytest.raises(NotImplementedError):
+        engine.attn_padded_dim(129)
+    g = torch.Generator().manual_seed(d)
+    B, L, H, C = 2, 10, 3, 3 * d
+    x = torch.randn(B, L, C, generator=g)
+    wq, bq = torch.randn(3 * C, C, generator=g) / C**0.5, torch.randn(3 * C, generator=g)
+    wo = torch.randn(C, C, generator=g) / C**0.5
+
+    def attend(w, b, wout, dd, scale):
+        qkv = F.linear(x, w, b)
+        if order in ("nHC", "3HC"):
+            q, k, v = qkv.reshape(B, L, 3, H, dd).permute(2, 0, 3, 1, 4)
+        else:
+            q, k, v = qkv.reshape(B, L, H, 3, dd).permute(3, 0, 2, 1, 4)
+        y = F.scaled_dot_product_attention(q, k, v, scale=scale)
+        return F.linear(y.transpose(1, 2).reshape(B, L, H * dd), wout)
+
+    ref = attend(wq, bq, wo, d, d**-0.5)
+    wp, bp = engine.pad_qkv_heads(wq, bq, H, d, dp, order)
+    got = attend(wp, bp, engine.pad_proj_heads(wo, H, d, dp), dp, d**-0.5)
+    assert wp.shape == (3 * H * dp, C) and torch.allclose(got, ref, atol=1e-5, rtol=1e-5)
+    t = engine.pad_head_table(torch.arange(2 * H * (d // 2), dtype=torch.float32).reshape(2, -1), H, d // 2, dp // 2)
+    assert t.shape == (2, H * (dp // 2)) and t.reshape(2, H, dp // 2)[..., d // 2 :].abs().sum() == 0

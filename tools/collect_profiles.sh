@@ -3,7 +3,7 @@
 #   bench lines of every configuration, rocprofv3 --kernel-trace --stats tables of C2 / C3 / C5 / C6 (same command as the
 #   bench line, fewer steps, ONE mode per table: --no-native-line), the PMC traffic collections (tools/pmc_traffic.py, also run live by
 #   the default bench.py for its own configuration).
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -24,9 +24,11 @@ python bench.py --config c5cfg32 --steps 1 --warmup 1 --no-pmc > gpurun_out/${TA
 python bench.py --config c6 --steps 2 --warmup 1 --no-pmc > gpurun_out/${TAG}_bench_c6.json 2> gpurun_out/b_c6.err
 python bench.py --config c4 --denoise-steps 4 --steps 1 --warmup 0 --no-pmc > gpurun_out/${TAG}_bench_c4_4steps.json 2> gpurun_out/b_c4.err
 python bench.py --config vol --steps 3 --warmup 1 --no-pmc > gpurun_out/${TAG}_bench_vol.json 2> gpurun_out/b_vol.err
+# modules cast to half precision, activations in HBM in the module's type (round 6)
+for c in c2 c3 c5 c6; do python bench.py --config $c --steps 2 --warmup 1 --no-pmc --half bf16 --no-cpu-baseline > gpurun_out/${TAG}_bench_${c}_half.json 2> gpurun_out/b_${c}h.err; done
 [ "$2" = "c4full" ] && python bench.py --config c4 --steps 1 --warmup 0 --no-pmc --no-native-line > gpurun_out/${TAG}_bench_c4_full.json 2> gpurun_out/b_c4full.err
 head -6 gpurun_out/${TAG}_c2_kernel_stats.txt
-for c in c2 c3 c5 c5cfg32 c6 c4_4steps vol c4_full; do python - <<PY
+for c in c2 c3 c5 c5cfg32 c6 c4_4steps vol c4_full c2_half c3_half c5_half c6_half; do python - <<PY
 import json
 try:
     d = json.load(open("gpurun_out/${TAG}_bench_$c.json"))
