@@ -181,6 +181,8 @@ class AzConvArgs(C.Structure):
         ("qk_rope_sin", c_f32p),
         ("depth_wrap", C.c_int32),
         ("dst_dtype", C.c_int32),
+        ("w_scale", C.c_float),
+        ("reserved1", C.c_int32),
     ]
 
 
@@ -268,6 +270,11 @@ PROTOTYPES: dict[str, list] = {
     "az_winograd_pack_filter_f32": [vp, vp, i32, i32, i32, i32, i32, i32, c_stream],
     "az_conv2d_winograd_x3_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_winograd_pack_filter_x3_f32": [vp, vp, i32, i32, i32, i32, i32, i32, c_stream],
+    "az_conv2d_f16x2_f32": [C.POINTER(AzConvArgs), c_stream],
+    "az_conv2d_winograd_f16x2_f32": [C.POINTER(AzConvArgs), c_stream],
+    "az_pack_conv_weight_f16x2_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, c_stream],
+    "az_winograd_pack_filter_f16x2_f32": [vp, vp, i32, i32, i32, i32, i32, i32, f32, c_stream],
+    "az_f16x2_weight_scale": [f32, i32],
     "az_conv2d_winograd4_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_winograd4_suggest_splitk": [i64, i32, i32, i32, i32],
     "az_winograd4_pack_filter_f32": [vp, vp, i32, i32, i32, i32, i32, i32, c_stream],
@@ -296,6 +303,8 @@ PROTOTYPES: dict[str, list] = {
     "az_calib_mfma_random_bf16": [vp, i32, i32, f32, f32, c_stream],
 }
 
+RESTYPES = {"az_f16x2_weight_scale": C.c_float}  # (everything else returns an int status)
+
 _lock = threading.Lock()
 _lib = None
 
@@ -321,7 +330,7 @@ def lib() -> C.CDLL:
                 for name, argtypes in PROTOTYPES.items():
                     fn = getattr(handle, name)  # AttributeError if the symbol is not exported
                     fn.argtypes = argtypes
-                    fn.restype = C.c_int
+                    fn.restype = RESTYPES.get(name, C.c_int)
                 _lib = handle
     return _lib
 

@@ -91,6 +91,23 @@ __device__ __forceinline__ void az_split3(float x0, float x1, unsigned& p1, unsi
   p3 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
 }
 
+// The activation operand of the "f16x2" kernels (include/azula_amd.h: az_conv2d_f16x2_f32): x' = x * AZ_F16X2_IN_SCALE as two IEEE
+// half pieces, h = fp16(x') (round to nearest: v_cvt_pk_f16_f32) and l = fp16((x' - h) * 2^11) -- x' = h + l / 2^11 to 22 - 23
+// significant bits; the residual is exact in fp32, scaled by 2^11 so that it is a NORMAL half value wherever h is (the matrix pipe
+// honours subnormal halves too: tools/mfma_denorm_probe.hip, so below 2^-14 the pieces degrade gracefully, absolute error <= 2^-36).
+// Two values per call; ph / pl = the packed (x1, x0) pairs.  Domain: |x'| < 65520 (beyond it h = Inf, l = NaN: NaN out).
+typedef _Float16 az_h2v __attribute__((ext_vector_type(2)));
+typedef float az_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void az_split2h(float x0, float x1, unsigned& ph, unsigned& pl) {
+  const az_f2v v = {x0 * AZ_F16X2_IN_SCALE, x1 * AZ_F16X2_IN_SCALE};
+  const az_h2v h = __builtin_convertvector(v, az_h2v);
+  // (x' - h) * 2^11 as ONE fused operation per value on the pre-scaled x (exact: the residual has at most 13 significant bits)
+  const az_f2v t = {x0 * (AZ_F16X2_IN_SCALE * 2048.f), x1 * (AZ_F16X2_IN_SCALE * 2048.f)};
+  const az_h2v l = {(_Float16)__builtin_fmaf((float)h.x, -2048.f, t.x), (_Float16)__builtin_fmaf((float)h.y, -2048.f, t.y)};
+  ph = __builtin_bit_cast(unsigned, h);
+  pl = __builtin_bit_cast(unsigned, l);
+}
+
 // Streaming accesses of the pure HBM streams (the transition kernels: every byte read once and written once per launch):
 // non-temporal 16-byte loads / stores (global_load_dwordx4 ... nt).  Measured on the 96 Mi-element transition
 // (profiles/r05_stream_nt_ab.txt): 12 B/element form 5.71 -> 6.14 TB/s, the 16 B form 5.46 -> 5.78, the 20 B form 5.40 -> 5.89;

@@ -51,6 +51,7 @@ struct ConvP {
   int tiles_n;  // ceil(npix / BN)
   int asm_loop; // fp32 K-32 kernel: one tap, whole K tiles -> the hand-scheduled K loop (igemm_kloop.inc)
   int m_tile0;  // bf16x3 kernel: first output-channel tile of this launch (the 256 x 256 kernel took the tiles before it)
+  float out_scale;  // f16x2 kernels: 1 / (AZ_F16X2_IN_SCALE * w_scale), applied to the accumulators behind the K loop (a power of two)
 };
 
 
@@ -702,6 +703,22 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigne
   az_split3(x0, x1, p1, p2, p3);  // (common.h: shared with the attention kernel)
 }
 
+// One partial product on the pipe of the mode: bf16 pieces (bf16x3) or IEEE half pieces (f16x2); the operands are 16-byte fragments.
+template <bool H2>
+__device__ __forceinline__ f32x16 x3_mfma(const uint4& fa, const uint4& fb, const f32x16& c) {
+  if constexpr (H2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa), __builtin_bit_cast(f16x8, fb), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), c, 0, 0, 0);
+}
+// The partial products of a mode as (weight piece, activation piece) pairs, smallest terms first.
+//   bf16x3: the six largest of the nine products of 3 x 3 exact pieces.
+//   f16x2 (H2): weights [wh | wl | wh / 2^11], activations [h | l = (x' - h) 2^11]:  wl h + (wh / 2^11) l + wh h.
+template <bool H2> struct X3Prod;
+template <> struct X3Prod<false> { static constexpr int N = 6; static constexpr int PA[6] = {2, 1, 0, 1, 0, 0}; static constexpr int PB[6] = {0, 1, 2, 0, 1, 0}; };
+template <> struct X3Prod<true> { static constexpr int N = 3; static constexpr int PA[6] = {1, 2, 0, 0, 0, 0}; static constexpr int PB[6] = {0, 1, 0, 0, 0, 0}; };
+
+// H2: the "f16x2" form (az_conv2d_f16x2_f32) -- the same tile, stages and epilogue; two activation planes instead of three, three
+// matrix instructions per 16 channels instead of six, the accumulators scaled by p.out_scale behind the K loop.
+template <bool H2>
 __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
   __shared__ __attribute__((aligned(16))) float xsmf[X_LDS_BYTES / 4];
   unsigned short* xsm = reinterpret_cast<unsigned short*>(xsmf);
@@ -838,9 +855,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
       const float x[8] = {rb[i][0].x, rb[i][0].y, rb[i][0].z, rb[i][0].w, rb[i][1].x, rb[i][1].y, rb[i][1].z, rb[i][1].w};
       unsigned q[3][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (H2) az_split2h(x[2 * j], x[2 * j + 1], q[0][j], q[1][j]);
+        else split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);
+      }
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < (H2 ? 2 : 3); ++pl)
         *reinterpret_cast<uint4*>(xsm + (3 + pl) * XPLANE + (r0 + 64 * i) * XLDS + wsw) =
             make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
     }
@@ -874,28 +894,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
     }
 #pragma unroll
     for (int ks = 0; ks < XBK / 16; ++ks) {
-      bf16x8 fa[3][2], fb[3][2];
+      uint4 fa[3][2], fb[3][2];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          fa[pl][t] = *reinterpret_cast<const bf16x8*>(As + pl * XPLANE + t * 32 * XLDS + fch[ks]);
-          fb[pl][t] = *reinterpret_cast<const bf16x8*>(Bs + pl * XPLANE + t * 32 * XLDS + fch[ks]);
+          fa[pl][t] = *reinterpret_cast<const uint4*>(As + pl * XPLANE + t * 32 * XLDS + fch[ks]);
+          if (!H2 || pl < 2) fb[pl][t] = *reinterpret_cast<const uint4*>(Bs + pl * XPLANE + t * 32 * XLDS + fch[ks]);
         }
       // smallest partial products first
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-      constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+      using PR = X3Prod<H2>;
 #pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][0], fb[PB[t]][0], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][0], fb[PB[t]][1], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][1], fb[PB[t]][0], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][1], fb[PB[t]][1], acc[1][1], 0, 0, 0);
+      for (int t = 0; t < PR::N; ++t) {
+        acc[0][0] = x3_mfma<H2>(fa[PR::PA[t]][0], fb[PR::PB[t]][0], acc[0][0]);
+        acc[0][1] = x3_mfma<H2>(fa[PR::PA[t]][0], fb[PR::PB[t]][1], acc[0][1]);
+        acc[1][0] = x3_mfma<H2>(fa[PR::PA[t]][1], fb[PR::PB[t]][0], acc[1][0]);
+        acc[1][1] = x3_mfma<H2>(fa[PR::PA[t]][1], fb[PR::PB[t]][1], acc[1][1]);
       }
     }
     __syncthreads();  // every wave has read this K tile
     if (more) store_tile();
     __syncthreads();
+  }
+  if constexpr (H2) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = acc[i][j] * p.out_scale;
   }
   store_acc_tiles(p, acc, m0, n0, wc, wp, lane, xsmf);
 }
@@ -979,7 +1004,8 @@ __device__ __forceinline__ void gemm_big_epilogue(const ConvP& p, const f32x16 (
 // NCT = 32-cout MFMA tiles per wave: 4 = the 256-cout tile, 3 = a 192-cout tile (768 = 4 x 192: whole rounds where 3 x 256 leaves a
 // quarter of the CUs idle).  TAPS: k x k filters with a stride and zero padding (the strided 3x3 convolutions of a UNet's
 // descent): the K walk is tap-major, the loader thread's pixel row is fixed, so a tap is one offset and one bounds test per step.
-template <int NCT, bool TAPS = false>
+// H2: the "f16x2" form (az_conv2d_f16x2_f32): two activation planes, 24 instead of 48 matrix instructions per step (NCT = 4).
+template <int NCT, bool TAPS = false, bool H2 = false>
 __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
   constexpr int CT = 64 * NCT;  // couts per tile
   __shared__ __attribute__((aligned(16))) float gsmf[G_LDS_BYTES / 4];
@@ -1063,9 +1089,12 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
     const float x[8] = {rxa[0].x, rxa[0].y, rxa[0].z, rxa[0].w, rxa[1].x, rxa[1].y, rxa[1].z, rxa[1].w};
     unsigned q[3][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (H2) az_split2h(x[2 * j], x[2 * j + 1], q[0][j], q[1][j]);
+      else split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);
+    }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < (H2 ? 2 : 3); ++pl)
       *reinterpret_cast<uint4*>(st + (3 + pl) * GPLANE) = make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
   };
 
@@ -1092,44 +1121,65 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
 #pragma unroll 1
   for (int i = 0; i < nk; ++i) {
     const int buf = i & 1;
-    bf16x8 fa[3][NCT], fb[3][2];
+    constexpr int NPB = H2 ? 2 : 3;  // activation planes
+    uint4 fa[3][NCT], fb[NPB][2];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-      for (int t = 0; t < NCT; ++t) fa[pl][t] = *reinterpret_cast<const bf16x8*>(As + buf * GSTAGE + pl * GPLANE + t * 1024);
+      for (int t = 0; t < NCT; ++t) fa[pl][t] = *reinterpret_cast<const uint4*>(As + buf * GSTAGE + pl * GPLANE + t * 1024);
+      if (pl < NPB) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) fb[pl][t] = *reinterpret_cast<const bf16x8*>(Bs + buf * GSTAGE + pl * GPLANE + t * 1024);
+        for (int t = 0; t < 2; ++t) fb[pl][t] = *reinterpret_cast<const uint4*>(Bs + buf * GSTAGE + pl * GPLANE + t * 1024);
+      }
     }
     // (unconditional, so that the iteration is ONE basic block the scheduler can interleave: the last two iterations restage
     // the final step into a stage nobody reads)
     store_step(buf ^ 1);                               // step i + 1 (in registers since the previous iteration) -> the other stage
     load_step(min(kt_begin + i + 2, kt_end - 1));      // in flight under the MFMAs below and the next iteration's first ones
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // smallest partial products first
-    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    using PR = X3Prod<H2>;  // smallest partial products first
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < PR::N; ++t)
 #pragma unroll
       for (int ci = 0; ci < NCT; ++ci)
 #pragma unroll
         for (int pj = 0; pj < 2; ++pj)
-          acc[ci][pj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][ci], fb[PB[t]][pj], acc[ci][pj], 0, 0, 0);
+          acc[ci][pj] = x3_mfma<H2>(fa[PR::PA[t]][ci], fb[PR::PB[t]][pj], acc[ci][pj]);
     // Issue order: the 18 fragment reads, then the staging of the next step (44 split instructions, 6 LDS stores, 5 loads) spread
     // under the 48 MFMAs -- the matrix pipe takes 32 cycles per instruction, ~5 other issues fit in each gap -- instead of in
     // front of them (the compiler's own order: the pipe idles while both waves of a SIMD stage).
-    constexpr int NM = 12 * NCT;  // MFMAs of the step
-    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NCT + 2), 0);  // DS reads
+    constexpr int NM = PR::N * 2 * NCT;  // MFMAs of the step
+    if constexpr (!H2) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NCT + 2), 0);  // DS reads
 #pragma unroll
-    for (int k = 0; k < NM; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
-      if (k < NM - 8) __builtin_amdgcn_sched_group_barrier(0x002, NCT == 4 ? 2 : 3, 0);  // two (three) vector instructions
-      if (k >= 8 && k < NM - 8 && (k & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS store
-      if (k >= NM - 8 && k < NM - 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // a buffer load
+      for (int k = 0; k < NM; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
+        if (k < NM - 8) __builtin_amdgcn_sched_group_barrier(0x002, NCT == 4 ? 2 : 3, 0);  // two (three) vector instructions
+        if (k >= 8 && k < NM - 8 && (k & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS store
+        if (k >= NM - 8 && k < NM - 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // a buffer load
+      }
+    } else {
+      // half as many matrix instructions for the same staging: the three weight planes' stores (no arithmetic in front of them)
+      // early, the split (28 vector instructions) three to a gap, the two activation stores behind it, the 5 loads last
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * NCT + 4, 0);  // DS reads
+#pragma unroll
+      for (int k = 0; k < NM; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
+        if (k < NM - 6) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // three vector instructions
+        if (k == 1 || k == 3 || k == 5 || k == NM - 9 || k == NM - 7) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS store
+        if (k >= NM - 6 && k < NM - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // a buffer load
+      }
     }
     // (measured alternatives: the staging ten MFMAs later 388 vs 371 us, one vector instruction per gap all along 380, on 16384 x 768 -> 3072;
     //  the compiler's own order, tools/ablate.py x3big_nosched: 411)
     __syncthreads();  // every wave has read stage `buf`; the other stage is complete
   }
 
+  if constexpr (H2) {
+#pragma unroll
+    for (int i = 0; i < NCT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = acc[i][j] * p.out_scale;
+  }
   gemm_big_epilogue<NCT>(p, acc, m0, n0, wc, wp, lane, tid, gsmf);
 }
 
@@ -2508,7 +2558,7 @@ static int x3_big_plan(const AzConvArgs* a, int64_t npix, int* splitk, int kstep
   return all;  // (a partial round still beats the small tile: 192 tiles 117 vs 125 us)
 }
 
-__attribute__((visibility("hidden"))) int azi_winograd_x3_launch(const WinoP& p, unsigned splitk, hipStream_t st);  // wino_x3.hip
+__attribute__((visibility("hidden"))) int azi_winograd_x3_launch(const WinoP& p, unsigned splitk, hipStream_t st, bool h2);  // wino_x3.hip
 
 extern "C" {
 
@@ -2571,7 +2621,7 @@ static int launch_splitk_reduce(const ConvP& cp, hipStream_t st, int io = 0) {  
   return az_launch_status();
 }
 
-static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half /* 0 fp32, 1 bf16, 2 f16 operands, 3 fp32 as 3 x bf16 */);
+static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half /* 0 fp32, 1 bf16, 2 f16 operands, 3 fp32 as 3 x bf16, 4 fp32 as 2 x f16 */);
 
 int az_conv2d_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 0); }
 
@@ -2613,6 +2663,14 @@ int az_conv2d_f16_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_d
 /* fp32 operands evaluated as 3 x bf16 pieces / 6 partial products (see conv_igemm_x3_kernel): `weight` is the packing
  * of az_pack_conv_weight_x3_f32; fp32-level accuracy at 0.375 x the matrix-pipe time of the fp32 MFMA.              */
 int az_conv2d_x3_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 3); }
+/* fp32 operands as 2 x f16 pieces / 3 partial products (include/azula_amd.h: "f16x2"): `weight` = az_pack_conv_weight_f16x2_f32
+ * output, `w_scale` the scale given to it; the x3 kernels' tiles, plans and epilogues.                                   */
+int az_conv2d_f16x2_f32(const AzConvArgs* a, az_stream_t stream) { return conv2d_direct(a, stream, 4); }
+
+static bool conv_pow2(float v) {  // a finite positive power of two
+  int e;
+  return v > 0.f && v < 3.0e38f && frexpf(v, &e) == 0.5f;
+}
 
 static void launch_igemm_half(const ConvP& p, bool f16, bool srch, dim3 grid, hipStream_t st) {
   if (f16 && srch) hipLaunchKernelGGL((conv_igemm_half_kernel<true, true>), grid, dim3(256), 0, st, p);
@@ -2675,10 +2733,13 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   const int64_t npix64 = (int64_t)a->batch * a->hout * a->wout;
   AZ_REQUIRE(npix64 < (1ll << 31), AZ_E_SHAPE);
 
+  const bool x3 = half == 3 || half == 4;  // fp32 operands as pieces: the same kernels, plans and packed layout (three 2-byte planes)
+  if (half == 4) AZ_REQUIRE(conv_pow2(a->w_scale), AZ_E_SHAPE);
   ConvP p;
   p.a = *a;
   p.npix = (int)npix64;
   p.cin_s = a->c0s + a->c1s;
+  p.out_scale = half == 4 ? 1.f / (AZ_F16X2_IN_SCALE * a->w_scale) : 1.f;
   // fp32 direct kernel: K tile 16 with three workgroups per CU when the workgroup count then fills the chip evenly
   // (see conv_igemm_kernel); AZ_IGEMM_K16 = 0 / 1 forces the choice (A/B measurements)
   bool k16 = false;
@@ -2718,10 +2779,10 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   int big_sk = 1;
   // 256-cout tiles of the 256 x 256 kernel (bf16x3: K steps of 16 channels; half-precision operands: 64)
   int big_ct = GB;
-  int nbig = half == 3 ? x3_big_plan(a, npix64, &big_sk, GBK, &big_ct) : (half == 1 || half == 2) ? x3_big_plan(a, npix64, &big_sk, HGK) : 0;
+  int nbig = x3 ? x3_big_plan(a, npix64, &big_sk, GBK, &big_ct) : (half == 1 || half == 2) ? x3_big_plan(a, npix64, &big_sk, HGK) : 0;
   if (nbig > 0 && nbig * big_ct < a->cout_s && a->splitk > 1) nbig = 0;  // (a remainder launch would need the same slabs: one kernel then)
   const bool big = nbig > 0;
-  const int bk = big ? (half == 3 ? GBK : HGK) : half == 3 ? XBK : (half ? HBK : (k16 ? 16 : BK));
+  const int bk = big ? (x3 ? GBK : HGK) : x3 ? XBK : (half ? HBK : (k16 ? 16 : BK));
   p.nkc0 = (a->c0s + bk - 1) / bk;
   p.nkc1 = (a->c1s + bk - 1) / bk;
   p.nk = a->ksize * a->ksize * (p.nkc0 + p.nkc1);
@@ -2732,7 +2793,7 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     AZ_REQUIRE(span * a->h0 * a->w0 * a->c0s * 4 < (1ll << 31), AZ_E_SHAPE);
     AZ_REQUIRE(span * a->h1 * a->w1 * a->c1s * 4 < (1ll << 31), AZ_E_SHAPE);
     AZ_REQUIRE((int64_t)a->cout_s * p.cin_s * 4 < (1ll << 31), AZ_E_SHAPE);
-    AZ_REQUIRE((int64_t)a->ksize * a->ksize * a->cout_s * p.cin_s * (half == 3 ? 6 : 4) <= (1ll << 31), AZ_E_SHAPE);
+    AZ_REQUIRE((int64_t)a->ksize * a->ksize * a->cout_s * p.cin_s * (x3 ? 6 : 4) <= (1ll << 31), AZ_E_SHAPE);
   }
   hipStream_t st = az_s(stream);
   if (!half && a->cout_s == 4 && a->ksize == 3 && a->stride == 1 && a->pad == 1 && !a->src1 && a->up0 == 0 && !a->aniso &&
@@ -2769,6 +2830,9 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     if (half == 3 && big_ct == 192) hipLaunchKernelGGL(conv_gemm_x3_big_kernel<3>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else if (half == 3 && x3_big_taps(a)) hipLaunchKernelGGL((conv_gemm_x3_big_kernel<4, true>), dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else if (half == 3) hipLaunchKernelGGL(conv_gemm_x3_big_kernel<4>, dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
+    else if (half == 4 && big_ct == 192) hipLaunchKernelGGL((conv_gemm_x3_big_kernel<3, false, true>), dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
+    else if (half == 4 && x3_big_taps(a)) hipLaunchKernelGGL((conv_gemm_x3_big_kernel<4, true, true>), dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
+    else if (half == 4) hipLaunchKernelGGL((conv_gemm_x3_big_kernel<4, false, true>), dim3((unsigned)nwg, (unsigned)splitk), dim3(512), 0, st, p);
     else {
       const dim3 g((unsigned)nwg, (unsigned)splitk);
 #define AZ_HBIG(F16, TAPS, SRCH) hipLaunchKernelGGL((conv_gemm_half_big_kernel<F16, TAPS, SRCH>), g, dim3(512), 0, st, p)
@@ -2786,7 +2850,7 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
     }
     if (nbig * big_ct < a->cout_s) {  // the remaining output channels (256-cout tiles only): 128 x 128 tiles, K tiles of 32
       ConvP q = p;
-      const int sbk = half == 3 ? XBK : HBK;
+      const int sbk = x3 ? XBK : HBK;
       q.nkc0 = (a->c0s + sbk - 1) / sbk;
       q.nkc1 = (a->c1s + sbk - 1) / sbk;
       q.nk = a->ksize * a->ksize * (q.nkc0 + q.nkc1);
@@ -2796,14 +2860,17 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
       q.tiles_m = (a->cout_s - nbig * GB + BM - 1) / BM;
       q.tiles_n = (p.npix + BN - 1) / BN;
       nwg = (int64_t)q.tiles_m * q.tiles_n;
-      if (half == 3) hipLaunchKernelGGL(conv_igemm_x3_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, q);
+      if (half == 3) hipLaunchKernelGGL(conv_igemm_x3_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, q);
+      else if (half == 4) hipLaunchKernelGGL(conv_igemm_x3_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, q);
       else launch_igemm_half(q, half == 2, a->src_dtype != 0, dim3((unsigned)nwg, (unsigned)splitk), st);
     }
   } else
   if (half == 1 || half == 2)
     launch_igemm_half(p, half == 2, a->src_dtype != 0, dim3((unsigned)nwg, (unsigned)splitk), st);
   else if (half == 3)
-    hipLaunchKernelGGL(conv_igemm_x3_kernel, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(conv_igemm_x3_kernel<false>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
+  else if (half == 4)
+    hipLaunchKernelGGL(conv_igemm_x3_kernel<true>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
   else if (k16)
     hipLaunchKernelGGL(conv_igemm_kernel<16>, dim3((unsigned)nwg, (unsigned)splitk), dim3(256), 0, st, p);
   else
@@ -2856,14 +2923,21 @@ int az_conv2d_winograd_f32(const AzConvArgs* a, az_stream_t stream) {
 
 /* The same convolution with the 16 frequency GEMMs on the bf16 matrix pipe as exact 3 x bf16 splits (wino_x3.hip): `weight` =
  * az_winograd_pack_filter_x3_f32 output (16-channel steps); every other field as az_conv2d_winograd_f32. */
-int az_conv2d_winograd_x3_f32(const AzConvArgs* a, az_stream_t stream) {
+static int winograd_x3_entry(const AzConvArgs* a, az_stream_t stream, bool h2);
+int az_conv2d_winograd_x3_f32(const AzConvArgs* a, az_stream_t stream) { return winograd_x3_entry(a, stream, false); }
+/* The f16x2 form of the same kernel (include/azula_amd.h): `weight` = az_winograd_pack_filter_f16x2_f32 output, `w_scale` its scale. */
+int az_conv2d_winograd_f16x2_f32(const AzConvArgs* a, az_stream_t stream) { return winograd_x3_entry(a, stream, true); }
+
+static int winograd_x3_entry(const AzConvArgs* a, az_stream_t stream, bool h2) {
   WinoP p;
   int splitk = 1;
   const int prc = wino_prepare(a, 16, 16ll * WC * 16 * 3 * 2, p, splitk);
   if (prc != AZ_OK) return prc;
   AZ_REQUIRE(p.tiles_w >= 2, AZ_E_UNSUPPORTED);  // (the kernel stages <= 32 tile-row segments per 64-tile block: maps >= 3 pixels wide)
+  if (h2) AZ_REQUIRE(conv_pow2(a->w_scale), AZ_E_SHAPE);
+  p.out_scale = h2 ? 1.f / (AZ_F16X2_IN_SCALE * a->w_scale) : 1.f;
   hipStream_t st = az_s(stream);
-  int rc = azi_winograd_x3_launch(p, (unsigned)splitk, st);
+  int rc = azi_winograd_x3_launch(p, (unsigned)splitk, st, h2);
   if (rc != AZ_OK) return rc;
   if (splitk > 1) {
     ConvP cp;

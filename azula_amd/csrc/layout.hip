@@ -97,9 +97,35 @@ __global__ __launch_bounds__(256) void pack_conv_weight_half_kernel(unsigned sho
 
 // Three-piece bf16 split of the same [tap][co][ci_packed] layout for the fp32-on-bf16-pipe kernel (conv_igemm_x3_kernel):
 // dst = [piece][tap][cout_s][cin_s]; w = w1 + w2 + w3 exactly (8-bit slices of the significand, by truncation).
+// The three 2-byte pieces of a packed weight.  H2 = false: v = p0 + p1 + p2 exactly (bf16, truncated 8-bit slices).  H2 = true
+// ("f16x2", include/azula_amd.h): v' = v * w_scale as IEEE half pieces p0 = wh = fp16(v'), p1 = wl = fp16(v' - wh) (the residual,
+// unscaled: subnormal for |v'| < 2^-3, i.e. below 2^-18 of the largest weight -- the matrix pipe honours subnormals), and
+// p2 = wh / 2^11, the factor of the activation's scaled low piece.
+template <bool H2>
+__device__ __forceinline__ void weight_pieces(float v, float w_scale, unsigned short& p0, unsigned short& p1, unsigned short& p2) {
+  if constexpr (H2) {
+    const float vs = v * w_scale;
+    const _Float16 h = (_Float16)vs;
+    const _Float16 l = (_Float16)(vs - (float)h);
+    const _Float16 hs = (_Float16)((float)h * 0.00048828125f);
+    p0 = __builtin_bit_cast(unsigned short, h);
+    p1 = __builtin_bit_cast(unsigned short, l);
+    p2 = __builtin_bit_cast(unsigned short, hs);
+  } else {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const float r1 = v - __builtin_bit_cast(float, u & 0xFFFF0000u);
+    const unsigned u1 = __builtin_bit_cast(unsigned, r1);
+    const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+    p0 = (unsigned short)(u >> 16);
+    p1 = (unsigned short)(u1 >> 16);
+    p2 = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+  }
+}
+
+template <bool H2>
 __global__ __launch_bounds__(256) void pack_conv_weight_x3_kernel(unsigned short* __restrict__ dst,
                                                                   const float* __restrict__ src, int cout, int cin,
-                                                                  int taps, int cout_s, int cin0, int c0s, int cin_s) {
+                                                                  int taps, int cout_s, int cin0, int c0s, int cin_s, float w_scale) {
   const int64_t total = (int64_t)taps * cout_s * cin_s;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
@@ -115,13 +141,7 @@ __global__ __launch_bounds__(256) void pack_conv_weight_x3_kernel(unsigned short
     }
     float v = 0.f;
     if (ci >= 0 && co < cout) v = src[((int64_t)co * cin + ci) * taps + tap];
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const float r1 = v - __builtin_bit_cast(float, u & 0xFFFF0000u);
-    const unsigned u1 = __builtin_bit_cast(unsigned, r1);
-    const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
-    dst[e] = (unsigned short)(u >> 16);
-    dst[total + e] = (unsigned short)(u1 >> 16);
-    dst[2 * total + e] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    weight_pieces<H2>(v, w_scale, dst[e], dst[total + e], dst[2 * total + e]);
   }
 }
 
@@ -170,8 +190,9 @@ __global__ __launch_bounds__(256) void winograd_filter_kernel(float* __restrict_
 // wave w owns the frequencies (xi = w & 3, nu = (w >> 2) + 2 f) of all 64 couts and lane (l31 = lane & 31, h = lane >> 5) holds
 // U[xi, nu][cout 32 half + l31][channels 8 h .. 8 h + 7] -- twelve contiguous 1 KB pieces per wave and step; the filter never
 // passes through LDS.
+template <bool H2>  // (H2: the f16x2 pieces of U * w_scale, see weight_pieces)
 __global__ __launch_bounds__(256) void winograd_filter_x3_kernel(unsigned short* __restrict__ dst, const float* __restrict__ src,
-                                                                 int cout, int cin, int cin0, int nk0, int nk, int cblocks) {
+                                                                 int cout, int cin, int cin0, int nk0, int nk, int cblocks, float w_scale) {
   const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
   const int64_t total = (int64_t)nk * cblocks * 8 * 4 * 64 * 8;  // values (three pieces each)
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -205,14 +226,8 @@ __global__ __launch_bounds__(256) void winograd_filter_x3_kernel(unsigned short*
         for (int b = 0; b < 3; ++b) acc += G[xi][a] * (double)g[a * 3 + b] * G[nu][b];
       v = (float)acc;
     }
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const float r1 = v - __builtin_bit_cast(float, u & 0xFFFF0000u);
-    const unsigned u1 = __builtin_bit_cast(unsigned, r1);
-    const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
     unsigned short* d = dst + (((((r * 8 + w) * 2 + f) * 2 + ch) * 3) * 64 + ln) * 8 + k8;  // piece 0; pieces are 512 elements apart
-    d[0] = (unsigned short)(u >> 16);
-    d[512] = (unsigned short)(u1 >> 16);
-    d[1024] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    weight_pieces<H2>(v, w_scale, d[0], d[512], d[1024]);
   }
 }
 
@@ -347,8 +362,34 @@ int az_pack_conv_weight_x3_f32(void* dst, const float* src, int32_t cout, int32_
   AZ_REQUIRE(cout > 0 && cin > 0 && ks > 0 && cout_s >= cout && cout_s % 4 == 0 && cin_s % 4 == 0, AZ_E_SHAPE);
   AZ_REQUIRE(cin0 >= 0 && cin0 <= cin && c0s >= cin0 && cin_s >= c0s + (cin - cin0), AZ_E_SHAPE);
   const int64_t total = (int64_t)ks * ks * cout_s * cin_s;
-  hipLaunchKernelGGL(pack_conv_weight_x3_kernel, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream),
-                     (unsigned short*)dst, src, cout, cin, ks * ks, cout_s, cin0, c0s, cin_s);
+  hipLaunchKernelGGL(pack_conv_weight_x3_kernel<false>, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream),
+                     (unsigned short*)dst, src, cout, cin, ks * ks, cout_s, cin0, c0s, cin_s, 1.f);
+  return az_launch_status();
+}
+
+static bool az_pow2(float v) {  // a finite positive power of two
+  int e;
+  return v > 0.f && v < 3.0e38f && frexpf(v, &e) == 0.5f;
+}
+
+float az_f16x2_weight_scale(float amax, int32_t winograd) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(winograd ? amax * 2.25f : amax, &e);  // value in [2^(e-1), 2^e)
+  int k = 14 - e;                                     // value * 2^k in [2^13, 2^14)
+  if (k > 100) k = 100;
+  if (k < -100) k = -100;
+  return ldexpf(1.f, k);
+}
+
+int az_pack_conv_weight_f16x2_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t ks, int32_t cout_s,
+                                  int32_t cin0, int32_t c0s, int32_t cin_s, float w_scale, az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(cout > 0 && cin > 0 && ks > 0 && cout_s >= cout && cout_s % 4 == 0 && cin_s % 4 == 0 && az_pow2(w_scale), AZ_E_SHAPE);
+  AZ_REQUIRE(cin0 >= 0 && cin0 <= cin && c0s >= cin0 && cin_s >= c0s + (cin - cin0), AZ_E_SHAPE);
+  const int64_t total = (int64_t)ks * ks * cout_s * cin_s;
+  hipLaunchKernelGGL(pack_conv_weight_x3_kernel<true>, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream),
+                     (unsigned short*)dst, src, cout, cin, ks * ks, cout_s, cin0, c0s, cin_s, w_scale);
   return az_launch_status();
 }
 
@@ -371,8 +412,20 @@ int az_winograd_pack_filter_x3_f32(void* dst, const float* src, int32_t cout, in
                  cblocks * 64 >= cout,
              AZ_E_SHAPE);
   const int64_t total = (int64_t)nk * cblocks * 8 * 4 * 64 * 8;
-  hipLaunchKernelGGL(winograd_filter_x3_kernel, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream),
-                     (unsigned short*)dst, src, cout, cin, cin0, nk0, nk, cblocks);
+  hipLaunchKernelGGL(winograd_filter_x3_kernel<false>, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream),
+                     (unsigned short*)dst, src, cout, cin, cin0, nk0, nk, cblocks, 1.f);
+  return az_launch_status();
+}
+
+int az_winograd_pack_filter_f16x2_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t cin0, int32_t nk0,
+                                      int32_t nk, int32_t cblocks, float w_scale, az_stream_t stream) {
+  AZ_REQUIRE(dst && src, AZ_E_NULL);
+  AZ_REQUIRE(cout > 0 && cin > 0 && cin0 >= 0 && cin0 <= cin && nk0 * 16 >= cin0 && (nk - nk0) * 16 >= cin - cin0 &&
+                 cblocks * 64 >= cout && az_pow2(w_scale),
+             AZ_E_SHAPE);
+  const int64_t total = (int64_t)nk * cblocks * 8 * 4 * 64 * 8;
+  hipLaunchKernelGGL(winograd_filter_x3_kernel<true>, dim3(az_stream_grid(total, 256)), dim3(256), 0, az_s(stream),
+                     (unsigned short*)dst, src, cout, cin, cin0, nk0, nk, cblocks, w_scale);
   return az_launch_status();
 }
 

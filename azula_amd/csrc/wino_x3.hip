@@ -40,6 +40,7 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int XT = 64;                       // tiles per workgroup
 constexpr int XC = 64;                       // output channels per workgroup
@@ -60,7 +61,13 @@ static_assert(X_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
 // AFF: 0 = plain input, 1 = the input is x * scale + shift (in_affine: a GroupNorm apply pass folded into the gather), 2 = SiLU of that.
 // TAIL: a source's channel count is not a multiple of 16 -- the last step of that source masks the channel pairs past its end.
-template <int AFF, bool TAIL>
+// H2: the "f16x2" form (az_conv2d_winograd_f16x2_f32, include/azula_amd.h): the filter arrives as the IEEE half pieces
+//   [uh | ul | uh / 2^11] of U * w_scale in the SAME fragment layout, V is split into two half pieces of V * AZ_F16X2_IN_SCALE,
+//   h and l = (V' - h) 2^11 (common.h: az_split2h), and a frequency's product is THREE v_mfma_f32_32x32x16_f16 per 16 channels
+//   (ul h + uh h + (uh / 2^11) l) instead of six bf16 ones: 12 matrix instructions per phase, 56 instead of 88 vector
+//   instructions of splitting per phase and wave, 8 fragment registers fewer.  The accumulators are multiplied by
+//   p.out_scale = 1 / (AZ_F16X2_IN_SCALE * w_scale) (a power of two) behind the K loop; everything else is the same code.
+template <int AFF, bool TAIL, bool H2 = false>
 __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];
   char* const smem = reinterpret_cast<char*>(wsm);
@@ -269,12 +276,12 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
   // the wave's filter fragments of (step kt, its frequency f, piece pl): both cout halves, rows = couts ch * 32 + l31,
   // k = 8 h .. 8 h + 7 of the step -- two contiguous 1 KB loads
   const unsigned u_lane = (unsigned)(lane * 16);
-  bf16x8 ua[2][3];  // [cout half][piece]
+  uint4 ua[2][3];  // [cout half][piece]
   auto load_u = [&](int kt, int f, int pl) __attribute__((always_inline)) {
     const unsigned soff =  // (wave-uniform, but derived from threadIdx: readfirstlane makes it a scalar operand)
         (unsigned)__builtin_amdgcn_readfirstlane((int)((((int64_t)kt * p.cblocks + cb) * 8 + wave) * (12 * 1024) + f * (6 * 1024)));
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));
+    for (int ch = 0; ch < 2; ++ch) ua[ch][pl] = __builtin_bit_cast(uint4, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));
   };
 
   f32x16 acc[8];  // [4 f + 2 ch + th]
@@ -310,13 +317,36 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
   };
   // the six partial products of a frequency in the order the B pieces become available: b0 (3 products), b1 (2), b2 (1); the A
   // pieces free up in the order a2 (after 4 MFMAs), a1 (after 16), a0 -- their registers take the next phase's fragments
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-  constexpr int PB[6] = {0, 0, 0, 1, 1, 2};
-  auto mf = [&](int f, int k) __attribute__((always_inline)) {  // MFMA k = 0..23 of a phase: product t = k / 4, tile half, cout half
+  // (H2: b = h serves the products with ul and uh, b = l the one with uh / 2^11; the A pieces free up in the order 1, 0, 2)
+  constexpr int PA[6] = {H2 ? 1 : 2, H2 ? 0 : 1, H2 ? 2 : 0, 1, 0, 0};
+  constexpr int PB[6] = {0, 0, H2 ? 1 : 0, 1, 1, 2};
+  auto mf = [&](int f, int k) __attribute__((always_inline)) {  // MFMA k = 0..23 (H2: 0..11) of a phase: product t = k / 4, tile half, cout half
     const int t = k >> 2, th = (k >> 1) & 1, ch = k & 1;
     f32x16& c = acc[4 * f + 2 * ch + th];
     uint4 bw = make_uint4(fw[th][PB[t]][0], fw[th][PB[t]][1], fw[th][PB[t]][2], fw[th][PB[t]][3]);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[ch][PA[t]], __builtin_bit_cast(bf16x8, bw), c, 0, 0, 0);
+    if constexpr (H2) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ua[ch][PA[t]]), __builtin_bit_cast(f16x8, bw), c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua[ch][PA[t]]), __builtin_bit_cast(bf16x8, bw), c, 0, 0, 0);
+  };
+  // H2: the two half pieces of tile half th (common.h: az_split2h, in two steps so that the products with h can start before the
+  // low piece exists): h = fp16(V'), xf <- V' 2^11;  then l = fp16(xf - 2^11 h)
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  auto h_piece = [&](int th) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 x = {xf[th][2 * j], xf[th][2 * j + 1]};
+      const f32x2 v = x * AZ_F16X2_IN_SCALE;
+      fw[th][0][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2v));
+      const f32x2 t = x * (AZ_F16X2_IN_SCALE * 2048.f);
+      xf[th][2 * j] = t.x, xf[th][2 * j + 1] = t.y;
+    }
+  };
+  auto l_piece = [&](int th) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const h2v hh = __builtin_bit_cast(h2v, fw[th][0][j]);
+      const h2v l = {(_Float16)__builtin_fmaf((float)hh.x, -2048.f, xf[th][2 * j]), (_Float16)__builtin_fmaf((float)hh.y, -2048.f, xf[th][2 * j + 1])};
+      fw[th][1][j] = __builtin_bit_cast(unsigned, l);
+    }
   };
 
   // One phase = the 24 MFMAs of (step kt, the wave's frequency f = hs) + the production of the NEXT half-stage into the other buffer:
@@ -331,6 +361,39 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
     constexpr int ob = 1 - hs;  // the buffer (and half of the frequencies) this phase produces
     const int ktu = hs == 0 ? kt : ktn;  // the step whose filter fragments are loaded next (frequency f = ob of it)
     // (entry: xf[0], xf[1] hold the phase's raw fragments, read behind the barrier)
+    if constexpr (H2) {
+      // 12 products per phase; the producer side is the same work as below, two slots' worth per slot
+      h_piece(0); XS_FENCE;
+      if constexpr (hs == 0) {
+        mf(hs, 0); h_piece(1); XS_FENCE;
+        mf(hs, 1); nu_store(ob, 0); nu_store(ob, 1); XS_FENCE;
+        mf(hs, 2); nu_store(ob, 2); nu_store(ob, 3); XS_FENCE;  // (rv is free from here)
+        mf(hs, 3); gl(ktn, 0); gl(ktn, 1); gl(ktn, 2); load_u(ktu, ob, 1); XS_FENCE;  // (a1 is free: the next phase's a1)
+        mf(hs, 4); gl(ktn, 3); gl(ktn, 4); gl(ktn, 5); XS_FENCE;
+        mf(hs, 5); l_piece(0); XS_FENCE;
+        mf(hs, 6); l_piece(1); XS_FENCE;
+        mf(hs, 7); load_u(ktu, ob, 0); XS_FENCE;  // (a0 is free)
+        mf(hs, 8); gs(0); gs(1); XS_FENCE;
+        mf(hs, 9); gs(2); gs(3); XS_FENCE;
+        mf(hs, 10); gs(4); gs(5); XS_FENCE;
+        mf(hs, 11);
+      } else {
+        mf(hs, 0); h_piece(1); affine_load(ktn); XS_FENCE;
+        mf(hs, 1); patch_rows(ktn, 0, 2); XS_FENCE;
+        mf(hs, 2); patch_rows(ktn, 2, 4); XS_FENCE;
+        mf(hs, 3); l_piece(0); load_u(ktu, ob, 1); XS_FENCE;
+        mf(hs, 4); l_piece(1); XS_FENCE;
+        affine();
+        mf(hs, 5); row_transform(0); row_transform(1); XS_FENCE;
+        mf(hs, 6); row_transform(2); row_transform(3); XS_FENCE;
+        mf(hs, 7); load_u(ktu, ob, 0); XS_FENCE;
+        mf(hs, 8); nu_store(ob, 0); XS_FENCE;
+        mf(hs, 9); nu_store(ob, 1); XS_FENCE;
+        mf(hs, 10); nu_store(ob, 2); XS_FENCE;
+        mf(hs, 11); nu_store(ob, 3);
+      }
+      load_u(ktu, ob, 2);
+    } else {
     piece(0, 0); XS_FENCE;
     if constexpr (hs == 0) {
       // (rv holds B^T d of step kt: consumed first, its registers then take the staging loads; the staging area is free: every
@@ -389,6 +452,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
       mf(hs, 23);
     }
     load_u(ktu, ob, 0);
+    }
     // the NEXT phase's fragments: its buffer is complete behind the barrier.  (Measured and not kept -- profiles/r05_wx3_sched_ab.txt:
     // the barrier AHEAD of the last four products, to cover the LDS round trip of these reads with matrix work, and the producer
     // side three slots earlier: + 3.5 % cycles, a wave then waits with products unissued.)
@@ -403,7 +467,11 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
     // (piece 2 first, fenced: the order in which the loop keeps its filter loads in flight.  The wait counts the compiler derives
     //  at the loop header are the stricter of the entry's and the back edge's; with the pieces in ascending order the entry made
     //  the first two products of EVERY step wait for all outstanding filter loads -- vmcnt(2) / vmcnt(0) instead of 5 / 4)
-    XS_FENCE; load_u(kt_begin, 0, 2); XS_FENCE; load_u(kt_begin, 0, 1); XS_FENCE; load_u(kt_begin, 0, 0); XS_FENCE;
+    if constexpr (H2) {
+      XS_FENCE; load_u(kt_begin, 0, 1); XS_FENCE; load_u(kt_begin, 0, 0); XS_FENCE; load_u(kt_begin, 0, 2); XS_FENCE;
+    } else {
+      XS_FENCE; load_u(kt_begin, 0, 2); XS_FENCE; load_u(kt_begin, 0, 1); XS_FENCE; load_u(kt_begin, 0, 0); XS_FENCE;
+    }
 #pragma unroll
     for (int m = 0; m < 6; ++m) gs(m);
     __syncthreads();
@@ -429,6 +497,10 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
   }
   __syncthreads();
 #undef XS_FENCE
+  if constexpr (H2) {  // back to the operands' scale (exact: a power of two)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = acc[q] * p.out_scale;
+  }
 
   // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  Z[xi][px] = sum_nu M[xi][nu] A[nu][px]: px = 0: M0 + M1 + M2,
   // px = 1: M1 - M2 - M3.  A wave holds M[xi][k] (f = 0) and M[xi][k + 2] (f = 1) of all 64 couts x 64 tiles:
@@ -576,25 +648,31 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
 }  // namespace
 
 // Launch (host side of az_conv2d_winograd_x3_f32, conv.hip validates the descriptor and fills `p` in 16-channel steps).
-template <int AFF, bool TAIL>
+template <int AFF, bool TAIL, bool H2>
 static int launch_x3(const WinoP& p, unsigned splitk, hipStream_t st) {
   static std::atomic<uint64_t> lds_set{0};  // (one per instantiation, one bit per device: common.h)
-  hipError_t e = az_max_dynamic_lds((const void*)conv_winograd_x3_kernel<AFF, TAIL>, X_LDS_BYTES, lds_set);
+  hipError_t e = az_max_dynamic_lds((const void*)conv_winograd_x3_kernel<AFF, TAIL, H2>, X_LDS_BYTES, lds_set);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv_winograd_x3_kernel<AFF, TAIL>), dim3((unsigned)((int64_t)p.cblocks * p.tblocks), splitk), dim3(512), X_LDS_BYTES,
+  hipLaunchKernelGGL((conv_winograd_x3_kernel<AFF, TAIL, H2>), dim3((unsigned)((int64_t)p.cblocks * p.tblocks), splitk), dim3(512), X_LDS_BYTES,
                      st, p);
   return az_launch_status();
 }
 
-__attribute__((visibility("hidden"))) int azi_winograd_x3_launch(const WinoP& p, unsigned splitk, hipStream_t st) {
+template <bool H2>
+static int launch_x3_mode(const WinoP& p, unsigned splitk, hipStream_t st) {
   const bool tail = (p.a.c0s % XK) != 0 || (p.a.c1s % XK) != 0;
   const int aff = !p.a.in_affine ? 0 : (p.a.in_act == 0 ? 1 : 2);
   switch (aff * 2 + (tail ? 1 : 0)) {
-    case 0: return launch_x3<0, false>(p, splitk, st);
-    case 1: return launch_x3<0, true>(p, splitk, st);
-    case 2: return launch_x3<1, false>(p, splitk, st);
-    case 3: return launch_x3<1, true>(p, splitk, st);
-    case 4: return launch_x3<2, false>(p, splitk, st);
-    default: return launch_x3<2, true>(p, splitk, st);
+    case 0: return launch_x3<0, false, H2>(p, splitk, st);
+    case 1: return launch_x3<0, true, H2>(p, splitk, st);
+    case 2: return launch_x3<1, false, H2>(p, splitk, st);
+    case 3: return launch_x3<1, true, H2>(p, splitk, st);
+    case 4: return launch_x3<2, false, H2>(p, splitk, st);
+    default: return launch_x3<2, true, H2>(p, splitk, st);
   }
+}
+
+// h2: the f16x2 form (p.out_scale set by the caller)
+__attribute__((visibility("hidden"))) int azi_winograd_x3_launch(const WinoP& p, unsigned splitk, hipStream_t st, bool h2) {
+  return h2 ? launch_x3_mode<true>(p, splitk, st) : launch_x3_mode<false>(p, splitk, st);
 }

@@ -151,8 +151,13 @@ WINOGRAD = os.environ.get("AZ_WINOGRAD", "1")
 # (az_conv2d_x3_f32) -- measured MORE accurate against fp64 than the fp32 MFMA (tests/test_gpu_kernels.py::
 # test_conv2d_x3_accuracy) at 0.375 x its matrix-pipe time: DiT-B/2 54.7 -> 70.1 images/s, JiT-B/16 43.6 -> 58.4.
 # "native": v_mfma_f32_32x32x2_f32 everywhere.  The stride-1 3 x 3 convolutions run the Winograd kernel in both modes (bf16x3: WINO_X3 below).
+# "f16x2": every fp32 operand as TWO IEEE half pieces (activations: h and the residual scaled by 2^11, of x / 16; weights: wh, wl
+# and wh / 2^11 of w times a power of two fixed at pack time), three partial products on v_mfma_f32_32x32x16_f16 in one fp32
+# accumulator -- half the matrix instructions of bf16x3 at the accuracy of the fp32 MFMA (include/azula_amd.h: az_conv2d_f16x2_f32),
+# on a STATED domain: activations below ~1e6 in magnitude (beyond it NaN, never a wrong finite value).
 FP32_MFMA = os.environ.get("AZ_FP32_MFMA", "bf16x3")
-assert FP32_MFMA in ("native", "bf16x3"), FP32_MFMA
+assert FP32_MFMA in ("native", "bf16x3", "f16x2"), FP32_MFMA
+PIECES = FP32_MFMA in ("bf16x3", "f16x2")  # fp32 operands as 2-byte pieces on the bf16 / f16 pipe
 ATTN_X3 = os.environ.get("AZ_ATTN_X3", "1") != "0"  # bf16x3 mode: attention contractions on the bf16 pipe too (az_attention_x3_f32)
 # The stride-1 3 x 3 layers in bf16x3 mode: "1" (default since round 5) = the Winograd kernel with its 16 frequency GEMMs on the bf16 pipe
 # as exact 3 x bf16 splits too (az_conv2d_winograd_x3_f32, csrc/wino_x3.hip: same transforms, same epilogue, 1.19 - 1.28 x the fp32
@@ -169,6 +174,9 @@ GN_FUSED = os.environ.get("AZ_GN_FUSED", "1") != "0"
 STEM_PLANAR = os.environ.get("AZ_STEM_PLANAR", "1") != "0"
 AFFINE_FUSED = os.environ.get("AZ_AFFINE_FUSED", "1") != "0"
 GN_FUSED_SPLITK = os.environ.get("AZ_GN_FUSED", "1") != "epilogue"  # ("epilogue": only the Winograd epilogue's moments -- A/B)
+
+
+WINO_X3_NAMES = ("az_conv2d_winograd_x3_f32", "az_conv2d_winograd_f16x2_f32")  # wino_x3.hip: the piece forms of the Winograd kernel
 
 
 class ConvWeights:
@@ -203,8 +211,9 @@ class ConvWeights:
         if bias is not None:
             self.bias = torch.zeros(self.cout_s, dtype=torch.float32, device=bld.device)
             self.bias[: self.cout] = bias.detach().to(device=bld.device, dtype=torch.float32)
-        self._direct = self._wino = self._wino4 = self._x3 = None
+        self._direct = self._wino = self._wino4 = self._x3 = self._h2 = self._wino_h2 = None
         self._half: dict = {}
+        self._amax = None
 
     def direct(self) -> torch.Tensor:
         r"""[tap][cout_s][cin_s] (K contiguous), zero padded (az_pack_conv_weight_f32)."""
@@ -249,6 +258,38 @@ class ConvWeights:
             )
             self._x3 = packed
         return self._x3
+
+    def w_scale(self, winograd: bool) -> float:
+        r"""The power of two the f16x2 packings multiply the weights by (``az_f16x2_weight_scale``: the largest magnitude -- of
+        the Winograd-domain filter when ``winograd`` -- lands in [2^13, 2^14)); handed to the kernels as ``AzConvArgs.w_scale``."""
+        if self._amax is None:
+            self._amax = float(self.w.abs().max()) if self.w.numel() else 0.0
+        return float(_lib.lib().az_f16x2_weight_scale(self._amax, int(winograd)))
+
+    def direct_f16x2(self) -> torch.Tensor:
+        r"""The direct layout as three IEEE half planes [wh | wl | wh / 2^11] of w * w_scale, for ``az_conv2d_f16x2_f32``."""
+        if self._h2 is None:
+            cin_s = self.c0s + self.c1s
+            packed = torch.empty(3 * self.ks * self.ks * self.cout_s * cin_s, dtype=torch.int16, device=self.device)
+            _lib.call(
+                "az_pack_conv_weight_f16x2_f32", packed.data_ptr(), self.w.data_ptr(), self.cout, self.cin, self.ks,
+                self.cout_s, self.cin0, self.c0s, cin_s, self.w_scale(False), _lib.stream_ptr(),
+            )
+            self._h2 = packed
+        return self._h2
+
+    def winograd_f16x2(self) -> torch.Tensor:
+        r"""The x3 Winograd filter layout with the f16x2 pieces of U * w_scale, for ``az_conv2d_winograd_f16x2_f32``."""
+        if self._wino_h2 is None:
+            nk0, nk1 = (self.c0s + 15) // 16, (self.c1s + 15) // 16
+            cb = (self.cout_s + 63) // 64
+            packed = torch.empty((nk0 + nk1) * cb * 16 * 64 * 16 * 3, dtype=torch.int16, device=self.device)
+            _lib.call(
+                "az_winograd_pack_filter_f16x2_f32", packed.data_ptr(), self.w.data_ptr(), self.cout, self.cin, self.cin0,
+                nk0, nk0 + nk1, cb, self.w_scale(True), _lib.stream_ptr(),
+            )
+            self._wino_h2 = packed
+        return self._wino_h2
 
     def winograd(self) -> torch.Tensor:
         r"""Filter transform U = G g G^T (az_winograd_pack_filter_f32: fp64 accumulate, one-off) laid out
@@ -441,7 +482,7 @@ class Builder:
         # az_conv2d_f32 runs its narrow-output VALU kernel (104 vs 342 us at 4 x 256^2, 256 -> 3)
         head = (winograd is None and legal and not aniso and a.cout_s == 4 and src1 is None and up0 == 0 and a.c0s % 16 == 0
                 and head_wgs >= 256 and depth is None)
-        wino_ok = legal and not head and winograd != "x3"
+        wino_ok = legal and not head and winograd not in ("x3", "h2")
         use_f4 = wino_ok and depth is None and (winograd == 4 or (winograd is None and WINOGRAD == "4" and tiles4 >= WINOGRAD4_MIN_TILES))
         use_wino = wino_ok and not use_f4 and ((WINOGRAD != "0") if winograd is None else bool(winograd))
         if use_wino:
@@ -453,25 +494,35 @@ class Builder:
         # TF/s); the 3x3 stride-1 layers stay on the fp32 Winograd kernel, which executes 2.25x fewer multiplies
         # (221 vs 181 TF/s algorithmic at 4 x 256^2, 256 -> 256).
         use_x3 = self.half is None and (
-            winograd == "x3"
-            or (winograd is None and FP32_MFMA == "bf16x3" and not head and not use_wino and not use_f4
+            winograd in ("x3", "h2")
+            or (winograd is None and PIECES and not head and not use_wino and not use_f4
                 and cin_s >= X3_MIN_CHANNELS and a.cout_s >= X3_MIN_CHANNELS)
         )
+        # (winograd = "x3" / "wx3": the bf16x3 kernels, "h2" / "wh2": the f16x2 ones, whatever the mode -- kernel tests)
+        h2 = winograd in ("h2", "wh2") or (winograd not in ("x3", "wx3") and FP32_MFMA == "f16x2")
         if use_f4:
             a.weight = packed.winograd4().data_ptr()
             a.splitk = lib.az_conv2d_winograd4_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
             name = "az_conv2d_winograd4_f32"
-        elif use_wino and wout >= 3 and (winograd == "wx3" or (winograd is None and WINO_X3 and FP32_MFMA == "bf16x3")):
+        elif use_wino and wout >= 3 and (winograd in ("wx3", "wh2") or (winograd is None and WINO_X3 and PIECES)):
             # the frequency GEMMs on the bf16 pipe as exact 3 x bf16 splits (wino_x3.hip); same descriptor, 16-channel steps
-            a.weight = packed.winograd_x3().data_ptr()
-            name = "az_conv2d_winograd_x3_f32"
+            # (f16x2: the same kernel with two half pieces per operand and three products)
+            if h2:
+                a.weight, a.w_scale = packed.winograd_f16x2().data_ptr(), packed.w_scale(True)
+                name = "az_conv2d_winograd_f16x2_f32"
+            else:
+                a.weight = packed.winograd_x3().data_ptr()
+                name = "az_conv2d_winograd_x3_f32"
         elif use_wino:
             a.weight = packed.winograd().data_ptr()
             name = "az_conv2d_winograd_f32"
         elif use_x3:
-            a.weight = packed.direct_x3().data_ptr()
+            if h2:
+                a.weight, a.w_scale = packed.direct_f16x2().data_ptr(), packed.w_scale(False)
+            else:
+                a.weight = packed.direct_x3().data_ptr()
             a.splitk = lib.az_conv2d_x3_suggest_splitk(C.byref(a))  # (the 256 x 256-tile kernel has its own rule)
-            name = "az_conv2d_x3_f32"
+            name = "az_conv2d_f16x2_f32" if h2 else "az_conv2d_x3_f32"
         elif self.half is not None:
             a.weight = packed.direct_half(self.half == torch.float16).data_ptr()
             a.splitk = lib.az_conv2d_suggest_splitk(npix, a.cout_s, cin_s, ks)
@@ -488,12 +539,12 @@ class Builder:
             # the apply pass inside the gather (the fp32 kernel on a source of the output's size only; the x3 kernel's patch masks
             # live in output coordinates, so it also reads a nearest-upsampled source)
             if src1 is None and a.c0s % 8 == 0 and not aniso and (
-                    name == "az_conv2d_winograd_x3_f32" or (name == "az_conv2d_winograd_f32" and up0 == 0)):
+                    name in WINO_X3_NAMES or (name == "az_conv2d_winograd_f32" and up0 == 0)):
                 a.in_affine, a.in_act = ST.data_ptr(), in_act
             else:
                 tmp_src = self.materialize(src0)
                 a.src0 = tmp_src.ptr
-        if (gn_stats and GN_FUSED and name in ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32") and a.splitk == 1 and out is not None and cout == a.cout_s
+        if (gn_stats and GN_FUSED and name in ("az_conv2d_winograd_f32", *WINO_X3_NAMES) and a.splitk == 1 and out is not None and cout == a.cout_s
                 and cout % 64 == 0 and hout % 2 == 0 and wout % 2 == 0 and ((hout // 2) * (wout // 2)) % 64 == 0):
             # the output feeds a GroupNorm: its epilogue also writes per-(tile block, channel quad) moments
             chunks = ((hout // 2) * (wout // 2)) // 64
@@ -515,7 +566,7 @@ class Builder:
             a.gn_quads, a.gn_chunks = quads.data_ptr(), chunks
             out.gn_quads = (quads, chunks)
             self.tape.keep.append(quads)
-        if (qk_prep is not None and QK_PREP and name in ("az_conv2d_f32", "az_conv2d_bf16_f32", "az_conv2d_f16_f32", "az_conv2d_x3_f32")
+        if (qk_prep is not None and QK_PREP and name in ("az_conv2d_f32", "az_conv2d_bf16_f32", "az_conv2d_f16_f32", "az_conv2d_x3_f32", "az_conv2d_f16x2_f32")
                 and a.splitk == 1 and act == 0 and gate is None and res is None and out is not None and a.cout_s == cout
                 and qk_prep["head_dim"] in (32, 64, 128) and cout == 3 * qk_prep["heads"] * qk_prep["head_dim"]):
             # the fused q | k | v projection of an attention layer: q / k RMS norm, gains and RoPE in THIS epilogue, once per
@@ -835,7 +886,7 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
         self.tape.keep.append(m8)
     a._flops = 4 * qkv.B * heads * L * L * dim
     name = "az_attention_f32"
-    if self.half is None and FP32_MFMA == "bf16x3" and ATTN_X3 and dim in (16, 32, 64, 80):
+    if self.half is None and PIECES and ATTN_X3 and dim in (16, 32, 64, 80):
         # the two contractions as 3 x bf16 pieces / 6 partial products: fp32 accuracy, 0.375 x the pipe time (64 x 12 heads x 256
         # tokens x 64: 140 -> 111 us; head_dim 128 needs one wave per SIMD there and measured slower, 458 vs 516 us: fp32 kernel)
         name = "az_attention_x3_f32"

@@ -342,6 +342,10 @@ typedef struct AzConvArgs {
                             * (rounded to nearest even on the way out; bias, activation, gate, residual arithmetic stays fp32; GroupNorm
                             * moments are those of the rounded values); the planar destination (dst_nchw) and the split-K workspace are
                             * always fp32 */
+  float w_scale;           /* az_conv2d_f16x2_f32 / az_conv2d_winograd_f16x2_f32 only (ignored elsewhere): the power of two the packing
+                            * (az_pack_conv_weight_f16x2_f32 / az_winograd_pack_filter_f16x2_f32) multiplied the weights by; the kernels
+                            * multiply their accumulators by 1 / (AZ_F16X2_IN_SCALE * w_scale), exactly */
+  int32_t reserved1;
 } AzConvArgs;
 /* Narrow outputs (cout_s == 4, 3x3 stride 1 pad 1, one un-upsampled source with c0s % 16 == 0: the image head of
  * azula/nn/unet.py) run a VALU kernel instead of the 128-cout MFMA tile; splitk is ignored there.              */
@@ -384,6 +388,27 @@ int az_conv2d_winograd_suggest_splitk(int64_t batch, int32_t hout, int32_t wout,
  * the epilogue, split-K and gn_quads as az_conv2d_winograd_f32.  Inputs are assumed finite (an Inf operand splits into NaN
  * pieces).                                                                                                                  */
 int az_conv2d_winograd_x3_f32(const AzConvArgs* args, az_stream_t stream);
+/* fp32 operands on the fp16 matrix pipe ("f16x2"; AZ_FP32_MFMA=f16x2): HALF the matrix instructions of the bf16x3 form.
+ * An activation x enters as x' = x * AZ_F16X2_IN_SCALE = h + l / 2^11 with h = fp16(x') and l = fp16((x' - h) * 2^11) (22 - 23
+ * significant bits), a weight as w' = w * w_scale = wh + wl (two fp16 pieces, the residual unscaled) plus a third plane
+ * whs = wh / 2^11, and a product is THREE partial products on v_mfma_f32_32x32x16_f16 with fp32 accumulation in ONE accumulator,
+ *      wh h + wl h + whs l  =  w' x' - wl (x' - h)      (the dropped term is <= 2^-22 |w' x'|),
+ * scaled back by 1 / (AZ_F16X2_IN_SCALE * w_scale) (powers of two: exact) before the fused epilogue.  Measured against fp64 the
+ * result is as accurate as the fp32 MFMA kernel (the fp32 accumulation dominates both; tests/test_gpu_kernels.py::
+ * test_conv2d_x3_accuracy).  The gfx950 matrix pipe honours fp16 subnormals (tools/mfma_denorm_probe.hip), so the pieces degrade
+ * gracefully at the small end.  DOMAIN (stated, unlike bf16x3's, which is all of fp32): |x| * AZ_F16X2_IN_SCALE < 65520 --
+ * activations up to ~1.0e6 (Winograd form: 4-pixel sums of the input, i.e. inputs up to ~2.6e5); beyond it a piece is Inf and the
+ * outputs that depend on it are NaN (never a silently wrong finite value).  At the small end every operand carries an absolute
+ * error <= 2^-36 / AZ_F16X2_IN_SCALE = 2.3e-10 (full relative precision from |x| >= 1e-3 on).  bf16x3 stays selectable
+ * (AZ_FP32_MFMA=bf16x3).  `weight` = az_pack_conv_weight_f16x2_f32 / az_winograd_pack_filter_f16x2_f32 output (the layouts of the x3
+ * packings: three 2-byte planes), `w_scale` the scale given to that packing; everything else as the x3 entries.  Same reference
+ * op: azula/nn/layers.py:25-68 ConvNd / torch.nn.Linear on tokens (azula/nn/dit.py:88-93, azula/nn/attention.py:45-46). */
+#define AZ_F16X2_IN_SCALE 0.0625f
+int az_conv2d_f16x2_f32(const AzConvArgs* args, az_stream_t stream);
+int az_conv2d_winograd_f16x2_f32(const AzConvArgs* args, az_stream_t stream);
+/* The weight scale the f16x2 packings want for a weight tensor whose largest magnitude is `amax`: the power of two that puts
+ * amax (times 2.25 for the Winograd transform G g G^T when `winograd`) into (2^13, 2^14]; 1 for amax = 0 / non-finite. */
+float az_f16x2_weight_scale(float amax, int32_t winograd);
 /* Winograd F(4x4,3x3) form (6x6 patches, 36 frequency GEMMs: 2.25 multiplies per output instead of 4 / 9).
  * NOT exact: the transforms multiply by 2, 4, 5, 8 and the filter transform by 1/4 .. 1/24, so the fp32
  * rounding error is ~20x that of the F(2x2) kernel (~1e-5 of the output scale per layer).  Opt-in
@@ -495,6 +520,10 @@ int az_pack_conv_weight_half_f32(void* dst, const float* src, int32_t cout, int3
  * dst holds 3 * ks*ks*cout_s*cin_s two-byte elements.                                                              */
 int az_pack_conv_weight_x3_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t ks, int32_t cout_s,
                                int32_t cin0, int32_t c0s, int32_t cin_s, az_stream_t stream);
+/* The same three-plane layout for az_conv2d_f16x2_f32: planes [wh | wl | wh / 2^11] of w' = w * w_scale as IEEE half values
+ * (wh = fp16(w'), wl = fp16(w' - wh)); w_scale = az_f16x2_weight_scale(max |w|, 0) (a power of two).                    */
+int az_pack_conv_weight_f16x2_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t ks, int32_t cout_s,
+                                  int32_t cin0, int32_t c0s, int32_t cin_s, float w_scale, az_stream_t stream);
 
 /* torch (cout, cin, 3, 3) -> Winograd filter transform U = G g G^T (fp64 accumulate, one rounding) in
  * the layout az_conv2d_winograd_f32 streams: [nk chunks of 8 cin][cblocks of 64 cout][16][64][8]; input
@@ -508,6 +537,10 @@ int az_winograd_pack_filter_f32(float* dst, const float* src, int32_t cout, int3
  * nk * cblocks * 49152 two-byte elements; channels [0, cin0) fill steps [0, nk0), the rest start at step nk0.      */
 int az_winograd_pack_filter_x3_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t cin0, int32_t nk0,
                                    int32_t nk, int32_t cblocks, az_stream_t stream);
+/* The same fragment-ordered layout for az_conv2d_winograd_f16x2_f32: the three 2-byte pieces of an element are
+ * [uh | ul | uh / 2^11] of u' = U * w_scale (IEEE half), w_scale = az_f16x2_weight_scale(max |g|, 1).                    */
+int az_winograd_pack_filter_f16x2_f32(void* dst, const float* src, int32_t cout, int32_t cin, int32_t cin0, int32_t nk0,
+                                      int32_t nk, int32_t cblocks, float w_scale, az_stream_t stream);
 
 /* Same for F(4x4,3x3) (points 0, +-1, +-2, inf): [nk chunks of 4 cin][cblocks of 64 cout][36][64][4]; packed
  * channel position pc maps to input channel pc (pc < cin0) or cin0 + pc - c0s (pc >= c0s).        */

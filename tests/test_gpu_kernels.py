@@ -392,18 +392,19 @@ CONV_CASES = [
 def conv_tol(cin, ks, wino=False):
     """Direct: exact fp32 fmaf chains.  F(2x2,3x3) only adds/subtracts (3x).  F(4x4,3x3) multiplies by up to 8
     and its filter transform by 1/24: ~20x the rounding error of F(2x2) (stated in include/azula_amd.h)."""
-    return (3e-6 * math.sqrt(cin * ks * ks) + 1e-5) * {False: 1, True: 3, 4: 40, "x3": 1, "wx3": 3}[wino]
+    return (3e-6 * math.sqrt(cin * ks * ks) + 1e-5) * {False: 1, True: 3, 4: 40, "x3": 1, "wx3": 3, "h2": 1, "wh2": 3}[wino]
 
 
 WINO_NAME = {False: "az_conv2d_f32", True: "az_conv2d_winograd_f32", 4: "az_conv2d_winograd4_f32", "x3": "az_conv2d_x3_f32",
-             "wx3": "az_conv2d_winograd_x3_f32"}  # "wx3": Winograd with its frequency GEMMs on the bf16 pipe (csrc/wino_x3.hip)
+             "wx3": "az_conv2d_winograd_x3_f32",  # "wx3": Winograd with its frequency GEMMs on the bf16 pipe (csrc/wino_x3.hip)
+             "h2": "az_conv2d_f16x2_f32", "wh2": "az_conv2d_winograd_f16x2_f32"}  # the f16x2 forms of the two (2 half pieces, 3 products)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ks,stride", CONV_CASES)
 @pytest.mark.parametrize("splitk", [0, 3])
-@pytest.mark.parametrize("wino", [False, True, 4, "x3", "wx3"])
+@pytest.mark.parametrize("wino", [False, True, 4, "x3", "wx3", "h2", "wh2"])
 def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk, wino):
-    if wino in (True, 4, "wx3") and (ks != 3 or stride != 1):
+    if wino in (True, 4, "wx3", "wh2") and (ks != 3 or stride != 1):
         pytest.skip("Winograd is the stride-1 3x3 path")
     from azula_amd.engine import Act, Builder
 
@@ -429,7 +430,7 @@ def test_conv2d_basic(az, B, Cin, Cout, H, W, ks, stride, splitk, wino):
     assert (y.buf.reshape(B, y.H, y.W, y.cs)[..., Cout:] == 0).all()
 
 
-@pytest.mark.parametrize("wino", [False, True, "x3", "wx3"])
+@pytest.mark.parametrize("wino", [False, True, "x3", "wx3", "h2", "wh2"])
 def test_conv2d_output_beyond_the_infinity_cache(az, wino):
     """An output of 256 MiB (1 x 512 x 512 x 256 fp32): from this size on the plain epilogue stores with the non-temporal hint
     (conv_shared.h: stream_out -- the output cannot stay in the Infinity Cache for its consumer).  Same bound as every other
@@ -453,7 +454,7 @@ def test_conv2d_output_beyond_the_infinity_cache(az, wino):
     assert max_err(out, ref) < conv_tol(Cin, 3, wino), max_err(out, ref)
 
 
-@pytest.mark.parametrize("wino", [False, True, 4, "x3", "wx3"])
+@pytest.mark.parametrize("wino", [False, True, 4, "x3", "wx3", "h2", "wh2"])
 def test_conv2d_random_shapes(az, wino):
     """Seeded sweep over ragged shapes (odd sizes, channel counts off the 4 / 8 / 32 grids, batch 1-3, optional second
     source with nearest-x2 upsampling, SiLU / gate / residual) for the three 3x3 stride-1 algorithms."""
@@ -461,7 +462,7 @@ def test_conv2d_random_shapes(az, wino):
 
     from azula_amd.engine import Act, Builder
 
-    rnd = random.Random(1234 + {False: 0, True: 7, 4: 4, "x3": 3, "wx3": 7}[wino])
+    rnd = random.Random(1234 + {False: 0, True: 7, 4: 4, "x3": 3, "wx3": 7, "h2": 3, "wh2": 7}[wino])
     g = torch.Generator().manual_seed(99)
     for case in range(10):
         B = rnd.randint(1, 3)
@@ -500,7 +501,7 @@ def test_conv2d_random_shapes(az, wino):
         assert err < conv_tol(C0 + C1, 3, wino) * max(1.0, ref.abs().max().item()), (case, B, H, W, C0, C1, Cout, act, err)
 
 
-@pytest.mark.parametrize("wino", [False, True, "wx3"])
+@pytest.mark.parametrize("wino", [False, True, "wx3", "wh2"])
 @pytest.mark.parametrize("shift", [-2, -1, 1, 2])
 @pytest.mark.parametrize("Cin,H,W", [(32, 16, 16), (64, 12, 20), (20, 9, 7)])
 def test_conv2d_depth_tap_between_poisoned_neighbours(az, wino, shift, Cin, H, W):
@@ -536,7 +537,7 @@ def test_conv2d_depth_tap_between_poisoned_neighbours(az, wino, shift, Cin, H, W
     assert max_err(out, ref) < conv_tol(Cin, 3, wino), max_err(out, ref)
 
 
-@pytest.mark.parametrize("wino", [False, True, "wx3"])
+@pytest.mark.parametrize("wino", [False, True, "wx3", "wh2"])
 @pytest.mark.parametrize("Cin,Cout,ks", [(32, 64, 1), (20, 24, 3), (64, 256, 1)])
 def test_conv2d_swiglu_epilogue(az, wino, Cin, Cout, ks):
     """AzConvArgs.act = 4: y[c] = x[2c] * silu(x[2c+1]) applied to the convolution's output in its epilogue (half the
@@ -562,12 +563,12 @@ def test_conv2d_swiglu_epilogue(az, wino, Cin, Cout, ks):
     assert max_err(out, ref) < 2 * conv_tol(Cin, ks, wino) * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("wino", [False, True, "x3", "wx3"])
+@pytest.mark.parametrize("wino", [False, True, "x3", "wx3", "h2", "wh2"])
 @pytest.mark.parametrize("Cin,Cout,ks,splitk", [(32, 64, 1, 0), (20, 24, 3, 0), (64, 128, 3, 2)])
 def test_conv2d_silu_of_the_sum_with_the_residual(az, wino, Cin, Cout, ks, splitk):
     """AzConvArgs.act = 6: y = silu(conv + bias + res), in place on the residual operand -- the last depth tap of a Conv3d -> SiLU
     pair (nn/unet3d.py: no activation pass of its own)."""
-    if wino in (True, "wx3") and ks != 3:
+    if wino in (True, "wx3", "wh2") and ks != 3:
         pytest.skip("Winograd is the stride-1 3x3 path")
     from azula_amd.engine import Act, Builder
 
@@ -591,10 +592,10 @@ def test_conv2d_silu_of_the_sum_with_the_residual(az, wino, Cin, Cout, ks, split
     bld.finish()
     bld.tape.run()
     out = from_nhwc(y.buf.reshape(B, H, W, y.cs), Cout)
-    assert max_err(out, ref) < 2 * conv_tol(Cin, ks, bool(wino) and wino != "x3") * max(1.0, ref.abs().max().item())
+    assert max_err(out, ref) < 2 * conv_tol(Cin, ks, bool(wino) and wino not in ("x3", "h2")) * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("mode", [True, "wx3"])
+@pytest.mark.parametrize("mode", [True, "wx3", "wh2"])
 def test_winograd_stream_fuzz(az, mode):
     """The hand-scheduled K loop (wino_kloop.inc) over 40 seeded cases that move every event of the stream around: 1 .. 24
     eight-channel stages (first / steady / second-to-last / last iteration bodies), two sources whose switch falls on any
@@ -767,7 +768,7 @@ def test_winograd_input_affine(az, asm, in_act, monkeypatch):
     assert az.lib().az_conv2d_f32(C.byref(a), az.stream_ptr()) == -4  # AZ_E_UNSUPPORTED
 
 
-@pytest.mark.parametrize("wino", [False, True, 4, "x3", "wx3"])
+@pytest.mark.parametrize("wino", [False, True, 4, "x3", "wx3", "h2", "wh2"])
 def test_conv2d_concat_upsample_narrow_gate_res(az, wino):
     """cat((y, upsample(x)[narrowed])) -> conv -> x0 + c * silu-free epilogue, as azula/nn/unet.py:253-257,93."""
     from azula_amd.engine import Act, Builder
@@ -793,7 +794,7 @@ def test_conv2d_concat_upsample_narrow_gate_res(az, wino):
     assert max_err(from_nhwc(out.buf.reshape(B, H, W, 12), Cout), ref) < conv_tol(Cy + Cx, 3, wino)
 
 
-@pytest.mark.parametrize("wino", [False, True, 4, "x3", "wx3"])
+@pytest.mark.parametrize("wino", [False, True, 4, "x3", "wx3", "h2", "wh2"])
 def test_conv2d_nchw_output_and_res_up(az, wino):
     from azula_amd.engine import Act, Builder
 
@@ -866,7 +867,7 @@ def test_conv2d_x3_accuracy(az, monkeypatch):
     b = torch.randn(Cout, generator=g)
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     errs = {}
-    for mode in (False, True, "x3", "wx3"):
+    for mode in (False, True, "x3", "wx3", "h2", "wh2"):
         bld = Builder(torch.device("cuda"))
         xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
         y = bld.conv(xa, bld.pack_conv(dev(w), dev(b)), Cout, winograd=mode)
@@ -882,6 +883,53 @@ def test_conv2d_x3_accuracy(az, monkeypatch):
     # the Winograd form with its frequency GEMMs as exact 3 x bf16 splits: the same transforms as the fp32 Winograd stream, so its
     # error is that stream's (the transforms' fp32 adds dominate both), not worse by more than the rounding of the accumulation order
     assert errs["wx3"][1] <= 1.25 * errs[True][1] and errs["wx3"][0] <= 1.5 * errs[True][0], errs
+    # f16x2 (two half pieces per operand, three products, one fp32 accumulator): each product carries ~2^-22 of relative error, far
+    # below what the fp32 accumulation of 2304 terms adds to every form -- at the level of the fp32 MFMA kernel / the fp32 Winograd stream
+    assert errs["h2"][1] <= 1.25 * errs[False][1] and errs["h2"][0] <= 1.5 * errs[False][0], errs
+    assert errs["wh2"][1] <= 1.25 * errs[True][1] and errs["wh2"][0] <= 1.5 * errs[True][0], errs
+
+
+@pytest.mark.parametrize("mode", ["h2", "wh2"])
+def test_f16x2_domain(az, mode):
+    """The STATED domain of the f16x2 split (include/azula_amd.h, csrc/common.h: az_split2h): activations of any magnitude below
+    65520 / AZ_F16X2_IN_SCALE ~ 1.0e6 (4-pixel sums of them in the Winograd form).  Inside it the relative error against fp64 is
+    at fp32 level for tensors of scale 1e-3 ... 1e4 (the weights are rescaled at pack time whatever their size: 1e-6 ... 1e3 here);
+    tensors of scale 1e-6 keep an ABSOLUTE operand error of 2^-36 * 16 = 2.3e-10 (the half pieces are subnormal, which the matrix
+    pipe honours: no flush to zero); beyond the domain the outputs that depend on the offending activation are NaN, never finite garbage."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(6)
+    B, Cin, Cout, H, W = 1, 64, 64, 16, 16
+
+    def run(x, w):
+        bld = Builder(torch.device("cuda"))
+        xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
+        y = bld.conv(xa, bld.pack_conv(dev(w), None), Cout, winograd=mode)
+        assert bld.tape.ops[-1][2] == WINO_NAME[mode]
+        bld.finish()
+        bld.tape.run()
+        return from_nhwc(y.buf.reshape(B, H, W, Cout), Cout).cpu()
+
+    w0 = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    for xs, ws, rel in ((1.0, 1.0, 3e-6), (1e-3, 1e-6, 3e-6), (1e4, 1e3, 3e-6), (30.0, 1.0, 3e-6), (1e-6, 1.0, 3e-4)):
+        x = torch.randn(B, Cin, H, W, generator=g) * xs
+        x[:, ::5] *= 1e-3  # (channels three decades below the rest: their pieces sit further down the half range)
+        w = w0 * ws
+        ref = F.conv2d(x.double(), w.double(), None, padding=1)
+        err = (run(x, w).double() - ref).abs().max().item()
+        print(mode, xs, ws, "relative error", err / ref.abs().max().item())
+        assert err < rel * ref.abs().max().item(), (xs, ws, err, ref.abs().max().item())
+    # exact zeros stay exact zeros (a zero-initialised layer, zero padding)
+    assert run(torch.randn(B, Cin, H, W, generator=g), torch.zeros_like(w0)).abs().max().item() == 0.0
+    # outside the domain: one activation of 4e6 -> every output its 3x3 window reaches is NaN; the rest of the map is untouched
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x[0, 3, 8, 8] = 4.0e6
+    out = run(x, w0)
+    ref = F.conv2d(x, w0, None, padding=1)
+    assert not torch.isfinite(out[0, :, 7:10, 7:10]).any()
+    far = torch.ones(B, Cout, H, W, dtype=torch.bool)
+    far[:, :, 5:12, 5:12] = False  # (the Winograd tiles touching that pixel turn NaN as a whole)
+    assert torch.isfinite(out[far]).all() and max_err(out[far], ref[far]) < conv_tol(Cin, 3, True)
 
 
 @pytest.mark.parametrize("mode", ["x3", "wx3"])
@@ -922,7 +970,7 @@ def test_x3_split_domain(az, mode):
     assert torch.isfinite(out[far]).all() and max_err(out[far], ref[far]) < conv_tol(Cin, 3, True)
 
 
-@pytest.mark.parametrize("wino", [False, True, "x3", "wx3"])
+@pytest.mark.parametrize("wino", [False, True, "x3", "wx3", "h2", "wh2"])
 def test_conv2d_is_deterministic_across_launches(az, wino):
     """Race screen for the LDS-exchange epilogues and the split-K combine: 12 launches of the same convolution (gate,
     residual, SiLU; one with split-K) must give bit-identical outputs."""
@@ -998,7 +1046,7 @@ def test_conv2d_half_operands(az, B, Cin, Cout, H, W, ks, stride, half):
     assert (y.buf.reshape(B, y.H, y.W, y.cs)[..., Cout:] == 0).all()
 
 
-@pytest.mark.parametrize("wino", [False, True, "wx3"])
+@pytest.mark.parametrize("wino", [False, True, "wx3", "wh2"])
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
 @pytest.mark.parametrize("gated", [False, True])
 @pytest.mark.parametrize("res_kind", ["none", "same", "up", "nobias"])
@@ -1101,7 +1149,7 @@ def test_groupnorm_statistics_from_the_splitk_combine(az, case, monkeypatch):
     assert e_ab < 2.5e-5
 
 
-@pytest.mark.parametrize("mode", [True, "wx3"])
+@pytest.mark.parametrize("mode", [True, "wx3", "wh2"])
 @pytest.mark.parametrize("form", ["plain", "gate_res", "silu", "concat", "mixed"])
 def test_groupnorm_statistics_from_the_conv_epilogue(az, form, mode, monkeypatch):
     """AzConvArgs.gn_quads: the Winograd epilogue leaves (n, mean, M2) per (image, 64-tile block, channel quad) and the
@@ -1199,7 +1247,8 @@ def test_calibration_kernels(az):
 @pytest.mark.parametrize("shape", [(2, 512, 768, 768), (1, 300, 64, 260), (3, 130, 128, 388), (1, 4096, 3072, 768), (1, 1000, 256, 1024),
                                    (64, 256, 128, 2304), (16, 1024, 3072, 768)])
 @pytest.mark.parametrize("act,res", [(0, False), (1, True)])
-def test_x3_gemm_big_tile(az, monkeypatch, shape, act, res):
+@pytest.mark.parametrize("mode", ["x3", "h2"])  # ("h2": the f16x2 form of the same kernels -- two half pieces, three products)
+def test_x3_gemm_big_tile(az, monkeypatch, shape, act, res, mode):
     """conv_gemm_x3_big_kernel (256 x 256 tile, 8 waves, two LDS stages) against the 128 x 128 bf16x3 kernel and fp64: same six
     partial products per K step of 16 channels, so the two agree to a few ulps; ragged token / channel tiles, split-K, residual."""
     from azula_amd.engine import Act, Builder
@@ -1225,7 +1274,7 @@ def test_x3_gemm_big_tile(az, monkeypatch, shape, act, res):
         bld = Builder(torch.device("cuda"))
         xin = Act(to_nhwc(dev(x)).reshape(-1), B, T, 1, Cin, Cin, True)  # (kept alive: the tape holds raw addresses)
         rin = Act(to_nhwc(dev(r)).reshape(-1), B, T, 1, Cout, (Cout + 3) // 4 * 4, True) if res else None
-        y = bld.conv(xin, bld.pack_conv(dev(w), dev(b)), Cout, act=act, res=rin, winograd="x3")
+        y = bld.conv(xin, bld.pack_conv(dev(w), dev(b)), Cout, act=act, res=rin, winograd=mode)
         bld.finish()
         bld.tape.run()
         outs[big] = from_nhwc(y.buf.reshape(B, T, 1, -1), Cout).double().cpu()
@@ -1237,7 +1286,8 @@ def test_x3_gemm_big_tile(az, monkeypatch, shape, act, res):
 
 
 @pytest.mark.parametrize("shape", [(4, 64, 64, 256, 256, 256), (1, 96, 100, 64, 128, 320), (2, 48, 48, 512, 256, 256)])
-def test_x3_gemm_big_tile_two_sources(az, monkeypatch, shape):
+@pytest.mark.parametrize("mode", ["x3", "h2"])
+def test_x3_gemm_big_tile_two_sources(az, monkeypatch, shape, mode):
     """The 256 x 256 bf16x3 kernel on a channel concatenation read in place (the 1x1 skip convolutions of ADM's decoder,
     plugins/adm/_src/unet.py:215,631): K steps walk source 0, then source 1; against the 128 x 128 kernel and fp64."""
     from azula_amd.engine import Act, Builder
@@ -1255,7 +1305,7 @@ def test_x3_gemm_big_tile_two_sources(az, monkeypatch, shape):
         bld = Builder(torch.device("cuda"))
         a0 = Act(to_nhwc(dev(x0)).reshape(-1), B, H, W, C0, C0, True)
         a1 = Act(to_nhwc(dev(x1)).reshape(-1), B, H, W, C1, C1, True)
-        y = bld.conv(a0, bld.pack_conv(dev(w), dev(b), cin0=C0), Cout, src1=a1, winograd="x3")
+        y = bld.conv(a0, bld.pack_conv(dev(w), dev(b), cin0=C0), Cout, src1=a1, winograd=mode)
         bld.finish()
         bld.tape.run()
         outs[big] = from_nhwc(y.buf.reshape(B, H, W, -1), Cout).double().cpu()
@@ -1301,7 +1351,8 @@ def test_half_gemm_big_tile(az, monkeypatch, shape, half):
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ks,stride", [(2, 64, 256, 40, 36, 3, 2), (1, 32, 320, 33, 47, 3, 1), (3, 48, 256, 17, 19, 5, 2),
                                                       (2, 128, 256, 64, 64, 3, 2), (1, 64, 200, 30, 30, 1, 2), (2, 32, 256, 21, 21, 7, 3)])
-def test_x3_big_tile_with_taps(az, monkeypatch, B, Cin, Cout, H, W, ks, stride):
+@pytest.mark.parametrize("mode", ["x3", "h2"])
+def test_x3_big_tile_with_taps(az, monkeypatch, B, Cin, Cout, H, W, ks, stride, mode):
     """conv_gemm_x3_big_kernel<4, TAPS>: k x k filters, strides, zero padding, tiles that span image borders and several images --
     against the 128 x 128 bf16x3 kernel (same products; the K walk is tap-major in both) and an fp64 convolution."""
     from azula_amd.engine import Act, Builder
@@ -1317,7 +1368,7 @@ def test_x3_big_tile_with_taps(az, monkeypatch, B, Cin, Cout, H, W, ks, stride):
         monkeypatch.setenv("AZ_DEBUG_AB", "1")  # (A/B overrides are honoured only under the debug switch)
         bld = Builder(torch.device("cuda"))
         xin = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
-        y = bld.conv(xin, bld.pack_conv(dev(w), dev(b)), Cout, stride=stride, act=1, winograd="x3")
+        y = bld.conv(xin, bld.pack_conv(dev(w), dev(b)), Cout, stride=stride, act=1, winograd=mode)
         bld.finish()
         bld.tape.run()
         outs[big] = from_nhwc(y.buf.reshape(B, y.H, y.W, -1), Cout).double().cpu()

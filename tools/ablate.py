@@ -22,14 +22,14 @@ VARIANTS = {
     # no-load variants FREEZE operands (constant data toggles nothing in the matrix pipe): they overstate under the power cap
     "wx3_nogather": [("wino_x3.hip", "      gq[m] = buf_ld4(r, off, (unsigned)(kc * XK * 4));",
                       "      asm volatile(\"\" : \"+v\"(gq[m].x), \"+v\"(gq[m].y), \"+v\"(gq[m].z), \"+v\"(gq[m].w) : \"v\"(off));")],
-    "wx3_nou": [("wino_x3.hip", "    for (int ch = 0; ch < 2; ++ch) ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
+    "wx3_nou": [("wino_x3.hip", "    for (int ch = 0; ch < 2; ++ch) ua[ch][pl] = __builtin_bit_cast(uint4, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
                  "    for (int ch = 0; ch < 2; ++ch) asm volatile(\"\" : \"+v\"(ua[ch][pl]) : \"s\"(soff));")],
-    "wx3_nomfma": [("wino_x3.hip", "    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[ch][PA[t]], __builtin_bit_cast(bf16x8, bw), c, 0, 0, 0);",
-                    "    asm volatile(\"\" : \"+v\"(c) : \"v\"(bw.x), \"v\"(bw.y), \"v\"(bw.z), \"v\"(bw.w));")],
+    "wx3_nomfma": [("wino_x3.hip", "    else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua[ch][PA[t]]), __builtin_bit_cast(bf16x8, bw), c, 0, 0, 0);",
+                    "    else asm volatile(\"\" : \"+v\"(c) : \"v\"(bw.x), \"v\"(bw.y), \"v\"(bw.z), \"v\"(bw.w));")],
     # energy probes on RANDOM data (the kernel sits at the 1400 W cap: time = energy / cap, so a variant's time change is the
     # energy share of what it removes, as long as the data stay random)
-    "wx3_halfmfma": [("wino_x3.hip", "    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[ch][PA[t]], __builtin_bit_cast(bf16x8, bw), c, 0, 0, 0);",
-                      "    if (t < 3) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[ch][PA[t]], __builtin_bit_cast(bf16x8, bw), c, 0, 0, 0);")],
+    "wx3_halfmfma": [("wino_x3.hip", "    else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua[ch][PA[t]]), __builtin_bit_cast(bf16x8, bw), c, 0, 0, 0);",
+                      "    else if (t < 3) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua[ch][PA[t]]), __builtin_bit_cast(bf16x8, bw), c, 0, 0, 0);")],
     "wx3_nosplit": [("wino_x3.hip", "      xf[th][i] = x - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u);",
                      "      xf[th][i] = x;")],
     "wx3_halfstore": [("wino_x3.hip", "    *reinterpret_cast<f32x2*>(dst + X_FREQ) = hs == 0 ? u1 + u2 : u1 - u3;",
@@ -58,21 +58,21 @@ VARIANTS["wx3_noloads"] = VARIANTS["wx3_nogather"] + VARIANTS["wx3_nou"]
 # ---- wino_x3.hip: per-wave phase timeline (s_memtime sums per workgroup, waves 0 and 4 of the first 512 workgroups):
 #      sections of a phase: [0] slots 0-11, [1] slots 12-23, [2] last filter loads, [3] barrier + next fragment reads
 VARIANTS["wx3_tl"] = [
-    ("wino_x3.hip", "namespace {\n\ntypedef __bf16 bf16x8",
+    ("wino_x3.hip", "namespace {\n\ntypedef __bf16 bf16x8 __attribute__",
      "__device__ unsigned az_wx3_tl[512 * 2 * 12];\n"
      "extern \"C\" int az_debug_wx3_timeline(unsigned* host, int n_words) {\n"
      "  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(az_wx3_tl), (size_t)n_words * 4, 0, hipMemcpyDeviceToHost);\n}\n"
-     "namespace {\n\ntypedef __bf16 bf16x8"),
-    ("wino_x3.hip", "  bf16x8 ua[2][3];  // [cout half][piece]\n",
-     "  bf16x8 ua[2][3];\n  unsigned tlacc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};\n  const unsigned long long tl_entry = __builtin_readcyclecounter();\n"),
+     "namespace {\n\ntypedef __bf16 bf16x8 __attribute__"),
+    ("wino_x3.hip", "  uint4 ua[2][3];  // [cout half][piece]\n",
+     "  uint4 ua[2][3];\n  unsigned tlacc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};\n  const unsigned long long tl_entry = __builtin_readcyclecounter();\n"),
     ("wino_x3.hip", "    constexpr int ob = 1 - hs;  // the buffer (and half of the frequencies) this phase produces\n",
-     "    constexpr int ob = 1 - hs;\n    const unsigned long long tl0 = __builtin_readcyclecounter();\n    unsigned long long tl1 = tl0;\n"),
+     "    constexpr int ob = 1 - hs;\n    const unsigned long long tl0 = __builtin_readcyclecounter();\n    unsigned long long tl1 = tl0, tl2 = tl0;\n"),
     ("wino_x3.hip", "      mf(hs, 12); gl(ktn, 2); gl(ktn, 3); remainder(0, 2, 4); XS_FENCE;\n",
      "      tl1 = __builtin_readcyclecounter();\n      mf(hs, 12); gl(ktn, 2); gl(ktn, 3); remainder(0, 2, 4); XS_FENCE;\n"),
     ("wino_x3.hip", "      mf(hs, 12); patch_rows(ktn, 0, 2); XS_FENCE;\n",
      "      tl1 = __builtin_readcyclecounter();\n      mf(hs, 12); patch_rows(ktn, 0, 2); XS_FENCE;\n"),
-    ("wino_x3.hip", "    load_u(ktu, ob, 0);\n    // the NEXT phase's fragments",
-     "    const unsigned long long tl2 = __builtin_readcyclecounter();\n    load_u(ktu, ob, 0);\n    const unsigned long long tl3 = __builtin_readcyclecounter();\n    // the NEXT phase's fragments"),
+    ("wino_x3.hip", "    load_u(ktu, ob, 0);\n    }\n    // the NEXT phase's fragments",
+     "    tl2 = __builtin_readcyclecounter();\n    load_u(ktu, ob, 0);\n    }\n    const unsigned long long tl3 = __builtin_readcyclecounter();\n    // the NEXT phase's fragments"),
     ("wino_x3.hip", "    __syncthreads();\n    frag_read(ob, 0); frag_read(ob, 1);\n    XS_FENCE;\n  };\n",
      "    __syncthreads();\n    frag_read(ob, 0); frag_read(ob, 1);\n    XS_FENCE;\n"
      "    const unsigned long long tl4 = __builtin_readcyclecounter();\n"
@@ -93,8 +93,8 @@ VARIANTS["wx3_tl"] = [
 VARIANTS["igemm_noload"] = [("conv.hip", "      load_tile();  // global loads in flight under the MFMAs below\n", "")]
 VARIANTS["igemm_nostore"] = [("conv.hip", "    if (more) store_tile(buf ^ 1);\n    __syncthreads();\n  }\n  }\n", "  }\n  }\n")]
 VARIANTS["x3_nosplit"] = [  # what would activations that arrive pre-split cost the 128 x 128 bf16x3 kernel?
-    ("conv.hip", "      for (int j = 0; j < 4; ++j) split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);\n#pragma unroll\n      for (int pl = 0; pl < 3; ++pl)",
-     "      for (int j = 0; j < 4; ++j) q[0][j] = q[1][j] = q[2][j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x[2 * j + 1]), __builtin_bit_cast(unsigned, x[2 * j]), 0x07060302u);\n#pragma unroll\n      for (int pl = 0; pl < 3; ++pl)"),
+    ("conv.hip", "        else split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);\n      }\n#pragma unroll\n      for (int pl = 0; pl < (H2 ? 2 : 3); ++pl)\n        *reinterpret_cast<uint4*>(xsm",
+     "        else q[0][j] = q[1][j] = q[2][j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x[2 * j + 1]), __builtin_bit_cast(unsigned, x[2 * j]), 0x07060302u);\n      }\n#pragma unroll\n      for (int pl = 0; pl < (H2 ? 2 : 3); ++pl)\n        *reinterpret_cast<uint4*>(xsm"),
 ]
 # ---- conv_gemm_half_big_kernel (half-precision operands, 256 x 256 tile; typed launches): where does a K step's time go?  (timing only;
 #      profiles/r06_half_gemm.txt (5) was measured with these on the two-register-set form that was then dropped)
@@ -110,8 +110,10 @@ VARIANTS["hbig_noepi"] = [("conv.hip", "  if (a.dst_dtype) gemm_big_epilogue<4, 
                            "  if (acc[0][0][0] == 12345.678f) gemm_big_epilogue<4>(p, acc, m0, n0, wc, wp, lane, tid, gsmf);\n")]
 VARIANTS["hbig_nosched"] = [("conv.hip", "    for (int k = 0; k < 32; ++k) {\n      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);\n      if ((k & 7) == 1 && k < 24) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // the next k-step's fragments",
                              "    for (int k = 0; k < 0; ++k) {\n      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);\n      if ((k & 7) == 1 && k < 24) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // the next k-step's fragments")]
-VARIANTS["x3big_nosched"] = [("conv.hip", "    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NCT + 2), 0);  // DS reads\n", "    if (false)\n    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NCT + 2), 0);\n"),
-                             ("conv.hip", "    for (int k = 0; k < NM; ++k) {\n      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);", "    for (int k = 0; k < 0; ++k) {\n      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);")]
+VARIANTS["x3big_nosched"] = [("conv.hip", "    if constexpr (!H2) {\n      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NCT + 2), 0);  // DS reads\n", "    if constexpr (false) {\n      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NCT + 2), 0);\n")]
+# the f16x2 form of that kernel with the compiler's own issue order
+VARIANTS["h2big_nosched"] = [("conv.hip", "    if constexpr (!H2) {\n      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NCT + 2), 0);  // DS reads\n", "    if constexpr (!H2 && NCT > 0) {\n      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NCT + 2), 0);\n"),
+                             ("conv.hip", "    } else {\n      // half as many matrix instructions for the same staging:", "    } else if constexpr (false) {\n      // half as many matrix instructions for the same staging:")]
 VARIANTS["x3_no192"] = [("conv.hip", "  const bool ok192 = ct != nullptr && kstep == GBK && a->act <= 3 && !x3_big_taps(a);", "  const bool ok192 = false;")]
 VARIANTS["ax_oneprod"] = [
     ("attention.hip", "        for (int t = 0; t < 6; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qf[PB[t]][ks], sacc, 0, 0, 0);",
@@ -148,8 +150,8 @@ _G_CONS = [
 ]
 # half of the filter-fragment loads (cout half 1 reuses cout half 0's fragments: operands stay random, unlike wx3_nou): its time
 # change x 2 = what the filter stream costs the kernel
-VARIANTS["wx3_halfu"] = [("wino_x3.hip", "    for (int ch = 0; ch < 2; ++ch) ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
-                          "    for (int ch = 0; ch < 1; ++ch) ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));\n    ua[1][pl] = ua[0][pl];")]
+VARIANTS["wx3_halfu"] = [("wino_x3.hip", "    for (int ch = 0; ch < 2; ++ch) ua[ch][pl] = __builtin_bit_cast(uint4, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
+                          "    for (int ch = 0; ch < 1; ++ch) ua[ch][pl] = __builtin_bit_cast(uint4, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));\n    ua[1][pl] = ua[0][pl];")]
 # ---- gate for F(4x4,3x3) on the split operands (tools/f4_gate.py): timing only, WRONG results.  Launched on a map of
 #      0.75 x 0.75 the size, the shipped F(2x2) stream executes exactly the (tile x frequency) work of F(4x4) on the full map: 36 / 16
 #      frequencies x 1 / 4 of the tiles = 0.5625 of the matrix instructions, V values (patch reads, transforms, V stores, fragment reads,
@@ -164,10 +166,10 @@ VARIANTS["wx3_f4proxy"] = [
      "    rv[c] = (d0 - d2) + z2;\n    rv[4 + c] = (d1 + d2) + z2;\n    rv[8 + c] = (d2 - d1) + z2;\n    rv[12 + c] = (d1 - d3) + z2;\n"),
     ("wino_x3.hip", "    *reinterpret_cast<f32x2*>(dst) = hs == 0 ? u0 - u2 : u2 - u1;\n    *reinterpret_cast<f32x2*>(dst + X_FREQ) = hs == 0 ? u1 + u2 : u1 - u3;\n",
      "    *reinterpret_cast<f32x2*>(dst) = (hs == 0 ? u0 - u2 : u2 - u1) + z2;\n    *reinterpret_cast<f32x2*>(dst + X_FREQ) = (hs == 0 ? u1 + u2 : u1 - u3) + z2;\n"),
-    ("wino_x3.hip", "    for (int ch = 0; ch < 2; ++ch) ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
+    ("wino_x3.hip", "    for (int ch = 0; ch < 2; ++ch) ua[ch][pl] = __builtin_bit_cast(uint4, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
      "    for (int ch = 0; ch < 2; ++ch) {\n      uint4 r0 = __builtin_bit_cast(uint4, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));\n"
      "      const uint4 r1 = __builtin_bit_cast(uint4, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff + 49152u));\n"
-     "      r0.x |= r1.x & zu; r0.y |= r1.y & zu; r0.z |= r1.z & zu; r0.w |= r1.w & zu;\n      ua[ch][pl] = __builtin_bit_cast(bf16x8, r0);\n    }"),
+     "      r0.x |= r1.x & zu; r0.y |= r1.y & zu; r0.z |= r1.z & zu; r0.w |= r1.w & zu;\n      ua[ch][pl] = r0;\n    }"),
 ]
 # the same with only one of the two surcharges (which one costs what)
 VARIANTS["wx3_f4proxy_adds"] = VARIANTS["wx3_f4proxy"][:3]
@@ -192,8 +194,8 @@ VARIANTS["tr_grid2k"] = [("transition.hip", "  const int64_t gcap = 16384 / gy <
 VARIANTS["epi_plainst"] = [("conv_shared.h", "        if (stream_out) az_st_stream(d, f);\n        else *reinterpret_cast<float4*>(d) = f;", "        *reinterpret_cast<float4*>(d) = f;")]
 VARIANTS["epi_ntall"] = [("conv_shared.h", "        if (stream_out) az_st_stream(d, f);\n        else *reinterpret_cast<float4*>(d) = f;", "        az_st_stream(d, f);")]
 # the x3 Winograd kernel's filter stream with the non-temporal hint (aux = 2): the small-map layers read every filter byte once or twice
-VARIANTS["wx3_unt"] = [("wino_x3.hip", "ua[ch][pl] = __builtin_bit_cast(bf16x8, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
-                        "ua[ch][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(u_lane + (unsigned)((ch * 3 + pl) * 1024)), (int)soff, 2));")]
+VARIANTS["wx3_unt"] = [("wino_x3.hip", "ua[ch][pl] = __builtin_bit_cast(uint4, buf_ld4(rw, u_lane + (unsigned)((ch * 3 + pl) * 1024), soff));",
+                        "ua[ch][pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(u_lane + (unsigned)((ch * 3 + pl) * 1024)), (int)soff, 2));")]
 # further candidates for the hint (one line each): the row norms' output, the stem's output, the epilogue's residual reads
 VARIANTS["rn_ntst"] = [("norm.hip", "          *reinterpret_cast<float4*>(yr + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);", "          az_st_stream(yr + c, make_float4(o4[0], o4[1], o4[2], o4[3]));")]
 VARIANTS["stem_ntst"] = [("conv.hip", "        *reinterpret_cast<float4*>(a.dst + (((int64_t)b * H + oh) * W + ow) * a.cout_s + q * 4) = o;", "        az_st_stream(a.dst + (((int64_t)b * H + oh) * W + ow) * a.cout_s + q * 4, o);")]
