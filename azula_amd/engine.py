@@ -157,7 +157,11 @@ WINOGRAD = os.environ.get("AZ_WINOGRAD", "1")
 # on a STATED domain: activations below ~1e6 in magnitude (beyond it NaN, never a wrong finite value).
 FP32_MFMA = os.environ.get("AZ_FP32_MFMA", "bf16x3")
 assert FP32_MFMA in ("native", "bf16x3", "f16x2"), FP32_MFMA
-PIECES = FP32_MFMA in ("bf16x3", "f16x2")  # fp32 operands as 2-byte pieces on the bf16 / f16 pipe
+
+
+def pieces() -> bool:
+    r"""fp32 operands as 2-byte pieces on the bf16 / f16 pipe (read per plan: bench.py flips FP32_MFMA between plans)."""
+    return FP32_MFMA in ("bf16x3", "f16x2")
 ATTN_X3 = os.environ.get("AZ_ATTN_X3", "1") != "0"  # bf16x3 mode: attention contractions on the bf16 pipe too (az_attention_x3_f32)
 # The stride-1 3 x 3 layers in bf16x3 mode: "1" (default since round 5) = the Winograd kernel with its 16 frequency GEMMs on the bf16 pipe
 # as exact 3 x bf16 splits too (az_conv2d_winograd_x3_f32, csrc/wino_x3.hip: same transforms, same epilogue, 1.19 - 1.28 x the fp32
@@ -495,7 +499,7 @@ class Builder:
         # (221 vs 181 TF/s algorithmic at 4 x 256^2, 256 -> 256).
         use_x3 = self.half is None and (
             winograd in ("x3", "h2")
-            or (winograd is None and PIECES and not head and not use_wino and not use_f4
+            or (winograd is None and pieces() and not head and not use_wino and not use_f4
                 and cin_s >= X3_MIN_CHANNELS and a.cout_s >= X3_MIN_CHANNELS)
         )
         # (winograd = "x3" / "wx3": the bf16x3 kernels, "h2" / "wh2": the f16x2 ones, whatever the mode -- kernel tests)
@@ -504,7 +508,7 @@ class Builder:
             a.weight = packed.winograd4().data_ptr()
             a.splitk = lib.az_conv2d_winograd4_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
             name = "az_conv2d_winograd4_f32"
-        elif use_wino and wout >= 3 and (winograd in ("wx3", "wh2") or (winograd is None and WINO_X3 and PIECES)):
+        elif use_wino and wout >= 3 and (winograd in ("wx3", "wh2") or (winograd is None and WINO_X3 and pieces())):
             # the frequency GEMMs on the bf16 pipe as exact 3 x bf16 splits (wino_x3.hip); same descriptor, 16-channel steps
             # (f16x2: the same kernel with two half pieces per operand and three products)
             if h2:
@@ -886,7 +890,7 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
         self.tape.keep.append(m8)
     a._flops = 4 * qkv.B * heads * L * L * dim
     name = "az_attention_f32"
-    if self.half is None and PIECES and ATTN_X3 and dim in (16, 32, 64, 80):
+    if self.half is None and pieces() and ATTN_X3 and dim in (16, 32, 64, 80):
         # the two contractions as 3 x bf16 pieces / 6 partial products: fp32 accuracy, 0.375 x the pipe time (64 x 12 heads x 256
         # tokens x 64: 140 -> 111 us; head_dim 128 needs one wave per SIMD there and measured slower, 458 vs 516 us: fp32 kernel)
         name = "az_attention_x3_f32"

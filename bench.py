@@ -29,6 +29,11 @@ PEAK_BF16_TFLOPS = 2516.8  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 P
 # az_conv2d_x3_f32 ("bf16x3"): six v_mfma_f32_32x32x16_bf16 partial products per fp32 product, so with the bf16 pipe 100 % busy it
 # delivers PEAK_BF16 / 6 algorithmic TFLOP/s: the peak its `frac` is taken against (frac == executed bf16 MFMA FLOP/s / bf16 peak)
 X3_PRODUCTS = 6
+# "f16x2" (az_conv2d_f16x2_f32 / az_conv2d_winograd_f16x2_f32): three v_mfma_f32_32x32x16_f16 partial products per fp32 product (the f16 pipe
+# has the bf16 pipe's dense rate): with the pipe 100 % busy PEAK / 3 algorithmic TFLOP/s
+PIECE_PRODUCTS = {"az_conv2d_x3_f32": 6, "az_attention_x3_f32": 6, "az_conv2d_winograd_x3_f32": 6,
+                  "az_conv2d_f16x2_f32": 3, "az_conv2d_winograd_f16x2_f32": 3}
+PIECE_CONV = ("az_conv2d_x3_f32", "az_conv2d_winograd_x3_f32", "az_conv2d_f16x2_f32", "az_conv2d_winograd_f16x2_f32")
 PEAK_HBM_GBS = 8000.0  # HBM3E spec (6.3 TB/s measured achievable)
 # F(2x2,3x3) Winograd executes 4 multiplies per output where the direct form (the ALGORITHMIC count of SURVEY 8d,
 # 2*pixels*Cout*Cin*9) has 9: with the fp32 MFMA pipe 100 % busy it delivers 2.25 x 157.3 algorithmic TFLOP/s.  That is
@@ -129,7 +134,7 @@ def build_denoiser(cfg, device):
 
 
 CONV_OPS = ("az_conv2d_f32", "az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32", "az_conv2d_winograd4_f32", "az_conv2d_bf16_f32",
-            "az_conv2d_f16_f32", "az_conv2d_x3_f32")
+            "az_conv2d_f16_f32", "az_conv2d_x3_f32", "az_conv2d_f16x2_f32", "az_conv2d_winograd_f16x2_f32")
 ATTN_OPS = ("az_attention_f32", "az_attention_x3_f32", "az_attention_bf16_f32", "az_attention_f16_f32")
 
 
@@ -219,6 +224,7 @@ KERNEL_OF = {  # C-ABI entry point -> the __global__ kernel it launches (names a
     "az_conv2d_winograd_f32": "conv_winograd_kernel", "az_conv2d_f32": "conv_igemm_kernel", "az_attention_f32": "attention_kernel", "az_attention_x3_f32": "attention_x3_kernel",
     "az_conv2d_stem_f32": "conv_stem_kernel", "az_conv2d_bf16_f32": "conv_igemm_half_kernel", "az_conv2d_f16_f32": "conv_igemm_half_kernel", "az_conv2d_x3_f32": "conv_gemm_x3_big_kernel / conv_igemm_x3_kernel",  # (256 x 256 tiles where they fill rounds / 128 x 128 tiles)
     "az_conv2d_winograd4_f32": "conv_winograd4_kernel", "az_conv2d_winograd_x3_f32": "conv_winograd_x3_kernel",
+    "az_conv2d_f16x2_f32": "conv_gemm_x3_big_kernel / conv_igemm_x3_kernel", "az_conv2d_winograd_f16x2_f32": "conv_winograd_x3_kernel",  # (the H2 = true instantiations)
 }
 
 
@@ -520,7 +526,7 @@ def main() -> None:
     ap.add_argument("--denoise-steps", type=int, default=0, help="override the config's sampler steps (checks only)")
     ap.add_argument("--half", choices=["bf16", "f16"], default=None,
                     help="cast the backbone to half precision (mixed-precision mode; NOT the headline fp32 number)")
-    ap.add_argument("--fp32-mfma", choices=["native", "bf16x3"], default=None,
+    ap.add_argument("--fp32-mfma", choices=["native", "bf16x3", "f16x2"], default=None,
                     help="how the DIRECT-kernel fp32 convs / GEMMs use the matrix pipe (default: env AZ_FP32_MFMA or bf16x3 = exact "
                          "3-piece bf16 split, 6 partial products, fp32 accumulate; native = v_mfma_f32_32x32x2_f32 everywhere)")
     ap.add_argument("--no-native-line", action="store_true", help="skip the extra native-fp32-MFMA sampling reported beside a bf16x3 run")
@@ -566,7 +572,12 @@ def main() -> None:
         cfg["name"] += f" [backbone cast to {args.half}: MFMA operands {args.half}, fp32 accumulate -- not a headline number]"
     from azula_amd import engine as _engine
 
-    if _engine.FP32_MFMA != "native" and not args.half:
+    if _engine.FP32_MFMA == "f16x2" and not args.half:
+        cfg["name"] += (" [fp32 arithmetic; every convolution / token GEMM with its fp32 operands as two IEEE half pieces (activations x / 16: "
+                        "h and the residual x 2^11; weights x a power of two: wh, wl, wh / 2^11), THREE partial products on v_mfma_f32_32x32x16_f16, "
+                        "fp32 accumulate (AZ_FP32_MFMA=f16x2; accuracy of the fp32 MFMA, domain |activation| < 1e6; bf16x3 and native stay selectable); "
+                        "stride-1 3x3 convs on the Winograd F(2x2,3x3) kernel with its 16 frequency GEMMs in the same form; attention as 3 x bf16 pieces]")
+    elif _engine.FP32_MFMA != "native" and not args.half:
         cfg["name"] += (" [fp32 arithmetic; the direct-kernel contractions (1x1 / stride-2 / small-map convs, token GEMMs) as exact "
                         "3 x bf16 splits, 6 partial products on the bf16 MFMA, fp32 accumulate (default mode, AZ_FP32_MFMA=native "
                         "for v_mfma_f32_32x32x2_f32 everywhere); stride-1 3x3 convs on the Winograd F(2x2,3x3) kernel, "
@@ -659,7 +670,8 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": (f"{args.half} operands / f32 accumulate" if args.half
-                      else ("f32" if _engine.FP32_MFMA == "native" else "f32 (bf16x3 split, f32 accumulate)")),
+                      else {"native": "f32", "bf16x3": "f32 (bf16x3 split, f32 accumulate)",
+                            "f16x2": "f32 (f16x2 split: 2 half pieces per operand, 3 partial products, f32 accumulate)"}[_engine.FP32_MFMA]),
             "data": "synthetic (random-init weights under seed 0, x1 ~ sampler.init under seed 1)",
             "config": {"workload": cfg["name"], "per_gpu_batch": B, "global_batch": world * B,
                        "denoise_steps": cfg["steps"], "parallelism": f"batch-sharded x{world}, all-gather of x0"},
@@ -671,6 +683,7 @@ def main() -> None:
         if _engine.FP32_MFMA != "native" and not args.half and world == 1 and not args.no_native_line:
             # the native-fp32-MFMA line beside the bf16x3 one (reviewer's condition iii): the same workload with every contraction
             # on v_mfma_f32_32x32x2_f32, two samplings after one warm-up, same process
+            mode_was = _engine.FP32_MFMA
             _engine.FP32_MFMA = "native"
             try:
                 den_n = build_denoiser(cfg, device)
@@ -691,7 +704,7 @@ def main() -> None:
                 }
                 del den_n, smp_n, x1n, x0n
             finally:
-                _engine.FP32_MFMA = "bf16x3"
+                _engine.FP32_MFMA = mode_was
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(den, cfg)
             out["speedup_vs_cpu"] = round(images_per_s / out["cpu_baseline"]["value"], 1)
@@ -746,10 +759,11 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
     for fam, f in fams.items():
         if not f["flops"]:
             continue
-        wino = fam in ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32")
-        x3 = fam in ("az_conv2d_x3_f32", "az_attention_x3_f32", "az_conv2d_winograd_x3_f32")  # 3 x bf16 operand pieces, 6 partial products per fp32 product
+        wino = fam in ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32", "az_conv2d_winograd_f16x2_f32")
+        x3 = fam in PIECE_PRODUCTS  # operand pieces: 6 (3 x bf16) or 3 (2 x f16) partial products per fp32 product
+        nprod = PIECE_PRODUCTS.get(fam, 1)
         half_ops = fam in ("az_conv2d_bf16_f32", "az_conv2d_f16_f32", "az_attention_bf16_f32", "az_attention_f16_f32")  # --half: one 2-byte MFMA per product
-        peak = (PEAK_BF16_TFLOPS if half_ops else PEAK_BF16_TFLOPS / X3_PRODUCTS if x3 else PEAK_FP32_TFLOPS) * (WINOGRAD_GAIN if wino else 1.0)
+        peak = (PEAK_BF16_TFLOPS if half_ops else PEAK_BF16_TFLOPS / nprod if x3 else PEAK_FP32_TFLOPS) * (WINOGRAD_GAIN if wino else 1.0)
         f = dict(f, ms_event_pairs=f["ms"], ms=b2b[fam])  # the family's launches back to back inside one event pair
         tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
         k = {
@@ -764,7 +778,7 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
                       "frac_from_graph_step: the conservative figure, see there.  avg_us_with_event_pairs: one pair per launch (~10 us of idle each)",
             "algorithmic_over_nominal": round(tf / PEAK_FP32_TFLOPS, 4),  # (algorithmic FLOP/s over the fp32 MFMA peak, as SURVEY 8d is written)
             "algorithmic_flops_per_step": f["flops"],
-            "executed_mfma_tflops": round(tf * (X3_PRODUCTS if x3 else 1.0) / (WINOGRAD_GAIN if wino else 1.0), 2),
+            "executed_mfma_tflops": round(tf * nprod / (WINOGRAD_GAIN if wino else 1.0), 2),
             "mfma_peak": PEAK_BF16_TFLOPS if (x3 or half_ops) else PEAK_FP32_TFLOPS,
             "traffic": None,
         }
@@ -772,13 +786,15 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
             k["peak_note"] = (f"{PEAK_BF16_TFLOPS} TF/s dense bf16 / f16 MFMA (v_mfma_f32_32x32x16_{{bf16,f16}}, fp32 accumulate): the module was cast to "
                               "half precision, one matrix instruction per product; activations live in HBM in the module's type (engine.HALF_ACT) "
                               "for the azula UNet / ViT / DiT families")
+        how = ("six v_mfma_f32_32x32x16_bf16 partial products of exact 3 x bf16 operand splits" if nprod == 6 else
+               "three v_mfma_f32_32x32x16_f16 partial products of 2 x f16 operand pieces (f16x2)")
         if x3:
-            k["peak_note"] = (f"{PEAK_BF16_TFLOPS} TF/s dense bf16 MFMA / {X3_PRODUCTS}: every fp32 product is six v_mfma_f32_32x32x16_bf16 partial "
-                              "products of exact 3 x bf16 operand splits (fp32 accumulate); frac = executed bf16 MFMA FLOP/s / the bf16 MFMA peak")
+            k["peak_note"] = (f"{PEAK_BF16_TFLOPS} TF/s dense bf16 / f16 MFMA / {nprod}: every fp32 product is {how} (fp32 accumulate); "
+                              "frac = executed MFMA FLOP/s / the 2-byte MFMA peak")
         if wino and x3:
-            k["peak_note"] = (f"{PEAK_BF16_TFLOPS} TF/s dense bf16 MFMA / {X3_PRODUCTS} x {WINOGRAD_GAIN}: F(2x2,3x3) executes 4 multiplies per output "
-                              "where the algorithmic (direct) count has 9, and every fp32 product of its 16 frequency GEMMs is six "
-                              "v_mfma_f32_32x32x16_bf16 partial products of exact 3 x bf16 splits; frac = executed bf16 MFMA FLOP/s / the bf16 MFMA peak")
+            k["peak_note"] = (f"{PEAK_BF16_TFLOPS} TF/s dense bf16 / f16 MFMA / {nprod} x {WINOGRAD_GAIN}: F(2x2,3x3) executes 4 multiplies per output "
+                              f"where the algorithmic (direct) count has 9, and every fp32 product of its 16 frequency GEMMs is {how}; "
+                              "frac = executed MFMA FLOP/s / the 2-byte MFMA peak")
         elif wino:
             k["peak_note"] = (f"{PEAK_FP32_TFLOPS} TF/s fp32 MFMA x {WINOGRAD_GAIN}: F(2x2,3x3) executes 4 multiplies per output where the "
                               "algorithmic (direct) count has 9; frac = executed MFMA FLOP/s / the fp32 MFMA peak")
@@ -804,7 +820,7 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
     dom["ms_per_denoise_step_from_graph_step"] = round(dom_ms_graph, 3)
     roof = dict(dom)
     roof["graph_ms_per_denoise_step"] = round(graph_step_ms, 3)
-    if not args.half and dom["kernel"] not in ("attention_kernel", "attention_x3_kernel") and dom["entry"] not in ("az_conv2d_x3_f32", "az_conv2d_winograd_x3_f32"):
+    if not args.half and dom["kernel"] not in ("attention_kernel", "attention_x3_kernel") and dom["entry"] not in PIECE_CONV:
         sus = sustained_mfma_tflops(device)
         sus_rnd = sustained_mfma_tflops(device, random_operands=True)
         roof["sustained_mfma_tflops"] = round(sus, 1)
@@ -815,11 +831,11 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
                                   "multiplies constants (no bit activity, ~690 W: the pipe holds the nominal peak), "
                                   "az_calib_mfma_random_f32 per-lane random operands (the activity of real data: the 1400 W cap sets the "
                                   "clock -- tools/power_probe.py, profiles/r04_power_probe.txt); `frac` stays relative to the nominal peak")
-    if not args.half and any(e in kernels for e in ("az_conv2d_x3_f32", "az_conv2d_winograd_x3_f32")):
+    if not args.half and any(e in kernels for e in PIECE_CONV):
         # the bf16x3 families: what the 1400 W cap leaves v_mfma_f32_32x32x16_bf16 on random operands, registers only (az_calib_mfma_random_bf16,
         # 2 waves per SIMD); the families' `frac` stays on the nominal 2516.8 TF/s
         sus16 = sustained_mfma_tflops(device, bf16=True)
-        for e in ("az_conv2d_x3_f32", "az_conv2d_winograd_x3_f32"):
+        for e in PIECE_CONV:
             if e not in kernels:
                 continue
             x3k = kernels[e]
@@ -829,6 +845,7 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
                 roof["sustained_bf16_mfma_tflops_random_operands"] = x3k["sustained_bf16_mfma_tflops_random_operands"]
                 roof["frac_of_sustained_random_operands"] = x3k["frac_of_sustained_random_operands"]
     mf = ("bf16 v_mfma_f32_32x32x16_bf16, 6 partial products per fp32 product" if dom["entry"] in ("az_conv2d_x3_f32", "az_conv2d_winograd_x3_f32")
+          else "f16 v_mfma_f32_32x32x16_f16, 3 partial products per fp32 product" if dom["entry"] in PIECE_CONV
           else "fp32 v_mfma_f32_32x32x2_f32")
     roof["kernel"] = f"{dom['kernel']} ({mf}), all {dom['launches']} launches of one denoise step"
     roof["note"] = ("achieved = ALGORITHMIC FLOP (2*pixels*Cout*Cin*k^2; attention 4*B*H*T^2*d) of the kernel's launches in one "

@@ -23,7 +23,7 @@ w = torch.randn(Cout, Cin, ks, ks, device=dev) / (Cin * ks * ks) ** 0.5 * scale
 b = torch.randn(Cout, device=dev)
 if os.environ.get("AZ_AFFINE"):  # the input carries a pending normalisation (AzConvArgs.in_affine): AZ_AFFINE=1 plain, 2 with SiLU
     x.affine = (torch.randn(2 * B * Cin, device=dev) * scale, int(os.environ["AZ_AFFINE"]) - 1)
-wino = {"1": True, "0": False, "4": 4, "x3": "x3", "wx3": "wx3"}.get(os.environ.get("AZ_WINO", ""), None)
+wino = {"1": True, "0": False, "4": 4, "x3": "x3", "wx3": "wx3", "h2": "h2", "wh2": "wh2"}.get(os.environ.get("AZ_WINO", ""), None)
 y = bld.conv(x, bld.pack_conv(w, b), Cout, stride=stride, act=int(os.environ.get("AZ_ACT", "1")), winograd=wino, gn_stats=bool(os.environ.get("AZ_GN")))
 if os.environ.get("AZ_SPLITK"):  # override the suggested split-K (A/B)
     _d = [k for k in bld.tape.keep if hasattr(k, "_flops")][-1]
