@@ -281,6 +281,7 @@ PROTOTYPES: dict[str, list] = {
     "az_pack_conv_weight_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, c_stream],
     "az_attention_f32": [C.POINTER(AzAttnArgs), c_stream],
     "az_attention_x3_f32": [C.POINTER(AzAttnArgs), c_stream],
+    "az_attention_f16x2_f32": [C.POINTER(AzAttnArgs), c_stream],
     "az_attention_bf16_f32": [C.POINTER(AzAttnArgs), c_stream],
     "az_attention_f16_f32": [C.POINTER(AzAttnArgs), c_stream],
     "az_swiglu_f32": [vp, vp, i64, i64, i64, i64, c_stream],

@@ -579,7 +579,12 @@ __global__ __launch_bounds__(256) void attention_half_kernel(AzAttnArgs a) {
 // of one fp32 rounding of the product -- at 6 x 32 cycles per 16 values against 8 x 64 for v_mfma_f32_32x32x2_f32.
 // Layout and fragment maps are attention_half_kernel's with three planes per operand: K [piece][key][D + 8], V [piece][key][row
 // stride] read transposed by ds_read_b64_tr_b16, q pieces and probability pieces in registers; norms, gains, RoPE, the online softmax (scores in log2 units, hardware exp2) stay fp32 as in attention_kernel.
-template <int D, int NW>  // NW = waves (32 queries each) per workgroup: 4, or 8 where the grid still fills the chip (the K / V tile is split and staged once per workgroup)
+// H2: the "f16x2" form (az_attention_f16x2_f32; include/azula_amd.h: az_conv2d_f16x2_f32): THREE products per contraction on
+// v_mfma_f32_32x32x16_f16.  S^T = K Q^T: the keys take the three-piece role [kh | kl | kh / 2^11] of k * 2^4 (az_split_w2h), the
+// queries the two-piece role [h | l] of q / 2^4 (az_split2h) -- the scales cancel; O^T = V^T P^T: the probabilities (at most 2^8 under
+// the lazy maximum) the three-piece role of p * 2^6, the values the two-piece role of v / 2^4 -- 1 / 4 folded into the final 1 / l.
+// K keeps three LDS planes, V two; q two fragments per 16 channels.  Domain: |k| < 4094, |v|, |q * scale * log2 e| < 1.0e6 (beyond: NaN).
+template <int D, int NW, bool H2 = false>  // NW = waves (32 queries each) per workgroup: 4, or 8 where the grid still fills the chip (the K / V tile is split and staged once per workgroup)
 __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {
   constexpr int NT = 64 * NW;
   constexpr int DP = (D + 31) / 32 * 32;
@@ -591,9 +596,14 @@ __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {
   // = +-16 dwords (mod 64): the 4 keys x 2 channel blocks that a 32-lane half reads in one access fall on eight distinct bank octets
   constexpr int VLS = DP == 32 ? 32 : DP == 128 ? 160 : 96;
   constexpr int KPL = KT * KLS, VPL = KT * VLS;  // elements per piece plane
-  __shared__ __attribute__((aligned(16))) unsigned short xsm[3 * (KPL + VPL)];
+  constexpr int NVP = H2 ? 2 : 3;  // V planes
+  __shared__ __attribute__((aligned(16))) unsigned short xsm[3 * KPL + NVP * VPL];
   unsigned short* Ks = xsm;
   unsigned short* Vt = xsm + 3 * KPL;
+  auto mma = [](const abf16x8& x, const abf16x8& y, const f32x16& c) __attribute__((always_inline)) {  // one partial product on the mode's pipe
+    if constexpr (H2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(af16x8, x), __builtin_bit_cast(af16x8, y), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+  };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -640,11 +650,11 @@ __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {
 
   // zero V once: channels d >= D (padding of the last 32-wide output tile) are never written again
   if (D < DP)
-    for (int e = tid; e < 3 * VPL / 2; e += NT) reinterpret_cast<unsigned*>(Vt)[e] = 0u;
+    for (int e = tid; e < NVP * VPL / 2; e += NT) reinterpret_cast<unsigned*>(Vt)[e] = 0u;
 
   // ---- Q fragments: lane holds q[qi][16 ks + 8 h2 + (0..7)], scaled to log2 units (and RMS-normalised, gained, rotated) in
   // fp32, then split: qf[piece][ks]
-  abf16x8 qf[3][KS];
+  abf16x8 qf[H2 ? 2 : 3][KS];
   {
     float qv[KS][8];
     float ss = 0.f;
@@ -686,9 +696,12 @@ __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {
       }
       unsigned q3[3][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) az_split3(qv[ks][2 * j], qv[ks][2 * j + 1], q3[0][j], q3[1][j], q3[2][j]);
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (H2) az_split2h(qv[ks][2 * j], qv[ks][2 * j + 1], q3[0][j], q3[1][j]);
+        else az_split3(qv[ks][2 * j], qv[ks][2 * j + 1], q3[0][j], q3[1][j], q3[2][j]);
+      }
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) qf[pl][ks] = __builtin_bit_cast(abf16x8, make_uint4(q3[pl][0], q3[pl][1], q3[pl][2], q3[pl][3]));
+      for (int pl = 0; pl < (H2 ? 2 : 3); ++pl) qf[pl][ks] = __builtin_bit_cast(abf16x8, make_uint4(q3[pl][0], q3[pl][1], q3[pl][2], q3[pl][3]));
     }
   }
 
@@ -700,6 +713,10 @@ __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
   constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // (A piece, B piece) of the six partial products, smallest first
   constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+  // H2, three products: S^T (A = key planes [kh | kl | khs], B = query pieces [h | l]) and O^T (A = value planes [h | l], B = probability pieces [ph | pl | phs])
+  constexpr int SA[3] = {1, 2, 0}, SB[3] = {0, 1, 0};
+  constexpr int OA[3] = {0, 1, 0}, OB[3] = {1, 2, 0};
+  constexpr float inv_rescale = H2 ? 0.25f : 1.f;  // O^T accumulates (v / 2^4) (p 2^6)
 
   for (int k0 = 0; k0 < T; k0 += KT) {
     __syncthreads();  // previous tile fully consumed (and, first time, the V^T zero fill is complete)
@@ -747,14 +764,21 @@ __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {
           kv.w = r1 * sn.y + i1 * c.y;
         }
         unsigned k3[3][2], v3[3][2];
-        az_split3(kv.x, kv.y, k3[0][0], k3[1][0], k3[2][0]);
-        az_split3(kv.z, kv.w, k3[0][1], k3[1][1], k3[2][1]);
-        az_split3(vv.x, vv.y, v3[0][0], v3[1][0], v3[2][0]);
-        az_split3(vv.z, vv.w, v3[0][1], v3[1][1], v3[2][1]);
+        if constexpr (H2) {
+          az_split_w2h(kv.x, kv.y, 16.f, k3[0][0], k3[1][0], k3[2][0]);
+          az_split_w2h(kv.z, kv.w, 16.f, k3[0][1], k3[1][1], k3[2][1]);
+          az_split2h(vv.x, vv.y, v3[0][0], v3[1][0]);
+          az_split2h(vv.z, vv.w, v3[0][1], v3[1][1]);
+        } else {
+          az_split3(kv.x, kv.y, k3[0][0], k3[1][0], k3[2][0]);
+          az_split3(kv.z, kv.w, k3[0][1], k3[1][1], k3[2][1]);
+          az_split3(vv.x, vv.y, v3[0][0], v3[1][0], v3[2][0]);
+          az_split3(vv.z, vv.w, v3[0][1], v3[1][1], v3[2][1]);
+        }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
           *reinterpret_cast<uint2*>(Ks + pl * KPL + row * KLS + lc * 4) = make_uint2(k3[pl][0], k3[pl][1]);
-          *reinterpret_cast<uint2*>(Vt + pl * VPL + row * VLS + lc * 4) = make_uint2(v3[pl][0], v3[pl][1]);
+          if (pl < NVP) *reinterpret_cast<uint2*>(Vt + pl * VPL + row * VLS + lc * 4) = make_uint2(v3[pl][0], v3[pl][1]);
         }
       }
     }
@@ -775,7 +799,10 @@ __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const abf16x8*>(kr + pl * KPL + 16 * ks);
 #pragma unroll
-        for (int t = 0; t < 6; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qf[PB[t]][ks], sacc, 0, 0, 0);
+        for (int t = 0; t < (H2 ? 3 : 6); ++t) {
+          if constexpr (H2) sacc = mma(kf[SA[t]], qf[SB[t]][ks], sacc);
+          else sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qf[PB[t]][ks], sacc, 0, 0, 0);
+        }
       }
       if (k0 + sub * 32 + 32 > T) {  // ragged last tile (wave-uniform): keys past T
 #pragma unroll
@@ -828,7 +855,10 @@ __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {
       for (int s2 = 0; s2 < 2; ++s2) {
         unsigned p3[3][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) az_split3(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1], p3[0][j], p3[1][j], p3[2][j]);
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (H2) az_split_w2h(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1], 64.f, p3[0][j], p3[1][j], p3[2][j]);
+          else az_split3(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1], p3[0][j], p3[1][j], p3[2][j]);
+        }
         abf16x8 pb[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) pb[pl] = __builtin_bit_cast(abf16x8, make_uint4(p3[pl][0], p3[pl][1], p3[pl][2], p3[pl][3]));
@@ -839,21 +869,24 @@ __global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {
           abf16x8 va[3];
           const unsigned short* vr = Vt + (sub * 32 + 16 * s2 + 4 * h2 + ((lane & 15) >> 2)) * VLS + 32 * t + (lane & 16) + 4 * (lane & 3);
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
+          for (int pl = 0; pl < NVP; ++pl) {
             const as3_s4* pa = (const as3_s4*)(vr + pl * VPL);
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<as3_s4*>(pa));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<as3_s4*>(pa) + 2 * VLS);  // (+ 8 keys: 8 VLS elements = 2 VLS vectors of 4)
             va[pl] = __builtin_bit_cast(abf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
           }
 #pragma unroll
-          for (int u = 0; u < 6; ++u) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[u]], pb[PB[u]], oacc[t], 0, 0, 0);
+          for (int u = 0; u < (H2 ? 3 : 6); ++u) {
+            if constexpr (H2) oacc[t] = mma(va[OA[u]], pb[OB[u]], oacc[t]);
+            else oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[u]], pb[PB[u]], oacc[t], 0, 0, 0);
+          }
         }
       }
     }
   }
 
   if (qi < T) {
-    const float inv = 1.f / l_run;
+    const float inv = inv_rescale / l_run;
     float* op = a.out + (int64_t)b * a.o_bstride + (int64_t)hd * a.o_hstride + (int64_t)qi * a.o_tstride;
 #pragma unroll
     for (int t = 0; t < DT; ++t)
@@ -1012,7 +1045,13 @@ int az_attention_f16_f32(const AzAttnArgs* a, az_stream_t stream) { return atten
 
 /* az_attention_f32 with both contractions evaluated as 3 x bf16 operand pieces / 6 partial products on the bf16 MFMA (fp32
  * accumulation, fp32 softmax): fp32-level accuracy at 0.375 x the matrix-pipe time.  head_dim 16, 32, 64, 80 or 128.       */
-int az_attention_x3_f32(const AzAttnArgs* a, az_stream_t stream) {
+static int attention_x3_launch(const AzAttnArgs* a, az_stream_t stream, bool h2);
+int az_attention_x3_f32(const AzAttnArgs* a, az_stream_t stream) { return attention_x3_launch(a, stream, false); }
+/* The f16x2 form of the same kernel (include/azula_amd.h): q / v as two IEEE half pieces, k / the probabilities as three, three
+ * partial products per contraction on v_mfma_f32_32x32x16_f16.  Domain: |k| < 4094, |v| and |q * scale * log2 e| < 1.0e6.        */
+int az_attention_f16x2_f32(const AzAttnArgs* a, az_stream_t stream) { return attention_x3_launch(a, stream, true); }
+
+static int attention_x3_launch(const AzAttnArgs* a, az_stream_t stream, bool h2) {
   AZ_REQUIRE(a && a->q && a->k && a->v && a->out, AZ_E_NULL);
   AZ_REQUIRE(a->io_dtype == 0, AZ_E_UNSUPPORTED);  // (half-precision tensors: the bf16 / f16 entries)
   AZ_REQUIRE(a->batch > 0 && a->heads > 0 && a->tokens > 0, AZ_E_SHAPE);
@@ -1032,14 +1071,19 @@ int az_attention_x3_f32(const AzAttnArgs* a, az_stream_t stream) {
   const int qt = wide ? 256 : QT;
   dim3 grid((unsigned)((a->tokens + qt - 1) / qt), (unsigned)bh);
 #define AZ_ATT_X3(DD)                                                                                         \
-  if (wide) hipLaunchKernelGGL((attention_x3_kernel<DD, 8>), grid, dim3(512), 0, st, *a);                     \
+  if (wide && h2) hipLaunchKernelGGL((attention_x3_kernel<DD, 8, true>), grid, dim3(512), 0, st, *a);         \
+  else if (wide) hipLaunchKernelGGL((attention_x3_kernel<DD, 8>), grid, dim3(512), 0, st, *a);                \
+  else if (h2) hipLaunchKernelGGL((attention_x3_kernel<DD, 4, true>), grid, dim3(256), 0, st, *a);            \
   else hipLaunchKernelGGL((attention_x3_kernel<DD, 4>), grid, dim3(256), 0, st, *a)
   switch (a->head_dim) {
     case 16: AZ_ATT_X3(16); break;
     case 32: AZ_ATT_X3(32); break;
     case 64: AZ_ATT_X3(64); break;
     case 80: AZ_ATT_X3(80); break;
-    default: hipLaunchKernelGGL((attention_x3_kernel<128, 4>), grid, dim3(256), 0, st, *a); break;
+    default:
+      if (h2) hipLaunchKernelGGL((attention_x3_kernel<128, 4, true>), grid, dim3(256), 0, st, *a);
+      else hipLaunchKernelGGL((attention_x3_kernel<128, 4>), grid, dim3(256), 0, st, *a);
+      break;
   }
 #undef AZ_ATT_X3
   return az_launch_status();

@@ -108,6 +108,21 @@ __device__ __forceinline__ void az_split2h(float x0, float x1, unsigned& ph, uns
   pl = __builtin_bit_cast(unsigned, l);
 }
 
+// The OTHER operand of an f16x2 product when it is formed inside a kernel (the keys and the probabilities of the attention kernel;
+// packed weights get the same three pieces from layout.hip): x' = x * scale as ph = fp16(x'), pl = fp16(x' - ph) (the residual,
+// unscaled) and phs = ph / 2^11, the factor of the partner's scaled low piece.  `scale` puts the operand's largest magnitudes near
+// 2^10 .. 2^14, so that the unscaled residual stays a normal half for everything within ~2^-14 of them.
+__device__ __forceinline__ void az_split_w2h(float x0, float x1, float scale, unsigned& ph, unsigned& pl, unsigned& phs) {
+  const az_f2v v = {x0 * scale, x1 * scale};
+  const az_h2v h = __builtin_convertvector(v, az_h2v);
+  const az_f2v r = v - __builtin_convertvector(h, az_f2v);
+  const az_h2v l = __builtin_convertvector(r, az_h2v);
+  const az_h2v hs = h * (_Float16)0.00048828125f;
+  ph = __builtin_bit_cast(unsigned, h);
+  pl = __builtin_bit_cast(unsigned, l);
+  phs = __builtin_bit_cast(unsigned, hs);
+}
+
 // Streaming accesses of the pure HBM streams (the transition kernels: every byte read once and written once per launch):
 // non-temporal 16-byte loads / stores (global_load_dwordx4 ... nt).  Measured on the 96 Mi-element transition
 // (profiles/r05_stream_nt_ab.txt): 12 B/element form 5.71 -> 6.14 TB/s, the 16 B form 5.46 -> 5.78, the 20 B form 5.40 -> 5.89;

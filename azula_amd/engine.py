@@ -162,6 +162,7 @@ assert FP32_MFMA in ("native", "bf16x3", "f16x2"), FP32_MFMA
 def pieces() -> bool:
     r"""fp32 operands as 2-byte pieces on the bf16 / f16 pipe (read per plan: bench.py flips FP32_MFMA between plans)."""
     return FP32_MFMA in ("bf16x3", "f16x2")
+ATTN_H2 = os.environ.get("AZ_ATTN_H2", "1") != "0"  # f16x2 mode: the attention contractions in that form too ("0": bf16x3 attention -- A/B)
 ATTN_X3 = os.environ.get("AZ_ATTN_X3", "1") != "0"  # bf16x3 mode: attention contractions on the bf16 pipe too (az_attention_x3_f32)
 # The stride-1 3 x 3 layers in bf16x3 mode: "1" (default since round 5) = the Winograd kernel with its 16 frequency GEMMs on the bf16 pipe
 # as exact 3 x bf16 splits too (az_conv2d_winograd_x3_f32, csrc/wino_x3.hip: same transforms, same epilogue, 1.19 - 1.28 x the fp32
@@ -893,7 +894,7 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
     if self.half is None and pieces() and ATTN_X3 and dim in (16, 32, 64, 80):
         # the two contractions as 3 x bf16 pieces / 6 partial products: fp32 accuracy, 0.375 x the pipe time (64 x 12 heads x 256
         # tokens x 64: 140 -> 111 us; head_dim 128 needs one wave per SIMD there and measured slower, 458 vs 516 us: fp32 kernel)
-        name = "az_attention_x3_f32"
+        name = "az_attention_f16x2_f32" if FP32_MFMA == "f16x2" and ATTN_H2 else "az_attention_x3_f32"
     if self.half is not None:  # module cast to half precision: contractions on the bf16 / f16 MFMA
         name = "az_attention_f16_f32" if self.half == torch.float16 else "az_attention_bf16_f32"
     self.tape.add(name, C.byref(a), keep=[a])

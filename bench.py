@@ -32,7 +32,7 @@ X3_PRODUCTS = 6
 # "f16x2" (az_conv2d_f16x2_f32 / az_conv2d_winograd_f16x2_f32): three v_mfma_f32_32x32x16_f16 partial products per fp32 product (the f16 pipe
 # has the bf16 pipe's dense rate): with the pipe 100 % busy PEAK / 3 algorithmic TFLOP/s
 PIECE_PRODUCTS = {"az_conv2d_x3_f32": 6, "az_attention_x3_f32": 6, "az_conv2d_winograd_x3_f32": 6,
-                  "az_conv2d_f16x2_f32": 3, "az_conv2d_winograd_f16x2_f32": 3}
+                  "az_conv2d_f16x2_f32": 3, "az_conv2d_winograd_f16x2_f32": 3, "az_attention_f16x2_f32": 3}
 PIECE_CONV = ("az_conv2d_x3_f32", "az_conv2d_winograd_x3_f32", "az_conv2d_f16x2_f32", "az_conv2d_winograd_f16x2_f32")
 PEAK_HBM_GBS = 8000.0  # HBM3E spec (6.3 TB/s measured achievable)
 # F(2x2,3x3) Winograd executes 4 multiplies per output where the direct form (the ALGORITHMIC count of SURVEY 8d,
@@ -135,7 +135,7 @@ def build_denoiser(cfg, device):
 
 CONV_OPS = ("az_conv2d_f32", "az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32", "az_conv2d_winograd4_f32", "az_conv2d_bf16_f32",
             "az_conv2d_f16_f32", "az_conv2d_x3_f32", "az_conv2d_f16x2_f32", "az_conv2d_winograd_f16x2_f32")
-ATTN_OPS = ("az_attention_f32", "az_attention_x3_f32", "az_attention_bf16_f32", "az_attention_f16_f32")
+ATTN_OPS = ("az_attention_f32", "az_attention_x3_f32", "az_attention_f16x2_f32", "az_attention_bf16_f32", "az_attention_f16_f32")
 
 
 def sampler_kwargs(cfg, device):
@@ -221,7 +221,7 @@ def tape_profile(sampler, device):
 
 
 KERNEL_OF = {  # C-ABI entry point -> the __global__ kernel it launches (names as rocprofv3 prints them)
-    "az_conv2d_winograd_f32": "conv_winograd_kernel", "az_conv2d_f32": "conv_igemm_kernel", "az_attention_f32": "attention_kernel", "az_attention_x3_f32": "attention_x3_kernel",
+    "az_conv2d_winograd_f32": "conv_winograd_kernel", "az_conv2d_f32": "conv_igemm_kernel", "az_attention_f32": "attention_kernel", "az_attention_x3_f32": "attention_x3_kernel", "az_attention_f16x2_f32": "attention_x3_kernel",
     "az_conv2d_stem_f32": "conv_stem_kernel", "az_conv2d_bf16_f32": "conv_igemm_half_kernel", "az_conv2d_f16_f32": "conv_igemm_half_kernel", "az_conv2d_x3_f32": "conv_gemm_x3_big_kernel / conv_igemm_x3_kernel",  # (256 x 256 tiles where they fill rounds / 128 x 128 tiles)
     "az_conv2d_winograd4_f32": "conv_winograd4_kernel", "az_conv2d_winograd_x3_f32": "conv_winograd_x3_kernel",
     "az_conv2d_f16x2_f32": "conv_gemm_x3_big_kernel / conv_igemm_x3_kernel", "az_conv2d_winograd_f16x2_f32": "conv_winograd_x3_kernel",  # (the H2 = true instantiations)
@@ -576,7 +576,7 @@ def main() -> None:
         cfg["name"] += (" [fp32 arithmetic; every convolution / token GEMM with its fp32 operands as two IEEE half pieces (activations x / 16: "
                         "h and the residual x 2^11; weights x a power of two: wh, wl, wh / 2^11), THREE partial products on v_mfma_f32_32x32x16_f16, "
                         "fp32 accumulate (AZ_FP32_MFMA=f16x2; accuracy of the fp32 MFMA, domain |activation| < 1e6; bf16x3 and native stay selectable); "
-                        "stride-1 3x3 convs on the Winograd F(2x2,3x3) kernel with its 16 frequency GEMMs in the same form; attention as 3 x bf16 pieces]")
+                        "stride-1 3x3 convs on the Winograd F(2x2,3x3) kernel with its 16 frequency GEMMs in the same form; attention contractions too]")
     elif _engine.FP32_MFMA != "native" and not args.half:
         cfg["name"] += (" [fp32 arithmetic; the direct-kernel contractions (1x1 / stride-2 / small-map convs, token GEMMs) as exact "
                         "3 x bf16 splits, 6 partial products on the bf16 MFMA, fp32 accumulate (default mode, AZ_FP32_MFMA=native "

@@ -479,6 +479,12 @@ int az_attention_f32(const AzAttnArgs* args, az_stream_t stream);
  * RoPE in fp32); the attention of fp32 modules when AZ_FP32_MFMA = bf16x3 (the default).  head_dim 16, 32, 64, 80, 128.
  * Replaces the same reference lines as az_attention_f32. */
 int az_attention_x3_f32(const AzAttnArgs* args, az_stream_t stream);
+/* The same kernel in the f16x2 form (see az_conv2d_f16x2_f32): three partial products per contraction on v_mfma_f32_32x32x16_f16 --
+ * the keys as [kh | kl | kh / 2^11] of k * 2^4 and the queries as [h | l] of q / 2^4 (the scales cancel); the probabilities (at most
+ * 2^8 under the lazy running maximum) as three pieces of p * 2^6, the values as two of v / 2^4 (1 / 4 folded into the final 1 / l).
+ * Softmax, norms, gains, RoPE in fp32 as before.  Domain: |k| < 4094, |v| and |q * scale * log2 e| < 1.0e6 (beyond: NaN).  Same
+ * reference op: torch SDPA behind azula/nn/attention.py:89-104, plugins/adm/_src/unet.py:338-379.                          */
+int az_attention_f16x2_f32(const AzAttnArgs* args, az_stream_t stream);
 int az_attention_bf16_f32(const AzAttnArgs* args, az_stream_t stream);
 int az_attention_f16_f32(const AzAttnArgs* args, az_stream_t stream);
 

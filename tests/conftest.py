@@ -67,3 +67,10 @@ def golden():
 
 def max_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+# C-ABI entries by kernel family, whatever AZ_FP32_MFMA mode built the plan (native / bf16x3 / f16x2): tests that check WHICH
+# kernel family a layer landed on use these
+WINO_OPS = ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32", "az_conv2d_winograd_f16x2_f32")
+DIRECT_OPS = ("az_conv2d_f32", "az_conv2d_x3_f32", "az_conv2d_f16x2_f32")
+ATTN_OPS = ("az_attention_f32", "az_attention_x3_f32", "az_attention_f16x2_f32")

@@ -13,7 +13,7 @@ Reference: azula/nn/unet.py:205-259, azula/plugins/adm/_src/unet.py:605-634, azu
 import pytest
 import torch
 
-from conftest import max_err
+from conftest import ATTN_OPS, DIRECT_OPS, WINO_OPS, max_err
 from oracle import nets, sampling
 
 pytestmark = pytest.mark.gpu
@@ -47,7 +47,7 @@ def test_c2_at_full_resolution_against_the_oracle(c2_full):
     net._plans.clear()
     mean = den(x1.cuda(), torch.tensor(0.6, device="cuda")).mean
     ops = [n for _, _, n in next(iter(net._plans.values())).tape.ops]
-    assert ops.count("az_conv2d_winograd_x3_f32") + ops.count("az_conv2d_winograd_f32") >= 40, "the 3 x 3 layers must be on the Winograd kernels"
+    assert sum(ops.count(n) for n in WINO_OPS) >= 40, "the 3 x 3 layers must be on the Winograd kernels"
     ref_mean = oracle_mean(x1, torch.tensor(0.6))
     sc = max(1.0, ref_mean.abs().max().item())
     e1 = max_err(mean, ref_mean)
@@ -107,7 +107,7 @@ def test_adm_256_at_full_resolution_against_the_oracle():
     x1 = torch.randn(1, 3, RES, RES)
     out = den.backbone(x1.cuda(), torch.tensor([417], device="cuda"))
     ops = [n for _, _, n in next(iter(den.backbone._plans.values())).tape.ops]
-    assert ops.count("az_attention_f32") + ops.count("az_attention_x3_f32") >= 8
+    assert sum(ops.count(n) for n in ATTN_OPS) >= 8
     ref_out = bb(x1, torch.tensor([417]))
     so = max(1.0, ref_out.abs().max().item())
     e0 = max_err(out, ref_out)

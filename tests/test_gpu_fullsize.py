@@ -18,7 +18,7 @@ torch.set_grad_enabled(False)
 STEPS = 3
 
 
-WINO = ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32")  # the Winograd entries (fp32 stream / frequency GEMMs on the bf16 pipe)
+WINO = ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32", "az_conv2d_winograd_f16x2_f32")  # the Winograd entries (fp32 stream / frequency GEMMs on the bf16 / f16 pipe)
 
 
 @pytest.fixture(scope="module")

@@ -13,7 +13,7 @@ Tolerances are <= 5 x the errors measured on MI355X (printed by the tests)."""
 import pytest
 import torch
 
-from conftest import max_err
+from conftest import ATTN_OPS, DIRECT_OPS, WINO_OPS, max_err
 from oracle import nets, sampling
 
 pytestmark = pytest.mark.gpu
@@ -49,7 +49,7 @@ def test_c2_channel_plan_against_the_oracle(c2_net, policy, monkeypatch):
     net._plans.clear()
     mean = den(x1.cuda(), torch.tensor(0.6, device="cuda")).mean
     ops = [n for _, _, n in next(iter(net._plans.values())).tape.ops]
-    nw, nd = ops.count("az_conv2d_winograd_f32") + ops.count("az_conv2d_winograd_x3_f32"), ops.count("az_conv2d_f32") + ops.count("az_conv2d_x3_f32")  # (direct family: native or bf16x3)
+    nw, nd = sum(ops.count(n) for n in WINO_OPS), sum(ops.count(n) for n in DIRECT_OPS)  # (whatever the AZ_FP32_MFMA mode)
     if policy == "2":
         assert nw >= 50 and nd <= 8, (nw, nd)  # only the stride-2 convolutions and the stem / head stay direct
     elif policy == "0":
@@ -152,7 +152,7 @@ def test_adm_256_widths_against_the_oracle(adm_net):
     den, x1, ref_out, ref_mean, ref_x0, _, _ = adm_net
     out = den.backbone(x1.cuda(), torch.tensor([417], device="cuda"))
     ops = [n for _, _, n in next(iter(den.backbone._plans.values())).tape.ops]
-    assert ops.count("az_attention_f32") + ops.count("az_attention_x3_f32") >= 8, "the attention blocks at 1/8, 1/16, 1/32 must be on the tape"
+    assert sum(ops.count(n) for n in ATTN_OPS) >= 8, "the attention blocks at 1/8, 1/16, 1/32 must be on the tape"
     so = max(1.0, ref_out.abs().max().item())
     e0 = max_err(out, ref_out)
     mean = den(x1.cuda(), torch.tensor(0.5, device="cuda")).mean
@@ -221,7 +221,7 @@ def test_dit_b2_full_width_against_the_oracle(dit_b2, k16, monkeypatch):
     net._plans.clear()
     mean = den(x1.cuda(), torch.tensor(0.6, device="cuda")).mean
     ops = [n for _, _, n in next(iter(net._plans.values())).tape.ops]
-    assert ops.count("az_attention_f32") + ops.count("az_attention_x3_f32") == 12 and ops.count("az_conv2d_f32") + ops.count("az_conv2d_x3_f32") >= 4 * 12
+    assert sum(ops.count(n) for n in ATTN_OPS) == 12 and sum(ops.count(n) for n in DIRECT_OPS) >= 4 * 12
     sc = max(1.0, ref_mean.abs().max().item())
     e1 = max_err(mean, ref_mean)
     smp = DDIMSampler(den, steps=3, silent=True)

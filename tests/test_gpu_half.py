@@ -27,7 +27,7 @@ def _bar(y32, y16, half):
 def _uses_half_kernel(plan, half):
     want = "az_conv2d_f16_f32" if half == torch.float16 else "az_conv2d_bf16_f32"
     names = {n for _, _, n in plan.tape.ops}
-    return want in names and "az_conv2d_f32" not in names and "az_conv2d_winograd_f32" not in names and "az_conv2d_winograd_x3_f32" not in names
+    return want in names and "az_conv2d_f32" not in names and "az_conv2d_winograd_f32" not in names and "az_conv2d_winograd_x3_f32" not in names and "az_conv2d_winograd_f16x2_f32" not in names
 
 
 @pytest.mark.parametrize("half", HALVES)
@@ -313,7 +313,7 @@ def test_unet_half_activations_in_hbm(half, norm):
     plan = next(iter(net._plans.values()))
     assert plan.bld.half_act
     names = [n for _, _, n in plan.tape.ops]
-    assert not any(n in names for n in ("az_affine_act_f32", "az_groupnorm_stats_f32", "az_rownorm_mod_f32", "az_conv2d_f32", "az_conv2d_x3_f32"))
+    assert not any(n in names for n in ("az_affine_act_f32", "az_groupnorm_stats_f32", "az_rownorm_mod_f32", "az_conv2d_f32", "az_conv2d_x3_f32", "az_conv2d_f16x2_f32"))
     convs = [a[0]._obj for _, a, n in plan.tape.ops if n.startswith("az_conv2d")]
     assert convs[0].src_dtype == 0 and convs[0].dst_dtype == 1 and convs[-1].src_dtype == 1 and convs[-1].dst_nchw == 1
     assert all(c.src_dtype == 1 and c.dst_dtype == 1 for c in convs[1:-1])
@@ -359,7 +359,7 @@ def test_adm_half_activations_in_hbm(half):
     plan = next(iter(den.backbone._plans.values()))
     assert plan.bld.half_act and o16.dtype == half
     names = [n for _, _, n in plan.tape.ops]
-    assert "az_affine_act_h16" in names and not any(n in names for n in ("az_affine_act_f32", "az_groupnorm_stats_f32", "az_conv2d_f32", "az_conv2d_x3_f32"))
+    assert "az_affine_act_h16" in names and not any(n in names for n in ("az_affine_act_f32", "az_groupnorm_stats_f32", "az_conv2d_f32", "az_conv2d_x3_f32", "az_conv2d_f16x2_f32"))
     q99, mx, bq, bm = _bar(o32, o16, half)
     print("adm, half activations", half, "q99/scale", q99, "max/scale", mx)
     assert q99 < 2 * bq and mx < 2 * bm

@@ -5,7 +5,7 @@ backbone forward 1e-4 abs on O(1) activations; DDIM-64 trajectory 5e-4 abs on |x
 import pytest
 import torch
 
-from conftest import max_err
+from conftest import ATTN_OPS, DIRECT_OPS, WINO_OPS, max_err
 from oracle import nets, sampling, synth
 
 pytestmark = pytest.mark.gpu
@@ -139,18 +139,20 @@ def test_unet_forward_through_winograd(golden, monkeypatch):
         net = net.cuda().eval()
         y = net(g["x"].cuda(), g["modB"].cuda())
         plan = next(iter(net._plans.values()))
-        assert any(name_ in ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32") for _, _, name_ in plan.tape.ops)
+        assert any(name_ in WINO_OPS for _, _, name_ in plan.tape.ops)
         err, sc = max_err(y, g["y_modB"]), g["y_modB"].abs().max().item()
         print(name, "winograd max|d| vs reference:", err, "scale", sc)
         assert err < 2e-4 * max(1.0, sc)
 
 
-def test_unet_forward_through_bf16x3(golden, monkeypatch):
+@pytest.mark.parametrize("mode,entry", [("bf16x3", "az_conv2d_x3_f32"), ("f16x2", "az_conv2d_f16x2_f32")])
+def test_unet_forward_through_bf16x3(golden, monkeypatch, mode, entry):
     """The same reference vectors with the fp32 convolutions evaluated on the bf16 MFMA as 3 x bf16 pieces / 6 partial
-    products (AZ_FP32_MFMA=bf16x3, az_conv2d_x3_f32): same tolerance as the native fp32 path."""
+    products (AZ_FP32_MFMA=bf16x3, az_conv2d_x3_f32) or on the f16 MFMA as 2 x f16 pieces / 3 partial products (f16x2,
+    az_conv2d_f16x2_f32): same tolerance as the native fp32 path."""
     from azula_amd import engine
 
-    monkeypatch.setattr(engine, "FP32_MFMA", "bf16x3")
+    monkeypatch.setattr(engine, "FP32_MFMA", mode)
     monkeypatch.setattr(engine, "X3_MIN_CHANNELS", 4)  # the golden UNets are narrow
     for name in ("unet_group", "unet_layer_odd"):
         g = golden("g5_" + name)
@@ -160,9 +162,9 @@ def test_unet_forward_through_bf16x3(golden, monkeypatch):
         net = net.cuda().eval()
         y = net(g["x"].cuda(), g["modB"].cuda())
         plan = next(iter(net._plans.values()))
-        assert any(name_ == "az_conv2d_x3_f32" for _, _, name_ in plan.tape.ops)
+        assert any(name_ == entry for _, _, name_ in plan.tape.ops)
         err, sc = max_err(y, g["y_modB"]), g["y_modB"].abs().max().item()
-        print(name, "bf16x3 max|d| vs reference:", err, "scale", sc)
+        print(name, mode, "max|d| vs reference:", err, "scale", sc)
         assert err < 1e-4 * max(1.0, sc)
 
 

@@ -16,15 +16,16 @@ torch.set_grad_enabled(False)
 
 @pytest.mark.parametrize("B,H,T,D", [(2, 4, 16, 16), (1, 2, 64, 32), (2, 3, 256, 64), (1, 2, 100, 64), (1, 1, 1024, 64), (1, 2, 40, 128), (2, 2, 72, 80)])
 @pytest.mark.parametrize("order,rms", [("nHC", True), ("nHC", False), ("H3C", False), ("3HC", False)])
-@pytest.mark.parametrize("x3", [True, False])
+@pytest.mark.parametrize("x3", [True, False, "f16x2"])
 def test_attention_kernel(monkeypatch, B, H, T, D, order, rms, x3):
-    """az_attention_x3_f32 (the contractions as 3 x bf16 pieces / 6 partial products on the bf16 MFMA: the default of fp32
-    modules) and az_attention_f32 (fp32 MFMA), both against torch's SDPA at the same bound."""
+    """az_attention_x3_f32 (the contractions as 3 x bf16 pieces / 6 partial products on the bf16 MFMA), az_attention_f16x2_f32
+    (2 x f16 pieces / 3 partial products on the f16 MFMA) and az_attention_f32 (fp32 MFMA), all against torch's SDPA at the same bound."""
     from azula_amd import engine
     from azula_amd.engine import Act, Builder
 
-    monkeypatch.setattr(engine, "ATTN_X3", x3)
-    monkeypatch.setattr(engine, "FP32_MFMA", "bf16x3")
+    monkeypatch.setattr(engine, "ATTN_X3", bool(x3))
+    monkeypatch.setattr(engine, "FP32_MFMA", "f16x2" if x3 == "f16x2" else "bf16x3")
+    xname = "az_attention_f16x2_f32" if x3 == "f16x2" else "az_attention_x3_f32"
 
     g = torch.Generator().manual_seed(B * T + D)
     q, k, v = (torch.randn(B, H, T, D, generator=g) for _ in range(3))
@@ -38,12 +39,12 @@ def test_attention_kernel(monkeypatch, B, H, T, D, order, rms, x3):
     bld = Builder(torch.device("cuda"))
     act = Act(qkv.cuda().contiguous().reshape(-1), B, T, 1, 3 * H * D, 3 * H * D, True)
     out = bld.attention(act, H, order, rms, 1.0 / math.sqrt(D))
-    assert [n for _, _, n in bld.tape.ops] == ["az_attention_x3_f32" if x3 and D <= 80 else "az_attention_f32"]
+    assert [n for _, _, n in bld.tape.ops] == [xname if x3 and D <= 80 else "az_attention_f32"]
     if x3 and D > 80:  # the engine keeps head_dim 128 on the fp32 kernel (faster there); the entry point itself takes it
         from azula_amd import _lib
 
         _, args, _ = bld.tape.ops[0]
-        bld.tape.ops[0] = (_lib.lib().az_attention_x3_f32, args, "az_attention_x3_f32")
+        bld.tape.ops[0] = (getattr(_lib.lib(), xname), args, xname)
     bld.tape.run()
     got = out.buf.reshape(B, T, H * D)
     assert max_err(got, ref) < 2e-5, max_err(got, ref)
@@ -158,16 +159,18 @@ def test_vit_forward_matches_reference(golden):
         assert err < 1e-4 * max(1.0, sc)
 
 
-def test_vit_ddim50_through_bf16x3(golden, monkeypatch):
+@pytest.mark.parametrize("mode,entry", [("bf16x3", "az_conv2d_x3_f32"), ("f16x2", "az_conv2d_f16x2_f32")])
+def test_vit_ddim50_through_bf16x3(golden, monkeypatch, mode, entry):
     """DDIM-50 of the golden ViT with every token GEMM on the bf16 MFMA as 3 x bf16 pieces / 6 partial products
-    (AZ_FP32_MFMA=bf16x3): same tolerance as the native fp32 run (hid_channels = 64 >= 32, so the GEMMs qualify)."""
+    (AZ_FP32_MFMA=bf16x3) or on the f16 MFMA as 2 x f16 pieces / 3 partial products (f16x2): same tolerance as the native fp32 run
+    (hid_channels = 64 >= 32, so the GEMMs qualify)."""
     from azula_amd import engine
     from azula_amd.denoise import KarrasDenoiser
     from azula_amd.nn import TimeModulated
     from azula_amd.noise import VPSchedule
     from azula_amd.sample import DDIMSampler
 
-    monkeypatch.setattr(engine, "FP32_MFMA", "bf16x3")
+    monkeypatch.setattr(engine, "FP32_MFMA", mode)
     g = golden("g6_vit_loop")
     cfg = g.meta["cfg"]
     w = TimeModulated(build_vit(cfg), cfg["mod_features"], name="vit")
@@ -176,9 +179,9 @@ def test_vit_ddim50_through_bf16x3(golden, monkeypatch):
     smp = DDIMSampler(den, steps=50, silent=True)
     x0 = smp(g["x1"].cuda())
     loop = next(iter(smp._fused_cache.values()))
-    assert any(name_ == "az_conv2d_x3_f32" for _, _, name_ in loop.tape.ops)
+    assert any(name_ == entry for _, _, name_ in loop.tape.ops)
     err, sc = max_err(x0, g["ddim50"]), g["ddim50"].abs().max().item()
-    print("ViT DDIM-50 bf16x3 max|d| vs reference:", err, "scale", sc)
+    print("ViT DDIM-50", mode, "max|d| vs reference:", err, "scale", sc)
     assert err < 5e-4 * max(1.0, sc)
 
 

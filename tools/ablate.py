@@ -39,15 +39,15 @@ VARIANTS = {
 VARIANTS["att_eager"] = [("attention.hip", "      const bool jump = mt > m_run + 8.f;", "      const bool jump = mt > m_run;")]
 # attention_x3_kernel timing ablations (64 x 12 heads x 256 tokens x 64: profiles/r05_attention_x3_ablation.txt)
 _ATT_CHEAP = "{{ {0} = __builtin_bit_cast(unsigned, {3}); {1} = {0}; {2} = {0}; }}"
-VARIANTS["att_nopsplit"] = [("attention.hip", "for (int j = 0; j < 4; ++j) az_split3(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1], p3[0][j], p3[1][j], p3[2][j]);",
-                             "for (int j = 0; j < 4; ++j) " + _ATT_CHEAP.format("p3[0][j]", "p3[1][j]", "p3[2][j]", "sacc[8 * s2 + 2 * j]"))]
+VARIANTS["att_nopsplit"] = [("attention.hip", "          else az_split3(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1], p3[0][j], p3[1][j], p3[2][j]);",
+                             "          else " + _ATT_CHEAP.format("p3[0][j]", "p3[1][j]", "p3[2][j]", "sacc[8 * s2 + 2 * j]"))]
 VARIANTS["att_nokvsplit"] = [
-    ("attention.hip", "        az_split3(kv.x, kv.y, k3[0][0], k3[1][0], k3[2][0]);\n        az_split3(kv.z, kv.w, k3[0][1], k3[1][1], k3[2][1]);\n"
-                      "        az_split3(vv.x, vv.y, v3[0][0], v3[1][0], v3[2][0]);\n        az_split3(vv.z, vv.w, v3[0][1], v3[1][1], v3[2][1]);\n",
+    ("attention.hip", "          az_split3(kv.x, kv.y, k3[0][0], k3[1][0], k3[2][0]);\n          az_split3(kv.z, kv.w, k3[0][1], k3[1][1], k3[2][1]);\n"
+                      "          az_split3(vv.x, vv.y, v3[0][0], v3[1][0], v3[2][0]);\n          az_split3(vv.z, vv.w, v3[0][1], v3[1][1], v3[2][1]);\n",
      "        " + _ATT_CHEAP.format("k3[0][0]", "k3[1][0]", "k3[2][0]", "kv.x") + _ATT_CHEAP.format("k3[0][1]", "k3[1][1]", "k3[2][1]", "kv.z")
      + _ATT_CHEAP.format("v3[0][0]", "v3[1][0]", "v3[2][0]", "vv.x") + _ATT_CHEAP.format("v3[0][1]", "v3[1][1]", "v3[2][1]", "vv.z") + "\n")]
-VARIANTS["att_1mfma"] = [("attention.hip", "for (int t = 0; t < 6; ++t) sacc", "for (int t = 0; t < 1; ++t) sacc"),
-                         ("attention.hip", "for (int u = 0; u < 6; ++u) oacc", "for (int u = 0; u < 1; ++u) oacc")]
+VARIANTS["att_1mfma"] = [("attention.hip", "for (int t = 0; t < (H2 ? 3 : 6); ++t) {", "for (int t = 0; t < 1; ++t) {"),
+                         ("attention.hip", "for (int u = 0; u < (H2 ? 3 : 6); ++u) {", "for (int u = 0; u < 1; ++u) {")]
 VARIANTS["att_noexp"] = [("attention.hip", "const float pe = __builtin_amdgcn_exp2f(sacc[r] - m_sub);", "const float pe = sacc[r] - m_sub;")]
 VARIANTS["att_nosoftmax"] = VARIANTS["att_noexp"] + VARIANTS["att_nopsplit"]
 VARIANTS["att_novalu"] = VARIANTS["att_nosoftmax"] + VARIANTS["att_nokvsplit"]
@@ -116,15 +116,13 @@ VARIANTS["h2big_nosched"] = [("conv.hip", "    if constexpr (!H2) {\n      __bui
                              ("conv.hip", "    } else {\n      // half as many matrix instructions for the same staging:", "    } else if constexpr (false) {\n      // half as many matrix instructions for the same staging:")]
 VARIANTS["x3_no192"] = [("conv.hip", "  const bool ok192 = ct != nullptr && kstep == GBK && a->act <= 3 && !x3_big_taps(a);", "  const bool ok192 = false;")]
 VARIANTS["ax_oneprod"] = [
-    ("attention.hip", "        for (int t = 0; t < 6; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qf[PB[t]][ks], sacc, 0, 0, 0);",
-     "        for (int t = 5; t < 6; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qf[PB[t]][ks], sacc, 0, 0, 0);"),
-    ("attention.hip", "          for (int u = 0; u < 6; ++u) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[u]], pb[PB[u]], oacc[t], 0, 0, 0);",
-     "          for (int u = 5; u < 6; ++u) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[u]], pb[PB[u]], oacc[t], 0, 0, 0);"),
+    ("attention.hip", "        for (int t = 0; t < (H2 ? 3 : 6); ++t) {", "        for (int t = (H2 ? 2 : 5); t < (H2 ? 3 : 6); ++t) {"),
+    ("attention.hip", "          for (int u = 0; u < (H2 ? 3 : 6); ++u) {", "          for (int u = (H2 ? 2 : 5); u < (H2 ? 3 : 6); ++u) {"),
 ]
 VARIANTS["ax_noexp"] = [("attention.hip", "        const float pe = __builtin_amdgcn_exp2f(sacc[r] - m_sub);", "        const float pe = sacc[r] - m_sub;")]
 VARIANTS["ax_nosplitp"] = [
-    ("attention.hip", "        for (int j = 0; j < 4; ++j) az_split3(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1], p3[0][j], p3[1][j], p3[2][j]);",
-     "        for (int j = 0; j < 4; ++j) p3[0][j] = p3[1][j] = p3[2][j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sacc[8 * s2 + 2 * j + 1]), __builtin_bit_cast(unsigned, sacc[8 * s2 + 2 * j]), 0x07060302u);"),
+    ("attention.hip", "          else az_split3(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1], p3[0][j], p3[1][j], p3[2][j]);",
+     "          else p3[0][j] = p3[1][j] = p3[2][j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sacc[8 * s2 + 2 * j + 1]), __builtin_bit_cast(unsigned, sacc[8 * s2 + 2 * j]), 0x07060302u);"),
 ]
 # (ax_novt -- the scattered V^T store of round 4 -- went with that code: V is staged row-major and consumed through ds_read_b64_tr_b16)
 
@@ -206,6 +204,15 @@ _AF_ST = [("norm.hip", "    for (int u = 0; u < UN; ++u) st4_io<IO>(y, yo + (int
 VARIANTS["aff_ntld"] = _AF_LD
 VARIANTS["aff_ntst"] = _AF_ST
 VARIANTS["aff_nt"] = _AF_LD + _AF_ST
+
+# ---- f16x2 form of the x3 Winograd kernel (wino_x3.hip, H2): the low piece by v_fma_mixlo / mixhi_f16 (fp32 fma with an f16 source,
+#      rounded to f16 in the same instruction: 2 instead of 4 vector instructions per pair) -- RESULTS STAY CORRECT
+VARIANTS["wx3h_mix"] = [("wino_x3.hip",
+    "      const h2v l = {(_Float16)__builtin_fmaf((float)hh.x, -2048.f, xf[th][2 * j]), (_Float16)__builtin_fmaf((float)hh.y, -2048.f, xf[th][2 * j + 1])};\n      fw[th][1][j] = __builtin_bit_cast(unsigned, l);\n",
+    "      (void)hh;\n      unsigned lw;\n"
+    "      asm(\"v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\" : \"=v\"(lw) : \"v\"(fw[th][0][j]), \"s\"(-2048.f), \"v\"(xf[th][2 * j]));\n"
+    "      asm(\"v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\" : \"+v\"(lw) : \"v\"(fw[th][0][j]), \"s\"(-2048.f), \"v\"(xf[th][2 * j + 1]));\n"
+    "      fw[th][1][j] = lw;\n")]
 
 
 def build(name: str, patches=None, regen_env=None, head_files=None) -> str:
