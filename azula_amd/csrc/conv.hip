@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
     const unsigned soffA = (unsigned)(kbase * 4);
     const bool kv0 = kbase + kc8 * 8 < cs, kv1 = kbase + kc8 * 8 + 4 < cs;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < (H2 ? 2 : 3); ++pl) {  // (H2: the third plane, wh / 2^11, is derived from the first in store_tile)
       const unsigned soffW = (unsigned)((pl * wplane + wtap) * 2);
 #pragma unroll
       for (int i = 0; i < 2; ++i) ra[pl][i] = buf_ld4(rw, voffW[i], soffW);
@@ -845,6 +845,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
   };
   const int wsw = (kc8 ^ ((r0 >> 2) & 3)) * 8;  // swizzled chunk of this thread's rows (r0 and r0 + 64 share bits 2..3)
   auto store_tile = [&]() __attribute__((always_inline)) {
+    if constexpr (H2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) ra[2][i] = __builtin_bit_cast(float4, __builtin_bit_cast(f16x8, ra[0][i]) * (_Float16)0.00048828125f);
+    }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -1056,13 +1060,16 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
   const unsigned voffX1 = (unsigned)(((int64_t)px_l * a.c1s + lch * 8) * 4);
   const int lds_row = lrow * 32 + ((lch ^ ((lrow >> 3) & 1)) * 16);  // byte offset inside a plane
 
+  // H2: the third weight plane (wh / 2^11) is the first with another exponent: derived by the loader thread (four v_pk_mul_f16, the
+  // packing's rounding bit for bit) instead of loaded -- 4 instead of 5 16-byte loads per thread and step
+  constexpr int NWL = H2 ? 2 : 3;  // weight planes loaded
   float4 rwt[3], rxa[2];
   auto load_step = [&](int kt) __attribute__((always_inline)) {
     if constexpr (TAPS) {
       const int tap = kt / nk_tap, kr = kt - tap * nk_tap;  // (wave-uniform)
       const int ky = tap / a.ksize, kx = tap - ky * a.ksize;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) rwt[pl] = buf_ld4(rw, voffW, (unsigned)((pl * wplane + tap * wtap + (int64_t)kr * GBK) * 2));
+      for (int pl = 0; pl < NWL; ++pl) rwt[pl] = buf_ld4(rw, voffW, (unsigned)((pl * wplane + tap * wtap + (int64_t)kr * GBK) * 2));
       const int ih = ihb + ky, iw = iwb + kx;
       const bool ok = rowok && (unsigned)ih < (unsigned)a.h0 && (unsigned)iw < (unsigned)a.w0;  // (zero padding: reads zeros)
       const int pix = (pb_l + ih) * a.w0 + iw;
@@ -1074,7 +1081,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
       rxa[1] = buf_ld4(r, ok ? vo + 16u : OOB, so);
     } else {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) rwt[pl] = buf_ld4(rw, voffW, (unsigned)((pl * wplane + (int64_t)kt * GBK) * 2));
+      for (int pl = 0; pl < NWL; ++pl) rwt[pl] = buf_ld4(rw, voffW, (unsigned)((pl * wplane + (int64_t)kt * GBK) * 2));
       const bool s1 = kt >= p.nkc0;  // (wave-uniform; selects, not a branch: the iteration stays one basic block)
       const __amdgpu_buffer_rsrc_t r = s1 ? rx1 : rx;
       const unsigned vo = s1 ? voffX1 : voffX, so = (unsigned)((s1 ? kt - p.nkc0 : kt) * GBK * 4);
@@ -1084,6 +1091,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
   };
   auto store_step = [&](int buf) __attribute__((always_inline)) {
     char* st = smem + buf * GSTAGE + lds_row;
+    if constexpr (H2) rwt[2] = __builtin_bit_cast(float4, __builtin_bit_cast(f16x8, rwt[0]) * (_Float16)0.00048828125f);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<float4*>(st + pl * GPLANE) = rwt[pl];
     const float x[8] = {rxa[0].x, rxa[0].y, rxa[0].z, rxa[0].w, rxa[1].x, rxa[1].y, rxa[1].z, rxa[1].w};
@@ -1159,14 +1167,14 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
       }
     } else {
       // half as many matrix instructions for the same staging: the three weight planes' stores (no arithmetic in front of them)
-      // early, the split (28 vector instructions) three to a gap, the two activation stores behind it, the 5 loads last
+      // early, the split (28 vector instructions) three to a gap, the two activation stores behind it, the 4 loads last
       __builtin_amdgcn_sched_group_barrier(0x100, 3 * NCT + 4, 0);  // DS reads
 #pragma unroll
       for (int k = 0; k < NM; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
         if (k < NM - 6) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // three vector instructions
         if (k == 1 || k == 3 || k == 5 || k == NM - 9 || k == NM - 7) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS store
-        if (k >= NM - 6 && k < NM - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // a buffer load
+        if (k >= NM - 5 && k < NM - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // a buffer load (four: the third weight plane is derived)
       }
     }
     // (measured alternatives: the staging ten MFMAs later 388 vs 371 us, one vector instruction per gap all along 380, on 16384 x 768 -> 3072;

@@ -276,7 +276,16 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
   // the wave's filter fragments of (step kt, its frequency f, piece pl): both cout halves, rows = couts ch * 32 + l31,
   // k = 8 h .. 8 h + 7 of the step -- two contiguous 1 KB loads
   const unsigned u_lane = (unsigned)(lane * 16);
+  // H2: the third piece of a filter value, uh / 2^11, is the first with another exponent: derived here by four v_pk_mul_f16 per
+  // fragment (the same rounding as the packing's, bit for bit) instead of loaded -- 8 instead of 12 KB of filter per wave and step
+  // through the vector memory path, which a step's 144 KB (filter + gather) load as much as its matrix instructions load the pipe
+  constexpr bool H2_DERIVE = true;
   uint4 ua[2][3];  // [cout half][piece]
+  typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+  auto derive_u2 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) ua[ch][2] = __builtin_bit_cast(uint4, __builtin_bit_cast(f16x8v, ua[ch][0]) * (_Float16)0.00048828125f);
+  };
   auto load_u = [&](int kt, int f, int pl) __attribute__((always_inline)) {
     const unsigned soff =  // (wave-uniform, but derived from threadIdx: readfirstlane makes it a scalar operand)
         (unsigned)__builtin_amdgcn_readfirstlane((int)((((int64_t)kt * p.cblocks + cb) * 8 + wave) * (12 * 1024) + f * (6 * 1024)));
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
         mf(hs, 3); gl(ktn, 0); gl(ktn, 1); gl(ktn, 2); load_u(ktu, ob, 1); XS_FENCE;  // (a1 is free: the next phase's a1)
         mf(hs, 4); gl(ktn, 3); gl(ktn, 4); gl(ktn, 5); XS_FENCE;
         mf(hs, 5); l_piece(0); XS_FENCE;
-        mf(hs, 6); l_piece(1); XS_FENCE;
+        mf(hs, 6); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;
         mf(hs, 7); load_u(ktu, ob, 0); XS_FENCE;  // (a0 is free)
         mf(hs, 8); gs(0); gs(1); XS_FENCE;
         mf(hs, 9); gs(2); gs(3); XS_FENCE;
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
         mf(hs, 1); patch_rows(ktn, 0, 2); XS_FENCE;
         mf(hs, 2); patch_rows(ktn, 2, 4); XS_FENCE;
         mf(hs, 3); l_piece(0); load_u(ktu, ob, 1); XS_FENCE;
-        mf(hs, 4); l_piece(1); XS_FENCE;
+        mf(hs, 4); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;
         affine();
         mf(hs, 5); row_transform(0); row_transform(1); XS_FENCE;
         mf(hs, 6); row_transform(2); row_transform(3); XS_FENCE;
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
         mf(hs, 10); nu_store(ob, 2); XS_FENCE;
         mf(hs, 11); nu_store(ob, 3);
       }
-      load_u(ktu, ob, 2);
+      if constexpr (!H2_DERIVE) load_u(ktu, ob, 2);
     } else {
     piece(0, 0); XS_FENCE;
     if constexpr (hs == 0) {
@@ -468,7 +477,8 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
     //  at the loop header are the stricter of the entry's and the back edge's; with the pieces in ascending order the entry made
     //  the first two products of EVERY step wait for all outstanding filter loads -- vmcnt(2) / vmcnt(0) instead of 5 / 4)
     if constexpr (H2) {
-      XS_FENCE; load_u(kt_begin, 0, 1); XS_FENCE; load_u(kt_begin, 0, 0); XS_FENCE; load_u(kt_begin, 0, 2); XS_FENCE;
+      XS_FENCE; load_u(kt_begin, 0, 1); XS_FENCE; load_u(kt_begin, 0, 0); XS_FENCE;
+      if constexpr (!H2_DERIVE) { load_u(kt_begin, 0, 2); XS_FENCE; }
     } else {
       XS_FENCE; load_u(kt_begin, 0, 2); XS_FENCE; load_u(kt_begin, 0, 1); XS_FENCE; load_u(kt_begin, 0, 0); XS_FENCE;
     }

@@ -122,7 +122,7 @@ class Pool:
 class Act:
     r"""An NHWC activation: ``buf`` holds (B, H, W, cs) floats, ``C`` real channels."""
 
-    __slots__ = ("buf", "B", "H", "W", "C", "cs", "pinned", "gn_quads", "affine", "qk_prepared")
+    __slots__ = ("buf", "B", "H", "W", "C", "cs", "pinned", "gn_quads", "affine", "qk_prepared", "bounded")
 
     @property
     def half(self) -> bool:
@@ -131,6 +131,12 @@ class Act:
 
     def __init__(self, buf: torch.Tensor, B: int, H: int, W: int, C_: int, cs: int, pinned: bool = False) -> None:
         self.buf, self.B, self.H, self.W, self.C, self.cs, self.pinned = buf, B, H, W, C_, cs, pinned
+        # bounded: the magnitudes in this tensor do not scale with the sampler's state -- it is the output of a normalisation, or of
+        # convolutions / attention over such outputs without a residual add (bounded by the WEIGHTS).  The f16x2 kernels, whose
+        # activation operand has a stated range (|x| < ~1e6, include/azula_amd.h), are chosen only for bounded inputs; residual /
+        # input streams (which grow with x_t: an unstable multistep sampler reaches 1e7 in tests/test_gpu_unet.py) go through
+        # the bf16x3 kernels, whose domain is all of fp32.  Default False: unknown = unbounded.
+        self.bounded = False
         self.gn_quads = None  # (partials tensor, chunks per image): GroupNorm moments written by the producing conv
         self.qk_prepared = False  # a fused qkv projection whose q / k are already normalised / gained / rotated (AzConvArgs.act = 5)
         self.affine = None    # ([scale | shift] tensor, act): a normalisation whose apply pass has not run -- the values are
@@ -504,7 +510,8 @@ class Builder:
                 and cin_s >= X3_MIN_CHANNELS and a.cout_s >= X3_MIN_CHANNELS)
         )
         # (winograd = "x3" / "wx3": the bf16x3 kernels, "h2" / "wh2": the f16x2 ones, whatever the mode -- kernel tests)
-        h2 = winograd in ("h2", "wh2") or (winograd not in ("x3", "wx3") and FP32_MFMA == "f16x2")
+        src_bounded = (src0.bounded or src0.affine is not None) and (src1 is None or src1.bounded)  # (a pending normalisation is applied in the gather / materialised)
+        h2 = winograd in ("h2", "wh2") or (winograd not in ("x3", "wx3") and FP32_MFMA == "f16x2" and src_bounded)
         if use_f4:
             a.weight = packed.winograd4().data_ptr()
             a.splitk = lib.az_conv2d_winograd4_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
@@ -599,6 +606,8 @@ class Builder:
         self.tape.add(name, C.byref(a), keep=[a] if gate is None else [gate, a])  # the descriptor holds raw addresses
         if tmp_src is not None:
             self.free(tmp_src)
+        if out is not None:
+            out.bounded = src_bounded and res is None  # (a residual add joins the unbounded stream)
         return out
 
     def conv_stem(self, x: torch.Tensor, B: int, cin: int, H: int, W: int, packed: "ConvWeights", cout: int, *,
@@ -630,6 +639,7 @@ class Builder:
         r"""``narrow(Upsample(scale_factor=(sh, sw), mode="nearest")(x), (hout, wout))`` as a pass of its own -- only for
         factors that are not powers of two (those are a shift inside the consuming convolution's gather)."""
         y = self.new_act(x.B, hout, wout, x.C)
+        y.bounded = x.bounded
         self.tape.add("az_upsample_nearest_f32", y.ptr, x.ptr, x.B, x.H, x.W, x.cs, sh, sw, hout, wout)
         return y
 
@@ -652,6 +662,7 @@ class Builder:
         ST, act = x.affine
         n = x.B * x.cs
         y = self.new_act(x.B, x.H, x.W, x.C, f32=not x.half)
+        y.bounded = True
         self._affine_act(y, x, None, 0, ST.data_ptr(), ST.data_ptr() + 4 * n, x.B, x.H, x.W, x.cs, act, 0)
         return y
 
@@ -712,17 +723,20 @@ class Builder:
             # no apply pass: the consumer (Builder.conv) reads x and applies scale / shift itself
             y = Act(x.buf, B, x.H, x.W, x.C, x.cs, True)
             y.affine = (ST, act)
+            y.bounded = True  # (the values the consumer sees: act(buf * scale + shift))
             return y
         if pool:  # 1: 2x2, 2: along the width only (a 1-D signal held as a one-row image)
             y = self.new_act(B, x.H // 2 if pool == 1 else x.H, x.W // 2, x.C, f32=not x.half)
         else:
             y = self.new_act(B, x.H, x.W, x.C, f32=not x.half)
         self._affine_act(y, x, x1p, c0s, S.data_ptr(), T.data_ptr(), B, x.H, x.W, x.cs, act, pool)
+        y.bounded = True
         return y
 
     def row_norm(self, x: Act, kind: int, *, weight=None, scale=None, shift=None, scale_off=0, shift_off=0, bstride=0,
                  eps=1e-5):
         y = self.new_act(x.B, x.H, x.W, x.C, f32=not x.half)
+        y.bounded = True
         rows = x.B * x.H * x.W
         args = (y.ptr, x.ptr, weight.data_ptr() if weight is not None else None,
                 scale.data_ptr() + 4 * scale_off if scale is not None else None,
@@ -851,6 +865,7 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
     assert qkv.cs == qkv.C and dim * heads == Cq
     L = qkv.H * qkv.W
     out = self.new_act(qkv.B, qkv.H, qkv.W, Cq, f32=not qkv.half)
+    out.bounded = qkv.bounded  # (a convex combination of the values)
     a = AzAttnArgs()
     a.io_dtype = int(qkv.half)  # (q, k, v, out in the module's 2-byte type: the bf16 / f16 entries only)
     es = 2 if qkv.half else 4
@@ -894,7 +909,7 @@ def _builder_attention(self, qkv: Act, heads: int, order: str, qk_rmsnorm: bool,
     if self.half is None and pieces() and ATTN_X3 and dim in (16, 32, 64, 80):
         # the two contractions as 3 x bf16 pieces / 6 partial products: fp32 accuracy, 0.375 x the pipe time (64 x 12 heads x 256
         # tokens x 64: 140 -> 111 us; head_dim 128 needs one wave per SIMD there and measured slower, 458 vs 516 us: fp32 kernel)
-        name = "az_attention_f16x2_f32" if FP32_MFMA == "f16x2" and ATTN_H2 else "az_attention_x3_f32"
+        name = "az_attention_f16x2_f32" if FP32_MFMA == "f16x2" and ATTN_H2 and qkv.bounded else "az_attention_x3_f32"
     if self.half is not None:  # module cast to half precision: contractions on the bf16 / f16 MFMA
         name = "az_attention_f16_f32" if self.half == torch.float16 else "az_attention_bf16_f32"
     self.tape.add(name, C.byref(a), keep=[a])

@@ -168,6 +168,7 @@ class ADMPlan:
             if a is None or not three_d:
                 return a
             v = Act(a.buf, B, D * a.H, a.W, a.C, a.cs, True)
+            v.bounded = a.bounded
             if a.gn_quads is not None:
                 v.gn_quads = (a.gn_quads[0], D * a.gn_quads[1])
             return v
@@ -176,7 +177,9 @@ class ADMPlan:
             r"""Inverse of `vol` for a pass's result (pooled or not): B (D H') x W' images -> B D planes of H' x W'."""
             if not three_d:
                 return a
-            return Act(a.buf, PB, a.H // D, a.W, a.C, a.cs, a.pinned)
+            p_ = Act(a.buf, PB, a.H // D, a.W, a.C, a.cs, a.pinned)
+            p_.bounded = a.bounded
+            return p_
 
         def group_norm(x: Act, *args, x1: Act | None = None, **kw) -> Act:
             return planes(bld.group_norm(vol(x), *args, x1=vol(x1), **kw))
@@ -315,6 +318,7 @@ class ADMPlan:
             Cc = ab.channels
             n_ = group_norm(x, 32, weight=bld.const(ab.norm.weight), bias=bld.const(ab.norm.bias))
             tok = Act(n_.buf, B, D * n_.H * n_.W, 1, Cc, n_.cs, True)
+            tok.bounded = n_.bounded  # (the normalised tokens: the same memory)
             ch = Cc // ab.num_heads
             chp = engine.attn_padded_dim(ch, bld.half)
             order = "3HC" if ab.new_order else "H3C"
