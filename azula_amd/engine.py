@@ -157,17 +157,23 @@ WINOGRAD = os.environ.get("AZ_WINOGRAD", "1")
 # (az_conv2d_x3_f32) -- measured MORE accurate against fp64 than the fp32 MFMA (tests/test_gpu_kernels.py::
 # test_conv2d_x3_accuracy) at 0.375 x its matrix-pipe time: DiT-B/2 54.7 -> 70.1 images/s, JiT-B/16 43.6 -> 58.4.
 # "native": v_mfma_f32_32x32x2_f32 everywhere.  The stride-1 3 x 3 convolutions run the Winograd kernel in both modes (bf16x3: WINO_X3 below).
-# "f16x2": every fp32 operand as TWO IEEE half pieces (activations: h and the residual scaled by 2^11, of x / 16; weights: wh, wl
-# and wh / 2^11 of w times a power of two fixed at pack time), three partial products on v_mfma_f32_32x32x16_f16 in one fp32
-# accumulator -- half the matrix instructions of bf16x3 at the accuracy of the fp32 MFMA (include/azula_amd.h: az_conv2d_f16x2_f32),
-# on a STATED domain: activations below ~1e6 in magnitude (beyond it NaN, never a wrong finite value).
-FP32_MFMA = os.environ.get("AZ_FP32_MFMA", "bf16x3")
+# "f16x2" (default since round 6): every fp32 operand as TWO IEEE half pieces (activations: h and the residual scaled by 2^11, of
+# x / 16; weights: wh, wl and wh / 2^11 of w times a power of two fixed at pack time), three partial products on
+# v_mfma_f32_32x32x16_f16 in one fp32 accumulator -- half the matrix instructions of bf16x3, measured the MOST accurate of the
+# modes against fp64 (half as many fp32 accumulation steps: rms 5.2e-7 against 6.7e-7 bf16x3 / 7.5e-7 fp32 MFMA on the K = 2304
+# layer of test_conv2d_x3_accuracy), on a STATED range of its activation operand, |x| < ~1e6 (beyond it NaN, never a wrong finite
+# value: include/azula_amd.h).  It therefore takes only BOUNDED inputs (Act.bounded: outputs of normalisations and of
+# convolutions / attention over them); layers that read the residual / input stream run the bf16x3 kernels in this mode too.
+# C2 16.95 -> 15.2 ms per denoise step, C3 85 -> 107+ images/s, C5 32.1 -> 28.5 ms, C6 63.6 -> 84 images/s (profiles/r06_f16x2_gate*.txt).
+FP32_MFMA = os.environ.get("AZ_FP32_MFMA", "f16x2")
 assert FP32_MFMA in ("native", "bf16x3", "f16x2"), FP32_MFMA
 
 
 def pieces() -> bool:
     r"""fp32 operands as 2-byte pieces on the bf16 / f16 pipe (read per plan: bench.py flips FP32_MFMA between plans)."""
     return FP32_MFMA in ("bf16x3", "f16x2")
+
+
 ATTN_H2 = os.environ.get("AZ_ATTN_H2", "1") != "0"  # f16x2 mode: the attention contractions in that form too ("0": bf16x3 attention -- A/B)
 ATTN_X3 = os.environ.get("AZ_ATTN_X3", "1") != "0"  # bf16x3 mode: attention contractions on the bf16 pipe too (az_attention_x3_f32)
 # The stride-1 3 x 3 layers in bf16x3 mode: "1" (default since round 5) = the Winograd kernel with its 16 frequency GEMMs on the bf16 pipe
@@ -607,7 +613,7 @@ class Builder:
         if tmp_src is not None:
             self.free(tmp_src)
         if out is not None:
-            out.bounded = src_bounded and res is None  # (a residual add joins the unbounded stream)
+            out.bounded = src_bounded and (res is None or res.bounded)  # (a residual add of the stream joins the stream; of a bounded tensor -- y + MSA(y) of a DiT block -- stays bounded)
         return out
 
     def conv_stem(self, x: torch.Tensor, B: int, cin: int, H: int, W: int, packed: "ConvWeights", cout: int, *,

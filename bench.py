@@ -681,30 +681,35 @@ def main() -> None:
         out["tolerance"] = tolerance_statement(args)
         out.update(roofline_report(sampler, device, args, world, ms_per_step / cfg["steps"]))
         if _engine.FP32_MFMA != "native" and not args.half and world == 1 and not args.no_native_line:
-            # the native-fp32-MFMA line beside the bf16x3 one (reviewer's condition iii): the same workload with every contraction
-            # on v_mfma_f32_32x32x2_f32, two samplings after one warm-up, same process
+            # the other modes beside the one that was timed (reviewer's conditions: the all-native line since round 3; both piece modes
+            # since f16x2 became selectable): the same workload, same seed, two samplings after one warm-up, same process
             mode_was = _engine.FP32_MFMA
-            _engine.FP32_MFMA = "native"
-            try:
-                den_n = build_denoiser(cfg, device)
-                smp_n = Smp(den_n, steps=cfg["steps"], silent=True)
-                torch.manual_seed(1)
-                x1n = init_sharded(smp_n, (B, *cfg["shape"]), device=device)
-                sample_sharded(smp_n, x1n, **kwargs)
-                torch.cuda.synchronize(device)
-                t0 = time.perf_counter()
-                for _ in range(2):
-                    x0n = sample_sharded(smp_n, x1n, **kwargs)
-                torch.cuda.synchronize(device)
-                dtn = (time.perf_counter() - t0) / 2
-                out["native_fp32_mfma"] = {
-                    "value": round(B / dtn, 4), "unit": "images/s", "ms_per_denoise_step": round(dtn * 1e3 / cfg["steps"], 3),
-                    "max_abs_difference_of_x0": float((x0n - x0[:B]).abs().max()),
-                    "note": "AZ_FP32_MFMA=native: every contraction on v_mfma_f32_32x32x2_f32 (the round-3 headline mode), 2 samplings, same seed",
-                }
-                del den_n, smp_n, x1n, x0n
-            finally:
-                _engine.FP32_MFMA = mode_was
+            notes = {"native": ("native_fp32_mfma", "AZ_FP32_MFMA=native: every contraction on v_mfma_f32_32x32x2_f32 (the round-3 headline mode)"),
+                     "bf16x3": ("bf16x3_mode", "AZ_FP32_MFMA=bf16x3: every fp32 operand as three exact bf16 pieces, six partial products (the default of rounds 4 - 6a)"),
+                     "f16x2": ("f16x2_mode", "AZ_FP32_MFMA=f16x2: fp32 operands as two half pieces, three partial products, on bounded inputs")}
+            for other in [m for m in ("bf16x3", "f16x2", "native") if m != mode_was]:
+                _engine.FP32_MFMA = other
+                try:
+                    den_n = build_denoiser(cfg, device)
+                    smp_n = Smp(den_n, steps=cfg["steps"], silent=True)
+                    torch.manual_seed(1)
+                    x1n = init_sharded(smp_n, (B, *cfg["shape"]), device=device)
+                    sample_sharded(smp_n, x1n, **kwargs)
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    for _ in range(2):
+                        x0n = sample_sharded(smp_n, x1n, **kwargs)
+                    torch.cuda.synchronize(device)
+                    dtn = (time.perf_counter() - t0) / 2
+                    out[notes[other][0]] = {
+                        "value": round(B / dtn, 4), "unit": "images/s", "ms_per_denoise_step": round(dtn * 1e3 / cfg["steps"], 3),
+                        "max_abs_difference_of_x0": float((x0n - x0[:B]).abs().max()),
+                        "note": notes[other][1] + ", 2 samplings, same seed",
+                    }
+                    del den_n, smp_n, x1n, x0n
+                    torch.cuda.empty_cache()
+                finally:
+                    _engine.FP32_MFMA = mode_was
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(den, cfg)
             out["speedup_vs_cpu"] = round(images_per_s / out["cpu_baseline"]["value"], 1)
@@ -800,7 +805,10 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
                               "algorithmic (direct) count has 9; frac = executed MFMA FLOP/s / the fp32 MFMA peak")
         kn = KERNEL_OF.get(fam)
         if pmc and kn:
-            hit = [v for name, v in pmc.get("forward", {}).items() if re.search(r"(^|::|\s)(?:" + kn.replace(" / ", "|") + r")[(<]", name)]
+            # (the bf16x3 and f16x2 forms are instantiations of the same kernels: the last template argument, H2, tells them apart)
+            h2 = {6: False, 3: True}.get(nprod)
+            hit = [v for name, v in pmc.get("forward", {}).items() if re.search(r"(^|::|\s)(?:" + kn.replace(" / ", "|") + r")[(<]", name)
+                   and (h2 is None or bool(re.search(r"true>\(", name)) == h2)]
             if hit:
                 k["traffic"] = round(sum(h["traffic_bytes_per_forward"] for h in hit) / sum(h["launches_per_forward"] for h in hit))
                 k["traffic_per_denoise_step"] = round(sum(h["traffic_bytes_per_forward"] for h in hit))

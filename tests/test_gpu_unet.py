@@ -168,6 +168,34 @@ def test_unet_forward_through_bf16x3(golden, monkeypatch, mode, entry):
         assert err < 1e-4 * max(1.0, sc)
 
 
+def test_f16x2_runs_only_on_bounded_inputs(golden, monkeypatch):
+    """AZ_FP32_MFMA=f16x2: the kernels whose activation operand has a stated range (|x| < ~1e6) take only inputs whose magnitude does
+    not scale with the state -- outputs of normalisations and of convolutions over them (engine.Act.bounded); the layers that read
+    the residual / input stream stay on the bf16x3 kernels, whose domain is all of fp32.  So a state of 1e7 (an unstable multistep
+    sampler produces one in test_multistep_and_pc_samplers_on_gpu) goes through: finite, equal to the bf16x3 plan's result."""
+    from azula_amd import engine
+
+    monkeypatch.setattr(engine, "X3_MIN_CHANNELS", 4)  # the golden UNet is narrow
+    monkeypatch.setattr(engine, "WINOGRAD", "2")
+    g = golden("g5_unet_group")
+    cfg = g.meta["cfg"]
+    outs = {}
+    for mode in ("bf16x3", "f16x2"):
+        monkeypatch.setattr(engine, "FP32_MFMA", mode)
+        net = build_unet(cfg)
+        net.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in g.meta["shapes"].items()}, g.meta["weight_seed"]))
+        net = net.cuda().eval()
+        outs[mode] = [net(g["x"].cuda() * s, g["modB"].cuda()) for s in (1.0, 1.0e7)]
+        names = [n for _, _, n in next(iter(net._plans.values())).tape.ops]
+        if mode == "f16x2":  # both families on one tape: f16x2 behind the norms, bf16x3 on the stream
+            assert any(n.endswith("f16x2_f32") for n in names) and any(n in ("az_conv2d_x3_f32", "az_conv2d_winograd_x3_f32") for n in names), names
+    for a, b in zip(outs["f16x2"], outs["bf16x3"]):
+        assert torch.isfinite(a).all()
+        sc = b.abs().max().item()
+        print("f16x2 vs bf16x3 plan:", max_err(a, b), "scale", sc)
+        assert max_err(a, b) < 2e-5 * sc
+
+
 def test_next_samplers_on_gpu(golden):
     """Euler and Ito ride the fused transition kernel (folded coefficients); Heun is a two-evaluation step
     captured as ONE graph (two table rows per step); all against reference-generated vectors (G8)."""

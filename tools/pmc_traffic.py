@@ -174,11 +174,11 @@ def workload(args) -> None:
         # compulsory bytes of the Winograd launches: every input, filter, residual and output element once
         comp = 0
         for d in convs:
-            if d._algo not in ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32"):
+            if d._algo not in ("az_conv2d_winograd_f32", "az_conv2d_winograd_x3_f32", "az_conv2d_winograd_f16x2_f32"):
                 continue
             npix_in = d.batch * d.h0 * d.w0 * d.c0s + (d.batch * d.h1 * d.w1 * d.c1s if d.src1 else 0)
             npix_out = d.batch * d.hout * d.wout * d.cout_s
-            filt = 16 * d.cout_s * (d.c0s + d.c1s)  # (x3: three bf16 pieces per value = 6 bytes)
+            filt = 16 * d.cout_s * (d.c0s + d.c1s)  # (x3: three bf16 pieces per value = 6 bytes; f16x2: two half pieces are READ, the third is derived = 4 bytes)
             comp += 4 * (npix_in + npix_out + (npix_out if d.res else 0)) + (6 if d._algo.endswith("_x3_f32") else 4) * filt
         manifest["winograd_compulsory_bytes_per_forward"] = comp
     with open(args.manifest, "w") as f:
