@@ -76,9 +76,10 @@ __device__ __forceinline__ float az_wave_max(float v) {
 // the "bf16x3" kernels, which evaluate a product as the six largest of the nine partial products on v_mfma_f32_32x32x16_bf16
 // with fp32 accumulation (conv.hip, wino_x3.hip, attention.hip).  Two values per call; p1 / p2 / p3 = the packed (x1, x0) pairs of the pieces.
 // Domain: FINITE inputs.  x = +-Inf gives Inf - Inf = NaN remainders (an Inf operand turns into NaN where the fp32 MFMA would
-// propagate Inf; NaN stays NaN), and the low pieces of operands below ~2^-110 are subnormal bf16 values, which the matrix pipe
-// flushes: such products keep ~16 instead of 24 significant bits (their absolute error is below 2^-126, far under any
-// accumulated sum of O(1) activations).  tests/test_gpu_kernels.py::test_x3_split_domain pins both statements.
+// propagate Inf; NaN stays NaN), and the low pieces of operands below ~2^-110 fall under the bf16 subnormal range: such
+// products keep ~16 instead of 24 significant bits (their absolute error is below 2^-126, far under any accumulated sum of O(1)
+// activations).  (The gfx950 matrix pipe HONOURS subnormal bf16 / fp16 operands -- tools/mfma_denorm_probe.hip, round 6; an
+// earlier version of this comment assumed a flush.)  tests/test_gpu_kernels.py::test_x3_split_domain pins both statements.
 __device__ __forceinline__ void az_split3(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
   const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
   const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);  // exact: the low 16 significand bits

@@ -214,6 +214,76 @@ VARIANTS["wx3h_mix"] = [("wino_x3.hip",
     "      asm(\"v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\" : \"+v\"(lw) : \"v\"(fw[th][0][j]), \"s\"(-2048.f), \"v\"(xf[th][2 * j + 1]));\n"
     "      fw[th][1][j] = lw;\n")]
 
+# ---- f16x2 form of the x3 Winograd kernel: slot-order experiments (RESULTS STAY CORRECT)
+_H2_P0_OLD = ("        mf(hs, 0); h_piece(1); XS_FENCE;\n"
+              "        mf(hs, 1); nu_store(ob, 0); nu_store(ob, 1); XS_FENCE;\n"
+              "        mf(hs, 2); nu_store(ob, 2); nu_store(ob, 3); XS_FENCE;  // (rv is free from here)\n"
+              "        mf(hs, 3); gl(ktn, 0); gl(ktn, 1); gl(ktn, 2); load_u(ktu, ob, 1); XS_FENCE;  // (a1 is free: the next phase's a1)\n"
+              "        mf(hs, 4); gl(ktn, 3); gl(ktn, 4); gl(ktn, 5); XS_FENCE;\n"
+              "        mf(hs, 5); l_piece(0); XS_FENCE;\n"
+              "        mf(hs, 6); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;\n"
+              "        mf(hs, 7); load_u(ktu, ob, 0); XS_FENCE;  // (a0 is free)\n"
+              "        mf(hs, 8); gs(0); gs(1); XS_FENCE;\n"
+              "        mf(hs, 9); gs(2); gs(3); XS_FENCE;\n"
+              "        mf(hs, 10); gs(4); gs(5); XS_FENCE;\n"
+              "        mf(hs, 11);\n")
+_H2_P1_OLD = ("        mf(hs, 0); h_piece(1); affine_load(ktn); XS_FENCE;\n"
+              "        mf(hs, 1); patch_rows(ktn, 0, 2); XS_FENCE;\n"
+              "        mf(hs, 2); patch_rows(ktn, 2, 4); XS_FENCE;\n"
+              "        mf(hs, 3); l_piece(0); load_u(ktu, ob, 1); XS_FENCE;\n"
+              "        mf(hs, 4); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;\n"
+              "        affine();\n"
+              "        mf(hs, 5); row_transform(0); row_transform(1); XS_FENCE;\n"
+              "        mf(hs, 6); row_transform(2); row_transform(3); XS_FENCE;\n"
+              "        mf(hs, 7); load_u(ktu, ob, 0); XS_FENCE;\n"
+              "        mf(hs, 8); nu_store(ob, 0); XS_FENCE;\n"
+              "        mf(hs, 9); nu_store(ob, 1); XS_FENCE;\n"
+              "        mf(hs, 10); nu_store(ob, 2); XS_FENCE;\n"
+              "        mf(hs, 11); nu_store(ob, 3);\n")
+# (a) two products per slot: half the fences, the compiler orders inside a slot
+VARIANTS["wx3h_2mf"] = [
+    ("wino_x3.hip", _H2_P0_OLD,
+     "        mf(hs, 0); mf(hs, 1); h_piece(1); nu_store(ob, 0); nu_store(ob, 1); XS_FENCE;\n"
+     "        mf(hs, 2); mf(hs, 3); nu_store(ob, 2); nu_store(ob, 3); gl(ktn, 0); gl(ktn, 1); gl(ktn, 2); load_u(ktu, ob, 1); XS_FENCE;\n"
+     "        mf(hs, 4); mf(hs, 5); gl(ktn, 3); gl(ktn, 4); gl(ktn, 5); l_piece(0); XS_FENCE;\n"
+     "        mf(hs, 6); mf(hs, 7); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); load_u(ktu, ob, 0); XS_FENCE;\n"
+     "        mf(hs, 8); mf(hs, 9); gs(0); gs(1); gs(2); gs(3); XS_FENCE;\n"
+     "        mf(hs, 10); mf(hs, 11); gs(4); gs(5);\n"),
+    ("wino_x3.hip", _H2_P1_OLD,
+     "        mf(hs, 0); mf(hs, 1); h_piece(1); affine_load(ktn); patch_rows(ktn, 0, 2); XS_FENCE;\n"
+     "        mf(hs, 2); mf(hs, 3); patch_rows(ktn, 2, 4); l_piece(0); load_u(ktu, ob, 1); XS_FENCE;\n"
+     "        mf(hs, 4); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;\n"
+     "        affine();\n"
+     "        mf(hs, 5); row_transform(0); row_transform(1); XS_FENCE;\n"
+     "        mf(hs, 6); mf(hs, 7); row_transform(2); row_transform(3); load_u(ktu, ob, 0); XS_FENCE;\n"
+     "        mf(hs, 8); mf(hs, 9); nu_store(ob, 0); nu_store(ob, 1); XS_FENCE;\n"
+     "        mf(hs, 10); mf(hs, 11); nu_store(ob, 2); nu_store(ob, 3);\n")]
+# (b) the staging loads of the next step right behind the first product (longer cover before their LDS stores), the V stores behind them
+VARIANTS["wx3h_earlygl"] = [
+    ("wino_x3.hip", _H2_P0_OLD,
+     "        mf(hs, 0); h_piece(1); XS_FENCE;\n"
+     "        mf(hs, 1); nu_store(ob, 0); nu_store(ob, 1); XS_FENCE;\n"
+     "        mf(hs, 2); nu_store(ob, 2); nu_store(ob, 3); gl(ktn, 0); gl(ktn, 1); gl(ktn, 2); XS_FENCE;\n"
+     "        mf(hs, 3); gl(ktn, 3); gl(ktn, 4); gl(ktn, 5); load_u(ktu, ob, 1); XS_FENCE;\n"
+     "        mf(hs, 4); l_piece(0); XS_FENCE;\n"
+     "        mf(hs, 5); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;\n"
+     "        mf(hs, 6); XS_FENCE;\n"
+     "        mf(hs, 7); load_u(ktu, ob, 0); XS_FENCE;\n"
+     "        mf(hs, 8); gs(0); XS_FENCE;\n"
+     "        mf(hs, 9); gs(1); gs(2); XS_FENCE;\n"
+     "        mf(hs, 10); gs(3); gs(4); XS_FENCE;\n"
+     "        mf(hs, 11); gs(5);\n")]
+# (c) no fences at all in the f16x2 phases: the compiler's own order
+VARIANTS["wx3h_nofence"] = [
+    ("wino_x3.hip", "    if constexpr (H2) {\n      // 12 products per phase; the producer side is the same work as below, two slots' worth per slot\n",
+     "    if constexpr (H2) {\n#undef XS_FENCE\n#define XS_FENCE (void)0\n"),
+    ("wino_x3.hip", "      if constexpr (!H2_DERIVE) load_u(ktu, ob, 2);\n    } else {\n",
+     "      if constexpr (!H2_DERIVE) load_u(ktu, ob, 2);\n#undef XS_FENCE\n#define XS_FENCE __builtin_amdgcn_sched_barrier(0)\n    } else {\n")]
+# ---- f16x2 form of the 256 x 256 GEMM: issue-pattern experiments
+_H2G_OLD = "        if (k < NM - 6) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // three vector instructions\n"
+VARIANTS["h2big_valu2"] = [("conv.hip", _H2G_OLD, "        if (k < NM - 4) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);\n")]
+VARIANTS["h2big_valu4"] = [("conv.hip", _H2G_OLD, "        if (k < NM - 10) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);\n")]
+
 
 def build(name: str, patches=None, regen_env=None, head_files=None) -> str:
     r"""`patches`: a substitution list instead of VARIANTS[name]; `regen_env`: generator overrides (KL_* / KG_*) -- the copy's
