@@ -374,18 +374,20 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
       // 12 products per phase; the producer side is the same work as below, two slots' worth per slot
       h_piece(0); XS_FENCE;
       if constexpr (hs == 0) {
+        // (the staging loads of the next step as early as rv allows and their LDS stores spread over the last four slots: the
+        //  longest cover for the loads -- measured against three other orders, profiles/r06_f16x2_sched_ab.txt: - 2.4 ... - 3 %)
         mf(hs, 0); h_piece(1); XS_FENCE;
         mf(hs, 1); nu_store(ob, 0); nu_store(ob, 1); XS_FENCE;
-        mf(hs, 2); nu_store(ob, 2); nu_store(ob, 3); XS_FENCE;  // (rv is free from here)
-        mf(hs, 3); gl(ktn, 0); gl(ktn, 1); gl(ktn, 2); load_u(ktu, ob, 1); XS_FENCE;  // (a1 is free: the next phase's a1)
-        mf(hs, 4); gl(ktn, 3); gl(ktn, 4); gl(ktn, 5); XS_FENCE;
-        mf(hs, 5); l_piece(0); XS_FENCE;
-        mf(hs, 6); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;
+        mf(hs, 2); nu_store(ob, 2); nu_store(ob, 3); gl(ktn, 0); gl(ktn, 1); gl(ktn, 2); XS_FENCE;  // (rv is free from here)
+        mf(hs, 3); gl(ktn, 3); gl(ktn, 4); gl(ktn, 5); load_u(ktu, ob, 1); XS_FENCE;  // (a1 is free: the next phase's a1)
+        mf(hs, 4); l_piece(0); XS_FENCE;
+        mf(hs, 5); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;
+        mf(hs, 6); XS_FENCE;
         mf(hs, 7); load_u(ktu, ob, 0); XS_FENCE;  // (a0 is free)
-        mf(hs, 8); gs(0); gs(1); XS_FENCE;
-        mf(hs, 9); gs(2); gs(3); XS_FENCE;
-        mf(hs, 10); gs(4); gs(5); XS_FENCE;
-        mf(hs, 11);
+        mf(hs, 8); gs(0); XS_FENCE;
+        mf(hs, 9); gs(1); gs(2); XS_FENCE;
+        mf(hs, 10); gs(3); gs(4); XS_FENCE;
+        mf(hs, 11); gs(5);
       } else {
         mf(hs, 0); h_piece(1); affine_load(ktn); XS_FENCE;
         mf(hs, 1); patch_rows(ktn, 0, 2); XS_FENCE;

@@ -738,16 +738,41 @@ TOLERANCE["c4"] = dict(TOLERANCE["c5"], where="tests/test_gpu_adm.py::test_adm_d
                                                 "4.8e-7 rms) + tests/test_gpu_fullwidth.py::test_adm_256_widths_ddpm_against_the_oracle (3.0e-5)",
                        measured_max_abs_err=3.0e-5, scale=1.04)
 TOLERANCE["c5cfg"] = TOLERANCE["c5cfg32"] = dict(TOLERANCE["c5"], where=TOLERANCE["c5"]["where"] + "; CFG batch independence 2.2e-4 (tests/test_gpu_fullsize.py)")
+# the same tests measured with f16x2 as the mode of fp32 modules (the default since round 6; profiles/r06_f16x2_gate4.txt): what replaces
+# `measured_max_abs_err` / `full_resolution` above when that mode was timed (the entries above are the bf16x3 runs)
+TOLERANCE_F16X2 = {
+    "c2": dict(measured_max_abs_err=2.1e-6, full_resolution="3 x 256 x 256, batch 1: posterior mean 4.8e-7, DDIM-2 4.8e-7 on scale 1.3; sample 3 of batch 4 == its "
+                                                             "batch-1 evaluation to 3.3e-7 (tests/test_gpu_fullres.py)"),
+    "c3": dict(measured_max_abs_err=8.9e-7, where="tests/test_gpu_fullwidth.py::test_dit_b2_full_width_against_the_oracle: DDIM-3, DiT-B/2 at full width, batch 2 "
+                                                  "(posterior mean 7.2e-7); small ViT DDIM-50: 4.8e-6 on scale 13.2 (tests/test_gpu_vit.py)"),
+    "c5": dict(measured_max_abs_err=2.4e-4, where="tests/test_gpu_fullres.py::test_adm_256_at_full_resolution_against_the_oracle: DDIM-2 at 3 x 256 x 256 (backbone 4.2e-6 "
+                                                  "on scale 2.85); DDIM-64 of the small ADM: 6.0e-6 (tests/test_gpu_adm.py)"),
+    "c6": dict(measured_max_abs_err=2.9e-6),
+    "c4": dict(measured_max_abs_err=8.7e-5, where="tests/test_gpu_adm.py::test_adm_ddpm1000_full_length_matches_oracle (DDPM-1000, small ADM: 4.9e-6 max, 4.8e-7 rms) + "
+                                                  "tests/test_gpu_fullwidth.py::test_adm_256_widths_ddpm_against_the_oracle (8.7e-5)"),
+}
+TOLERANCE_F16X2["c5cfg"] = TOLERANCE_F16X2["c5cfg32"] = dict(TOLERANCE_F16X2["c5"])
 
 
 def tolerance_statement(args) -> dict:
+    from azula_amd import engine as _engine
+
     if args.half:  # the reference's own mixed-precision bar (tests/test_nn_unet.py:78-91), scaled x 8 for bf16's 3 fewer significand bits
         k = 1 if args.half == "f16" else 8
         return dict(stated=f"half vs fp32 forward on O(1) outputs: q99 < {1e-3 * k:g}, max < {1e-2 * k:g} (the reference's own test, x 8 for bf16)",
                     measured="ViT q99 5.4e-4 / 4.7e-3, max 6.4e-4 / 5.7e-3 (f16 / bf16); UNet in tests/test_gpu_half.py",
                     where="tests/test_gpu_half.py (half activations in HBM; typed kernels == the fp32-activation kernels rounded, bit for bit)")
     t = dict(TOLERANCE.get(args.config, dict(stated="max|x0 - reference| <= 1e-4 x max|x0|", where="tests/ (per-family GPU parity tests)")))
-    t["mode"] = "bf16x3 (exact 3 x bf16 operand splits, fp32 accumulate); stride-1 3x3 layers: Winograd F(2x2,3x3) on the split operands"
+    if _engine.FP32_MFMA == "f16x2":
+        t.update(TOLERANCE_F16X2.get(args.config, {}))
+        t["mode"] = ("f16x2 (fp32 operands as 2 x f16 pieces, 3 partial products, fp32 accumulate; error against fp64 on a K = 2304 layer: rms 5.2e-7 "
+                     "against 6.7e-7 for bf16x3 and 7.5e-7 for the fp32 MFMA, tests/test_gpu_kernels.py::test_conv2d_x3_accuracy) on bounded inputs -- "
+                     "outputs of normalisations and of convolutions / attention over them; layers reading the residual / input stream: bf16x3; "
+                     "stride-1 3x3 layers: Winograd F(2x2,3x3) on the pieces.  Stated range of the f16x2 activation operand: |x| < 1.0e6 (NaN beyond)")
+    elif _engine.FP32_MFMA == "bf16x3":
+        t["mode"] = "bf16x3 (exact 3 x bf16 operand splits, fp32 accumulate); stride-1 3x3 layers: Winograd F(2x2,3x3) on the split operands"
+    else:
+        t["mode"] = "native (v_mfma_f32_32x32x2_f32 everywhere); stride-1 3x3 layers: Winograd F(2x2,3x3), fp32 stream"
     return t
 
 
@@ -856,6 +881,13 @@ def roofline_report(sampler, device, args, world, graph_step_ms) -> dict:
           else "f16 v_mfma_f32_32x32x16_f16, 3 partial products per fp32 product" if dom["entry"] in PIECE_CONV
           else "fp32 v_mfma_f32_32x32x2_f32")
     roof["kernel"] = f"{dom['kernel']} ({mf}), all {dom['launches']} launches of one denoise step"
+    if dom["entry"] in ("az_conv2d_f16x2_f32", "az_conv2d_winograd_f16x2_f32"):
+        roof["frac_note"] = ("f16x2 executes HALF the matrix instructions of bf16x3 for the same algorithmic work, so `frac` (executed MFMA FLOP/s / the "
+                             "2-byte MFMA peak) is lower than the bf16x3 line's although the kernel is faster (compare `achieved`, algorithmic TF/s, and the "
+                             "`bf16x3_mode` line of this run).  What bounds the kernel is its non-matrix work under the 1400 W cap -- gather, transforms, "
+                             "splits, LDS and the filter stream (the vector-memory path moves 112 KB per 16-channel step of a Winograd block): "
+                             "profiles/r06_f16x2_*.txt, profiles/r05_wx3_energy_probes.txt (with every matrix instruction removed the bf16x3 form "
+                             "still took 651 of 987 us)")
     roof["note"] = ("achieved = ALGORITHMIC FLOP (2*pixels*Cout*Cin*k^2; attention 4*B*H*T^2*d) of the kernel's launches in one "
                     "denoise step / the sum of their HIP-event durations; traffic = HBM-side bytes per launch from rocprofv3 "
                     "FETCH_SIZE / WRITE_SIZE x the calibration factors measured in the same run")

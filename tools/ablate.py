@@ -217,16 +217,16 @@ VARIANTS["wx3h_mix"] = [("wino_x3.hip",
 # ---- f16x2 form of the x3 Winograd kernel: slot-order experiments (RESULTS STAY CORRECT)
 _H2_P0_OLD = ("        mf(hs, 0); h_piece(1); XS_FENCE;\n"
               "        mf(hs, 1); nu_store(ob, 0); nu_store(ob, 1); XS_FENCE;\n"
-              "        mf(hs, 2); nu_store(ob, 2); nu_store(ob, 3); XS_FENCE;  // (rv is free from here)\n"
-              "        mf(hs, 3); gl(ktn, 0); gl(ktn, 1); gl(ktn, 2); load_u(ktu, ob, 1); XS_FENCE;  // (a1 is free: the next phase's a1)\n"
-              "        mf(hs, 4); gl(ktn, 3); gl(ktn, 4); gl(ktn, 5); XS_FENCE;\n"
-              "        mf(hs, 5); l_piece(0); XS_FENCE;\n"
-              "        mf(hs, 6); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;\n"
+              "        mf(hs, 2); nu_store(ob, 2); nu_store(ob, 3); gl(ktn, 0); gl(ktn, 1); gl(ktn, 2); XS_FENCE;  // (rv is free from here)\n"
+              "        mf(hs, 3); gl(ktn, 3); gl(ktn, 4); gl(ktn, 5); load_u(ktu, ob, 1); XS_FENCE;  // (a1 is free: the next phase's a1)\n"
+              "        mf(hs, 4); l_piece(0); XS_FENCE;\n"
+              "        mf(hs, 5); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;\n"
+              "        mf(hs, 6); XS_FENCE;\n"
               "        mf(hs, 7); load_u(ktu, ob, 0); XS_FENCE;  // (a0 is free)\n"
-              "        mf(hs, 8); gs(0); gs(1); XS_FENCE;\n"
-              "        mf(hs, 9); gs(2); gs(3); XS_FENCE;\n"
-              "        mf(hs, 10); gs(4); gs(5); XS_FENCE;\n"
-              "        mf(hs, 11);\n")
+              "        mf(hs, 8); gs(0); XS_FENCE;\n"
+              "        mf(hs, 9); gs(1); gs(2); XS_FENCE;\n"
+              "        mf(hs, 10); gs(3); gs(4); XS_FENCE;\n"
+              "        mf(hs, 11); gs(5);\n")
 _H2_P1_OLD = ("        mf(hs, 0); h_piece(1); affine_load(ktn); XS_FENCE;\n"
               "        mf(hs, 1); patch_rows(ktn, 0, 2); XS_FENCE;\n"
               "        mf(hs, 2); patch_rows(ktn, 2, 4); XS_FENCE;\n"
@@ -258,21 +258,55 @@ VARIANTS["wx3h_2mf"] = [
      "        mf(hs, 6); mf(hs, 7); row_transform(2); row_transform(3); load_u(ktu, ob, 0); XS_FENCE;\n"
      "        mf(hs, 8); mf(hs, 9); nu_store(ob, 0); nu_store(ob, 1); XS_FENCE;\n"
      "        mf(hs, 10); mf(hs, 11); nu_store(ob, 2); nu_store(ob, 3);\n")]
-# (b) the staging loads of the next step right behind the first product (longer cover before their LDS stores), the V stores behind them
-VARIANTS["wx3h_earlygl"] = [
+# (b) the order of the first f16x2 builds: staging loads one slot later, their LDS stores two to a slot (the tree's order measured 2.4 - 3 % faster)
+VARIANTS["wx3h_lategl"] = [
     ("wino_x3.hip", _H2_P0_OLD,
      "        mf(hs, 0); h_piece(1); XS_FENCE;\n"
      "        mf(hs, 1); nu_store(ob, 0); nu_store(ob, 1); XS_FENCE;\n"
-     "        mf(hs, 2); nu_store(ob, 2); nu_store(ob, 3); gl(ktn, 0); gl(ktn, 1); gl(ktn, 2); XS_FENCE;\n"
-     "        mf(hs, 3); gl(ktn, 3); gl(ktn, 4); gl(ktn, 5); load_u(ktu, ob, 1); XS_FENCE;\n"
-     "        mf(hs, 4); l_piece(0); XS_FENCE;\n"
-     "        mf(hs, 5); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;\n"
+     "        mf(hs, 2); nu_store(ob, 2); nu_store(ob, 3); XS_FENCE;\n"
+     "        mf(hs, 3); gl(ktn, 0); gl(ktn, 1); gl(ktn, 2); load_u(ktu, ob, 1); XS_FENCE;\n"
+     "        mf(hs, 4); gl(ktn, 3); gl(ktn, 4); gl(ktn, 5); XS_FENCE;\n"
+     "        mf(hs, 5); l_piece(0); XS_FENCE;\n"
+     "        mf(hs, 6); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;\n"
+     "        mf(hs, 7); load_u(ktu, ob, 0); XS_FENCE;\n"
+     "        mf(hs, 8); gs(0); gs(1); XS_FENCE;\n"
+     "        mf(hs, 9); gs(2); gs(3); XS_FENCE;\n"
+     "        mf(hs, 10); gs(4); gs(5); XS_FENCE;\n"
+     "        mf(hs, 11);\n")]
+# (b2) the staging loads one slot earlier still (behind the first two V stores)
+VARIANTS["wx3h_gl1"] = [
+    ("wino_x3.hip", _H2_P0_OLD,
+     "        mf(hs, 0); h_piece(1); XS_FENCE;\n"
+     "        mf(hs, 1); nu_store(ob, 0); nu_store(ob, 1); nu_store(ob, 2); nu_store(ob, 3); XS_FENCE;\n"
+     "        mf(hs, 2); gl(ktn, 0); gl(ktn, 1); gl(ktn, 2); gl(ktn, 3); gl(ktn, 4); gl(ktn, 5); XS_FENCE;\n"
+     "        mf(hs, 3); l_piece(0); load_u(ktu, ob, 1); XS_FENCE;\n"
+     "        mf(hs, 4); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;\n"
+     "        mf(hs, 5); XS_FENCE;\n"
      "        mf(hs, 6); XS_FENCE;\n"
      "        mf(hs, 7); load_u(ktu, ob, 0); XS_FENCE;\n"
      "        mf(hs, 8); gs(0); XS_FENCE;\n"
      "        mf(hs, 9); gs(1); gs(2); XS_FENCE;\n"
      "        mf(hs, 10); gs(3); gs(4); XS_FENCE;\n"
      "        mf(hs, 11); gs(5);\n")]
+# (b3) phase 1: the low pieces first, the patch reads behind them
+VARIANTS["wx3h_p1"] = [
+    ("wino_x3.hip", _H2_P1_OLD,
+     "        mf(hs, 0); h_piece(1); affine_load(ktn); XS_FENCE;\n"
+     "        mf(hs, 1); l_piece(0); XS_FENCE;\n"
+     "        mf(hs, 2); l_piece(1); if constexpr (H2_DERIVE) derive_u2(); XS_FENCE;\n"
+     "        mf(hs, 3); patch_rows(ktn, 0, 2); load_u(ktu, ob, 1); XS_FENCE;\n"
+     "        mf(hs, 4); patch_rows(ktn, 2, 4); XS_FENCE;\n"
+     "        affine();\n"
+     "        mf(hs, 5); row_transform(0); row_transform(1); XS_FENCE;\n"
+     "        mf(hs, 6); row_transform(2); row_transform(3); XS_FENCE;\n"
+     "        mf(hs, 7); load_u(ktu, ob, 0); XS_FENCE;\n"
+     "        mf(hs, 8); nu_store(ob, 0); XS_FENCE;\n"
+     "        mf(hs, 9); nu_store(ob, 1); XS_FENCE;\n"
+     "        mf(hs, 10); nu_store(ob, 2); XS_FENCE;\n"
+     "        mf(hs, 11); nu_store(ob, 3);\n")]
+# (b4) phase 1 without fences (the compiler's order there, the pinned order in phase 0)
+VARIANTS["wx3h_p1nofence"] = [
+    ("wino_x3.hip", _H2_P1_OLD, _H2_P1_OLD.replace("XS_FENCE;", ""))]
 # (c) no fences at all in the f16x2 phases: the compiler's own order
 VARIANTS["wx3h_nofence"] = [
     ("wino_x3.hip", "    if constexpr (H2) {\n      // 12 products per phase; the producer side is the same work as below, two slots' worth per slot\n",
