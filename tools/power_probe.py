@@ -4,6 +4,7 @@ MFMA-only / no-staging ablations when A/B libraries are given.
 
     python tools/power_probe.py [seconds]          # -> stdout table; raw samples in gpurun_out/power_probe_raw.txt
     python tools/power_probe.py [seconds] wx3      # only: az_conv2d_winograd_f32 against az_conv2d_winograd_x3_f32 on the gate layers
+    python tools/power_probe.py [seconds] f16x2    # only: the bf16x3 against the f16x2 forms (Winograd layers, token GEMMs), random data and zeros
 """
 import os
 import re
@@ -120,5 +121,30 @@ if MODE == "wx3":
                 ms = sample_while(bld.tape.run, f"{name} {B}x{H}x{W} {Cin}->{Cout}{' zeros' if zero else ''}")
                 fl = 2 * B * H * W * Cin * Cout * 9
                 print(f"    -> {fl / ms / 1e9:.1f} TF/s algorithmic")
+if MODE == "f16x2":  # bf16x3 against f16x2: Winograd layers and token GEMMs, random data and zeros (is the kernel still at the cap?)
+    print("idle:", re.sub(r"\s+", " ", smi())[:600])
+    torch.manual_seed(0)
+    for (B, H, W, Cin, Cout) in ((4, 256, 256, 256, 256), (4, 64, 64, 512, 512)):
+        for mode, name in (("wx3", "winograd bf16x3"), ("wh2", "winograd f16x2 ")):
+            for zero in (False, True):
+                bld = Builder(dev)
+                sc = 0.0 if zero else 1.0
+                x = Act(torch.randn(B * H * W * Cin, device=dev) * sc, B, H, W, Cin, Cin, True)
+                w = torch.randn(Cout, Cin, 3, 3, device=dev) / (Cin * 9) ** 0.5 * (sc if zero else 1.0)
+                y = bld.conv(x, bld.pack_conv(w, torch.randn(Cout, device=dev)), Cout, act=1, winograd=mode)
+                bld.finish()
+                ms = sample_while(bld.tape.run, f"{name} {B}x{H}x{W} {Cin}->{Cout}{' zeros' if zero else ''}")
+                print(f"    -> {2 * B * H * W * Cin * Cout * 9 / ms / 1e9:.1f} TF/s algorithmic")
+    for (T, Cin, Cout) in ((16384, 768, 3072), (16384, 3072, 768)):
+        for mode, name in (("x3", "GEMM bf16x3"), ("h2", "GEMM f16x2 ")):
+            for zero in (False, True):
+                bld = Builder(dev)
+                sc = 0.0 if zero else 1.0
+                x = Act(torch.randn(T * Cin, device=dev) * sc, 1, T, 1, Cin, Cin, True)
+                w = torch.randn(Cout, Cin, device=dev) / Cin ** 0.5 * (sc if zero else 1.0)
+                y = bld.conv(x, bld.pack_conv(w, torch.randn(Cout, device=dev)), Cout, winograd=mode)
+                bld.finish()
+                ms = sample_while(bld.tape.run, f"{name} {T} x {Cin} -> {Cout}{' zeros' if zero else ''}")
+                print(f"    -> {2 * T * Cin * Cout / ms / 1e9:.1f} TF/s algorithmic")
 os.makedirs("gpurun_out", exist_ok=True)
 open("gpurun_out/power_probe_raw.txt", "w").write("\n".join(raw[:400]))
