@@ -109,6 +109,37 @@ __device__ __forceinline__ void az_split2h(float x0, float x1, unsigned& ph, uns
   pl = __builtin_bit_cast(unsigned, l);
 }
 
+// The same split with a scale chosen at run time (AzConvArgs.in_absmax0: inputs whose magnitude is not bounded by construction):
+// p and p2048 = 2048 p are wave-uniform powers of two.
+__device__ __forceinline__ void az_split2h(float x0, float x1, float p, float p2048, unsigned& ph, unsigned& pl) {
+  const az_f2v v = {x0 * p, x1 * p};
+  const az_h2v h = __builtin_convertvector(v, az_h2v);
+  const az_f2v t = {x0 * p2048, x1 * p2048};
+  const az_h2v l = {(_Float16)__builtin_fmaf((float)h.x, -2048.f, t.x), (_Float16)__builtin_fmaf((float)h.y, -2048.f, t.y)};
+  ph = __builtin_bit_cast(unsigned, h);
+  pl = __builtin_bit_cast(unsigned, l);
+}
+// The activation scale of an f16x2 launch: AZ_F16X2_IN_SCALE, or -- with the absmax slots of its sources (az_absmax_f32) -- the
+// power of two that puts gain * max |x| into [2^13, 2^14) (gain = 4 for the Winograd form: B^T d B sums four pixels), exponent
+// clamped to +-60; a non-finite maximum keeps the fixed scale (the offending elements then poison only the outputs they reach).
+// Wave-uniform (every lane reads the same 256 slots); the result sits in a scalar register.
+__device__ __forceinline__ float az_f16x2_in_scale(const float* s0, const float* s1, float gain, int lane) {
+  if (s0 == nullptr) return AZ_F16X2_IN_SCALE;
+  float4 v = *reinterpret_cast<const float4*>(s0 + 4 * lane);
+  float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+  if (s1 != nullptr) {
+    v = *reinterpret_cast<const float4*>(s1 + 4 * lane);
+    m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+  }
+  m = az_wave_max(m) * gain;
+  const unsigned mb = (unsigned)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(unsigned, m));
+  int e = (int)((mb >> 23) & 255u) - 127;  // floor(log2 m) for normal m
+  if (((mb >> 23) & 255u) == 255u) return AZ_F16X2_IN_SCALE;  // Inf / NaN
+  int pe = 13 - e;
+  pe = pe > 60 ? 60 : (pe < -60 ? -60 : pe);
+  return __builtin_bit_cast(float, (unsigned)(127 + pe) << 23);
+}
+
 // The OTHER operand of an f16x2 product when it is formed inside a kernel (the keys and the probabilities of the attention kernel;
 // packed weights get the same three pieces from layout.hip): x' = x * scale as ph = fp16(x'), pl = fp16(x' - ph) (the residual,
 // unscaled) and phs = ph / 2^11, the factor of the partner's scaled low piece.  `scale` puts the operand's largest magnitudes near

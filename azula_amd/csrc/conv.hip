@@ -51,7 +51,7 @@ struct ConvP {
   int tiles_n;  // ceil(npix / BN)
   int asm_loop; // fp32 K-32 kernel: one tap, whole K tiles -> the hand-scheduled K loop (igemm_kloop.inc)
   int m_tile0;  // bf16x3 kernel: first output-channel tile of this launch (the 256 x 256 kernel took the tiles before it)
-  float out_scale;  // f16x2 kernels: 1 / (AZ_F16X2_IN_SCALE * w_scale), applied to the accumulators behind the K loop (a power of two)
+  float out_scale;  // f16x2 kernels: 1 / w_scale; the accumulators are multiplied by out_scale / (the activation scale) behind the K loop (powers of two)
 };
 
 
@@ -739,6 +739,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
   const int n0 = tile_n * BN;
   const int kt_begin = blockIdx.y * p.kps;
   const int kt_end = min(p.nk, kt_begin + p.kps);
+  // H2: the activation scale of this launch (fixed, or from the sources' absmax slots: common.h)
+  const float pin = H2 ? az_f16x2_in_scale(a.in_absmax0, a.in_absmax1, 1.f, lane) : 1.f;
+  const float pin2k = pin * 2048.f;
 
   const int hw_out = a.hout * a.wout;
   const int b_first = n0 / hw_out;
@@ -860,7 +863,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
       unsigned q[3][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if constexpr (H2) az_split2h(x[2 * j], x[2 * j + 1], q[0][j], q[1][j]);
+        if constexpr (H2) az_split2h(x[2 * j], x[2 * j + 1], pin, pin2k, q[0][j], q[1][j]);
         else split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);
       }
 #pragma unroll
@@ -921,10 +924,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(ConvP p) {
     __syncthreads();
   }
   if constexpr (H2) {
+    const float osc = __fdiv_rn(p.out_scale, pin);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = acc[i][j] * p.out_scale;
+      for (int j = 0; j < 2; ++j) acc[i][j] = acc[i][j] * osc;
   }
   store_acc_tiles(p, acc, m0, n0, wc, wp, lane, xsmf);
 }
@@ -1032,6 +1036,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
   const int kt_begin = blockIdx.y * p.kps;
   const int kt_end = min(p.nk, kt_begin + p.kps);
   const int nk = kt_end - kt_begin;
+  // H2: the activation scale of this launch (fixed, or from the sources' absmax slots: common.h)
+  const float pin = H2 ? az_f16x2_in_scale(a.in_absmax0, a.in_absmax1, 1.f, lane) : 1.f;
+  const float pin2k = pin * 2048.f;
 
   const int64_t wtap = (int64_t)a.cout_s * p.cin_s;               // elements per (piece, tap)
   const int64_t wplane = (int64_t)a.ksize * a.ksize * wtap;       // elements per weight piece
@@ -1098,7 +1105,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
     unsigned q[3][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if constexpr (H2) az_split2h(x[2 * j], x[2 * j + 1], q[0][j], q[1][j]);
+      if constexpr (H2) az_split2h(x[2 * j], x[2 * j + 1], pin, pin2k, q[0][j], q[1][j]);
       else split3(x[2 * j], x[2 * j + 1], q[0][j], q[1][j], q[2][j]);
     }
 #pragma unroll
@@ -1183,10 +1190,11 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_big_kernel(ConvP p) {
   }
 
   if constexpr (H2) {
+    const float osc = __fdiv_rn(p.out_scale, pin);
 #pragma unroll
     for (int i = 0; i < NCT; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = acc[i][j] * p.out_scale;
+      for (int j = 0; j < 2; ++j) acc[i][j] = acc[i][j] * osc;
   }
   gemm_big_epilogue<NCT>(p, acc, m0, n0, wc, wp, lane, tid, gsmf);
 }
@@ -2747,7 +2755,8 @@ static int conv2d_direct(const AzConvArgs* a, az_stream_t stream, int half) {
   p.a = *a;
   p.npix = (int)npix64;
   p.cin_s = a->c0s + a->c1s;
-  p.out_scale = half == 4 ? 1.f / (AZ_F16X2_IN_SCALE * a->w_scale) : 1.f;
+  p.out_scale = half == 4 ? 1.f / a->w_scale : 1.f;
+  if (half == 4) AZ_REQUIRE(AZ_ALIGNED16(a->in_absmax0) && AZ_ALIGNED16(a->in_absmax1) && (a->in_absmax0 || !a->in_absmax1), AZ_E_ALIGN);
   // fp32 direct kernel: K tile 16 with three workgroups per CU when the workgroup count then fills the chip evenly
   // (see conv_igemm_kernel); AZ_IGEMM_K16 = 0 / 1 forces the choice (A/B measurements)
   bool k16 = false;
@@ -2943,7 +2952,8 @@ static int winograd_x3_entry(const AzConvArgs* a, az_stream_t stream, bool h2) {
   if (prc != AZ_OK) return prc;
   AZ_REQUIRE(p.tiles_w >= 2, AZ_E_UNSUPPORTED);  // (the kernel stages <= 32 tile-row segments per 64-tile block: maps >= 3 pixels wide)
   if (h2) AZ_REQUIRE(conv_pow2(a->w_scale), AZ_E_SHAPE);
-  p.out_scale = h2 ? 1.f / (AZ_F16X2_IN_SCALE * a->w_scale) : 1.f;
+  p.out_scale = h2 ? 1.f / a->w_scale : 1.f;
+  if (h2) AZ_REQUIRE(AZ_ALIGNED16(a->in_absmax0) && AZ_ALIGNED16(a->in_absmax1) && (a->in_absmax0 || !a->in_absmax1), AZ_E_ALIGN);
   hipStream_t st = az_s(stream);
   int rc = azi_winograd_x3_launch(p, (unsigned)splitk, st, h2);
   if (rc != AZ_OK) return rc;

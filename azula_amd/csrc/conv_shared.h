@@ -390,5 +390,5 @@ struct WinoP {
   int cblocks;         // ceil(cout_s / WC)
   int tblocks;         // ceil(ntiles / WT)
   int gt, gc;          // workgroup order: rectangles of gt tile blocks x gc cout blocks, tile block fastest inside (1, cblocks: cout fastest)
-  float out_scale;     // f16x2 form of the x3 kernel: 1 / (AZ_F16X2_IN_SCALE * w_scale), applied to the accumulators behind the K loop
+  float out_scale;     // f16x2 form of the x3 kernel: 1 / w_scale; the accumulators are multiplied by out_scale / (the activation scale) behind the K loop
 };

@@ -580,6 +580,30 @@ __global__ __launch_bounds__(256) void rownorm_mod_kernel(float* __restrict__ y,
   }
 }
 
+// slots[block] = max |x| over the float4s the block visits (grid-stride, four loads in flight per thread); every slot is written.
+__global__ __launch_bounds__(256) void absmax_kernel(float* __restrict__ slots, const float* __restrict__ x, int64_t n4, int64_t n) {
+  __shared__ float sh[4];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  float m = 0.f;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + 4 * (i + u * stride));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
+  }
+  for (; i < n4; i += stride) {
+    const float4 v = *reinterpret_cast<const float4*>(x + 4 * i);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) m = fmaxf(m, fabsf(x[4 * n4 + threadIdx.x]));  // (a tail of < 4 elements)
+  m = az_wave_max(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) slots[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
 }  // namespace
 
 template <int IO>
@@ -614,6 +638,14 @@ static int affine_act_h16_launch(float* y, const float* x, const float* x1, int6
 }
 
 extern "C" {
+
+int az_absmax_f32(float* slots, const float* x, int64_t n, az_stream_t stream) {
+  AZ_REQUIRE(slots && x, AZ_E_NULL);
+  AZ_REQUIRE(n > 0, AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(x) && AZ_ALIGNED16(slots), AZ_E_ALIGN);
+  hipLaunchKernelGGL(absmax_kernel, dim3(AZ_ABSMAX_SLOTS), dim3(256), 0, az_s(stream), slots, x, n / 4, n);
+  return az_launch_status();
+}
 
 int az_groupnorm_stats_f32(float* partials, const float* x, const float* x1, int64_t c0s, int64_t B, int64_t HW,
                            int64_t C, int64_t cs, int32_t groups, int32_t nchunks, az_stream_t stream) {

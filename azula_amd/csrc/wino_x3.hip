@@ -98,6 +98,9 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
 
   const int kt_begin = blockIdx.y * p.kps;
   const int kt_end = min(p.nk, kt_begin + p.kps);
+  // H2: the activation scale of this launch: the fixed one, or from the sources' absmax slots (x 4: V = B^T d B sums four pixels)
+  const float pin = H2 ? az_f16x2_in_scale(a.in_absmax0, a.in_absmax1, 4.f, lane) : 1.f;
+  const float pin2k = pin * 2048.f;
 
   const int64_t s0_elems = (int64_t)a.h0 * a.w0 * a.c0s;
   const int64_t s1_elems = (int64_t)a.h1 * a.w1 * a.c1s;
@@ -343,9 +346,9 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f32x2 x = {xf[th][2 * j], xf[th][2 * j + 1]};
-      const f32x2 v = x * AZ_F16X2_IN_SCALE;
+      const f32x2 v = x * pin;
       fw[th][0][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2v));
-      const f32x2 t = x * (AZ_F16X2_IN_SCALE * 2048.f);
+      const f32x2 t = x * pin2k;
       xf[th][2 * j] = t.x, xf[th][2 * j + 1] = t.y;
     }
   };
@@ -509,9 +512,10 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
   }
   __syncthreads();
 #undef XS_FENCE
-  if constexpr (H2) {  // back to the operands' scale (exact: a power of two)
+  if constexpr (H2) {  // back to the operands' scale (exact: powers of two)
+    const float osc = __fdiv_rn(p.out_scale, pin);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = acc[q] * p.out_scale;
+    for (int q = 0; q < 8; ++q) acc[q] = acc[q] * osc;
   }
 
   // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  Z[xi][px] = sum_nu M[xi][nu] A[nu][px]: px = 0: M0 + M1 + M2,

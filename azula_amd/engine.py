@@ -122,7 +122,7 @@ class Pool:
 class Act:
     r"""An NHWC activation: ``buf`` holds (B, H, W, cs) floats, ``C`` real channels."""
 
-    __slots__ = ("buf", "B", "H", "W", "C", "cs", "pinned", "gn_quads", "affine", "qk_prepared", "bounded")
+    __slots__ = ("buf", "B", "H", "W", "C", "cs", "pinned", "gn_quads", "affine", "qk_prepared", "bounded", "absmax")
 
     @property
     def half(self) -> bool:
@@ -137,6 +137,7 @@ class Act:
         # input streams (which grow with x_t: an unstable multistep sampler reaches 1e7 in tests/test_gpu_unet.py) go through
         # the bf16x3 kernels, whose domain is all of fp32.  Default False: unknown = unbounded.
         self.bounded = False
+        self.absmax = None  # AZ_ABSMAX_SLOTS floats written by az_absmax_f32 over this tensor on the tape so far (Builder.absmax_of), or None
         self.gn_quads = None  # (partials tensor, chunks per image): GroupNorm moments written by the producing conv
         self.qk_prepared = False  # a fused qkv projection whose q / k are already normalised / gained / rotated (AzConvArgs.act = 5)
         self.affine = None    # ([scale | shift] tensor, act): a normalisation whose apply pass has not run -- the values are
@@ -174,6 +175,10 @@ def pieces() -> bool:
     return FP32_MFMA in ("bf16x3", "f16x2")
 
 
+# f16x2 mode, layers whose input is NOT bounded (residual / input streams): "1" (default) = f16x2 kernels too where it pays, with the
+# activation scale taken from the sources' largest magnitude (one streaming az_absmax_f32 pass per source tensor and step, shared
+# by its consumers; AzConvArgs.in_absmax0 / in_absmax1: no stated range) -- the UNet's strided and skip-merge convolutions; "0" = bf16x3
+F16X2_DYNAMIC = os.environ.get("AZ_F16X2_DYNAMIC", "1") != "0"
 ATTN_H2 = os.environ.get("AZ_ATTN_H2", "1") != "0"  # f16x2 mode: the attention contractions in that form too ("0": bf16x3 attention -- A/B)
 ATTN_X3 = os.environ.get("AZ_ATTN_X3", "1") != "0"  # bf16x3 mode: attention contractions on the bf16 pipe too (az_attention_x3_f32)
 # The stride-1 3 x 3 layers in bf16x3 mode: "1" (default since round 5) = the Winograd kernel with its 16 frequency GEMMs on the bf16 pipe
@@ -499,7 +504,7 @@ class Builder:
         # az_conv2d_f32 runs its narrow-output VALU kernel (104 vs 342 us at 4 x 256^2, 256 -> 3)
         head = (winograd is None and legal and not aniso and a.cout_s == 4 and src1 is None and up0 == 0 and a.c0s % 16 == 0
                 and head_wgs >= 256 and depth is None)
-        wino_ok = legal and not head and winograd not in ("x3", "h2")
+        wino_ok = legal and not head and winograd not in ("x3", "h2", "h2d")
         use_f4 = wino_ok and depth is None and (winograd == 4 or (winograd is None and WINOGRAD == "4" and tiles4 >= WINOGRAD4_MIN_TILES))
         use_wino = wino_ok and not use_f4 and ((WINOGRAD != "0") if winograd is None else bool(winograd))
         if use_wino:
@@ -511,23 +516,36 @@ class Builder:
         # TF/s); the 3x3 stride-1 layers stay on the fp32 Winograd kernel, which executes 2.25x fewer multiplies
         # (221 vs 181 TF/s algorithmic at 4 x 256^2, 256 -> 256).
         use_x3 = self.half is None and (
-            winograd in ("x3", "h2")
+            winograd in ("x3", "h2", "h2d")
             or (winograd is None and pieces() and not head and not use_wino and not use_f4
                 and cin_s >= X3_MIN_CHANNELS and a.cout_s >= X3_MIN_CHANNELS)
         )
-        # (winograd = "x3" / "wx3": the bf16x3 kernels, "h2" / "wh2": the f16x2 ones, whatever the mode -- kernel tests)
+        # (winograd = "x3" / "wx3": the bf16x3 kernels, "h2" / "wh2": the f16x2 ones, "h2d" / "wh2d": those with the activation scale
+        #  measured from the sources -- az_absmax_f32 --, whatever the mode: kernel tests)
         src_bounded = (src0.bounded or src0.affine is not None) and (src1 is None or src1.bounded)  # (a pending normalisation is applied in the gather / materialised)
-        h2 = winograd in ("h2", "wh2") or (winograd not in ("x3", "wx3") and FP32_MFMA == "f16x2" and src_bounded)
+        h2 = winograd in ("h2", "wh2", "h2d", "wh2d") or (winograd not in ("x3", "wx3") and FP32_MFMA == "f16x2" and src_bounded)
+        dyn = winograd in ("h2d", "wh2d")
+        if (not h2 and winograd is None and FP32_MFMA == "f16x2" and F16X2_DYNAMIC and self.half is None and depth is None
+                and (use_wino or use_x3) and not use_f4):
+            # unbounded sources: f16x2 with the scale measured per step, where the pass over the sources costs clearly less than the
+            # matrix instructions it saves (~12 % of a Winograd layer at ~350 TF/s algorithmic, ~25 % of a direct one at ~190)
+            flops = 2.0 * npix * cout * (src0.C + (src1.C if src1 is not None else 0)) * ks * ks
+            gain_s = 0.12 * flops / 350e12 if use_wino else 0.25 * flops / 190e12
+            cost_s = sum(4e-6 + s_.buf.numel() * 4 / 5.0e12 for s_ in (src0, src1) if s_ is not None and s_.absmax is None)
+            dyn = h2 = gain_s > 1.5 * cost_s
         if use_f4:
             a.weight = packed.winograd4().data_ptr()
             a.splitk = lib.az_conv2d_winograd4_suggest_splitk(B, hout, wout, a.cout_s, cin_s)
             name = "az_conv2d_winograd4_f32"
-        elif use_wino and wout >= 3 and (winograd in ("wx3", "wh2") or (winograd is None and WINO_X3 and pieces())):
+        elif use_wino and wout >= 3 and (winograd in ("wx3", "wh2", "wh2d") or (winograd is None and WINO_X3 and pieces())):
             # the frequency GEMMs on the bf16 pipe as exact 3 x bf16 splits (wino_x3.hip); same descriptor, 16-channel steps
             # (f16x2: the same kernel with two half pieces per operand and three products)
             if h2:
                 a.weight, a.w_scale = packed.winograd_f16x2().data_ptr(), packed.w_scale(True)
                 name = "az_conv2d_winograd_f16x2_f32"
+                if dyn:
+                    a.in_absmax0 = self.absmax_of(src0).data_ptr()
+                    a.in_absmax1 = self.absmax_of(src1).data_ptr() if src1 is not None else None
             else:
                 a.weight = packed.winograd_x3().data_ptr()
                 name = "az_conv2d_winograd_x3_f32"
@@ -537,6 +555,9 @@ class Builder:
         elif use_x3:
             if h2:
                 a.weight, a.w_scale = packed.direct_f16x2().data_ptr(), packed.w_scale(False)
+                if dyn:
+                    a.in_absmax0 = self.absmax_of(src0).data_ptr()
+                    a.in_absmax1 = self.absmax_of(src1).data_ptr() if src1 is not None else None
             else:
                 a.weight = packed.direct_x3().data_ptr()
             a.splitk = lib.az_conv2d_x3_suggest_splitk(C.byref(a))  # (the 256 x 256-tile kernel has its own rule)
@@ -640,6 +661,16 @@ class Builder:
         a._algo = "az_conv2d_stem_f32"
         self.tape.add("az_conv2d_stem_f32", C.byref(a), keep=[a, x])
         return out
+
+    def absmax_of(self, x: Act) -> torch.Tensor:
+        r"""The AZ_ABSMAX_SLOTS partial maxima of |x| (``az_absmax_f32``: one streaming pass, recorded once per tensor and shared by
+        its consumers) -- the activation scale of an f16x2 launch on an unbounded input (``AzConvArgs.in_absmax0 / in_absmax1``)."""
+        if x.absmax is None:
+            assert not x.half and x.affine is None
+            slots = self.empty(256)
+            self.tape.add("az_absmax_f32", slots.data_ptr(), x.ptr, x.B * x.H * x.W * x.cs, keep=[x.buf])
+            x.absmax = slots
+        return x.absmax
 
     def upsample_nearest(self, x: Act, sh: int, sw: int, hout: int, wout: int) -> Act:
         r"""``narrow(Upsample(scale_factor=(sh, sw), mode="nearest")(x), (hout, wout))`` as a pass of its own -- only for

@@ -179,6 +179,8 @@ def stream_bytes(name, args):
             return d.batch * d.hin * d.win * (d.c0s + d.cout_s) * 4
         if name == "az_rownorm_mod_f32":  # (y, x, weight, scale, shift, bstride, rows, rows_per_batch, C, cs, kind, eps)
             return 2 * args[6] * args[9] * 4
+        if name == "az_absmax_f32":  # (slots, x, n): one read of the tensor
+            return args[2] * 4
     except Exception:  # noqa: BLE001 -- accounting only
         pass
     return None

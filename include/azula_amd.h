@@ -346,6 +346,12 @@ typedef struct AzConvArgs {
                             * (az_pack_conv_weight_f16x2_f32 / az_winograd_pack_filter_f16x2_f32) multiplied the weights by; the kernels
                             * multiply their accumulators by 1 / (AZ_F16X2_IN_SCALE * w_scale), exactly */
   int32_t reserved1;
+  const float* in_absmax0; /* az_conv2d_f16x2_f32 / az_conv2d_winograd_f16x2_f32 only, optional: AZ_ABSMAX_SLOTS floats written by az_absmax_f32 over */
+  const float* in_absmax1; /* src0 (and src1): the kernel then scales its activation operand by the power of two that puts the LARGEST
+                            * magnitude of the sources (x 4 in the Winograd form, whose V sums four pixels) into [2^13, 2^14) instead of
+                            * by the fixed AZ_F16X2_IN_SCALE -- no stated range any more (any finite fp32 input), full relative precision
+                            * for everything within 2^-27 of the largest value.  For inputs whose magnitude is not bounded by
+                            * construction (residual / input streams).  NULL: the fixed scale.  Non-finite maxima fall back to it. */
 } AzConvArgs;
 /* Narrow outputs (cout_s == 4, 3x3 stride 1 pad 1, one un-upsampled source with c0s % 16 == 0: the image head of
  * azula/nn/unet.py) run a VALU kernel instead of the 128-cout MFMA tile; splitk is ignored there.              */
@@ -409,6 +415,11 @@ int az_conv2d_winograd_f16x2_f32(const AzConvArgs* args, az_stream_t stream);
 /* The weight scale the f16x2 packings want for a weight tensor whose largest magnitude is `amax`: the power of two that puts
  * amax (times 2.25 for the Winograd transform G g G^T when `winograd`) into (2^13, 2^14]; 1 for amax = 0 / non-finite. */
 float az_f16x2_weight_scale(float amax, int32_t winograd);
+/* slots[i] = max |x| over the elements workgroup i visits, i < AZ_ABSMAX_SLOTS (every slot is written: no initialisation, no
+ * atomics, deterministic): the largest magnitude of an activation tensor for AzConvArgs.in_absmax0 / in_absmax1.  One streaming
+ * read of the tensor (HBM-bound).  NaN elements are ignored (they turn the outputs they reach into NaN through their own pieces). */
+#define AZ_ABSMAX_SLOTS 256
+int az_absmax_f32(float* slots, const float* x, int64_t n, az_stream_t stream);
 /* Winograd F(4x4,3x3) form (6x6 patches, 36 frequency GEMMs: 2.25 multiplies per output instead of 4 / 9).
  * NOT exact: the transforms multiply by 2, 4, 5, 8 and the filter transform by 1/4 .. 1/24, so the fp32
  * rounding error is ~20x that of the F(2x2) kernel (~1e-5 of the output scale per layer).  Opt-in

@@ -889,6 +889,59 @@ def test_conv2d_x3_accuracy(az, monkeypatch):
     assert errs["wh2"][1] <= 1.25 * errs[True][1] and errs["wh2"][0] <= 1.5 * errs[True][0], errs
 
 
+@pytest.mark.parametrize("mode", ["h2d", "wh2d"])
+@pytest.mark.parametrize("two", [False, True])
+def test_f16x2_dynamic_scale_has_no_range(az, mode, two):
+    """AzConvArgs.in_absmax0 / in_absmax1 (az_absmax_f32 over the sources): the f16x2 kernels scale their activation operand by the
+    power of two that fits the sources' largest magnitude -- any finite fp32 input goes through at fp32-level relative error, from
+    1e-20 to 1e20 (the fixed scale's range ends at ~1e6: test_f16x2_domain), also for a channel concatenation of two sources of
+    very different size; a non-finite element poisons only the outputs it reaches."""
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(8)
+    B, C0, C1, Cout, H, W = 2, 64, 32 if two else 0, 96, 20, 24
+    w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / math.sqrt(9 * (C0 + C1))
+
+    def run(x0, x1):
+        bld = Builder(torch.device("cuda"))
+        a0 = Act(to_nhwc(dev(x0)).reshape(-1), B, H, W, C0, C0, True)
+        a1 = Act(to_nhwc(dev(x1)).reshape(-1), B, H, W, C1, C1, True) if two else None
+        y = bld.conv(a0, bld.pack_conv(dev(w), None, cin0=C0 if two else None), Cout, src1=a1, winograd=mode)
+        names = [n for _, _, n in bld.tape.ops]
+        assert names.count("az_absmax_f32") == (2 if two else 1) and names[-1] == WINO_NAME[mode[:-1]], names
+        bld.finish()
+        bld.tape.run()
+        return from_nhwc(y.buf.reshape(B, H, W, Cout), Cout).cpu()
+
+    for s0, s1 in ((1.0, 1.0), (1e7, 3.0), (1e-20, 1e-20), (1e20, 1e15), (3e-5, 40.0)):
+        x0 = torch.randn(B, C0, H, W, generator=g) * s0
+        x1 = torch.randn(B, max(C1, 1), H, W, generator=g) * s1
+        ref = F.conv2d((torch.cat([x0, x1], 1) if two else x0).double(), w.double(), None, padding=1)
+        out = run(x0, x1)
+        err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+        print(mode, two, s0, s1, "relative error", err)
+        assert torch.isfinite(out).all() and err < 3e-6, (s0, s1, err)
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    x0[1, 5, 9, 9] = float("inf")
+    out = run(x0, torch.randn(B, max(C1, 1), H, W, generator=g))
+    assert not torch.isfinite(out[1, :, 8:11, 8:11]).any() and torch.isfinite(out[0]).all()
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1000, 65536 * 3 + 2, 4 * 1024 * 1024])
+def test_absmax(az, n):
+    """az_absmax_f32: AZ_ABSMAX_SLOTS partial maxima whose maximum is max |x| (every slot written; NaN elements ignored)."""
+    from azula_amd import _lib
+
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n + 4, generator=g)
+    x[n // 2] = -123.5
+    x[n:] = 1e9  # (past the end: must not be read into the result)
+    xd = dev(x)
+    slots = torch.full((256,), float("nan"), device="cuda")
+    _lib.call("az_absmax_f32", slots.data_ptr(), xd.data_ptr(), n, _lib.stream_ptr())
+    assert torch.isfinite(slots).all() and slots.max().item() == x[:n].abs().max().item()
+
+
 @pytest.mark.parametrize("mode", ["h2", "wh2"])
 def test_f16x2_domain(az, mode):
     """The STATED domain of the f16x2 split (include/azula_amd.h, csrc/common.h: az_split2h): activations of any magnitude below
