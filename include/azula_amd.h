@@ -405,7 +405,9 @@ int az_conv2d_winograd_x3_f32(const AzConvArgs* args, az_stream_t stream);
  * gracefully at the small end.  DOMAIN (stated, unlike bf16x3's, which is all of fp32): |x| * AZ_F16X2_IN_SCALE < 65520 --
  * activations up to ~1.0e6 (Winograd form: 4-pixel sums of the input, i.e. inputs up to ~2.6e5); beyond it a piece is Inf and the
  * outputs that depend on it are NaN (never a silently wrong finite value).  At the small end every operand carries an absolute
- * error <= 2^-36 / AZ_F16X2_IN_SCALE = 2.3e-10 (full relative precision from |x| >= 1e-3 on).  bf16x3 stays selectable
+ * error <= 2^-36 / AZ_F16X2_IN_SCALE = 2.3e-10 (full relative precision from |x| >= 1e-3 on).  That range is for inputs whose
+ * magnitude is bounded by construction (behind a normalisation); for any other input pass the sources' largest magnitude
+ * (in_absmax0 / in_absmax1, from az_absmax_f32) and the kernel picks the scale itself: no stated range.  bf16x3 stays selectable
  * (AZ_FP32_MFMA=bf16x3).  `weight` = az_pack_conv_weight_f16x2_f32 / az_winograd_pack_filter_f16x2_f32 output (the layouts of the x3
  * packings: three 2-byte planes), `w_scale` the scale given to that packing; everything else as the x3 entries.  Same reference
  * op: azula/nn/layers.py:25-68 ConvNd / torch.nn.Linear on tokens (azula/nn/dit.py:88-93, azula/nn/attention.py:45-46). */
