@@ -50,10 +50,14 @@ constexpr int X_FREQ = XT * X_ROW;           // 4 KB
 constexpr int X_HALF = 8 * X_FREQ;           // one half-stage (8 frequencies): 32 KB
 constexpr int X_STAGE = 2 * X_HALF;          // raw staging behind the two half-stage buffers: <= 768 pixel slots x 64 B = 48 KB
 constexpr int X_SLOTS = 768;                 // (8 (64 + segments) slots: up to 32 segments, i.e. maps at least 3 pixels wide; the host checks)
-constexpr int X_DOFF1 = X_STAGE + X_SLOTS * 64;  // the second source's staging offsets (6 per thread, 32 B apart: 16 KB), read back at the switch
+// A staged pixel slot holds the step's 16 channels (64 B) at a stride of 80 B: a wave's patch read touches 8 horizontally adjacent
+// tiles = slots two apart, i.e. 128 B apart at a 64-byte stride -- four of the eight on the same banks (SQ_LDS_BANK_CONFLICT = 22 % of
+// the kernel's LDS cycles, profiles/r06b_wx3_pmc.txt); 160 B apart they tile the 64 banks exactly twice.
+constexpr int X_SLOT = 80;
+constexpr int X_DOFF1 = X_STAGE + X_SLOTS * X_SLOT;  // the second source's staging offsets (6 per thread, 32 B apart: 16 KB), read back at the switch
 constexpr int X_OT = 2 * XC + 4;             // epilogue: floats per tile row of one xi's [tile][px][cout] exchange buffer
 constexpr int X_EPI_BYTES = (4 * XT * X_OT + 3 * XT + 384) * 4;  // 137,472 B: four xi partials + tile table + GroupNorm partials
-constexpr int X_LDS_BYTES = X_EPI_BYTES;     // (>= the K loop's 64 + 48 + 16 KB and the 128 KB hand-off of the k = 1 waves' partials)
+constexpr int X_LDS_BYTES = X_DOFF1 + 512 * 32 > X_EPI_BYTES ? X_DOFF1 + 512 * 32 : X_EPI_BYTES;  // the K loop's 64 + 60 + 16 KB (>= the epilogue's buffers and the 128 KB hand-off of the k = 1 waves' partials)
 static_assert(X_LDS_BYTES >= X_DOFF1 + 512 * 32 && X_LDS_BYTES >= 4 * 128 * 64 * 4, "the epilogue reuses the K loop's LDS");
 constexpr int XU_STEP_BYTES = 16 * XC * XK * 3 * 2;  // one (step, cout block) filter chunk: 96 KB
 static_assert(4 * X_SLOTS <= 6 * 512, "six staging pieces per thread");
@@ -195,8 +199,8 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
   // the thread's own patch: LDS address of (row 0, column 0), row stride; validity of its 16 positions (in_affine keeps padding at zero)
   int pj_s, pj_len;
   seg_of(fdiv(vj + tw0, p.tiles_w), pj_s, pj_len);
-  const int prow = (2 * pj_len + 2) * 64;
-  const char* const patch = smem + X_STAGE + (8 * (pj_s + fdiv(vj + tw0, p.tiles_w)) + 2 * (vj - pj_s)) * 64 + vq * 8;
+  const int prow = (2 * pj_len + 2) * X_SLOT;
+  const char* const patch = smem + X_STAGE + (8 * (pj_s + fdiv(vj + tw0, p.tiles_w)) + 2 * (vj - pj_s)) * X_SLOT + vq * 8;
   unsigned vmask = 0;
   if constexpr (AFF != 0) {
 #pragma unroll
@@ -224,13 +228,13 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_x3_kernel(WinoP p) {
     }
   };
   auto gs = [&](int m) __attribute__((always_inline)) {
-    if (m < 5 || m < ndma) *reinterpret_cast<float4*>(smem + X_STAGE + (m * 512 + tid) * 16) = gq[m];
+    if (m < 5 || m < ndma) *reinterpret_cast<float4*>(smem + X_STAGE + ((m * 512 + tid) >> 2) * X_SLOT + (tid & 3) * 16) = gq[m];
   };
   auto patch_rows = [&](int kt, int r0, int r1) __attribute__((always_inline)) {  // rows [r0, r1) of the staged patch -> rv
 #pragma unroll
     for (int r = r0; r < r1; ++r)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) rv[4 * r + c] = *reinterpret_cast<const f32x2*>(patch + r * prow + c * 64);
+      for (int c = 0; c < 4; ++c) rv[4 * r + c] = *reinterpret_cast<const f32x2*>(patch + r * prow + c * X_SLOT);
   };
   // with in_affine the input is act(x * scale + shift) (padding positions stay zero): applied to the raw patch in place
   // the scale / shift pair of the thread's channel pair for step kt: two bounds-checked 8-byte loads issued well ahead of their

@@ -133,7 +133,7 @@ VARIANTS["ax_nosplitp"] = [
 _G_PROD = [
     ("wino_x3.hip", "  const int cb = (rect - rrow * rcols) * p.gc + rin_c;\n", "  const int cb = (rect - rrow * rcols) * p.gc + rin_c;\n  const bool prod = !(cb & 1);\n"),
     ("wino_x3.hip", "    if (m < 5 || m < ndma) {  // (uniform; a block always has at least 520 slots = 4.06 pieces per thread)", "    if (prod && (m < 5 || m < ndma)) {"),
-    ("wino_x3.hip", "    if (m < 5 || m < ndma) *reinterpret_cast<float4*>(smem + X_STAGE + (m * 512 + tid) * 16) = gq[m];", "    if (prod && (m < 5 || m < ndma)) *reinterpret_cast<float4*>(smem + X_STAGE + (m * 512 + tid) * 16) = gq[m];"),
+    ("wino_x3.hip", "    if (m < 5 || m < ndma) *reinterpret_cast<float4*>(smem + X_STAGE + ((m * 512 + tid) >> 2) * X_SLOT + (tid & 3) * 16) = gq[m];", "    if (prod && (m < 5 || m < ndma)) *reinterpret_cast<float4*>(smem + X_STAGE + ((m * 512 + tid) >> 2) * X_SLOT + (tid & 3) * 16) = gq[m];"),
     ("wino_x3.hip", "  auto patch_rows = [&](int kt, int r0, int r1) __attribute__((always_inline)) {  // rows [r0, r1) of the staged patch -> rv\n", "  auto patch_rows = [&](int kt, int r0, int r1) __attribute__((always_inline)) {\n    if (!prod) return;\n"),
     ("wino_x3.hip", "    const f32x2 d0 = rv[c], d1 = rv[4 + c], d2 = rv[8 + c], d3 = rv[12 + c];\n", "    if (!prod) return;\n    const f32x2 d0 = rv[c], d1 = rv[4 + c], d2 = rv[8 + c], d3 = rv[12 + c];\n"),
     ("wino_x3.hip", "    const f32x2 u0 = rv[4 * xi], u1 = rv[4 * xi + 1], u2 = rv[4 * xi + 2], u3 = rv[4 * xi + 3];\n", "    if (!prod) return;\n    const f32x2 u0 = rv[4 * xi], u1 = rv[4 * xi + 1], u2 = rv[4 * xi + 2], u3 = rv[4 * xi + 3];\n"),
@@ -317,6 +317,9 @@ VARIANTS["wx3h_nofence"] = [
 _H2G_OLD = "        if (k < NM - 6) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // three vector instructions\n"
 VARIANTS["h2big_valu2"] = [("conv.hip", _H2G_OLD, "        if (k < NM - 4) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);\n")]
 VARIANTS["h2big_valu4"] = [("conv.hip", _H2G_OLD, "        if (k < NM - 10) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);\n")]
+
+# ---- x3 Winograd kernel: staged pixel slots at 64 B (the layout until round 6b: 4-way bank conflicts of the patch reads) instead of 80 B
+VARIANTS["wx3_slot64"] = [("wino_x3.hip", "constexpr int X_SLOT = 80;", "constexpr int X_SLOT = 64;")]
 
 
 def build(name: str, patches=None, regen_env=None, head_files=None) -> str:
