@@ -50,14 +50,15 @@ constexpr int X_FREQ = XT * X_ROW;           // 4 KB
 constexpr int X_HALF = 8 * X_FREQ;           // one half-stage (8 frequencies): 32 KB
 constexpr int X_STAGE = 2 * X_HALF;          // raw staging behind the two half-stage buffers: <= 768 pixel slots x 64 B = 48 KB
 constexpr int X_SLOTS = 768;                 // (8 (64 + segments) slots: up to 32 segments, i.e. maps at least 3 pixels wide; the host checks)
-// A staged pixel slot holds the step's 16 channels (64 B) at a stride of 80 B: a wave's patch read touches 8 horizontally adjacent
-// tiles = slots two apart, i.e. 128 B apart at a 64-byte stride -- four of the eight on the same banks (SQ_LDS_BANK_CONFLICT = 22 % of
-// the kernel's LDS cycles, profiles/r06b_wx3_pmc.txt); 160 B apart they tile the 64 banks exactly twice.
-constexpr int X_SLOT = 80;
+// Stride of a staged pixel slot (the step's 16 channels = 64 B).  Measured and not kept: 80 B, meant to spread the patch reads of a
+// wave (8 adjacent tiles = slots two apart) over all banks -- a tie to 1 % slower on five layers in both piece forms, and
+// SQ_LDS_BANK_CONFLICT ROSE (35.7 M -> 57.9 M cycles per launch at 4 x 256^2: the 16-byte staging stores then straddle bank groups);
+// profiles/r06_wx3_slot_ab.txt, tools/ablate.py wx3_slot80.
+constexpr int X_SLOT = 64;
 constexpr int X_DOFF1 = X_STAGE + X_SLOTS * X_SLOT;  // the second source's staging offsets (6 per thread, 32 B apart: 16 KB), read back at the switch
 constexpr int X_OT = 2 * XC + 4;             // epilogue: floats per tile row of one xi's [tile][px][cout] exchange buffer
 constexpr int X_EPI_BYTES = (4 * XT * X_OT + 3 * XT + 384) * 4;  // 137,472 B: four xi partials + tile table + GroupNorm partials
-constexpr int X_LDS_BYTES = X_DOFF1 + 512 * 32 > X_EPI_BYTES ? X_DOFF1 + 512 * 32 : X_EPI_BYTES;  // the K loop's 64 + 60 + 16 KB (>= the epilogue's buffers and the 128 KB hand-off of the k = 1 waves' partials)
+constexpr int X_LDS_BYTES = X_DOFF1 + 512 * 32 > X_EPI_BYTES ? X_DOFF1 + 512 * 32 : X_EPI_BYTES;  // (the epilogue's buffers: >= the K loop's 64 + 48 + 16 KB and the 128 KB hand-off of the k = 1 waves' partials)
 static_assert(X_LDS_BYTES >= X_DOFF1 + 512 * 32 && X_LDS_BYTES >= 4 * 128 * 64 * 4, "the epilogue reuses the K loop's LDS");
 constexpr int XU_STEP_BYTES = 16 * XC * XK * 3 * 2;  // one (step, cout block) filter chunk: 96 KB
 static_assert(4 * X_SLOTS <= 6 * 512, "six staging pieces per thread");

@@ -634,6 +634,7 @@ class Builder:
         if tmp_src is not None:
             self.free(tmp_src)
         if out is not None:
+            out.absmax = None  # (a caller-owned destination is rewritten: maxima recorded for its previous contents are stale)
             out.bounded = src_bounded and (res is None or res.bounded)  # (a residual add of the stream joins the stream; of a bounded tensor -- y + MSA(y) of a DiT block -- stays bounded)
         return out
 
@@ -664,7 +665,8 @@ class Builder:
 
     def absmax_of(self, x: Act) -> torch.Tensor:
         r"""The AZ_ABSMAX_SLOTS partial maxima of |x| (``az_absmax_f32``: one streaming pass, recorded once per tensor and shared by
-        its consumers) -- the activation scale of an f16x2 launch on an unbounded input (``AzConvArgs.in_absmax0 / in_absmax1``)."""
+        its consumers) -- the activation scale of an f16x2 launch on an unbounded input (``AzConvArgs.in_absmax0 / in_absmax1``).
+        Valid as long as the tensor is not rewritten on the tape: ops that write into an existing Act reset ``absmax`` (``conv(out=...)``)."""
         if x.absmax is None:
             assert not x.half and x.affine is None
             slots = self.empty(256)

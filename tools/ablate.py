@@ -318,8 +318,8 @@ _H2G_OLD = "        if (k < NM - 6) __builtin_amdgcn_sched_group_barrier(0x002, 
 VARIANTS["h2big_valu2"] = [("conv.hip", _H2G_OLD, "        if (k < NM - 4) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);\n")]
 VARIANTS["h2big_valu4"] = [("conv.hip", _H2G_OLD, "        if (k < NM - 10) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);\n")]
 
-# ---- x3 Winograd kernel: staged pixel slots at 64 B (the layout until round 6b: 4-way bank conflicts of the patch reads) instead of 80 B
-VARIANTS["wx3_slot64"] = [("wino_x3.hip", "constexpr int X_SLOT = 80;", "constexpr int X_SLOT = 64;")]
+# ---- x3 Winograd kernel: staged pixel slots at a stride of 80 B instead of 64 B (measured: no gain, more bank conflicts -- profiles/r06_wx3_slot_ab.txt)
+VARIANTS["wx3_slot80"] = [("wino_x3.hip", "constexpr int X_SLOT = 64;", "constexpr int X_SLOT = 80;")]
 
 
 def build(name: str, patches=None, regen_env=None, head_files=None) -> str:
