@@ -344,7 +344,8 @@ typedef struct AzConvArgs {
                             * always fp32 */
   float w_scale;           /* az_conv2d_f16x2_f32 / az_conv2d_winograd_f16x2_f32 only (ignored elsewhere): the power of two the packing
                             * (az_pack_conv_weight_f16x2_f32 / az_winograd_pack_filter_f16x2_f32) multiplied the weights by; the kernels
-                            * multiply their accumulators by 1 / (AZ_F16X2_IN_SCALE * w_scale), exactly */
+                            * multiply their accumulators by 1 / (activation scale * w_scale), exactly (the activation scale:
+                            * AZ_F16X2_IN_SCALE, or the one derived from in_absmax0 / in_absmax1 below) */
   int32_t reserved1;
   const float* in_absmax0; /* az_conv2d_f16x2_f32 / az_conv2d_winograd_f16x2_f32 only, optional: AZ_ABSMAX_SLOTS floats written by az_absmax_f32 over */
   const float* in_absmax1; /* src0 (and src1): the kernel then scales its activation operand by the power of two that puts the LARGEST

@@ -107,6 +107,26 @@ def test_argument_errors_are_returned_not_raised(built_lib):
     assert lib.az_groupnorm_stats_h16(0x1000, 0x1000, None, 0, 1, 16, 24, 24, 8, 1, 1, None) == -4  # groups of 3 channels: no typed form
     assert lib.az_affine_act_h16(0x1000, 0x1000, None, 0, 0x1000, 0x1000, 1, 4, 4, 12, 0, 0, 1, None) == -2  # cs % 8
     assert lib.az_token_fill_h16(0x1000, 8, 0, 4, 0x1000, 64, 0x1000, 1, 60, 1, None) == -2
+    # round 6: the f16x2 entries share the x3 entries' validation and add their own (the weight scale is a power of two, the absmax
+    # slots are 16-byte aligned and in_absmax1 comes only with in_absmax0)
+    conv = _lib.AzConvArgs(src0=0x1000, weight=0x1000, dst=0x1000, c0s=8, cout_s=8, batch=1, hin=4, win=4, hout=4, wout=4,
+                           ksize=3, stride=1, pad=1, splitk=1, h0=4, w0=4, w_scale=3.0)
+    assert lib.az_conv2d_f16x2_f32(ctypes.byref(conv), None) == -2 and lib.az_conv2d_winograd_f16x2_f32(ctypes.byref(conv), None) == -2
+    conv.w_scale, conv.in_absmax0 = 1024.0, 0x1004
+    assert lib.az_conv2d_f16x2_f32(ctypes.byref(conv), None) == -3 and lib.az_conv2d_winograd_f16x2_f32(ctypes.byref(conv), None) == -3
+    conv.in_absmax0, conv.in_absmax1 = None, 0x1000
+    assert lib.az_conv2d_f16x2_f32(ctypes.byref(conv), None) == -3
+    conv.in_absmax1, conv.dst_dtype = None, 1
+    assert lib.az_conv2d_f16x2_f32(ctypes.byref(conv), None) == -4  # typed tensors: the bf16 / f16 entries only
+    assert lib.az_pack_conv_weight_f16x2_f32(0x1000, 0x1000, 8, 8, 3, 8, 8, 8, 8, 3.0, None) == -2
+    assert lib.az_winograd_pack_filter_f16x2_f32(0x1000, 0x1000, 8, 8, 8, 1, 1, 1, 0.0, None) == -2
+    assert lib.az_absmax_f32(None, 0x1000, 16, None) == -1 and lib.az_absmax_f32(0x1000, 0x1000, 0, None) == -2 and lib.az_absmax_f32(0x1000, 0x1004, 16, None) == -3
+    att = _lib.AzAttnArgs(q=0x1000, k=0x1000, v=0x1000, out=0x1000, batch=1, heads=1, tokens=8, head_dim=48)
+    assert lib.az_attention_f16x2_f32(ctypes.byref(att), None) == -4
+    # the weight scale the packings want: amax (x 2.25 for the Winograd transform) lands in [2^13, 2^14); degenerate maxima -> 1
+    ws = lib.az_f16x2_weight_scale
+    assert ws(1.0, 0) == 8192.0 and ws(0.9, 0) == 16384.0 and ws(1.0, 1) == 4096.0 and ws(0.0, 0) == 1.0 and ws(float("inf"), 0) == 1.0
+    assert 8192.0 <= 0.013 * ws(0.013, 0) < 16384.0 and 8192.0 <= 2.25 * 300.0 * ws(300.0, 1) < 16384.0
     for code, word in ((-1, b"NULL"), (-2, b"shape"), (-3, b"align"), (-4, b"unsupported")):
         assert word.lower() in lib.az_error_string(code).lower()
     with pytest.raises(_lib.AzulaAmdError, match="az_scale_f32"):
