@@ -26,18 +26,27 @@ from ..engine import Act, Builder, ada_zero_triple, mod_front_tape, pad4
 class Vol:
     r"""(B, D, H, W, cs) floats in ``buf``; ``C`` real channels."""
 
-    __slots__ = ("buf", "B", "D", "H", "W", "C", "cs")
+    __slots__ = ("buf", "B", "D", "H", "W", "C", "cs", "bounded")
 
-    def __init__(self, buf: torch.Tensor, B: int, D: int, H: int, W: int, C: int, cs: int) -> None:
+    def __init__(self, buf: torch.Tensor, B: int, D: int, H: int, W: int, C: int, cs: int, bounded: bool = False) -> None:
         self.buf, self.B, self.D, self.H, self.W, self.C, self.cs = buf, B, D, H, W, C, cs
+        self.bounded = bounded  # (engine.Act.bounded: the magnitudes do not scale with the sampler's state -- what the f16x2 kernels take)
+
+    def _view(self, a: Act) -> Act:
+        a.bounded = self.bounded
+        return a
 
     def planes(self, b: int, d0: int, d1: int) -> Act:
         n = self.H * self.W * self.cs
-        return Act(self.buf[(b * self.D + d0) * n : (b * self.D + d1) * n], d1 - d0, self.H, self.W, self.C, self.cs, True)
+        return self._view(Act(self.buf[(b * self.D + d0) * n : (b * self.D + d1) * n], d1 - d0, self.H, self.W, self.C, self.cs, True))
 
     def image(self) -> Act:
         r"""The volume as B images of (D H) x W pixels: what the norms and elementwise passes see."""
-        return Act(self.buf, self.B, self.D * self.H, self.W, self.C, self.cs, True)
+        return self._view(Act(self.buf, self.B, self.D * self.H, self.W, self.C, self.cs, True))
+
+    def all_planes(self) -> Act:
+        r"""The volume as B D images of H x W pixels: what one depth-tap launch over all planes sees."""
+        return self._view(Act(self.buf, self.B * self.D, self.H, self.W, self.C, self.cs, True))
 
 
 def new_vol(bld: Builder, B: int, D: int, H: int, W: int, C: int) -> Vol:
@@ -73,6 +82,8 @@ def conv3d(bld: Builder, x: Vol, conv, *, stride=1, periodic: bool = False, x1: 
     Ho = (Hin + 2 * (kh // 2) - kh) // sh_ + 1
     Wo = (Win + 2 * (kw // 2) - kw) // sw_ + 1
     out = new_vol(bld, x.B, Do, Ho, Wo, cout)
+    # (bounded sources and no residual of the stream: the sum of the taps is bounded by the weights, like a 2-D convolution's output)
+    out.bounded = x.bounded and (x1 is None or x1.bounded) and (res is None or res.bounded)
     taps = [p] + [j for j in range(kd) if j != p]  # centre first: it exists for every output plane and writes it
     packs = {j: bld.pack_conv(w[:, :, j], bias if j == p else None, cin0=x.C if x1 is not None else None) for j in taps}
     # ---- ONE launch per depth tap for all planes of all samples (AzConvArgs.depth: the kernels' loaders take a plane whose
@@ -84,12 +95,13 @@ def conv3d(bld: Builder, x: Vol, conv, *, stride=1, periodic: bool = False, x1: 
             and (x1 is None or (ud_ == 0 and x1.D == Din) or (ud_ == 1 and (Din + 1) // 2 <= x1.D)))
     if fast:
         g = dict(gate=gate, gate_off=gate_off, gate_bstride=0) if gate is not None else {}
-        planes = lambda v: Act(v.buf, v.B * v.D, v.H, v.W, v.C, v.cs, True)  # noqa: E731
+        planes = lambda v: v.all_planes()  # noqa: E731
         x1u, kw_ = None, {}
         if x1 is not None:
             src1 = x1
             if ud_ == 1:  # nearest x2 along the depth axis (narrowed to Din planes): plane d of the wide volume = plane d >> 1
                 x1u = new_vol(bld, x1.B, Din, x1.H, x1.W, x1.C)
+                x1u.bounded = x1.bounded
                 n = x1.H * x1.W * x1.cs
                 if 2 * x1.D == Din:  # one launch per parity over all samples
                     for half_ in (0, 1):
@@ -104,6 +116,7 @@ def conv3d(bld: Builder, x: Vol, conv, *, stride=1, periodic: bool = False, x1: 
                 src1 = x1u
             kw_ = dict(src1=planes(src1), up1=(uh_, uw_), hin=Hin, win=Win)
         full = out if sd_ == 1 else new_vol(bld, x.B, Din, Ho, Wo, cout)  # (a strided depth axis: every plane, then every sd-th kept)
+        full.bounded = out.bounded
         allo = planes(full)
         allr = planes(res) if res is not None else None
         # (the activation of the sum rides on the last tap's store: act 6 = silu(tap + what the earlier taps left; no pass of its own)
@@ -168,14 +181,15 @@ def upsample3d_nearest(bld: Builder, x: Vol, factors, like: Vol) -> Vol:
     in-plane by ``az_upsample_nearest_f32`` on every plane, along the depth axis by a gather of whole planes with ATen's
     source index ``min(floor(d * float32(1 / s)), D - 1)`` (``az_gather_rows_f32``, index table built on the host)."""
     sd_, sh_, sw_ = factors
-    planes = Act(x.buf, x.B * x.D, x.H, x.W, x.C, x.cs, True)
+    planes = x.all_planes()
     wide = bld.upsample_nearest(planes, sh_, sw_, like.H, like.W) if (sh_, sw_) != (1, 1) or (x.H, x.W) != (like.H, like.W) else planes
     if sd_ == 1 and x.D == like.D:
-        return Vol(wide.buf, x.B, x.D, like.H, like.W, x.C, x.cs)
+        return Vol(wide.buf, x.B, x.D, like.H, like.W, x.C, x.cs, x.bounded)
     inv = torch.tensor(1.0 / sd_, dtype=torch.float32)
     src = torch.clamp(torch.floor(torch.arange(like.D, dtype=torch.float32) * inv).to(torch.int64), max=x.D - 1)
     idx = (torch.arange(x.B)[:, None] * x.D + src[None, :]).reshape(-1)
     out = new_vol(bld, x.B, like.D, like.H, like.W, x.C)
+    out.bounded = x.bounded
     n = like.H * like.W * x.cs
     idx_dev = idx.to(bld.device)
     bld.tape.add("az_gather_rows_f32", out.buf.data_ptr(), wide.buf.data_ptr(), idx_dev.data_ptr(), x.B * like.D, n, x.B * x.D, keep=[idx_dev])
@@ -193,7 +207,7 @@ def block3d(blk, bld: Builder, x: Vol, D_mod: int, mod_rows: int, mod_jobs: list
         n_ = bld.group_norm(xi, blk.groups, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
     else:
         n_ = bld.row_norm(xi, 0 if blk.norm_kind == "layer" else 1, scale=abc, shift=abc, scale_off=0, shift_off=cs, bstride=bstride)
-    nv = Vol(n_.buf, x.B, x.D, x.H, x.W, Cc, cs)
+    nv = Vol(n_.buf, x.B, x.D, x.H, x.W, Cc, cs, n_.bounded)  # (the normalised volume: what the block's first convolution reads)
     c0, c3 = blk.ffn[0], blk.ffn[3]
     h1 = conv3d(bld, nv, c0, periodic=blk.periodic, silu=True)
     bld.free(n_)
