@@ -361,8 +361,8 @@ def pmc_traffic(config: str, live: bool = True, timeout: int = 420):
     with "source", or the committed profile of the same tool when the live run is unavailable / disabled."""
     import subprocess
 
-    committed = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_traffic_{config}.json") for r in ("r05", "r04", "r03", "r02")) if os.path.exists(p)),
-                     os.path.join(ROOT, "profiles", f"r05_traffic_{config}.json"))
+    committed = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_traffic_{config}.json") for r in ("r06b", "r06", "r05", "r04", "r03", "r02")) if os.path.exists(p)),
+                     os.path.join(ROOT, "profiles", f"r06b_traffic_{config}.json"))
     if live and os.environ.get("AZ_BENCH_PMC", "1") != "0":
         try:
             res = subprocess.run(
