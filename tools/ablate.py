@@ -321,6 +321,11 @@ VARIANTS["h2big_valu4"] = [("conv.hip", _H2G_OLD, "        if (k < NM - 10) __bu
 # ---- x3 Winograd kernel: staged pixel slots at a stride of 80 B instead of 64 B (measured: no gain, more bank conflicts -- profiles/r06_wx3_slot_ab.txt)
 VARIANTS["wx3_slot80"] = [("wino_x3.hip", "constexpr int X_SLOT = 64;", "constexpr int X_SLOT = 80;")]
 
+# ---- f16x2 attention, 256-query workgroups at head_dim <= 64: four waves per SIMD (<= 128 registers: two resident workgroups per CU, so
+#      that one's load / stage / barrier skeleton hides under the other's products) -- the compiler spills 31 registers to get there
+VARIANTS["att_h2_2wg"] = [("attention.hip", "__global__ __launch_bounds__(64 * NW) void attention_x3_kernel(AzAttnArgs a) {",
+                           "__global__ __launch_bounds__(64 * NW, (H2 && NW == 8 && D <= 64) ? 4 : 1) void attention_x3_kernel(AzAttnArgs a) {")]
+
 
 def build(name: str, patches=None, regen_env=None, head_files=None) -> str:
     r"""`patches`: a substitution list instead of VARIANTS[name]; `regen_env`: generator overrides (KL_* / KG_*) -- the copy's
