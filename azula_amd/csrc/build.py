@@ -81,8 +81,8 @@ def build(force: bool = False, verbose: bool = False, regen: bool = False) -> st
             env = {k: v for k, v in os.environ.items() if k != "AZ_KLOOP_AB"}
             subprocess.run([sys.executable, os.path.join(HERE, gen)], check=True, stdout=subprocess.DEVNULL, env=env)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
-    objs = []
-    for s in srcs:
+    objs, jobs = [], []
+    for s in srcs:  # (the translation units compile side by side: conv.hip and wino_x3.hip take a minute each)
         src = os.path.join(HERE, s)
         obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
         objs.append(obj)
@@ -94,7 +94,10 @@ def build(force: bool = False, verbose: bool = False, regen: bool = False) -> st
             cmd = [hipcc(), *FLAGS, *extra, "-x", "hip", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
     if force or _stale(LIB, objs):
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
         if verbose:
