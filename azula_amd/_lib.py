@@ -278,6 +278,7 @@ PROTOTYPES: dict[str, list] = {
     "az_winograd_pack_filter_f16x2_f32": [vp, vp, i32, i32, i32, i32, i32, i32, f32, c_stream],
     "az_f16x2_weight_scale": [f32, i32],
     "az_absmax_f32": [vp, vp, i64, c_stream],
+    "az_absmax_from_moments_f32": [vp, vp, i64, c_stream],
     "az_conv2d_winograd4_f32": [C.POINTER(AzConvArgs), c_stream],
     "az_conv2d_winograd4_suggest_splitk": [i64, i32, i32, i32, i32],
     "az_winograd4_pack_filter_f32": [vp, vp, i32, i32, i32, i32, i32, i32, c_stream],

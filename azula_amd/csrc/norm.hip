@@ -604,6 +604,22 @@ __global__ __launch_bounds__(256) void absmax_kernel(float* __restrict__ slots, 
   if (threadIdx.x == 0) slots[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
 }
 
+// The same slots from GroupNorm partial moments (n, mean, M2, -) that a producing convolution left (AzConvArgs.gn_quads): every element
+// of a partial satisfies |x| <= |mean| + sqrt(M2), so the largest such bound is an upper bound of max |x| -- loose by up to sqrt(n),
+// which costs an f16x2 launch a few of its 30 binades of headroom and no precision -- for the price of reading the partials.
+__global__ __launch_bounds__(256) void absmax_moments_kernel(float* __restrict__ slots, const float4* __restrict__ partials, int64_t count) {
+  __shared__ float sh[4];
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    const float4 q = partials[i];
+    if (q.x > 0.f) m = fmaxf(m, fabsf(q.y) + sqrtf(fmaxf(q.z, 0.f)));
+  }
+  m = az_wave_max(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) slots[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
 }  // namespace
 
 template <int IO>
@@ -644,6 +660,14 @@ int az_absmax_f32(float* slots, const float* x, int64_t n, az_stream_t stream) {
   AZ_REQUIRE(n > 0, AZ_E_SHAPE);
   AZ_REQUIRE(AZ_ALIGNED16(x) && AZ_ALIGNED16(slots), AZ_E_ALIGN);
   hipLaunchKernelGGL(absmax_kernel, dim3(AZ_ABSMAX_SLOTS), dim3(256), 0, az_s(stream), slots, x, n / 4, n);
+  return az_launch_status();
+}
+
+int az_absmax_from_moments_f32(float* slots, const float* partials, int64_t count, az_stream_t stream) {
+  AZ_REQUIRE(slots && partials, AZ_E_NULL);
+  AZ_REQUIRE(count > 0, AZ_E_SHAPE);
+  AZ_REQUIRE(AZ_ALIGNED16(partials) && AZ_ALIGNED16(slots), AZ_E_ALIGN);
+  hipLaunchKernelGGL(absmax_moments_kernel, dim3(AZ_ABSMAX_SLOTS), dim3(256), 0, az_s(stream), slots, reinterpret_cast<const float4*>(partials), count);
   return az_launch_status();
 }
 

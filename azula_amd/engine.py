@@ -179,6 +179,9 @@ def pieces() -> bool:
 # activation scale taken from the sources' largest magnitude (one streaming az_absmax_f32 pass per source tensor and step, shared
 # by its consumers; AzConvArgs.in_absmax0 / in_absmax1: no stated range) -- the UNet's strided and skip-merge convolutions; "0" = bf16x3
 F16X2_DYNAMIC = os.environ.get("AZ_F16X2_DYNAMIC", "1") != "0"
+# ... and where the tensor's producer left GroupNorm moments (Act.gn_quads), the maximum is BOUNDED from them instead of measured
+# (az_absmax_from_moments_f32: no pass over the tensor) -- ADM's 1x1 skip projections, whose pass would cost what it saves ("0": measure)
+F16X2_MOMENTS = os.environ.get("AZ_F16X2_MOMENTS", "1") != "0"
 ATTN_H2 = os.environ.get("AZ_ATTN_H2", "1") != "0"  # f16x2 mode: the attention contractions in that form too ("0": bf16x3 attention -- A/B)
 ATTN_X3 = os.environ.get("AZ_ATTN_X3", "1") != "0"  # bf16x3 mode: attention contractions on the bf16 pipe too (az_attention_x3_f32)
 # The stride-1 3 x 3 layers in bf16x3 mode: "1" (default since round 5) = the Winograd kernel with its 16 frequency GEMMs on the bf16 pipe
@@ -531,7 +534,8 @@ class Builder:
             # matrix instructions it saves (~12 % of a Winograd layer at ~350 TF/s algorithmic, ~25 % of a direct one at ~190)
             flops = 2.0 * npix * cout * (src0.C + (src1.C if src1 is not None else 0)) * ks * ks
             gain_s = 0.12 * flops / 350e12 if use_wino else 0.25 * flops / 190e12
-            cost_s = sum(4e-6 + s_.buf.numel() * 4 / 5.0e12 for s_ in (src0, src1) if s_ is not None and s_.absmax is None)
+            cost_s = sum(4e-6 + (0.0 if (s_.gn_quads is not None and F16X2_MOMENTS) else s_.buf.numel() * 4 / 5.0e12)
+                         for s_ in (src0, src1) if s_ is not None and s_.absmax is None)
             dyn = h2 = gain_s > 1.5 * cost_s
         if use_f4:
             a.weight = packed.winograd4().data_ptr()
@@ -670,7 +674,13 @@ class Builder:
         if x.absmax is None:
             assert not x.half and x.affine is None
             slots = self.empty(256)
-            self.tape.add("az_absmax_f32", slots.data_ptr(), x.ptr, x.B * x.H * x.W * x.cs, keep=[x.buf])
+            if x.gn_quads is not None and F16X2_MOMENTS:
+                # the producing convolution left GroupNorm moments of this tensor: |x| <= |mean| + sqrt(M2) per record -- an upper
+                # bound of the maximum for the price of reading the records (az_absmax_from_moments_f32)
+                q = x.gn_quads[0]
+                self.tape.add("az_absmax_from_moments_f32", slots.data_ptr(), q.data_ptr(), q.numel() // 4, keep=[q])
+            else:
+                self.tape.add("az_absmax_f32", slots.data_ptr(), x.ptr, x.B * x.H * x.W * x.cs, keep=[x.buf])
             x.absmax = slots
         return x.absmax
 

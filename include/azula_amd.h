@@ -423,6 +423,10 @@ float az_f16x2_weight_scale(float amax, int32_t winograd);
  * read of the tensor (HBM-bound).  NaN elements are ignored (they turn the outputs they reach into NaN through their own pieces). */
 #define AZ_ABSMAX_SLOTS 256
 int az_absmax_f32(float* slots, const float* x, int64_t n, az_stream_t stream);
+/* The same slots WITHOUT reading the tensor, from the GroupNorm partial moments its producing convolution left (AzConvArgs.gn_quads:
+ * `count` records of (n, mean, M2, -)): every element of a record satisfies |x| <= |mean| + sqrt(M2), so the slots hold an UPPER
+ * bound of max |x| (loose by up to sqrt(n): a few binades of the f16x2 pieces' 30, no precision).  NaN moments are ignored. */
+int az_absmax_from_moments_f32(float* slots, const float* partials, int64_t count, az_stream_t stream);
 /* Winograd F(4x4,3x3) form (6x6 patches, 36 frequency GEMMs: 2.25 multiplies per output instead of 4 / 9).
  * NOT exact: the transforms multiply by 2, 4, 5, 8 and the filter transform by 1/4 .. 1/24, so the fp32
  * rounding error is ~20x that of the F(2x2) kernel (~1e-5 of the output scale per layer).  Opt-in

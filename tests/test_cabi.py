@@ -121,6 +121,7 @@ def test_argument_errors_are_returned_not_raised(built_lib):
     assert lib.az_pack_conv_weight_f16x2_f32(0x1000, 0x1000, 8, 8, 3, 8, 8, 8, 8, 3.0, None) == -2
     assert lib.az_winograd_pack_filter_f16x2_f32(0x1000, 0x1000, 8, 8, 8, 1, 1, 1, 0.0, None) == -2
     assert lib.az_absmax_f32(None, 0x1000, 16, None) == -1 and lib.az_absmax_f32(0x1000, 0x1000, 0, None) == -2 and lib.az_absmax_f32(0x1000, 0x1004, 16, None) == -3
+    assert lib.az_absmax_from_moments_f32(0x1000, None, 4, None) == -1 and lib.az_absmax_from_moments_f32(0x1000, 0x1000, 0, None) == -2
     att = _lib.AzAttnArgs(q=0x1000, k=0x1000, v=0x1000, out=0x1000, batch=1, heads=1, tokens=8, head_dim=48)
     assert lib.az_attention_f16x2_f32(ctypes.byref(att), None) == -4
     # the weight scale the packings want: amax (x 2.25 for the Winograd transform) lands in [2^13, 2^14); degenerate maxima -> 1

@@ -942,6 +942,42 @@ def test_absmax(az, n):
     assert torch.isfinite(slots).all() and slots.max().item() == x[:n].abs().max().item()
 
 
+@pytest.mark.parametrize("mode", [True, "wh2", "x3"])
+def test_absmax_from_the_producers_moments(az, mode):
+    """az_absmax_from_moments_f32: the GroupNorm partial moments a convolution leaves of its output (AzConvArgs.gn_quads: Winograd
+    epilogue or split-K combine) bound its largest magnitude from above -- |x| <= |mean| + sqrt(M2) per record -- within sqrt(n) of
+    the true maximum, so that a consumer's f16x2 activation scale needs no pass over the tensor (engine.Builder.absmax_of)."""
+    from azula_amd import _lib
+    from azula_amd.engine import Act, Builder
+
+    g = torch.Generator().manual_seed(11)
+    B, Cin, Cout, H, W = 2, 64, 128, 32, 32
+    x = torch.randn(B, Cin, H, W, generator=g) * 3
+    x[1, 7, 5, 9] = 250.0  # (an outlier: the bound must cover it)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bld = Builder(torch.device("cuda"))
+    xa = Act(to_nhwc(dev(x)).reshape(-1), B, H, W, Cin, Cin, True)
+    y = bld.conv(xa, bld.pack_conv(dev(w), None), Cout, winograd=mode, gn_stats=True)
+    if mode == "x3":  # the direct kernels leave moments from their split-K combine only
+        d = [k for k in bld.tape.keep if hasattr(k, "_flops")][-1]
+        assert d.splitk > 1 or y.gn_quads is None
+    if y.gn_quads is None:
+        pytest.skip("this launch form leaves no moments for this shape")
+    slots = bld.absmax_of(y)
+    assert bld.tape.ops[-1][2] == "az_absmax_from_moments_f32"
+    bld.finish()
+    bld.tape.run()
+    out = from_nhwc(y.buf.reshape(B, H, W, Cout), Cout)
+    true_max, bound = out.abs().max().item(), slots.max().item()
+    n = out.numel() * 4 // y.gn_quads[0].numel()  # elements per record
+    print(mode, "max |y|", true_max, "bound from the moments", bound, "elements per record", n)
+    assert true_max <= bound <= true_max * math.sqrt(n) * 1.01 + 1e-6
+    # and the measured form on the same tensor
+    exact = torch.empty(256, device="cuda")
+    _lib.call("az_absmax_f32", exact.data_ptr(), y.ptr, y.buf.numel(), _lib.stream_ptr())
+    assert exact.max().item() == true_max
+
+
 @pytest.mark.parametrize("mode", ["h2", "wh2"])
 def test_f16x2_domain(az, mode):
     """The STATED domain of the f16x2 split (include/azula_amd.h, csrc/common.h: az_split2h): activations of any magnitude below
