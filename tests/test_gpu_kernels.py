@@ -943,13 +943,14 @@ def test_absmax(az, n):
 
 
 @pytest.mark.parametrize("mode", [True, "wh2", "x3"])
-def test_absmax_from_the_producers_moments(az, mode):
+def test_absmax_from_the_producers_moments(az, mode, monkeypatch):
     """az_absmax_from_moments_f32: the GroupNorm partial moments a convolution leaves of its output (AzConvArgs.gn_quads: Winograd
     epilogue or split-K combine) bound its largest magnitude from above -- |x| <= |mean| + sqrt(M2) per record -- within sqrt(n) of
     the true maximum, so that a consumer's f16x2 activation scale needs no pass over the tensor (engine.Builder.absmax_of)."""
-    from azula_amd import _lib
+    from azula_amd import _lib, engine
     from azula_amd.engine import Act, Builder
 
+    monkeypatch.setattr(engine, "F16X2_MOMENTS", True)  # (whatever AZ_F16X2_MOMENTS says: this test is about that path)
     g = torch.Generator().manual_seed(11)
     B, Cin, Cout, H, W = 2, 64, 128, 32, 32
     x = torch.randn(B, Cin, H, W, generator=g) * 3
